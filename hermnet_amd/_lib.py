@@ -1,0 +1,74 @@
+"""ctypes binding of `libhermnet_hip.so` (C ABI in `include/hermnet_hip.h`).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C hermnet_amd/csrc`.
+There is NO fallback: if it is missing the product path raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhermnet_hip.so")
+
+HN_ENV = {"polynomial": 0, "exponential": 1}
+_ERR = {1: "HN_ERR_BAD_ARG (unsupported shape or null pointer)",
+        2: "HN_ERR_LDS (weight tile does not fit the 160 KiB LDS)",
+        3: "HN_ERR_LAUNCH (kernel launch failed)"}
+
+c_fp = ctypes.c_void_p  # device pointers travel as integers
+
+
+class RbfDesc(ctypes.Structure):
+    _fields_ = [("offset", c_fp), ("num_rbf", ctypes.c_int), ("inv_rc", ctypes.c_float),
+                ("coeff", ctypes.c_float), ("env_kind", ctypes.c_int), ("env_p", ctypes.c_int)]
+
+
+class Graph(ctypes.Structure):
+    _fields_ = [("num_nodes", ctypes.c_int), ("num_edges", ctypes.c_int), ("num_rel", ctypes.c_int),
+                ("type_rowptr", c_fp), ("csr_rowptr", c_fp), ("csr_src", c_fp),
+                ("csc_rowptr", c_fp), ("csc_tgt", c_fp), ("csc_pos", c_fp)]
+
+
+# name -> (restype, argtypes); mirrors include/hermnet_hip.h one to one
+SIGNATURES = {
+    "hermnet_abi_version": (ctypes.c_int, []),
+    "hermnet_build_info": (ctypes.c_char_p, []),
+    "hermnet_edge_geometry_fwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
+    "hermnet_edge_geometry_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
+    "hermnet_message_scatter_fwd": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), ctypes.c_int,
+                                                   c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "hermnet_message_scatter_bwd": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), ctypes.c_int,
+                                                   c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                                   c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "hermnet_host_rbf_row": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                            ctypes.c_int, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the native library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "hermnet_amd: native library %s not found -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C hermnet_amd/csrc`).  There is no CPU/eager fallback for the hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, _ERR.get(rc, "error %d" % rc)))
+
+
+def ptr(t):
+    """Device/host pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,100 @@
+"""HVNet / HeteroVertexConv with the reference's constructor, `forward(data)` signature and
+state_dict keys (`HermNet/hermnet.py`), executing the hot path on MI355X."""
+from typing import Dict, List, Union
+
+import torch
+from torch import nn
+
+from .elements import atomic_numbers
+from .ops import EdgeGeometry
+from .relations import RelationalGraph
+from .rmnet import PaiNNModule, RadialBasis, ScaledSiLU, relational_layer
+
+
+class HeteroVertexConv(nn.Module):
+    """`hermnet.py:11-65`: one PaiNNModule per element type; weights are selected by the
+    TARGET atom's type.  All relations run in one fused launch."""
+
+    def __init__(self, mods: Dict[str, nn.Module]):
+        super().__init__()
+        self.mods = nn.ModuleDict(mods)
+
+    def forward(self, data):
+        """data must come from `HVNet.forward` (carries the relation-ordered graph)."""
+        g = data.get("_hn_graph")
+        if g is None:
+            raise RuntimeError("HeteroVertexConv.forward needs a Data prepared by HVNet.forward")
+        data.x, data.vec = relational_layer(self.mods.values(), data.x, data.vec, data._hn_edge, g, data._hn_rbf)
+        return data
+
+
+class HVNet(nn.Module):
+    """Heterogeneous Vertex Network (`hermnet.py:68-152`).
+
+    forward(data) -> energy [num_graphs]; data needs pos, atomic_number, edge_index, batch and,
+    for periodic systems, cell [B,3,3] + edge_shift [E,3].
+    """
+
+    def __init__(self, elems: Union[str, List[str]], rc: float = 5.,
+                 intensive: bool = False, num_layers: int = 5,
+                 hidden_channels: int = 512, num_rbf: int = 128,
+                 rbf={"name": "gaussian"},
+                 envelope={"name": "polynomial", "exponent": 5}):
+        super().__init__()
+        if isinstance(elems, str):
+            elems = [elems]
+        self.elems = list(elems)
+        self.rc = rc   # read by the calculators (plugin/ase_interface/calculator.py:49)
+        self.num_layers = num_layers
+        self.hidden_channels = hidden_channels
+        self.intensive = intensive
+
+        self.embed = nn.Embedding(len(atomic_numbers), hidden_channels)
+        self.radial_basis = RadialBasis(num_radial=num_rbf, cutoff=rc, rbf=rbf, envelope=envelope)
+        self.hermconvs = nn.ModuleList()
+        for _ in range(num_layers):
+            self.hermconvs.append(HeteroVertexConv(
+                mods={ntype: PaiNNModule(hidden_channels=hidden_channels, num_rbf=num_rbf) for ntype in self.elems}))
+        self.out_energy = nn.Sequential(
+            nn.Linear(hidden_channels, hidden_channels // 2),
+            ScaledSiLU(),
+            nn.Linear(hidden_channels // 2, 1),
+        )
+
+    def forward(self, data):
+        pos = data.pos
+        if not pos.is_cuda:
+            raise RuntimeError("hermnet_amd.HVNet runs on MI355X only (data is on %s); there is no CPU fallback"
+                               % pos.device)
+        if data.get("batch") is None:
+            # the reference fails here (scatter(..., None), hermnet.py:130); a single graph is meant
+            data.batch = torch.zeros(pos.size(0), dtype=torch.long, device=pos.device)
+        zl = [atomic_numbers[el] for el in self.elems]
+        graph = RelationalGraph.build(data.atomic_number, data.edge_index, zl,
+                                      edge_shift=data.get("edge_shift") if data.get("cell") is not None else None,
+                                      batch=data.batch)
+        rbf = self.radial_basis.descriptor()
+        edge = EdgeGeometry.apply(pos, data.get("cell"), graph)          # with_edge, hermnet.py:133-152
+
+        x = self.embed(data.atomic_number.long()[graph.node_order])        # hermnet.py:123, row order
+        vec = None                                                          # zeros, hermnet.py:124
+        data._hn_graph, data._hn_edge, data._hn_rbf = graph, edge, rbf
+        data.x, data.vec = x, vec
+        for conv in self.hermconvs:
+            data = conv(data)
+        x = data.x
+
+        per_atom_energy = self.out_energy(x).squeeze(1)                     # hermnet.py:129
+        energy = torch.zeros(graph.num_graphs, dtype=per_atom_energy.dtype, device=x.device)
+        energy = energy.index_add(0, graph.batch_rows, per_atom_energy)    # hermnet.py:130
+        if self.intensive:
+            cnt = torch.bincount(graph.batch_rows, minlength=graph.num_graphs).clamp(min=1)
+            energy = energy / cnt.to(energy.dtype)
+        return energy
+
+
+class HTNet(nn.Module):
+    """`hermnet.py:155-157`: not implemented in the reference either."""
+
+    def __init__(self):
+        raise NotImplementedError

@@ -1,0 +1,155 @@
+"""Host-side cutoff neighbour search (input producer of the hot path).
+
+Replaces `HermNet/data.py:14-24` (`neighbor_search`), which delegates to
+`ase.neighborlist.primitive_neighbor_list('ijS', ...)` for periodic cells and to
+`torch_cluster.radius_graph` otherwise -- neither package exists on the MI355X
+image, so the build owns this step.
+
+Conventions:
+  * pair (i, j, S) is listed iff |pos[j] - pos[i] + S @ cell| < rc  (strict),
+    (i, i, 0) is never listed, self-images (i, i, S != 0) are;
+  * output order is canonical: lexicographic in (i, j, Sx, Sy, Sz);
+  * indices are int64 (what the reference hands to the model), shifts int.
+
+`neighbor_search` wraps the raw list in the reference's calling convention:
+`edge_index = [i; j]` and an `edge_shift` such that the model-side formula
+(`HermNet/hermnet.py:135-139`: pos[ei0] - pos[ei1] + edge_shift @ cell) yields
+the true minimum-image vector, i.e. edge_shift = -S.  `reference_compat=True`
+reproduces `data.py:19-24` literally (edge_shift = +S, the sign quirk described
+in SURVEY.md section 0) for pipeline-level parity tests.
+"""
+import numpy as np
+import torch
+
+
+def _expand_ranges(start, end):
+    """Concatenate aranges [start_k, end_k) -> (flat_index, owner_k)."""
+    cnt = (end - start).astype(np.int64)
+    total = int(cnt.sum())
+    if total == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    owner = np.repeat(np.arange(len(cnt), dtype=np.int64), cnt)
+    first = np.cumsum(cnt) - cnt
+    flat = np.arange(total, dtype=np.int64) - np.repeat(first, cnt) + np.repeat(start.astype(np.int64), cnt)
+    return flat, owner
+
+
+def neighbor_list(pos, rc, cell=None, pbc=(True, True, True), chunk=200000):
+    """Cell-list neighbour search in float64.  Returns (i, j, S) canonical-sorted.
+
+    pos [N,3]; cell [3,3] (rows are lattice vectors) or None for an open system.
+    """
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, 3)
+    n = pos.shape[0]
+    rc = float(rc)
+    if n == 0:
+        z = np.zeros(0, np.int64)
+        return z, z, np.zeros((0, 3), np.int64)
+
+    if cell is None:
+        pts, owner, img = pos, np.arange(n, dtype=np.int64), np.zeros((n, 3), np.int64)
+        wrap = np.zeros((n, 3), np.int64)
+        real = pos
+    else:
+        cell = np.asarray(cell, dtype=np.float64).reshape(3, 3)
+        pbc = np.asarray(pbc, dtype=bool).reshape(3)
+        inv = np.linalg.inv(cell)
+        frac = pos @ inv
+        wrap = np.where(pbc, np.floor(frac), 0.0)
+        fw = frac - wrap
+        wrap = wrap.astype(np.int64)
+        real = fw @ cell
+        # plane spacings decide how many periodic images reach into the cutoff sphere
+        heights = 1.0 / np.linalg.norm(inv, axis=0)
+        nimg = np.where(pbc, np.ceil(rc / heights).astype(np.int64), 0)
+        margin = rc / heights
+        pts_l, owner_l, img_l = [], [], []
+        ar = np.arange(n, dtype=np.int64)
+        for sx in range(-nimg[0], nimg[0] + 1):
+            for sy in range(-nimg[1], nimg[1] + 1):
+                for sz in range(-nimg[2], nimg[2] + 1):
+                    s = np.array([sx, sy, sz], dtype=np.float64)
+                    f = fw + s
+                    keep = np.all((f >= -margin - 1e-9) & (f <= 1.0 + margin + 1e-9) | ~pbc, axis=1)
+                    if not keep.any():
+                        continue
+                    pts_l.append(f[keep] @ cell)
+                    owner_l.append(ar[keep])
+                    img_l.append(np.broadcast_to(np.array([sx, sy, sz], np.int64), (int(keep.sum()), 3)))
+        pts = np.concatenate(pts_l)
+        owner = np.concatenate(owner_l)
+        img = np.concatenate(img_l)
+
+    # uniform Cartesian bins of edge >= rc over the bounding box of all points
+    lo = pts.min(axis=0) - 1e-6
+    nb = np.maximum(((pts.max(axis=0) - lo) / rc).astype(np.int64) + 1, 1)
+    pb = np.minimum(((pts - lo) / rc).astype(np.int64), nb - 1)
+    pid = (pb[:, 0] * nb[1] + pb[:, 1]) * nb[2] + pb[:, 2]
+    order = np.argsort(pid, kind="stable")
+    pid_s = pid[order]
+    rb = np.minimum(((real - lo) / rc).astype(np.int64), nb - 1)
+
+    out_i, out_j, out_s = [], [], []
+    rc2 = rc * rc
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        ids = np.arange(c0, c1, dtype=np.int64)
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                bx = rb[c0:c1, 0] + dx
+                by = rb[c0:c1, 1] + dy
+                ok = (bx >= 0) & (bx < nb[0]) & (by >= 0) & (by < nb[1])
+                if not ok.any():
+                    continue
+                # the three z-neighbour bins are contiguous in the sorted id space
+                z0 = np.maximum(rb[c0:c1, 2] - 1, 0)
+                z1 = np.minimum(rb[c0:c1, 2] + 1, nb[2] - 1)
+                base = (bx * nb[1] + by) * nb[2]
+                st = np.searchsorted(pid_s, base + z0, side="left")
+                en = np.searchsorted(pid_s, base + z1, side="right")
+                st = np.where(ok, st, 0)
+                en = np.where(ok, en, 0)
+                flat, own = _expand_ranges(st, en)
+                if flat.size == 0:
+                    continue
+                cand = order[flat]
+                ii = ids[own]
+                d = pts[cand] - real[ii]
+                d2 = np.einsum("ij,ij->i", d, d)
+                sel = d2 < rc2
+                jj = owner[cand]
+                ss = img[cand]
+                sel &= ~((jj == ii) & np.all(ss == 0, axis=1))
+                out_i.append(ii[sel])
+                out_j.append(jj[sel])
+                out_s.append(ss[sel])
+    if not out_i:
+        z = np.zeros(0, np.int64)
+        return z, z, np.zeros((0, 3), np.int64)
+    i = np.concatenate(out_i)
+    j = np.concatenate(out_j)
+    s = np.concatenate(out_s)
+    # shifts were found for wrapped coordinates; express them for the caller's positions
+    s = s - wrap[j] + wrap[i]
+    key = np.lexsort((s[:, 2], s[:, 1], s[:, 0], j, i))
+    return i[key], j[key], s[key]
+
+
+def neighbor_search(pos, rc, cell=None, reference_compat=False):
+    """Drop-in for `HermNet/data.py:14-24`.
+
+    pos: float Tensor [N,3]; cell: Tensor [3,3] or [1,3,3] or None.
+    Returns `edge_index` (open system) or `(edge_index, edge_shift)` (periodic),
+    int64 [2,E] / float32 [E,3], exactly the reference's return shapes.
+    """
+    p = pos.detach().cpu().numpy()
+    if cell is None:
+        i, j, _ = neighbor_list(p, rc, None)
+        # radius_graph convention: row 0 = source (neighbour), row 1 = target (centre)
+        return torch.from_numpy(np.vstack([j, i])).long()
+    c = cell.detach().cpu().numpy().reshape(-1, 3, 3)[0]
+    i, j, s = neighbor_list(p, rc, c)
+    edge_index = torch.from_numpy(np.vstack([i, j])).long()
+    sign = 1.0 if reference_compat else -1.0
+    edge_shift = torch.from_numpy(sign * s.astype(np.float32)).float()
+    return edge_index, edge_shift

@@ -1,0 +1,117 @@
+"""Autograd wrappers around the C-ABI kernels (host side of the operator boundary,
+SURVEY.md section 8(b)).  Tensors are allocated by PyTorch; the library only enqueues
+kernels on the current stream.  CUDA(HIP) tensors only -- there is no CPU path."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("hermnet_amd.%s: the hot path runs on MI355X only (got a %s tensor); "
+                           "there is no CPU fallback" % (what, t.device))
+
+
+class RbfDescriptor(object):
+    """Host mirror of `hn_rbf_desc` (Gaussian basis * envelope, rmnet.py:156-193)."""
+
+    def __init__(self, offset, rc, env_kind, env_p):
+        self.offset = offset
+        self.num_rbf = int(offset.numel())
+        self.inv_rc = 1.0 / rc
+        # GaussianSmearing: coeff = -0.5 / (offset[1] - offset[0]).item() ** 2
+        self.coeff = None
+        self.env_kind = env_kind
+        self.env_p = env_p
+
+    def struct(self):
+        if self.coeff is None:
+            o = self.offset.detach().float().cpu()
+            self.coeff = -0.5 / float(o[1] - o[0]) ** 2
+        return _lib.RbfDesc(self.offset.data_ptr(), self.num_rbf, self.inv_rc, self.coeff,
+                            self.env_kind, self.env_p)
+
+
+class EdgeGeometry(torch.autograd.Function):
+    """`HVNet.with_edge` (hermnet.py:133-152) -> edge[E,4] = (rhat, d) in CSR order."""
+
+    @staticmethod
+    def forward(ctx, pos, cell, graph):
+        _require_gpu(pos, "EdgeGeometry")
+        lib = _lib.load()
+        pos_c = pos.detach().float().contiguous()
+        edge = torch.empty(graph.E, 4, dtype=torch.float32, device=pos.device)
+        cell_c = None
+        if graph.shift is not None and cell is not None:
+            cell_c = cell.detach().float().reshape(-1, 3, 3).contiguous()
+        batch32 = getattr(graph, "_batch32", None)
+        _lib.check(lib.hermnet_edge_geometry_fwd(
+            _lib.ptr(pos_c), _lib.ptr(graph.src_id), _lib.ptr(graph.tgt_id),
+            _lib.ptr(graph.shift if cell_c is not None else None), _lib.ptr(cell_c), _lib.ptr(batch32),
+            graph.E, _lib.ptr(edge), _stream()), "hermnet_edge_geometry_fwd")
+        ctx.graph = graph
+        ctx.keep = (pos_c, cell_c)
+        return edge
+
+    @staticmethod
+    def backward(ctx, gedge):
+        graph = ctx.graph
+        lib = _lib.load()
+        gD = gedge.float().contiguous()
+        gpos_rows = torch.empty(graph.N, 3, dtype=torch.float32, device=gD.device)
+        _lib.check(lib.hermnet_edge_geometry_bwd(
+            _lib.ptr(gD), _lib.ptr(graph.csr_rowptr), None, _lib.ptr(graph.out_rowptr),
+            _lib.ptr(graph.out_edges), graph.N, _lib.ptr(gpos_rows), _stream()), "hermnet_edge_geometry_bwd")
+        return gpos_rows[graph.row_of_node], None, None
+
+
+class MessageScatter(torch.autograd.Function):
+    """rbf_proj + propagate + residual of one HeteroVertexConv layer, all relations
+    (rmnet.py:24-26, 55-73; utils.py:11-24).  Returns (x1, vec1).
+
+    The `edge` input carries (rhat, d); the gradient returned for it is the Cartesian
+    gradient w.r.t. the edge vector D (what `EdgeGeometry.backward` consumes).
+    First-order only: gradients w.r.t. rbf_proj weights are not produced (force path)."""
+
+    @staticmethod
+    def forward(ctx, xh, vec, x, edge, wt, brbf, graph, rbf):
+        _require_gpu(x, "MessageScatter")
+        lib = _lib.load()
+        H = x.size(1)
+        xh = xh.contiguous()
+        x = x.contiguous()
+        vec_c = None if vec is None else vec.contiguous()
+        x1 = torch.empty_like(x)
+        vec1 = torch.empty(x.size(0), 3, H, dtype=x.dtype, device=x.device)
+        gs, rs = graph.as_struct(), rbf.struct()
+        _lib.check(lib.hermnet_message_scatter_fwd(
+            ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), _lib.ptr(vec_c), _lib.ptr(x),
+            _lib.ptr(wt), _lib.ptr(brbf), _lib.ptr(edge), _lib.ptr(x1), _lib.ptr(vec1), _stream()),
+            "hermnet_message_scatter_fwd")
+        ctx.save_for_backward(xh, vec_c, edge, wt, brbf)
+        ctx.graph, ctx.rbf, ctx.H = graph, rbf, H
+        return x1, vec1
+
+    @staticmethod
+    def backward(ctx, gx1, gvec1):
+        xh, vec, edge, wt, brbf = ctx.saved_tensors
+        graph, rbf, H = ctx.graph, ctx.rbf, ctx.H
+        lib = _lib.load()
+        gx1 = gx1.contiguous()
+        gvec1 = gvec1.contiguous()
+        gxh = torch.empty_like(xh)
+        gvec = None if vec is None else torch.empty_like(vec)
+        gx = torch.empty_like(gx1)
+        gedge = torch.zeros(H // 64, graph.E, 4, dtype=torch.float32, device=gx1.device)
+        gs, rs = graph.as_struct(), rbf.struct()
+        _lib.check(lib.hermnet_message_scatter_bwd(
+            ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), _lib.ptr(vec), _lib.ptr(wt), _lib.ptr(brbf),
+            _lib.ptr(edge), _lib.ptr(gx1), _lib.ptr(gvec1), _lib.ptr(gxh), _lib.ptr(gvec), _lib.ptr(gx),
+            _lib.ptr(gedge), _stream()), "hermnet_message_scatter_bwd")
+        return gxh, gvec, gx, gedge.sum(0), None, None, None, None

@@ -1,0 +1,216 @@
+"""Relational message-passing modules: parameter containers with the reference's names
+and state_dict layout (`HermNet/rmnet.py`), whose edge-level work runs in the gfx950
+kernels of `hermnet_amd/csrc/message_kernels.hip`.
+
+What stays in PyTorch here is node-level dense algebra (LayerNorm + the two MLPs,
+`rmnet.py:52` and `rmnet.py:94-107`): plain library GEMMs with elementwise epilogues.
+"""
+import math
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import _lib
+from .ops import MessageScatter, RbfDescriptor
+
+
+class ScaledSiLU(nn.Module):
+    """`rmnet.py:110-117`."""
+
+    def __init__(self):
+        super().__init__()
+        self.scale_factor = 1 / 0.6
+
+    def forward(self, x):
+        return F.silu(x) * self.scale_factor
+
+
+class GaussianSmearing(nn.Module):
+    """PyG `GaussianSmearing(start, stop, num_gaussians)` as used at `rmnet.py:156-158`:
+    buffer `offset` = linspace, python-float `coeff`."""
+
+    def __init__(self, start=0.0, stop=5.0, num_gaussians=50):
+        super().__init__()
+        offset = torch.linspace(start, stop, num_gaussians)
+        self.coeff = -0.5 / (offset[1] - offset[0]).item() ** 2
+        self.register_buffer("offset", offset)
+
+
+class PolynomialEnvelope(nn.Module):
+    """`rmnet.py:175-193` (evaluated inside the kernels: `hermnet_math.h: hn_envelope`)."""
+
+    def __init__(self, exponent):
+        super().__init__()
+        assert exponent > 0
+        self.p = int(exponent)
+        self.kind = _lib.HN_ENV["polynomial"]
+
+
+class ExponentialEnvelope(nn.Module):
+    """`rmnet.py:196-208`."""
+
+    def __init__(self):
+        super().__init__()
+        self.p = 0
+        self.kind = _lib.HN_ENV["exponential"]
+
+
+class SphericalBesselBasis(nn.Module):
+    """`rmnet.py:211-233` (parameters only; see RadialBasis.descriptor)."""
+
+    def __init__(self, num_radial, cutoff):
+        super().__init__()
+        self.norm_const = math.sqrt(2 / (cutoff ** 3))
+        self.frequencies = nn.Parameter(data=math.pi * torch.arange(1, num_radial + 1).float(), requires_grad=True)
+
+
+class BernsteinBasis(nn.Module):
+    """`rmnet.py:236-275` (parameters only)."""
+
+    def __init__(self, num_radial, pregamma_initial=0.45264):
+        super().__init__()
+        from scipy.special import binom
+        import numpy as np
+        self.register_buffer("prefactor", torch.tensor(binom(num_radial - 1, np.arange(num_radial)), dtype=torch.float),
+                             persistent=False)
+        self.pregamma = nn.Parameter(data=torch.tensor(pregamma_initial, dtype=torch.float), requires_grad=True)
+        exp1 = torch.arange(num_radial)
+        self.register_buffer("exp1", exp1[None, :], persistent=False)
+        self.register_buffer("exp2", (num_radial - 1 - exp1)[None, :], persistent=False)
+
+
+class RadialBasis(nn.Module):
+    """`rmnet.py:134-172`.  The basis is never materialised as an [E, R] tensor: the
+    kernels evaluate envelope * Gaussian taps per edge in registers."""
+
+    def __init__(self, num_radial, cutoff, rbf={"name": "gaussian"}, envelope={"name": "polynomial", "exponent": 5}):
+        super().__init__()
+        self.inv_cutoff = 1 / cutoff
+        self.cutoff = cutoff
+        self.num_radial = num_radial
+        env_name = envelope["name"].lower()
+        env_hparams = {k: v for k, v in envelope.items() if k != "name"}
+        if env_name == "polynomial":
+            self.envelope = PolynomialEnvelope(**env_hparams)
+        elif env_name == "exponential":
+            self.envelope = ExponentialEnvelope(**env_hparams)
+        else:
+            raise ValueError(f"Unknown envelope function '{env_name}'.")
+        rbf_name = rbf["name"].lower()
+        rbf_hparams = {k: v for k, v in rbf.items() if k != "name"}
+        self.rbf_name = rbf_name
+        if rbf_name == "gaussian":
+            self.rbf = GaussianSmearing(start=0, stop=1, num_gaussians=num_radial, **rbf_hparams)
+        elif rbf_name == "spherical_bessel":
+            self.rbf = SphericalBesselBasis(num_radial=num_radial, cutoff=cutoff, **rbf_hparams)
+        elif rbf_name == "bernstein":
+            self.rbf = BernsteinBasis(num_radial=num_radial, **rbf_hparams)
+        else:
+            raise ValueError(f"Unknown radial basis function '{rbf_name}'.")
+        self._desc = None
+
+    def descriptor(self):
+        if self.rbf_name != "gaussian":
+            raise NotImplementedError(
+                "hermnet_amd: the gfx950 message kernel implements the Gaussian basis (the reference default, "
+                "hermnet.py:87); '%s' parameters load for state_dict compatibility but have no kernel yet"
+                % self.rbf_name)
+        off = self.rbf.offset
+        if self._desc is None or self._desc.offset.data_ptr() != off.data_ptr():
+            self._desc = RbfDescriptor(off, self.cutoff, self.envelope.kind, self.envelope.p)
+        return self._desc
+
+
+class PaiNNMessage(nn.Module):
+    """Parameters of `rmnet.py:35-76`.  Node part (`x_proj(LayerNorm(x))`) runs here; the edge
+    part (rbf_proj, gather, message, aggregate) runs fused for all relations in
+    `hermnet_message_scatter_fwd` (see HeteroVertexConv)."""
+
+    def __init__(self, hidden_channels, num_rbf):
+        super().__init__()
+        self.hidden_channels = hidden_channels
+        self.x_proj = nn.Sequential(
+            nn.Linear(hidden_channels, hidden_channels),
+            ScaledSiLU(),
+            nn.Linear(hidden_channels, hidden_channels * 3),
+        )
+        self.rbf_proj = nn.Linear(num_rbf, hidden_channels * 3)
+        self.inv_sqrt_3 = 1 / math.sqrt(3.0)
+        self.inv_sqrt_h = 1 / math.sqrt(hidden_channels)
+        self.x_layernorm = nn.LayerNorm(hidden_channels)
+
+    def node_projection(self, x):
+        """xh = x_proj(LayerNorm(x))  (`rmnet.py:52`)."""
+        return self.x_proj(self.x_layernorm(x))
+
+
+class PaiNNUpdate(nn.Module):
+    """`rmnet.py:79-107` (node-level; dense GEMMs + elementwise)."""
+
+    def __init__(self, hidden_channels):
+        super().__init__()
+        self.hidden_channels = hidden_channels
+        self.vec_proj = nn.Linear(hidden_channels, hidden_channels * 2, bias=False)
+        self.xvec_proj = nn.Sequential(
+            nn.Linear(hidden_channels * 2, hidden_channels),
+            ScaledSiLU(),
+            nn.Linear(hidden_channels, hidden_channels * 3),
+        )
+        self.inv_sqrt_2 = 1 / math.sqrt(2.0)
+        self.inv_sqrt_h = 1 / math.sqrt(hidden_channels)
+
+    def forward(self, x, vec):
+        H = self.hidden_channels
+        vec1, vec2 = torch.split(self.vec_proj(vec), H, dim=-1)
+        vec_dot = (vec1 * vec2).sum(dim=1) * self.inv_sqrt_h
+        x_vec_h = self.xvec_proj(torch.cat([x, torch.sqrt(torch.sum(vec2 ** 2, dim=-2) + 1e-8)], dim=-1))
+        xvec1, xvec2, xvec3 = torch.split(x_vec_h, H, dim=-1)
+        dx = (xvec1 + xvec2 * vec_dot) * self.inv_sqrt_2
+        dvec = xvec3.unsqueeze(1) * vec1
+        return dx, dvec
+
+
+class PaiNNModule(nn.Module):
+    """`rmnet.py:11-32`: message + residual + update for one relation."""
+
+    def __init__(self, hidden_channels=512, num_rbf=128):
+        super().__init__()
+        self.num_rbf = num_rbf
+        self.message_layer = PaiNNMessage(hidden_channels, num_rbf)
+        self.update_layer = PaiNNUpdate(hidden_channels)
+        self.inv_sqrt_2 = 1 / math.sqrt(2.0)
+
+
+def relational_layer(mods, x, vec, edge, graph, rbf):
+    """One HeteroVertexConv layer in relation (row) order: `hermnet.py:37-65`.
+
+    x [N,H], vec [N,3,H] or None (layer 0: zeros, `hermnet.py:124`); returns new (x, vec).
+    """
+    mlist = list(mods)
+    H = x.size(1)
+    # xh_t for every row and relation (sources of relation t carry the TARGET type's projection, SURVEY A5 i)
+    xh = torch.stack([m.message_layer.node_projection(x) for m in mlist], dim=0)
+    wt = torch.stack([m.message_layer.rbf_proj.weight.detach().t() for m in mlist], dim=0).contiguous()
+    brbf = torch.stack([m.message_layer.rbf_proj.bias.detach() for m in mlist], dim=0).contiguous()
+    x1, vec1 = MessageScatter.apply(xh, vec, x, edge, wt, brbf, graph, rbf)
+    xs, vs = [], []
+    rp = graph.type_rowptr_host
+    for t, m in enumerate(mlist):
+        lo, hi = rp[t], rp[t + 1]
+        if hi == lo:
+            continue
+        xt, vt = x1[lo:hi], vec1[lo:hi]
+        dx, dvec = m.update_layer(xt, vt)
+        xs.append(xt + dx)
+        vs.append(vt + dvec)
+    nk = rp[-1]
+    if nk < graph.N:   # atoms whose element is not in `elems`: zero rows (hermnet.py:51)
+        xs.append(x.new_zeros(graph.N - nk, H))
+        vs.append(x.new_zeros(graph.N - nk, 3, H))
+    x_out = torch.cat(xs, 0) if len(xs) != 1 else xs[0]
+    v_out = torch.cat(vs, 0) if len(vs) != 1 else vs[0]
+    if graph.needs_mask:   # relations without any edge are skipped by the reference (hermnet.py:56-57)
+        x_out = x_out * graph.row_active[:, None]
+        v_out = v_out * graph.row_active[:, None, None]
+    return x_out, v_out

@@ -1,0 +1,128 @@
+/*
+ * hermnet_hip.h -- C ABI of the MI355X (gfx950) hot-path library `libhermnet_hip.so`.
+ *
+ * The reference has no FFI: its hot path is reached through Python operators.
+ * Each entry point below names the reference operator (file:line under
+ * /root/reference) it replaces; INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add at that call site.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - all buffers are allocated and owned by the caller (PyTorch in our host
+ *     code); the library never allocates, frees or retains them;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work
+ *     on it (no host synchronisation, graph-capturable);
+ *   - return value 0 = ok, non-zero = HN_ERR_* (host code raises RuntimeError);
+ *   - float = IEEE fp32 (the reference is fp32-only), indices = int32.
+ *
+ * Node order.  All node-level arrays are in "relation order": atoms sorted by
+ * (relation index of their element, original id); atoms whose element is not in
+ * the model's element list come last.  `type_rowptr[T+1]` delimits the row range
+ * of each relation; rows >= type_rowptr[T] are unknown-type atoms (sources only).
+ *
+ * Edge orders.  CSR: edges sorted by (row(target), original edge id).
+ *               CSC: edges sorted by (relation(target), row(source), CSR position).
+ */
+#ifndef HERMNET_HIP_H
+#define HERMNET_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HN_OK 0
+#define HN_ERR_BAD_ARG 1      /* unsupported shape / null pointer */
+#define HN_ERR_LDS 2          /* weight tile does not fit the 160 KiB LDS */
+#define HN_ERR_LAUNCH 3       /* hipLaunchKernel / hipGetLastError failed */
+
+#define HN_ENV_POLYNOMIAL 0   /* rmnet.py:175-193 */
+#define HN_ENV_EXPONENTIAL 1  /* rmnet.py:196-208 */
+
+/* Library / build identification (also used as the "is the native path loaded" probe). */
+int hermnet_abi_version(void);
+const char* hermnet_build_info(void);
+
+/* Radial-basis description shared by the message kernels:
+ *   u = d * inv_rc; env(u) per rmnet.py:175-208; Gaussian taps exp(coeff*(u-offset[k])^2)
+ *   (PyG GaussianSmearing as used at rmnet.py:156-158: offset = linspace(0,1,R),
+ *   coeff = -0.5/(offset[1]-offset[0])^2). */
+typedef struct hn_rbf_desc {
+  const float* offset;   /* [R] device */
+  int   num_rbf;         /* R */
+  float inv_rc;          /* 1/rc */
+  float coeff;           /* Gaussian coefficient (negative) */
+  int   env_kind;        /* HN_ENV_* */
+  int   env_p;           /* polynomial exponent p */
+} hn_rbf_desc;
+
+/* Graph in relation order (built once per neighbour list by the host code). */
+typedef struct hn_graph {
+  int num_nodes;              /* N */
+  int num_edges;              /* E */
+  int num_rel;                /* T */
+  const int* type_rowptr;     /* [T+1] */
+  const int* csr_rowptr;      /* [N+1]  by target row */
+  const int* csr_src;         /* [E]    source row of each CSR edge */
+  const int* csc_rowptr;      /* [T*N+1] by (relation(target), source row) */
+  const int* csc_tgt;         /* [E]    target row of each CSC edge */
+  const int* csc_pos;         /* [E]    CSR position of each CSC edge */
+} hn_graph;
+
+/* ---- A2: HVNet.with_edge (hermnet.py:133-152) -------------------------------------------
+ * edge[e] = (rx, ry, rz, d) for CSR edge e, D = pos[src] - pos[tgt] (+ shift @ cell[batch[src]]),
+ * d = |D| with d ~ 0 (atol 1e-6) replaced by 1e-6, r = D / d.
+ * `src_id`/`tgt_id` are ORIGINAL atom ids in CSR edge order; `shift` is [E,3] in CSR order
+ * (NULL for open systems, then cell/batch are ignored); cell [B,3,3]; batch [N] original order. */
+int hermnet_edge_geometry_fwd(const float* pos, const int* src_id, const int* tgt_id,
+                              const float* shift, const float* cell, const int* batch,
+                              int num_edges, float* edge /* [E,4] */, void* stream);
+
+/* Backward of the above w.r.t. pos: gpos[N,3] (ORIGINAL order, overwritten) from
+ * gD[E,4] (Cartesian gradient w.r.t. D, CSR order; .w ignored).  Deterministic: per-atom
+ * segmented sums over `in_rowptr/in_edges` (edges whose target is the atom, sign -) and
+ * `out_rowptr/out_edges` (edges whose source is the atom, sign +); both index CSR positions. */
+int hermnet_edge_geometry_bwd(const float* gD, const int* in_rowptr, const int* in_edges,
+                              const int* out_rowptr, const int* out_edges,
+                              int num_nodes, float* gpos, void* stream);
+
+/* ---- A3+A7(rbf_proj)+A8+A9+A10 and the residual of A6 ---------------------------------------
+ * Replaces, for ALL relations of one HeteroVertexConv layer at once,
+ *   PaiNNMessage.forward's rbf_proj + propagate (rmnet.py:55-73), RadialBasis.forward
+ *   (rmnet.py:168-172), in_subgraph's edge slicing (utils.py:11-24) and the residual
+ *   `x = (x + dx)/sqrt(2); vec = vec + dvec` (rmnet.py:24-26).
+ * xh   [T,N,3H]  xh[t] = x_proj_t(LayerNorm_t(x)) for every row (sources of relation t)
+ * vec  [N,3,H]   (NULL => treated as zero: layer 0, hermnet.py:124)
+ * x    [N,H]
+ * wt   [T,R,3H]  rbf_proj.weight of relation t, transposed;  brbf [T,3H] its bias
+ * edge [E,4]     from hermnet_edge_geometry_fwd (CSR order)
+ * out: x1 [N,H], vec1 [N,3,H]; rows >= type_rowptr[T] are written as zero.
+ * H must be a multiple of 64. */
+int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc* rbf, int hidden,
+                                const float* xh, const float* vec, const float* x,
+                                const float* wt, const float* brbf, const float* edge,
+                                float* x1, float* vec1, void* stream);
+
+/* Backward of hermnet_message_scatter_fwd for the force path (first order).
+ * in : gx1 [N,H], gvec1 [N,3,H] (gradients w.r.t. x1, vec1) + the forward inputs
+ * out: gxh [T,N,3H], gvec [N,3,H] (NULL allowed when vec was NULL), gx [N,H],
+ *      gedge [H/64, E, 4]: per 64-channel column block, Cartesian gradient w.r.t. the edge
+ *      vector D in CSR order (caller sums over the leading axis; buffer must be zero-filled). */
+int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc* rbf, int hidden,
+                                const float* xh, const float* vec,
+                                const float* wt, const float* brbf, const float* edge,
+                                const float* gx1, const float* gvec1,
+                                float* gxh, float* gvec, float* gx, float* gedge, void* stream);
+
+/* Host-side (CPU) evaluation of the per-edge radial contraction exactly as the device code
+ * computes it (banded 12-tap Gaussian window): rb[c] = b[c] + env(u) * sum_k W[c,k] g_k(u) and
+ * its derivative d rb / d d.  Used by the CPU test-suite to check the banded formulation
+ * against the dense reference formula without a GPU.  All pointers are HOST pointers. */
+int hermnet_host_rbf_row(const float* offset_host, int num_rbf, float inv_rc, float coeff,
+                         int env_kind, int env_p, const float* wt_host /* [R,C] */,
+                         const float* b_host /* [C] */, int C, float d,
+                         float* rb_host /* [C] */, float* drb_host /* [C] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HERMNET_HIP_H */

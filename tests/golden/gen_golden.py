@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  RUN ONLY IN THE BUILD CONTAINER (needs /root/reference).
+
+Executes the reference's own `HermNet/{hermnet,rmnet,utils}.py`, unmodified and in
+place, on deterministic synthetic inputs and writes small `.npz` fixtures next to
+this file.  Third-party modules the reference imports but the image lacks are
+provided by `tests/golden/_standins/` (restated published semantics; see its
+README).  One harness-side substitution is needed for forces: the reference's
+`with_edge` writes in place into the output of `.norm()` (`hermnet.py:147`), which
+current autograd rejects; `_with_edge_out_of_place` is the same formula with
+`torch.where` (energy is bit-identical with and without it -- checked below).
+
+Weights are NOT stored: they are `hermnet_amd.synth.synth_state_dict(sd, seed)`,
+a pure function of (key order, shapes, seed); a checksum is stored instead.
+
+    python tests/golden/gen_golden.py            # all cases except the 10k one
+    python tests/golden/gen_golden.py --full     # + config 2 (10k atoms, ~2 min, ~20 GB)
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(HERE, "_standins"))
+sys.path.insert(0, "/root/reference")
+
+from torch_geometric.data import Data as RefData  # stand-in  # noqa: E402
+import HermNet.hermnet as ref_hermnet  # the reference itself  # noqa: E402
+
+from hermnet_amd import synth  # noqa: E402
+
+
+def _with_edge_out_of_place(self, data):
+    edge_index, pos = data.edge_index, data.pos
+    j, i = edge_index
+    distance_vec = pos[j] - pos[i]
+    if data.get('cell') is not None and data.get('edge_shift') is not None:
+        distance_vec = distance_vec + torch.einsum('ni, nij -> nj', data.edge_shift, data.cell[data.batch[j]])
+    edge_dist = distance_vec.norm(dim=-1)
+    mask_zero = torch.isclose(edge_dist, torch.tensor(0.0), atol=1e-6)
+    edge_dist = torch.where(mask_zero, torch.full_like(edge_dist, 1.0e-6), edge_dist)
+    data.edge_dist = edge_dist
+    data.edge_vec = distance_vec / edge_dist[:, None]
+    return data
+
+
+def sd_checksum(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd.keys()):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def to_ref(d):
+    kw = {k: v.clone() for k, v in d}
+    return RefData(**kw)
+
+
+def run_reference(d, elems, model_kw, seed, want_inter):
+    torch.manual_seed(0)
+    model = ref_hermnet.HVNet(elems, **model_kw)
+    sd = synth.synth_state_dict(model.state_dict(), seed)
+    model.load_state_dict(sd)
+    model.eval()
+    # 1) untouched reference forward (energy only)
+    with torch.no_grad():
+        e_plain = model(to_ref(d)).detach().clone()
+    # 2) forces through the out-of-place geometry
+    orig = ref_hermnet.HVNet.with_edge
+    ref_hermnet.HVNet.with_edge = _with_edge_out_of_place
+    try:
+        rd = to_ref(d)
+        rd.pos.requires_grad_(True)
+        inter = {}
+        if want_inter:
+            hooks = []
+            for l, conv in enumerate(model.hermconvs):
+                def mk(l):
+                    def hook(mod, inp, out):
+                        inter["x_l%d" % l] = out.x.detach().clone().numpy()
+                        inter["vec_l%d" % l] = out.vec.detach().clone().numpy()
+                    return hook
+                hooks.append(conv.register_forward_hook(mk(l)))
+        e = model(rd)
+        f = -torch.autograd.grad(e.sum(), rd.pos)[0]
+        if want_inter:
+            inter["edge_dist"] = rd.edge_dist.detach().numpy()
+            inter["edge_vec"] = rd.edge_vec.detach().numpy()
+            for h in hooks:
+                h.remove()
+    finally:
+        ref_hermnet.HVNet.with_edge = orig
+    assert torch.equal(e_plain, e.detach()), "out-of-place geometry changed the energy"
+    return sd, e.detach().numpy(), f.numpy(), inter
+
+
+def cases(full):
+    H128 = dict(rc=5.0, hidden_channels=128, num_rbf=128)
+    out = [
+        # C1 of BASELINE.json: the reference's own CPU-runnable case
+        ("c1_si64", synth.si_diamond(), ["Si"], dict(num_layers=2, **H128), 1, True, True),
+        # same cell through the reference's literal (sign-quirky) neighbour pipeline:
+        # 822 edges get wrong images, many with d >= rc -> bias-only messages
+        ("c1_si64_refcompat", synth.si_diamond(reference_compat=True), ["Si"], dict(num_layers=2, **H128), 1, True, True),
+        # 3-relation alloy, small
+        ("alloy108", synth.fcc_alloy(reps=(3, 3, 3)), ["Al", "Ni", "Cu"], dict(num_layers=3, **H128), 2, True, True),
+        # a listed element with no atoms is skipped by the build (reference crashes) -> not generated.
+        # atoms whose element is NOT in elems -> zero rows (SURVEY A5 ii)
+        ("alloy108_unknown_type", synth.fcc_alloy(reps=(3, 3, 3)), ["Al", "Cu"], dict(num_layers=2, **H128), 3, True, False),
+        # other widths: H=64/R=32 and H=256/R=64, rc=4
+        ("alloy108_h64", synth.fcc_alloy(reps=(3, 3, 3)), ["Al", "Ni", "Cu"],
+         dict(num_layers=2, rc=5.0, hidden_channels=64, num_rbf=32), 4, True, False),
+        ("alloy32_h256", synth.fcc_alloy(reps=(2, 2, 2), rc=4.0), ["Al", "Ni", "Cu"],
+         dict(num_layers=2, rc=4.0, hidden_channels=256, num_rbf=64), 5, True, False),
+        # C5-shaped: batch of open molecules, extensive and intensive read-out
+        ("mol16", synth.molecule_batch(num_graphs=16), ["H", "C", "O"], dict(num_layers=3, **H128), 6, True, False),
+        ("mol16_intensive", synth.molecule_batch(num_graphs=16), ["H", "C", "O"],
+         dict(num_layers=2, intensive=True, **H128), 7, True, False),
+        # alternative radial bases / envelope (API parity)
+        ("alloy32_bessel_expenv", synth.fcc_alloy(reps=(2, 2, 2), rc=4.0), ["Al", "Ni", "Cu"],
+         dict(num_layers=2, rc=4.0, hidden_channels=64, num_rbf=16, rbf={"name": "spherical_bessel"},
+              envelope={"name": "exponential"}), 8, True, False),
+        ("alloy32_bernstein", synth.fcc_alloy(reps=(2, 2, 2), rc=4.0), ["Al", "Ni", "Cu"],
+         dict(num_layers=2, rc=4.0, hidden_channels=64, num_rbf=16, rbf={"name": "bernstein"}), 9, True, False),
+    ]
+    if full:
+        out.append(("c2_alloy10k", synth.fcc_alloy(), ["Al", "Ni", "Cu"], dict(num_layers=5, **H128), 10, False, False))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    for name, d, elems, kw, seed, store_graph, want_inter in cases(args.full):
+        if args.only and args.only != name:
+            continue
+        t0 = time.time()
+        sd, e, f, inter = run_reference(d, elems, kw, seed, want_inter)
+        meta = dict(name=name, elems=elems, model_kw=kw, weight_seed=seed, sd_sha256=sd_checksum(sd),
+                    num_edges=int(d.edge_index.size(1)), torch=torch.__version__,
+                    edge_index_sha256=hashlib.sha256(d.edge_index.numpy().tobytes()).hexdigest())
+        arrays = dict(pos=d.pos.numpy(), atomic_number=d.atomic_number.numpy(), batch=d.batch.numpy(),
+                      energy=e, forces=f, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+        if d.get("cell") is not None:
+            arrays["cell"] = d.cell.numpy()
+        if store_graph:
+            arrays["edge_index"] = d.edge_index.numpy().astype(np.int32)
+            if d.get("edge_shift") is not None:
+                arrays["edge_shift"] = d.edge_shift.numpy().astype(np.int8)
+        for k, v in inter.items():
+            arrays[k] = v
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **arrays)
+        print("%-26s N=%-6d E=%-7d energy=%s max|F|=%.5f sumF=%.1e  %.1fs  %d KB" % (
+            name, d.pos.size(0), d.edge_index.size(1), np.array2string(e[:2], precision=8),
+            np.abs(f).max(), np.abs(f.sum(0)).max(), time.time() - t0, os.path.getsize(path) // 1024))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,81 @@
+"""Shared test helpers: golden-fixture loading and oracle access.
+
+`oracle/` is test infrastructure; only tests/, smoke() and bench.py's cpu_baseline import it."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import torch
+
+import hermnet_amd as hn
+from hermnet_amd.synth import synth_state_dict
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+SMALL_CASES = ["c1_si64", "c1_si64_refcompat", "alloy108", "alloy108_unknown_type", "alloy108_h64",
+               "alloy32_h256", "mol16", "mol16_intensive"]
+NONGAUSS_CASES = ["alloy32_bessel_expenv", "alloy32_bernstein"]
+
+
+def sd_checksum(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd.keys()):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+class Golden(object):
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.name = name
+        self.arrays = {k: z[k] for k in z.files}
+        self.meta = json.loads(bytes(z["meta"]).decode())
+        self.elems = self.meta["elems"]
+        self.model_kw = self.meta["model_kw"]
+        self.energy = torch.from_numpy(z["energy"])
+        self.forces = torch.from_numpy(z["forces"])
+
+    def data(self, regenerate_graph=None):
+        a = self.arrays
+        kw = dict(pos=torch.from_numpy(a["pos"]), atomic_number=torch.from_numpy(a["atomic_number"]),
+                  batch=torch.from_numpy(a["batch"]))
+        if "cell" in a:
+            kw["cell"] = torch.from_numpy(a["cell"])
+        if "edge_index" in a:
+            kw["edge_index"] = torch.from_numpy(a["edge_index"].astype(np.int64))
+            if "edge_shift" in a:
+                kw["edge_shift"] = torch.from_numpy(a["edge_shift"].astype(np.float32))
+        else:
+            d = regenerate_graph()
+            assert hashlib.sha256(d.edge_index.numpy().tobytes()).hexdigest() == self.meta["edge_index_sha256"]
+            kw["edge_index"] = d.edge_index
+            if d.get("edge_shift") is not None:
+                kw["edge_shift"] = d.edge_shift
+        return hn.Data(**kw)
+
+    def model(self):
+        """Product module with the fixture's deterministic weights (checksum-verified)."""
+        m = hn.HVNet(self.elems, **self.model_kw)
+        sd = synth_state_dict(m.state_dict(), self.meta["weight_seed"])
+        assert sd_checksum(sd) == self.meta["sd_sha256"], "state_dict layout differs from the reference's"
+        m.load_state_dict(sd)
+        m.eval()
+        return m
+
+    def oracle_kwargs(self):
+        kw = dict(self.model_kw)
+        out = dict(rc=kw.get("rc", 5.0), intensive=kw.get("intensive", False), num_layers=kw["num_layers"],
+                   hidden_channels=kw["hidden_channels"], num_rbf=kw["num_rbf"])
+        if "rbf" in kw:
+            out["rbf"] = kw["rbf"]
+        if "envelope" in kw:
+            out["envelope_spec"] = kw["envelope"]
+        return out
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b|  (forces have components near zero)."""
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
