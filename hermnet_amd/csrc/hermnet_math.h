@@ -42,15 +42,16 @@ HN_HD HnEnv hn_envelope(float u, int kind, int p) {
   HnEnv e;
   if (!(u < 1.0f)) { e.val = 0.0f; e.der = 0.0f; return e; }
   if (kind == 0) {
-    const float a = -(float)((p + 1) * (p + 2)) * 0.5f;
-    const float b = (float)(p * (p + 2));
-    const float c = -(float)(p * (p + 1)) * 0.5f;
+    // 1 + a u^p + b u^(p+1) + c u^(p+2)  ==  1 - u^p (1 + p w + p(p+1)/2 w^2),  w = 1 - u  (exact identity).
+    // The reference's left-to-right fp32 sum cancels terms of magnitude ~p^2 and carries ~2e-6 absolute
+    // noise; this form has no internal cancellation (~1e-7).  d/du = -K u^(p-1) w^2, K = p(p+1)(p+2)/2.
     const float up1 = hn_powi(u, p - 1);   // u^(p-1)
     const float up = up1 * u;
-    const float upp = up * u;
-    const float uppp = upp * u;
-    e.val = 1.0f + a * up + b * upp + c * uppp;
-    e.der = a * (float)p * up1 + b * (float)(p + 1) * up + c * (float)(p + 2) * upp;
+    const float w = 1.0f - u;
+    const float fp = (float)p;
+    e.val = 1.0f - up * (1.0f + w * (fp + 0.5f * fp * (fp + 1.0f) * w));
+    const float K = 0.5f * fp * (fp + 1.0f) * (fp + 2.0f);
+    e.der = -K * up1 * w * w;
   } else {
     const float den = (1.0f - u) * (1.0f + u);
     const float q = -(u * u) / den;

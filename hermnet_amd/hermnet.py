@@ -61,11 +61,15 @@ class HVNet(nn.Module):
             nn.Linear(hidden_channels // 2, 1),
         )
 
-    def forward(self, data):
-        pos = data.pos
+    @staticmethod
+    def _require_device(pos):
         if not pos.is_cuda:
             raise RuntimeError("hermnet_amd.HVNet runs on MI355X only (data is on %s); there is no CPU fallback"
                                % pos.device)
+
+    def forward(self, data):
+        pos = data.pos
+        self._require_device(pos)
         if data.get("batch") is None:
             # the reference fails here (scatter(..., None), hermnet.py:130); a single graph is meant
             data.batch = torch.zeros(pos.size(0), dtype=torch.long, device=pos.device)

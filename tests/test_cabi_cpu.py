@@ -1,0 +1,106 @@
+"""CPU: the C-ABI library loads without a GPU, exports every symbol include/hermnet_hip.h
+declares, and its banded radial contraction (the formulation the kernels use) agrees with the
+dense reference formula (rmnet.py:55,168-172) and with finite differences."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from hermnet_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "hermnet_hip.h")).read()
+    declared = set(re.findall(r"\b(hermnet_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES.keys()), declared ^ set(_lib.SIGNATURES.keys())
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.hermnet_abi_version() == 1
+    assert b"gfx950" in lib.hermnet_build_info()
+
+
+def _dense(offset, inv_rc, coeff, env_kind, p, wt, b, d):
+    """float64 dense evaluation of rbf_proj(env * gaussians) and its d-derivative."""
+    u = d * inv_rc
+    off = offset.astype(np.float64)
+    if env_kind == 0:
+        a_, b_, c_ = -(p + 1) * (p + 2) / 2, p * (p + 2), -p * (p + 1) / 2
+        env = 1 + a_ * u ** p + b_ * u ** (p + 1) + c_ * u ** (p + 2)
+        denv = a_ * p * u ** (p - 1) + b_ * (p + 1) * u ** p + c_ * (p + 2) * u ** (p + 1)
+    else:
+        q = -(u * u) / ((1 - u) * (1 + u))
+        env = np.exp(q)
+        denv = -2 * u / ((1 - u) * (1 + u)) ** 2 * env
+    if u >= 1:
+        env = denv = 0.0
+    gk = np.exp(coeff * (u - off) ** 2)
+    dgk = gk * 2 * coeff * (u - off)
+    rb = b + env * (gk @ wt)
+    drb = inv_rc * (denv * (gk @ wt) + env * (dgk @ wt))
+    return rb, drb
+
+
+def ref_env(u, env_kind, p):
+    u = float(u)
+    if env_kind == 0:
+        return 1 - (p + 1) * (p + 2) / 2 * u ** p + p * (p + 2) * u ** (p + 1) - p * (p + 1) / 2 * u ** (p + 2)
+    return np.exp(-(u * u) / ((1 - u) * (1 + u)))
+
+
+@pytest.mark.parametrize("R,env_kind,p", [(128, 0, 5), (32, 0, 5), (64, 1, 0), (16, 0, 3)])
+def test_banded_rbf_row_matches_dense(R, env_kind, p):
+    lib = _lib.load()
+    rs = np.random.RandomState(R)
+    C, rc = 24, 5.0
+    offset = torch.linspace(0, 1, R).numpy().copy()
+    coeff = -0.5 / float(offset[1] - offset[0]) ** 2
+    wt = (rs.uniform(-1, 1, size=(R, C)) / np.sqrt(R)).astype(np.float32)
+    b = rs.uniform(-0.1, 0.1, size=C).astype(np.float32)
+    rb = np.zeros(C, np.float32)
+    drb = np.zeros(C, np.float32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    worst = worst_d = worst32 = 0.0
+    for d in list(rs.uniform(0.05, rc * 0.999, size=200)) + [1e-6, 0.01, rc * 0.9999, rc, rc * 1.5, 33.7, 1e4]:
+        rcode = lib.hermnet_host_rbf_row(P(offset), R, 1.0 / rc, coeff, env_kind, p, P(wt), P(b), C,
+                                         float(np.float32(d)), P(rb), P(drb))
+        assert rcode == 0
+        ref, dref = _dense(offset, np.float32(1.0 / rc), coeff, env_kind, p, wt.astype(np.float64), b.astype(np.float64),
+                           float(np.float32(d)))
+        assert np.all(np.isfinite(rb)) and np.all(np.isfinite(drb))
+        scale = np.abs(ref).max()
+        worst = max(worst, np.abs(rb - ref).max() / scale)
+        # same dense sum in fp32 with the reference's operation order isolates the band truncation
+        u32 = np.float32(d) * np.float32(1.0 / rc)
+        if u32 < 1:
+            g32 = np.exp(np.float32(coeff) * (u32 - offset) ** 2, dtype=np.float32)
+            ref32 = b.astype(np.float64) + float(np.float32(ref_env(u32, env_kind, p))) * (g32.astype(np.float64) @ wt.astype(np.float64))
+            worst32 = max(worst32, np.abs(rb - ref32).max() / scale)
+        worst_d = max(worst_d, np.abs(drb - dref).max() / max(np.abs(dref).max(), 0.1))   # abs error floor: derivative -> 0 at the cutoff
+        if d >= rc:   # beyond the cutoff only the bias is left
+            assert np.array_equal(rb, b) and not drb.any()
+    # dropped taps are < exp(-18) of the largest; the rest is fp32 rounding of u - offset[k]
+    assert worst32 < 1e-6, worst32    # band truncation + summation order only
+    assert worst < 2e-5, worst        # + fp32 rounding of (u - offset[k]) * (R-1), shared with the reference
+    assert worst_d < 2e-4, worst_d
+
+
+def test_banded_rbf_derivative_vs_finite_difference():
+    lib = _lib.load()
+    R, C, rc = 128, 8, 5.0
+    rs = np.random.RandomState(0)
+    offset = torch.linspace(0, 1, R).numpy().copy()
+    coeff = -0.5 / float(offset[1] - offset[0]) ** 2
+    wt = (rs.uniform(-1, 1, size=(R, C)) / np.sqrt(R)).astype(np.float64)
+    b = np.zeros(C)
+    for d in [0.7, 2.345, 4.2]:
+        h = 1e-6
+        rp, _ = _dense(offset, 1 / rc, coeff, 0, 5, wt, b, d + h)
+        rm, _ = _dense(offset, 1 / rc, coeff, 0, 5, wt, b, d - h)
+        _, dr = _dense(offset, 1 / rc, coeff, 0, 5, wt, b, d)
+        assert np.allclose((rp - rm) / (2 * h), dr, rtol=1e-5, atol=1e-7)

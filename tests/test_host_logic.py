@@ -1,0 +1,178 @@
+"""CPU tests of the host logic: neighbour list, relation-ordered graph, container, state_dict
+layout, and the host pipeline of HVNet with the two fused operators replaced by their plain
+PyTorch restatements (tests/ref_ops.py) -- checked against the reference goldens."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+import hermnet_amd as hn
+from hermnet_amd import synth
+from hermnet_amd.elements import atomic_numbers
+from hermnet_amd.neighbor import neighbor_list
+from hermnet_amd.relations import RelationalGraph
+from helpers import Golden, SMALL_CASES, rel_err
+import ref_ops
+
+
+def _brute(pos, cell, rc, nimg=1):
+    I, J, S = [], [], []
+    for s in itertools.product(range(-nimg, nimg + 1), repeat=3):
+        sv = np.array(s) @ cell
+        dm = np.linalg.norm(pos[None, :, :] + sv - pos[:, None, :], axis=-1)
+        ii, jj = np.nonzero(dm < rc)
+        keep = ~((ii == jj) & (s == (0, 0, 0)))
+        I.append(ii[keep]); J.append(jj[keep]); S.append(np.broadcast_to(np.array(s), (keep.sum(), 3)))
+    I, J, S = np.concatenate(I), np.concatenate(J), np.concatenate(S)
+    k = np.lexsort((S[:, 2], S[:, 1], S[:, 0], J, I))
+    return I[k], J[k], S[k]
+
+
+@pytest.mark.parametrize("case", ["cubic", "triclinic", "small_cell", "unwrapped"])
+def test_neighbor_list_bit_exact_vs_brute_force(case):
+    rs = np.random.RandomState(3)
+    if case == "cubic":
+        cell = np.diag([9.0, 10.0, 11.0]); n = 60; nimg = 1; rc = 4.0
+    elif case == "triclinic":
+        cell = np.array([[9.0, 0, 0], [2.0, 8.5, 0], [1.0, -1.5, 9.5]]); n = 50; nimg = 2; rc = 4.0
+    elif case == "small_cell":   # cell shorter than rc: self images and several images per pair
+        cell = np.diag([3.0, 3.5, 4.0]); n = 5; nimg = 3; rc = 4.9   # (rc=5 would put the (1,0,1)+(−1,0,1) self-images exactly on the cutoff)
+    else:
+        cell = np.diag([8.0, 8.0, 8.0]); n = 40; nimg = 1; rc = 3.5
+    pos = rs.uniform(0, 1, size=(n, 3)) @ cell
+    if case == "unwrapped":
+        pos = pos + rs.randint(-2, 3, size=(n, 3)) @ cell   # atoms outside the cell
+        nimg = 6
+    i, j, s = neighbor_list(pos, rc, cell)
+    I, J, S = _brute(pos, cell, rc, nimg)
+    assert np.array_equal(i, I) and np.array_equal(j, J) and np.array_equal(s, S)
+    # identity the reference relies on: |pos[j] - pos[i] + S cell| < rc
+    d = np.linalg.norm(pos[j] - pos[i] + s @ cell, axis=1)
+    assert d.max() < rc
+
+
+def test_neighbor_list_open_system_and_empty():
+    rs = np.random.RandomState(0)
+    pos = rs.uniform(-4, 4, size=(80, 3))
+    i, j, s = neighbor_list(pos, 3.0, None)
+    dm = np.linalg.norm(pos[None] - pos[:, None], axis=-1)
+    ii, jj = np.nonzero((dm < 3.0) & ~np.eye(80, dtype=bool))
+    assert np.array_equal(i, ii) and np.array_equal(j, jj) and not s.any()
+    i, j, s = neighbor_list(np.zeros((0, 3)), 3.0, None)
+    assert len(i) == 0
+    ei = hn.neighbor_search(torch.from_numpy(pos).float(), 3.0)
+    assert ei.dtype == torch.int64 and ei.shape[0] == 2
+    assert np.array_equal(ei[1].numpy(), ii) and np.array_equal(ei[0].numpy(), jj)  # [source; target]
+
+
+def test_neighbor_search_sign_conventions():
+    d = synth.si_diamond()
+    dq = synth.si_diamond(reference_compat=True)
+    assert torch.equal(d.edge_index, dq.edge_index) and torch.equal(d.edge_shift, -dq.edge_shift)
+    # with the build's convention the model-side formula (hermnet.py:135-139) gives true images
+    j, i = d.edge_index
+    D = d.pos[j] - d.pos[i] + d.edge_shift @ d.cell[0]
+    assert float(D.norm(dim=1).max()) < 5.0
+    Dq = dq.pos[j] - dq.pos[i] + dq.edge_shift @ dq.cell[0]
+    assert float(Dq.norm(dim=1).max()) > 20.0     # the reference's literal pipeline: wrong images
+    assert int((dq.edge_shift.abs().sum(1) > 0).sum()) == 822 and d.edge_index.size(1) == 1792
+
+
+def test_synthetic_config2_shape():
+    d = synth.fcc_alloy(reps=(4, 4, 4))
+    assert d.pos.shape == (256, 3) and set(d.atomic_number.tolist()) == {13, 28, 29}
+
+
+def test_data_container_access_forms():
+    d = hn.Data(pos=torch.zeros(3, 3), atomic_number=torch.tensor([1, 1, 8]))
+    assert d.batch is None and d.get("cell") is None and d["pos"].shape == (3, 3)
+    d.edge_index = torch.zeros(2, 0, dtype=torch.long)
+    assert d.num_edges == 0 and d.num_nodes == 3 and "edge_index" in d
+    assert dict(iter(d)).keys() == {"pos", "atomic_number", "edge_index"}
+    import copy
+    c = copy.copy(d)
+    c.pos = torch.ones(3, 3)
+    assert float(d.pos.sum()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["alloy108", "alloy108_unknown_type", "mol16"])
+def test_relational_graph_structure(name):
+    g = Golden(name)
+    d = g.data()
+    zl = [atomic_numbers[e] for e in g.elems]
+    gr = RelationalGraph.build(d.atomic_number, d.edge_index, zl, d.get("edge_shift"), d.batch)
+    N, E, T = gr.N, gr.E, gr.T
+    z = d.atomic_number
+    rows_z = z[gr.node_order]
+    rp = gr.type_rowptr_host
+    for t in range(T):
+        assert (rows_z[rp[t]:rp[t + 1]] == zl[t]).all()
+        assert (gr.node_order[rp[t]:rp[t + 1]].diff() > 0).all()       # ascending ids inside a relation
+    assert not torch.isin(rows_z[rp[T]:], torch.tensor(zl)).any()
+    assert torch.equal(gr.row_of_node[gr.node_order], torch.arange(N))
+    src, tgt = d.edge_index
+    # CSR: segment r holds exactly the edges whose target is row r, in ascending edge id
+    rowptr = gr.csr_rowptr.long()
+    tgt_row = torch.repeat_interleave(torch.arange(N), rowptr[1:] - rowptr[:-1])
+    assert torch.equal(gr.row_of_node[tgt[gr.csr_perm]], tgt_row)
+    assert torch.equal(gr.csr_src.long(), gr.row_of_node[src[gr.csr_perm]])
+    for r in range(0, N, 7):
+        seg = gr.csr_perm[rowptr[r]:rowptr[r + 1]]
+        assert (seg.diff() > 0).all()
+    # CSC: segment (t, r) holds the CSR positions of edges from row r to targets of relation t
+    cp = gr.csc_rowptr.long()
+    assert cp.numel() == T * N + 1
+    rel_row = torch.bucketize(torch.arange(N), gr.type_rowptr.long()[1:], right=True)
+    n_known = int((rel_row[tgt_row] < T).sum())
+    assert int(cp[-1]) == n_known
+    pos = gr.csc_pos.long()
+    seg_id = torch.repeat_interleave(torch.arange(T * N), cp[1:] - cp[:-1])
+    assert torch.equal(seg_id // N, rel_row[tgt_row[pos[:n_known]]])
+    assert torch.equal(seg_id % N, gr.csr_src.long()[pos[:n_known]])
+    assert torch.equal(gr.csc_tgt.long()[:n_known], tgt_row[pos[:n_known]])
+    # out adjacency
+    op = gr.out_rowptr.long()
+    src_of = torch.repeat_interleave(torch.arange(N), op[1:] - op[:-1])
+    assert torch.equal(gr.csr_src.long()[gr.out_edges.long()], src_of)
+    assert gr.rel_edges_host == [int(((rel_row[tgt_row]) == t).sum()) for t in range(T)]
+
+
+def test_state_dict_layout_matches_reference():
+    g = Golden("alloy108")
+    keys = list(g.model().state_dict().keys())     # Golden.model() verifies the sha256 over keys+values
+    assert keys[0] == "embed.weight" and keys[1] == "radial_basis.rbf.offset"
+    assert "hermconvs.2.mods.Cu.update_layer.xvec_proj.2.bias" in keys
+    assert "hermconvs.0.mods.Al.message_layer.x_layernorm.weight" in keys
+    assert keys[-1] == "out_energy.2.bias"
+    m = hn.HVNet("C", hidden_channels=64, num_rbf=16, num_layers=1)
+    assert m.rc == 5.0 and list(m.hermconvs[0].mods.keys()) == ["C"]
+    for spec, key in [({"name": "spherical_bessel"}, "radial_basis.rbf.frequencies"),
+                      ({"name": "bernstein"}, "radial_basis.rbf.pregamma")]:
+        m = hn.HVNet(["C"], hidden_channels=64, num_rbf=16, num_layers=1, rbf=spec)
+        assert key in m.state_dict()
+
+
+class _FakeFn(object):
+    def __init__(self, fn):
+        self.apply = fn
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+def test_host_pipeline_with_reference_ops_matches_golden(name, monkeypatch):
+    """Everything around the two kernels (row ordering, per-relation node algebra, masks,
+    read-out) on CPU, with the kernels replaced by tests/ref_ops.py: must reproduce the
+    reference's energies and forces."""
+    import hermnet_amd.hermnet as hmod
+    import hermnet_amd.rmnet as rmod
+    g = Golden(name)
+    model = g.model()
+    monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
+    monkeypatch.setattr(hmod, "EdgeGeometry", _FakeFn(lambda pos, cell, graph: ref_ops.geometry_ref(pos, graph, cell)))
+    monkeypatch.setattr(rmod, "MessageScatter", _FakeFn(ref_ops.message_scatter_ref))
+    d = g.data()
+    d.pos.requires_grad_(True)
+    e = model(d)
+    f = -torch.autograd.grad(e.sum(), d.pos)[0]
+    assert rel_err(e.detach(), g.energy) < 2e-6
+    assert rel_err(f, g.forces) < 1e-5
