@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Headline benchmark: atom-steps/sec (energy + forces) of HVNet on BASELINE.json configs[1]
+(10k-atom 3-element fcc alloy, rc=5 A, hidden=128, num_rbf=128, 5 layers), fp32, synthetic data,
+random-init (seeded) weights.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+
+A "step" = HVNet.forward(data) + autograd.grad(E, pos) on a prebuilt `Data` (neighbour list
+excluded); the relation-ordered graph build (the replacement of
+the reference's per-layer `in_subgraph`) IS inside the step.  Inputs are resident in HBM before
+the timed region.  N > 1: one process per GPU (torchrun), every rank evaluates its own
+10k-atom replica ("replicas only" until the halo-sharded path lands -- DESIGN.md section (e)),
+no data-path collective, scaling "weak".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(E, N, H, T):
+    """Algorithmic HBM bytes per launch of the message kernels (DESIGN.md section "Kernels").
+    fwd: per edge 2 int32 + (rhat,d) 16 B + xh_j row 12H (+ vec_j row 12H when layer>0);
+                       per target atom: x1,vec1 write 16H.
+    bwd (this build):  per edge 2 int32 + edge 16 B + gx1,gvec1 rows of the target 16H + gD write 16*(H/64);
+                       per source atom and relation: xh row 12H read + gxh row 12H write; per atom: vec 12H read,
+                       gvec,gx 16H write, gx1/gvec1 identity 16H read."""
+    fwd_l0 = E * (8 + 16 + 12 * H) + N * 16 * H
+    fwd = E * (8 + 16 + 24 * H) + N * 16 * H
+    bwd = E * (8 + 16 + 16 * H + 16 * (H // 64)) + N * (T * 24 * H + 12 * H + 32 * H)
+    return {"message_scatter_fwd_l0": fwd_l0, "message_scatter_fwd": fwd,
+            "message_scatter_bwd": bwd, "message_scatter_bwd_l0": bwd - N * 12 * H}
+
+
+def cpu_baseline(model_kw, elems, seed):
+    """The reference CPU path (oracle, mode="faithful": same op sequence incl. the O(N*E)
+    in_subgraph loop) timed on a bounded sample: a 2,500-atom slice of the same alloy."""
+    from hermnet_amd import synth
+    import hermnet_amd as hn
+    from oracle import hermnet_oracle as orc
+    sample = synth.fcc_alloy(reps=(5, 5, 25))
+    m = hn.HVNet(elems, **model_kw)
+    sd = synth.synth_state_dict(m.state_dict(), seed)
+    kw = dict(rc=model_kw["rc"], num_layers=model_kw["num_layers"], hidden_channels=model_kw["hidden_channels"],
+              num_rbf=model_kw["num_rbf"])
+    cores = torch.get_num_threads()
+    small = synth.fcc_alloy(reps=(3, 3, 3))
+    orc.energy_and_forces(sd, elems, small, mode="faithful", **kw)      # warm-up (first call costs seconds)
+    t0 = time.time()
+    orc.energy_and_forces(sd, elems, sample, mode="faithful", **kw)
+    dt = time.time() - t0
+    n = sample.pos.size(0)
+    return {"value": n / dt, "unit": "atom-steps/s", "cores": cores, "kind": "port",
+            "sample": "oracle mode=faithful (reference op sequence incl. in_subgraph loop), one energy+forces "
+                      "step on a 2,500-atom slice (fcc 5x5x25) of the same alloy/model: %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--atoms", default="10k", choices=["10k", "100k"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                         % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import hermnet_amd as hn
+    from hermnet_amd import synth, ops, _lib
+    _lib.load()   # fail loudly if the HIP library is missing
+
+    elems = ["Al", "Ni", "Cu"]
+    model_kw = dict(rc=5.0, num_layers=5, hidden_channels=128, num_rbf=128)
+    seed = 10
+    model = hn.HVNet(elems, **model_kw).eval()
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), seed))
+    model = model.to(dev)
+    reps = (10, 10, 25) if args.atoms == "10k" else (10, 10, 250)
+    data = synth.fcc_alloy(reps=reps, seed=rank).to(dev)     # each rank: its own replica
+    N, E = data.pos.size(0), data.edge_index.size(1)
+    H, T = model_kw["hidden_channels"], len(elems)
+
+    def step():
+        data.pos.requires_grad_(True)
+        e = model(data)
+        f = -torch.autograd.grad(e.sum(), data.pos)[0]
+        return e, f
+
+    for _ in range(args.warmup):
+        step()
+    timer = ops.KernelTimer()
+    ops.set_kernel_timer(timer)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        e, f = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ksum = timer.summary()            # name -> (launches, mean ms), HIP events on the launch stream
+        ab = algorithmic_bytes(E, N, H, T)
+        kernels = {}
+        for name, (cnt, ms) in ksum.items():
+            kernels[name] = {"launches_per_step": cnt / args.steps, "avg_ms": ms,
+                             "algorithmic_GB": ab[name] / 1e9, "GBps": ab[name] / 1e9 / (ms / 1e3)}
+        # dominant kernel = largest share of the step
+        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom)
+        out = {
+            "metric": "atom-steps/sec (energy+forces) on 10k-atom 3-element cell; HBM GB/s vs roofline",
+            "value": N * world * args.steps / dt, "unit": "atom-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d-atom 3-element fcc alloy (Al/Ni/Cu), HVNet rc=5.0 hidden=128 "
+                                   "num_rbf=128 layers=5, E=%d directed edges, energy+forces per step" % (N, E),
+                       "atoms_per_gpu": N, "edges_per_gpu": E,
+                       "parallelism": "1 GPU" if world == 1 else "replicas only x%d (no data-path collective)" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic},
+            "kernels": kernels,
+            "energy": float(e[0]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model_kw, elems, seed)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,7 +70,7 @@ HN_HD HnEnv hn_envelope(float u, int kind, int p) {
 HN_HD int hn_window_lo(float u, int R) {
   float t = u * (float)(R - 1);
   // clamp before the float->int conversion: u can be large for beyond-cutoff edges
-  t = t < 0.0f ? 0.0f : (t > (float)(R + HN_TAP_BELOW) ? (float)(R + HN_TAP_BELOW) : t);
+  t = fminf(fmaxf(t, 0.0f), (float)(R + HN_TAP_BELOW));   // also maps NaN to 0
   int lo = (int)t - HN_TAP_BELOW;   // t >= 0 so the cast is floor
   return lo;                        // in [-5, R] -> padded row lo + HN_PAD in [6, R + 11]
 }

@@ -89,11 +89,16 @@ class HVNet(nn.Module):
         x = data.x
 
         per_atom_energy = self.out_energy(x).squeeze(1)                     # hermnet.py:129
-        energy = torch.zeros(graph.num_graphs, dtype=per_atom_energy.dtype, device=x.device)
-        energy = energy.index_add(0, graph.batch_rows, per_atom_energy)    # hermnet.py:130
-        if self.intensive:
-            cnt = torch.bincount(graph.batch_rows, minlength=graph.num_graphs).clamp(min=1)
-            energy = energy / cnt.to(energy.dtype)
+        # scatter(per_atom_energy, batch, reduce=sum|mean) (hermnet.py:130) as an ordered segment
+        # reduction: no atomics, so the energy is bit-reproducible run to run
+        if graph.num_graphs == 1:
+            energy = per_atom_energy.sum().reshape(1)
+            if self.intensive:
+                energy = energy / max(graph.N, 1)
+        else:
+            energy = torch.segment_reduce(per_atom_energy[graph.graph_perm], "sum", lengths=graph.graph_lengths)
+            if self.intensive:
+                energy = energy / graph.graph_lengths.clamp(min=1).to(energy.dtype)
         return energy
 
 

@@ -8,6 +8,39 @@ import torch
 from . import _lib
 
 
+class KernelTimer(object):
+    """Optional per-launch timing with HIP events recorded on the launch stream (used by
+    bench.py for the roofline figure).  Nothing is synchronised here; call `summary()` after
+    the caller's own device synchronisation."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def launch(self, name, fn):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn()
+        b.record()
+        self.pairs.setdefault(name, []).append((a, b))
+        return rc
+
+    def summary(self):
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.pairs.items()}
+
+
+_TIMER = None
+
+
+def set_kernel_timer(timer):
+    global _TIMER
+    _TIMER = timer
+
+
+def _launch(name, fn):
+    return fn() if _TIMER is None else _TIMER.launch(name, fn)
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -50,7 +83,7 @@ class EdgeGeometry(torch.autograd.Function):
         cell_c = None
         if graph.shift is not None and cell is not None:
             cell_c = cell.detach().float().reshape(-1, 3, 3).contiguous()
-        batch32 = getattr(graph, "_batch32", None)
+        batch32 = graph.batch32
         _lib.check(lib.hermnet_edge_geometry_fwd(
             _lib.ptr(pos_c), _lib.ptr(graph.src_id), _lib.ptr(graph.tgt_id),
             _lib.ptr(graph.shift if cell_c is not None else None), _lib.ptr(cell_c), _lib.ptr(batch32),
@@ -90,9 +123,9 @@ class MessageScatter(torch.autograd.Function):
         x1 = torch.empty_like(x)
         vec1 = torch.empty(x.size(0), 3, H, dtype=x.dtype, device=x.device)
         gs, rs = graph.as_struct(), rbf.struct()
-        _lib.check(lib.hermnet_message_scatter_fwd(
+        _lib.check(_launch("message_scatter_fwd" + ("" if vec_c is not None else "_l0"), lambda: lib.hermnet_message_scatter_fwd(
             ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), _lib.ptr(vec_c), _lib.ptr(x),
-            _lib.ptr(wt), _lib.ptr(brbf), _lib.ptr(edge), _lib.ptr(x1), _lib.ptr(vec1), _stream()),
+            _lib.ptr(wt), _lib.ptr(brbf), _lib.ptr(edge), _lib.ptr(x1), _lib.ptr(vec1), _stream())),
             "hermnet_message_scatter_fwd")
         ctx.save_for_backward(xh, vec_c, edge, wt, brbf)
         ctx.graph, ctx.rbf, ctx.H = graph, rbf, H
@@ -110,8 +143,8 @@ class MessageScatter(torch.autograd.Function):
         gx = torch.empty_like(gx1)
         gedge = torch.zeros(H // 64, graph.E, 4, dtype=torch.float32, device=gx1.device)
         gs, rs = graph.as_struct(), rbf.struct()
-        _lib.check(lib.hermnet_message_scatter_bwd(
+        _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"), lambda: lib.hermnet_message_scatter_bwd(
             ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), _lib.ptr(vec), _lib.ptr(wt), _lib.ptr(brbf),
             _lib.ptr(edge), _lib.ptr(gx1), _lib.ptr(gvec1), _lib.ptr(gxh), _lib.ptr(gvec), _lib.ptr(gx),
-            _lib.ptr(gedge), _stream()), "hermnet_message_scatter_bwd")
+            _lib.ptr(gedge), _stream())), "hermnet_message_scatter_bwd")
         return gxh, gvec, gx, gedge.sum(0), None, None, None, None

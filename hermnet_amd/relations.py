@@ -17,7 +17,7 @@ class RelationalGraph(object):
     __slots__ = ("N", "E", "T", "node_order", "row_of_node", "type_rowptr", "type_rowptr_host",
                  "rel_edges_host", "csr_rowptr", "csr_src", "csr_perm", "csc_rowptr", "csc_tgt", "csc_pos",
                  "out_rowptr", "out_edges", "src_id", "tgt_id", "shift", "row_active", "needs_mask",
-                 "batch_rows", "batch32", "num_graphs", "device")
+                 "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device")
 
     @staticmethod
     def build(atomic_number, edge_index, z_list, edge_shift=None, batch=None):
@@ -93,6 +93,13 @@ class RelationalGraph(object):
         g.shift = None if edge_shift is None else edge_shift[csr_perm].float().contiguous()
         g.batch_rows = None if batch is None else batch.long()[g.node_order]
         g.batch32 = None if batch is None else batch.to(i32).contiguous()
+        # deterministic per-graph read-out: rows grouped by graph (stable) + segment lengths
+        if g.batch_rows is not None and g.num_graphs > 1:
+            g.graph_perm = torch.argsort(g.batch_rows, stable=True)
+            g.graph_lengths = torch.bincount(g.batch_rows, minlength=g.num_graphs)
+        else:
+            g.graph_perm = None
+            g.graph_lengths = None
         return g
 
     def as_struct(self):
