@@ -16,12 +16,16 @@
 // exchange per row; nothing is accumulated in HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/hermnet_hip.h"
 #include "hermnet_math.h"
 
 #define HN_WAVES 16                 // waves per workgroup (1024 threads, 4 per SIMD)
 #define HN_THREADS (HN_WAVES * 64)
 #define HN_LDS_ROW (3 * HN_CB)      // floats per tap row in LDS: [part][64]
+#ifndef HN_TAP_UNROLL
+#define HN_TAP_UNROLL 12
+#endif
 
 namespace {
 
@@ -77,10 +81,11 @@ __device__ __forceinline__ float half_allsum(float v) {
 // Stage the zero-padded weight tile of (relation t, column block cb) and the tap centres into LDS.
 //   wl[(k + HN_PAD) * 192 + part * 64 + c] = wt[t][k][part * H + cb * 64 + c]   (0 outside 0 <= k < R)
 //   mu[k + HN_PAD] = offset[clamp(k)]
+template <int NTHREADS>
 __device__ __forceinline__ void stage_weights(const MsgArgs& a, int t, int cb, float* wl, float* mu) {
   const int rows = a.R + 2 * HN_PAD + 1;
   const int n4 = rows * (HN_LDS_ROW / 4);
-  for (int idx = threadIdx.x; idx < n4; idx += HN_THREADS) {
+  for (int idx = threadIdx.x; idx < n4; idx += NTHREADS) {
     const int kk = idx / (HN_LDS_ROW / 4);
     const int q = idx - kk * (HN_LDS_ROW / 4);
     const int part = q >> 4;          // 16 float4 per 64-channel part
@@ -93,7 +98,7 @@ __device__ __forceinline__ void stage_weights(const MsgArgs& a, int t, int cb, f
     }
     *reinterpret_cast<float4*>(wl + kk * HN_LDS_ROW + part * HN_CB + c4 * 4) = v;
   }
-  for (int kk = threadIdx.x; kk < rows; kk += HN_THREADS) {
+  for (int kk = threadIdx.x; kk < rows; kk += NTHREADS) {
     int k = kk - HN_PAD;
     k = k < 0 ? 0 : (k >= a.R ? a.R - 1 : k);
     mu[kk] = a.offset[k];
@@ -109,7 +114,7 @@ __device__ __forceinline__ void banded_rbf(const float* wl, const float* mu, int
   for (int p = 0; p < 3; ++p) { S0[p] = make_float2(0.f, 0.f); if (WITH_DER) S1[p] = make_float2(0.f, 0.f); }
   const float* wrow = wl + (lo + HN_PAD) * HN_LDS_ROW + 2 * hl;
   const float* mrow = mu + (lo + HN_PAD);
-#pragma unroll
+#pragma unroll HN_TAP_UNROLL
   for (int m = 0; m < HN_TAPS; ++m) {
     const float diff = u - mrow[m];
     const float g = __expf(coeff * (diff * diff));
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(HN_THREADS, 4) void message_scatter_fwd_kernel(MsgA
     }
     return;
   }
-  stage_weights(a, t, cb, wl, mu);
+  stage_weights<HN_THREADS>(a, t, cb, wl, mu);
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -253,12 +258,37 @@ __global__ __launch_bounds__(HN_THREADS, 4) void message_scatter_fwd_kernel(MsgA
 }
 
 // ------------------------------------------------------------------------------------------
-// Backward (forces): one workgroup = (column block, chunk of SOURCE rows); loops over the
-// relations of the targets, restaging the weight tile per relation.  All sums keyed by the
-// source row stay in registers: gxh[t][row] is written once per relation, gvec[row]/gx[row] once.
+// Backward (forces): one workgroup = (column block, chunk of SOURCE rows); it loops over the
+// relations of the targets, restaging the weight tile per relation.  Sums keyed by the source row
+// stay in registers for the whole CSC segment: gxh[t][row] is written once per relation; gvec[row]
+// is written at t = 0 (with the residual's identity term) and read-modify-written by the same
+// lanes for t > 0.  Per-edge cross-lane sums (dE/dD, 3 floats) use DPP inside 16-lane rows.
 // ------------------------------------------------------------------------------------------
-template <bool HAS_VEC>
-__global__ __launch_bounds__(HN_THREADS, 4) void message_scatter_bwd_kernel(MsgArgs a) {
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+// Sum over the 32 lanes of each half-wave; every lane ends with its half's total.
+__device__ __forceinline__ float half_allsum_dpp(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
+  v += dpp_mov<0x141>(v);   // row_half_mirror      : other quad of the 8-lane group
+  v += dpp_mov<0x140>(v);   // row_mirror           : other half of the 16-lane row
+  v += __shfl_xor(v, 16, 64);
+  return v;
+}
+
+struct BwdIn {
+  float4 g;       // (rx, ry, rz, d)
+  float2 gx1;     // d/dx1 of the target row
+  float2 gd[3];   // d/dvec1 of the target row
+  int pos;
+  float lv;       // 1 for a live edge, 0 for the padding half of an odd segment
+};
+
+template <bool HAS_VEC, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(MsgArgs a) {
   extern __shared__ __align__(16) float lds[];
   float* wl = lds;
   float* mu = lds + (a.R + 2 * HN_PAD + 1) * HN_LDS_ROW;
@@ -278,18 +308,9 @@ __global__ __launch_bounds__(HN_THREADS, 4) void message_scatter_bwd_kernel(MsgA
   const float inv_sqrt2 = 0.70710678118654752f;
   float4* gedge = a.gedge + (size_t)cb * a.E;
 
-  // rows_per_block <= HN_WAVES * MAXR: each wave keeps the gvec accumulators of its (up to MAXR)
-  // rows across the relation loop.
-  constexpr int MAXR = 2;
-  float2 gv[MAXR][3];
-#pragma unroll
-  for (int k = 0; k < MAXR; ++k)
-#pragma unroll
-    for (int d = 0; d < 3; ++d) gv[k][d] = make_float2(0.f, 0.f);
-
   for (int t = 0; t < a.T; ++t) {
     __syncthreads();   // previous tile no longer in use
-    stage_weights(a, t, cb, wl, mu);
+    stage_weights<NW * 64>(a, t, cb, wl, mu);
     __syncthreads();
     const float* xh_t = a.xh + (size_t)t * a.N * 3 * H;
     float* gxh_t = a.gxh + (size_t)t * a.N * 3 * H;
@@ -297,10 +318,7 @@ __global__ __launch_bounds__(HN_THREADS, 4) void message_scatter_bwd_kernel(MsgA
 #pragma unroll
     for (int p = 0; p < 3; ++p) bias[p] = ld2(a.brbf + (size_t)t * 3 * H + p * H + col);
 
-#pragma unroll
-    for (int k = 0; k < MAXR; ++k) {
-      const int r = r0 + wave + k * HN_WAVES;
-      if (r >= r1) continue;      // wave-uniform
+    for (int r = r0 + wave; r < r1; r += NW) {
       const int beg = a.csc_rowptr[(size_t)t * a.N + r], end = a.csc_rowptr[(size_t)t * a.N + r + 1];
       const float* xr = xh_t + (size_t)r * 3 * H + col;
       const float2 xs = ld2(xr), xa = ld2(xr + H), xb = ld2(xr + 2 * H);
@@ -311,68 +329,83 @@ __global__ __launch_bounds__(HN_THREADS, 4) void message_scatter_bwd_kernel(MsgA
         for (int d = 0; d < 3; ++d) vj[d] = ld2(vr + d * H);
       }
       float2 gs = make_float2(0.f, 0.f), ga = make_float2(0.f, 0.f), gb = make_float2(0.f, 0.f);
+      float2 gv[3] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
 
-      for (int e0 = beg; e0 < end; e0 += 2) {
-        const int e = e0 + half;
-        const bool live = e < end;
-        // every lane runs the cross-lane reductions below, so dead lanes compute on a valid edge
-        // and contribute zero.
-        const int es = live ? e : e0;
-        const int i = a.csc_tgt[es];
-        const int pos = a.csc_pos[es];
-        const float4 g = a.edge[pos];
-        const float2 gx1 = ld2(a.gx1 + (size_t)i * H + col);
-        float2 gd[3];
-        const float* gvr = a.gvec1 + (size_t)i * 3 * H + col;
+      for (int base = beg; base < end; base += 64) {
+        const int cnt = min(64, end - base);
+        // one coalesced index load per 64 edges; pairs pick their entries with a lane shuffle
+        const int my_tgt = lane < cnt ? a.csc_tgt[base + lane] : 0;
+        const int my_pos = lane < cnt ? a.csc_pos[base + lane] : 0;
+        const int npair = (cnt + 1) >> 1;
+
+        auto load_pair = [&](int it) {
+          BwdIn in;
+          const int idx = 2 * it + half;
+          const int i = __shfl(my_tgt, idx, 64);
+          in.pos = __shfl(my_pos, idx, 64);
+          in.lv = idx < cnt ? 1.0f : 0.0f;
+          in.g = a.edge[in.pos];
+          in.gx1 = ld2(a.gx1 + (size_t)i * H + col);
+          const float* gvr = a.gvec1 + (size_t)i * 3 * H + col;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) gd[d] = ld2(gvr + d * H);
+          for (int d = 0; d < 3; ++d) in.gd[d] = ld2(gvr + d * H);
+          return in;
+        };
 
-        const float u = g.w * a.inv_rc;
-        const HnEnv env = hn_envelope(u, a.env_kind, a.env_p);
-        const int lo = hn_window_lo(u, a.R);
-        float2 S0[3], S1[3];
-        banded_rbf<true>(wl, mu, lo, u, a.coeff, hl, S0, S1);
-        const float lv = live ? 1.0f : 0.0f;
-        // d rbfh / d d = inv_rc * (env' S0 + env * 2 coeff S1)
-        const float c0 = a.inv_rc * env.der, c1 = a.inv_rc * env.val * 2.0f * a.coeff;
-        const float rd[3] = {g.x, g.y, g.z};
-        float pd = 0.f;                    // partial dE/dd over this lane's channels
-        float pr[3] = {0.f, 0.f, 0.f};     // partial dE/d rhat
+        BwdIn cur = load_pair(0);
+        for (int it = 0; it < npair; ++it) {
+          BwdIn nxt = cur;
+          if (it + 1 < npair) nxt = load_pair(it + 1);   // wave-uniform: prefetch the next pair
+
+          const float4 g = cur.g;
+          const float u = g.w * a.inv_rc;
+          const HnEnv env = hn_envelope(u, a.env_kind, a.env_p);
+          const int lo = hn_window_lo(u, a.R);
+          float2 S0[3], S1[3];
+          banded_rbf<true>(wl, mu, lo, u, a.coeff, hl, S0, S1);
+          const float lv = cur.lv;
+          // d rbfh / d d = inv_rc * (env' S0 + env * 2 coeff S1)
+          const float c0 = a.inv_rc * env.der, c1 = a.inv_rc * env.val * 2.0f * a.coeff;
+          const float rd[3] = {g.x, g.y, g.z};
+          float pd = 0.f;                    // partial dE/dd over this lane's channels
+          float pr[3] = {0.f, 0.f, 0.f};     // partial dE/d rhat
 #define HN_BWD_CH(C)                                                                         \
-        {                                                                                    \
-          const float rs = fmaf(env.val, S0[0].C, bias[0].C);                                \
-          const float ra = fmaf(env.val, S0[1].C, bias[1].C);                                \
-          const float rb = fmaf(env.val, S0[2].C, bias[2].C);                                \
-          const float drs = fmaf(c0, S0[0].C, c1 * S1[0].C);                                 \
-          const float dra = fmaf(c0, S0[1].C, c1 * S1[1].C);                                 \
-          const float drb = fmaf(c0, S0[2].C, c1 * S1[2].C);                                 \
-          const float gdx = gx1.C * inv_sqrt2 * lv;                                          \
-          const float g0 = gd[0].C * lv, g1 = gd[1].C * lv, g2 = gd[2].C * lv;               \
-          const float A = (g0 * vj[0].C + g1 * vj[1].C + g2 * vj[2].C) * inv_sqrt3h;         \
-          const float B = (g0 * rd[0] + g1 * rd[1] + g2 * rd[2]) * inv_sqrth;                \
-          gs.C = fmaf(gdx, rs, gs.C);                                                        \
-          ga.C = fmaf(A, ra, ga.C);                                                          \
-          gb.C = fmaf(B, rb, gb.C);                                                          \
-          const float w = xa.C * ra * inv_sqrt3h;                                            \
-          gv[k][0].C = fmaf(g0, w, gv[k][0].C);                                              \
-          gv[k][1].C = fmaf(g1, w, gv[k][1].C);                                              \
-          gv[k][2].C = fmaf(g2, w, gv[k][2].C);                                              \
-          pd += gdx * xs.C * drs + A * xa.C * dra + B * xb.C * drb;                          \
-          const float q = xb.C * rb * inv_sqrth;                                             \
-          pr[0] = fmaf(g0, q, pr[0]); pr[1] = fmaf(g1, q, pr[1]); pr[2] = fmaf(g2, q, pr[2]); \
-        }
-        HN_BWD_CH(x)
-        HN_BWD_CH(y)
+          {                                                                                  \
+            const float rs = fmaf(env.val, S0[0].C, bias[0].C);                              \
+            const float ra = fmaf(env.val, S0[1].C, bias[1].C);                              \
+            const float rb = fmaf(env.val, S0[2].C, bias[2].C);                              \
+            const float drs = fmaf(c0, S0[0].C, c1 * S1[0].C);                               \
+            const float dra = fmaf(c0, S0[1].C, c1 * S1[1].C);                               \
+            const float drb = fmaf(c0, S0[2].C, c1 * S1[2].C);                               \
+            const float gdx = cur.gx1.C * inv_sqrt2 * lv;                                    \
+            const float g0 = cur.gd[0].C * lv, g1 = cur.gd[1].C * lv, g2 = cur.gd[2].C * lv; \
+            const float A = (g0 * vj[0].C + g1 * vj[1].C + g2 * vj[2].C) * inv_sqrt3h;       \
+            const float B = (g0 * rd[0] + g1 * rd[1] + g2 * rd[2]) * inv_sqrth;              \
+            gs.C = fmaf(gdx, rs, gs.C);                                                      \
+            ga.C = fmaf(A, ra, ga.C);                                                        \
+            gb.C = fmaf(B, rb, gb.C);                                                        \
+            const float w = xa.C * ra * inv_sqrt3h;                                          \
+            gv[0].C = fmaf(g0, w, gv[0].C);                                                  \
+            gv[1].C = fmaf(g1, w, gv[1].C);                                                  \
+            gv[2].C = fmaf(g2, w, gv[2].C);                                                  \
+            pd += gdx * xs.C * drs + A * xa.C * dra + B * xb.C * drb;                        \
+            const float q = xb.C * rb * inv_sqrth;                                           \
+            pr[0] = fmaf(g0, q, pr[0]); pr[1] = fmaf(g1, q, pr[1]); pr[2] = fmaf(g2, q, pr[2]); \
+          }
+          HN_BWD_CH(x)
+          HN_BWD_CH(y)
 #undef HN_BWD_CH
-        // Cartesian gradient w.r.t. D (d = |D|, rhat = D/d): gD = pd rhat + (pr - (pr.rhat) rhat)/d
-        const float dotp = pr[0] * rd[0] + pr[1] * rd[1] + pr[2] * rd[2];
-        const float invd = 1.0f / g.w;
-        float gD[3];
+          // Cartesian gradient w.r.t. D (d = |D|, rhat = D/d): gD = pd rhat + (pr - (pr.rhat) rhat)/d
+          const float dotp = pr[0] * rd[0] + pr[1] * rd[1] + pr[2] * rd[2];
+          const float invd = 1.0f / g.w;
+          float gD[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) gD[d] = half_allsum(fmaf(pd - dotp * invd, rd[d], pr[d] * invd));
-        if (live && hl == 0) gedge[pos] = make_float4(gD[0], gD[1], gD[2], 0.f);
+          for (int d = 0; d < 3; ++d) gD[d] = half_allsum_dpp(fmaf(pd - dotp * invd, rd[d], pr[d] * invd));
+          if (lv != 0.0f && hl == 0) gedge[cur.pos] = make_float4(gD[0], gD[1], gD[2], 0.f);
+          cur = nxt;
+        }
       }
-      // combine halves and write this relation's gxh row (both halves hold the sums; half 0 stores)
+      // combine halves; half 0 stores this relation's gxh row, gvec/gx are split over both halves
       gs.x = xhalf_sum(gs.x); gs.y = xhalf_sum(gs.y);
       ga.x = xhalf_sum(ga.x); ga.y = xhalf_sum(ga.y);
       gb.x = xhalf_sum(gb.x); gb.y = xhalf_sum(gb.y);
@@ -380,29 +413,25 @@ __global__ __launch_bounds__(HN_THREADS, 4) void message_scatter_bwd_kernel(MsgA
         float* go = gxh_t + (size_t)r * 3 * H + col;
         st2(go, gs); st2(go + H, ga); st2(go + 2 * H, gb);
       }
-    }
-  }
-  // identity paths of the residual: gvec += gvec1 (known rows), gx = gx1 / sqrt2 (known rows)
-#pragma unroll
-  for (int k = 0; k < MAXR; ++k) {
-    const int r = r0 + wave + k * HN_WAVES;
-    if (r >= r1) continue;
-    const bool known = r < nk;
-    const size_t vo = (size_t)r * 3 * H + col;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { gv[k][d].x = xhalf_sum(gv[k][d].x); gv[k][d].y = xhalf_sum(gv[k][d].y); }
-    if (half == 0) {
-      const float2 g1 = known ? ld2(a.gx1 + (size_t)r * H + col) : make_float2(0.f, 0.f);
-      st2(a.gx + (size_t)r * H + col, make_float2(g1.x * inv_sqrt2, g1.y * inv_sqrt2));
-      if (HAS_VEC) {
-        const float2 i0 = known ? ld2(a.gvec1 + vo) : make_float2(0.f, 0.f);
-        st2(a.gvec + vo, make_float2(gv[k][0].x + i0.x, gv[k][0].y + i0.y));
+      const bool known = r < nk;
+      if (t == 0 && half == 0) {   // residual identity: gx = gx1 / sqrt2 on rows that are targets
+        const float2 g1 = known ? ld2(a.gx1 + (size_t)r * H + col) : make_float2(0.f, 0.f);
+        st2(a.gx + (size_t)r * H + col, make_float2(g1.x * inv_sqrt2, g1.y * inv_sqrt2));
       }
-    } else if (HAS_VEC) {
-      const float2 i1 = known ? ld2(a.gvec1 + vo + H) : make_float2(0.f, 0.f);
-      const float2 i2 = known ? ld2(a.gvec1 + vo + 2 * H) : make_float2(0.f, 0.f);
-      st2(a.gvec + vo + H, make_float2(gv[k][1].x + i1.x, gv[k][1].y + i1.y));
-      st2(a.gvec + vo + 2 * H, make_float2(gv[k][2].x + i2.x, gv[k][2].y + i2.y));
+      if (HAS_VEC) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { gv[d].x = xhalf_sum(gv[d].x); gv[d].y = xhalf_sum(gv[d].y); }
+        const size_t vo = (size_t)r * 3 * H + col;
+        // component 0 by half 0, components 1 and 2 by half 1
+        const int d_lo = half == 0 ? 0 : 1, d_hi = half == 0 ? 1 : 3;
+        for (int d = d_lo; d < d_hi; ++d) {
+          float2 prev;
+          if (t == 0) prev = known ? ld2(a.gvec1 + vo + d * H) : make_float2(0.f, 0.f);
+          else prev = ld2(a.gvec + vo + d * H);
+          const float2 add = d == 0 ? gv[0] : (d == 1 ? gv[1] : gv[2]);
+          st2(a.gvec + vo + d * H, make_float2(prev.x + add.x, prev.y + add.y));
+        }
+      }
     }
   }
 }
@@ -417,6 +446,40 @@ int fill_args(const hn_graph* g, const hn_rbf_desc* rbf, int hidden, MsgArgs& a)
   a.env_kind = rbf->env_kind; a.env_p = rbf->env_p;
   a.H = hidden;
   return HN_OK;
+}
+
+// tuning knobs (environment, read once): HERMNET_BWD_WAVES = 8|16, HERMNET_ROWS_PER_BLOCK
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+int bwd_waves() { int w = env_int("HERMNET_BWD_WAVES", 8); return w == 16 ? 16 : 8; }
+
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+// Rows per workgroup such that the grid is a whole number of "rounds" of one workgroup per CU
+// (the 116 KB weight tile allows one resident workgroup per CU): `work` = rows x column blocks,
+// `slack` = workgroups lost to per-relation rounding.  Targets ~32 rows per workgroup.
+int pick_rows(int rows, int ncb, int slack, int override_rows) {
+  if (override_rows > 0) return override_rows;
+  const long work = (long)rows * ncb;
+  const int cus = num_cus();
+  long rounds = (work + (long)cus * 16) / ((long)cus * 32);
+  if (rounds < 1) rounds = 1;
+  long wgs = (long)cus * rounds - slack;
+  if (wgs < 1) wgs = 1;
+  long rpb = (work + wgs - 1) / wgs;
+  if (rpb < 8) rpb = 8;
+  return (int)rpb;
 }
 
 size_t lds_bytes(int R) {
@@ -437,7 +500,8 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   a.xh = xh; a.vec = vec; a.x = x; a.wt = wt; a.brbf = brbf;
   a.edge = reinterpret_cast<const float4*>(edge);
   a.x1 = x1; a.vec1 = vec1;
-  a.rows_per_block = 32;
+  static const int rpb_fwd = env_int("HERMNET_FWD_ROWS", 0);
+  a.rows_per_block = pick_rows(a.N, hidden / HN_CB, a.T * (hidden / HN_CB), rpb_fwd);
   const size_t lds = lds_bytes(a.R);
   if (lds > 160 * 1024) return HN_ERR_LDS;
   // blocks: sum_t ceil(N_t / rpb) <= N / rpb + T, plus one surplus block that zeroes unknown rows
@@ -467,14 +531,18 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   a.edge = reinterpret_cast<const float4*>(edge);
   a.gx1 = gx1; a.gvec1 = gvec1; a.gxh = gxh; a.gvec = gvec; a.gx = gx;
   a.gedge = reinterpret_cast<float4*>(gedge);
-  a.rows_per_block = 32;
+  static const int rpb_bwd = env_int("HERMNET_BWD_ROWS", 0);
+  a.rows_per_block = pick_rows(a.N, hidden / HN_CB, 0, rpb_bwd);
   const size_t lds = lds_bytes(a.R);
   if (lds > 160 * 1024) return HN_ERR_LDS;
   dim3 grid((unsigned)((a.N + a.rows_per_block - 1) / a.rows_per_block), (unsigned)(hidden / HN_CB));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  auto k = vec ? message_scatter_bwd_kernel<true> : message_scatter_bwd_kernel<false>;
+  static const int nw = bwd_waves();
+  void (*k)(MsgArgs);
+  if (nw == 8) k = vec ? message_scatter_bwd_kernel<true, 8> : message_scatter_bwd_kernel<false, 8>;
+  else k = vec ? message_scatter_bwd_kernel<true, 16> : message_scatter_bwd_kernel<false, 16>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess) return HN_ERR_LDS;
-  hipLaunchKernelGGL(k, grid, dim3(HN_THREADS), lds, s, a);
+  hipLaunchKernelGGL(k, grid, dim3(nw * 64), lds, s, a);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the two message kernels on the config-2 graph (10k atoms, E=431,340).
+Tuning knobs come from the environment (read once by the library): HERMNET_BWD_WAVES,
+HERMNET_FWD_ROWS, HERMNET_BWD_ROWS.  Prints avg ms and algorithmic GB/s per kernel."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import hermnet_amd as hn  # noqa: E402
+from hermnet_amd import synth, _lib  # noqa: E402
+from hermnet_amd.ops import EdgeGeometry, _stream  # noqa: E402
+from hermnet_amd.relations import RelationalGraph  # noqa: E402
+from bench import algorithmic_bytes  # noqa: E402
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    d = synth.fcc_alloy().to(dev)
+    g = RelationalGraph.build(d.atomic_number, d.edge_index, [13, 28, 29], d.edge_shift, d.batch)
+    model = hn.HVNet(["Al", "Ni", "Cu"], rc=5.0, num_layers=1, hidden_channels=128, num_rbf=128).to(dev)
+    rbf = model.radial_basis.descriptor()
+    N, E, T, H, R = g.N, g.E, g.T, 128, 128
+    edge = EdgeGeometry.apply(d.pos, d.cell, g)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=gen)
+    xh, x, vec = rnd(T, N, 3 * H), rnd(N, H), rnd(N, 3, H)
+    wt, brbf = rnd(T, R, 3 * H) / 11.3, rnd(T, 3 * H) * 0.1
+    x1, vec1 = torch.empty_like(x), torch.empty_like(vec)
+    gx1, gvec1 = rnd(N, H), rnd(N, 3, H)
+    gxh, gvec, gx = torch.empty_like(xh), torch.empty_like(vec), torch.empty_like(x)
+    gedge = torch.zeros(H // 64, E, 4, device=dev)
+    gs, rs = g.as_struct(), rbf.struct()
+    P = _lib.ptr
+
+    def fwd(v):
+        return lib.hermnet_message_scatter_fwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(v), P(x), P(wt), P(brbf),
+                                               P(edge), P(x1), P(vec1), _stream())
+
+    def bwd(v):
+        return lib.hermnet_message_scatter_bwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(v), P(wt), P(brbf), P(edge),
+                                               P(gx1), P(gvec1), P(gxh), P(gvec if v is not None else None), P(gx),
+                                               P(gedge), _stream())
+
+    ab = algorithmic_bytes(E, N, H, T)
+    res = {}
+    for name, fn, arg in [("message_scatter_fwd", fwd, vec), ("message_scatter_fwd_l0", fwd, None),
+                          ("message_scatter_bwd", bwd, vec), ("message_scatter_bwd_l0", bwd, None)]:
+        for _ in range(3):
+            assert fn(arg) == 0
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn(arg)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / iters
+        res[name] = ms
+        print("%-24s %8.3f ms  %7.1f GB/s (algorithmic)" % (name, ms, ab[name] / 1e6 / ms))
+    knobs = {k: v for k, v in os.environ.items() if k.startswith("HERMNET_")}
+    print("knobs", knobs, "checksum", float(x1.sum() + vec1.sum()), float(gxh.sum() + gvec.sum() + gedge.sum()))
+
+
+if __name__ == "__main__":
+    main()
