@@ -97,6 +97,8 @@ def main():
     model = hn.HVNet(elems, **model_kw).eval()
     model.load_state_dict(synth.synth_state_dict(model.state_dict(), seed))
     model = model.to(dev)
+    for p_ in model.parameters():      # energy/force evaluation: no parameter gradients
+        p_.requires_grad_(False)
     reps = (10, 10, 25) if args.atoms == "10k" else (10, 10, 250)
     data = synth.fcc_alloy(reps=reps, seed=rank).to(dev)     # each rank: its own replica
     N, E = data.pos.size(0), data.edge_index.size(1)
@@ -135,10 +137,11 @@ def main():
         ab = algorithmic_bytes(E, N, H, T)
         kernels = {}
         for name, (cnt, ms) in ksum.items():
-            kernels[name] = {"launches_per_step": cnt / args.steps, "avg_ms": ms,
-                             "algorithmic_GB": ab[name] / 1e9, "GBps": ab[name] / 1e9 / (ms / 1e3)}
+            kernels[name] = {"launches_per_step": cnt / args.steps, "avg_ms": ms}
+            if name in ab:
+                kernels[name].update({"algorithmic_GB": ab[name] / 1e9, "GBps": ab[name] / 1e9 / (ms / 1e3)})
         # dominant kernel = largest share of the step
-        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
+        dom = max(ab, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"] if k in kernels else 0.0)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):

@@ -39,6 +39,13 @@ SIGNATURES = {
     "hermnet_message_scatter_bwd": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), ctypes.c_int,
                                                    c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                                    c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "hermnet_ssilu_fwd": (ctypes.c_int, [c_fp, c_fp, ctypes.c_long, c_fp]),
+    "hermnet_ssilu_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_long, ctypes.c_long, c_fp]),
+    "hermnet_update_mid": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_update_out": (ctypes.c_int, [c_fp] * 8 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_update_out_bwd": (ctypes.c_int, [c_fp] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_update_mid_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_host_rbf_row": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                             ctypes.c_int, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp]),
 }

@@ -1,0 +1,259 @@
+// gfx950 elementwise / row-wise kernels of the node-level part of a HeteroVertexConv layer.
+// The dense contractions between them are library GEMMs; these kernels fuse everything else so
+// that a layer costs a fixed, small number of launches.  HBM-streaming, float4 per lane.
+//
+//   hermnet_ssilu_fwd / _bwd        ScaledSiLU                      /root/reference/HermNet/rmnet.py:110-117
+//   hermnet_update_mid  / _bwd      vec_dot, |vec2|, cat([x, |vec2|])   rmnet.py:95-100
+//   hermnet_update_out  / _bwd      dx, dvec, residual (+ zero rows)    rmnet.py:101-107, 29-31; hermnet.py:51,56-61
+#include <hip/hip_runtime.h>
+#include "../../include/hermnet_hip.h"
+
+namespace {
+
+constexpr float kInvSqrt2 = 0.70710678118654752f;
+constexpr float kSiluScale = 1.0f / 0.6f;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+
+// a[row, col] = silu(h) / 0.6 ; both [rows, cols] with row strides
+__global__ __launch_bounds__(256) void ssilu_fwd_kernel(const float* __restrict__ h, float* __restrict__ a, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = ld4(h + 4 * i);
+  float4 o;
+  o.x = v.x * sigmoidf_(v.x) * kSiluScale;
+  o.y = v.y * sigmoidf_(v.y) * kSiluScale;
+  o.z = v.z * sigmoidf_(v.z) * kSiluScale;
+  o.w = v.w * sigmoidf_(v.w) * kSiluScale;
+  st4(a + 4 * i, o);
+}
+
+__device__ __forceinline__ float dssilu(float x) {
+  const float s = sigmoidf_(x);
+  return s * (1.0f + x * (1.0f - s)) * kSiluScale;
+}
+
+// gh[n, t, c] = g[t?..] * d ssilu(h[n, t, c]);  g is addressed as g[n * gs_n + t * gs_t + c]
+// (gs_n = T*C, gs_t = C for the same layout as h; gs_n = C, gs_t = N*C for a [T,N,C] gradient).
+__global__ __launch_bounds__(256) void ssilu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ h,
+                                                        float* __restrict__ gh, int N, int T, int C,
+                                                        long gs_n, long gs_t) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index into h
+  const int c4n = C >> 2;
+  const long total = (long)N * T * c4n;
+  if (i >= total) return;
+  const int c4 = (int)(i % c4n);
+  const long nt = i / c4n;
+  const int t = (int)(nt % T);
+  const long n = nt / T;
+  const float4 hv = ld4(h + 4 * i);
+  const float4 gv = ld4(g + n * gs_n + t * gs_t + 4 * c4);
+  float4 o;
+  o.x = gv.x * dssilu(hv.x);
+  o.y = gv.y * dssilu(hv.y);
+  o.z = gv.z * dssilu(hv.z);
+  o.w = gv.w * dssilu(hv.w);
+  st4(gh + 4 * i, o);
+}
+
+// vp [N,3,2H] -> vdot [N,H], xin [N,2H] = [x1 | sqrt(sum_d v2^2 + 1e-8)]
+__global__ __launch_bounds__(256) void update_mid_kernel(const float* __restrict__ vp, const float* __restrict__ x1,
+                                                         float* __restrict__ vdot, float* __restrict__ xin,
+                                                         int rows, int H) {
+  const int h4n = H >> 2;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * h4n) return;
+  const int c = (int)(i % h4n) * 4;
+  const long r = i / h4n;
+  const float inv_sqrt_h = rsqrtf((float)H);
+  float4 dot = make_float4(0.f, 0.f, 0.f, 0.f), sq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float4 a = ld4(vp + (r * 3 + d) * 2 * H + c);
+    const float4 b = ld4(vp + (r * 3 + d) * 2 * H + H + c);
+    dot.x = fmaf(a.x, b.x, dot.x); dot.y = fmaf(a.y, b.y, dot.y); dot.z = fmaf(a.z, b.z, dot.z); dot.w = fmaf(a.w, b.w, dot.w);
+    sq.x = fmaf(b.x, b.x, sq.x); sq.y = fmaf(b.y, b.y, sq.y); sq.z = fmaf(b.z, b.z, sq.z); sq.w = fmaf(b.w, b.w, sq.w);
+  }
+  st4(vdot + r * H + c, make_float4(dot.x * inv_sqrt_h, dot.y * inv_sqrt_h, dot.z * inv_sqrt_h, dot.w * inv_sqrt_h));
+  st4(xin + r * 2 * H + c, ld4(x1 + r * H + c));
+  st4(xin + r * 2 * H + H + c,
+      make_float4(sqrtf(sq.x + 1e-8f), sqrtf(sq.y + 1e-8f), sqrtf(sq.z + 1e-8f), sqrtf(sq.w + 1e-8f)));
+}
+
+// x_out = x1 + (q1 + q2 vdot)/sqrt2 ; vec_out[d] = vec1[d] + q3 v1[d]; rows with m == 0 (or >= nk) are zero
+__global__ __launch_bounds__(256) void update_out_kernel(const float* __restrict__ q, const float* __restrict__ vdot,
+                                                         const float* __restrict__ vp, const float* __restrict__ x1,
+                                                         const float* __restrict__ vec1, const float* __restrict__ mask,
+                                                         float* __restrict__ xo, float* __restrict__ vo,
+                                                         int N, int nk, int H) {
+  const int h4n = H >> 2;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * h4n) return;
+  const int c = (int)(i % h4n) * 4;
+  const long r = i / h4n;
+  const bool on = r < nk && (mask == nullptr || mask[r] != 0.0f);
+  if (!on) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    st4(xo + r * H + c, z);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) st4(vo + (r * 3 + d) * H + c, z);
+    return;
+  }
+  const float4 q1 = ld4(q + r * 3 * H + c), q2 = ld4(q + r * 3 * H + H + c), q3 = ld4(q + r * 3 * H + 2 * H + c);
+  const float4 vd = ld4(vdot + r * H + c), xv = ld4(x1 + r * H + c);
+  st4(xo + r * H + c, make_float4(xv.x + (q1.x + q2.x * vd.x) * kInvSqrt2, xv.y + (q1.y + q2.y * vd.y) * kInvSqrt2,
+                                  xv.z + (q1.z + q2.z * vd.z) * kInvSqrt2, xv.w + (q1.w + q2.w * vd.w) * kInvSqrt2));
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float4 v1 = ld4(vp + (r * 3 + d) * 2 * H + c);
+    const float4 vv = ld4(vec1 + (r * 3 + d) * H + c);
+    st4(vo + (r * 3 + d) * H + c,
+        make_float4(fmaf(q3.x, v1.x, vv.x), fmaf(q3.y, v1.y, vv.y), fmaf(q3.z, v1.z, vv.z), fmaf(q3.w, v1.w, vv.w)));
+  }
+}
+
+// backward of update_out: gq [N,3H], gvdot [N,H], gvp[:, :, 0:H] (= gvo q3; the v2 half is written by
+// update_mid_bwd), gx1o [N,H] (= masked gxo), gv1o [N,3,H] (= masked gvo)
+__global__ __launch_bounds__(256) void update_out_bwd_kernel(
+    const float* __restrict__ gxo, const float* __restrict__ gvo, const float* __restrict__ q,
+    const float* __restrict__ vdot, const float* __restrict__ vp, const float* __restrict__ mask,
+    float* __restrict__ gq, float* __restrict__ gvdot, float* __restrict__ gvp, float* __restrict__ gx1o,
+    float* __restrict__ gv1o, int N, int nk, int H) {
+  const int h4n = H >> 2;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * h4n) return;
+  const int c = (int)(i % h4n) * 4;
+  const long r = i / h4n;
+  const bool on = r < nk && (mask == nullptr || mask[r] != 0.0f);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!on) {
+    st4(gx1o + r * H + c, z);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) st4(gv1o + (r * 3 + d) * H + c, z);
+    if (r < nk) {   // inactive relation: keep the GEMM inputs finite
+      st4(gq + r * 3 * H + c, z); st4(gq + r * 3 * H + H + c, z); st4(gq + r * 3 * H + 2 * H + c, z);
+      st4(gvdot + r * H + c, z);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) st4(gvp + (r * 3 + d) * 2 * H + c, z);
+    }
+    return;
+  }
+  const float4 gx = ld4(gxo + r * H + c);
+  const float4 q2 = ld4(q + r * 3 * H + H + c), q3 = ld4(q + r * 3 * H + 2 * H + c);
+  const float4 vd = ld4(vdot + r * H + c);
+  st4(gx1o + r * H + c, gx);
+  st4(gq + r * 3 * H + c, make_float4(gx.x * kInvSqrt2, gx.y * kInvSqrt2, gx.z * kInvSqrt2, gx.w * kInvSqrt2));
+  st4(gq + r * 3 * H + H + c, make_float4(gx.x * vd.x * kInvSqrt2, gx.y * vd.y * kInvSqrt2, gx.z * vd.z * kInvSqrt2,
+                                          gx.w * vd.w * kInvSqrt2));
+  st4(gvdot + r * H + c, make_float4(gx.x * q2.x * kInvSqrt2, gx.y * q2.y * kInvSqrt2, gx.z * q2.z * kInvSqrt2,
+                                     gx.w * q2.w * kInvSqrt2));
+  float4 g3 = z;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float4 gv = ld4(gvo + (r * 3 + d) * H + c);
+    const float4 v1 = ld4(vp + (r * 3 + d) * 2 * H + c);
+    g3.x = fmaf(gv.x, v1.x, g3.x); g3.y = fmaf(gv.y, v1.y, g3.y); g3.z = fmaf(gv.z, v1.z, g3.z); g3.w = fmaf(gv.w, v1.w, g3.w);
+    st4(gvp + (r * 3 + d) * 2 * H + c, make_float4(gv.x * q3.x, gv.y * q3.y, gv.z * q3.z, gv.w * q3.w));
+    st4(gv1o + (r * 3 + d) * H + c, gv);
+  }
+  st4(gq + r * 3 * H + 2 * H + c, g3);
+}
+
+// backward of update_mid: completes gvp [N,3,2H] and gx1 = gx1o + gxin[:, :H]
+__global__ __launch_bounds__(256) void update_mid_bwd_kernel(
+    const float* __restrict__ gvdot, const float* __restrict__ gxin, const float* __restrict__ vp,
+    const float* __restrict__ xin, float* __restrict__ gvp, float* __restrict__ gx1, int rows, int H) {
+  const int h4n = H >> 2;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * h4n) return;
+  const int c = (int)(i % h4n) * 4;
+  const long r = i / h4n;
+  const float s = rsqrtf((float)H);
+  const float4 gd = ld4(gvdot + r * H + c);
+  const float4 gn = ld4(gxin + r * 2 * H + H + c);
+  const float4 nr = ld4(xin + r * 2 * H + H + c);
+  const float4 gnn = make_float4(gn.x / nr.x, gn.y / nr.y, gn.z / nr.z, gn.w / nr.w);
+  const float4 ge = ld4(gxin + r * 2 * H + c);
+  const float4 g0 = ld4(gx1 + r * H + c);
+  st4(gx1 + r * H + c, make_float4(g0.x + ge.x, g0.y + ge.y, g0.z + ge.z, g0.w + ge.w));
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const long o = (r * 3 + d) * 2 * H + c;
+    const float4 v1 = ld4(vp + o), v2 = ld4(vp + o + H);
+    const float4 p = ld4(gvp + o);
+    st4(gvp + o, make_float4(fmaf(gd.x * s, v2.x, p.x), fmaf(gd.y * s, v2.y, p.y), fmaf(gd.z * s, v2.z, p.z),
+                             fmaf(gd.w * s, v2.w, p.w)));
+    st4(gvp + o + H, make_float4(fmaf(gd.x * s, v1.x, gnn.x * v2.x), fmaf(gd.y * s, v1.y, gnn.y * v2.y),
+                                 fmaf(gd.z * s, v1.z, gnn.z * v2.z), fmaf(gd.w * s, v1.w, gnn.w * v2.w)));
+  }
+}
+
+inline dim3 grid_for(long n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+#define HN_LAUNCH_END return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH
+
+}  // namespace
+
+extern "C" int hermnet_ssilu_fwd(const float* h, float* a, long numel, void* stream) {
+  if (numel < 0 || (numel & 3)) return HN_ERR_BAD_ARG;
+  if (numel == 0) return HN_OK;
+  if (!h || !a) return HN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ssilu_fwd_kernel, grid_for(numel / 4, 256), dim3(256), 0, (hipStream_t)stream, h, a, numel / 4);
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_ssilu_bwd(const float* g, const float* h, float* gh, int N, int T, int C,
+                                 long g_stride_n, long g_stride_t, void* stream) {
+  if (N < 0 || T <= 0 || C <= 0 || (C & 3) || (g_stride_n & 3) || (g_stride_t & 3)) return HN_ERR_BAD_ARG;
+  if (N == 0) return HN_OK;
+  if (!g || !h || !gh) return HN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ssilu_bwd_kernel, grid_for((long)N * T * (C / 4), 256), dim3(256), 0, (hipStream_t)stream,
+                     g, h, gh, N, T, C, g_stride_n, g_stride_t);
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_update_mid(const float* vp, const float* x1, float* vdot, float* xin, int rows, int hidden,
+                                  void* stream) {
+  if (rows < 0 || hidden <= 0 || (hidden & 3)) return HN_ERR_BAD_ARG;
+  if (rows == 0) return HN_OK;
+  if (!vp || !x1 || !vdot || !xin) return HN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(update_mid_kernel, grid_for((long)rows * (hidden / 4), 256), dim3(256), 0, (hipStream_t)stream,
+                     vp, x1, vdot, xin, rows, hidden);
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_update_out(const float* q, const float* vdot, const float* vp, const float* x1,
+                                  const float* vec1, const float* row_mask, float* x_out, float* vec_out,
+                                  int num_nodes, int num_known, int hidden, void* stream) {
+  if (num_nodes < 0 || hidden <= 0 || (hidden & 3) || num_known > num_nodes) return HN_ERR_BAD_ARG;
+  if (num_nodes == 0) return HN_OK;
+  if (!q || !vdot || !vp || !x1 || !vec1 || !x_out || !vec_out) return HN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(update_out_kernel, grid_for((long)num_nodes * (hidden / 4), 256), dim3(256), 0,
+                     (hipStream_t)stream, q, vdot, vp, x1, vec1, row_mask, x_out, vec_out, num_nodes, num_known, hidden);
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_update_out_bwd(const float* gx_out, const float* gvec_out, const float* q, const float* vdot,
+                                      const float* vp, const float* row_mask, float* gq, float* gvdot, float* gvp,
+                                      float* gx1, float* gvec1, int num_nodes, int num_known, int hidden,
+                                      void* stream) {
+  if (num_nodes < 0 || hidden <= 0 || (hidden & 3) || num_known > num_nodes) return HN_ERR_BAD_ARG;
+  if (num_nodes == 0) return HN_OK;
+  if (!gx_out || !gvec_out || !q || !vdot || !vp || !gq || !gvdot || !gvp || !gx1 || !gvec1) return HN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(update_out_bwd_kernel, grid_for((long)num_nodes * (hidden / 4), 256), dim3(256), 0,
+                     (hipStream_t)stream, gx_out, gvec_out, q, vdot, vp, row_mask, gq, gvdot, gvp, gx1, gvec1,
+                     num_nodes, num_known, hidden);
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_update_mid_bwd(const float* gvdot, const float* gxin, const float* vp, const float* xin,
+                                      float* gvp, float* gx1, int rows, int hidden, void* stream) {
+  if (rows < 0 || hidden <= 0 || (hidden & 3)) return HN_ERR_BAD_ARG;
+  if (rows == 0) return HN_OK;
+  if (!gvdot || !gxin || !vp || !xin || !gvp || !gx1) return HN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(update_mid_bwd_kernel, grid_for((long)rows * (hidden / 4), 256), dim3(256), 0,
+                     (hipStream_t)stream, gvdot, gxin, vp, xin, gvp, gx1, rows, hidden);
+  HN_LAUNCH_END;
+}

@@ -8,6 +8,9 @@ from torch import nn
 from .elements import atomic_numbers
 from .ops import EdgeGeometry
 from .relations import RelationalGraph
+import os
+
+from .layer import FusedRelationalLayer, LayerWeights
 from .rmnet import PaiNNModule, RadialBasis, ScaledSiLU, relational_layer
 
 
@@ -18,13 +21,21 @@ class HeteroVertexConv(nn.Module):
     def __init__(self, mods: Dict[str, nn.Module]):
         super().__init__()
         self.mods = nn.ModuleDict(mods)
+        self._weights = None
 
     def forward(self, data):
         """data must come from `HVNet.forward` (carries the relation-ordered graph)."""
         g = data.get("_hn_graph")
         if g is None:
             raise RuntimeError("HeteroVertexConv.forward needs a Data prepared by HVNet.forward")
-        data.x, data.vec = relational_layer(self.mods.values(), data.x, data.vec, data._hn_edge, g, data._hn_rbf)
+        if os.environ.get("HERMNET_FUSED_LAYER", "1") == "0":
+            # debugging path: same kernels for the edge part, node algebra through PyTorch autograd
+            data.x, data.vec = relational_layer(self.mods.values(), data.x, data.vec, data._hn_edge, g, data._hn_rbf)
+            return data
+        if self._weights is None:
+            self._weights = LayerWeights(self.mods.values())
+        data.x, data.vec = FusedRelationalLayer.apply(data.x, data.vec, data._hn_edge, g, data._hn_rbf,
+                                                      self._weights.refresh())
         return data
 
 

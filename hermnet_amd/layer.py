@@ -1,0 +1,165 @@
+"""One HeteroVertexConv layer (`HermNet/hermnet.py:37-65` + `rmnet.py:21-32`) as a single
+autograd node with a hand-written first-order backward.
+
+The launch sequence is fixed and short: LayerNorm, 2 GEMMs, the fused message kernel, and per
+relation three GEMMs joined by fused elementwise kernels (`csrc/node_kernels.hip`).  Parameters
+are treated as constants (energy/force evaluation; parameter gradients are not produced --
+training is out of scope).
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib, nodeops
+from .ops import _launch, _stream
+
+P = _lib.ptr
+
+
+class LayerWeights(object):
+    """Kernel-ready views of one HeteroVertexConv's parameters, rebuilt when they change."""
+
+    def __init__(self, mods):
+        self.mods = list(mods)
+        self.key = None
+
+    def _version_key(self):
+        return tuple((p.data_ptr(), p._version) for m in self.mods for p in m.parameters())
+
+    @torch.no_grad()
+    def refresh(self):
+        key = self._version_key()
+        if key == self.key:
+            return self
+        ml = [m.message_layer for m in self.mods]
+        ul = [m.update_layer for m in self.mods]
+        # LayerNorm affine folded into the first Linear: (n*g + b) W1^T + b1 = n (W1*g)^T + (W1 b + b1)
+        w1 = [m.x_proj[0].weight * m.x_layernorm.weight[None, :] for m in ml]
+        b1 = [m.x_proj[0].weight @ m.x_layernorm.bias + m.x_proj[0].bias for m in ml]
+        self.w1cat = torch.cat(w1, 0).contiguous()                                  # [T*H, H]
+        self.b1cat = torch.cat(b1, 0).contiguous()                                  # [T*H]
+        self.w2 = torch.stack([m.x_proj[2].weight for m in ml], 0).contiguous()     # [T, 3H, H]
+        self.w2t = self.w2.transpose(1, 2).contiguous()                             # [T, H, 3H]
+        self.b2 = torch.stack([m.x_proj[2].bias for m in ml], 0)[:, None, :].contiguous()   # [T,1,3H]
+        self.wt = torch.stack([m.rbf_proj.weight.t() for m in ml], 0).contiguous()  # [T, R, 3H]
+        self.brbf = torch.stack([m.rbf_proj.bias for m in ml], 0).contiguous()      # [T, 3H]
+        self.wv = [u.vec_proj.weight.contiguous() for u in ul]                      # [2H, H]
+        self.wvt = [w.t().contiguous() for w in self.wv]                            # [H, 2H]
+        self.wx0 = [u.xvec_proj[0].weight.contiguous() for u in ul]                 # [H, 2H]
+        self.wx0t = [w.t().contiguous() for w in self.wx0]
+        self.bx0 = [u.xvec_proj[0].bias for u in ul]
+        self.wx2 = [u.xvec_proj[2].weight.contiguous() for u in ul]                 # [3H, H]
+        self.wx2t = [w.t().contiguous() for w in self.wx2]
+        self.bx2 = [u.xvec_proj[2].bias for u in ul]
+        self.key = key
+        return self
+
+
+def _msg_fwd(graph, rbf, H, xh, vec, x, w, edge):
+    lib = _lib.load()
+    x1 = torch.empty_like(x)
+    vec1 = torch.empty(x.size(0), 3, H, dtype=x.dtype, device=x.device)
+    gs, rs = graph.as_struct(), rbf.struct()
+    _lib.check(_launch("message_scatter_fwd" + ("" if vec is not None else "_l0"),
+                       lambda: lib.hermnet_message_scatter_fwd(
+                           ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(vec), P(x), P(w.wt), P(w.brbf), P(edge),
+                           P(x1), P(vec1), _stream())), "hermnet_message_scatter_fwd")
+    return x1, vec1
+
+
+def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1):
+    lib = _lib.load()
+    gxh = torch.empty_like(xh)
+    gvec = None if vec is None else torch.empty_like(vec)
+    gx = torch.empty_like(gx1)
+    gedge = torch.zeros(H // 64, graph.E, 4, dtype=torch.float32, device=gx1.device)
+    gs, rs = graph.as_struct(), rbf.struct()
+    _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"),
+                       lambda: lib.hermnet_message_scatter_bwd(
+                           ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(vec), P(w.wt), P(w.brbf), P(edge),
+                           P(gx1), P(gvec1), P(gxh), P(gvec), P(gx), P(gedge), _stream())),
+               "hermnet_message_scatter_bwd")
+    return gxh, gvec, gx, gedge
+
+
+class FusedRelationalLayer(torch.autograd.Function):
+    """(x, vec, edge) -> (x_out, vec_out) for one layer, relation (row) order."""
+
+    @staticmethod
+    def forward(ctx, x, vec, edge, graph, rbf, w):
+        N, H = x.shape
+        T = graph.T
+        rp = graph.type_rowptr_host
+        nk = rp[-1]
+        x = x.contiguous()
+        vec = None if vec is None else vec.contiguous()
+        # --- node projection of every relation: xh[t] = x_proj_t(LayerNorm_t(x))  (rmnet.py:52)
+        n, mean, rstd = torch.native_layer_norm(x, [H], None, None, 1e-5)
+        h = torch.addmm(w.b1cat, n, w.w1cat.t())                                     # [N, T*H]
+        a = nodeops.ssilu_fwd(h)
+        xh = torch.baddbmm(w.b2, a.view(N, T, H).transpose(0, 1), w.w2t)             # [T, N, 3H]
+        # --- fused edge part + residual (rmnet.py:55-73, 24-26)
+        x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge)
+        # --- PaiNNUpdate on the rows of each relation (rmnet.py:94-107)
+        vp = torch.empty(N, 3, 2 * H, dtype=x.dtype, device=x.device)
+        for t in range(T):
+            lo, hi = rp[t], rp[t + 1]
+            if hi > lo:
+                torch.mm(vec1[lo:hi].view(-1, H), w.wvt[t], out=vp[lo:hi].view(-1, 2 * H))
+        vdot, xin = nodeops.update_mid(vp, x1, nk, H)
+        h2 = torch.empty(N, H, dtype=x.dtype, device=x.device)
+        for t in range(T):
+            lo, hi = rp[t], rp[t + 1]
+            if hi > lo:
+                torch.addmm(w.bx0[t], xin[lo:hi], w.wx0t[t], out=h2[lo:hi])
+        a2 = nodeops.ssilu_fwd(h2[:nk]) if nk > 0 else h2[:0]
+        q = torch.empty(N, 3 * H, dtype=x.dtype, device=x.device)
+        for t in range(T):
+            lo, hi = rp[t], rp[t + 1]
+            if hi > lo:
+                torch.addmm(w.bx2[t], a2[lo:hi], w.wx2t[t], out=q[lo:hi])
+        x_out, vec_out = nodeops.update_out(q, vdot, vp, x1, vec1, graph.row_active, N, nk, H)
+        ctx.save_for_backward(x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q)
+        ctx.graph, ctx.rbf, ctx.w = graph, rbf, w
+        return x_out, vec_out
+
+    @staticmethod
+    def backward(ctx, gxo, gvo):
+        x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q = ctx.saved_tensors
+        graph, rbf, w = ctx.graph, ctx.rbf, ctx.w
+        N, H = x.shape
+        T = graph.T
+        rp = graph.type_rowptr_host
+        nk = rp[-1]
+        gxo = gxo.contiguous()
+        gvo = gvo.contiguous()
+        gq, gvdot, gvp, gx1, gvec1 = nodeops.update_out_bwd(gxo, gvo, q, vdot, vp, graph.row_active, N, nk, H)
+        ga2 = torch.empty(N, H, dtype=x.dtype, device=x.device)
+        for t in range(T):
+            lo, hi = rp[t], rp[t + 1]
+            if hi > lo:
+                torch.mm(gq[lo:hi], w.wx2[t], out=ga2[lo:hi])
+        gh2 = nodeops.ssilu_bwd(ga2, h2, nk, 1, H, H, H) if nk > 0 else ga2[:0]
+        gxin = torch.empty(N, 2 * H, dtype=x.dtype, device=x.device)
+        for t in range(T):
+            lo, hi = rp[t], rp[t + 1]
+            if hi > lo:
+                torch.mm(gh2[lo:hi], w.wx0[t], out=gxin[lo:hi])
+        nodeops.update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, nk, H)
+        for t in range(T):
+            lo, hi = rp[t], rp[t + 1]
+            if hi > lo:
+                g = gvec1[lo:hi].view(-1, H)
+                torch.addmm(g, gvp[lo:hi].view(-1, 2 * H), w.wv[t], out=g)
+        gxh, gvec_in, gx_in, gedge = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1)
+        gx_total = None
+        if ctx.needs_input_grad[0]:
+            ga = torch.bmm(gxh, w.w2)                                                # [T, N, H]
+            gh = nodeops.ssilu_bwd(ga, h, N, T, H, H, N * H)                         # [N, T*H]
+            gn = torch.mm(gh, w.w1cat)                                               # [N, H]
+            gx_ln = torch.ops.aten.native_layer_norm_backward(gn, x, [H], mean, rstd, None, None,
+                                                              [True, False, False])[0]
+            gx_total = gx_in + gx_ln
+        ge = gedge[0] if gedge.size(0) == 1 else gedge.sum(0)
+        return gx_total, gvec_in, ge, None, None, None

@@ -1,0 +1,58 @@
+"""Thin Python wrappers (allocate outputs, pass pointers) around the node-level fused
+kernels of `csrc/node_kernels.hip`.  One call = one kernel launch on the current stream."""
+import ctypes
+
+import torch
+
+from . import _lib
+from .ops import _launch, _stream
+
+P = _lib.ptr
+
+
+def ssilu_fwd(h):
+    a = torch.empty_like(h)
+    _lib.check(_launch("ssilu_fwd", lambda: _lib.load().hermnet_ssilu_fwd(P(h), P(a), h.numel(), _stream())),
+               "hermnet_ssilu_fwd")
+    return a
+
+
+def ssilu_bwd(g, h, N, T, C, gs_n, gs_t):
+    gh = torch.empty(N, T * C, dtype=h.dtype, device=h.device)
+    _lib.check(_launch("ssilu_bwd", lambda: _lib.load().hermnet_ssilu_bwd(P(g), P(h), P(gh), N, T, C, gs_n, gs_t,
+                                                                          _stream())), "hermnet_ssilu_bwd")
+    return gh
+
+
+def update_mid(vp, x1, rows, H):
+    vdot = torch.empty(x1.size(0), H, dtype=x1.dtype, device=x1.device)
+    xin = torch.empty(x1.size(0), 2 * H, dtype=x1.dtype, device=x1.device)
+    _lib.check(_launch("update_mid", lambda: _lib.load().hermnet_update_mid(P(vp), P(x1), P(vdot), P(xin), rows, H,
+                                                                            _stream())), "hermnet_update_mid")
+    return vdot, xin
+
+
+def update_out(q, vdot, vp, x1, vec1, mask, N, nk, H):
+    xo = torch.empty(N, H, dtype=x1.dtype, device=x1.device)
+    vo = torch.empty(N, 3, H, dtype=x1.dtype, device=x1.device)
+    _lib.check(_launch("update_out", lambda: _lib.load().hermnet_update_out(
+        P(q), P(vdot), P(vp), P(x1), P(vec1), P(mask), P(xo), P(vo), N, nk, H, _stream())), "hermnet_update_out")
+    return xo, vo
+
+
+def update_out_bwd(gxo, gvo, q, vdot, vp, mask, N, nk, H):
+    dev, dt = gxo.device, gxo.dtype
+    gq = torch.empty(N, 3 * H, dtype=dt, device=dev)
+    gvdot = torch.empty(N, H, dtype=dt, device=dev)
+    gvp = torch.empty(N, 3, 2 * H, dtype=dt, device=dev)
+    gx1 = torch.empty(N, H, dtype=dt, device=dev)
+    gvec1 = torch.empty(N, 3, H, dtype=dt, device=dev)
+    _lib.check(_launch("update_out_bwd", lambda: _lib.load().hermnet_update_out_bwd(
+        P(gxo), P(gvo), P(q), P(vdot), P(vp), P(mask), P(gq), P(gvdot), P(gvp), P(gx1), P(gvec1), N, nk, H,
+        _stream())), "hermnet_update_out_bwd")
+    return gq, gvdot, gvp, gx1, gvec1
+
+
+def update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, rows, H):
+    _lib.check(_launch("update_mid_bwd", lambda: _lib.load().hermnet_update_mid_bwd(
+        P(gvdot), P(gxin), P(vp), P(xin), P(gvp), P(gx1), rows, H, _stream())), "hermnet_update_mid_bwd")

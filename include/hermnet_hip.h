@@ -113,6 +113,32 @@ int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc* rbf, int h
                                 const float* gx1, const float* gvec1,
                                 float* gxh, float* gvec, float* gx, float* gedge, void* stream);
 
+/* ---- node-level fused elementwise stages (A11/A12; the GEMMs between them are library calls) ----
+ * ScaledSiLU (rmnet.py:110-117): a = silu(h)/0.6 over `numel` contiguous floats (multiple of 4). */
+int hermnet_ssilu_fwd(const float* h, float* a, long numel, void* stream);
+/* gh[n,t,c] = g[n*g_stride_n + t*g_stride_t + c] * d ssilu(h[n,t,c]); h, gh contiguous [N,T,C]. */
+int hermnet_ssilu_bwd(const float* g, const float* h, float* gh, int N, int T, int C,
+                      long g_stride_n, long g_stride_t, void* stream);
+/* PaiNNUpdate middle (rmnet.py:95-100): vp [rows,3,2H] = vec_proj(vec1) ->
+ * vdot [rows,H] = sum_d v1 v2 / sqrt(H);  xin [rows,2H] = [x1 | sqrt(sum_d v2^2 + 1e-8)]. */
+int hermnet_update_mid(const float* vp, const float* x1, float* vdot, float* xin, int rows, int hidden,
+                       void* stream);
+/* PaiNNUpdate tail + residual (rmnet.py:101-107,29-31) + zero rows (hermnet.py:51,56-57):
+ * x_out = x1 + (q1 + q2 vdot)/sqrt2, vec_out[d] = vec1[d] + q3 v1[d]; rows >= num_known or with
+ * row_mask[r] == 0 (row_mask may be NULL) are written as zero without reading the other inputs. */
+int hermnet_update_out(const float* q, const float* vdot, const float* vp, const float* x1,
+                       const float* vec1, const float* row_mask, float* x_out, float* vec_out,
+                       int num_nodes, int num_known, int hidden, void* stream);
+/* Backward of hermnet_update_out: gq [N,3H], gvdot [N,H], the v1 half of gvp [N,3,2H], and the
+ * identity parts gx1 [N,H] / gvec1 [N,3,H] (masked copies of the incoming gradients). */
+int hermnet_update_out_bwd(const float* gx_out, const float* gvec_out, const float* q, const float* vdot,
+                           const float* vp, const float* row_mask, float* gq, float* gvdot, float* gvp,
+                           float* gx1, float* gvec1, int num_nodes, int num_known, int hidden, void* stream);
+/* Backward of hermnet_update_mid: completes gvp (both halves) from gvdot and gxin [rows,2H] and
+ * accumulates gxin[:, :H] into gx1. */
+int hermnet_update_mid_bwd(const float* gvdot, const float* gxin, const float* vp, const float* xin,
+                           float* gvp, float* gx1, int rows, int hidden, void* stream);
+
 /* Host-side (CPU) evaluation of the per-edge radial contraction exactly as the device code
  * computes it (banded 12-tap Gaussian window): rb[c] = b[c] + env(u) * sum_k W[c,k] g_k(u) and
  * its derivative d rb / d d.  Used by the CPU test-suite to check the banded formulation

@@ -61,3 +61,113 @@ def message_scatter_ref(xh, vec, x, edge, wt, brbf, graph, rbf):
     v0 = vec if vec is not None else torch.zeros_like(dv)
     vec1 = (v0 + dv) * rk[:, None, None]
     return x1, vec1
+
+
+# ---------------------------------------------------------------------------------------------
+# Plain-PyTorch versions of the node-level fused kernels (same contracts as hermnet_amd.nodeops)
+# and of the message kernels' forward/backward entry points used by hermnet_amd.layer.
+# ---------------------------------------------------------------------------------------------
+def ssilu_fwd(h):
+    return torch.nn.functional.silu(h) / 0.6
+
+
+def _dssilu(h):
+    s = torch.sigmoid(h)
+    return s * (1 + h * (1 - s)) / 0.6
+
+
+def ssilu_bwd(g, h, N, T, C, gs_n, gs_t):
+    gg = torch.as_strided(g, (N, T, C), (gs_n, gs_t, 1))
+    return (gg * _dssilu(h.reshape(-1)[:N * T * C].view(N, T, C))).reshape(N, T * C)
+
+
+def update_mid(vp, x1, rows, H):
+    v1, v2 = vp[..., :H], vp[..., H:]
+    vdot = torch.zeros(x1.size(0), H, dtype=x1.dtype)
+    xin = torch.zeros(x1.size(0), 2 * H, dtype=x1.dtype)
+    vdot[:rows] = (v1[:rows] * v2[:rows]).sum(1) / math.sqrt(H)
+    xin[:rows, :H] = x1[:rows]
+    xin[:rows, H:] = torch.sqrt((v2[:rows] ** 2).sum(1) + 1e-8)
+    return vdot, xin
+
+
+def _on(mask, N, nk):
+    on = torch.arange(N) < nk
+    if mask is not None:
+        on = on & (mask != 0)
+    return on
+
+
+def update_out(q, vdot, vp, x1, vec1, mask, N, nk, H):
+    on = _on(mask, N, nk)
+    q1, q2, q3 = q[:, :H], q[:, H:2 * H], q[:, 2 * H:]
+    xo = x1 + (q1 + q2 * vdot) / math.sqrt(2.0)
+    vo = vec1 + q3[:, None, :] * vp[..., :H]
+    z = torch.zeros(())
+    return torch.where(on[:, None], xo, z), torch.where(on[:, None, None], vo, z)
+
+
+def update_out_bwd(gxo, gvo, q, vdot, vp, mask, N, nk, H):
+    on = _on(mask, N, nk)
+    z = torch.zeros(())
+    gx = torch.where(on[:, None], gxo, z)
+    gv = torch.where(on[:, None, None], gvo, z)
+    q2, q3 = q[:, H:2 * H], q[:, 2 * H:]
+    s = 1 / math.sqrt(2.0)
+    gq = torch.cat([gx * s, gx * vdot * s, (gv * vp[..., :H]).sum(1)], 1)
+    gq = torch.where(on[:, None], gq, z)
+    gvdot = torch.where(on[:, None], gx * q2 * s, z)
+    gvp = torch.zeros(N, 3, 2 * H, dtype=gxo.dtype)
+    gvp[..., :H] = torch.where(on[:, None, None], gv * q3[:, None, :], z)
+    gvp[..., H:] = float("nan")          # the kernel leaves this half for update_mid_bwd
+    gvp[nk:] = float("nan")
+    return gq, gvdot, gvp, gx.clone(), gv.clone()
+
+
+def update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, rows, H):
+    s = 1 / math.sqrt(H)
+    v1, v2 = vp[:rows, :, :H], vp[:rows, :, H:]
+    gd = gvdot[:rows, None, :]
+    gnn = (gxin[:rows, H:] / xin[:rows, H:])[:, None, :]
+    gx1[:rows] += gxin[:rows, :H]
+    p = gvp[:rows, :, :H].clone()
+    gvp[:rows, :, :H] = p + gd * s * v2
+    gvp[:rows, :, H:] = gd * s * v1 + gnn * v2
+
+
+def msg_fwd(graph, rbf, H, xh, vec, x, w, edge):
+    return message_scatter_ref(xh, vec, x, edge, w.wt, w.brbf, graph, rbf)
+
+
+def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1):
+    """Backward contract of hermnet_message_scatter_bwd via autograd of the dense restatement;
+    the edge gradient is Cartesian (w.r.t. D = rhat * d)."""
+    with torch.enable_grad():
+        xh_ = xh.detach().requires_grad_(True)
+        x_ = torch.zeros(xh.size(1), H, dtype=xh.dtype).requires_grad_(True)
+        v_ = vec.detach().requires_grad_(True) if vec is not None else None
+        D = (edge[:, :3] * edge[:, 3:4]).detach().requires_grad_(True)
+        dn = D.norm(dim=-1)
+        e_ = torch.cat([D / dn[:, None], dn[:, None]], 1)
+        x1, vec1 = message_scatter_ref(xh_, v_, x_, e_, w.wt, w.brbf, graph, rbf)
+        ins = [xh_, x_, D] + ([v_] if vec is not None else [])
+        gr = torch.autograd.grad([x1, vec1], ins, [gx1, gvec1])
+    gedge = torch.cat([gr[2], torch.zeros(D.size(0), 1, dtype=D.dtype)], 1)[None]
+    return gr[0], (gr[3] if vec is not None else None), gr[1], gedge
+
+
+class RefEdgeGeometry(torch.autograd.Function):
+    """Same contract as hermnet_amd.ops.EdgeGeometry: the incoming gradient is Cartesian (dE/dD)."""
+
+    @staticmethod
+    def forward(ctx, pos, cell, graph):
+        ctx.graph = graph
+        return geometry_ref(pos.detach(), graph, cell)
+
+    @staticmethod
+    def backward(ctx, gedge):
+        g = ctx.graph
+        gp = torch.zeros(g.N, 3, dtype=gedge.dtype)
+        gp.index_add_(0, g.src_id.long(), gedge[:, :3])
+        gp.index_add_(0, g.tgt_id.long(), -gedge[:, :3])
+        return gp, None, None
