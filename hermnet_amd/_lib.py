@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhermnet_hip.so")
+LIB_PATH = os.environ.get("HERMNET_LIB_PATH") or os.path.join(_HERE, "csrc", "libhermnet_hip.so")
 
 HN_ENV = {"polynomial": 0, "exponential": 1}
 _ERR = {1: "HN_ERR_BAD_ARG (unsupported shape or null pointer)",

@@ -9,22 +9,26 @@
 //   residual                          rmnet.py:24-26     (epilogue, single write of x1 / vec1)
 //   in_subgraph                       utils.py:11-24     (replaced by the relation-ordered CSR/CSC)
 //
-// Mapping (wave = 64 lanes): a wave owns one target (fwd) or source (bwd) row; its two 32-lane
-// halves take alternate edges of the row's segment; a lane owns two adjacent channels (float2)
-// of a 64-channel column block, so a half-wave moves one 256-byte row segment per load and reads
-// the LDS weight tile with conflict-free ds_read_b64.  Halves are combined with one cross-half
-// exchange per row; nothing is accumulated in HBM.
+// Mapping (wave = 64 lanes).  A wave owns one target (fwd) or source (bwd) row at a time.  A lane
+// owns VW adjacent channels of a 64-channel column block, so 64/VW lanes cover the block and the
+// wave processes VW consecutive edges of the row's segment at once (VW = 2: two 32-lane halves,
+// VW = 4: four 16-lane quarters).  A lane group moves one 256-byte row segment per load and reads
+// the LDS weight tile with conflict-free ds_read_b64 / ds_read_b128.  Groups are combined once per
+// row; nothing is accumulated in HBM, there are no atomics, results are bit-reproducible.
+//
+// The kernels are VALU-issue bound (rocprofv3: VALU busy 56-72 %, LDS < 15 %), so the variants
+// trade registers (waves per SIMD) against per-edge instruction overhead; see DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../include/hermnet_hip.h"
 #include "hermnet_math.h"
 
-#define HN_WAVES 16                 // waves per workgroup (1024 threads, 4 per SIMD)
-#define HN_THREADS (HN_WAVES * 64)
 #define HN_LDS_ROW (3 * HN_CB)      // floats per tap row in LDS: [part][64]
-#ifndef HN_TAP_UNROLL
-#define HN_TAP_UNROLL 12
+// Phase fence for the instruction scheduler: without it hipcc hoists the LDS reads of all three
+// parts (and the next edges' loads) to the top of the iteration and spills.
+#ifndef HN_SB
+#define HN_SB __builtin_amdgcn_sched_barrier(0)
 #endif
 
 namespace {
@@ -62,41 +66,140 @@ struct MsgArgs {
   int rows_per_block;
 };
 
-__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
-__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+// ---- VW-wide per-lane vectors ------------------------------------------------------------------
+template <int VW> struct VecT;
+template <> struct VecT<2> { typedef float2 type; };
+template <> struct VecT<4> { typedef float4 type; };
 
-// Sum over the two 32-lane halves of the wave (lane l <-> l^32).
-__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+template <int VW>
+struct Vec {
+  float v[VW];
+  __device__ __forceinline__ static Vec zero() {
+    Vec r;
+#pragma unroll
+    for (int i = 0; i < VW; ++i) r.v[i] = 0.f;
+    return r;
+  }
+  __device__ __forceinline__ static Vec load(const float* p) {
+    typename VecT<VW>::type t = *reinterpret_cast<const typename VecT<VW>::type*>(p);
+    Vec r;
+    const float* f = reinterpret_cast<const float*>(&t);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) r.v[i] = f[i];
+    return r;
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    typename VecT<VW>::type t;
+    float* f = reinterpret_cast<float*>(&t);
+#pragma unroll
+    for (int i = 0; i < VW; ++i) f[i] = v[i];
+    *reinterpret_cast<typename VecT<VW>::type*>(p) = t;
+  }
+};
 
-// Sum over the 32 lanes of each half; every lane of the half ends with the total.
-__device__ __forceinline__ float half_allsum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 8, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 1, 64);
+template <int VW>
+__device__ __forceinline__ Vec<VW> v_fma(const Vec<VW>& a, const Vec<VW>& b, const Vec<VW>& c) {   // a * b + c
+  Vec<VW> r;
+#pragma unroll
+  for (int i = 0; i < VW; ++i) r.v[i] = fmaf(a.v[i], b.v[i], c.v[i]);
+  return r;
+}
+template <int VW>
+__device__ __forceinline__ Vec<VW> v_sfma(float s, const Vec<VW>& a, const Vec<VW>& c) {   // s * a + c
+  Vec<VW> r;
+#pragma unroll
+  for (int i = 0; i < VW; ++i) r.v[i] = fmaf(s, a.v[i], c.v[i]);
+  return r;
+}
+template <int VW>
+__device__ __forceinline__ Vec<VW> v_mul(const Vec<VW>& a, const Vec<VW>& b) {
+  Vec<VW> r;
+#pragma unroll
+  for (int i = 0; i < VW; ++i) r.v[i] = a.v[i] * b.v[i];
+  return r;
+}
+template <int VW>
+__device__ __forceinline__ Vec<VW> v_scale(const Vec<VW>& a, float s) {
+  Vec<VW> r;
+#pragma unroll
+  for (int i = 0; i < VW; ++i) r.v[i] = a.v[i] * s;
+  return r;
+}
+template <int VW>
+__device__ __forceinline__ Vec<VW> v_add(const Vec<VW>& a, const Vec<VW>& b) {
+  Vec<VW> r;
+#pragma unroll
+  for (int i = 0; i < VW; ++i) r.v[i] = a.v[i] + b.v[i];
+  return r;
+}
+template <int VW>
+__device__ __forceinline__ float v_hsum(const Vec<VW>& a) {
+  float s = a.v[0];
+#pragma unroll
+  for (int i = 1; i < VW; ++i) s += a.v[i];
+  return s;
+}
+
+// ---- cross-lane sums ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+// Sum over the VW lane groups of the wave (same channel, different edge slot); all lanes get the total.
+template <int VW>
+__device__ __forceinline__ float groups_sum1(float v) {
+  if (VW == 4) v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+template <int VW>
+__device__ __forceinline__ Vec<VW> groups_sum(Vec<VW> a) {
+#pragma unroll
+  for (int i = 0; i < VW; ++i) a.v[i] = groups_sum1<VW>(a.v[i]);
+  return a;
+}
+
+// Sum over the 64/VW lanes of each lane group (all channels of one edge); every lane gets its group's total.
+template <int VW>
+__device__ __forceinline__ float group_allsum(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
+  v += dpp_mov<0x141>(v);   // row_half_mirror      : other quad of the 8-lane group
+  v += dpp_mov<0x140>(v);   // row_mirror           : other half of the 16-lane DPP row
+  if (VW == 2) v += __shfl_xor(v, 16, 64);
   return v;
 }
 
-// Stage the zero-padded weight tile of (relation t, column block cb) and the tap centres into LDS.
+// ---- LDS staging ---------------------------------------------------------------------------------
+// Zero-padded weight tile of (relation t, column block cb) and the tap centres:
 //   wl[(k + HN_PAD) * 192 + part * 64 + c] = wt[t][k][part * H + cb * 64 + c]   (0 outside 0 <= k < R)
 //   mu[k + HN_PAD] = offset[clamp(k)]
 template <int NTHREADS>
 __device__ __forceinline__ void stage_weights(const MsgArgs& a, int t, int cb, float* wl, float* mu) {
   const int rows = a.R + 2 * HN_PAD + 1;
   const int n4 = rows * (HN_LDS_ROW / 4);
-  for (int idx = threadIdx.x; idx < n4; idx += NTHREADS) {
-    const int kk = idx / (HN_LDS_ROW / 4);
-    const int q = idx - kk * (HN_LDS_ROW / 4);
-    const int part = q >> 4;          // 16 float4 per 64-channel part
-    const int c4 = q & 15;
-    const int k = kk - HN_PAD;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k >= 0 && k < a.R) {
-      const float* src = a.wt + ((size_t)(t * a.R + k) * 3 * a.H + part * a.H + cb * HN_CB + c4 * 4);
-      v = *reinterpret_cast<const float4*>(src);
+  constexpr int INFLIGHT = 8;   // independent 16-byte loads per thread before the first LDS write
+  for (int base = threadIdx.x; base < n4; base += NTHREADS * INFLIGHT) {
+    float4 v[INFLIGHT];
+#pragma unroll
+    for (int q8 = 0; q8 < INFLIGHT; ++q8) {
+      const int idx = base + q8 * NTHREADS;
+      const int kk = idx / (HN_LDS_ROW / 4);
+      const int q = idx - kk * (HN_LDS_ROW / 4);
+      const int k = kk - HN_PAD;
+      v[q8] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < n4 && k >= 0 && k < a.R) {
+        // 16 float4 per 64-channel part: part = q >> 4, c4 = q & 15
+        v[q8] = *reinterpret_cast<const float4*>(
+            a.wt + ((size_t)(t * a.R + k) * 3 * a.H + (q >> 4) * a.H + cb * HN_CB + (q & 15) * 4));
+      }
     }
-    *reinterpret_cast<float4*>(wl + kk * HN_LDS_ROW + part * HN_CB + c4 * 4) = v;
+#pragma unroll
+    for (int q8 = 0; q8 < INFLIGHT; ++q8) {
+      const int idx = base + q8 * NTHREADS;
+      if (idx < n4) *reinterpret_cast<float4*>(wl + (size_t)idx * 4) = v[q8];   // LDS image is idx-linear
+    }
   }
   for (int kk = threadIdx.x; kk < rows; kk += NTHREADS) {
     int k = kk - HN_PAD;
@@ -105,30 +208,40 @@ __device__ __forceinline__ void stage_weights(const MsgArgs& a, int t, int cb, f
   }
 }
 
-// Banded contraction for one edge: S0[part] = sum_m g_m W[lo+m][part], and (WITH_DER)
-// S1[part] = sum_m g_m (u - mu_m) W[lo+m][part], g_m = exp(coeff (u - mu_m)^2)  (rmnet.py:156-172).
+// ---- radial basis ----------------------------------------------------------------------------------
+// Tap values of one edge: g[m] = exp(coeff (u - mu_m)^2), gd[m] = g[m] (u - mu_m), m = 0..11
+// (same fp32 operation order per tap as the reference, rmnet.py:156-172).
 template <bool WITH_DER>
-__device__ __forceinline__ void banded_rbf(const float* wl, const float* mu, int lo, float u, float coeff,
-                                           int hl, float2 (&S0)[3], float2 (&S1)[3]) {
-#pragma unroll
-  for (int p = 0; p < 3; ++p) { S0[p] = make_float2(0.f, 0.f); if (WITH_DER) S1[p] = make_float2(0.f, 0.f); }
-  const float* wrow = wl + (lo + HN_PAD) * HN_LDS_ROW + 2 * hl;
+__device__ __forceinline__ void rbf_taps(const float* mu, int lo, float u, float coeff,
+                                         float (&g)[HN_TAPS], float (&gd)[HN_TAPS]) {
   const float* mrow = mu + (lo + HN_PAD);
-#pragma unroll HN_TAP_UNROLL
-  for (int m = 0; m < HN_TAPS; ++m) {
-    const float diff = u - mrow[m];
-    const float g = __expf(coeff * (diff * diff));
-    const float gd = g * diff;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      const float2 w = ld2(wrow + m * HN_LDS_ROW + p * HN_CB);
-      S0[p].x = fmaf(g, w.x, S0[p].x);
-      S0[p].y = fmaf(g, w.y, S0[p].y);
-      if (WITH_DER) {
-        S1[p].x = fmaf(gd, w.x, S1[p].x);
-        S1[p].y = fmaf(gd, w.y, S1[p].y);
-      }
-    }
+  for (int m = 0; m < HN_TAPS; ++m) g[m] = mrow[m];
+#pragma unroll
+  for (int m = 0; m < HN_TAPS; ++m) {
+    const float diff = u - g[m];
+    g[m] = __expf(coeff * (diff * diff));
+    if (WITH_DER) gd[m] = g[m] * diff;
+  }
+}
+
+// Banded contraction of one part (s, a or b) for this lane's VW channels:
+//   S0 = sum_m g_m W[lo+m][part],  (WITH_DER) S1 = sum_m gd_m W[lo+m][part].
+// One conflict-free LDS read per tap, double buffered behind the FMAs of the previous tap.
+template <bool WITH_DER, int VW>
+__device__ __forceinline__ void rbf_part(const float* wcol, const float (&g)[HN_TAPS], const float (&gd)[HN_TAPS],
+                                         Vec<VW>& S0, Vec<VW>& S1) {
+  S0 = Vec<VW>::zero();
+  if (WITH_DER) S1 = Vec<VW>::zero();
+  Vec<VW> wa = Vec<VW>::load(wcol), wb;
+#pragma unroll
+  for (int m = 0; m < HN_TAPS; m += 2) {
+    wb = Vec<VW>::load(wcol + (m + 1) * HN_LDS_ROW);
+    S0 = v_sfma(g[m], wa, S0);
+    if (WITH_DER) S1 = v_sfma(gd[m], wa, S1);
+    if (m + 2 < HN_TAPS) wa = Vec<VW>::load(wcol + (m + 2) * HN_LDS_ROW);
+    S0 = v_sfma(g[m + 1], wb, S0);
+    if (WITH_DER) S1 = v_sfma(gd[m + 1], wb, S1);
   }
 }
 
@@ -152,11 +265,20 @@ __device__ __forceinline__ int decode_block(const MsgArgs& a, int bx, int& t, in
 // ------------------------------------------------------------------------------------------
 // Forward: one workgroup = (relation, column block, chunk of target rows).
 // ------------------------------------------------------------------------------------------
-template <bool HAS_VEC>
-__global__ __launch_bounds__(HN_THREADS, 4) void message_scatter_fwd_kernel(MsgArgs a) {
+template <bool HAS_VEC, int VW>
+struct FwdIn {
+  float4 g;        // (rx, ry, rz, d)
+  Vec<VW> xs, xa, xb;
+  Vec<VW> vj[3];
+  bool live;
+};
+
+template <bool HAS_VEC, int NW, int VW, bool PF>
+__global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(MsgArgs a) {
   extern __shared__ __align__(16) float lds[];
   float* wl = lds;
   float* mu = lds + (a.R + 2 * HN_PAD + 1) * HN_LDS_ROW;
+  constexpr int LPE = 64 / VW;   // lanes per edge
 
   const int cb = blockIdx.y;
   int t, r0, r1;
@@ -165,7 +287,7 @@ __global__ __launch_bounds__(HN_THREADS, 4) void message_scatter_fwd_kernel(MsgA
     // the first surplus block zeroes the rows of unknown-type atoms (they are never targets)
     if (surplus == 0) {
       const int c = cb * HN_CB + (threadIdx.x & 63);
-      for (int r = a.type_rowptr[a.T] + (int)(threadIdx.x >> 6); r < a.N; r += HN_WAVES) {
+      for (int r = a.type_rowptr[a.T] + (int)(threadIdx.x >> 6); r < a.N; r += NW) {
         a.x1[(size_t)r * a.H + c] = 0.f;
 #pragma unroll
         for (int d = 0; d < 3; ++d) a.vec1[((size_t)r * 3 + d) * a.H + c] = 0.f;
@@ -173,86 +295,109 @@ __global__ __launch_bounds__(HN_THREADS, 4) void message_scatter_fwd_kernel(MsgA
     }
     return;
   }
-  stage_weights<HN_THREADS>(a, t, cb, wl, mu);
+  stage_weights<NW * 64>(a, t, cb, wl, mu);
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int half = lane >> 5;
-  const int hl = lane & 31;
+  const int grp = lane / LPE;            // lane group = edge slot
+  const int gl = lane % LPE;
   const int H = a.H;
-  const int col = cb * HN_CB + 2 * hl;   // first of this lane's two channels
+  const int col = cb * HN_CB + VW * gl;  // first of this lane's VW channels
   const float inv_sqrt3h = 0.57735026918962576f * rsqrtf((float)H);  // (1/sqrt3)(1/sqrtH)
   const float inv_sqrth = rsqrtf((float)H);
   const float* xh_t = a.xh + (size_t)t * a.N * 3 * H;
 
-  float2 bias[3];
+  Vec<VW> bias[3];
 #pragma unroll
-  for (int p = 0; p < 3; ++p) bias[p] = ld2(a.brbf + (size_t)t * 3 * H + p * H + col);
+  for (int p = 0; p < 3; ++p) bias[p] = Vec<VW>::load(a.brbf + (size_t)t * 3 * H + p * H + col);
 
-  for (int r = r0 + wave; r < r1; r += HN_WAVES) {
+  for (int r = r0 + wave; r < r1; r += NW) {
     const int beg = a.csr_rowptr[r], end = a.csr_rowptr[r + 1];
-    float2 ax = make_float2(0.f, 0.f);
-    float2 av[3] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+    Vec<VW> ax = Vec<VW>::zero();
+    Vec<VW> av[3] = {Vec<VW>::zero(), Vec<VW>::zero(), Vec<VW>::zero()};
 
-    for (int e = beg + half; e < end; e += 2) {
-      const int j = a.csr_src[e];
-      const float4 g = a.edge[e];
-      const float* xr = xh_t + (size_t)j * 3 * H + col;
-      const float2 xs = ld2(xr), xa = ld2(xr + H), xb = ld2(xr + 2 * H);
-      float2 vj[3];
-      if (HAS_VEC) {
-        const float* vr = a.vec + (size_t)j * 3 * H + col;
+    for (int base = beg; base < end; base += 64) {
+      const int cnt = min(64, end - base);
+      // one coalesced index load per 64 edges; lane groups pick their entries with a lane shuffle
+      const int my_src = lane < cnt ? a.csr_src[base + lane] : 0;
+      const int nit = (cnt + VW - 1) / VW;
+
+      auto load_edges = [&](int it) {
+        FwdIn<HAS_VEC, VW> in;
+        const int idx = VW * it + grp;
+        const int j = __shfl(my_src, idx, 64);
+        in.live = idx < cnt;
+        in.g = a.edge[base + (in.live ? idx : 0)];
+        const float* xr = xh_t + (size_t)j * 3 * H + col;
+        // (masked at use, not here: touching the registers now would wait for the loads)
+        in.xs = Vec<VW>::load(xr); in.xa = Vec<VW>::load(xr + H); in.xb = Vec<VW>::load(xr + 2 * H);
+        if (HAS_VEC) {
+          const float* vr = a.vec + (size_t)j * 3 * H + col;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) vj[d] = ld2(vr + d * H);
-      }
-      const float u = g.w * a.inv_rc;
-      const HnEnv env = hn_envelope(u, a.env_kind, a.env_p);
-      const int lo = hn_window_lo(u, a.R);
-      float2 S0[3], S1[3];
-      banded_rbf<false>(wl, mu, lo, u, a.coeff, hl, S0, S1);
-      // rbfh = bias + env * S0 (rmnet.py:55); message (rmnet.py:61-67)
-      float2 rs, ra, rb;
-      rs.x = fmaf(env.val, S0[0].x, bias[0].x); rs.y = fmaf(env.val, S0[0].y, bias[0].y);
-      ra.x = fmaf(env.val, S0[1].x, bias[1].x); ra.y = fmaf(env.val, S0[1].y, bias[1].y);
-      rb.x = fmaf(env.val, S0[2].x, bias[2].x); rb.y = fmaf(env.val, S0[2].y, bias[2].y);
-      ax.x = fmaf(xs.x, rs.x, ax.x);
-      ax.y = fmaf(xs.y, rs.y, ax.y);
-      const float2 mb = make_float2(xb.x * rb.x * inv_sqrth, xb.y * rb.y * inv_sqrth);
-      const float rd[3] = {g.x, g.y, g.z};
-      if (HAS_VEC) {
-        const float2 ma = make_float2(xa.x * ra.x * inv_sqrt3h, xa.y * ra.y * inv_sqrt3h);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          av[d].x = fmaf(vj[d].x, ma.x, fmaf(mb.x, rd[d], av[d].x));
-          av[d].y = fmaf(vj[d].y, ma.y, fmaf(mb.y, rd[d], av[d].y));
+          for (int d = 0; d < 3; ++d) in.vj[d] = Vec<VW>::load(vr + d * H);
         }
-      } else {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          av[d].x = fmaf(mb.x, rd[d], av[d].x);
-          av[d].y = fmaf(mb.y, rd[d], av[d].y);
+        return in;
+      };
+
+      FwdIn<HAS_VEC, VW> cur = load_edges(0);
+      for (int it = 0; it < nit; ++it) {
+        FwdIn<HAS_VEC, VW> nxt;
+        if (PF) {
+          // prefetch the next VW edges (the last iteration re-loads its own: no branch, so the
+          // loads stay asynchronous until the register copy at the end of the iteration)
+          nxt = load_edges(min(it + 1, nit - 1));
+          __builtin_amdgcn_sched_barrier(0);
         }
+        const float u = cur.g.w * a.inv_rc;
+        const HnEnv env = hn_envelope(u, a.env_kind, a.env_p);
+        const int lo = hn_window_lo(u, a.R);
+        float g[HN_TAPS], gd[HN_TAPS];
+        rbf_taps<false>(mu, lo, u, a.coeff, g, gd);
+        HN_SB;
+        const float* wcol = wl + (lo + HN_PAD) * HN_LDS_ROW + VW * gl;
+        // padding slots (segment length not a multiple of VW) contribute nothing: every term is
+        // linear in rbfh = bias + env * S0 (rmnet.py:55), so scale it by 0 for them
+        const float lv = cur.live ? 1.0f : 0.0f;
+        const float ev = env.val * lv;
+        Vec<VW> S0, S1;
+        // message (rmnet.py:61-67), one part at a time to keep the register footprint small
+        rbf_part<false, VW>(wcol, g, gd, S0, S1);                               // part s -> dx
+        ax = v_fma(cur.xs, v_sfma(ev, S0, v_scale(bias[0], lv)), ax);
+        HN_SB;
+        rbf_part<false, VW>(wcol + 2 * HN_CB, g, gd, S0, S1);                   // part b -> rhat term of dvec
+        const Vec<VW> mb = v_scale(v_mul(cur.xb, v_sfma(ev, S0, v_scale(bias[2], lv))), inv_sqrth);
+        av[0] = v_sfma(cur.g.x, mb, av[0]);
+        av[1] = v_sfma(cur.g.y, mb, av[1]);
+        av[2] = v_sfma(cur.g.z, mb, av[2]);
+        HN_SB;
+        if (HAS_VEC) {
+          rbf_part<false, VW>(wcol + HN_CB, g, gd, S0, S1);                     // part a -> vec_j term of dvec
+          const Vec<VW> ma = v_scale(v_mul(cur.xa, v_sfma(ev, S0, v_scale(bias[1], lv))), inv_sqrt3h);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) av[d] = v_fma(cur.vj[d], ma, av[d]);
+        }
+        HN_SB;
+        if (PF) cur = nxt;
+        else if (it + 1 < nit) cur = load_edges(it + 1);
       }
     }
-    // combine the two halves, then residual epilogue (rmnet.py:24-26); half 0 writes x1 and
-    // vec1[0], half 1 writes vec1[1], vec1[2].
-    ax.x = xhalf_sum(ax.x); ax.y = xhalf_sum(ax.y);
+    // combine the lane groups, then the residual epilogue (rmnet.py:24-26).  The four output rows
+    // (x1, vec1[0..2]) are spread over the lane groups (256 B per group and row).
+    ax = groups_sum<VW>(ax);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { av[d].x = xhalf_sum(av[d].x); av[d].y = xhalf_sum(av[d].y); }
-    const size_t xo = (size_t)r * H + col;
-    const size_t vo = (size_t)r * 3 * H + col;
-    if (half == 0) {
-      const float2 x0 = ld2(a.x + xo);
-      st2(a.x1 + xo, make_float2((x0.x + ax.x) * 0.70710678118654752f, (x0.y + ax.y) * 0.70710678118654752f));
-      float2 v0 = make_float2(0.f, 0.f);
-      if (HAS_VEC) v0 = ld2(a.vec + vo);
-      st2(a.vec1 + vo, make_float2(v0.x + av[0].x, v0.y + av[0].y));
-    } else {
-      float2 v1 = make_float2(0.f, 0.f), v2 = make_float2(0.f, 0.f);
-      if (HAS_VEC) { v1 = ld2(a.vec + vo + H); v2 = ld2(a.vec + vo + 2 * H); }
-      st2(a.vec1 + vo + H, make_float2(v1.x + av[1].x, v1.y + av[1].y));
-      st2(a.vec1 + vo + 2 * H, make_float2(v2.x + av[2].x, v2.y + av[2].y));
+    for (int d = 0; d < 3; ++d) av[d] = groups_sum<VW>(av[d]);
+    for (int o = grp; o < 4; o += VW) {     // o = 0: x1, o = 1..3: vec1[o-1]
+      if (o == 0) {
+        const size_t xo = (size_t)r * H + col;
+        v_scale(v_add(Vec<VW>::load(a.x + xo), ax), 0.70710678118654752f).store(a.x1 + xo);
+      } else {
+        const size_t vo = ((size_t)r * 3 + (o - 1)) * H + col;
+        const Vec<VW> acc = o == 1 ? av[0] : (o == 2 ? av[1] : av[2]);
+        Vec<VW> v0 = Vec<VW>::zero();
+        if (HAS_VEC) v0 = Vec<VW>::load(a.vec + vo);
+        v_add(v0, acc).store(a.vec1 + vo);
+      }
     }
   }
 }
@@ -262,46 +407,34 @@ __global__ __launch_bounds__(HN_THREADS, 4) void message_scatter_fwd_kernel(MsgA
 // relations of the targets, restaging the weight tile per relation.  Sums keyed by the source row
 // stay in registers for the whole CSC segment: gxh[t][row] is written once per relation; gvec[row]
 // is written at t = 0 (with the residual's identity term) and read-modify-written by the same
-// lanes for t > 0.  Per-edge cross-lane sums (dE/dD, 3 floats) use DPP inside 16-lane rows.
+// lanes for t > 0.  The per-edge cross-lane sum (dE/dD, 3 floats over one lane group) is 4 DPP
+// steps (+ one cross-row exchange for VW = 2).
 // ------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-
-// Sum over the 32 lanes of each half-wave; every lane ends with its half's total.
-__device__ __forceinline__ float half_allsum_dpp(float v) {
-  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
-  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
-  v += dpp_mov<0x141>(v);   // row_half_mirror      : other quad of the 8-lane group
-  v += dpp_mov<0x140>(v);   // row_mirror           : other half of the 16-lane row
-  v += __shfl_xor(v, 16, 64);
-  return v;
-}
-
+template <int VW>
 struct BwdIn {
-  float4 g;       // (rx, ry, rz, d)
-  float2 gx1;     // d/dx1 of the target row
-  float2 gd[3];   // d/dvec1 of the target row
+  float4 g;         // (rx, ry, rz, d)
+  Vec<VW> gx1;      // d/dx1 of the target row
+  Vec<VW> gd[3];    // d/dvec1 of the target row
   int pos;
-  float lv;       // 1 for a live edge, 0 for the padding half of an odd segment
+  bool live;
 };
 
-template <bool HAS_VEC, int NW>
+template <bool HAS_VEC, int NW, int VW, bool PF>
 __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(MsgArgs a) {
   extern __shared__ __align__(16) float lds[];
   float* wl = lds;
   float* mu = lds + (a.R + 2 * HN_PAD + 1) * HN_LDS_ROW;
+  constexpr int LPE = 64 / VW;
 
   const int cb = blockIdx.y;
   const int r0 = blockIdx.x * a.rows_per_block;
   const int r1 = min(r0 + a.rows_per_block, a.N);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int half = lane >> 5;
-  const int hl = lane & 31;
+  const int grp = lane / LPE;
+  const int gl = lane % LPE;
   const int H = a.H;
-  const int col = cb * HN_CB + 2 * hl;
+  const int col = cb * HN_CB + VW * gl;
   const int nk = a.type_rowptr[a.T];     // rows below nk have a known type (are targets)
   const float inv_sqrt3h = 0.57735026918962576f * rsqrtf((float)H);
   const float inv_sqrth = rsqrtf((float)H);
@@ -314,122 +447,139 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
     __syncthreads();
     const float* xh_t = a.xh + (size_t)t * a.N * 3 * H;
     float* gxh_t = a.gxh + (size_t)t * a.N * 3 * H;
-    float2 bias[3];
+    Vec<VW> bias[3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) bias[p] = ld2(a.brbf + (size_t)t * 3 * H + p * H + col);
+    for (int p = 0; p < 3; ++p) bias[p] = Vec<VW>::load(a.brbf + (size_t)t * 3 * H + p * H + col);
 
     for (int r = r0 + wave; r < r1; r += NW) {
       const int beg = a.csc_rowptr[(size_t)t * a.N + r], end = a.csc_rowptr[(size_t)t * a.N + r + 1];
       const float* xr = xh_t + (size_t)r * 3 * H + col;
-      const float2 xs = ld2(xr), xa = ld2(xr + H), xb = ld2(xr + 2 * H);
-      float2 vj[3] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+      const Vec<VW> xs = Vec<VW>::load(xr), xa = Vec<VW>::load(xr + H), xb = Vec<VW>::load(xr + 2 * H);
+      Vec<VW> vj[3] = {Vec<VW>::zero(), Vec<VW>::zero(), Vec<VW>::zero()};
       if (HAS_VEC) {
         const float* vr = a.vec + (size_t)r * 3 * H + col;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) vj[d] = ld2(vr + d * H);
+        for (int d = 0; d < 3; ++d) vj[d] = Vec<VW>::load(vr + d * H);
       }
-      float2 gs = make_float2(0.f, 0.f), ga = make_float2(0.f, 0.f), gb = make_float2(0.f, 0.f);
-      float2 gv[3] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+      Vec<VW> gs = Vec<VW>::zero(), ga = Vec<VW>::zero(), gb = Vec<VW>::zero();
+      Vec<VW> gv[3] = {Vec<VW>::zero(), Vec<VW>::zero(), Vec<VW>::zero()};
 
       for (int base = beg; base < end; base += 64) {
         const int cnt = min(64, end - base);
-        // one coalesced index load per 64 edges; pairs pick their entries with a lane shuffle
         const int my_tgt = lane < cnt ? a.csc_tgt[base + lane] : 0;
         const int my_pos = lane < cnt ? a.csc_pos[base + lane] : 0;
-        const int npair = (cnt + 1) >> 1;
+        const int nit = (cnt + VW - 1) / VW;
 
-        auto load_pair = [&](int it) {
-          BwdIn in;
-          const int idx = 2 * it + half;
+        auto load_edges = [&](int it) {
+          BwdIn<VW> in;
+          const int idx = VW * it + grp;
           const int i = __shfl(my_tgt, idx, 64);
           in.pos = __shfl(my_pos, idx, 64);
-          in.lv = idx < cnt ? 1.0f : 0.0f;
+          in.live = idx < cnt;
           in.g = a.edge[in.pos];
-          in.gx1 = ld2(a.gx1 + (size_t)i * H + col);
+          in.gx1 = Vec<VW>::load(a.gx1 + (size_t)i * H + col);
           const float* gvr = a.gvec1 + (size_t)i * 3 * H + col;
 #pragma unroll
-          for (int d = 0; d < 3; ++d) in.gd[d] = ld2(gvr + d * H);
-          return in;
+          for (int d = 0; d < 3; ++d) in.gd[d] = Vec<VW>::load(gvr + d * H);
+          return in;   // padding slots are masked at use
         };
 
-        BwdIn cur = load_pair(0);
-        for (int it = 0; it < npair; ++it) {
-          BwdIn nxt = cur;
-          if (it + 1 < npair) nxt = load_pair(it + 1);   // wave-uniform: prefetch the next pair
-
+        BwdIn<VW> cur = load_edges(0);
+        for (int it = 0; it < nit; ++it) {
+          BwdIn<VW> nxt;
+          if (PF) {
+            nxt = load_edges(min(it + 1, nit - 1));   // unconditional prefetch, see the forward kernel
+            __builtin_amdgcn_sched_barrier(0);
+          }
           const float4 g = cur.g;
           const float u = g.w * a.inv_rc;
           const HnEnv env = hn_envelope(u, a.env_kind, a.env_p);
           const int lo = hn_window_lo(u, a.R);
-          float2 S0[3], S1[3];
-          banded_rbf<true>(wl, mu, lo, u, a.coeff, hl, S0, S1);
-          const float lv = cur.lv;
+          float g_[HN_TAPS], gd_[HN_TAPS];
+          rbf_taps<true>(mu, lo, u, a.coeff, g_, gd_);
+          HN_SB;
+          const float* wcol = wl + (lo + HN_PAD) * HN_LDS_ROW + VW * gl;
           // d rbfh / d d = inv_rc * (env' S0 + env * 2 coeff S1)
           const float c0 = a.inv_rc * env.der, c1 = a.inv_rc * env.val * 2.0f * a.coeff;
           const float rd[3] = {g.x, g.y, g.z};
-          float pd = 0.f;                    // partial dE/dd over this lane's channels
-          float pr[3] = {0.f, 0.f, 0.f};     // partial dE/d rhat
-#define HN_BWD_CH(C)                                                                         \
-          {                                                                                  \
-            const float rs = fmaf(env.val, S0[0].C, bias[0].C);                              \
-            const float ra = fmaf(env.val, S0[1].C, bias[1].C);                              \
-            const float rb = fmaf(env.val, S0[2].C, bias[2].C);                              \
-            const float drs = fmaf(c0, S0[0].C, c1 * S1[0].C);                               \
-            const float dra = fmaf(c0, S0[1].C, c1 * S1[1].C);                               \
-            const float drb = fmaf(c0, S0[2].C, c1 * S1[2].C);                               \
-            const float gdx = cur.gx1.C * inv_sqrt2 * lv;                                    \
-            const float g0 = cur.gd[0].C * lv, g1 = cur.gd[1].C * lv, g2 = cur.gd[2].C * lv; \
-            const float A = (g0 * vj[0].C + g1 * vj[1].C + g2 * vj[2].C) * inv_sqrt3h;       \
-            const float B = (g0 * rd[0] + g1 * rd[1] + g2 * rd[2]) * inv_sqrth;              \
-            gs.C = fmaf(gdx, rs, gs.C);                                                      \
-            ga.C = fmaf(A, ra, ga.C);                                                        \
-            gb.C = fmaf(B, rb, gb.C);                                                        \
-            const float w = xa.C * ra * inv_sqrt3h;                                          \
-            gv[0].C = fmaf(g0, w, gv[0].C);                                                  \
-            gv[1].C = fmaf(g1, w, gv[1].C);                                                  \
-            gv[2].C = fmaf(g2, w, gv[2].C);                                                  \
-            pd += gdx * xs.C * drs + A * xa.C * dra + B * xb.C * drb;                        \
-            const float q = xb.C * rb * inv_sqrth;                                           \
-            pr[0] = fmaf(g0, q, pr[0]); pr[1] = fmaf(g1, q, pr[1]); pr[2] = fmaf(g2, q, pr[2]); \
+          // padding slots: every term is linear in (gx1, gvec1), so scale those by 0
+          const float lv = cur.live ? 1.0f : 0.0f;
+          const Vec<VW> gdx = v_scale(cur.gx1, lv * inv_sqrt2);
+          const Vec<VW> g0 = v_scale(cur.gd[0], lv), g1 = v_scale(cur.gd[1], lv), g2 = v_scale(cur.gd[2], lv);
+          Vec<VW> pdv;                       // partial dE/dd per channel
+          Vec<VW> S0, S1;
+          // ---- part s: dx = sum xs * rs
+          rbf_part<true, VW>(wcol, g_, gd_, S0, S1);
+          {
+            const Vec<VW> rs = v_sfma(env.val, S0, bias[0]);
+            const Vec<VW> drs = v_sfma(c0, S0, v_scale(S1, c1));
+            gs = v_fma(gdx, rs, gs);
+            pdv = v_mul(v_mul(gdx, xs), drs);
           }
-          HN_BWD_CH(x)
-          HN_BWD_CH(y)
-#undef HN_BWD_CH
+          HN_SB;
+          // ---- part a: dvec += vec_j * (xa * ra) / sqrt(3H)
+          if (HAS_VEC) {
+            rbf_part<true, VW>(wcol + HN_CB, g_, gd_, S0, S1);
+            const Vec<VW> ra = v_sfma(env.val, S0, bias[1]);
+            const Vec<VW> dra = v_sfma(c0, S0, v_scale(S1, c1));
+            const Vec<VW> A = v_scale(v_fma(g0, vj[0], v_fma(g1, vj[1], v_mul(g2, vj[2]))), inv_sqrt3h);
+            ga = v_fma(A, ra, ga);
+            const Vec<VW> w = v_scale(v_mul(xa, ra), inv_sqrt3h);
+            gv[0] = v_fma(g0, w, gv[0]);
+            gv[1] = v_fma(g1, w, gv[1]);
+            gv[2] = v_fma(g2, w, gv[2]);
+            pdv = v_fma(v_mul(A, xa), dra, pdv);
+          }
+          HN_SB;
+          // ---- part b: dvec += rhat * (xb * rb) / sqrt(H)
+          Vec<VW> q;
+          {
+            rbf_part<true, VW>(wcol + 2 * HN_CB, g_, gd_, S0, S1);
+            const Vec<VW> rb = v_sfma(env.val, S0, bias[2]);
+            const Vec<VW> drb = v_sfma(c0, S0, v_scale(S1, c1));
+            const Vec<VW> B = v_scale(v_sfma(rd[0], g0, v_sfma(rd[1], g1, v_scale(g2, rd[2]))), inv_sqrth);
+            gb = v_fma(B, rb, gb);
+            pdv = v_fma(v_mul(B, xb), drb, pdv);
+            q = v_scale(v_mul(xb, rb), inv_sqrth);
+          }
+          HN_SB;
+          const float pd = v_hsum(pdv);
+          const float pr[3] = {v_hsum(v_mul(g0, q)), v_hsum(v_mul(g1, q)), v_hsum(v_mul(g2, q))};   // dE/d rhat
           // Cartesian gradient w.r.t. D (d = |D|, rhat = D/d): gD = pd rhat + (pr - (pr.rhat) rhat)/d
           const float dotp = pr[0] * rd[0] + pr[1] * rd[1] + pr[2] * rd[2];
           const float invd = 1.0f / g.w;
           float gD[3];
 #pragma unroll
-          for (int d = 0; d < 3; ++d) gD[d] = half_allsum_dpp(fmaf(pd - dotp * invd, rd[d], pr[d] * invd));
-          if (lv != 0.0f && hl == 0) gedge[cur.pos] = make_float4(gD[0], gD[1], gD[2], 0.f);
-          cur = nxt;
+          for (int d = 0; d < 3; ++d) gD[d] = group_allsum<VW>(fmaf(pd - dotp * invd, rd[d], pr[d] * invd));
+          if (cur.live && gl == 0) gedge[cur.pos] = make_float4(gD[0], gD[1], gD[2], 0.f);
+          HN_SB;
+          if (PF) cur = nxt;
+          else if (it + 1 < nit) cur = load_edges(it + 1);
         }
       }
-      // combine halves; half 0 stores this relation's gxh row, gvec/gx are split over both halves
-      gs.x = xhalf_sum(gs.x); gs.y = xhalf_sum(gs.y);
-      ga.x = xhalf_sum(ga.x); ga.y = xhalf_sum(ga.y);
-      gb.x = xhalf_sum(gb.x); gb.y = xhalf_sum(gb.y);
-      if (half == 0) {
-        float* go = gxh_t + (size_t)r * 3 * H + col;
-        st2(go, gs); st2(go + H, ga); st2(go + 2 * H, gb);
-      }
+      // combine lane groups; the output rows (gxh s/a/b, gx | gvec[0..2]) are spread over the groups
+      gs = groups_sum<VW>(gs); ga = groups_sum<VW>(ga); gb = groups_sum<VW>(gb);
       const bool known = r < nk;
-      if (t == 0 && half == 0) {   // residual identity: gx = gx1 / sqrt2 on rows that are targets
-        const float2 g1 = known ? ld2(a.gx1 + (size_t)r * H + col) : make_float2(0.f, 0.f);
-        st2(a.gx + (size_t)r * H + col, make_float2(g1.x * inv_sqrt2, g1.y * inv_sqrt2));
+      if (grp == 0) {
+        float* go = gxh_t + (size_t)r * 3 * H + col;
+        gs.store(go); ga.store(go + H); gb.store(go + 2 * H);
+        if (t == 0) {   // residual identity: gx = gx1 / sqrt2 on rows that are targets
+          const Vec<VW> g1 = known ? Vec<VW>::load(a.gx1 + (size_t)r * H + col) : Vec<VW>::zero();
+          v_scale(g1, inv_sqrt2).store(a.gx + (size_t)r * H + col);
+        }
       }
       if (HAS_VEC) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { gv[d].x = xhalf_sum(gv[d].x); gv[d].y = xhalf_sum(gv[d].y); }
-        const size_t vo = (size_t)r * 3 * H + col;
-        // component 0 by half 0, components 1 and 2 by half 1
-        const int d_lo = half == 0 ? 0 : 1, d_hi = half == 0 ? 1 : 3;
-        for (int d = d_lo; d < d_hi; ++d) {
-          float2 prev;
-          if (t == 0) prev = known ? ld2(a.gvec1 + vo + d * H) : make_float2(0.f, 0.f);
-          else prev = ld2(a.gvec + vo + d * H);
-          const float2 add = d == 0 ? gv[0] : (d == 1 ? gv[1] : gv[2]);
-          st2(a.gvec + vo + d * H, make_float2(prev.x + add.x, prev.y + add.y));
+        for (int d = 0; d < 3; ++d) gv[d] = groups_sum<VW>(gv[d]);
+        // gvec[d] handled by lane group (d + 1) % VW  (VW = 4: groups 1,2,3; VW = 2: groups 1,0,1)
+        for (int d = 0; d < 3; ++d) {
+          if (((d + 1) % VW) != grp) continue;
+          const size_t vo = ((size_t)r * 3 + d) * H + col;
+          Vec<VW> prev;
+          if (t == 0) prev = known ? Vec<VW>::load(a.gvec1 + vo) : Vec<VW>::zero();
+          else prev = Vec<VW>::load(a.gvec + vo);
+          const Vec<VW> add = d == 0 ? gv[0] : (d == 1 ? gv[1] : gv[2]);
+          v_add(prev, add).store(a.gvec + vo);
         }
       }
     }
@@ -448,12 +598,11 @@ int fill_args(const hn_graph* g, const hn_rbf_desc* rbf, int hidden, MsgArgs& a)
   return HN_OK;
 }
 
-// tuning knobs (environment, read once): HERMNET_BWD_WAVES = 8|16, HERMNET_ROWS_PER_BLOCK
+// tuning knobs (environment, read once); variant = waves per workgroup * 100 + VW * 10 + prefetch
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
-int bwd_waves() { int w = env_int("HERMNET_BWD_WAVES", 8); return w == 16 ? 16 : 8; }
 
 int num_cus() {
   static int n = 0;
@@ -486,6 +635,32 @@ size_t lds_bytes(int R) {
   return (size_t)(R + 2 * HN_PAD + 1) * (HN_LDS_ROW + 1) * sizeof(float);
 }
 
+typedef void (*kern_t)(MsgArgs);
+
+template <bool HAS_VEC>
+kern_t pick_fwd(int variant, int& nw) {
+  switch (variant) {
+    case 1621: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, true>;
+    case 820:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 2, false>;
+    case 821:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 2, true>;
+    case 840:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, false>;
+    case 841:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, true>;
+    default:   nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, false>;   // 1620
+  }
+}
+
+template <bool HAS_VEC>
+kern_t pick_bwd(int variant, int& nw) {
+  switch (variant) {
+    case 1621: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, true>;
+    case 820:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 2, false>;
+    case 821:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 2, true>;
+    case 840:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 4, false>;
+    case 841:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 4, true>;
+    default:   nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, false>;   // 1620
+  }
+}
+
 }  // namespace
 
 extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc* rbf, int hidden,
@@ -501,16 +676,21 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   a.edge = reinterpret_cast<const float4*>(edge);
   a.x1 = x1; a.vec1 = vec1;
   static const int rpb_fwd = env_int("HERMNET_FWD_ROWS", 0);
+  // defaults from tools/kbench.py on MI355X (config 2): see DESIGN.md "Kernel variants"
+  static const int variant_vec = env_int("HERMNET_FWD_VARIANT", 841);
+  static const int variant_l0 = env_int("HERMNET_FWD_VARIANT_L0", 840);
+  const int variant = vec ? variant_vec : variant_l0;
   a.rows_per_block = pick_rows(a.N, hidden / HN_CB, a.T * (hidden / HN_CB), rpb_fwd);
   const size_t lds = lds_bytes(a.R);
   if (lds > 160 * 1024) return HN_ERR_LDS;
   // blocks: sum_t ceil(N_t / rpb) <= N / rpb + T, plus one surplus block that zeroes unknown rows
   dim3 grid((unsigned)(a.N / a.rows_per_block + a.T + 1), (unsigned)(hidden / HN_CB));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  auto k = vec ? message_scatter_fwd_kernel<true> : message_scatter_fwd_kernel<false>;
+  int nw = 16;
+  kern_t k = vec ? pick_fwd<true>(variant, nw) : pick_fwd<false>(variant, nw);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess) return HN_ERR_LDS;
-  hipLaunchKernelGGL(k, grid, dim3(HN_THREADS), lds, s, a);
+  hipLaunchKernelGGL(k, grid, dim3(nw * 64), lds, s, a);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
 
@@ -532,15 +712,16 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   a.gx1 = gx1; a.gvec1 = gvec1; a.gxh = gxh; a.gvec = gvec; a.gx = gx;
   a.gedge = reinterpret_cast<float4*>(gedge);
   static const int rpb_bwd = env_int("HERMNET_BWD_ROWS", 0);
+  static const int variant_vec = env_int("HERMNET_BWD_VARIANT", 821);
+  static const int variant_l0 = env_int("HERMNET_BWD_VARIANT_L0", 840);
+  const int variant = vec ? variant_vec : variant_l0;
   a.rows_per_block = pick_rows(a.N, hidden / HN_CB, 0, rpb_bwd);
   const size_t lds = lds_bytes(a.R);
   if (lds > 160 * 1024) return HN_ERR_LDS;
   dim3 grid((unsigned)((a.N + a.rows_per_block - 1) / a.rows_per_block), (unsigned)(hidden / HN_CB));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  static const int nw = bwd_waves();
-  void (*k)(MsgArgs);
-  if (nw == 8) k = vec ? message_scatter_bwd_kernel<true, 8> : message_scatter_bwd_kernel<false, 8>;
-  else k = vec ? message_scatter_bwd_kernel<true, 16> : message_scatter_bwd_kernel<false, 16>;
+  int nw = 16;
+  kern_t k = vec ? pick_bwd<true>(variant, nw) : pick_bwd<false>(variant, nw);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess) return HN_ERR_LDS;
   hipLaunchKernelGGL(k, grid, dim3(nw * 64), lds, s, a);
