@@ -8,6 +8,7 @@ from torch import nn
 from .elements import atomic_numbers
 from .ops import EdgeGeometry
 from .relations import RelationalGraph
+from .sharding import HaloExchange, SumAcrossRanks
 import os
 
 from .layer import FusedRelationalLayer, LayerWeights
@@ -85,21 +86,48 @@ class HVNet(nn.Module):
             # the reference fails here (scatter(..., None), hermnet.py:130); a single graph is meant
             data.batch = torch.zeros(pos.size(0), dtype=torch.long, device=pos.device)
         zl = [atomic_numbers[el] for el in self.elems]
+        # atom-sharded evaluation (hermnet_amd/sharding.py): this rank's atoms + one-hop halo
+        shard = data.get("_hn_shard")
+        rel_active = None if shard is None else [z in shard.z_with_in_edges for z in zl]
         graph = RelationalGraph.build(data.atomic_number, data.edge_index, zl,
                                       edge_shift=data.get("edge_shift") if data.get("cell") is not None else None,
-                                      batch=data.batch)
+                                      batch=data.batch, rel_active=rel_active)
         rbf = self.radial_basis.descriptor()
+        row_plan = None
+        if shard is not None:
+            if shard.owned_mask.device != pos.device:
+                shard.to(pos.device)
+            pos = HaloExchange.apply(pos, shard.atom_plan)                  # halo coordinates from their owners
+            row_plan = shard.atom_plan.remap(graph.row_of_node)
         edge = EdgeGeometry.apply(pos, data.get("cell"), graph)          # with_edge, hermnet.py:133-152
 
         x = self.embed(data.atomic_number.long()[graph.node_order])        # hermnet.py:123, row order
         vec = None                                                          # zeros, hermnet.py:124
         data._hn_graph, data._hn_edge, data._hn_rbf = graph, edge, rbf
         data.x, data.vec = x, vec
-        for conv in self.hermconvs:
+        for li, conv in enumerate(self.hermconvs):
             data = conv(data)
+            if row_plan is not None and li + 1 < len(self.hermconvs):
+                # one exchange per layer: (x | vec) rows of halo atoms, 4H floats each
+                n = data.x.size(0)
+                packed = torch.cat([data.x, data.vec.reshape(n, -1)], dim=1)
+                packed = HaloExchange.apply(packed, row_plan)
+                H = self.hidden_channels
+                data.x, data.vec = packed[:, :H], packed[:, H:].reshape(n, 3, H)
         x = data.x
 
         per_atom_energy = self.out_energy(x).squeeze(1)                     # hermnet.py:129
+        if shard is not None:
+            owned_rows = shard.owned_mask[graph.node_order]
+            e_own = per_atom_energy * owned_rows.to(per_atom_energy.dtype)
+            energy = torch.zeros(shard.num_graphs, dtype=e_own.dtype, device=x.device).index_add(0, graph.batch_rows, e_own)
+            energy = SumAcrossRanks.apply(energy, shard.group)
+            if self.intensive:
+                cnt = torch.zeros(shard.num_graphs, dtype=e_own.dtype, device=x.device).index_add(
+                    0, graph.batch_rows, owned_rows.to(e_own.dtype))
+                dist_cnt = SumAcrossRanks.apply(cnt, shard.group)
+                energy = energy / dist_cnt.clamp(min=1)
+            return energy
         # scatter(per_atom_energy, batch, reduce=sum|mean) (hermnet.py:130) as an ordered segment
         # reduction: no atomics, so the energy is bit-reproducible run to run
         if graph.num_graphs == 1:

@@ -20,7 +20,7 @@ class RelationalGraph(object):
                  "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device")
 
     @staticmethod
-    def build(atomic_number, edge_index, z_list, edge_shift=None, batch=None):
+    def build(atomic_number, edge_index, z_list, edge_shift=None, batch=None, rel_active=None):
         """atomic_number [N] int, edge_index [2,E] int (row 0 = source, row 1 = target,
         `hermnet.py:135`), z_list: atomic numbers of the model's elements in module order."""
         g = RelationalGraph()
@@ -70,10 +70,11 @@ class RelationalGraph(object):
         g.num_graphs = int(host[-1])
         # hermnet.py:56-57: a relation without edges is skipped -> its rows stay zero; rows of
         # unknown-type atoms are zero as well (hermnet.py:51).
-        g.needs_mask = any(ne == 0 and g.type_rowptr_host[t + 1] > g.type_rowptr_host[t]
-                           for t, ne in enumerate(g.rel_edges_host))
+        # (`rel_active`: the caller knows better, e.g. a shard whose relation has edges on other ranks only)
+        active = [ne > 0 for ne in g.rel_edges_host] if rel_active is None else [bool(a) for a in rel_active]
+        g.needs_mask = any((not active[t]) and g.type_rowptr_host[t + 1] > g.type_rowptr_host[t] for t in range(T))
         if g.needs_mask:
-            act = torch.cat([(rel_edges > 0), torch.zeros(1, dtype=torch.bool, device=dev)])
+            act = torch.tensor(active + [False], dtype=torch.bool, device=dev)
             g.row_active = act[rel_row].float()
         else:
             g.row_active = None

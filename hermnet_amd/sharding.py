@@ -1,0 +1,202 @@
+"""Atom-sharded evaluation of one structure over the GPUs of a node.
+
+The reference has nothing comparable (one graph lives on one device; its only collective is
+DDP for training, `example/dist_train.py:25,67`).  The build shards the hot path by TARGET atom:
+
+  * atoms are split into `world` slabs along one cell axis (equal atom counts);
+  * a rank keeps every directed edge whose target it owns; sources it does not own are its
+    one-hop halo;
+  * layer 0 needs no exchange (x0 = embed(Z), vec0 = 0 are local); after each of the first
+    L-1 layers the owners send the new (x, vec) rows of halo atoms to the ranks that need them --
+    ONE variable-size all-to-all (RCCL point-to-point over xGMI) of n_halo * 4H floats per layer;
+  * backward mirrors it (gradients of halo rows return to the owners and are accumulated there),
+    positions use the same exchange once per step, the energy is one scalar all-reduce.
+
+Every rank derives the complete plan from the global `Data` (the calculators have all
+coordinates on the host anyway), so there is no negotiation step.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .data import Data
+
+
+class ExchangePlan(object):
+    """Index lists of one halo exchange in some local ordering.
+
+    send_idx   [n_send]  local indices of owned entries to send, grouped by destination rank
+    send_counts[world]   entries per destination
+    recv_idx   [n_recv]  local indices of halo entries to fill, grouped by source rank
+    recv_counts[world]
+    """
+
+    def __init__(self, send_idx, send_counts, recv_idx, recv_counts, group=None):
+        self.send_idx, self.send_counts = send_idx, [int(c) for c in send_counts]
+        self.recv_idx, self.recv_counts = recv_idx, [int(c) for c in recv_counts]
+        self.group = group
+
+    def remap(self, index_map):
+        """Same exchange expressed in another ordering (e.g. relation rows): idx -> index_map[idx]."""
+        return ExchangePlan(index_map[self.send_idx], self.send_counts, index_map[self.recv_idx],
+                            self.recv_counts, self.group)
+
+
+def _all_to_all_rows(buf, in_counts, out_counts, group):
+    out = buf.new_empty((sum(out_counts),) + tuple(buf.shape[1:]))
+    dist.all_to_all_single(out, buf.contiguous(), output_split_sizes=out_counts, input_split_sizes=in_counts,
+                           group=group)
+    return out
+
+
+class HaloExchange(torch.autograd.Function):
+    """out = x with its halo entries replaced by the owners' current values (differentiable)."""
+
+    @staticmethod
+    def forward(ctx, x, plan):
+        ctx.plan = plan
+        recv = _all_to_all_rows(x.detach()[plan.send_idx], plan.send_counts, plan.recv_counts, plan.group)
+        out = x.detach().clone()
+        out[plan.recv_idx] = recv
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        back = _all_to_all_rows(g[plan.recv_idx], plan.recv_counts, plan.send_counts, plan.group)
+        gx = g.clone()
+        gx[plan.recv_idx] = 0            # the local halo values were overwritten in forward
+        gx.index_add_(0, plan.send_idx, back)
+        return gx, None
+
+
+class SumAcrossRanks(torch.autograd.Function):
+    """E_total = sum_r E_r (all-reduce); d E_total / d E_r = 1 on every rank."""
+
+    @staticmethod
+    def forward(ctx, e, group):
+        out = e.detach().clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class ShardPlan(object):
+    """What HVNet.forward needs to run one rank's share: see `partition`."""
+
+    def __init__(self, rank, world, owned_global, halo_global, atom_plan, owned_mask, num_graphs, group=None):
+        self.rank, self.world = rank, world
+        self.num_graphs = int(num_graphs)     # of the GLOBAL batch (a rank may own no atom of some graph)
+        self.owned_global = owned_global      # LongTensor: global ids of owned atoms (local ids 0..n_owned-1)
+        self.halo_global = halo_global        # LongTensor: global ids of halo atoms (local ids n_owned..)
+        self.atom_plan = atom_plan            # ExchangePlan in local atom order
+        self.owned_mask = owned_mask          # BoolTensor [N_loc]
+        self.group = group
+        self.z_with_in_edges = None           # atomic numbers that receive >= 1 edge GLOBALLY (hermnet.py:56-57)
+
+    @property
+    def n_owned(self):
+        return int(self.owned_global.numel())
+
+    def to(self, device):
+        self.owned_global = self.owned_global.to(device)
+        self.halo_global = self.halo_global.to(device)
+        self.owned_mask = self.owned_mask.to(device)
+        p = self.atom_plan
+        self.atom_plan = ExchangePlan(p.send_idx.to(device), p.send_counts, p.recv_idx.to(device), p.recv_counts,
+                                      p.group)
+        return self
+
+
+def slab_owner(pos, cell, world, axis=None):
+    """Owner rank of every atom: equal-count slabs along `axis` (default: the longest cell vector)."""
+    pos = np.asarray(pos, dtype=np.float64)
+    n = pos.shape[0]
+    if cell is not None:
+        c = np.asarray(cell, dtype=np.float64).reshape(3, 3)
+        if axis is None:
+            axis = int(np.argmax(np.linalg.norm(c, axis=1)))
+        frac = pos @ np.linalg.inv(c)
+        coord = frac[:, axis] - np.floor(frac[:, axis])
+    else:
+        if axis is None:
+            axis = int(np.argmax(pos.max(0) - pos.min(0)))
+        coord = pos[:, axis]
+    order = np.argsort(coord, kind="stable")
+    owner = np.empty(n, dtype=np.int64)
+    bounds = [(n * r) // world for r in range(world + 1)]
+    for r in range(world):
+        owner[order[bounds[r]:bounds[r + 1]]] = r
+    return owner
+
+
+def partition(data, rank, world, axis=None, group=None):
+    """Split a global `Data` (host tensors) for `rank` of `world`.
+
+    Returns (local_data, plan).  local_data holds owned atoms first (ascending global id) then halo
+    atoms; its edges are the global edges whose target is owned, re-indexed locally; `batch`,
+    `cell`, `edge_shift` follow.  Positions of halo atoms are placeholders (zeros): HVNet.forward
+    fills them through the exchange so that force contributions flow back to the owners.
+    """
+    pos = data.pos.detach().cpu().numpy()
+    cell = data.get("cell")
+    cell_np = None if cell is None else cell.detach().cpu().numpy().reshape(-1, 3, 3)[0]
+    owner = slab_owner(pos, cell_np, world, axis)
+    ei = data.edge_index.cpu().numpy()
+    src, tgt = ei[0], ei[1]
+    n = pos.shape[0]
+
+    def halo_of(r):
+        """(global ids of rank r's halo atoms, their owners), sorted by (owner, id)."""
+        need = np.unique(src[(owner[tgt] == r) & (owner[src] != r)])
+        key = np.lexsort((need, owner[need]))
+        need = need[key]
+        return need, owner[need]
+
+    owned = np.nonzero(owner == rank)[0]
+    halo, halo_owner = halo_of(rank)
+    local_ids = np.concatenate([owned, halo])
+    g2l = np.full(n, -1, dtype=np.int64)
+    g2l[local_ids] = np.arange(len(local_ids))
+    emask = owner[tgt] == rank
+    lsrc, ltgt = g2l[src[emask]], g2l[tgt[emask]]
+    assert (lsrc >= 0).all() and (ltgt >= 0).all()
+
+    # what I receive: my halo grouped by owner; what I send: for every other rank, its halo atoms that I own
+    recv_counts = [int((halo_owner == p).sum()) for p in range(world)]
+    recv_idx = g2l[halo]
+    send_lists = []
+    for p in range(world):
+        if p == rank:
+            send_lists.append(np.zeros(0, dtype=np.int64))
+            continue
+        hp, hp_owner = halo_of(p)
+        send_lists.append(g2l[hp[hp_owner == rank]])
+    send_counts = [len(s) for s in send_lists]
+    send_idx = np.concatenate(send_lists) if send_lists else np.zeros(0, dtype=np.int64)
+
+    pos_l = data.pos[torch.from_numpy(local_ids)].clone()
+    pos_l[len(owned):] = 0.0
+    kw = dict(pos=pos_l,
+              atomic_number=data.atomic_number[torch.from_numpy(local_ids)],
+              edge_index=torch.from_numpy(np.vstack([lsrc, ltgt])).long(),
+              batch=(data.batch if data.get("batch") is not None else torch.zeros(n, dtype=torch.long))[
+                  torch.from_numpy(local_ids)])
+    if cell is not None:
+        kw["cell"] = cell
+        if data.get("edge_shift") is not None:
+            kw["edge_shift"] = data.edge_shift[torch.from_numpy(np.nonzero(emask)[0])]
+    local = Data(**kw)
+    owned_mask = torch.zeros(len(local_ids), dtype=torch.bool)
+    owned_mask[:len(owned)] = True
+    num_graphs = int(data.batch.max()) + 1 if data.get("batch") is not None and n > 0 else 1
+    plan = ShardPlan(rank, world, torch.from_numpy(owned), torch.from_numpy(halo),
+                     ExchangePlan(torch.from_numpy(send_idx), send_counts, torch.from_numpy(recv_idx), recv_counts,
+                                  group),
+                     owned_mask, num_graphs, group)
+    plan.z_with_in_edges = set(int(v) for v in np.unique(data.atomic_number.cpu().numpy()[tgt]))
+    local._hn_shard = plan
+    return local, plan
