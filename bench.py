@@ -8,9 +8,10 @@ random-init (seeded) weights.
 A "step" = HVNet.forward(data) + autograd.grad(E, pos) on a prebuilt `Data` (neighbour list
 excluded); the relation-ordered graph build (the replacement of
 the reference's per-layer `in_subgraph`) IS inside the step.  Inputs are resident in HBM before
-the timed region.  N > 1: one process per GPU (torchrun), every rank evaluates its own
-10k-atom replica ("replicas only" until the halo-sharded path lands -- DESIGN.md section (e)),
-no data-path collective, scaling "weak".
+the timed region.  N > 1: one process per GPU (torchrun); ONE periodic cell of N x 10k atoms
+(fcc 10 x 10 x 25N) is sharded by atom into N slabs, each rank owns ~10k atoms plus its one-hop
+halo; per layer one RCCL all-to-all moves the halo rows (hermnet_amd/sharding.py), the energy is
+one scalar all-reduce.  Per-GPU work is fixed, so scaling is "weak".
 
 Prints ONE JSON line on rank 0.
 """
@@ -72,7 +73,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--atoms", default="10k", choices=["10k", "100k"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal with several ranks sharing one GPU (exchange staged through the host)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,11 +83,15 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
                          % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % max(ndev, 1))
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import hermnet_amd as hn
     from hermnet_amd import synth, ops, _lib
@@ -99,9 +105,17 @@ def main():
     model = model.to(dev)
     for p_ in model.parameters():      # energy/force evaluation: no parameter gradients
         p_.requires_grad_(False)
-    reps = (10, 10, 25) if args.atoms == "10k" else (10, 10, 250)
-    data = synth.fcc_alloy(reps=reps, seed=rank).to(dev)     # each rank: its own replica
-    N, E = data.pos.size(0), data.edge_index.size(1)
+    gdata = synth.fcc_alloy(reps=(10, 10, 25 * world), seed=0)      # every rank builds the same global cell
+    N_global, E_global = gdata.pos.size(0), gdata.edge_index.size(1)
+    if world > 1:
+        from hermnet_amd.sharding import partition
+        data, plan = partition(gdata, rank, world)
+        halo = int(plan.halo_global.numel())
+        data = data.to(dev)
+    else:
+        data, halo = gdata.to(dev), 0
+    del gdata
+    N, E = data.pos.size(0), data.edge_index.size(1)                # local: owned + halo atoms, edges by owned target
     H, T = model_kw["hidden_channels"], len(elems)
 
     def step():
@@ -148,14 +162,17 @@ def main():
             traffic = json.load(open(tpath)).get(dom)
         out = {
             "metric": "atom-steps/sec (energy+forces) on 10k-atom 3-element cell; HBM GB/s vs roofline",
-            "value": N * world * args.steps / dt, "unit": "atom-steps/s",
+            "value": N_global * args.steps / dt, "unit": "atom-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: %d-atom 3-element fcc alloy (Al/Ni/Cu), HVNet rc=5.0 hidden=128 "
-                                   "num_rbf=128 layers=5, E=%d directed edges, energy+forces per step" % (N, E),
-                       "atoms_per_gpu": N, "edges_per_gpu": E,
-                       "parallelism": "1 GPU" if world == 1 else "replicas only x%d (no data-path collective)" % world},
+                                   "num_rbf=128 layers=5, E=%d directed edges, energy+forces per step"
+                                   % (N_global, E_global),
+                       "atoms_total": N_global, "atoms_owned_rank0": N - halo, "halo_atoms_rank0": halo,
+                       "edges_rank0": E,
+                       "parallelism": "1 GPU" if world == 1 else
+                       "atom-sharded x%d slabs, one-hop halo all-to-all per layer over %s" % (world, args.backend)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic},
             "kernels": kernels,

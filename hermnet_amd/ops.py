@@ -90,6 +90,7 @@ class EdgeGeometry(torch.autograd.Function):
             graph.E, _lib.ptr(edge), _stream()), "hermnet_edge_geometry_fwd")
         ctx.graph = graph
         ctx.keep = (pos_c, cell_c)
+        ctx.cell_shape = None if cell is None else tuple(cell.shape)
         return edge
 
     @staticmethod
@@ -101,7 +102,19 @@ class EdgeGeometry(torch.autograd.Function):
         _lib.check(lib.hermnet_edge_geometry_bwd(
             _lib.ptr(gD), _lib.ptr(graph.csr_rowptr), None, _lib.ptr(graph.out_rowptr),
             _lib.ptr(graph.out_edges), graph.N, _lib.ptr(gpos_rows), _stream()), "hermnet_edge_geometry_bwd")
-        return gpos_rows[graph.row_of_node], None, None
+        gcell = None
+        if ctx.needs_input_grad[1] and ctx.keep[1] is not None:
+            # D = ... + shift @ cell[batch[src]]  =>  dE/dcell[b] = sum_{e in b} shift_e (x) gD_e
+            # (what `virial_calc`, utils.py:153-155, differentiates for NPT runs)
+            outer = graph.shift[:, :, None] * gD[:, None, :3]
+            nb = ctx.keep[1].size(0)
+            if nb == 1:
+                gcell = outer.sum(0, keepdim=True)
+            else:
+                b = graph.batch32.long()[graph.src_id.long()]
+                gcell = torch.zeros(nb, 3, 3, dtype=gD.dtype, device=gD.device).index_add_(0, b, outer)
+            gcell = gcell.reshape(ctx.cell_shape)
+        return gpos_rows[graph.row_of_node], gcell, None
 
 
 class MessageScatter(torch.autograd.Function):

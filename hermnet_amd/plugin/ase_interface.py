@@ -1,0 +1,96 @@
+"""ASE calculator adapter: the intended API of `plugin/ase_interface/calculator.py:10-98`.
+
+The reference bodies cannot run as written (SURVEY.md section 8(b) lists the defects: missing
+`model.rc`, `torch.from_numpy` on a Tensor, `cell[0]` on a 3x3 cell, no `batch`, the Voigt vector
+taking `[0,1]` for `xx`); this module reproduces the intent, not the defects.
+"""
+import numpy as np
+import torch
+
+from ..data import Data, neighbor_search
+from ..elements import atomic_numbers
+from ..utils import virial_calc
+
+try:  # ASE is optional on the MI355X image
+    from ase.calculators.calculator import Calculator as _Base, all_changes
+except Exception:  # pragma: no cover - exercised on the GPU image
+    all_changes = ['positions', 'numbers', 'cell', 'pbc', 'initial_charges', 'initial_magmoms']
+
+    class _Base(object):
+        """Minimal stand-in for `ase.calculators.calculator.Calculator`."""
+
+        def __init__(self, **kwargs):
+            self.results = {}
+            self.atoms = None
+
+        def calculate(self, atoms=None, properties=('energy',), system_changes=all_changes):
+            self.atoms = atoms
+
+
+def build_graph(cell, elements, pos, rc):
+    """`calculator.py:10-27`: numpy (cell [3,3] or None, Z [N], pos [N,3]) -> `Data` with the cutoff graph."""
+    pos_t = torch.from_numpy(np.asarray(pos)).float()
+    z = torch.from_numpy(np.asarray(elements)).long()
+    data = Data(atomic_number=z, pos=pos_t, batch=torch.zeros(pos_t.size(0), dtype=torch.long))
+    if cell is None or not np.any(np.asarray(cell)):
+        data.edge_index = neighbor_search(pos=pos_t, rc=rc)
+    else:
+        cell_t = torch.from_numpy(np.asarray(cell, dtype=np.float64).reshape(3, 3)).float()
+        data.edge_index, data.edge_shift = neighbor_search(pos=pos_t, rc=rc, cell=cell_t)
+        data.cell = cell_t.reshape(1, 3, 3)
+    return data
+
+
+def model_calc(model, data, device, pbc, ensemble='NVT', trn_mean=0.0, units='metal'):
+    """`calculator.py:59-98` / `lmp_calc.py:36-85`: (energy float, forces [N,3] float32, virial [6]).
+
+    virial (NPT only) is the symmetrised pressure*volume tensor of `virial_calc` in the order
+    [xx, yy, zz, xy, xz, yz] (LAMMPS `fix client/md`); zeros for NVT like the reference."""
+    device = torch.device(device)
+    data = data.to(device)
+    data.pos.requires_grad = True
+    npt = ensemble.lower() == 'npt'
+    if npt and pbc and data.get('cell') is not None:
+        data.cell.requires_grad = True
+    model.eval()
+    energy = model(data) + trn_mean
+    forces = -torch.autograd.grad(energy.sum(), data.pos, retain_graph=npt and pbc)[0]
+    if npt:
+        v = virial_calc(cell=data.get('cell'), pos=data.pos.detach(), forces=forces, energy=energy, units=units,
+                        pbc=bool(pbc) and data.get('cell') is not None).detach().cpu().numpy()
+        virial = np.array([v[0, 0], v[1, 1], v[2, 2], v[0, 1], v[0, 2], v[1, 2]])
+    else:
+        virial = np.zeros(6, dtype=np.float32)
+    return energy.detach().cpu().item(), forces.detach().cpu().numpy().reshape(-1, 3), virial
+
+
+class NNCalculator(_Base):
+    """`calculator.py:30-57`.  `model_path=None` keeps the weights already in `model`."""
+    implemented_properties = ['energy', 'free_energy', 'forces', 'stress']
+
+    def __init__(self, model, model_path, trn_mean, device_='cuda', ensemble='NVT'):
+        super(NNCalculator, self).__init__()
+        self.device_ = device_
+        device = torch.device(device_)
+        self.model = model.to(device)
+        if model_path is not None:
+            self.model.load_state_dict(torch.load(model_path, map_location=device))
+        for p in self.model.parameters():       # energy/force evaluation only
+            p.requires_grad_(False)
+        self.trn_mean = trn_mean
+        self.ensemble = ensemble
+
+    def calculate(self, atoms, properties=('energy',), system_changes=all_changes):
+        super(NNCalculator, self).calculate(atoms, properties, system_changes)
+        pbc = bool(np.any(atoms.pbc))
+        cell = np.asarray(atoms.cell if not hasattr(atoms, "todict") else atoms.todict()['cell']) if pbc else None
+        elems = np.array([atomic_numbers[s] for s in atoms.get_chemical_symbols()])
+        data = build_graph(cell=cell, elements=elems, pos=atoms.positions, rc=self.model.rc)
+        energy, forces, virial = self.model_calc(data=data, device=self.device_, pbc=pbc, ensemble=self.ensemble)
+        self.results['energy'] = energy
+        self.results['free_energy'] = energy
+        self.results['forces'] = forces
+        self.results['stress'] = virial
+
+    def model_calc(self, data, device, pbc, ensemble='NVT'):
+        return model_calc(self.model, data, device, pbc, ensemble, self.trn_mean)

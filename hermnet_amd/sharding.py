@@ -42,7 +42,15 @@ class ExchangePlan(object):
                             self.recv_counts, self.group)
 
 
+def _host_staged(group, t):
+    """gloo has no device all-to-all: rehearsal runs (several ranks sharing one GPU) stage through the host.
+    The production backend is "nccl" (= RCCL over xGMI), which takes the device buffers directly."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def _all_to_all_rows(buf, in_counts, out_counts, group):
+    if _host_staged(group, buf):
+        return _all_to_all_rows(buf.cpu(), in_counts, out_counts, group).to(buf.device)
     out = buf.new_empty((sum(out_counts),) + tuple(buf.shape[1:]))
     dist.all_to_all_single(out, buf.contiguous(), output_split_sizes=out_counts, input_split_sizes=in_counts,
                            group=group)
@@ -76,6 +84,10 @@ class SumAcrossRanks(torch.autograd.Function):
     @staticmethod
     def forward(ctx, e, group):
         out = e.detach().clone()
+        if _host_staged(group, out):
+            host = out.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            return host.to(out.device)
         dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
         return out
 

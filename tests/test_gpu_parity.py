@@ -6,6 +6,8 @@ Tolerance (BASELINE.json north_star): energies and forces within 1e-5 relative
 (forces relative to max|F|); neighbour indices bit-exact."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -221,3 +223,52 @@ def test_fused_layer_equals_autograd_composed_layer(name, monkeypatch):
         res.append((e.detach(), f))
     assert rel_err(res[0][0], res[1][0]) < 2e-6
     assert rel_err(res[0][1], res[1][1]) < 5e-6
+
+
+class _FakeAtoms(object):
+    """Duck-typed stand-in for ase.Atoms (ASE is not installed on the MI355X image)."""
+
+    def __init__(self, pos, z, cell):
+        from hermnet_amd.elements import chemical_symbols
+        self.positions = pos
+        self._sym = [chemical_symbols[int(v)] for v in z]
+        self.cell = cell
+        self.pbc = [cell is not None] * 3
+
+    def get_chemical_symbols(self):
+        return self._sym
+
+
+@pytest.mark.parametrize("name", ["alloy108", "mol16"])
+def test_calculator_plugin_energy_forces_virial(name):
+    """NNCalculator / model_calc (plugin/ase_interface/calculator.py:30-98 intent) incl. the NPT virial
+    (utils.py:138-160) against the oracle differentiated w.r.t. the cell."""
+    from hermnet_amd.plugin import NNCalculator
+    from hermnet_amd.utils import virial_calc
+    from oracle import hermnet_oracle as orc
+    dev = _dev()
+    g = Golden(name)
+    d = g.data()
+    if name == "mol16":      # one molecule of the batch, open boundaries
+        keep = d.batch == 0
+        pos, z, cell = d.pos[keep].numpy(), d.atomic_number[keep].numpy(), None
+    else:
+        pos, z, cell = d.pos.numpy(), d.atomic_number.numpy(), d.cell[0].numpy()
+    calc = NNCalculator(g.model(), None, trn_mean=0.25, device_="cuda:0", ensemble="NPT")
+    atoms = _FakeAtoms(pos.astype("float64"), z, cell)
+    calc.calculate(atoms, ["energy", "forces", "stress"])
+    # oracle on the same graph (the plugin builds it with the build's own neighbour search)
+    from hermnet_amd.plugin import build_graph
+    dd = build_graph(cell, z, pos, calc.model.rc)
+    sd = g.model().state_dict()
+    p = dd.pos.clone().requires_grad_(True)
+    c = dd.cell.clone().requires_grad_(True) if cell is not None else None
+    e = orc.hvnet_energy(sd, g.elems, p, dd.atomic_number, dd.edge_index, dd.batch, dd.get("edge_shift"), c,
+                         **g.oracle_kwargs()) + 0.25
+    f = -torch.autograd.grad(e.sum(), p, retain_graph=cell is not None)[0]
+    v = virial_calc(c, p.detach(), f, e, "metal", pbc=cell is not None).detach()
+    vv = torch.tensor([v[0, 0], v[1, 1], v[2, 2], v[0, 1], v[0, 2], v[1, 2]])
+    assert abs(calc.results["energy"] - float(e)) < 1e-5 * abs(float(e))
+    assert rel_err(torch.from_numpy(calc.results["forces"]), f) < TOL
+    assert rel_err(torch.from_numpy(np.asarray(calc.results["stress"], dtype="float32")), vv) < 5e-5
+    assert calc.results["free_energy"] == calc.results["energy"]

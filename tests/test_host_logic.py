@@ -203,3 +203,39 @@ def test_fused_layer_orchestration_matches_golden(name, monkeypatch):
     f = -torch.autograd.grad(e.sum(), d.pos)[0]
     assert rel_err(e.detach(), g.energy) < 2e-6
     assert rel_err(f, g.forces) < 1e-5
+
+
+def test_lammps_plugin_helpers():
+    from hermnet_amd.plugin import lmp_interface as L
+    a = L.parse_args(["-m", "zmq", "-p", "tcp://x", "-f", "m.pt", "-t", "Al", "Ni", "Cu", "-e", "NPT"])
+    assert a.elems == ["Al", "Ni", "Cu"] and a.rc == 5.0 and a.device == "cuda" and a.units == "metal"
+    assert list(L.lammps_types_to_numbers([1, 3, 2, 1], a.elems)) == [13, 29, 28, 13]
+    assert (L.SETUP, L.STEP, L.FORCES, L.ENERGY, L.VIRIAL) == (1, 2, 1, 2, 3)
+
+    class CS(object):
+        def __init__(self):
+            self.log = []
+
+        def send(self, *a):
+            self.log.append(("send",) + a)
+
+        def pack(self, *a):
+            self.log.append(("pack",) + a)
+
+        def pack_double(self, *a):
+            self.log.append(("pack_double",) + a)
+
+    cs = CS()
+    L.pack_reply(cs, 2, np.arange(6.0), -1.5, np.zeros(6))
+    assert cs.log[0] == ("send", 2, 3) and cs.log[1][:4] == ("pack", 1, 4, 6) and cs.log[2] == ("pack_double", 2, -1.5)
+    assert cs.log[3][:4] == ("pack", 3, 4, 6)
+
+
+def test_virial_units():
+    from hermnet_amd.utils import virial_calc
+    pos = torch.tensor([[0.0, 0, 0], [1.0, 2, 3]])
+    f = torch.tensor([[0.5, 0, 0], [-0.5, 0, 0]])
+    v = virial_calc(None, pos, f, None, units="metal", pbc=False)
+    assert torch.allclose(v[0, 0], torch.tensor(-0.5 * 1.6021765e6)) and torch.allclose(v, v.T)
+    with pytest.raises(ValueError):
+        virial_calc(None, pos, f, None, units="bogus")
