@@ -55,7 +55,8 @@ def cpu_baseline(model_kw, elems, seed):
     sd = synth.synth_state_dict(m.state_dict(), seed)
     kw = dict(rc=model_kw["rc"], num_layers=model_kw["num_layers"], hidden_channels=model_kw["hidden_channels"],
               num_rbf=model_kw["num_rbf"])
-    cores = torch.get_num_threads()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else torch.get_num_threads()
+    torch.set_num_threads(cores)      # all host cores this process may use
     small = synth.fcc_alloy(reps=(3, 3, 3))
     orc.energy_and_forces(sd, elems, small, mode="faithful", **kw)      # warm-up (first call costs seconds)
     t0 = time.time()
@@ -176,7 +177,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic},
             "kernels": kernels,
-            "energy": float(e[0]),
+            "energy": float(e.detach()[0]),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_kw, elems, seed)

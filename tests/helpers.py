@@ -78,4 +78,5 @@ class Golden(object):
 
 def rel_err(a, b):
     """max |a-b| / max |b|  (forces have components near zero)."""
+    a, b = a.detach(), b.detach()
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
