@@ -101,7 +101,7 @@ class HVNet(nn.Module):
             row_plan = shard.atom_plan.remap(graph.row_of_node)
         edge = EdgeGeometry.apply(pos, data.get("cell"), graph)          # with_edge, hermnet.py:133-152
 
-        x = self.embed(data.atomic_number.long()[graph.node_order])        # hermnet.py:123, row order
+        x = self.embed(graph.z_rows)                                        # hermnet.py:123, row order (pads: Z=0)
         vec = None                                                          # zeros, hermnet.py:124
         data._hn_graph, data._hn_edge, data._hn_rbf = graph, edge, rbf
         data.x, data.vec = x, vec
@@ -116,24 +116,23 @@ class HVNet(nn.Module):
                 data.x, data.vec = packed[:, :H], packed[:, H:].reshape(n, 3, H)
         x = data.x
 
-        per_atom_energy = self.out_energy(x).squeeze(1)                     # hermnet.py:129
+        per_atom_energy = self.out_energy(x).squeeze(1)[graph.row_of_node]  # hermnet.py:129, back in atom order
+        batch = data.batch.long()
         if shard is not None:
-            owned_rows = shard.owned_mask[graph.node_order]
-            e_own = per_atom_energy * owned_rows.to(per_atom_energy.dtype)
-            energy = torch.zeros(shard.num_graphs, dtype=e_own.dtype, device=x.device).index_add(0, graph.batch_rows, e_own)
+            own = shard.owned_mask.to(per_atom_energy.dtype)
+            e_own = per_atom_energy * own
+            energy = torch.zeros(shard.num_graphs, dtype=e_own.dtype, device=x.device).index_add(0, batch, e_own)
             energy = SumAcrossRanks.apply(energy, shard.group)
             if self.intensive:
-                cnt = torch.zeros(shard.num_graphs, dtype=e_own.dtype, device=x.device).index_add(
-                    0, graph.batch_rows, owned_rows.to(e_own.dtype))
-                dist_cnt = SumAcrossRanks.apply(cnt, shard.group)
-                energy = energy / dist_cnt.clamp(min=1)
+                cnt = torch.zeros(shard.num_graphs, dtype=e_own.dtype, device=x.device).index_add(0, batch, own)
+                energy = energy / SumAcrossRanks.apply(cnt, shard.group).clamp(min=1)
             return energy
         # scatter(per_atom_energy, batch, reduce=sum|mean) (hermnet.py:130) as an ordered segment
         # reduction: no atomics, so the energy is bit-reproducible run to run
         if graph.num_graphs == 1:
             energy = per_atom_energy.sum().reshape(1)
             if self.intensive:
-                energy = energy / max(graph.N, 1)
+                energy = energy / max(graph.num_atoms, 1)
         else:
             energy = torch.segment_reduce(per_atom_energy[graph.graph_perm], "sum", lengths=graph.graph_lengths)
             if self.intensive:

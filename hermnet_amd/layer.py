@@ -52,6 +52,11 @@ class LayerWeights(object):
         self.wx2 = [u.xvec_proj[2].weight.contiguous() for u in ul]                 # [3H, H]
         self.wx2t = [w.t().contiguous() for w in self.wx2]
         self.bx2 = [u.xvec_proj[2].bias for u in ul]
+        # stacked copies for the uniform-block layout (one batched GEMM per stage)
+        st = lambda lst: torch.stack(lst, 0).contiguous()
+        self.wv_s, self.wvt_s = st(self.wv), st(self.wvt)
+        self.wx0_s, self.wx0t_s, self.bx0_s = st(self.wx0), st(self.wx0t), st(self.bx0)[:, None, :].contiguous()
+        self.wx2_s, self.wx2t_s, self.bx2_s = st(self.wx2), st(self.wx2t), st(self.bx2)[:, None, :].contiguous()
         self.key = key
         return self
 
@@ -103,22 +108,32 @@ class FusedRelationalLayer(torch.autograd.Function):
         x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge)
         # --- PaiNNUpdate on the rows of each relation (rmnet.py:94-107)
         vp = torch.empty(N, 3, 2 * H, dtype=x.dtype, device=x.device)
-        for t in range(T):
-            lo, hi = rp[t], rp[t + 1]
-            if hi > lo:
-                torch.mm(vec1[lo:hi].view(-1, H), w.wvt[t], out=vp[lo:hi].view(-1, 2 * H))
-        vdot, xin = nodeops.update_mid(vp, x1, nk, H)
         h2 = torch.empty(N, H, dtype=x.dtype, device=x.device)
-        for t in range(T):
-            lo, hi = rp[t], rp[t + 1]
-            if hi > lo:
-                torch.addmm(w.bx0[t], xin[lo:hi], w.wx0t[t], out=h2[lo:hi])
-        a2 = nodeops.ssilu_fwd(h2[:nk]) if nk > 0 else h2[:0]
         q = torch.empty(N, 3 * H, dtype=x.dtype, device=x.device)
-        for t in range(T):
-            lo, hi = rp[t], rp[t + 1]
-            if hi > lo:
-                torch.addmm(w.bx2[t], a2[lo:hi], w.wx2t[t], out=q[lo:hi])
+        uni, B = graph.uniform and nk > 0, graph.block
+        if uni:   # every relation owns `B` rows: one batched GEMM per stage
+            torch.bmm(vec1[:nk].view(T, 3 * B, H), w.wvt_s, out=vp[:nk].view(T, 3 * B, 2 * H))
+        else:
+            for t in range(T):
+                lo, hi = rp[t], rp[t + 1]
+                if hi > lo:
+                    torch.mm(vec1[lo:hi].view(-1, H), w.wvt[t], out=vp[lo:hi].view(-1, 2 * H))
+        vdot, xin = nodeops.update_mid(vp, x1, nk, H)
+        if uni:
+            torch.baddbmm(w.bx0_s, xin[:nk].view(T, B, 2 * H), w.wx0t_s, out=h2[:nk].view(T, B, H))
+        else:
+            for t in range(T):
+                lo, hi = rp[t], rp[t + 1]
+                if hi > lo:
+                    torch.addmm(w.bx0[t], xin[lo:hi], w.wx0t[t], out=h2[lo:hi])
+        a2 = nodeops.ssilu_fwd(h2[:nk]) if nk > 0 else h2[:0]
+        if uni:
+            torch.baddbmm(w.bx2_s, a2.view(T, B, H), w.wx2t_s, out=q[:nk].view(T, B, 3 * H))
+        else:
+            for t in range(T):
+                lo, hi = rp[t], rp[t + 1]
+                if hi > lo:
+                    torch.addmm(w.bx2[t], a2[lo:hi], w.wx2t[t], out=q[lo:hi])
         x_out, vec_out = nodeops.update_out(q, vdot, vp, x1, vec1, graph.row_active, N, nk, H)
         ctx.save_for_backward(x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q)
         ctx.graph, ctx.rbf, ctx.w = graph, rbf, w
@@ -136,22 +151,33 @@ class FusedRelationalLayer(torch.autograd.Function):
         gvo = gvo.contiguous()
         gq, gvdot, gvp, gx1, gvec1 = nodeops.update_out_bwd(gxo, gvo, q, vdot, vp, graph.row_active, N, nk, H)
         ga2 = torch.empty(N, H, dtype=x.dtype, device=x.device)
-        for t in range(T):
-            lo, hi = rp[t], rp[t + 1]
-            if hi > lo:
-                torch.mm(gq[lo:hi], w.wx2[t], out=ga2[lo:hi])
-        gh2 = nodeops.ssilu_bwd(ga2, h2, nk, 1, H, H, H) if nk > 0 else ga2[:0]
         gxin = torch.empty(N, 2 * H, dtype=x.dtype, device=x.device)
-        for t in range(T):
-            lo, hi = rp[t], rp[t + 1]
-            if hi > lo:
-                torch.mm(gh2[lo:hi], w.wx0[t], out=gxin[lo:hi])
+        uni, B = graph.uniform and nk > 0, graph.block
+        if uni:
+            torch.bmm(gq[:nk].view(T, B, 3 * H), w.wx2_s, out=ga2[:nk].view(T, B, H))
+        else:
+            for t in range(T):
+                lo, hi = rp[t], rp[t + 1]
+                if hi > lo:
+                    torch.mm(gq[lo:hi], w.wx2[t], out=ga2[lo:hi])
+        gh2 = nodeops.ssilu_bwd(ga2, h2, nk, 1, H, H, H) if nk > 0 else ga2[:0]
+        if uni:
+            torch.bmm(gh2.view(T, B, H), w.wx0_s, out=gxin[:nk].view(T, B, 2 * H))
+        else:
+            for t in range(T):
+                lo, hi = rp[t], rp[t + 1]
+                if hi > lo:
+                    torch.mm(gh2[lo:hi], w.wx0[t], out=gxin[lo:hi])
         nodeops.update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, nk, H)
-        for t in range(T):
-            lo, hi = rp[t], rp[t + 1]
-            if hi > lo:
-                g = gvec1[lo:hi].view(-1, H)
-                torch.addmm(g, gvp[lo:hi].view(-1, 2 * H), w.wv[t], out=g)
+        if uni:
+            gv = gvec1[:nk].view(T, 3 * B, H)
+            torch.baddbmm(gv, gvp[:nk].view(T, 3 * B, 2 * H), w.wv_s, out=gv)
+        else:
+            for t in range(T):
+                lo, hi = rp[t], rp[t + 1]
+                if hi > lo:
+                    g = gvec1[lo:hi].view(-1, H)
+                    torch.addmm(g, gvp[lo:hi].view(-1, 2 * H), w.wv[t], out=g)
         gxh, gvec_in, gx_in, gedge = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1)
         gx_total = None
         if ctx.needs_input_grad[0]:

@@ -14,73 +14,103 @@ import torch
 
 
 class RelationalGraph(object):
-    __slots__ = ("N", "E", "T", "node_order", "row_of_node", "type_rowptr", "type_rowptr_host",
-                 "rel_edges_host", "csr_rowptr", "csr_src", "csr_perm", "csc_rowptr", "csc_tgt", "csc_pos",
-                 "out_rowptr", "out_edges", "src_id", "tgt_id", "shift", "row_active", "needs_mask",
+    """Rows = atoms in relation order.  With `uniform` layout every relation owns a block of
+    `block` = max_t N_t rows (short relations are padded with inert rows), so the per-relation node
+    GEMMs of a layer are ONE batched GEMM over a [T, block, .] view; atoms of unknown element follow
+    after the T blocks.  Without it (very unbalanced compositions) blocks are tight and the host
+    loops over relations."""
+
+    __slots__ = ("N", "E", "T", "num_atoms", "uniform", "block", "node_order", "row_of_node", "z_rows",
+                 "type_rowptr", "type_rowptr_host", "csr_rowptr", "csr_src", "csr_perm", "csc_rowptr", "csc_tgt",
+                 "csc_pos", "out_rowptr", "out_edges", "src_id", "tgt_id", "shift", "row_active", "row_real",
                  "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device")
 
     @staticmethod
-    def build(atomic_number, edge_index, z_list, edge_shift=None, batch=None, rel_active=None):
+    def build(atomic_number, edge_index, z_list, edge_shift=None, batch=None, rel_active=None, uniform=None):
         """atomic_number [N] int, edge_index [2,E] int (row 0 = source, row 1 = target,
-        `hermnet.py:135`), z_list: atomic numbers of the model's elements in module order."""
+        `hermnet.py:135`), z_list: atomic numbers of the model's elements in module order.
+        `uniform`: None = automatic (padding overhead <= 15 %), True/False = forced."""
         g = RelationalGraph()
         dev = atomic_number.device
-        N = int(atomic_number.numel())
+        NA = int(atomic_number.numel())
         E = int(edge_index.size(1))
         T = len(z_list)
-        g.N, g.E, g.T, g.device = N, E, T, dev
+        g.num_atoms, g.E, g.T, g.device = NA, E, T, dev
         z = atomic_number.long()
         zl = torch.tensor(list(z_list), dtype=torch.long, device=dev)
         eq = z[:, None] == zl[None, :]
         # relation of each atom: first matching element, T for "not in elems" (hermnet.py:53 finds none)
-        rel = torch.where(eq.any(1), eq.int().argmax(1), torch.full((N,), T, dtype=torch.long, device=dev))
-        ar = torch.arange(N, device=dev)
-        g.node_order = torch.argsort(rel * N + ar)
+        rel = torch.where(eq.any(1), eq.int().argmax(1), torch.full((NA,), T, dtype=torch.long, device=dev))
+        counts = torch.zeros(T + 1, dtype=torch.long, device=dev).index_add_(0, rel, torch.ones_like(rel))
+        nb = batch.long().max().reshape(1) + 1 if (batch is not None and NA > 0) else torch.ones(1, dtype=torch.long, device=dev)
+        host = torch.cat([counts, nb]).cpu().tolist()          # the one host sync of the build
+        cnt_host, g.num_graphs = host[:T + 1], int(host[-1])
+        known = sum(cnt_host[:T])
+        block = max(cnt_host[:T]) if T > 0 else 0
+        if uniform is None:
+            uniform = T > 1 and T * block <= 1.15 * known + 64
+        g.uniform = bool(uniform) or T == 1
+        if g.uniform:
+            starts = [t * block for t in range(T)] + [T * block]
+            g.block = block
+        else:
+            starts = [0]
+            for t in range(T):
+                starts.append(starts[-1] + cnt_host[t])
+            g.block = 0
+        N = starts[T] + cnt_host[T]                             # rows (>= atoms when padded)
+        g.N = N
+        g.type_rowptr_host = starts[:T + 1]
+
+        ar = torch.arange(NA, device=dev)
+        g.node_order = torch.argsort(rel * NA + ar)             # atoms sorted by (relation, id)
+        first_sorted = torch.zeros(T + 1, dtype=torch.long, device=dev)
+        first_sorted[1:] = torch.cumsum(counts[:T], 0)          # position of each relation in the sorted list
+        starts_d = torch.tensor(starts, dtype=torch.long, device=dev)
+        rel_sorted = rel[g.node_order]
+        rows_sorted = ar - first_sorted[rel_sorted] + starts_d[rel_sorted]
         g.row_of_node = torch.empty_like(g.node_order)
-        g.row_of_node[g.node_order] = ar
-        counts = torch.bincount(rel, minlength=T + 1)
-        type_rowptr = torch.zeros(T + 1, dtype=torch.long, device=dev)
-        type_rowptr[1:] = torch.cumsum(counts[:T], 0)
+        g.row_of_node[g.node_order] = rows_sorted
+        g.z_rows = torch.zeros(N, dtype=torch.long, device=dev)
+        g.z_rows[g.row_of_node] = z
+        g.row_real = torch.zeros(N, dtype=torch.float32, device=dev)
+        g.row_real[g.row_of_node] = 1.0
+        rel_row = torch.full((N,), T, dtype=torch.long, device=dev)
+        for t in range(T):
+            rel_row[starts[t]:(starts[t + 1] if t + 1 <= T else N)] = t
+        rel_row[starts[T]:] = T
+
+        def rowptr_of(sorted_keys, nkeys):
+            """CSR row pointer of an ascending key list (no host sync, unlike bincount)."""
+            return torch.searchsorted(sorted_keys, torch.arange(nkeys + 1, device=dev))
 
         src, tgt = edge_index[0].long(), edge_index[1].long()
         rs, rt = g.row_of_node[src], g.row_of_node[tgt]
-        csr_perm = torch.argsort(rt, stable=True)
+        rt_s, csr_perm = torch.sort(rt, stable=True)
         csr_src = rs[csr_perm]
-        rt_s = rt[csr_perm]
-        csr_rowptr = torch.zeros(N + 1, dtype=torch.long, device=dev)
-        csr_rowptr[1:] = torch.cumsum(torch.bincount(rt, minlength=N), 0)
+        csr_rowptr = rowptr_of(rt_s, N)
 
-        rel_row = rel[g.node_order]                       # relation of each row
-        key2 = rel_row[rt_s] * N + csr_src                # (relation(target), row(source))
-        csc_pos = torch.argsort(key2, stable=True)
+        key2 = rel_row[rt_s] * N + csr_src                      # (relation(target), row(source))
+        key2_s, csc_pos = torch.sort(key2, stable=True)
         csc_tgt = rt_s[csc_pos]
-        csc_cnt = torch.bincount(key2, minlength=(T + 1) * N)[:T * N]
-        csc_rowptr = torch.zeros(T * N + 1, dtype=torch.long, device=dev)
-        csc_rowptr[1:] = torch.cumsum(csc_cnt, 0)
+        csc_rowptr = rowptr_of(key2_s, T * N)
 
-        out_edges = torch.argsort(csr_src, stable=True)
-        out_rowptr = torch.zeros(N + 1, dtype=torch.long, device=dev)
-        out_rowptr[1:] = torch.cumsum(torch.bincount(csr_src, minlength=N), 0)
+        src_s, out_edges = torch.sort(csr_src, stable=True)
+        out_rowptr = rowptr_of(src_s, N)
 
-        rel_edges = csc_rowptr[torch.arange(1, T + 1, device=dev) * N] - csc_rowptr[torch.arange(0, T, device=dev) * N]
-        nb = batch.long().max().reshape(1) + 1 if (batch is not None and N > 0) else torch.ones(1, dtype=torch.long, device=dev)
-        host = torch.cat([type_rowptr, rel_edges, nb]).cpu().tolist()   # the one host sync of the build
-        g.type_rowptr_host = host[:T + 1]
-        g.rel_edges_host = host[T + 1:2 * T + 1]
-        g.num_graphs = int(host[-1])
         # hermnet.py:56-57: a relation without edges is skipped -> its rows stay zero; rows of
-        # unknown-type atoms are zero as well (hermnet.py:51).
+        # unknown-type atoms (hermnet.py:51) and padding rows are zero as well.
         # (`rel_active`: the caller knows better, e.g. a shard whose relation has edges on other ranks only)
-        active = [ne > 0 for ne in g.rel_edges_host] if rel_active is None else [bool(a) for a in rel_active]
-        g.needs_mask = any((not active[t]) and g.type_rowptr_host[t + 1] > g.type_rowptr_host[t] for t in range(T))
-        if g.needs_mask:
-            act = torch.tensor(active + [False], dtype=torch.bool, device=dev)
-            g.row_active = act[rel_row].float()
+        if rel_active is None:
+            tn = torch.arange(T + 1, device=dev) * N
+            act = torch.cat([(csc_rowptr[tn[1:]] - csc_rowptr[tn[:-1]]) > 0,
+                             torch.zeros(1, dtype=torch.bool, device=dev)])
         else:
-            g.row_active = None
+            act = torch.tensor([bool(a) for a in rel_active] + [False], dtype=torch.bool, device=dev)
+        g.row_active = act[rel_row].float() * g.row_real
 
         i32 = torch.int32
-        g.type_rowptr = type_rowptr.to(i32)
+        g.type_rowptr = starts_d[:T + 1].to(i32)
         g.csr_rowptr = csr_rowptr.to(i32)
         g.csr_src = csr_src.to(i32)
         g.csr_perm = csr_perm
@@ -92,12 +122,16 @@ class RelationalGraph(object):
         g.src_id = src[csr_perm].to(i32)
         g.tgt_id = tgt[csr_perm].to(i32)
         g.shift = None if edge_shift is None else edge_shift[csr_perm].float().contiguous()
-        g.batch_rows = None if batch is None else batch.long()[g.node_order]
         g.batch32 = None if batch is None else batch.to(i32).contiguous()
-        # deterministic per-graph read-out: rows grouped by graph (stable) + segment lengths
-        if g.batch_rows is not None and g.num_graphs > 1:
-            g.graph_perm = torch.argsort(g.batch_rows, stable=True)
-            g.graph_lengths = torch.bincount(g.batch_rows, minlength=g.num_graphs)
+        g.batch_rows = None
+        if batch is not None:
+            g.batch_rows = torch.zeros(N, dtype=torch.long, device=dev)
+            g.batch_rows[g.row_of_node] = batch.long()
+        # deterministic per-graph read-out: atoms grouped by graph (stable) + segment lengths
+        if batch is not None and g.num_graphs > 1:
+            g.graph_perm = torch.argsort(batch.long(), stable=True)
+            g.graph_lengths = torch.zeros(g.num_graphs, dtype=torch.long, device=dev).index_add_(
+                0, batch.long(), torch.ones_like(batch.long()))
         else:
             g.graph_perm = None
             g.graph_lengths = None

@@ -210,7 +210,7 @@ def relational_layer(mods, x, vec, edge, graph, rbf):
         vs.append(x.new_zeros(graph.N - nk, 3, H))
     x_out = torch.cat(xs, 0) if len(xs) != 1 else xs[0]
     v_out = torch.cat(vs, 0) if len(vs) != 1 else vs[0]
-    if graph.needs_mask:   # relations without any edge are skipped by the reference (hermnet.py:56-57)
-        x_out = x_out * graph.row_active[:, None]
-        v_out = v_out * graph.row_active[:, None, None]
+    # relations without any edge are skipped by the reference (hermnet.py:56-57); padding rows stay zero
+    x_out = x_out * graph.row_active[:, None]
+    v_out = v_out * graph.row_active[:, None, None]
     return x_out, v_out

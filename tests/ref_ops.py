@@ -167,7 +167,7 @@ class RefEdgeGeometry(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gedge):
         g = ctx.graph
-        gp = torch.zeros(g.N, 3, dtype=gedge.dtype)
+        gp = torch.zeros(g.num_atoms, 3, dtype=gedge.dtype)
         gp.index_add_(0, g.src_id.long(), gedge[:, :3])
         gp.index_add_(0, g.tgt_id.long(), -gedge[:, :3])
         return gp, None, None

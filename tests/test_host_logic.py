@@ -96,24 +96,33 @@ def test_data_container_access_forms():
     assert float(d.pos.sum()) == 0.0
 
 
+@pytest.mark.parametrize("uniform", [False, True])
 @pytest.mark.parametrize("name", ["alloy108", "alloy108_unknown_type", "mol16"])
-def test_relational_graph_structure(name):
+def test_relational_graph_structure(name, uniform):
     g = Golden(name)
     d = g.data()
     zl = [atomic_numbers[e] for e in g.elems]
-    gr = RelationalGraph.build(d.atomic_number, d.edge_index, zl, d.get("edge_shift"), d.batch)
-    N, E, T = gr.N, gr.E, gr.T
+    gr = RelationalGraph.build(d.atomic_number, d.edge_index, zl, d.get("edge_shift"), d.batch, uniform=uniform)
+    N, NA, E, T = gr.N, gr.num_atoms, gr.E, gr.T
     z = d.atomic_number
-    rows_z = z[gr.node_order]
     rp = gr.type_rowptr_host
+    assert gr.uniform == uniform and N >= NA and NA == z.numel()
+    if uniform:
+        assert all(rp[t + 1] - rp[t] == gr.block for t in range(T))
+    else:
+        assert N == NA
+    # every atom has exactly one row; rows of a relation hold its atoms in ascending id, pads are inert
+    assert torch.equal(torch.sort(gr.row_of_node).values, torch.nonzero(gr.row_real).flatten())
+    assert torch.equal(gr.z_rows[gr.row_of_node], z) and int(gr.row_real.sum()) == NA
     for t in range(T):
-        assert (rows_z[rp[t]:rp[t + 1]] == zl[t]).all()
-        assert (gr.node_order[rp[t]:rp[t + 1]].diff() > 0).all()       # ascending ids inside a relation
-    assert not torch.isin(rows_z[rp[T]:], torch.tensor(zl)).any()
-    assert torch.equal(gr.row_of_node[gr.node_order], torch.arange(N))
+        atoms_t = torch.nonzero(z == zl[t]).flatten()
+        assert torch.equal(gr.row_of_node[atoms_t], rp[t] + torch.arange(atoms_t.numel()))
+    unknown = torch.nonzero(~torch.isin(z, torch.tensor(zl))).flatten()
+    assert torch.equal(gr.row_of_node[unknown], rp[T] + torch.arange(unknown.numel()))
     src, tgt = d.edge_index
     # CSR: segment r holds exactly the edges whose target is row r, in ascending edge id
     rowptr = gr.csr_rowptr.long()
+    assert rowptr.numel() == N + 1 and int(rowptr[-1]) == E
     tgt_row = torch.repeat_interleave(torch.arange(N), rowptr[1:] - rowptr[:-1])
     assert torch.equal(gr.row_of_node[tgt[gr.csr_perm]], tgt_row)
     assert torch.equal(gr.csr_src.long(), gr.row_of_node[src[gr.csr_perm]])
@@ -135,7 +144,9 @@ def test_relational_graph_structure(name):
     op = gr.out_rowptr.long()
     src_of = torch.repeat_interleave(torch.arange(N), op[1:] - op[:-1])
     assert torch.equal(gr.csr_src.long()[gr.out_edges.long()], src_of)
-    assert gr.rel_edges_host == [int(((rel_row[tgt_row]) == t).sum()) for t in range(T)]
+    # active rows: real atoms of relations that receive at least one edge
+    has_edges = torch.tensor([int(((rel_row[tgt_row]) == t).sum()) > 0 for t in range(T)] + [False])
+    assert torch.equal(gr.row_active, has_edges[rel_row].float() * gr.row_real)
 
 
 def test_state_dict_layout_matches_reference():
