@@ -38,7 +38,7 @@ SIGNATURES = {
                                                    c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "hermnet_message_scatter_bwd": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), ctypes.c_int,
                                                    c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
-                                                   c_fp, c_fp, c_fp, c_fp, c_fp]),
+                                                   c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
     "hermnet_ssilu_fwd": (ctypes.c_int, [c_fp, c_fp, ctypes.c_long, c_fp]),
     "hermnet_ssilu_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_long, ctypes.c_long, c_fp]),

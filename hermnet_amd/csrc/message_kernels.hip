@@ -64,6 +64,7 @@ struct MsgArgs {
   float* gx;           // bwd out [N,H]
   float4* gedge;       // bwd out [H/64,E]
   int rows_per_block;
+  int split_t;         // bwd: 1 = one relation per workgroup (blockIdx.z), gvec is [T,N,3,H] partial sums
 };
 
 // ---- VW-wide per-lane vectors ------------------------------------------------------------------
@@ -209,19 +210,25 @@ __device__ __forceinline__ void stage_weights(const MsgArgs& a, int t, int cb, f
 }
 
 // ---- radial basis ----------------------------------------------------------------------------------
-// Tap values of one edge: g[m] = exp(coeff (u - mu_m)^2), gd[m] = g[m] (u - mu_m), m = 0..11
-// (same fp32 operation order per tap as the reference, rmnet.py:156-172).
+// Tap values of one edge, evaluated cooperatively: lane m < 12 of the edge's lane group computes
+// tap m (same fp32 operation order as the reference, rmnet.py:156-172:  g = exp(coeff (u - mu_m)^2))
+// and parks {g, g (u - mu_m)} in the wave's LDS scratch; every lane then reads the 12 pairs back
+// as broadcasts.  One exp per edge and lane instead of twelve.
+__device__ __forceinline__ void coop_taps(const float* mu, float2* tb, int lo, float u, float coeff, int gl) {
+  if (gl < HN_TAPS) {
+    const float diff = u - mu[lo + HN_PAD + gl];
+    const float g = __expf(coeff * (diff * diff));
+    tb[gl] = make_float2(g, g * diff);
+  }
+}
+
 template <bool WITH_DER>
-__device__ __forceinline__ void rbf_taps(const float* mu, int lo, float u, float coeff,
-                                         float (&g)[HN_TAPS], float (&gd)[HN_TAPS]) {
-  const float* mrow = mu + (lo + HN_PAD);
-#pragma unroll
-  for (int m = 0; m < HN_TAPS; ++m) g[m] = mrow[m];
+__device__ __forceinline__ void rbf_taps(const float2* tb, float (&g)[HN_TAPS], float (&gd)[HN_TAPS]) {
 #pragma unroll
   for (int m = 0; m < HN_TAPS; ++m) {
-    const float diff = u - g[m];
-    g[m] = __expf(coeff * (diff * diff));
-    if (WITH_DER) gd[m] = g[m] * diff;
+    const float2 t = tb[m];
+    g[m] = t.x;
+    if (WITH_DER) gd[m] = t.y;
   }
 }
 
@@ -233,6 +240,14 @@ __device__ __forceinline__ void rbf_part(const float* wcol, const float (&g)[HN_
                                          Vec<VW>& S0, Vec<VW>& S1) {
   S0 = Vec<VW>::zero();
   if (WITH_DER) S1 = Vec<VW>::zero();
+#if defined(HN_SIMPLE_PART)
+#pragma unroll
+  for (int m = 0; m < HN_TAPS; ++m) {
+    const Vec<VW> w = Vec<VW>::load(wcol + m * HN_LDS_ROW);
+    S0 = v_sfma(g[m], w, S0);
+    if (WITH_DER) S1 = v_sfma(gd[m], w, S1);
+  }
+#else
   Vec<VW> wa = Vec<VW>::load(wcol), wb;
 #pragma unroll
   for (int m = 0; m < HN_TAPS; m += 2) {
@@ -242,6 +257,25 @@ __device__ __forceinline__ void rbf_part(const float* wcol, const float (&g)[HN_
     if (m + 2 < HN_TAPS) wa = Vec<VW>::load(wcol + (m + 2) * HN_LDS_ROW);
     S0 = v_sfma(g[m + 1], wb, S0);
     if (WITH_DER) S1 = v_sfma(gd[m + 1], wb, S1);
+  }
+#endif
+}
+
+// All three parts in one pass over the taps (no g[] arrays): the register-lean form used by the
+// 16-wave (<= 128 VGPR) variants.
+template <bool WITH_DER, int VW>
+__device__ __forceinline__ void rbf_all(const float* wcol, const float2* tb, Vec<VW> (&S0)[3], Vec<VW> (&S1)[3]) {
+#pragma unroll
+  for (int p = 0; p < 3; ++p) { S0[p] = Vec<VW>::zero(); if (WITH_DER) S1[p] = Vec<VW>::zero(); }
+#pragma unroll
+  for (int m = 0; m < HN_TAPS; ++m) {
+    const float2 t = tb[m];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const Vec<VW> w = Vec<VW>::load(wcol + m * HN_LDS_ROW + p * HN_CB);
+      S0[p] = v_sfma(t.x, w, S0[p]);
+      if (WITH_DER) S1[p] = v_sfma(t.y, w, S1[p]);
+    }
   }
 }
 
@@ -273,11 +307,12 @@ struct FwdIn {
   bool live;
 };
 
-template <bool HAS_VEC, int NW, int VW, bool PF>
+template <bool HAS_VEC, int NW, int VW, bool PF, bool FUSED>
 __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(MsgArgs a) {
   extern __shared__ __align__(16) float lds[];
   float* wl = lds;
   float* mu = lds + (a.R + 2 * HN_PAD + 1) * HN_LDS_ROW;
+  float2* tapbase = reinterpret_cast<float2*>(mu + ((a.R + 2 * HN_PAD + 1 + 3) & ~3));
   constexpr int LPE = 64 / VW;   // lanes per edge
 
   const int cb = blockIdx.y;
@@ -302,6 +337,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
   const int wave = threadIdx.x >> 6;
   const int grp = lane / LPE;            // lane group = edge slot
   const int gl = lane % LPE;
+  float2* tb = tapbase + (wave * VW + grp) * 16;   // this lane group's tap scratch
   const int H = a.H;
   const int col = cb * HN_CB + VW * gl;  // first of this lane's VW channels
   const float inv_sqrt3h = 0.57735026918962576f * rsqrtf((float)H);  // (1/sqrt3)(1/sqrtH)
@@ -352,27 +388,30 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
         const float u = cur.g.w * a.inv_rc;
         const HnEnv env = hn_envelope(u, a.env_kind, a.env_p);
         const int lo = hn_window_lo(u, a.R);
-        float g[HN_TAPS], gd[HN_TAPS];
-        rbf_taps<false>(mu, lo, u, a.coeff, g, gd);
-        HN_SB;
         const float* wcol = wl + (lo + HN_PAD) * HN_LDS_ROW + VW * gl;
+        float g[HN_TAPS], gd[HN_TAPS];
+        Vec<VW> S0p[3], S1p[3];
+        coop_taps(mu, tb, lo, u, a.coeff, gl);
+        if (FUSED) rbf_all<false, VW>(wcol, tb, S0p, S1p);
+        else rbf_taps<false>(tb, g, gd);
+        HN_SB;
         // padding slots (segment length not a multiple of VW) contribute nothing: every term is
         // linear in rbfh = bias + env * S0 (rmnet.py:55), so scale it by 0 for them
         const float lv = cur.live ? 1.0f : 0.0f;
         const float ev = env.val * lv;
         Vec<VW> S0, S1;
         // message (rmnet.py:61-67), one part at a time to keep the register footprint small
-        rbf_part<false, VW>(wcol, g, gd, S0, S1);                               // part s -> dx
+        if (FUSED) S0 = S0p[0]; else rbf_part<false, VW>(wcol, g, gd, S0, S1);   // part s -> dx
         ax = v_fma(cur.xs, v_sfma(ev, S0, v_scale(bias[0], lv)), ax);
         HN_SB;
-        rbf_part<false, VW>(wcol + 2 * HN_CB, g, gd, S0, S1);                   // part b -> rhat term of dvec
+        if (FUSED) S0 = S0p[2]; else rbf_part<false, VW>(wcol + 2 * HN_CB, g, gd, S0, S1);   // part b -> rhat term
         const Vec<VW> mb = v_scale(v_mul(cur.xb, v_sfma(ev, S0, v_scale(bias[2], lv))), inv_sqrth);
         av[0] = v_sfma(cur.g.x, mb, av[0]);
         av[1] = v_sfma(cur.g.y, mb, av[1]);
         av[2] = v_sfma(cur.g.z, mb, av[2]);
         HN_SB;
         if (HAS_VEC) {
-          rbf_part<false, VW>(wcol + HN_CB, g, gd, S0, S1);                     // part a -> vec_j term of dvec
+          if (FUSED) S0 = S0p[1]; else rbf_part<false, VW>(wcol + HN_CB, g, gd, S0, S1);   // part a -> vec_j term
           const Vec<VW> ma = v_scale(v_mul(cur.xa, v_sfma(ev, S0, v_scale(bias[1], lv))), inv_sqrt3h);
 #pragma unroll
           for (int d = 0; d < 3; ++d) av[d] = v_fma(cur.vj[d], ma, av[d]);
@@ -419,11 +458,12 @@ struct BwdIn {
   bool live;
 };
 
-template <bool HAS_VEC, int NW, int VW, bool PF>
+template <bool HAS_VEC, int NW, int VW, bool PF, bool FUSED>
 __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(MsgArgs a) {
   extern __shared__ __align__(16) float lds[];
   float* wl = lds;
   float* mu = lds + (a.R + 2 * HN_PAD + 1) * HN_LDS_ROW;
+  float2* tapbase = reinterpret_cast<float2*>(mu + ((a.R + 2 * HN_PAD + 1 + 3) & ~3));
   constexpr int LPE = 64 / VW;
 
   const int cb = blockIdx.y;
@@ -433,6 +473,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
   const int wave = threadIdx.x >> 6;
   const int grp = lane / LPE;
   const int gl = lane % LPE;
+  float2* tb = tapbase + (wave * VW + grp) * 16;
   const int H = a.H;
   const int col = cb * HN_CB + VW * gl;
   const int nk = a.type_rowptr[a.T];     // rows below nk have a known type (are targets)
@@ -441,7 +482,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
   const float inv_sqrt2 = 0.70710678118654752f;
   float4* gedge = a.gedge + (size_t)cb * a.E;
 
-  for (int t = 0; t < a.T; ++t) {
+  const int t_lo = a.split_t ? blockIdx.z : 0, t_hi = a.split_t ? blockIdx.z + 1 : a.T;
+  for (int t = t_lo; t < t_hi; ++t) {
     __syncthreads();   // previous tile no longer in use
     stage_weights<NW * 64>(a, t, cb, wl, mu);
     __syncthreads();
@@ -495,10 +537,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
           const float u = g.w * a.inv_rc;
           const HnEnv env = hn_envelope(u, a.env_kind, a.env_p);
           const int lo = hn_window_lo(u, a.R);
-          float g_[HN_TAPS], gd_[HN_TAPS];
-          rbf_taps<true>(mu, lo, u, a.coeff, g_, gd_);
-          HN_SB;
           const float* wcol = wl + (lo + HN_PAD) * HN_LDS_ROW + VW * gl;
+          float g_[HN_TAPS], gd_[HN_TAPS];
+          Vec<VW> S0p[3], S1p[3];
+          coop_taps(mu, tb, lo, u, a.coeff, gl);
+          if (FUSED) rbf_all<true, VW>(wcol, tb, S0p, S1p);
+          else rbf_taps<true>(tb, g_, gd_);
+          HN_SB;
           // d rbfh / d d = inv_rc * (env' S0 + env * 2 coeff S1)
           const float c0 = a.inv_rc * env.der, c1 = a.inv_rc * env.val * 2.0f * a.coeff;
           const float rd[3] = {g.x, g.y, g.z};
@@ -509,7 +554,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
           Vec<VW> pdv;                       // partial dE/dd per channel
           Vec<VW> S0, S1;
           // ---- part s: dx = sum xs * rs
-          rbf_part<true, VW>(wcol, g_, gd_, S0, S1);
+          if (FUSED) { S0 = S0p[0]; S1 = S1p[0]; } else rbf_part<true, VW>(wcol, g_, gd_, S0, S1);
           {
             const Vec<VW> rs = v_sfma(env.val, S0, bias[0]);
             const Vec<VW> drs = v_sfma(c0, S0, v_scale(S1, c1));
@@ -519,7 +564,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
           HN_SB;
           // ---- part a: dvec += vec_j * (xa * ra) / sqrt(3H)
           if (HAS_VEC) {
-            rbf_part<true, VW>(wcol + HN_CB, g_, gd_, S0, S1);
+            if (FUSED) { S0 = S0p[1]; S1 = S1p[1]; } else rbf_part<true, VW>(wcol + HN_CB, g_, gd_, S0, S1);
             const Vec<VW> ra = v_sfma(env.val, S0, bias[1]);
             const Vec<VW> dra = v_sfma(c0, S0, v_scale(S1, c1));
             const Vec<VW> A = v_scale(v_fma(g0, vj[0], v_fma(g1, vj[1], v_mul(g2, vj[2]))), inv_sqrt3h);
@@ -534,7 +579,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
           // ---- part b: dvec += rhat * (xb * rb) / sqrt(H)
           Vec<VW> q;
           {
-            rbf_part<true, VW>(wcol + 2 * HN_CB, g_, gd_, S0, S1);
+            if (FUSED) { S0 = S0p[2]; S1 = S1p[2]; } else rbf_part<true, VW>(wcol + 2 * HN_CB, g_, gd_, S0, S1);
             const Vec<VW> rb = v_sfma(env.val, S0, bias[2]);
             const Vec<VW> drb = v_sfma(c0, S0, v_scale(S1, c1));
             const Vec<VW> B = v_scale(v_sfma(rd[0], g0, v_sfma(rd[1], g1, v_scale(g2, rd[2]))), inv_sqrth);
@@ -577,9 +622,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
           const size_t vo = ((size_t)r * 3 + d) * H + col;
           Vec<VW> prev;
           if (t == 0) prev = known ? Vec<VW>::load(a.gvec1 + vo) : Vec<VW>::zero();
+          else if (a.split_t) prev = Vec<VW>::zero();
           else prev = Vec<VW>::load(a.gvec + vo);
           const Vec<VW> add = d == 0 ? gv[0] : (d == 1 ? gv[1] : gv[2]);
-          v_add(prev, add).store(a.gvec + vo);
+          v_add(prev, add).store(a.gvec + (a.split_t ? (size_t)t * a.N * 3 * H : 0) + vo);
         }
       }
     }
@@ -598,7 +644,7 @@ int fill_args(const hn_graph* g, const hn_rbf_desc* rbf, int hidden, MsgArgs& a)
   return HN_OK;
 }
 
-// tuning knobs (environment, read once); variant = waves per workgroup * 100 + VW * 10 + prefetch
+// tuning knobs (environment, read once)
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -631,33 +677,40 @@ int pick_rows(int rows, int ncb, int slack, int override_rows) {
   return (int)rpb;
 }
 
+// LDS image: weight tile [rows][192] | tap centres mu [rows, padded to 4] | per-wave tap scratch
+// (float2 {g, g*diff} x 16 per lane group).
 size_t lds_bytes(int R) {
-  return (size_t)(R + 2 * HN_PAD + 1) * (HN_LDS_ROW + 1) * sizeof(float);
+  const size_t rows = (size_t)(R + 2 * HN_PAD + 1);
+  return (rows * HN_LDS_ROW + ((rows + 3) & ~(size_t)3)) * sizeof(float) + 16 * 4 * 16 * sizeof(float2);
 }
 
 typedef void (*kern_t)(MsgArgs);
 
+// variant = waves * 1000 + VW * 100 + prefetch * 10 + fused-tap-loop
 template <bool HAS_VEC>
 kern_t pick_fwd(int variant, int& nw) {
   switch (variant) {
-    case 1621: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, true>;
-    case 820:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 2, false>;
-    case 821:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 2, true>;
-    case 840:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, false>;
-    case 841:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, true>;
-    default:   nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, false>;   // 1620
+    case 16200: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, false, false>;
+    case 16201: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, false, true>;
+    case 16210: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, true, false>;
+    case 16211: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, true, true>;
+    case 8210:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 2, true, false>;
+    case 8400:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, false, false>;
+    default:    nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, true, false>;    // 8410
   }
 }
 
 template <bool HAS_VEC>
 kern_t pick_bwd(int variant, int& nw) {
   switch (variant) {
-    case 1621: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, true>;
-    case 820:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 2, false>;
-    case 821:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 2, true>;
-    case 840:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 4, false>;
-    case 841:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 4, true>;
-    default:   nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, false>;   // 1620
+    case 16200: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, false, false>;
+    case 16201: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, false, true>;
+    case 16210: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, true, false>;
+    case 16211: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, true, true>;
+    case 8400:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 4, false, false>;
+    case 8410:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 4, true, false>;
+    case 8201:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 2, false, true>;
+    default:    nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 2, true, false>;    // 8210
   }
 }
 
@@ -677,8 +730,8 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   a.x1 = x1; a.vec1 = vec1;
   static const int rpb_fwd = env_int("HERMNET_FWD_ROWS", 0);
   // defaults from tools/kbench.py on MI355X (config 2): see DESIGN.md "Kernel variants"
-  static const int variant_vec = env_int("HERMNET_FWD_VARIANT", 841);
-  static const int variant_l0 = env_int("HERMNET_FWD_VARIANT_L0", 840);
+  static const int variant_vec = env_int("HERMNET_FWD_VARIANT", 8410);
+  static const int variant_l0 = env_int("HERMNET_FWD_VARIANT_L0", 8400);
   const int variant = vec ? variant_vec : variant_l0;
   a.rows_per_block = pick_rows(a.N, hidden / HN_CB, a.T * (hidden / HN_CB), rpb_fwd);
   const size_t lds = lds_bytes(a.R);
@@ -699,7 +752,7 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
                                            const float* wt, const float* brbf, const float* edge,
                                            const float* gx1, const float* gvec1,
                                            float* gxh, float* gvec, float* gx, float* gedge,
-                                           void* stream) {
+                                           int split_t, void* stream) {
   MsgArgs a = {};
   int rc = fill_args(g, rbf, hidden, a);
   if (rc) return rc;
@@ -712,13 +765,15 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   a.gx1 = gx1; a.gvec1 = gvec1; a.gxh = gxh; a.gvec = gvec; a.gx = gx;
   a.gedge = reinterpret_cast<float4*>(gedge);
   static const int rpb_bwd = env_int("HERMNET_BWD_ROWS", 0);
-  static const int variant_vec = env_int("HERMNET_BWD_VARIANT", 821);
-  static const int variant_l0 = env_int("HERMNET_BWD_VARIANT_L0", 840);
+  static const int variant_vec = env_int("HERMNET_BWD_VARIANT", 16201);
+  static const int variant_l0 = env_int("HERMNET_BWD_VARIANT_L0", 16201);
   const int variant = vec ? variant_vec : variant_l0;
-  a.rows_per_block = pick_rows(a.N, hidden / HN_CB, 0, rpb_bwd);
+  a.split_t = split_t ? 1 : 0;
+  a.rows_per_block = pick_rows(a.N, (hidden / HN_CB) * (a.split_t ? a.T : 1), 0, rpb_bwd) * (a.split_t ? a.T : 1);
   const size_t lds = lds_bytes(a.R);
   if (lds > 160 * 1024) return HN_ERR_LDS;
-  dim3 grid((unsigned)((a.N + a.rows_per_block - 1) / a.rows_per_block), (unsigned)(hidden / HN_CB));
+  dim3 grid((unsigned)((a.N + a.rows_per_block - 1) / a.rows_per_block), (unsigned)(hidden / HN_CB),
+            (unsigned)(a.split_t ? a.T : 1));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int nw = 16;
   kern_t k = vec ? pick_bwd<true>(variant, nw) : pick_bwd<false>(variant, nw);

@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import _lib, nodeops
-from .ops import _launch, _stream
+from .ops import _launch, _split_t, _stream
 
 P = _lib.ptr
 
@@ -76,15 +76,19 @@ def _msg_fwd(graph, rbf, H, xh, vec, x, w, edge):
 def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1):
     lib = _lib.load()
     gxh = torch.empty_like(xh)
-    gvec = None if vec is None else torch.empty_like(vec)
+    split = _split_t(graph)
+    gvec = None if vec is None else (torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
+                                     if split else torch.empty_like(vec))
     gx = torch.empty_like(gx1)
     gedge = torch.zeros(H // 64, graph.E, 4, dtype=torch.float32, device=gx1.device)
     gs, rs = graph.as_struct(), rbf.struct()
     _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"),
                        lambda: lib.hermnet_message_scatter_bwd(
                            ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(vec), P(w.wt), P(w.brbf), P(edge),
-                           P(gx1), P(gvec1), P(gxh), P(gvec), P(gx), P(gedge), _stream())),
+                           P(gx1), P(gvec1), P(gxh), P(gvec), P(gx), P(gedge), split, _stream())),
                "hermnet_message_scatter_bwd")
+    if split and gvec is not None:
+        gvec = gvec.sum(0)
     return gxh, gvec, gx, gedge
 
 

@@ -71,6 +71,12 @@ class RbfDescriptor(object):
                             self.env_kind, self.env_p)
 
 
+def _split_t(graph):
+    """One relation per workgroup in the backward message kernel (env HERMNET_BWD_SPLIT_T, default on for T > 1)."""
+    import os
+    return int(graph.T > 1 and os.environ.get("HERMNET_BWD_SPLIT_T", "0") != "0")
+
+
 class EdgeGeometry(torch.autograd.Function):
     """`HVNet.with_edge` (hermnet.py:133-152) -> edge[E,4] = (rhat, d) in CSR order."""
 
@@ -152,12 +158,16 @@ class MessageScatter(torch.autograd.Function):
         gx1 = gx1.contiguous()
         gvec1 = gvec1.contiguous()
         gxh = torch.empty_like(xh)
-        gvec = None if vec is None else torch.empty_like(vec)
+        split = _split_t(graph)
+        gvec = None if vec is None else (torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
+                                         if split else torch.empty_like(vec))
         gx = torch.empty_like(gx1)
         gedge = torch.zeros(H // 64, graph.E, 4, dtype=torch.float32, device=gx1.device)
         gs, rs = graph.as_struct(), rbf.struct()
         _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"), lambda: lib.hermnet_message_scatter_bwd(
             ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), _lib.ptr(vec), _lib.ptr(wt), _lib.ptr(brbf),
             _lib.ptr(edge), _lib.ptr(gx1), _lib.ptr(gvec1), _lib.ptr(gxh), _lib.ptr(gvec), _lib.ptr(gx),
-            _lib.ptr(gedge), _stream())), "hermnet_message_scatter_bwd")
+            _lib.ptr(gedge), split, _stream())), "hermnet_message_scatter_bwd")
+        if split and gvec is not None:
+            gvec = gvec.sum(0)
         return gxh, gvec, gx, gedge.sum(0), None, None, None, None

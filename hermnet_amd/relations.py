@@ -63,7 +63,7 @@ class RelationalGraph(object):
         g.type_rowptr_host = starts[:T + 1]
 
         ar = torch.arange(NA, device=dev)
-        g.node_order = torch.argsort(rel * NA + ar)             # atoms sorted by (relation, id)
+        g.node_order = torch.sort(rel.to(torch.int32), stable=True).indices   # atoms sorted by (relation, id)
         first_sorted = torch.zeros(T + 1, dtype=torch.long, device=dev)
         first_sorted[1:] = torch.cumsum(counts[:T], 0)          # position of each relation in the sorted list
         starts_d = torch.tensor(starts, dtype=torch.long, device=dev)
@@ -86,16 +86,20 @@ class RelationalGraph(object):
 
         src, tgt = edge_index[0].long(), edge_index[1].long()
         rs, rt = g.row_of_node[src], g.row_of_node[tgt]
-        rt_s, csr_perm = torch.sort(rt, stable=True)
+        i32k = torch.int32 if (T + 1) * N < 2 ** 31 else torch.long   # narrow keys: half the radix passes
+        rt_s, csr_perm = torch.sort(rt.to(i32k), stable=True)
+        rt_s = rt_s.long()
         csr_src = rs[csr_perm]
         csr_rowptr = rowptr_of(rt_s, N)
 
         key2 = rel_row[rt_s] * N + csr_src                      # (relation(target), row(source))
-        key2_s, csc_pos = torch.sort(key2, stable=True)
+        key2_s, csc_pos = torch.sort(key2.to(i32k), stable=True)
+        key2_s = key2_s.long()
         csc_tgt = rt_s[csc_pos]
         csc_rowptr = rowptr_of(key2_s, T * N)
 
-        src_s, out_edges = torch.sort(csr_src, stable=True)
+        src_s, out_edges = torch.sort(csr_src.to(i32k), stable=True)
+        src_s = src_s.long()
         out_rowptr = rowptr_of(src_s, N)
 
         # hermnet.py:56-57: a relation without edges is skipped -> its rows stay zero; rows of

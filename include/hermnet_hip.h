@@ -106,12 +106,15 @@ int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc* rbf, int h
  * in : gx1 [N,H], gvec1 [N,3,H] (gradients w.r.t. x1, vec1) + the forward inputs
  * out: gxh [T,N,3H], gvec [N,3,H] (NULL allowed when vec was NULL), gx [N,H],
  *      gedge [H/64, E, 4]: per 64-channel column block, Cartesian gradient w.r.t. the edge
- *      vector D in CSR order (caller sums over the leading axis; buffer must be zero-filled). */
+ *      vector D in CSR order (caller sums over the leading axis; buffer must be zero-filled).
+ * split_t = 0: one workgroup walks all relations, gvec is [N,3,H];
+ * split_t = 1: one relation per workgroup (3-D grid, better balance), gvec is [T,N,3,H] partial
+ *              sums (slice 0 carries the residual's identity term), the caller sums over T. */
 int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc* rbf, int hidden,
                                 const float* xh, const float* vec,
                                 const float* wt, const float* brbf, const float* edge,
                                 const float* gx1, const float* gvec1,
-                                float* gxh, float* gvec, float* gx, float* gedge, void* stream);
+                                float* gxh, float* gvec, float* gx, float* gedge, int split_t, void* stream);
 
 /* ---- node-level fused elementwise stages (A11/A12; the GEMMs between them are library calls) ----
  * ScaledSiLU (rmnet.py:110-117): a = silu(h)/0.6 over `numel` contiguous floats (multiple of 4). */

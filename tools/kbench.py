@@ -32,7 +32,9 @@ def main():
     wt, brbf = rnd(T, R, 3 * H) / 11.3, rnd(T, 3 * H) * 0.1
     x1, vec1 = torch.empty_like(x), torch.empty_like(vec)
     gx1, gvec1 = rnd(N, H), rnd(N, 3, H)
-    gxh, gvec, gx = torch.empty_like(xh), torch.empty_like(vec), torch.empty_like(x)
+    split = int(os.environ.get("HERMNET_BWD_SPLIT_T", "0") != "0")
+    gxh, gx = torch.empty_like(xh), torch.empty_like(x)
+    gvec = torch.empty(T, N, 3, H, device=dev) if split else torch.empty_like(vec)
     gedge = torch.zeros(H // 64, E, 4, device=dev)
     gs, rs = g.as_struct(), rbf.struct()
     P = _lib.ptr
@@ -44,7 +46,7 @@ def main():
     def bwd(v):
         return lib.hermnet_message_scatter_bwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(v), P(wt), P(brbf), P(edge),
                                                P(gx1), P(gvec1), P(gxh), P(gvec if v is not None else None), P(gx),
-                                               P(gedge), _stream())
+                                               P(gedge), split, _stream())
 
     ab = algorithmic_bytes(E, N, H, T)
     res = {}
