@@ -28,6 +28,12 @@ class Graph(ctypes.Structure):
                 ("csc_rowptr", c_fp), ("csc_tgt", c_fp), ("csc_pos", c_fp)]
 
 
+class RelationsOut(ctypes.Structure):
+    _fields_ = [(n, c_fp) for n in ("node_order", "row_of_node", "z_rows", "row_real", "row_active", "csr_rowptr",
+                                    "csr_src", "csr_perm", "src_id", "tgt_id", "shift_csr", "csc_rowptr", "csc_tgt",
+                                    "csc_pos", "out_rowptr", "out_edges")]
+
+
 # name -> (restype, argtypes); mirrors include/hermnet_hip.h one to one
 SIGNATURES = {
     "hermnet_abi_version": (ctypes.c_int, []),
@@ -39,6 +45,11 @@ SIGNATURES = {
     "hermnet_message_scatter_bwd": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), ctypes.c_int,
                                                    c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                                    c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
+    "hermnet_relation_counts": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp]),
+    "hermnet_build_relations_workspace": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "hermnet_build_relations": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_int,
+                                               c_fp, ctypes.c_int, c_fp, ctypes.POINTER(RelationsOut), c_fp,
+                                               ctypes.c_size_t, c_fp]),
     "hermnet_ssilu_fwd": (ctypes.c_int, [c_fp, c_fp, ctypes.c_long, c_fp]),
     "hermnet_ssilu_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_long, ctypes.c_long, c_fp]),

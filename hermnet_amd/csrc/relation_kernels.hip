@@ -1,0 +1,232 @@
+// gfx950 device-side construction of the relation-ordered graph: the build's replacement for
+// `in_subgraph` (/root/reference/HermNet/utils.py:11-24, called per relation per layer at
+// hermnet.py:52-54).  Instead of N_t O(E) scans per relation per layer, the edge list is sorted
+// three times per neighbour list with a stable LSD radix sort (hipCUB / rocPRIM, keys of
+// ceil(log2 N) bits) and the row pointers come from binary searches -- ~25 launches, no host sync,
+// everything int32.  HBM-streaming integer work: E * ~100 B.
+//
+// Orders produced (see include/hermnet_hip.h):
+//   rows : atoms sorted by (relation, id), each relation's block starting at row_start[t]
+//   CSR  : edges by (row(target), edge id)
+//   CSC  : edges by (relation(target), row(source), CSR position)
+//   out  : CSR positions by row(source)
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include "../../include/hermnet_hip.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+inline dim3 grid_for(long n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+__device__ __forceinline__ int relation_of(long z, const int* __restrict__ zlist, int T) {
+  for (int t = 0; t < T; ++t)
+    if ((long)zlist[t] == z) return t;     // first matching element; T = "not in elems" (hermnet.py:53)
+  return T;
+}
+
+__global__ __launch_bounds__(kBlock) void count_relations_kernel(const long* __restrict__ z, int NA,
+                                                                const int* __restrict__ zlist, int T,
+                                                                int* __restrict__ counts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < NA) atomicAdd(&counts[relation_of(z[i], zlist, T)], 1);   // integer atomics: exact, order-free
+}
+
+__global__ __launch_bounds__(kBlock) void atom_keys_kernel(const long* __restrict__ z, int NA,
+                                                          const int* __restrict__ zlist, int T,
+                                                          unsigned* __restrict__ key, int* __restrict__ val) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < NA) { key[i] = (unsigned)relation_of(z[i], zlist, T); val[i] = i; }
+}
+
+// sorted position p -> row = p - first_sorted[rel] + row_start[rel]
+__global__ __launch_bounds__(kBlock) void assign_rows_kernel(
+    const unsigned* __restrict__ rel_sorted, const int* __restrict__ node_order, int NA,
+    const int* __restrict__ row_start, int T, const long* __restrict__ z, int* __restrict__ row_of_node,
+    int* __restrict__ z_rows, float* __restrict__ row_real) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= NA) return;
+  const int rel = (int)rel_sorted[p];
+  // first sorted position of this relation = number of sorted entries with a smaller relation:
+  // binary search on the sorted relation list
+  int lo = 0, hi = NA;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)rel_sorted[mid] < rel) lo = mid + 1; else hi = mid; }
+  const int atom = node_order[p];
+  const int row = p - lo + row_start[rel];
+  row_of_node[atom] = row;
+  z_rows[row] = (int)z[atom];
+  row_real[row] = 1.0f;
+}
+
+__global__ __launch_bounds__(kBlock) void edge_keys_kernel(const long* __restrict__ edge_index, int E,
+                                                          const int* __restrict__ row_of_node,
+                                                          unsigned* __restrict__ key, int* __restrict__ val) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < E) { key[e] = (unsigned)row_of_node[edge_index[(size_t)E + e]]; val[e] = e; }   // row(target)
+}
+
+__device__ __forceinline__ int relation_of_row(int row, const int* __restrict__ row_start, int T) {
+  int t = 0;
+  while (t < T && row >= row_start[t + 1]) ++t;   // row_start[T] = first unknown row
+  return t;
+}
+
+// CSR-ordered per-edge arrays + the CSC sort key
+__global__ __launch_bounds__(kBlock) void csr_gather_kernel(
+    const long* __restrict__ edge_index, const float* __restrict__ shift, int E, int N, int T,
+    const int* __restrict__ row_of_node, const int* __restrict__ row_start,
+    const unsigned* __restrict__ rt_sorted, const int* __restrict__ csr_perm, int* __restrict__ csr_src,
+    int* __restrict__ src_id, int* __restrict__ tgt_id, float* __restrict__ shift_csr,
+    unsigned* __restrict__ key2, unsigned* __restrict__ key3, int* __restrict__ pos) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= E) return;
+  const int e = csr_perm[k];
+  const int s = (int)edge_index[e], t = (int)edge_index[(size_t)E + e];
+  const int rs = row_of_node[s];
+  csr_src[k] = rs;
+  src_id[k] = s;
+  tgt_id[k] = t;
+  if (shift != nullptr) {
+    shift_csr[3 * k + 0] = shift[3 * e + 0];
+    shift_csr[3 * k + 1] = shift[3 * e + 1];
+    shift_csr[3 * k + 2] = shift[3 * e + 2];
+  }
+  key2[k] = (unsigned)relation_of_row((int)rt_sorted[k], row_start, T) * (unsigned)N + (unsigned)rs;
+  key3[k] = (unsigned)rs;
+  pos[k] = k;
+}
+
+// rowptr[r] = number of sorted keys < r  (r = 0..nrows)
+__global__ __launch_bounds__(kBlock) void rowptr_kernel(const unsigned* __restrict__ sorted, int n, int nrows,
+                                                       int* __restrict__ rowptr) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nrows) return;
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted[mid] < (unsigned)r) lo = mid + 1; else hi = mid; }
+  rowptr[r] = lo;
+}
+
+__global__ __launch_bounds__(kBlock) void csc_tgt_kernel(const unsigned* __restrict__ rt_sorted,
+                                                        const int* __restrict__ csc_pos, int E,
+                                                        int* __restrict__ csc_tgt) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < E) csc_tgt[k] = (int)rt_sorted[csc_pos[k]];
+}
+
+// row_active = real row of a relation that receives >= 1 edge (hermnet.py:56-57), or the caller's override
+__global__ __launch_bounds__(kBlock) void row_active_kernel(const int* __restrict__ csc_rowptr,
+                                                           const int* __restrict__ row_start, int N, int T,
+                                                           const unsigned char* __restrict__ rel_active,
+                                                           const float* __restrict__ row_real,
+                                                           float* __restrict__ row_active) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  const int t = relation_of_row(r, row_start, T);
+  float on = 0.0f;
+  if (t < T) {
+    const bool act = rel_active ? rel_active[t] != 0
+                                : (csc_rowptr[(size_t)(t + 1) * N] - csc_rowptr[(size_t)t * N]) > 0;
+    on = act ? row_real[r] : 0.0f;
+  }
+  row_active[r] = on;
+}
+
+int bits_for(unsigned max_key_exclusive) {
+  int b = 1;
+  while (b < 32 && (1u << b) < max_key_exclusive) ++b;
+  return b;
+}
+
+size_t sort_temp_bytes(int n) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr,
+                                           (const int*)nullptr, (int*)nullptr, n, 0, 32, (hipStream_t)0);
+  return bytes;
+}
+
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" int hermnet_relation_counts(const long* atomic_number, int num_atoms, const int* z_list, int num_rel,
+                                       int* counts, void* stream) {
+  if (num_atoms < 0 || num_rel <= 0 || !z_list || !counts) return HN_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(counts, 0, sizeof(int) * (num_rel + 1), s) != hipSuccess) return HN_ERR_LAUNCH;
+  if (num_atoms == 0) return HN_OK;
+  if (!atomic_number) return HN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(count_relations_kernel, grid_for(num_atoms), dim3(kBlock), 0, s, atomic_number, num_atoms,
+                     z_list, num_rel, counts);
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}
+
+extern "C" size_t hermnet_build_relations_workspace(int num_atoms, int num_rows, int num_edges, int num_rel) {
+  (void)num_rows; (void)num_rel;
+  const size_t n = (size_t)(num_edges > num_atoms ? num_edges : num_atoms) + 1;
+  // 2 key buffers + 2 value buffers (ping-pong) + 1 extra key (source rows) + the sort's own storage
+  return align256(sort_temp_bytes((int)n)) + 5 * align256(n * sizeof(unsigned)) + 256;
+}
+
+extern "C" int hermnet_build_relations(const long* atomic_number, const long* edge_index, const float* shift,
+                                       int num_atoms, int num_edges, const int* z_list, int num_rel,
+                                       const int* row_start, int num_rows,
+                                       const unsigned char* rel_active, const hn_relations_out* out,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  const int NA = num_atoms, E = num_edges, T = num_rel, N = num_rows;
+  if (NA < 0 || E < 0 || T <= 0 || N < NA || !out || !z_list || !row_start) return HN_ERR_BAD_ARG;
+  if ((size_t)(T + 1) * (size_t)N >= 0xFFFFFFFFull) return HN_ERR_BAD_ARG;   // keys are 32-bit
+  if (workspace_bytes < hermnet_build_relations_workspace(NA, N, E, T) || !workspace) return HN_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t n = (size_t)(E > NA ? E : NA) + 1;
+  char* w = reinterpret_cast<char*>(workspace);
+  const size_t tb = align256(sort_temp_bytes((int)n));
+  void* temp = w; w += tb;
+  unsigned* keyA = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
+  unsigned* keyB = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
+  int* valA = reinterpret_cast<int*>(w); w += align256(n * sizeof(unsigned));
+  unsigned* key3 = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
+  unsigned* rt_sorted = reinterpret_cast<unsigned*>(w);
+  size_t tbytes = tb;
+
+  // ---- rows
+  if (hipMemsetAsync(out->z_rows, 0, sizeof(int) * N, s) != hipSuccess) return HN_ERR_LAUNCH;
+  if (hipMemsetAsync(out->row_real, 0, sizeof(float) * N, s) != hipSuccess) return HN_ERR_LAUNCH;
+  if (NA > 0) {
+    hipLaunchKernelGGL(atom_keys_kernel, grid_for(NA), dim3(kBlock), 0, s, atomic_number, NA, z_list, T, keyA, valA);
+    if (hipcub::DeviceRadixSort::SortPairs(temp, tbytes, keyA, keyB, valA, out->node_order, NA, 0, bits_for(T + 1), s)
+        != hipSuccess) return HN_ERR_LAUNCH;
+    hipLaunchKernelGGL(assign_rows_kernel, grid_for(NA), dim3(kBlock), 0, s, keyB, out->node_order, NA, row_start,
+                       T, atomic_number, out->row_of_node, out->z_rows, out->row_real);
+  }
+  // ---- CSR by (row(target), edge id)
+  if (E > 0) {
+    hipLaunchKernelGGL(edge_keys_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, E, out->row_of_node, keyA, valA);
+    tbytes = tb;
+    if (hipcub::DeviceRadixSort::SortPairs(temp, tbytes, keyA, rt_sorted, valA, out->csr_perm, E, 0,
+                                           bits_for((unsigned)N), s) != hipSuccess) return HN_ERR_LAUNCH;
+    hipLaunchKernelGGL(csr_gather_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, shift, E, N, T,
+                       out->row_of_node, row_start, rt_sorted, out->csr_perm, out->csr_src, out->src_id,
+                       out->tgt_id, out->shift_csr, keyA, key3, valA);
+  }
+  hipLaunchKernelGGL(rowptr_kernel, grid_for(N + 1), dim3(kBlock), 0, s, rt_sorted, E, N, out->csr_rowptr);
+  // ---- CSC by (relation(target), row(source), CSR position)
+  if (E > 0) {
+    tbytes = tb;
+    if (hipcub::DeviceRadixSort::SortPairs(temp, tbytes, keyA, keyB, valA, out->csc_pos, E, 0,
+                                           bits_for((unsigned)((T + 1) * (size_t)N)), s) != hipSuccess)
+      return HN_ERR_LAUNCH;
+    hipLaunchKernelGGL(csc_tgt_kernel, grid_for(E), dim3(kBlock), 0, s, rt_sorted, out->csc_pos, E, out->csc_tgt);
+  }
+  hipLaunchKernelGGL(rowptr_kernel, grid_for((long)T * N + 1), dim3(kBlock), 0, s, keyB, E, T * N, out->csc_rowptr);
+  // ---- out adjacency by row(source)
+  if (E > 0) {
+    tbytes = tb;
+    if (hipcub::DeviceRadixSort::SortPairs(temp, tbytes, key3, keyB, valA, out->out_edges, E, 0,
+                                           bits_for((unsigned)N), s) != hipSuccess) return HN_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(rowptr_kernel, grid_for(N + 1), dim3(kBlock), 0, s, keyB, E, N, out->out_rowptr);
+  hipLaunchKernelGGL(row_active_kernel, grid_for(N), dim3(kBlock), 0, s, out->csc_rowptr, row_start, N, T,
+                     rel_active, out->row_real, out->row_active);
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}

@@ -10,7 +10,11 @@ plus the out-adjacency by source row for the position gradient.  All index
 arrays are int32 device tensors.  One small D2H copy (T+1 row offsets and T edge
 counts) tells the host where each relation's rows start.
 """
+import os
+
 import torch
+
+_COUNT_CACHE = {}
 
 
 class RelationalGraph(object):
@@ -29,7 +33,96 @@ class RelationalGraph(object):
     def build(atomic_number, edge_index, z_list, edge_shift=None, batch=None, rel_active=None, uniform=None):
         """atomic_number [N] int, edge_index [2,E] int (row 0 = source, row 1 = target,
         `hermnet.py:135`), z_list: atomic numbers of the model's elements in module order.
-        `uniform`: None = automatic (padding overhead <= 15 %), True/False = forced."""
+        `uniform`: None = automatic (padding overhead <= 15 %), True/False = forced.
+
+        GPU tensors take the device-side build (`csrc/relation_kernels.hip`); host tensors (tests,
+        planning) take the PyTorch restatement below, which defines the expected result bit for bit."""
+        if atomic_number.is_cuda and os.environ.get("HERMNET_NATIVE_RELATIONS", "1") != "0":
+            return RelationalGraph._build_native(atomic_number, edge_index, z_list, edge_shift, batch, rel_active,
+                                                 uniform)
+        return RelationalGraph._build_torch(atomic_number, edge_index, z_list, edge_shift, batch, rel_active, uniform)
+
+    @staticmethod
+    def _layout(cnt_host, T, uniform):
+        known = sum(cnt_host[:T])
+        block = max(cnt_host[:T]) if T > 0 else 0
+        if uniform is None:
+            uniform = T > 1 and T * block <= 1.15 * known + 64
+        uniform = bool(uniform) or T == 1
+        if uniform:
+            starts = [t * block for t in range(T)] + [T * block]
+        else:
+            starts, block = [0], 0
+            for t in range(T):
+                starts.append(starts[-1] + cnt_host[t])
+        return uniform, block, starts, starts[T] + cnt_host[T]
+
+    @staticmethod
+    def _build_native(atomic_number, edge_index, z_list, edge_shift, batch, rel_active, uniform):
+        import ctypes
+        from . import _lib
+        from .ops import _stream
+        lib = _lib.load()
+        g = RelationalGraph()
+        dev = atomic_number.device
+        NA, E, T = int(atomic_number.numel()), int(edge_index.size(1)), len(z_list)
+        g.num_atoms, g.E, g.T, g.device = NA, E, T, dev
+        z = atomic_number.long().contiguous()
+        ei = edge_index.long().contiguous()
+        i32, P = torch.int32, _lib.ptr
+        # element counts and graph count: a host sync, skipped while the same tensors are passed again
+        # (atom types and batch assignment do not change along an MD trajectory)
+        key = (z.data_ptr(), z._version, NA, tuple(z_list),
+               None if batch is None else (batch.data_ptr(), batch._version))
+        hit = _COUNT_CACHE.get(key)
+        if hit is None:
+            zl = torch.tensor(list(z_list), dtype=i32, device=dev)
+            counts = torch.empty(T + 1, dtype=i32, device=dev)
+            _lib.check(lib.hermnet_relation_counts(P(z), NA, P(zl), T, P(counts), _stream()), "hermnet_relation_counts")
+            nb = batch.long().max().reshape(1) + 1 if (batch is not None and NA > 0) else torch.ones(1, dtype=torch.long, device=dev)
+            host = torch.cat([counts.long(), nb]).cpu().tolist()
+            hit = (zl, host[:T + 1], int(host[-1]))
+            if len(_COUNT_CACHE) > 16:
+                _COUNT_CACHE.clear()
+            _COUNT_CACHE[key] = hit
+        zl, cnt_host, g.num_graphs = hit
+        g.uniform, g.block, starts, N = RelationalGraph._layout(cnt_host, T, uniform)
+        g.N, g.type_rowptr_host = N, starts[:T + 1]
+        g.type_rowptr = torch.tensor(starts[:T + 1], dtype=i32, device=dev)
+        e32 = lambda n: torch.empty(n, dtype=i32, device=dev)
+        g.node_order, g.row_of_node, z_rows = e32(NA), e32(NA), e32(N)
+        g.row_real = torch.empty(N, dtype=torch.float32, device=dev)
+        g.row_active = torch.empty(N, dtype=torch.float32, device=dev)
+        g.csr_rowptr, g.csr_src, g.csr_perm, g.src_id, g.tgt_id = e32(N + 1), e32(E), e32(E), e32(E), e32(E)
+        g.csc_rowptr, g.csc_tgt, g.csc_pos = e32(T * N + 1), e32(E), e32(E)
+        g.out_rowptr, g.out_edges = e32(N + 1), e32(E)
+        shift = None if edge_shift is None else edge_shift.float().contiguous()
+        g.shift = None if shift is None else torch.empty(E, 3, dtype=torch.float32, device=dev)
+        act = None if rel_active is None else torch.tensor([bool(a) for a in rel_active], dtype=torch.uint8, device=dev)
+        wbytes = lib.hermnet_build_relations_workspace(NA, N, E, T)
+        work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        out = _lib.RelationsOut(P(g.node_order), P(g.row_of_node), P(z_rows), P(g.row_real), P(g.row_active),
+                                P(g.csr_rowptr), P(g.csr_src), P(g.csr_perm), P(g.src_id), P(g.tgt_id), P(g.shift),
+                                P(g.csc_rowptr), P(g.csc_tgt), P(g.csc_pos), P(g.out_rowptr), P(g.out_edges))
+        _lib.check(lib.hermnet_build_relations(P(z), P(ei), P(shift), NA, E, P(zl), T, P(g.type_rowptr), N, P(act),
+                                               ctypes.byref(out), P(work), wbytes, _stream()),
+                   "hermnet_build_relations")
+        g.z_rows = z_rows.long()
+        g.row_of_node = g.row_of_node.long()      # used as a gather index by the host code
+        g.node_order = g.node_order.long()
+        g.batch32 = None if batch is None else batch.to(i32).contiguous()
+        g.batch_rows = None
+        if batch is not None and g.num_graphs > 1:
+            g.graph_perm = torch.argsort(batch.long(), stable=True)
+            g.graph_lengths = torch.zeros(g.num_graphs, dtype=torch.long, device=dev).index_add_(
+                0, batch.long(), torch.ones_like(batch.long()))
+        else:
+            g.graph_perm = None
+            g.graph_lengths = None
+        return g
+
+    @staticmethod
+    def _build_torch(atomic_number, edge_index, z_list, edge_shift=None, batch=None, rel_active=None, uniform=None):
         g = RelationalGraph()
         dev = atomic_number.device
         NA = int(atomic_number.numel())
@@ -45,21 +138,8 @@ class RelationalGraph(object):
         nb = batch.long().max().reshape(1) + 1 if (batch is not None and NA > 0) else torch.ones(1, dtype=torch.long, device=dev)
         host = torch.cat([counts, nb]).cpu().tolist()          # the one host sync of the build
         cnt_host, g.num_graphs = host[:T + 1], int(host[-1])
-        known = sum(cnt_host[:T])
-        block = max(cnt_host[:T]) if T > 0 else 0
-        if uniform is None:
-            uniform = T > 1 and T * block <= 1.15 * known + 64
-        g.uniform = bool(uniform) or T == 1
-        if g.uniform:
-            starts = [t * block for t in range(T)] + [T * block]
-            g.block = block
-        else:
-            starts = [0]
-            for t in range(T):
-                starts.append(starts[-1] + cnt_host[t])
-            g.block = 0
-        N = starts[T] + cnt_host[T]                             # rows (>= atoms when padded)
-        g.N = N
+        g.uniform, g.block, starts, N = RelationalGraph._layout(cnt_host, T, uniform)
+        g.N = N                                                 # rows (>= atoms when padded)
         g.type_rowptr_host = starts[:T + 1]
 
         ar = torch.arange(NA, device=dev)

@@ -26,6 +26,8 @@
 #ifndef HERMNET_HIP_H
 #define HERMNET_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -67,6 +69,40 @@ typedef struct hn_graph {
   const int* csc_tgt;         /* [E]    target row of each CSC edge */
   const int* csc_pos;         /* [E]    CSR position of each CSC edge */
 } hn_graph;
+
+/* ---- A13: in_subgraph (utils.py:11-24) replaced by a one-off device-side build of the relation-ordered
+ * graph per neighbour list (three stable radix sorts + binary-searched row pointers, no host sync).
+ * Step 1 counts the atoms of each relation (counts[T+1] device ints, last = element not in z_list);
+ * the host turns the counts into the row layout `row_start[T+1]` (first row of every relation block,
+ * then the first row of the unknown-element atoms) and `num_rows`; step 2 fills `out`. */
+typedef struct hn_relations_out {
+  int* node_order;    /* [NA]    atoms sorted by (relation, id) */
+  int* row_of_node;   /* [NA]    row of every atom */
+  int* z_rows;        /* [N]     atomic number per row (0 for padding rows) */
+  float* row_real;    /* [N]     1 for rows that hold an atom */
+  float* row_active;  /* [N]     1 for real rows of relations that receive edges (hermnet.py:56-57) */
+  int* csr_rowptr;    /* [N+1] */
+  int* csr_src;       /* [E]     source row, CSR order */
+  int* csr_perm;      /* [E]     original edge id of each CSR edge */
+  int* src_id;        /* [E]     original source / target atom ids in CSR order (edge geometry) */
+  int* tgt_id;        /* [E] */
+  float* shift_csr;   /* [E,3]   edge_shift in CSR order (ignored when `shift` is NULL) */
+  int* csc_rowptr;    /* [T*N+1] */
+  int* csc_tgt;       /* [E] */
+  int* csc_pos;       /* [E] */
+  int* out_rowptr;    /* [N+1]   edges by source row (position gradient) */
+  int* out_edges;     /* [E]     CSR positions */
+} hn_relations_out;
+
+int hermnet_relation_counts(const long* atomic_number, int num_atoms, const int* z_list, int num_rel,
+                            int* counts, void* stream);
+size_t hermnet_build_relations_workspace(int num_atoms, int num_rows, int num_edges, int num_rel);
+/* edge_index [2,E] int64 (row 0 = source, row 1 = target, hermnet.py:135); shift [E,3] or NULL;
+ * rel_active [T] bytes or NULL (NULL: a relation is active iff it receives at least one edge). */
+int hermnet_build_relations(const long* atomic_number, const long* edge_index, const float* shift,
+                            int num_atoms, int num_edges, const int* z_list, int num_rel,
+                            const int* row_start, int num_rows, const unsigned char* rel_active,
+                            const hn_relations_out* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- A2: HVNet.with_edge (hermnet.py:133-152) -------------------------------------------
  * edge[e] = (rx, ry, rz, d) for CSR edge e, D = pos[src] - pos[tgt] (+ shift @ cell[batch[src]]),

@@ -272,3 +272,37 @@ def test_calculator_plugin_energy_forces_virial(name):
     assert rel_err(torch.from_numpy(calc.results["forces"]), f) < TOL
     assert rel_err(torch.from_numpy(np.asarray(calc.results["stress"], dtype="float32")), vv) < 5e-5
     assert calc.results["free_energy"] == calc.results["energy"]
+
+
+@pytest.mark.parametrize("name", ["c1_si64", "alloy108", "alloy108_unknown_type", "mol16"])
+@pytest.mark.parametrize("uniform", [None, False, True])
+def test_native_relation_build_is_bit_exact(name, uniform, monkeypatch):
+    """Device-side relation build (csrc/relation_kernels.hip) vs the PyTorch restatement: every
+    index array identical (integer work: bit-exact is the bar)."""
+    dev = _dev()
+    g = Golden(name)
+    d = g.data().to(dev)
+    zl = [atomic_numbers[e] for e in g.elems]
+    shift = d.get("edge_shift") if d.get("cell") is not None else None
+    nat = RelationalGraph.build(d.atomic_number, d.edge_index, zl, shift, d.batch, uniform=uniform)
+    ref = RelationalGraph._build_torch(d.atomic_number, d.edge_index, zl, shift, d.batch, uniform=uniform)
+    assert (nat.N, nat.E, nat.T, nat.num_atoms, nat.uniform, nat.block, nat.num_graphs) == \
+           (ref.N, ref.E, ref.T, ref.num_atoms, ref.uniform, ref.block, ref.num_graphs)
+    assert nat.type_rowptr_host == ref.type_rowptr_host
+    for f in ["node_order", "row_of_node", "z_rows", "type_rowptr", "csr_rowptr", "csr_src", "csr_perm", "csc_rowptr",
+              "csc_tgt", "csc_pos", "out_rowptr", "out_edges", "src_id", "tgt_id", "row_real", "row_active", "shift"]:
+        a, b = getattr(nat, f), getattr(ref, f)
+        if b is None:
+            assert a is None, f
+            continue
+        n_valid = b.numel()
+        if f in ("csc_tgt", "csc_pos"):      # entries past the edges with a known-relation target are undefined
+            n_valid = int(ref.csc_rowptr[-1])
+        assert torch.equal(a.reshape(-1)[:n_valid].long() if a.dtype != torch.float32 else a.reshape(-1)[:n_valid],
+                           b.reshape(-1)[:n_valid].long() if b.dtype != torch.float32 else b.reshape(-1)[:n_valid]), f
+    # override of the relation activity (sharded runs)
+    nat2 = RelationalGraph.build(d.atomic_number, d.edge_index, zl, shift, d.batch, rel_active=[True] + [False] * (len(zl) - 1),
+                                 uniform=uniform)
+    ref2 = RelationalGraph._build_torch(d.atomic_number, d.edge_index, zl, shift, d.batch,
+                                        rel_active=[True] + [False] * (len(zl) - 1), uniform=uniform)
+    assert torch.equal(nat2.row_active, ref2.row_active)
