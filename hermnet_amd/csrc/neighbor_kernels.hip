@@ -1,0 +1,358 @@
+// gfx950 cutoff neighbour search (cell list) -- the input producer of the hot path.
+//
+// Replaces /root/reference/HermNet/data.py:14-24 `neighbor_search`, which calls
+// ase.neighborlist.primitive_neighbor_list('ijS', ...) (periodic) or torch_cluster.radius_graph
+// on the HOST every step (plugin/ase_interface/calculator.py:49, plugin/lmp_interface/lmp_calc.py:224).
+// Same conventions as the host implementation in hermnet_amd/neighbor.py (which it must match
+// bit for bit on well-separated inputs): pair (i, j, S) listed iff |pos_j - pos_i + S cell| < rc
+// (strict), no (i, i, 0), self images allowed, output sorted by (i, j, Sx, Sy, Sz); float64
+// arithmetic on the float32 coordinates.
+//
+// Pipeline: wrap + bin (fractional bins >= rc wide) -> sort atoms by bin -> count pairs per atom
+// -> exclusive scan -> fill -> one radix sort of 64-bit (i, j, S) keys.  Integer/streaming work.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include "../../include/hermnet_hip.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxImg = 8;                 // |S| per axis after un-wrapping must stay below this
+constexpr int kCode = 2 * kMaxImg + 1;     // 17 values per axis
+inline dim3 grid_for(long n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+struct NbrGeom {
+  double cell[9];     // rows = lattice vectors (identity for open systems)
+  double inv[9];      // inverse
+  double lo[3];       // open systems: lower corner of the bounding box
+  int nbins[3];
+  int reach[3];       // neighbour bins to visit on each side
+  int periodic;       // all three axes periodic, or none
+  double rc2;
+};
+
+__device__ __forceinline__ void frac_of(const NbrGeom& g, const double* p, double* f) {
+  // p @ inv  (row vector times matrix)
+  f[0] = p[0] * g.inv[0] + p[1] * g.inv[3] + p[2] * g.inv[6];
+  f[1] = p[0] * g.inv[1] + p[1] * g.inv[4] + p[2] * g.inv[7];
+  f[2] = p[0] * g.inv[2] + p[1] * g.inv[5] + p[2] * g.inv[8];
+}
+
+__device__ __forceinline__ void cart_of(const NbrGeom& g, const double* f, double* p) {
+  p[0] = f[0] * g.cell[0] + f[1] * g.cell[3] + f[2] * g.cell[6];
+  p[1] = f[0] * g.cell[1] + f[1] * g.cell[4] + f[2] * g.cell[7];
+  p[2] = f[0] * g.cell[2] + f[1] * g.cell[5] + f[2] * g.cell[8];
+}
+
+// wrapped fractional coordinate, integer wrap, bin id
+__global__ __launch_bounds__(kBlock) void nbr_bin_kernel(const float* __restrict__ pos, int N, NbrGeom g,
+                                                        double* __restrict__ fw, int* __restrict__ wrap,
+                                                        unsigned* __restrict__ bin, int* __restrict__ ids) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double p[3] = {(double)pos[3 * i], (double)pos[3 * i + 1], (double)pos[3 * i + 2]};
+  double f[3];
+  int b[3];
+  if (g.periodic) {
+    frac_of(g, p, f);
+    for (int k = 0; k < 3; ++k) {
+      const double w = floor(f[k]);
+      wrap[3 * i + k] = (int)w;
+      f[k] -= w;
+      int bk = (int)(f[k] * g.nbins[k]);
+      b[k] = bk >= g.nbins[k] ? g.nbins[k] - 1 : bk;
+    }
+  } else {
+    for (int k = 0; k < 3; ++k) {
+      f[k] = p[k];
+      wrap[3 * i + k] = 0;
+      int bk = (int)((p[k] - g.lo[k]) * g.inv[4 * k]);     // inv diagonal = 1 / bin width
+      b[k] = bk < 0 ? 0 : (bk >= g.nbins[k] ? g.nbins[k] - 1 : bk);
+    }
+  }
+  fw[3 * i] = f[0]; fw[3 * i + 1] = f[1]; fw[3 * i + 2] = f[2];
+  bin[i] = (unsigned)((b[0] * g.nbins[1] + b[1]) * g.nbins[2] + b[2]);
+  ids[i] = i;
+}
+
+__global__ __launch_bounds__(kBlock) void nbr_binstart_kernel(const unsigned* __restrict__ sorted_bin, int N,
+                                                             int nbin_total, int* __restrict__ start) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nbin_total) return;
+  int lo = 0, hi = N;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_bin[mid] < (unsigned)r) lo = mid + 1; else hi = mid; }
+  start[r] = lo;
+}
+
+// Visit every candidate (j, image) of atom i; FILL = false counts, FILL = true writes 64-bit keys
+// key = ((i * N + j) * 17^3 + code(S)),  S = image - wrap_j + wrap_i (shift for the caller's coordinates).
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restrict__ fw, const int* __restrict__ wrap,
+                                                          const int* __restrict__ sorted_ids,
+                                                          const int* __restrict__ bin_start, int N, NbrGeom g,
+                                                          const long* __restrict__ offset, int* __restrict__ count,
+                                                          unsigned long long* __restrict__ keys,
+                                                          int* __restrict__ overflow) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double fi[3] = {fw[3 * i], fw[3 * i + 1], fw[3 * i + 2]};
+  double pi[3];
+  if (g.periodic) cart_of(g, fi, pi); else { pi[0] = fi[0]; pi[1] = fi[1]; pi[2] = fi[2]; }
+  int bi[3];
+  for (int k = 0; k < 3; ++k) {
+    int bk;
+    if (g.periodic) bk = (int)(fi[k] * g.nbins[k]); else bk = (int)((fi[k] - g.lo[k]) * g.inv[4 * k]);
+    bi[k] = bk < 0 ? 0 : (bk >= g.nbins[k] ? g.nbins[k] - 1 : bk);
+  }
+  long out = FILL ? offset[i] : 0;
+  int n = 0;
+  for (int ox = -g.reach[0]; ox <= g.reach[0]; ++ox)
+    for (int oy = -g.reach[1]; oy <= g.reach[1]; ++oy)
+      for (int oz = -g.reach[2]; oz <= g.reach[2]; ++oz) {
+        int tb[3] = {bi[0] + ox, bi[1] + oy, bi[2] + oz};
+        int img[3] = {0, 0, 0};
+        bool ok = true;
+        for (int k = 0; k < 3; ++k) {
+          if (g.periodic) {
+            // floor division: image shift carried by leaving the cell through this face
+            int q = tb[k] >= 0 ? tb[k] / g.nbins[k] : -((-tb[k] + g.nbins[k] - 1) / g.nbins[k]);
+            img[k] = q;
+            tb[k] -= q * g.nbins[k];
+          } else if (tb[k] < 0 || tb[k] >= g.nbins[k]) {
+            ok = false;
+          }
+        }
+        if (!ok) continue;
+        const int b = (tb[0] * g.nbins[1] + tb[1]) * g.nbins[2] + tb[2];
+        for (int s = bin_start[b]; s < bin_start[b + 1]; ++s) {
+          const int j = sorted_ids[s];
+          double fj[3] = {fw[3 * j] + img[0], fw[3 * j + 1] + img[1], fw[3 * j + 2] + img[2]};
+          double pj[3];
+          if (g.periodic) cart_of(g, fj, pj); else { pj[0] = fj[0]; pj[1] = fj[1]; pj[2] = fj[2]; }
+          const double dx = pj[0] - pi[0], dy = pj[1] - pi[1], dz = pj[2] - pi[2];
+          const double d2 = dx * dx + dy * dy + dz * dz;
+          if (!(d2 < g.rc2)) continue;
+          if (j == i && img[0] == 0 && img[1] == 0 && img[2] == 0) continue;
+          if (FILL) {
+            const int S[3] = {img[0] - wrap[3 * j] + wrap[3 * i], img[1] - wrap[3 * j + 1] + wrap[3 * i + 1],
+                              img[2] - wrap[3 * j + 2] + wrap[3 * i + 2]};
+            if (S[0] < -kMaxImg || S[0] > kMaxImg || S[1] < -kMaxImg || S[1] > kMaxImg || S[2] < -kMaxImg ||
+                S[2] > kMaxImg)
+              atomicOr(overflow, 1);
+            const unsigned long long code =
+                (unsigned long long)(((S[0] + kMaxImg) * kCode + (S[1] + kMaxImg)) * kCode + (S[2] + kMaxImg));
+            keys[out++] = ((unsigned long long)i * (unsigned long long)N + (unsigned long long)j) *
+                              (unsigned long long)(kCode * kCode * kCode) + code;
+          } else {
+            ++n;
+          }
+        }
+      }
+  if (!FILL) count[i] = n;
+}
+
+// sorted keys -> edge_index [2,E] int64 ([i; j]) and shifts [E,3] float32 (sign * S)
+__global__ __launch_bounds__(kBlock) void nbr_decode_kernel(const unsigned long long* __restrict__ keys, long E,
+                                                           int N, float sign, int swap_rows,
+                                                           long* __restrict__ edge_index, float* __restrict__ shift) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const unsigned long long key = keys[e];
+  const unsigned long long c3 = (unsigned long long)(kCode * kCode * kCode);
+  const unsigned long long pair = key / c3;
+  const int code = (int)(key - pair * c3);
+  const long i = (long)(pair / (unsigned long long)N), j = (long)(pair - (unsigned long long)i * N);
+  edge_index[e] = swap_rows ? j : i;
+  edge_index[E + e] = swap_rows ? i : j;
+  if (shift != nullptr) {
+    shift[3 * e + 0] = sign * (float)(code / (kCode * kCode) - kMaxImg);
+    shift[3 * e + 1] = sign * (float)((code / kCode) % kCode - kMaxImg);
+    shift[3 * e + 2] = sign * (float)(code % kCode - kMaxImg);
+  }
+}
+
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+int key_bits(int N) {
+  double v = (double)N * (double)N * (double)(kCode * kCode * kCode);
+  int b = 1;
+  while (b < 64 && ldexp(1.0, b) < v) ++b;
+  return b;
+}
+
+struct NbrWork {
+  double* fw; int* wrap; unsigned* bin; unsigned* bin_sorted; int* ids; int* ids_sorted; int* bin_start;
+  int* count; long* offset; int* overflow; void* temp; size_t temp_bytes;
+};
+
+size_t temp_bytes_for(int N) {
+  size_t a = 0, b = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
+                                           (int*)nullptr, N, 0, 32, (hipStream_t)0);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const int*)nullptr, (long*)nullptr, N + 1, (hipStream_t)0);
+  return a > b ? a : b;
+}
+
+int make_geom(const double* cell_host, const double* lo_host, const double* hi_host, double rc, NbrGeom& g, long& nbins) {
+  g.rc2 = rc * rc;
+  if (cell_host) {
+    g.periodic = 1;
+    double c[9];
+    for (int k = 0; k < 9; ++k) { c[k] = cell_host[k]; g.cell[k] = c[k]; }
+    const double det = c[0] * (c[4] * c[8] - c[5] * c[7]) - c[1] * (c[3] * c[8] - c[5] * c[6]) + c[2] * (c[3] * c[7] - c[4] * c[6]);
+    if (fabs(det) < 1e-12) return HN_ERR_BAD_ARG;
+    g.inv[0] = (c[4] * c[8] - c[5] * c[7]) / det; g.inv[1] = (c[2] * c[7] - c[1] * c[8]) / det; g.inv[2] = (c[1] * c[5] - c[2] * c[4]) / det;
+    g.inv[3] = (c[5] * c[6] - c[3] * c[8]) / det; g.inv[4] = (c[0] * c[8] - c[2] * c[6]) / det; g.inv[5] = (c[2] * c[3] - c[0] * c[5]) / det;
+    g.inv[6] = (c[3] * c[7] - c[4] * c[6]) / det; g.inv[7] = (c[1] * c[6] - c[0] * c[7]) / det; g.inv[8] = (c[0] * c[4] - c[1] * c[3]) / det;
+    for (int k = 0; k < 3; ++k) {
+      // plane spacing along axis k = 1 / |column k of inv|
+      const double h = 1.0 / sqrt(g.inv[k] * g.inv[k] + g.inv[3 + k] * g.inv[3 + k] + g.inv[6 + k] * g.inv[6 + k]);
+      int nb = (int)floor(h / rc);
+      if (nb < 1) nb = 1;
+      if (nb > 1024) nb = 1024;
+      g.nbins[k] = nb;
+      g.reach[k] = (int)ceil(rc / (h / nb) - 1e-12);
+      if (g.reach[k] < 1) g.reach[k] = 1;
+      if (g.reach[k] > kMaxImg) return HN_ERR_BAD_ARG;       // cell far smaller than the cutoff
+      g.lo[k] = 0.0;
+    }
+  } else {
+    g.periodic = 0;
+    for (int k = 0; k < 9; ++k) { g.cell[k] = (k % 4 == 0) ? 1.0 : 0.0; g.inv[k] = 0.0; }
+    for (int k = 0; k < 3; ++k) {
+      const double span = hi_host[k] - lo_host[k] + 2e-6;
+      int nb = (int)floor(span / rc);
+      if (nb < 1) nb = 1;
+      if (nb > 1024) nb = 1024;
+      g.nbins[k] = nb;
+      g.lo[k] = lo_host[k] - 1e-6;
+      g.inv[4 * k] = nb / span;                               // 1 / bin width (>= rc wide)
+      g.reach[k] = 1;
+    }
+  }
+  nbins = (long)g.nbins[0] * g.nbins[1] * g.nbins[2];
+  return HN_OK;
+}
+
+void carve(void* workspace, int N, long nbins, NbrWork& w) {
+  char* p = reinterpret_cast<char*>(workspace);
+  auto take = [&](size_t bytes) { void* r = p; p += align256(bytes); return r; };
+  w.fw = (double*)take(sizeof(double) * 3 * (size_t)N);
+  w.wrap = (int*)take(sizeof(int) * 3 * (size_t)N);
+  w.bin = (unsigned*)take(sizeof(unsigned) * (size_t)N);
+  w.bin_sorted = (unsigned*)take(sizeof(unsigned) * (size_t)N);
+  w.ids = (int*)take(sizeof(int) * (size_t)N);
+  w.ids_sorted = (int*)take(sizeof(int) * (size_t)N);
+  w.bin_start = (int*)take(sizeof(int) * (size_t)(nbins + 1));
+  w.count = (int*)take(sizeof(int) * (size_t)(N + 1));
+  w.offset = (long*)take(sizeof(long) * (size_t)(N + 1));
+  w.overflow = (int*)take(256);
+  w.temp = p;
+}
+
+size_t fixed_bytes(int N, long nbins) {
+  return align256(sizeof(double) * 3 * (size_t)N) + align256(sizeof(int) * 3 * (size_t)N) + 4 * align256(sizeof(int) * (size_t)N) +
+         align256(sizeof(int) * (size_t)(nbins + 1)) + align256(sizeof(int) * (size_t)(N + 1)) +
+         align256(sizeof(long) * (size_t)(N + 1)) + 256;
+}
+
+}  // namespace
+
+extern "C" size_t hermnet_neighbor_workspace(int num_atoms) {
+  // the bin grid is coarsened to at most 8 bins per atom
+  const long nbins = 8l * (num_atoms > 0 ? num_atoms : 1) + 64;
+  return fixed_bytes(num_atoms, nbins) + align256(temp_bytes_for(num_atoms > 0 ? num_atoms : 1)) + 512;
+}
+
+extern "C" size_t hermnet_neighbor_sort_workspace(long num_edges) {
+  size_t c = 0;
+  if (num_edges > 0)
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, c, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                            (int)num_edges, 0, 64, (hipStream_t)0);
+  return align256(c) + 256;
+}
+
+extern "C" int hermnet_neighbor_count(const float* pos, int num_atoms, const double* cell_host,
+                                      const double* lo_host, const double* hi_host, double rc,
+                                      void* workspace, size_t workspace_bytes, long* total_device, void* stream) {
+  const int N = num_atoms;
+  if (N < 0 || rc <= 0.0 || !workspace || !total_device) return HN_ERR_BAD_ARG;
+  if (!cell_host && (!lo_host || !hi_host)) return HN_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (N == 0) return hipMemsetAsync(total_device, 0, sizeof(long), s) == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+  if (!pos) return HN_ERR_BAD_ARG;
+  NbrGeom g;
+  long nbins = 0;
+  int rc_ = make_geom(cell_host, lo_host, hi_host, rc, g, nbins);
+  if (rc_) return rc_;
+  if (nbins > 8l * N + 64) {   // sparse box: coarsen the grid (bins only get wider, still >= rc)
+    while (nbins > 8l * N + 64) {
+      int kmax = 0;
+      for (int k = 1; k < 3; ++k) if (g.nbins[k] > g.nbins[kmax]) kmax = k;
+      if (g.nbins[kmax] <= 1) break;
+      const int nb = (g.nbins[kmax] + 1) / 2;
+      if (!g.periodic) g.inv[4 * kmax] *= (double)nb / g.nbins[kmax];
+      g.nbins[kmax] = nb;
+      nbins = (long)g.nbins[0] * g.nbins[1] * g.nbins[2];
+    }
+  }
+  if (workspace_bytes < fixed_bytes(N, nbins) + 512) return HN_ERR_BAD_ARG;
+  NbrWork w;
+  carve(workspace, N, 8l * N + 64, w);
+  w.temp_bytes = workspace_bytes - (size_t)((char*)w.temp - (char*)workspace);
+  hipLaunchKernelGGL(nbr_bin_kernel, grid_for(N), dim3(kBlock), 0, s, pos, N, g, w.fw, w.wrap, w.bin, w.ids);
+  int bits = 1;
+  while (bits < 32 && (1l << bits) < nbins) ++bits;
+  size_t tb = w.temp_bytes;
+  if (hipcub::DeviceRadixSort::SortPairs(w.temp, tb, w.bin, w.bin_sorted, w.ids, w.ids_sorted, N, 0, bits, s) != hipSuccess)
+    return HN_ERR_LAUNCH;
+  hipLaunchKernelGGL(nbr_binstart_kernel, grid_for(nbins + 1), dim3(kBlock), 0, s, w.bin_sorted, N, (int)nbins, w.bin_start);
+  if (hipMemsetAsync(w.count + N, 0, sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
+  hipLaunchKernelGGL(nbr_pairs_kernel<false>, grid_for(N), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N,
+                     g, (const long*)nullptr, w.count, (unsigned long long*)nullptr, w.overflow);
+  tb = w.temp_bytes;
+  if (hipcub::DeviceScan::ExclusiveSum(w.temp, tb, w.count, w.offset, N + 1, s) != hipSuccess) return HN_ERR_LAUNCH;
+  if (hipMemcpyAsync(total_device, w.offset + N, sizeof(long), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return HN_ERR_LAUNCH;
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}
+
+extern "C" int hermnet_neighbor_fill(const float* pos, int num_atoms, const double* cell_host,
+                                     const double* lo_host, const double* hi_host, double rc,
+                                     void* workspace, size_t workspace_bytes, void* sort_workspace,
+                                     size_t sort_workspace_bytes, long num_edges, float shift_sign,
+                                     int source_first, unsigned long long* keys_a, unsigned long long* keys_b,
+                                     long* edge_index, float* edge_shift, int* overflow_device, void* stream) {
+  const int N = num_atoms;
+  if (N <= 0 || num_edges < 0 || !workspace || !edge_index || !overflow_device) return HN_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(overflow_device, 0, sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
+  if (num_edges == 0) return HN_OK;
+  if (!keys_a || !keys_b || !sort_workspace || (double)N * N * 4913.0 >= 1.8e19) return HN_ERR_BAD_ARG;
+  if (num_edges > 0x7fffffffl) return HN_ERR_BAD_ARG;
+  NbrGeom g;
+  long nbins = 0;
+  int rc_ = make_geom(cell_host, lo_host, hi_host, rc, g, nbins);
+  if (rc_) return rc_;
+  while (nbins > 8l * N + 64) {   // must mirror hermnet_neighbor_count
+    int kmax = 0;
+    for (int k = 1; k < 3; ++k) if (g.nbins[k] > g.nbins[kmax]) kmax = k;
+    if (g.nbins[kmax] <= 1) break;
+    const int nb = (g.nbins[kmax] + 1) / 2;
+    if (!g.periodic) g.inv[4 * kmax] *= (double)nb / g.nbins[kmax];
+    g.nbins[kmax] = nb;
+    nbins = (long)g.nbins[0] * g.nbins[1] * g.nbins[2];
+  }
+  NbrWork w;
+  carve(workspace, N, 8l * N + 64, w);
+  w.temp_bytes = workspace_bytes - (size_t)((char*)w.temp - (char*)workspace);
+  hipLaunchKernelGGL(nbr_pairs_kernel<true>, grid_for(N), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N, g,
+                     w.offset, (int*)nullptr, keys_a, overflow_device);
+  size_t tb = sort_workspace_bytes;
+  if (hipcub::DeviceRadixSort::SortKeys(sort_workspace, tb, keys_a, keys_b, (int)num_edges, 0, key_bits(N), s) != hipSuccess)
+    return HN_ERR_LAUNCH;
+  hipLaunchKernelGGL(nbr_decode_kernel, grid_for(num_edges), dim3(kBlock), 0, s, keys_b, num_edges, N, shift_sign,
+                     source_first, edge_index, edge_shift);
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}

@@ -135,21 +135,70 @@ def neighbor_list(pos, rc, cell=None, pbc=(True, True, True), chunk=200000):
     return i[key], j[key], s[key]
 
 
+def _neighbor_search_device(pos, rc, cell, reference_compat):
+    """Device cell list (`csrc/neighbor_kernels.hip`); same result as the host path, tensors stay on the GPU."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    P = _lib.ptr
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dev = pos.device
+    p32 = pos.detach().float().contiguous()
+    N = int(p32.size(0))
+    dbl3 = ctypes.c_double * 3
+    cell_h = lo_h = hi_h = None
+    if cell is not None:
+        c = cell.detach().double().cpu().reshape(-1, 3, 3)[0].contiguous().numpy()
+        cell_h = (ctypes.c_double * 9)(*c.reshape(-1).tolist())
+    elif N > 0:
+        mm = torch.stack([p32.min(0).values, p32.max(0).values]).double().cpu().tolist()
+        lo_h, hi_h = dbl3(*mm[0]), dbl3(*mm[1])
+    else:
+        lo_h, hi_h = dbl3(0, 0, 0), dbl3(1, 1, 1)
+    ws_bytes = lib.hermnet_neighbor_workspace(N)
+    work = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    total = torch.zeros(1, dtype=torch.long, device=dev)
+    args = (P(p32), N, cell_h, lo_h, hi_h, float(rc), P(work), ws_bytes)
+    _lib.check(lib.hermnet_neighbor_count(*args, P(total), stream), "hermnet_neighbor_count")
+    E = int(total.item())                                    # the one host read of the search
+    edge_index = torch.empty(2, E, dtype=torch.long, device=dev)
+    periodic = cell is not None
+    shift = torch.empty(E, 3, dtype=torch.float32, device=dev) if periodic else None
+    if E > 0:
+        sw_bytes = lib.hermnet_neighbor_sort_workspace(E)
+        sort_work = torch.empty(sw_bytes, dtype=torch.uint8, device=dev)
+        keys = torch.empty(2, E, dtype=torch.long, device=dev)
+        overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        sign = 1.0 if reference_compat else -1.0
+        _lib.check(lib.hermnet_neighbor_fill(*args, P(sort_work), sw_bytes, E, sign, 0 if periodic else 1,
+                                             P(keys[0]), P(keys[1]), P(edge_index), P(shift), P(overflow), stream),
+                   "hermnet_neighbor_fill")
+        if int(overflow.item()) != 0:
+            return None
+    return (edge_index, shift) if periodic else edge_index
+
+
 def neighbor_search(pos, rc, cell=None, reference_compat=False):
     """Drop-in for `HermNet/data.py:14-24`.
 
     pos: float Tensor [N,3]; cell: Tensor [3,3] or [1,3,3] or None.
     Returns `edge_index` (open system) or `(edge_index, edge_shift)` (periodic),
-    int64 [2,E] / float32 [E,3], exactly the reference's return shapes.
+    int64 [2,E] / float32 [E,3], exactly the reference's return shapes.  GPU tensors are searched
+    on the GPU and the result stays there; host tensors take the numpy cell list below.
     """
+    if pos.is_cuda:
+        out = _neighbor_search_device(pos, rc, cell, reference_compat)
+        if out is not None:
+            return out
+    dev = pos.device
     p = pos.detach().cpu().numpy()
     if cell is None:
         i, j, _ = neighbor_list(p, rc, None)
         # radius_graph convention: row 0 = source (neighbour), row 1 = target (centre)
-        return torch.from_numpy(np.vstack([j, i])).long()
+        return torch.from_numpy(np.vstack([j, i])).long().to(dev)
     c = cell.detach().cpu().numpy().reshape(-1, 3, 3)[0]
     i, j, s = neighbor_list(p, rc, c)
     edge_index = torch.from_numpy(np.vstack([i, j])).long()
     sign = 1.0 if reference_compat else -1.0
     edge_shift = torch.from_numpy(sign * s.astype(np.float32)).float()
-    return edge_index, edge_shift
+    return edge_index.to(dev), edge_shift.to(dev)

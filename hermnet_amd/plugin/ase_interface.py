@@ -27,15 +27,19 @@ except Exception:  # pragma: no cover - exercised on the GPU image
             self.atoms = atoms
 
 
-def build_graph(cell, elements, pos, rc):
-    """`calculator.py:10-27`: numpy (cell [3,3] or None, Z [N], pos [N,3]) -> `Data` with the cutoff graph."""
+def build_graph(cell, elements, pos, rc, device=None):
+    """`calculator.py:10-27`: numpy (cell [3,3] or None, Z [N], pos [N,3]) -> `Data` with the cutoff graph.
+    With `device` set to the GPU the coordinates are uploaded first and the neighbour search runs on the
+    device (`csrc/neighbor_kernels.hip`) instead of the host -- the reference rebuilds the list every step."""
     pos_t = torch.from_numpy(np.asarray(pos)).float()
     z = torch.from_numpy(np.asarray(elements)).long()
-    data = Data(atomic_number=z, pos=pos_t, batch=torch.zeros(pos_t.size(0), dtype=torch.long))
+    if device is not None:
+        pos_t, z = pos_t.to(device), z.to(device)
+    data = Data(atomic_number=z, pos=pos_t, batch=torch.zeros(pos_t.size(0), dtype=torch.long, device=pos_t.device))
     if cell is None or not np.any(np.asarray(cell)):
         data.edge_index = neighbor_search(pos=pos_t, rc=rc)
     else:
-        cell_t = torch.from_numpy(np.asarray(cell, dtype=np.float64).reshape(3, 3)).float()
+        cell_t = torch.from_numpy(np.asarray(cell, dtype=np.float64).reshape(3, 3)).float().to(pos_t.device)
         data.edge_index, data.edge_shift = neighbor_search(pos=pos_t, rc=rc, cell=cell_t)
         data.cell = cell_t.reshape(1, 3, 3)
     return data
@@ -85,7 +89,8 @@ class NNCalculator(_Base):
         pbc = bool(np.any(atoms.pbc))
         cell = np.asarray(atoms.cell if not hasattr(atoms, "todict") else atoms.todict()['cell']) if pbc else None
         elems = np.array([atomic_numbers[s] for s in atoms.get_chemical_symbols()])
-        data = build_graph(cell=cell, elements=elems, pos=atoms.positions, rc=self.model.rc)
+        dev = self.device_ if torch.device(self.device_).type == 'cuda' else None
+        data = build_graph(cell=cell, elements=elems, pos=atoms.positions, rc=self.model.rc, device=dev)
         energy, forces, virial = self.model_calc(data=data, device=self.device_, pbc=pbc, ensemble=self.ensemble)
         self.results['energy'] = energy
         self.results['free_energy'] = energy

@@ -360,3 +360,37 @@ def test_config4_100k_atoms_properties():
     e2 = model(data)
     f2 = -torch.autograd.grad(e2.sum(), data.pos)[0]
     assert torch.equal(e, e2) and torch.equal(f, f2)
+
+
+@pytest.mark.parametrize("case", ["cubic", "triclinic", "small_cell", "unwrapped", "open", "alloy10k", "molecule"])
+def test_device_neighbor_search_bit_exact_vs_host(case):
+    """csrc/neighbor_kernels.hip vs the host cell list (itself checked against brute force on CPU):
+    identical (i, j, S) lists, identical order -- 'neighbour indices bit-exact' (north_star)."""
+    from hermnet_amd.neighbor import neighbor_search
+    dev = _dev()
+    rs = np.random.RandomState(3)
+    cell, rc = None, 4.0
+    if case == "cubic":
+        cell = np.diag([9.0, 10.0, 11.0]); pos = rs.uniform(0, 1, size=(60, 3)) @ cell
+    elif case == "triclinic":
+        cell = np.array([[9.0, 0, 0], [2.0, 8.5, 0], [1.0, -1.5, 9.5]]); pos = rs.uniform(0, 1, size=(50, 3)) @ cell
+    elif case == "small_cell":
+        cell = np.diag([3.0, 3.5, 4.0]); pos = rs.uniform(0, 1, size=(5, 3)) @ cell; rc = 4.9
+    elif case == "unwrapped":
+        cell = np.diag([8.0, 8.0, 8.0]); rc = 3.5
+        pos = rs.uniform(0, 1, size=(40, 3)) @ cell + rs.randint(-2, 3, size=(40, 3)) @ cell
+    elif case == "open":
+        pos = rs.uniform(-4, 4, size=(80, 3)); rc = 3.0
+    elif case == "alloy10k":
+        d = synth.fcc_alloy(); pos = d.pos.numpy().astype(np.float64); cell = d.cell[0].numpy().astype(np.float64); rc = 5.0
+    else:
+        d = synth.molecule_batch(num_graphs=1); pos = d.pos.numpy().astype(np.float64); rc = 5.0
+    p = torch.from_numpy(pos).float()
+    c = None if cell is None else torch.from_numpy(cell).float()
+    for compat in (False, True):
+        host = neighbor_search(p, rc, c, reference_compat=compat)
+        devr = neighbor_search(p.to(dev), rc, None if c is None else c.to(dev), reference_compat=compat)
+        if cell is None:
+            assert devr.is_cuda and torch.equal(devr.cpu(), host)
+        else:
+            assert devr[0].is_cuda and torch.equal(devr[0].cpu(), host[0]) and torch.equal(devr[1].cpu(), host[1])
