@@ -6,7 +6,7 @@ import torch
 from torch import nn
 
 from .elements import atomic_numbers
-from .ops import EdgeGeometry
+from .ops import EdgeGeometry, TrueEdgeGradient
 from .relations import RelationalGraph
 from .sharding import HaloExchange, SumAcrossRanks
 import os
@@ -29,6 +29,11 @@ class HeteroVertexConv(nn.Module):
         g = data.get("_hn_graph")
         if g is None:
             raise RuntimeError("HeteroVertexConv.forward needs a Data prepared by HVNet.forward")
+        if data.get("_hn_edge_embed") is not None:
+            # optional radial bases (Bessel / Bernstein): materialised basis, device ops + autograd
+            data.x, data.vec = relational_layer(self.mods.values(), data.x, data.vec, data._hn_edge, g, None,
+                                                edge_embed=data._hn_edge_embed)
+            return data
         if os.environ.get("HERMNET_FUSED_LAYER", "1") == "0":
             # debugging path: same kernels for the edge part, node algebra through PyTorch autograd
             data.x, data.vec = relational_layer(self.mods.values(), data.x, data.vec, data._hn_edge, g, data._hn_rbf)
@@ -92,7 +97,8 @@ class HVNet(nn.Module):
         graph = RelationalGraph.build(data.atomic_number, data.edge_index, zl,
                                       edge_shift=data.get("edge_shift") if data.get("cell") is not None else None,
                                       batch=data.batch, rel_active=rel_active)
-        rbf = self.radial_basis.descriptor()
+        fused = self.radial_basis.fused
+        rbf = self.radial_basis.descriptor() if fused else None
         row_plan = None
         if shard is not None:
             if shard.owned_mask.device != pos.device:
@@ -103,7 +109,11 @@ class HVNet(nn.Module):
 
         x = self.embed(graph.z_rows)                                        # hermnet.py:123, row order (pads: Z=0)
         vec = None                                                          # zeros, hermnet.py:124
+        if not fused:
+            edge = TrueEdgeGradient.apply(edge)      # autograd's (rhat, d) gradients -> Cartesian for the kernel
         data._hn_graph, data._hn_edge, data._hn_rbf = graph, edge, rbf
+        # rmnet.py:168-172 for the optional bases only: [E,R] basis from the kernel's distances
+        data._hn_edge_embed = None if fused else self.radial_basis(edge[:, 3])
         data.x, data.vec = x, vec
         for li, conv in enumerate(self.hermconvs):
             data = conv(data)

@@ -123,6 +123,25 @@ class EdgeGeometry(torch.autograd.Function):
         return gpos_rows[graph.row_of_node], gcell, None
 
 
+class TrueEdgeGradient(torch.autograd.Function):
+    """Identity on edge = (rhat, d) whose backward turns the TRUE gradient (dE/drhat, dE/dd), as produced
+    by PyTorch autograd on the generic (optional radial basis) path, into the Cartesian dE/dD that
+    `EdgeGeometry.backward` consumes:  gD = gd rhat + (gr - (gr.rhat) rhat) / d."""
+
+    @staticmethod
+    def forward(ctx, edge):
+        ctx.save_for_backward(edge)
+        return edge.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (edge,) = ctx.saved_tensors
+        rh, d = edge[:, :3], edge[:, 3:4]
+        gr, gd = g[:, :3], g[:, 3:4]
+        gD = gd * rh + (gr - (gr * rh).sum(1, keepdim=True) * rh) / d
+        return torch.cat([gD, torch.zeros_like(d)], dim=1)
+
+
 class MessageScatter(torch.autograd.Function):
     """rbf_proj + propagate + residual of one HeteroVertexConv layer, all relations
     (rmnet.py:24-26, 55-73; utils.py:11-24).  Returns (x1, vec1).

@@ -110,12 +110,37 @@ class RadialBasis(nn.Module):
             raise ValueError(f"Unknown radial basis function '{rbf_name}'.")
         self._desc = None
 
+    @property
+    def fused(self):
+        """True when the basis is the one the fused gfx950 kernel evaluates in registers (Gaussian, the
+        reference default, hermnet.py:87)."""
+        return self.rbf_name == "gaussian"
+
+    def forward(self, d):
+        """`rmnet.py:168-172` as differentiable device ops: envelope(d/rc)[:,None] * rbf(d/rc) -> [E,R].
+        Only used for the optional bases (spherical Bessel, Bernstein); the Gaussian default never
+        materialises this tensor."""
+        u = d * self.inv_cutoff
+        if isinstance(self.envelope, PolynomialEnvelope):
+            p = self.envelope.p
+            a, b, c = -(p + 1) * (p + 2) / 2, p * (p + 2), -p * (p + 1) / 2
+            env = 1 + a * u ** p + b * u ** (p + 1) + c * u ** (p + 2)
+        else:
+            env = torch.exp(-(u ** 2) / ((1 - u) * (1 + u)))
+        env = torch.where(u < 1, env, torch.zeros_like(u))
+        if self.rbf_name == "gaussian":
+            rbf = torch.exp(self.rbf.coeff * (u.view(-1, 1) - self.rbf.offset.view(1, -1)) ** 2)
+        elif self.rbf_name == "spherical_bessel":
+            rbf = self.rbf.norm_const / u[:, None] * torch.sin(self.rbf.frequencies * u[:, None])
+        else:
+            gamma = F.softplus(self.rbf.pregamma)
+            ed = torch.exp(-gamma * u)[:, None]
+            rbf = self.rbf.prefactor * (ed ** self.rbf.exp1) * ((1 - ed) ** self.rbf.exp2)
+        return env[:, None] * rbf
+
     def descriptor(self):
         if self.rbf_name != "gaussian":
-            raise NotImplementedError(
-                "hermnet_amd: the gfx950 message kernel implements the Gaussian basis (the reference default, "
-                "hermnet.py:87); '%s' parameters load for state_dict compatibility but have no kernel yet"
-                % self.rbf_name)
+            raise NotImplementedError("the fused kernel evaluates the Gaussian basis only; use RadialBasis.forward")
         off = self.rbf.offset
         if self._desc is None or self._desc.offset.data_ptr() != off.data_ptr():
             self._desc = RbfDescriptor(off, self.cutoff, self.envelope.kind, self.envelope.p)
@@ -182,7 +207,40 @@ class PaiNNModule(nn.Module):
         self.inv_sqrt_2 = 1 / math.sqrt(2.0)
 
 
-def relational_layer(mods, x, vec, edge, graph, rbf):
+def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
+    """Same contract as the fused kernel (rmnet.py:24-26,55-73) for a MATERIALISED basis `edge_embed`
+    [E,R] (CSR order): library GEMM per relation + gather/index_add device ops, differentiable by
+    PyTorch autograd.  Path of the optional radial bases only (API parity, not the benchmark)."""
+    T, N, H3 = xh.shape
+    H = H3 // 3
+    rowptr = graph.csr_rowptr.long()
+    tgt_row = torch.repeat_interleave(torch.arange(N, device=x.device), rowptr[1:] - rowptr[:-1])
+    src = graph.csr_src.long()
+    rel_row = torch.bucketize(torch.arange(N, device=x.device), graph.type_rowptr.long()[1:], right=True)
+    rel_e = rel_row[tgt_row]
+    dx = x.new_zeros(N, H)
+    dv = x.new_zeros(N, 3, H)
+    rhat = edge[:, :3]
+    for t in range(T):
+        sel = torch.nonzero(rel_e == t).flatten()
+        if sel.numel() == 0:
+            continue
+        rb = F.linear(edge_embed[sel], w_rbf[t], b_rbf[t])                     # rbf_proj, rmnet.py:55
+        m = xh[t].index_select(0, src[sel]) * rb
+        s_, a_, b_ = m[:, :H], m[:, H:2 * H], m[:, 2 * H:]
+        mv = b_[:, None, :] * rhat[sel][:, :, None]
+        if vec is not None:
+            mv = mv + vec.index_select(0, src[sel]) * (a_ * (1 / math.sqrt(3.0)))[:, None, :]
+        mv = mv * (1 / math.sqrt(H))
+        dx = dx.index_add(0, tgt_row[sel], s_)
+        dv = dv.index_add(0, tgt_row[sel], mv)
+    known = (rel_row < T).to(x.dtype)
+    x1 = (x + dx) * (1 / math.sqrt(2.0)) * known[:, None]
+    vec1 = ((vec if vec is not None else 0) + dv) * known[:, None, None]
+    return x1, vec1
+
+
+def relational_layer(mods, x, vec, edge, graph, rbf, edge_embed=None):
     """One HeteroVertexConv layer in relation (row) order: `hermnet.py:37-65`.
 
     x [N,H], vec [N,3,H] or None (layer 0: zeros, `hermnet.py:124`); returns new (x, vec).
@@ -193,7 +251,12 @@ def relational_layer(mods, x, vec, edge, graph, rbf):
     xh = torch.stack([m.message_layer.node_projection(x) for m in mlist], dim=0)
     wt = torch.stack([m.message_layer.rbf_proj.weight.detach().t() for m in mlist], dim=0).contiguous()
     brbf = torch.stack([m.message_layer.rbf_proj.bias.detach() for m in mlist], dim=0).contiguous()
-    x1, vec1 = MessageScatter.apply(xh, vec, x, edge, wt, brbf, graph, rbf)
+    if edge_embed is None:
+        x1, vec1 = MessageScatter.apply(xh, vec, x, edge, wt, brbf, graph, rbf)
+    else:
+        x1, vec1 = message_scatter_generic(xh, vec, x, edge, edge_embed,
+                                           [m.message_layer.rbf_proj.weight for m in mlist],
+                                           [m.message_layer.rbf_proj.bias for m in mlist], graph)
     xs, vs = [], []
     rp = graph.type_rowptr_host
     for t, m in enumerate(mlist):

@@ -16,7 +16,7 @@ from hermnet_amd import synth
 from hermnet_amd.ops import EdgeGeometry, MessageScatter
 from hermnet_amd.relations import RelationalGraph
 from hermnet_amd.elements import atomic_numbers
-from helpers import Golden, SMALL_CASES, rel_err
+from helpers import Golden, SMALL_CASES, NONGAUSS_CASES, rel_err
 import ref_ops
 
 pytestmark = pytest.mark.gpu
@@ -105,7 +105,7 @@ def test_message_scatter_op(name, has_vec):
         assert rel_err(a.double(), b) < 2 * TOL, nm
 
 
-@pytest.mark.parametrize("name", SMALL_CASES)
+@pytest.mark.parametrize("name", SMALL_CASES + NONGAUSS_CASES)
 def test_hvnet_matches_reference_golden(name):
     """Energy + forces of the HIP path vs the reference's own outputs (golden fixtures)."""
     dev = _dev()
