@@ -307,7 +307,7 @@ struct FwdIn {
   bool live;
 };
 
-template <bool HAS_VEC, int NW, int VW, bool PF, bool FUSED>
+template <bool HAS_VEC, int NW, int VW, int PF, bool FUSED>
 __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(MsgArgs a) {
   extern __shared__ __align__(16) float lds[];
   float* wl = lds;
@@ -359,12 +359,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
       const int my_src = lane < cnt ? a.csr_src[base + lane] : 0;
       const int nit = (cnt + VW - 1) / VW;
 
-      auto load_edges = [&](int it) {
-        FwdIn<HAS_VEC, VW> in;
+      // PF = 0: rows and geometry of the next edges are requested at the end of an iteration;
+      // PF = 1: both at the top (full prefetch, costs a second register set);
+      // PF = 2: geometry (16 B, decides taps and LDS rows) at the top, rows at the end -- the tap and
+      //         S0 arithmetic of the next iteration then starts at once while its rows are in flight.
+      auto load_geom = [&](int it, FwdIn<HAS_VEC, VW>& in) {
         const int idx = VW * it + grp;
-        const int j = __shfl(my_src, idx, 64);
         in.live = idx < cnt;
         in.g = a.edge[base + (in.live ? idx : 0)];
+      };
+      auto load_rows = [&](int it, FwdIn<HAS_VEC, VW>& in) {
+        const int j = __shfl(my_src, VW * it + grp, 64);
         const float* xr = xh_t + (size_t)j * 3 * H + col;
         // (masked at use, not here: touching the registers now would wait for the loads)
         in.xs = Vec<VW>::load(xr); in.xa = Vec<VW>::load(xr + H); in.xb = Vec<VW>::load(xr + 2 * H);
@@ -373,16 +378,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
 #pragma unroll
           for (int d = 0; d < 3; ++d) in.vj[d] = Vec<VW>::load(vr + d * H);
         }
+      };
+      auto load_edges = [&](int it) {
+        FwdIn<HAS_VEC, VW> in;
+        load_geom(it, in);
+        load_rows(it, in);
         return in;
       };
 
       FwdIn<HAS_VEC, VW> cur = load_edges(0);
       for (int it = 0; it < nit; ++it) {
         FwdIn<HAS_VEC, VW> nxt;
-        if (PF) {
-          // prefetch the next VW edges (the last iteration re-loads its own: no branch, so the
-          // loads stay asynchronous until the register copy at the end of the iteration)
+        if (PF == 1) {
+          // (the last iteration re-loads its own: no branch, so the loads stay asynchronous until the
+          // register copy at the end of the iteration)
           nxt = load_edges(min(it + 1, nit - 1));
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (PF == 2) {
+          load_geom(min(it + 1, nit - 1), nxt);
           __builtin_amdgcn_sched_barrier(0);
         }
         const float u = cur.g.w * a.inv_rc;
@@ -417,7 +430,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
           for (int d = 0; d < 3; ++d) av[d] = v_fma(cur.vj[d], ma, av[d]);
         }
         HN_SB;
-        if (PF) cur = nxt;
+        if (PF == 1) cur = nxt;
+        else if (PF == 2) { load_rows(min(it + 1, nit - 1), cur); cur.g = nxt.g; cur.live = nxt.live; }
         else if (it + 1 < nit) cur = load_edges(it + 1);
       }
     }
@@ -458,7 +472,7 @@ struct BwdIn {
   bool live;
 };
 
-template <bool HAS_VEC, int NW, int VW, bool PF, bool FUSED>
+template <bool HAS_VEC, int NW, int VW, int PF, bool FUSED>
 __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(MsgArgs a) {
   extern __shared__ __align__(16) float lds[];
   float* wl = lds;
@@ -512,25 +526,34 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
         const int my_pos = lane < cnt ? a.csc_pos[base + lane] : 0;
         const int nit = (cnt + VW - 1) / VW;
 
-        auto load_edges = [&](int it) {
-          BwdIn<VW> in;
+        auto load_geom = [&](int it, BwdIn<VW>& in) {
           const int idx = VW * it + grp;
-          const int i = __shfl(my_tgt, idx, 64);
           in.pos = __shfl(my_pos, idx, 64);
           in.live = idx < cnt;
           in.g = a.edge[in.pos];
+        };
+        auto load_rows = [&](int it, BwdIn<VW>& in) {
+          const int i = __shfl(my_tgt, VW * it + grp, 64);
           in.gx1 = Vec<VW>::load(a.gx1 + (size_t)i * H + col);
           const float* gvr = a.gvec1 + (size_t)i * 3 * H + col;
 #pragma unroll
-          for (int d = 0; d < 3; ++d) in.gd[d] = Vec<VW>::load(gvr + d * H);
-          return in;   // padding slots are masked at use
+          for (int d = 0; d < 3; ++d) in.gd[d] = Vec<VW>::load(gvr + d * H);   // padding slots are masked at use
+        };
+        auto load_edges = [&](int it) {
+          BwdIn<VW> in;
+          load_geom(it, in);
+          load_rows(it, in);
+          return in;
         };
 
         BwdIn<VW> cur = load_edges(0);
         for (int it = 0; it < nit; ++it) {
           BwdIn<VW> nxt;
-          if (PF) {
-            nxt = load_edges(min(it + 1, nit - 1));   // unconditional prefetch, see the forward kernel
+          if (PF == 1) {
+            nxt = load_edges(min(it + 1, nit - 1));   // prefetch modes: see the forward kernel
+            __builtin_amdgcn_sched_barrier(0);
+          } else if (PF == 2) {
+            load_geom(min(it + 1, nit - 1), nxt);
             __builtin_amdgcn_sched_barrier(0);
           }
           const float4 g = cur.g;
@@ -592,13 +615,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
           const float pr[3] = {v_hsum(v_mul(g0, q)), v_hsum(v_mul(g1, q)), v_hsum(v_mul(g2, q))};   // dE/d rhat
           // Cartesian gradient w.r.t. D (d = |D|, rhat = D/d): gD = pd rhat + (pr - (pr.rhat) rhat)/d
           const float dotp = pr[0] * rd[0] + pr[1] * rd[1] + pr[2] * rd[2];
-          const float invd = 1.0f / g.w;
+          const float invd = __builtin_amdgcn_rcpf(g.w);   // 1 ulp; the full-precision divide costs ~10 instructions
           float gD[3];
 #pragma unroll
           for (int d = 0; d < 3; ++d) gD[d] = group_allsum<VW>(fmaf(pd - dotp * invd, rd[d], pr[d] * invd));
           if (cur.live && gl == 0) gedge[cur.pos] = make_float4(gD[0], gD[1], gD[2], 0.f);
           HN_SB;
-          if (PF) cur = nxt;
+          if (PF == 1) cur = nxt;
+          else if (PF == 2) { load_rows(min(it + 1, nit - 1), cur); cur.g = nxt.g; cur.pos = nxt.pos; cur.live = nxt.live; }
           else if (it + 1 < nit) cur = load_edges(it + 1);
         }
       }
@@ -690,27 +714,33 @@ typedef void (*kern_t)(MsgArgs);
 template <bool HAS_VEC>
 kern_t pick_fwd(int variant, int& nw) {
   switch (variant) {
-    case 16200: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, false, false>;
-    case 16201: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, false, true>;
-    case 16210: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, true, false>;
-    case 16211: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, true, true>;
-    case 8210:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 2, true, false>;
-    case 8400:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, false, false>;
-    default:    nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, true, false>;    // 8410
+    case 16200: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, 0, false>;
+    case 16201: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, 0, true>;
+    case 16210: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, 1, false>;
+    case 16211: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, 1, true>;
+    case 8210:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 2, 1, false>;
+    case 8400:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, 0, false>;
+    case 8420:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, 2, false>;
+    case 16221: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, 2, true>;
+    case 16220: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, 2, false>;
+    default:    nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, 1, false>;    // 8410
   }
 }
 
 template <bool HAS_VEC>
 kern_t pick_bwd(int variant, int& nw) {
   switch (variant) {
-    case 16200: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, false, false>;
-    case 16201: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, false, true>;
-    case 16210: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, true, false>;
-    case 16211: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, true, true>;
-    case 8400:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 4, false, false>;
-    case 8410:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 4, true, false>;
-    case 8201:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 2, false, true>;
-    default:    nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 2, true, false>;    // 8210
+    case 16200: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, 0, false>;
+    case 16201: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, 0, true>;
+    case 16210: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, 1, false>;
+    case 16211: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, 1, true>;
+    case 8400:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 4, 0, false>;
+    case 8420:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 4, 2, false>;
+    case 16221: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, 2, true>;
+    case 16220: nw = 16; return message_scatter_bwd_kernel<HAS_VEC, 16, 2, 2, false>;
+    case 8410:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 4, 1, false>;
+    case 8201:  nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 2, 0, true>;
+    default:    nw = 8;  return message_scatter_bwd_kernel<HAS_VEC, 8, 2, 1, false>;    // 8210
   }
 }
 
@@ -730,8 +760,8 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   a.x1 = x1; a.vec1 = vec1;
   static const int rpb_fwd = env_int("HERMNET_FWD_ROWS", 0);
   // defaults from tools/kbench.py on MI355X (config 2): see DESIGN.md "Kernel variants"
-  static const int variant_vec = env_int("HERMNET_FWD_VARIANT", 8410);
-  static const int variant_l0 = env_int("HERMNET_FWD_VARIANT_L0", 8400);
+  static const int variant_vec = env_int("HERMNET_FWD_VARIANT", 8420);
+  static const int variant_l0 = env_int("HERMNET_FWD_VARIANT_L0", 16201);
   const int variant = vec ? variant_vec : variant_l0;
   a.rows_per_block = pick_rows(a.N, hidden / HN_CB, a.T * (hidden / HN_CB), rpb_fwd);
   const size_t lds = lds_bytes(a.R);
