@@ -710,6 +710,22 @@ size_t lds_bytes(int R) {
 
 typedef void (*kern_t)(MsgArgs);
 
+// Opt in to > 64 KB of dynamic LDS once per kernel (not per launch: it is a host-side attribute, and
+// per-launch calls are neither free nor welcome while a stream is being captured into a hipGraph).
+int ensure_lds(kern_t k, size_t lds) {
+  constexpr int kMax = 64;
+  static kern_t done[kMax];
+  static size_t done_lds[kMax];
+  static int ndone = 0;
+  for (int i = 0; i < ndone; ++i)
+    if (done[i] == k && done_lds[i] >= lds) return HN_OK;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+      hipSuccess)
+    return HN_ERR_LDS;
+  if (ndone < kMax) { done[ndone] = k; done_lds[ndone] = lds; ++ndone; }
+  return HN_OK;
+}
+
 // variant = waves * 1000 + VW * 100 + prefetch * 10 + fused-tap-loop
 template <bool HAS_VEC>
 kern_t pick_fwd(int variant, int& nw) {
@@ -771,8 +787,7 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int nw = 16;
   kern_t k = vec ? pick_fwd<true>(variant, nw) : pick_fwd<false>(variant, nw);
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds) != hipSuccess) return HN_ERR_LDS;
+  if (ensure_lds(k, lds) != HN_OK) return HN_ERR_LDS;
   hipLaunchKernelGGL(k, grid, dim3(nw * 64), lds, s, a);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
@@ -807,8 +822,7 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int nw = 16;
   kern_t k = vec ? pick_bwd<true>(variant, nw) : pick_bwd<false>(variant, nw);
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds) != hipSuccess) return HN_ERR_LDS;
+  if (ensure_lds(k, lds) != HN_OK) return HN_ERR_LDS;
   hipLaunchKernelGGL(k, grid, dim3(nw * 64), lds, s, a);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }

@@ -15,6 +15,27 @@ import os
 import torch
 
 _COUNT_CACHE = {}
+_CONST_CACHE = {}
+
+
+def _cached_i32(values, dev):
+    """Small constant index tensors are uploaded once (a pageable H2D copy per step would also break
+    hipGraph capture of the step)."""
+    key = ("i32", values, str(dev))
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        if len(_CONST_CACHE) > 64:
+            _CONST_CACHE.clear()
+        t = _CONST_CACHE[key] = torch.tensor(list(values), dtype=torch.int32, device=dev)
+    return t
+
+
+def _cached_u8(values, dev):
+    key = ("u8", values, str(dev))
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        t = _CONST_CACHE[key] = torch.tensor(list(values), dtype=torch.uint8, device=dev)
+    return t
 
 
 class RelationalGraph(object):
@@ -88,7 +109,7 @@ class RelationalGraph(object):
         zl, cnt_host, g.num_graphs = hit
         g.uniform, g.block, starts, N = RelationalGraph._layout(cnt_host, T, uniform)
         g.N, g.type_rowptr_host = N, starts[:T + 1]
-        g.type_rowptr = torch.tensor(starts[:T + 1], dtype=i32, device=dev)
+        g.type_rowptr = _cached_i32(tuple(starts[:T + 1]), dev)
         e32 = lambda n: torch.empty(n, dtype=i32, device=dev)
         g.node_order, g.row_of_node, z_rows = e32(NA), e32(NA), e32(N)
         g.row_real = torch.empty(N, dtype=torch.float32, device=dev)
@@ -98,7 +119,7 @@ class RelationalGraph(object):
         g.out_rowptr, g.out_edges = e32(N + 1), e32(E)
         shift = None if edge_shift is None else edge_shift.float().contiguous()
         g.shift = None if shift is None else torch.empty(E, 3, dtype=torch.float32, device=dev)
-        act = None if rel_active is None else torch.tensor([bool(a) for a in rel_active], dtype=torch.uint8, device=dev)
+        act = None if rel_active is None else _cached_u8(tuple(bool(a) for a in rel_active), dev)
         wbytes = lib.hermnet_build_relations_workspace(NA, N, E, T)
         work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
         out = _lib.RelationsOut(P(g.node_order), P(g.row_of_node), P(z_rows), P(g.row_real), P(g.row_active),
