@@ -1,9 +1,9 @@
 // gfx950 device-side construction of the relation-ordered graph: the build's replacement for
 // `in_subgraph` (/root/reference/HermNet/utils.py:11-24, called per relation per layer at
-// hermnet.py:52-54).  Instead of N_t O(E) scans per relation per layer, the edge list is sorted
-// three times per neighbour list with a stable LSD radix sort (hipCUB / rocPRIM, keys of
-// ceil(log2 N) bits) and the row pointers come from binary searches -- ~25 launches, no host sync,
-// everything int32.  HBM-streaming integer work: E * ~100 B.
+// hermnet.py:52-54).  Instead of N_t O(E) scans per relation per layer, the edge list is grouped
+// three times per neighbour list by counting sort (histogram -> scan -> scatter -> per-group rank
+// sort; identical to a stable sort by key, deterministic) -- ~25 launches, no host sync, everything
+// int32.  HBM-streaming integer work: E * ~100 B.
 //
 // Orders produced (see include/hermnet_hip.h):
 //   rows : atoms sorted by (relation, id), each relation's block starting at row_start[t]
@@ -132,6 +132,97 @@ __global__ __launch_bounds__(kBlock) void row_active_kernel(const int* __restric
   row_active[r] = on;
 }
 
+
+// ---- grouping by key without a global sort -------------------------------------------------------
+// "Group the indices 0..n-1 by key[i], ascending index inside a group" is what every edge order
+// needs (keys: row(target) | relation(target)*N + row(source) | row(source)).  A counting sort does it
+// in O(n): histogram (integer atomics), exclusive scan, scatter through per-key cursors (order inside a
+// group arbitrary), then a rank sort of every group (groups are neighbour lists: tens of entries).
+// The result is deterministic and identical to a stable sort by key.
+__global__ __launch_bounds__(kBlock) void hist_kernel(const int* __restrict__ key, int n, int* __restrict__ hist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&hist[key[i]], 1);
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_kernel(const int* __restrict__ key, int n, int* __restrict__ cursor,
+                                                        int* __restrict__ slots) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) slots[atomicAdd(&cursor[key[i]], 1)] = i;
+}
+
+// one wave per group: out[rowptr[g] + rank(v)] = v, rank = number of smaller members (members are unique)
+__global__ __launch_bounds__(kBlock) void group_rank_sort_kernel(const int* __restrict__ rowptr, int ngroups,
+                                                                const int* __restrict__ slots, int* __restrict__ out) {
+  const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (g >= ngroups) return;
+  const int lane = threadIdx.x & 63;
+  const int beg = rowptr[g], end = rowptr[g + 1];
+  for (int a = beg + lane; a < end; a += 64) {
+    const int v = slots[a];
+    int rank = 0;
+    for (int b = beg; b < end; ++b) rank += slots[b] < v ? 1 : 0;
+    out[beg + rank] = v;
+  }
+}
+
+struct GroupWork {
+  int* cursor;      // [max keys + 1]
+  int* slots;       // [n]
+  void* scan_temp;
+  size_t scan_bytes;
+};
+
+// rowptr [nkeys+1], out [n]
+int group_by_key(const int* key, int n, int nkeys, int* rowptr, int* out, const GroupWork& w, hipStream_t s) {
+  if (hipMemsetAsync(w.cursor, 0, sizeof(int) * (size_t)(nkeys + 1), s) != hipSuccess) return HN_ERR_LAUNCH;
+  if (n > 0) hipLaunchKernelGGL(hist_kernel, grid_for(n), dim3(kBlock), 0, s, key, n, w.cursor);
+  size_t sb = w.scan_bytes;
+  if (hipcub::DeviceScan::ExclusiveSum(w.scan_temp, sb, w.cursor, rowptr, nkeys + 1, s) != hipSuccess) return HN_ERR_LAUNCH;
+  if (n == 0) return HN_OK;
+  if (hipMemcpyAsync(w.cursor, rowptr, sizeof(int) * (size_t)nkeys, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return HN_ERR_LAUNCH;
+  hipLaunchKernelGGL(scatter_kernel, grid_for(n), dim3(kBlock), 0, s, key, n, w.cursor, w.slots);
+  hipLaunchKernelGGL(group_rank_sort_kernel, dim3((unsigned)((nkeys + 3) / 4)), dim3(kBlock), 0, s, rowptr, nkeys, w.slots, out);
+  return HN_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void edge_target_row_kernel(const long* __restrict__ edge_index, int E,
+                                                                const int* __restrict__ row_of_node,
+                                                                int* __restrict__ key) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < E) key[e] = row_of_node[edge_index[(size_t)E + e]];
+}
+
+// CSR-ordered per-edge arrays + the CSC / out-adjacency keys
+__global__ __launch_bounds__(kBlock) void csr_gather2_kernel(
+    const long* __restrict__ edge_index, const float* __restrict__ shift, int E, int N, int T,
+    const int* __restrict__ row_of_node, const int* __restrict__ row_start, const int* __restrict__ csr_perm,
+    int* __restrict__ csr_src, int* __restrict__ src_id, int* __restrict__ tgt_id, float* __restrict__ shift_csr,
+    int* __restrict__ rt_csr, int* __restrict__ key2, int* __restrict__ key3) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= E) return;
+  const int e = csr_perm[k];
+  const int s = (int)edge_index[e], t = (int)edge_index[(size_t)E + e];
+  const int rs = row_of_node[s], rt = row_of_node[t];
+  csr_src[k] = rs;
+  src_id[k] = s;
+  tgt_id[k] = t;
+  rt_csr[k] = rt;
+  if (shift != nullptr) {
+    shift_csr[3 * k + 0] = shift[3 * e + 0];
+    shift_csr[3 * k + 1] = shift[3 * e + 1];
+    shift_csr[3 * k + 2] = shift[3 * e + 2];
+  }
+  key2[k] = relation_of_row(rt, row_start, T) * N + rs;    // == T*N + rs for unknown-element targets
+  key3[k] = rs;
+}
+
+__global__ __launch_bounds__(kBlock) void csc_tgt2_kernel(const int* __restrict__ rt_csr, const int* __restrict__ csc_pos,
+                                                         int n, int* __restrict__ csc_tgt) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) csc_tgt[k] = rt_csr[csc_pos[k]];
+}
+
 int bits_for(unsigned max_key_exclusive) {
   int b = 1;
   while (b < 32 && (1u << b) < max_key_exclusive) ++b;
@@ -143,6 +234,12 @@ size_t sort_temp_bytes(int n) {
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr,
                                            (const int*)nullptr, (int*)nullptr, n, 0, 32, (hipStream_t)0);
   return bytes;
+}
+
+size_t work_temp_bytes(int n, int nkeys) {
+  size_t a = sort_temp_bytes(n), b = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const int*)nullptr, (int*)nullptr, nkeys + 1, (hipStream_t)0);
+  return a > b ? a : b;
 }
 
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -164,8 +261,9 @@ extern "C" int hermnet_relation_counts(const long* atomic_number, int num_atoms,
 extern "C" size_t hermnet_build_relations_workspace(int num_atoms, int num_rows, int num_edges, int num_rel) {
   (void)num_rows; (void)num_rel;
   const size_t n = (size_t)(num_edges > num_atoms ? num_edges : num_atoms) + 1;
-  // 2 key buffers + 2 value buffers (ping-pong) + 1 extra key (source rows) + the sort's own storage
-  return align256(sort_temp_bytes((int)n)) + 5 * align256(n * sizeof(unsigned)) + 256;
+  const size_t nk = (size_t)(num_rel + 1) * (size_t)num_rows + 2;
+  // 5 index buffers of n + cursor and full CSC row pointer of (T+1)*N + sort/scan storage
+  return align256(work_temp_bytes((int)n, (int)nk)) + 5 * align256(n * sizeof(unsigned)) + 2 * align256(nk * sizeof(int)) + 256;
 }
 
 extern "C" int hermnet_build_relations(const long* atomic_number, const long* edge_index, const float* shift,
@@ -180,13 +278,13 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t n = (size_t)(E > NA ? E : NA) + 1;
   char* w = reinterpret_cast<char*>(workspace);
-  const size_t tb = align256(sort_temp_bytes((int)n));
+  const size_t tb = align256(work_temp_bytes((int)n, (int)((size_t)(T + 1) * N + 2)));
   void* temp = w; w += tb;
   unsigned* keyA = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
   unsigned* keyB = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
   int* valA = reinterpret_cast<int*>(w); w += align256(n * sizeof(unsigned));
   unsigned* key3 = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
-  unsigned* rt_sorted = reinterpret_cast<unsigned*>(w);
+  unsigned* rt_sorted = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
   size_t tbytes = tb;
 
   // ---- rows
@@ -199,33 +297,36 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
     hipLaunchKernelGGL(assign_rows_kernel, grid_for(NA), dim3(kBlock), 0, s, keyB, out->node_order, NA, row_start,
                        T, atomic_number, out->row_of_node, out->z_rows, out->row_real);
   }
-  // ---- CSR by (row(target), edge id)
-  if (E > 0) {
-    hipLaunchKernelGGL(edge_keys_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, E, out->row_of_node, keyA, valA);
-    tbytes = tb;
-    if (hipcub::DeviceRadixSort::SortPairs(temp, tbytes, keyA, rt_sorted, valA, out->csr_perm, E, 0,
-                                           bits_for((unsigned)N), s) != hipSuccess) return HN_ERR_LAUNCH;
-    hipLaunchKernelGGL(csr_gather_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, shift, E, N, T,
-                       out->row_of_node, row_start, rt_sorted, out->csr_perm, out->csr_src, out->src_id,
-                       out->tgt_id, out->shift_csr, keyA, key3, valA);
-  }
-  hipLaunchKernelGGL(rowptr_kernel, grid_for(N + 1), dim3(kBlock), 0, s, rt_sorted, E, N, out->csr_rowptr);
-  // ---- CSC by (relation(target), row(source), CSR position)
-  if (E > 0) {
-    tbytes = tb;
-    if (hipcub::DeviceRadixSort::SortPairs(temp, tbytes, keyA, keyB, valA, out->csc_pos, E, 0,
-                                           bits_for((unsigned)((T + 1) * (size_t)N)), s) != hipSuccess)
-      return HN_ERR_LAUNCH;
-    hipLaunchKernelGGL(csc_tgt_kernel, grid_for(E), dim3(kBlock), 0, s, rt_sorted, out->csc_pos, E, out->csc_tgt);
-  }
-  hipLaunchKernelGGL(rowptr_kernel, grid_for((long)T * N + 1), dim3(kBlock), 0, s, keyB, E, T * N, out->csc_rowptr);
-  // ---- out adjacency by row(source)
-  if (E > 0) {
-    tbytes = tb;
-    if (hipcub::DeviceRadixSort::SortPairs(temp, tbytes, key3, keyB, valA, out->out_edges, E, 0,
-                                           bits_for((unsigned)N), s) != hipSuccess) return HN_ERR_LAUNCH;
-  }
-  hipLaunchKernelGGL(rowptr_kernel, grid_for(N + 1), dim3(kBlock), 0, s, keyB, E, N, out->out_rowptr);
+  // ---- edge orders by counting sort (see group_by_key)
+  int* ikeyA = reinterpret_cast<int*>(keyA);
+  int* ikey2 = reinterpret_cast<int*>(keyB);
+  int* ikey3 = reinterpret_cast<int*>(key3);
+  int* rt_csr = reinterpret_cast<int*>(rt_sorted);
+  GroupWork gw;
+  gw.slots = valA;
+  gw.cursor = reinterpret_cast<int*>(w); w += align256(sizeof(int) * ((size_t)(T + 1) * N + 2));
+  int* csc_rowptr_full = reinterpret_cast<int*>(w); w += align256(sizeof(int) * ((size_t)(T + 1) * N + 2));
+  gw.scan_temp = temp;
+  gw.scan_bytes = tb;
+  int rcg;
+  // CSR: edges grouped by row(target), ascending edge id
+  if (E > 0)
+    hipLaunchKernelGGL(edge_target_row_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, E, out->row_of_node, ikeyA);
+  if ((rcg = group_by_key(ikeyA, E, N, out->csr_rowptr, out->csr_perm, gw, s)) != HN_OK) return rcg;
+  if (E > 0)
+    hipLaunchKernelGGL(csr_gather2_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, shift, E, N, T, out->row_of_node,
+                       row_start, out->csr_perm, out->csr_src, out->src_id, out->tgt_id, out->shift_csr, rt_csr, ikey2,
+                       ikey3);
+  // CSC: CSR positions grouped by (relation(target), row(source)); edges to unknown-element targets fall
+  // into the extra key range [T*N, (T+1)*N) and are simply not covered by csc_rowptr[0 .. T*N]
+  if ((rcg = group_by_key(ikey2, E, (T + 1) * N, csc_rowptr_full, out->csc_pos, gw, s)) != HN_OK) return rcg;
+  if (hipMemcpyAsync(out->csc_rowptr, csc_rowptr_full, sizeof(int) * ((size_t)T * N + 1), hipMemcpyDeviceToDevice, s) !=
+      hipSuccess)
+    return HN_ERR_LAUNCH;
+  if (E > 0)
+    hipLaunchKernelGGL(csc_tgt2_kernel, grid_for(E), dim3(kBlock), 0, s, rt_csr, out->csc_pos, E, out->csc_tgt);
+  // out adjacency: CSR positions grouped by row(source)
+  if ((rcg = group_by_key(ikey3, E, N, out->out_rowptr, out->out_edges, gw, s)) != HN_OK) return rcg;
   hipLaunchKernelGGL(row_active_kernel, grid_for(N), dim3(kBlock), 0, s, out->csc_rowptr, row_start, N, T,
                      rel_active, out->row_real, out->row_active);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
