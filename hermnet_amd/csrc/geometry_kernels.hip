@@ -83,7 +83,7 @@ extern "C" int hermnet_edge_geometry_bwd(const float* gD, const int* in_rowptr, 
                                          int num_nodes, float* gpos, void* stream) {
   if (num_nodes < 0) return HN_ERR_BAD_ARG;
   if (num_nodes == 0) return HN_OK;
-  if (!gD || !in_rowptr || !out_rowptr || !gpos) return HN_ERR_BAD_ARG;
+  if (!in_rowptr || !out_rowptr || !gpos) return HN_ERR_BAD_ARG;   // gD may be NULL for an edge-less graph (never read)
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int block = 256;  // 4 atoms per block
   hipLaunchKernelGGL(edge_geometry_bwd_kernel, dim3((num_nodes + 3) / 4), dim3(block), 0, s,

@@ -801,7 +801,7 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   MsgArgs a = {};
   int rc = fill_args(g, rbf, hidden, a);
   if (rc) return rc;
-  if (!xh || !wt || !brbf || !gx1 || !gvec1 || !gxh || !gx || !gedge) return HN_ERR_BAD_ARG;
+  if (!xh || !wt || !brbf || !gx1 || !gvec1 || !gxh || !gx || (g->num_edges > 0 && !gedge)) return HN_ERR_BAD_ARG;
   if (vec && !gvec) return HN_ERR_BAD_ARG;
   if (g->num_edges > 0 && !edge) return HN_ERR_BAD_ARG;
   if (a.N == 0) return HN_OK;

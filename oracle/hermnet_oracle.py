@@ -228,5 +228,8 @@ def energy_and_forces(sd, elems, data, **kw):
     pos = data.pos.detach().clone().requires_grad_(True)
     e = hvnet_energy(sd, elems, pos, data.atomic_number, data.edge_index, data.batch,
                      data.get("edge_shift"), data.get("cell"), **kw)
-    f = -torch.autograd.grad(e.sum(), pos)[0]
+    if not e.requires_grad:          # no edge at all: the energy does not depend on the coordinates
+        return e.detach(), torch.zeros_like(pos)
+    g = torch.autograd.grad(e.sum(), pos, allow_unused=True)[0]
+    f = torch.zeros_like(pos) if g is None else -g
     return e.detach(), f

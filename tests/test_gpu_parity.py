@@ -394,3 +394,66 @@ def test_device_neighbor_search_bit_exact_vs_host(case):
             assert devr.is_cuda and torch.equal(devr.cpu(), host)
         else:
             assert devr[0].is_cuda and torch.equal(devr[0].cpu(), host[0]) and torch.equal(devr[1].cpu(), host[1])
+
+
+def _oracle_vs_hip(data, elems, kw, seed, tol=TOL):
+    from oracle import hermnet_oracle as orc
+    dev = _dev()
+    model = hn.HVNet(elems, **kw).eval()
+    sd = synth.synth_state_dict(model.state_dict(), seed)
+    model.load_state_dict(sd)
+    okw = dict(rc=kw.get("rc", 5.0), num_layers=kw["num_layers"], hidden_channels=kw["hidden_channels"],
+               num_rbf=kw["num_rbf"], intensive=kw.get("intensive", False))
+    e_ref, f_ref = orc.energy_and_forces(sd, elems if isinstance(elems, list) else [elems], data, **okw)
+    model = model.to(dev)
+    d = hn.Data(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in data}).to(dev)
+    d.pos.requires_grad_(True)
+    e = model(d)
+    g = torch.autograd.grad(e.sum(), d.pos, allow_unused=True)[0] if e.requires_grad else None
+    f = torch.zeros_like(d.pos) if g is None else -g
+    # (energies of a few atoms can cancel to ~1e-2 while the per-atom terms are O(1): absolute floor 1e-6)
+    assert float((e.detach().cpu() - e_ref).abs().max()) <= tol * max(float(e_ref.abs().max()), 0.1), (e, e_ref)
+    assert float((f.cpu() - f_ref).abs().max()) <= tol * max(float(f_ref.abs().max()), 1e-3)
+    return e.detach().cpu(), f.cpu()
+
+
+def test_edge_cases_empty_and_degenerate_graphs():
+    """Ragged / empty inputs: no edges at all, a single atom, only atoms of unlisted elements, an
+    isolated atom next to a bonded cluster, a listed element without atoms (the reference crashes
+    there; the build treats it as a no-op, as does the oracle)."""
+    kw = dict(rc=5.0, num_layers=2, hidden_channels=128, num_rbf=128)
+    # 1) atoms far apart: E = 0 -> every relation is skipped, rows are zero (hermnet.py:56-57)
+    pos = torch.tensor([[0.0, 0, 0], [20.0, 0, 0], [0, 20.0, 0], [0, 0, 20.0]])
+    d = hn.Data(pos=pos, atomic_number=torch.tensor([1, 6, 8, 1]), batch=torch.zeros(4, dtype=torch.long),
+                edge_index=torch.zeros(2, 0, dtype=torch.long))
+    e, f = _oracle_vs_hip(d, ["H", "C", "O"], kw, 31)
+    assert float(f.abs().max()) == 0.0
+    # 2) a single atom
+    d = hn.Data(pos=torch.zeros(1, 3), atomic_number=torch.tensor([6]), batch=torch.zeros(1, dtype=torch.long),
+                edge_index=torch.zeros(2, 0, dtype=torch.long))
+    _oracle_vs_hip(d, ["C"], kw, 32)
+    # 3) only unlisted elements (with edges between them)
+    mol = synth.molecule_batch(num_graphs=2, species=(7, 9))
+    _oracle_vs_hip(mol, ["H", "C", "O"], kw, 33)
+    # 4) isolated atom + cluster, and a listed element ("O") that has no atoms
+    mol = synth.molecule_batch(num_graphs=1, species=(1, 6))
+    n = mol.pos.size(0)
+    pos = torch.cat([mol.pos, torch.tensor([[40.0, 40.0, 40.0]])])
+    d = hn.Data(pos=pos, atomic_number=torch.cat([mol.atomic_number, torch.tensor([1])]),
+                batch=torch.zeros(n + 1, dtype=torch.long), edge_index=mol.edge_index)
+    _oracle_vs_hip(d, ["H", "C", "O"], kw, 34)
+
+
+@pytest.mark.parametrize("H,R,layers", [(512, 128, 2), (64, 20, 3), (192, 50, 2)])
+def test_other_widths_vs_oracle(H, R, layers):
+    """hidden_channels = 512 is the reference default (hermnet.py:86): 8 column blocks; odd num_rbf."""
+    data = synth.fcc_alloy(reps=(2, 2, 3))
+    _oracle_vs_hip(data, ["Al", "Ni", "Cu"], dict(rc=5.0, num_layers=layers, hidden_channels=H, num_rbf=R), 40 + H)
+
+
+def test_unsupported_width_is_refused_loudly():
+    dev = _dev()
+    data = synth.fcc_alloy(reps=(2, 2, 2)).to(dev)
+    model = hn.HVNet(["Al", "Ni", "Cu"], num_layers=1, hidden_channels=96, num_rbf=16).to(dev)
+    with pytest.raises(RuntimeError, match="HN_ERR_BAD_ARG"):
+        model(data)
