@@ -127,15 +127,17 @@ def main():
     model = model.to(dev)
     for p_ in model.parameters():      # energy/force evaluation: no parameter gradients
         p_.requires_grad_(False)
-    gdata = synth.fcc_alloy(reps=(10, 10, 25 * world), seed=0)      # every rank builds the same global cell
+    # every rank builds the same global cell; its neighbour list comes from the device cell list
+    # (bit-identical to the host list, tests/test_gpu_parity.py) and is outside the timed region
+    gdata = synth.fcc_alloy(reps=(10, 10, 25 * world), seed=0, device=dev)
     N_global, E_global = gdata.pos.size(0), gdata.edge_index.size(1)
     if world > 1:
         from hermnet_amd.sharding import partition
-        data, plan = partition(gdata, rank, world)
+        data, plan = partition(gdata.to("cpu"), rank, world)      # host-side planning
         halo = int(plan.halo_global.numel())
         data = data.to(dev)
     else:
-        data, halo = gdata.to(dev), 0
+        data, halo = gdata, 0
     del gdata
     N, E = data.pos.size(0), data.edge_index.size(1)                # local: owned + halo atoms, edges by owned target
     H, T = model_kw["hidden_channels"], len(elems)
@@ -200,6 +202,29 @@ def main():
             "kernels": kernels,
             "energy": float(e.detach()[0]),
         }
+        if world == 1:
+            # secondary figure: the step INCLUDING the device-side neighbour search, i.e. what a
+            # calculator does per MD step (the reference rebuilds the list on the host every step)
+            from hermnet_amd.neighbor import neighbor_search
+            pos0, cell0 = data.pos.detach(), data.cell
+
+            def md_step():
+                ei, sh = neighbor_search(pos0, model_kw["rc"], cell0)
+                d = hn.Data(pos=pos0.clone().requires_grad_(True), atomic_number=data.atomic_number, batch=data.batch,
+                            cell=cell0, edge_index=ei, edge_shift=sh)
+                en = model(d)
+                return en, -torch.autograd.grad(en.sum(), d.pos)[0]
+
+            for _ in range(2):
+                md_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nmd = max(3, min(args.steps, 10))
+            for _ in range(nmd):
+                md_step()
+            torch.cuda.synchronize()
+            out["secondary"] = {"atom_steps_per_s_incl_neighbor_search": N * nmd / (time.perf_counter() - t1),
+                                "note": "device cell-list neighbour search + relation build + energy + forces per step"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_kw, elems, seed)
         print(json.dumps(out))

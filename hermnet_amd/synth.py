@@ -47,16 +47,31 @@ def si_diamond(reps=(2, 2, 2), a=5.43, sigma=0.05, seed=0, rc=5.0, reference_com
     return periodic_data(pos, cell, z, rc, reference_compat)
 
 
-def fcc_alloy(reps=(10, 10, 25), a=3.6, sigma=0.05, seed=0, rc=5.0, species=(13, 28, 29),
-              reference_compat=False):
-    """C2/C4: jittered fcc alloy, 4*prod(reps) atoms, wrapped into the cell;
-    species drawn uniformly after the jitter draw from the same RandomState."""
+def fcc_alloy_atoms(reps=(10, 10, 25), a=3.6, sigma=0.05, seed=0, species=(13, 28, 29)):
+    """Coordinates, cell and species of the C2/C4 alloy (no neighbour list)."""
     pos, cell = _lattice(_FCC, a, reps)
     rs = np.random.RandomState(seed)
     pos = pos + rs.normal(scale=sigma, size=pos.shape)
     pos = pos - np.floor(pos / np.diag(cell)) * np.diag(cell)
     z = np.asarray(species, dtype=np.int64)[rs.randint(0, len(species), size=len(pos))]
-    return periodic_data(pos, cell, z, rc, reference_compat)
+    return pos, cell, z
+
+
+def fcc_alloy(reps=(10, 10, 25), a=3.6, sigma=0.05, seed=0, rc=5.0, species=(13, 28, 29),
+              reference_compat=False, device=None):
+    """C2/C4: jittered fcc alloy, 4*prod(reps) atoms, wrapped into the cell;
+    species drawn uniformly after the jitter draw from the same RandomState.
+    `device`: build the neighbour list with the device cell list (identical result, much faster for
+    the 80k-100k atom cells) and return the `Data` on that device."""
+    pos, cell, z = fcc_alloy_atoms(reps, a, sigma, seed, species)
+    if device is None:
+        return periodic_data(pos, cell, z, rc, reference_compat)
+    from .neighbor import neighbor_search
+    pos_t = torch.from_numpy(pos.astype(np.float32)).to(device)
+    cell_t = torch.from_numpy(cell.astype(np.float32)).to(device)
+    ei, sh = neighbor_search(pos_t, rc, cell_t, reference_compat=reference_compat)
+    return Data(pos=pos_t, atomic_number=torch.from_numpy(z).to(device), edge_index=ei, edge_shift=sh,
+                cell=cell_t.reshape(1, 3, 3), batch=torch.zeros(len(pos), dtype=torch.long, device=device))
 
 
 def molecule_batch(num_graphs=1024, nmin=9, nmax=30, species=(1, 6, 8), radius=3.0, min_sep=0.9,
