@@ -24,7 +24,7 @@
 #define HN_TAPS 12      // taps kept per edge
 #define HN_TAP_BELOW 5  // window = floor(t) - 5 .. floor(t) + 6
 #define HN_PAD 11       // zero rows before/after the R weight rows in LDS (window clamp range)
-#define HN_CB 64        // channels per column block (one half-wave x float2)
+#define HN_CB 64        // channels per column block (one lane group: 32 lanes x 2 or 16 lanes x 4 channels)
 
 struct HnEnv {
   float val;   // env(u)
