@@ -146,15 +146,10 @@ class HVNet(nn.Module):
                 energy = energy / SumAcrossRanks.apply(cnt, shard.group).clamp(min=1)
             return energy
         # scatter(per_atom_energy, batch, reduce=sum|mean) (hermnet.py:130) as an ordered segment
-        # reduction: no atomics, so the energy is bit-reproducible run to run
-        if graph.num_graphs == 1:
-            energy = per_atom_energy.sum().reshape(1)
-            if self.intensive:
-                energy = energy / max(graph.num_atoms, 1)
-        else:
-            energy = torch.segment_reduce(per_atom_energy[graph.graph_perm], "sum", lengths=graph.graph_lengths)
-            if self.intensive:
-                energy = energy / graph.graph_lengths.clamp(min=1).to(energy.dtype)
+        # reduction: no atomics, so the energies are bit-reproducible run to run
+        energy = torch.segment_reduce(per_atom_energy[graph.graph_perm], "sum", lengths=graph.graph_lengths)
+        if self.intensive:
+            energy = energy / graph.graph_lengths.clamp(min=1).to(energy.dtype)
         return energy
 
 

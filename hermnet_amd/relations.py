@@ -14,7 +14,7 @@ import os
 
 import torch
 
-_COUNT_CACHE = {}
+_COUNT_CACHE = []      # most recent first: (z tensor, version, batch tensor, version, z_list, result)
 _CONST_CACHE = {}
 
 
@@ -93,9 +93,14 @@ class RelationalGraph(object):
         i32, P = torch.int32, _lib.ptr
         # element counts and graph count: a host sync, skipped while the same tensors are passed again
         # (atom types and batch assignment do not change along an MD trajectory)
-        key = (z.data_ptr(), z._version, NA, tuple(z_list),
-               None if batch is None else (batch.data_ptr(), batch._version))
-        hit = _COUNT_CACHE.get(key)
+        # (identity of the tensor OBJECTS, which the cache keeps alive: an address alone could be reused by
+        # a different tensor of the same size)
+        hit = None
+        for ent in _COUNT_CACHE:
+            if (ent[0] is z and ent[1] == z._version and ent[2] is batch
+                    and ent[3] == (None if batch is None else batch._version) and ent[4] == tuple(z_list)):
+                hit = ent[5]
+                break
         if hit is None:
             zl = torch.tensor(list(z_list), dtype=i32, device=dev)
             counts = torch.empty(T + 1, dtype=i32, device=dev)
@@ -103,9 +108,8 @@ class RelationalGraph(object):
             nb = batch.long().max().reshape(1) + 1 if (batch is not None and NA > 0) else torch.ones(1, dtype=torch.long, device=dev)
             host = torch.cat([counts.long(), nb]).cpu().tolist()
             hit = (zl, host[:T + 1], int(host[-1]))
-            if len(_COUNT_CACHE) > 16:
-                _COUNT_CACHE.clear()
-            _COUNT_CACHE[key] = hit
+            _COUNT_CACHE.insert(0, (z, z._version, batch, None if batch is None else batch._version, tuple(z_list), hit))
+            del _COUNT_CACHE[8:]
         zl, cnt_host, g.num_graphs = hit
         g.uniform, g.block, starts, N = RelationalGraph._layout(cnt_host, T, uniform)
         g.N, g.type_rowptr_host = N, starts[:T + 1]
