@@ -98,40 +98,40 @@ struct Vec {
   }
 };
 
+// Elementwise ops are written on explicit <2 x float> pairs so that they select the packed fp32
+// instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, scalars broadcast by op_sel): the SLP
+// vectoriser packs only some of these chains on its own.
+typedef float hn_f2 __attribute__((ext_vector_type(2)));
+#define HN_PAIRWISE(expr)                                   \
+  Vec<VW> r;                                                \
+  _Pragma("unroll") for (int i = 0; i < VW; i += 2) {       \
+    const hn_f2 rv = (expr);                                \
+    r.v[i] = rv.x;                                          \
+    r.v[i + 1] = rv.y;                                      \
+  }                                                         \
+  return r;
+#define HN_P(x) (hn_f2{(x).v[i], (x).v[i + 1]})
+#define HN_S(x) (hn_f2{(x), (x)})
+
 template <int VW>
 __device__ __forceinline__ Vec<VW> v_fma(const Vec<VW>& a, const Vec<VW>& b, const Vec<VW>& c) {   // a * b + c
-  Vec<VW> r;
-#pragma unroll
-  for (int i = 0; i < VW; ++i) r.v[i] = fmaf(a.v[i], b.v[i], c.v[i]);
-  return r;
+  HN_PAIRWISE(__builtin_elementwise_fma(HN_P(a), HN_P(b), HN_P(c)))
 }
 template <int VW>
 __device__ __forceinline__ Vec<VW> v_sfma(float s, const Vec<VW>& a, const Vec<VW>& c) {   // s * a + c
-  Vec<VW> r;
-#pragma unroll
-  for (int i = 0; i < VW; ++i) r.v[i] = fmaf(s, a.v[i], c.v[i]);
-  return r;
+  HN_PAIRWISE(__builtin_elementwise_fma(HN_S(s), HN_P(a), HN_P(c)))
 }
 template <int VW>
 __device__ __forceinline__ Vec<VW> v_mul(const Vec<VW>& a, const Vec<VW>& b) {
-  Vec<VW> r;
-#pragma unroll
-  for (int i = 0; i < VW; ++i) r.v[i] = a.v[i] * b.v[i];
-  return r;
+  HN_PAIRWISE(HN_P(a) * HN_P(b))
 }
 template <int VW>
 __device__ __forceinline__ Vec<VW> v_scale(const Vec<VW>& a, float s) {
-  Vec<VW> r;
-#pragma unroll
-  for (int i = 0; i < VW; ++i) r.v[i] = a.v[i] * s;
-  return r;
+  HN_PAIRWISE(HN_P(a) * HN_S(s))
 }
 template <int VW>
 __device__ __forceinline__ Vec<VW> v_add(const Vec<VW>& a, const Vec<VW>& b) {
-  Vec<VW> r;
-#pragma unroll
-  for (int i = 0; i < VW; ++i) r.v[i] = a.v[i] + b.v[i];
-  return r;
+  HN_PAIRWISE(HN_P(a) + HN_P(b))
 }
 template <int VW>
 __device__ __forceinline__ float v_hsum(const Vec<VW>& a) {
@@ -777,7 +777,7 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   static const int rpb_fwd = env_int("HERMNET_FWD_ROWS", 0);
   // defaults from tools/kbench.py on MI355X (config 2): see DESIGN.md "Kernel variants"
   static const int variant_vec = env_int("HERMNET_FWD_VARIANT", 8420);
-  static const int variant_l0 = env_int("HERMNET_FWD_VARIANT_L0", 16201);
+  static const int variant_l0 = env_int("HERMNET_FWD_VARIANT_L0", 8400);
   const int variant = vec ? variant_vec : variant_l0;
   a.rows_per_block = pick_rows(a.N, hidden / HN_CB, a.T * (hidden / HN_CB), rpb_fwd);
   const size_t lds = lds_bytes(a.R);
@@ -810,7 +810,7 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   a.gx1 = gx1; a.gvec1 = gvec1; a.gxh = gxh; a.gvec = gvec; a.gx = gx;
   a.gedge = reinterpret_cast<float4*>(gedge);
   static const int rpb_bwd = env_int("HERMNET_BWD_ROWS", 0);
-  static const int variant_vec = env_int("HERMNET_BWD_VARIANT", 16201);
+  static const int variant_vec = env_int("HERMNET_BWD_VARIANT", 8420);
   static const int variant_l0 = env_int("HERMNET_BWD_VARIANT_L0", 16201);
   const int variant = vec ? variant_vec : variant_l0;
   a.split_t = split_t ? 1 : 0;
