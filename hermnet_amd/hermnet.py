@@ -84,9 +84,29 @@ class HVNet(nn.Module):
             raise RuntimeError("hermnet_amd.HVNet runs on MI355X only (data is on %s); there is no CPU fallback"
                                % pos.device)
 
+    @staticmethod
+    def _edge_geometry_autograd(pos, cell, graph):
+        """`with_edge` (hermnet.py:133-152) as differentiable device ops, CSR order -> edge[E,4] = (rhat, d).
+        Training path only: `create_graph=True` needs second derivatives, which the geometry kernel's
+        hand-written backward does not provide."""
+        src, tgt = graph.src_id.long(), graph.tgt_id.long()
+        D = pos[src] - pos[tgt]
+        if graph.shift is not None and cell is not None:
+            c = cell.reshape(-1, 3, 3)
+            D = D + torch.einsum("ni,nij->nj", graph.shift.to(D.dtype), c[graph.batch32.long()[src]])
+        d = D.norm(dim=-1)
+        d = torch.where(d.abs() <= 1.0e-6, torch.full_like(d, 1.0e-6), d)           # hermnet.py:146-147
+        return torch.cat([D / d[:, None], d[:, None]], dim=1)
+
     def forward(self, data):
+        """Two execution modes behind the same signature, chosen like any PyTorch module chooses:
+        `eval()` (calculators, MD, validation -- `calculator.py:73`, `lmp_calc.py:46`, `dist_train.py:109`):
+        the fused gfx950 kernels, first-order gradients w.r.t. pos / cell.  `train()` with grad mode on
+        (`dist_train.py:81-99`): every op is a differentiable device op, so `autograd.grad(E, pos,
+        create_graph=True)` and `loss.backward()` give the gradients of all parameters."""
         pos = data.pos
         self._require_device(pos)
+        train = self.training and torch.is_grad_enabled()
         if data.get("batch") is None:
             # the reference fails here (scatter(..., None), hermnet.py:130); a single graph is meant
             data.batch = torch.zeros(pos.size(0), dtype=torch.long, device=pos.device)
@@ -97,19 +117,25 @@ class HVNet(nn.Module):
         graph = RelationalGraph.build(data.atomic_number, data.edge_index, zl,
                                       edge_shift=data.get("edge_shift") if data.get("cell") is not None else None,
                                       batch=data.batch, rel_active=rel_active)
-        fused = self.radial_basis.fused
+        fused = self.radial_basis.fused and not train
         rbf = self.radial_basis.descriptor() if fused else None
         row_plan = None
         if shard is not None:
+            if train:
+                raise NotImplementedError("atom-sharded evaluation is first-order (energy/forces); train with "
+                                          "DistributedDataParallel over whole graphs (example/dist_train.py:63)")
             if shard.owned_mask.device != pos.device:
                 shard.to(pos.device)
             pos = HaloExchange.apply(pos, shard.atom_plan)                  # halo coordinates from their owners
             row_plan = shard.atom_plan.remap(graph.row_of_node)
-        edge = EdgeGeometry.apply(pos, data.get("cell"), graph)          # with_edge, hermnet.py:133-152
+        if train:
+            edge = self._edge_geometry_autograd(pos, data.get("cell"), graph)
+        else:
+            edge = EdgeGeometry.apply(pos, data.get("cell"), graph)      # with_edge, hermnet.py:133-152
 
         x = self.embed(graph.z_rows)                                        # hermnet.py:123, row order (pads: Z=0)
         vec = None                                                          # zeros, hermnet.py:124
-        if not fused:
+        if not fused and not train:
             edge = TrueEdgeGradient.apply(edge)      # autograd's (rhat, d) gradients -> Cartesian for the kernel
         data._hn_graph, data._hn_edge, data._hn_rbf = graph, edge, rbf
         # rmnet.py:168-172 for the optional bases only: [E,R] basis from the kernel's distances
@@ -147,7 +173,10 @@ class HVNet(nn.Module):
             return energy
         # scatter(per_atom_energy, batch, reduce=sum|mean) (hermnet.py:130) as an ordered segment
         # reduction: no atomics, so the energies are bit-reproducible run to run
-        energy = torch.segment_reduce(per_atom_energy[graph.graph_perm], "sum", lengths=graph.graph_lengths)
+        if train:   # segment_reduce has no second derivative
+            energy = torch.zeros(graph.num_graphs, dtype=x.dtype, device=x.device).index_add(0, batch, per_atom_energy)
+        else:
+            energy = torch.segment_reduce(per_atom_energy[graph.graph_perm], "sum", lengths=graph.graph_lengths)
         if self.intensive:
             energy = energy / graph.graph_lengths.clamp(min=1).to(energy.dtype)
         return energy

@@ -4,7 +4,7 @@ autograd node with a hand-written first-order backward.
 The launch sequence is fixed and short: LayerNorm, 2 GEMMs, the fused message kernel, and per
 relation three GEMMs joined by fused elementwise kernels (`csrc/node_kernels.hip`).  Parameters
 are treated as constants (energy/force evaluation; parameter gradients are not produced --
-training is out of scope).
+the training step runs through the differentiable device-op path, `HVNet.forward` in train() mode).
 """
 import ctypes
 import math

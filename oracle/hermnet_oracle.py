@@ -233,3 +233,23 @@ def energy_and_forces(sd, elems, data, **kw):
     g = torch.autograd.grad(e.sum(), pos, allow_unused=True)[0]
     f = torch.zeros_like(pos) if g is None else -g
     return e.detach(), f
+
+
+def training_loss_and_grads(sd, elems, data, y, forces, gamma=0.8, **kw):
+    """One optimisation step's loss and parameter gradients, `example/dist_train.py:86-99`:
+    e_loss = MSE(E, y), F = -d(sum E)/d pos with create_graph=True, f_loss = MSE(F, forces),
+    loss = (1-gamma) e_loss + gamma f_loss, loss.backward().  Returns (loss, e_loss, f_loss,
+    {state_dict key: gradient or None}); buffers (e.g. `radial_basis.rbf.offset`) are not differentiated."""
+    buffers = ("radial_basis.rbf.offset",)
+    p = {k: (v.detach().clone().requires_grad_(True) if (k not in buffers and v.is_floating_point()) else v)
+         for k, v in sd.items()}
+    pos = data.pos.detach().clone().requires_grad_(True)
+    e = hvnet_energy(p, elems, pos, data.atomic_number, data.edge_index, data.batch,
+                     data.get("edge_shift"), data.get("cell"), **kw)
+    e_loss = F.mse_loss(e, y)
+    f = -torch.autograd.grad(e.sum(), pos, create_graph=True)[0]
+    f_loss = F.mse_loss(f, forces)
+    loss = (1 - gamma) * e_loss + gamma * f_loss
+    keys = [k for k, v in p.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [p[k] for k in keys], allow_unused=True)
+    return loss.detach(), e_loss.detach(), f_loss.detach(), dict(zip(keys, grads))

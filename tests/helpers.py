@@ -17,6 +17,7 @@ GOLDEN = os.path.join(HERE, "golden")
 SMALL_CASES = ["c1_si64", "c1_si64_refcompat", "alloy108", "alloy108_unknown_type", "alloy108_h64",
                "alloy32_h256", "mol16", "mol16_intensive"]
 NONGAUSS_CASES = ["alloy32_bessel_expenv", "alloy32_bernstein"]
+TRAIN_CASES = ["train_alloy108_h64", "train_mol8_h64", "train_si64_intensive_h64"]
 
 
 def sd_checksum(sd):
@@ -64,6 +65,13 @@ class Golden(object):
         m.load_state_dict(sd)
         m.eval()
         return m
+
+    def training(self):
+        """Training-step fixture (tests/golden/gen_train_golden.py): targets, loss terms, parameter gradients."""
+        a = self.arrays
+        grads = {k[5:]: torch.from_numpy(v) for k, v in a.items() if k.startswith("grad:")}
+        return (torch.from_numpy(a["y"]), torch.from_numpy(a["force_target"]), self.meta["gamma"],
+                [float(v) for v in a["loss"]], grads)
 
     def oracle_kwargs(self):
         kw = dict(self.model_kw)

@@ -4,7 +4,7 @@ operation order)."""
 import pytest
 import torch
 
-from helpers import Golden, SMALL_CASES, NONGAUSS_CASES, rel_err
+from helpers import Golden, SMALL_CASES, NONGAUSS_CASES, TRAIN_CASES, rel_err
 from oracle import hermnet_oracle as orc
 
 TOL = 1e-6
@@ -71,3 +71,23 @@ def test_physics_invariants_of_the_oracle():
     d2.pos = d2.pos + torch.tensor([0.3, -0.2, 0.1])
     e2, f2 = orc.energy_and_forces(sd, g.elems, d2, **kw)
     assert rel_err(e2, e) < 1e-5 and rel_err(f2, f) < 1e-4   # translation invariance
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+@pytest.mark.parametrize("mode", ["faithful", "vectorised"])
+def test_oracle_training_step_matches_reference(name, mode):
+    """Loss of `example/dist_train.py:86-99` (force term through create_graph=True) and the gradient of
+    every parameter, against the reference's own backward pass."""
+    g = Golden(name)
+    sd = g.model().state_dict()
+    y, ftgt, gamma, (loss, e_loss, f_loss), grads = g.training()
+    l, le, lf, og = orc.training_loss_and_grads(sd, g.elems, g.data(), y, ftgt, gamma, mode=mode, **g.oracle_kwargs())
+    assert abs(float(le) - e_loss) < 2e-5 * max(1.0, e_loss)
+    assert abs(float(lf) - f_loss) < 2e-5 * max(1.0, f_loss)
+    assert abs(float(l) - loss) < 2e-5 * max(1.0, loss)
+    assert set(k for k, v in og.items() if v is not None) == set(grads.keys())
+    gmax = max(float(v.abs().max()) for v in grads.values())
+    for k, ref in grads.items():
+        # per tensor, relative to the tensor's largest entry (floor: 1e-3 of the largest gradient anywhere)
+        scale = max(float(ref.abs().max()), 1e-3 * gmax)
+        assert float((og[k] - ref).abs().max()) / scale < 2e-5, k
