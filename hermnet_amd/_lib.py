@@ -41,9 +41,9 @@ SIGNATURES = {
     "hermnet_edge_geometry_fwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
     "hermnet_edge_geometry_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
     "hermnet_message_scatter_fwd": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), ctypes.c_int,
-                                                   c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+                                                   c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "hermnet_message_scatter_bwd": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), ctypes.c_int,
-                                                   c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                                   c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                                    c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
     "hermnet_neighbor_workspace": (ctypes.c_size_t, [ctypes.c_int]),
     "hermnet_neighbor_sort_workspace": (ctypes.c_size_t, [ctypes.c_long]),
@@ -57,12 +57,14 @@ SIGNATURES = {
     "hermnet_build_relations": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_int,
                                                c_fp, ctypes.c_int, c_fp, ctypes.POINTER(RelationsOut), c_fp,
                                                ctypes.c_size_t, c_fp]),
-    "hermnet_ssilu_fwd": (ctypes.c_int, [c_fp, c_fp, ctypes.c_long, c_fp]),
-    "hermnet_ssilu_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+    "hermnet_ssilu_fwd": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_long, ctypes.c_int, c_fp]),
+    "hermnet_ssilu_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_long, ctypes.c_long, c_fp]),
     "hermnet_update_mid": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
-    "hermnet_update_out": (ctypes.c_int, [c_fp] * 8 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
-    "hermnet_update_out_bwd": (ctypes.c_int, [c_fp] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_update_out": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int] + [c_fp] * 7 +
+                           [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_update_out_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int] + [c_fp] * 8 +
+                               [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_update_mid_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_host_rbf_row": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                             ctypes.c_int, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp]),

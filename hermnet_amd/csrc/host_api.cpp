@@ -5,7 +5,7 @@
 #include "../../include/hermnet_hip.h"
 #include "hermnet_math.h"
 
-extern "C" int hermnet_abi_version(void) { return 1; }
+extern "C" int hermnet_abi_version(void) { return 2; }
 
 extern "C" const char* hermnet_build_info(void) {
   return "hermnet_hip abi=1 target=gfx950 taps=12 colblock=64 built " __DATE__ " " __TIME__;

@@ -57,6 +57,7 @@ struct MsgArgs {
   const float4* edge;  // [E] (rx,ry,rz,d)
   float* x1;           // fwd out
   float* vec1;         // fwd out
+  const float* xh_bias;  // [T,3H] or null: bias of the x_proj output, added on load (xh holds the GEMM without it)
   const float* gx1;    // bwd in
   const float* gvec1;  // bwd in
   float* gxh;          // bwd out [T,N,3H]
@@ -344,9 +345,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
   const float inv_sqrth = rsqrtf((float)H);
   const float* xh_t = a.xh + (size_t)t * a.N * 3 * H;
 
-  Vec<VW> bias[3];
+  Vec<VW> bias[3], xbias[3];
 #pragma unroll
-  for (int p = 0; p < 3; ++p) bias[p] = Vec<VW>::load(a.brbf + (size_t)t * 3 * H + p * H + col);
+  for (int p = 0; p < 3; ++p) {
+    bias[p] = Vec<VW>::load(a.brbf + (size_t)t * 3 * H + p * H + col);
+    xbias[p] = a.xh_bias ? Vec<VW>::load(a.xh_bias + (size_t)t * 3 * H + p * H + col) : Vec<VW>::zero();
+  }
 
   for (int r = r0 + wave; r < r1; r += NW) {
     const int beg = a.csr_rowptr[r], end = a.csr_rowptr[r + 1];
@@ -415,17 +419,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
         Vec<VW> S0, S1;
         // message (rmnet.py:61-67), one part at a time to keep the register footprint small
         if (FUSED) S0 = S0p[0]; else rbf_part<false, VW>(wcol, g, gd, S0, S1);   // part s -> dx
-        ax = v_fma(cur.xs, v_sfma(ev, S0, v_scale(bias[0], lv)), ax);
+        ax = v_fma(v_add(cur.xs, xbias[0]), v_sfma(ev, S0, v_scale(bias[0], lv)), ax);
         HN_SB;
         if (FUSED) S0 = S0p[2]; else rbf_part<false, VW>(wcol + 2 * HN_CB, g, gd, S0, S1);   // part b -> rhat term
-        const Vec<VW> mb = v_scale(v_mul(cur.xb, v_sfma(ev, S0, v_scale(bias[2], lv))), inv_sqrth);
+        const Vec<VW> mb = v_scale(v_mul(v_add(cur.xb, xbias[2]), v_sfma(ev, S0, v_scale(bias[2], lv))), inv_sqrth);
         av[0] = v_sfma(cur.g.x, mb, av[0]);
         av[1] = v_sfma(cur.g.y, mb, av[1]);
         av[2] = v_sfma(cur.g.z, mb, av[2]);
         HN_SB;
         if (HAS_VEC) {
           if (FUSED) S0 = S0p[1]; else rbf_part<false, VW>(wcol + HN_CB, g, gd, S0, S1);   // part a -> vec_j term
-          const Vec<VW> ma = v_scale(v_mul(cur.xa, v_sfma(ev, S0, v_scale(bias[1], lv))), inv_sqrt3h);
+          const Vec<VW> ma = v_scale(v_mul(v_add(cur.xa, xbias[1]), v_sfma(ev, S0, v_scale(bias[1], lv))), inv_sqrt3h);
 #pragma unroll
           for (int d = 0; d < 3; ++d) av[d] = v_fma(cur.vj[d], ma, av[d]);
         }
@@ -510,7 +514,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
     for (int r = r0 + wave; r < r1; r += NW) {
       const int beg = a.csc_rowptr[(size_t)t * a.N + r], end = a.csc_rowptr[(size_t)t * a.N + r + 1];
       const float* xr = xh_t + (size_t)r * 3 * H + col;
-      const Vec<VW> xs = Vec<VW>::load(xr), xa = Vec<VW>::load(xr + H), xb = Vec<VW>::load(xr + 2 * H);
+      Vec<VW> xs = Vec<VW>::load(xr), xa = Vec<VW>::load(xr + H), xb = Vec<VW>::load(xr + 2 * H);
+      if (a.xh_bias) {   // per source segment: free next to the per-edge work
+        const float* xbp = a.xh_bias + (size_t)t * 3 * H + col;
+        xs = v_add(xs, Vec<VW>::load(xbp)); xa = v_add(xa, Vec<VW>::load(xbp + H)); xb = v_add(xb, Vec<VW>::load(xbp + 2 * H));
+      }
       Vec<VW> vj[3] = {Vec<VW>::zero(), Vec<VW>::zero(), Vec<VW>::zero()};
       if (HAS_VEC) {
         const float* vr = a.vec + (size_t)r * 3 * H + col;
@@ -763,7 +771,7 @@ kern_t pick_bwd(int variant, int& nw) {
 }  // namespace
 
 extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc* rbf, int hidden,
-                                           const float* xh, const float* vec, const float* x,
+                                           const float* xh, const float* xh_bias, const float* vec, const float* x,
                                            const float* wt, const float* brbf, const float* edge,
                                            float* x1, float* vec1, void* stream) {
   MsgArgs a = {};
@@ -771,7 +779,7 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   if (rc) return rc;
   if (!xh || !x || !wt || !brbf || !x1 || !vec1 || (g->num_edges > 0 && !edge)) return HN_ERR_BAD_ARG;
   if (a.N == 0) return HN_OK;
-  a.xh = xh; a.vec = vec; a.x = x; a.wt = wt; a.brbf = brbf;
+  a.xh = xh; a.xh_bias = xh_bias; a.vec = vec; a.x = x; a.wt = wt; a.brbf = brbf;
   a.edge = reinterpret_cast<const float4*>(edge);
   a.x1 = x1; a.vec1 = vec1;
   static const int rpb_fwd = env_int("HERMNET_FWD_ROWS", 0);
@@ -793,7 +801,7 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
 }
 
 extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc* rbf, int hidden,
-                                           const float* xh, const float* vec,
+                                           const float* xh, const float* xh_bias, const float* vec,
                                            const float* wt, const float* brbf, const float* edge,
                                            const float* gx1, const float* gvec1,
                                            float* gxh, float* gvec, float* gx, float* gedge,
@@ -805,7 +813,7 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   if (vec && !gvec) return HN_ERR_BAD_ARG;
   if (g->num_edges > 0 && !edge) return HN_ERR_BAD_ARG;
   if (a.N == 0) return HN_OK;
-  a.xh = xh; a.vec = vec; a.wt = wt; a.brbf = brbf;
+  a.xh = xh; a.xh_bias = xh_bias; a.vec = vec; a.wt = wt; a.brbf = brbf;
   a.edge = reinterpret_cast<const float4*>(edge);
   a.gx1 = gx1; a.gvec1 = gvec1; a.gxh = gxh; a.gvec = gvec; a.gx = gx;
   a.gedge = reinterpret_cast<float4*>(gedge);

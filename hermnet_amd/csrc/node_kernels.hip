@@ -18,11 +18,24 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 
-// a[row, col] = silu(h) / 0.6 ; both [rows, cols] with row strides
-__global__ __launch_bounds__(256) void ssilu_fwd_kernel(const float* __restrict__ h, float* __restrict__ a, long n4) {
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// Bias row of `row` for a [rows, cols] operand: bias is [groups, cols], group = row / rows_per_bias
+// (rows_per_bias <= 0: one row for everything).  The GEMM that produced the operand ran without its bias
+// (a broadcast-bias GEMM costs a full extra write + read of the output); it is added on load here.
+__device__ __forceinline__ float4 bias4(const float* bias, int rows_per_bias, long row, int cols, int col) {
+  if (bias == nullptr) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const long grp = rows_per_bias > 0 ? row / rows_per_bias : 0;
+  return ld4(bias + grp * cols + col);
+}
+
+// a[row, col] = silu(h + bias) / 0.6 ; h, a contiguous [rows, cols]
+__global__ __launch_bounds__(256) void ssilu_fwd_kernel(const float* __restrict__ h, const float* __restrict__ bias,
+                                                        int rows_per_bias, float* __restrict__ a, long n4, int cols) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
-  const float4 v = ld4(h + 4 * i);
+  const int c4n = cols >> 2;
+  const float4 v = add4(ld4(h + 4 * i), bias4(bias, rows_per_bias, i / c4n, cols, (int)(i % c4n) * 4));
   float4 o;
   o.x = v.x * sigmoidf_(v.x) * kSiluScale;
   o.y = v.y * sigmoidf_(v.y) * kSiluScale;
@@ -36,9 +49,11 @@ __device__ __forceinline__ float dssilu(float x) {
   return s * (1.0f + x * (1.0f - s)) * kSiluScale;
 }
 
-// gh[n, t, c] = g[t?..] * d ssilu(h[n, t, c]);  g is addressed as g[n * gs_n + t * gs_t + c]
-// (gs_n = T*C, gs_t = C for the same layout as h; gs_n = C, gs_t = N*C for a [T,N,C] gradient).
+// gh[n, t, c] = g[t?..] * d ssilu(h[n, t, c] + bias);  g is addressed as g[n * gs_n + t * gs_t + c]
+// (gs_n = T*C, gs_t = C for the same layout as h; gs_n = C, gs_t = N*C for a [T,N,C] gradient);
+// bias as in ssilu_fwd for the [N, T*C] view of h.
 __global__ __launch_bounds__(256) void ssilu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ h,
+                                                        const float* __restrict__ bias, int rows_per_bias,
                                                         float* __restrict__ gh, int N, int T, int C,
                                                         long gs_n, long gs_t) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index into h
@@ -49,7 +64,7 @@ __global__ __launch_bounds__(256) void ssilu_bwd_kernel(const float* __restrict_
   const long nt = i / c4n;
   const int t = (int)(nt % T);
   const long n = nt / T;
-  const float4 hv = ld4(h + 4 * i);
+  const float4 hv = add4(ld4(h + 4 * i), bias4(bias, rows_per_bias, n, T * C, t * C + 4 * c4));
   const float4 gv = ld4(g + n * gs_n + t * gs_t + 4 * c4);
   float4 o;
   o.x = gv.x * dssilu(hv.x);
@@ -83,8 +98,10 @@ __global__ __launch_bounds__(256) void update_mid_kernel(const float* __restrict
       make_float4(sqrtf(sq.x + 1e-8f), sqrtf(sq.y + 1e-8f), sqrtf(sq.z + 1e-8f), sqrtf(sq.w + 1e-8f)));
 }
 
-// x_out = x1 + (q1 + q2 vdot)/sqrt2 ; vec_out[d] = vec1[d] + q3 v1[d]; rows with m == 0 (or >= nk) are zero
-__global__ __launch_bounds__(256) void update_out_kernel(const float* __restrict__ q, const float* __restrict__ vdot,
+// x_out = x1 + (q1 + q2 vdot)/sqrt2 ; vec_out[d] = vec1[d] + q3 v1[d]; rows with m == 0 (or >= nk) are zero;
+// q = q_in + bias (see bias4)
+__global__ __launch_bounds__(256) void update_out_kernel(const float* __restrict__ q, const float* __restrict__ qbias,
+                                                         int rows_per_bias, const float* __restrict__ vdot,
                                                          const float* __restrict__ vp, const float* __restrict__ x1,
                                                          const float* __restrict__ vec1, const float* __restrict__ mask,
                                                          float* __restrict__ xo, float* __restrict__ vo,
@@ -102,7 +119,9 @@ __global__ __launch_bounds__(256) void update_out_kernel(const float* __restrict
     for (int d = 0; d < 3; ++d) st4(vo + (r * 3 + d) * H + c, z);
     return;
   }
-  const float4 q1 = ld4(q + r * 3 * H + c), q2 = ld4(q + r * 3 * H + H + c), q3 = ld4(q + r * 3 * H + 2 * H + c);
+  const float4 q1 = add4(ld4(q + r * 3 * H + c), bias4(qbias, rows_per_bias, r, 3 * H, c));
+  const float4 q2 = add4(ld4(q + r * 3 * H + H + c), bias4(qbias, rows_per_bias, r, 3 * H, H + c));
+  const float4 q3 = add4(ld4(q + r * 3 * H + 2 * H + c), bias4(qbias, rows_per_bias, r, 3 * H, 2 * H + c));
   const float4 vd = ld4(vdot + r * H + c), xv = ld4(x1 + r * H + c);
   st4(xo + r * H + c, make_float4(xv.x + (q1.x + q2.x * vd.x) * kInvSqrt2, xv.y + (q1.y + q2.y * vd.y) * kInvSqrt2,
                                   xv.z + (q1.z + q2.z * vd.z) * kInvSqrt2, xv.w + (q1.w + q2.w * vd.w) * kInvSqrt2));
@@ -119,6 +138,7 @@ __global__ __launch_bounds__(256) void update_out_kernel(const float* __restrict
 // update_mid_bwd), gx1o [N,H] (= masked gxo), gv1o [N,3,H] (= masked gvo)
 __global__ __launch_bounds__(256) void update_out_bwd_kernel(
     const float* __restrict__ gxo, const float* __restrict__ gvo, const float* __restrict__ q,
+    const float* __restrict__ qbias, int rows_per_bias,
     const float* __restrict__ vdot, const float* __restrict__ vp, const float* __restrict__ mask,
     float* __restrict__ gq, float* __restrict__ gvdot, float* __restrict__ gvp, float* __restrict__ gx1o,
     float* __restrict__ gv1o, int N, int nk, int H) {
@@ -142,7 +162,8 @@ __global__ __launch_bounds__(256) void update_out_bwd_kernel(
     return;
   }
   const float4 gx = ld4(gxo + r * H + c);
-  const float4 q2 = ld4(q + r * 3 * H + H + c), q3 = ld4(q + r * 3 * H + 2 * H + c);
+  const float4 q2 = add4(ld4(q + r * 3 * H + H + c), bias4(qbias, rows_per_bias, r, 3 * H, H + c));
+  const float4 q3 = add4(ld4(q + r * 3 * H + 2 * H + c), bias4(qbias, rows_per_bias, r, 3 * H, 2 * H + c));
   const float4 vd = ld4(vdot + r * H + c);
   st4(gx1o + r * H + c, gx);
   st4(gq + r * 3 * H + c, make_float4(gx.x * kInvSqrt2, gx.y * kInvSqrt2, gx.z * kInvSqrt2, gx.w * kInvSqrt2));
@@ -196,21 +217,24 @@ inline dim3 grid_for(long n, int block) { return dim3((unsigned)((n + block - 1)
 
 }  // namespace
 
-extern "C" int hermnet_ssilu_fwd(const float* h, float* a, long numel, void* stream) {
-  if (numel < 0 || (numel & 3)) return HN_ERR_BAD_ARG;
-  if (numel == 0) return HN_OK;
+extern "C" int hermnet_ssilu_fwd(const float* h, const float* bias, int rows_per_bias, float* a, long rows, int cols,
+                                 void* stream) {
+  if (rows < 0 || cols <= 0 || (cols & 3)) return HN_ERR_BAD_ARG;
+  if (rows == 0) return HN_OK;
   if (!h || !a) return HN_ERR_BAD_ARG;
-  hipLaunchKernelGGL(ssilu_fwd_kernel, grid_for(numel / 4, 256), dim3(256), 0, (hipStream_t)stream, h, a, numel / 4);
+  const long n4 = rows * (cols / 4);
+  hipLaunchKernelGGL(ssilu_fwd_kernel, grid_for(n4, 256), dim3(256), 0, (hipStream_t)stream, h, bias, rows_per_bias,
+                     a, n4, cols);
   HN_LAUNCH_END;
 }
 
-extern "C" int hermnet_ssilu_bwd(const float* g, const float* h, float* gh, int N, int T, int C,
-                                 long g_stride_n, long g_stride_t, void* stream) {
+extern "C" int hermnet_ssilu_bwd(const float* g, const float* h, const float* bias, int rows_per_bias, float* gh,
+                                 int N, int T, int C, long g_stride_n, long g_stride_t, void* stream) {
   if (N < 0 || T <= 0 || C <= 0 || (C & 3) || (g_stride_n & 3) || (g_stride_t & 3)) return HN_ERR_BAD_ARG;
   if (N == 0) return HN_OK;
   if (!g || !h || !gh) return HN_ERR_BAD_ARG;
   hipLaunchKernelGGL(ssilu_bwd_kernel, grid_for((long)N * T * (C / 4), 256), dim3(256), 0, (hipStream_t)stream,
-                     g, h, gh, N, T, C, g_stride_n, g_stride_t);
+                     g, h, bias, rows_per_bias, gh, N, T, C, g_stride_n, g_stride_t);
   HN_LAUNCH_END;
 }
 
@@ -224,18 +248,21 @@ extern "C" int hermnet_update_mid(const float* vp, const float* x1, float* vdot,
   HN_LAUNCH_END;
 }
 
-extern "C" int hermnet_update_out(const float* q, const float* vdot, const float* vp, const float* x1,
+extern "C" int hermnet_update_out(const float* q, const float* qbias, int rows_per_bias, const float* vdot,
+                                  const float* vp, const float* x1,
                                   const float* vec1, const float* row_mask, float* x_out, float* vec_out,
                                   int num_nodes, int num_known, int hidden, void* stream) {
   if (num_nodes < 0 || hidden <= 0 || (hidden & 3) || num_known > num_nodes) return HN_ERR_BAD_ARG;
   if (num_nodes == 0) return HN_OK;
   if (!q || !vdot || !vp || !x1 || !vec1 || !x_out || !vec_out) return HN_ERR_BAD_ARG;
   hipLaunchKernelGGL(update_out_kernel, grid_for((long)num_nodes * (hidden / 4), 256), dim3(256), 0,
-                     (hipStream_t)stream, q, vdot, vp, x1, vec1, row_mask, x_out, vec_out, num_nodes, num_known, hidden);
+                     (hipStream_t)stream, q, qbias, rows_per_bias, vdot, vp, x1, vec1, row_mask, x_out, vec_out, num_nodes,
+                     num_known, hidden);
   HN_LAUNCH_END;
 }
 
-extern "C" int hermnet_update_out_bwd(const float* gx_out, const float* gvec_out, const float* q, const float* vdot,
+extern "C" int hermnet_update_out_bwd(const float* gx_out, const float* gvec_out, const float* q,
+                                      const float* qbias, int rows_per_bias, const float* vdot,
                                       const float* vp, const float* row_mask, float* gq, float* gvdot, float* gvp,
                                       float* gx1, float* gvec1, int num_nodes, int num_known, int hidden,
                                       void* stream) {
@@ -243,7 +270,8 @@ extern "C" int hermnet_update_out_bwd(const float* gx_out, const float* gvec_out
   if (num_nodes == 0) return HN_OK;
   if (!gx_out || !gvec_out || !q || !vdot || !vp || !gq || !gvdot || !gvp || !gx1 || !gvec1) return HN_ERR_BAD_ARG;
   hipLaunchKernelGGL(update_out_bwd_kernel, grid_for((long)num_nodes * (hidden / 4), 256), dim3(256), 0,
-                     (hipStream_t)stream, gx_out, gvec_out, q, vdot, vp, row_mask, gq, gvdot, gvp, gx1, gvec1,
+                     (hipStream_t)stream, gx_out, gvec_out, q, qbias, rows_per_bias, vdot, vp, row_mask, gq, gvdot, gvp, gx1,
+                     gvec1,
                      num_nodes, num_known, hidden);
   HN_LAUNCH_END;
 }

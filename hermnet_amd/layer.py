@@ -68,7 +68,7 @@ def _msg_fwd(graph, rbf, H, xh, vec, x, w, edge):
     gs, rs = graph.as_struct(), rbf.struct()
     _lib.check(_launch("message_scatter_fwd" + ("" if vec is not None else "_l0"),
                        lambda: lib.hermnet_message_scatter_fwd(
-                           ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(vec), P(x), P(w.wt), P(w.brbf), P(edge),
+                           ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(w.b2), P(vec), P(x), P(w.wt), P(w.brbf), P(edge),
                            P(x1), P(vec1), _stream())), "hermnet_message_scatter_fwd")
     return x1, vec1
 
@@ -84,7 +84,7 @@ def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1):
     gs, rs = graph.as_struct(), rbf.struct()
     _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"),
                        lambda: lib.hermnet_message_scatter_bwd(
-                           ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(vec), P(w.wt), P(w.brbf), P(edge),
+                           ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(w.b2), P(vec), P(w.wt), P(w.brbf), P(edge),
                            P(gx1), P(gvec1), P(gxh), P(gvec), P(gx), P(gedge), split, _stream())),
                "hermnet_message_scatter_bwd")
     if split and gvec is not None:
@@ -107,7 +107,9 @@ class FusedRelationalLayer(torch.autograd.Function):
         n, mean, rstd = torch.native_layer_norm(x, [H], None, None, 1e-5)
         h = torch.addmm(w.b1cat, n, w.w1cat.t())                                     # [N, T*H]
         a = nodeops.ssilu_fwd(h)
-        xh = torch.baddbmm(w.b2, a.view(N, T, H).transpose(0, 1), w.w2t)             # [T, N, 3H]
+        # (biases that would be broadcast over a batched GEMM's rows are added by the consuming kernel
+        # instead: baddbmm with a broadcast bias first copies it over the whole output)
+        xh = torch.bmm(a.view(N, T, H).transpose(0, 1), w.w2t)                       # [T, N, 3H], + b2 on load
         # --- fused edge part + residual (rmnet.py:55-73, 24-26)
         x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge)
         # --- PaiNNUpdate on the rows of each relation (rmnet.py:94-107)
@@ -124,21 +126,23 @@ class FusedRelationalLayer(torch.autograd.Function):
                     torch.mm(vec1[lo:hi].view(-1, H), w.wvt[t], out=vp[lo:hi].view(-1, 2 * H))
         vdot, xin = nodeops.update_mid(vp, x1, nk, H)
         if uni:
-            torch.baddbmm(w.bx0_s, xin[:nk].view(T, B, 2 * H), w.wx0t_s, out=h2[:nk].view(T, B, H))
+            torch.bmm(xin[:nk].view(T, B, 2 * H), w.wx0t_s, out=h2[:nk].view(T, B, H))
         else:
             for t in range(T):
                 lo, hi = rp[t], rp[t + 1]
                 if hi > lo:
                     torch.addmm(w.bx0[t], xin[lo:hi], w.wx0t[t], out=h2[lo:hi])
-        a2 = nodeops.ssilu_fwd(h2[:nk]) if nk > 0 else h2[:0]
+        kb = dict(bias=w.bx0_s, rows_per_bias=B) if uni else {}
+        a2 = nodeops.ssilu_fwd(h2[:nk], **kb) if nk > 0 else h2[:0]
         if uni:
-            torch.baddbmm(w.bx2_s, a2.view(T, B, H), w.wx2t_s, out=q[:nk].view(T, B, 3 * H))
+            torch.bmm(a2.view(T, B, H), w.wx2t_s, out=q[:nk].view(T, B, 3 * H))
         else:
             for t in range(T):
                 lo, hi = rp[t], rp[t + 1]
                 if hi > lo:
                     torch.addmm(w.bx2[t], a2[lo:hi], w.wx2t[t], out=q[lo:hi])
-        x_out, vec_out = nodeops.update_out(q, vdot, vp, x1, vec1, graph.row_active, N, nk, H)
+        qb = dict(qbias=w.bx2_s, rows_per_bias=B) if uni else {}
+        x_out, vec_out = nodeops.update_out(q, vdot, vp, x1, vec1, graph.row_active, N, nk, H, **qb)
         ctx.save_for_backward(x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q)
         ctx.graph, ctx.rbf, ctx.w = graph, rbf, w
         return x_out, vec_out
@@ -153,10 +157,12 @@ class FusedRelationalLayer(torch.autograd.Function):
         nk = rp[-1]
         gxo = gxo.contiguous()
         gvo = gvo.contiguous()
-        gq, gvdot, gvp, gx1, gvec1 = nodeops.update_out_bwd(gxo, gvo, q, vdot, vp, graph.row_active, N, nk, H)
+        uni, B = graph.uniform and nk > 0, graph.block
+        qb = dict(qbias=w.bx2_s, rows_per_bias=B) if uni else {}
+        kb = dict(bias=w.bx0_s, rows_per_bias=B) if uni else {}
+        gq, gvdot, gvp, gx1, gvec1 = nodeops.update_out_bwd(gxo, gvo, q, vdot, vp, graph.row_active, N, nk, H, **qb)
         ga2 = torch.empty(N, H, dtype=x.dtype, device=x.device)
         gxin = torch.empty(N, 2 * H, dtype=x.dtype, device=x.device)
-        uni, B = graph.uniform and nk > 0, graph.block
         if uni:
             torch.bmm(gq[:nk].view(T, B, 3 * H), w.wx2_s, out=ga2[:nk].view(T, B, H))
         else:
@@ -164,7 +170,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                 lo, hi = rp[t], rp[t + 1]
                 if hi > lo:
                     torch.mm(gq[lo:hi], w.wx2[t], out=ga2[lo:hi])
-        gh2 = nodeops.ssilu_bwd(ga2, h2, nk, 1, H, H, H) if nk > 0 else ga2[:0]
+        gh2 = nodeops.ssilu_bwd(ga2, h2, nk, 1, H, H, H, **kb) if nk > 0 else ga2[:0]
         if uni:
             torch.bmm(gh2.view(T, B, H), w.wx0_s, out=gxin[:nk].view(T, B, 2 * H))
         else:

@@ -10,17 +10,19 @@ from .ops import _launch, _stream
 P = _lib.ptr
 
 
-def ssilu_fwd(h):
+def ssilu_fwd(h, bias=None, rows_per_bias=0):
+    """a = ScaledSiLU(h + bias); h [rows, cols]; bias [groups, cols] (group = row // rows_per_bias) or None."""
     a = torch.empty_like(h)
-    _lib.check(_launch("ssilu_fwd", lambda: _lib.load().hermnet_ssilu_fwd(P(h), P(a), h.numel(), _stream())),
-               "hermnet_ssilu_fwd")
+    cols = h.size(-1)
+    _lib.check(_launch("ssilu_fwd", lambda: _lib.load().hermnet_ssilu_fwd(
+        P(h), P(bias), rows_per_bias, P(a), h.numel() // cols, cols, _stream())), "hermnet_ssilu_fwd")
     return a
 
 
-def ssilu_bwd(g, h, N, T, C, gs_n, gs_t):
+def ssilu_bwd(g, h, N, T, C, gs_n, gs_t, bias=None, rows_per_bias=0):
     gh = torch.empty(N, T * C, dtype=h.dtype, device=h.device)
-    _lib.check(_launch("ssilu_bwd", lambda: _lib.load().hermnet_ssilu_bwd(P(g), P(h), P(gh), N, T, C, gs_n, gs_t,
-                                                                          _stream())), "hermnet_ssilu_bwd")
+    _lib.check(_launch("ssilu_bwd", lambda: _lib.load().hermnet_ssilu_bwd(
+        P(g), P(h), P(bias), rows_per_bias, P(gh), N, T, C, gs_n, gs_t, _stream())), "hermnet_ssilu_bwd")
     return gh
 
 
@@ -32,15 +34,16 @@ def update_mid(vp, x1, rows, H):
     return vdot, xin
 
 
-def update_out(q, vdot, vp, x1, vec1, mask, N, nk, H):
+def update_out(q, vdot, vp, x1, vec1, mask, N, nk, H, qbias=None, rows_per_bias=0):
     xo = torch.empty(N, H, dtype=x1.dtype, device=x1.device)
     vo = torch.empty(N, 3, H, dtype=x1.dtype, device=x1.device)
     _lib.check(_launch("update_out", lambda: _lib.load().hermnet_update_out(
-        P(q), P(vdot), P(vp), P(x1), P(vec1), P(mask), P(xo), P(vo), N, nk, H, _stream())), "hermnet_update_out")
+        P(q), P(qbias), rows_per_bias, P(vdot), P(vp), P(x1), P(vec1), P(mask), P(xo), P(vo), N, nk, H, _stream())),
+        "hermnet_update_out")
     return xo, vo
 
 
-def update_out_bwd(gxo, gvo, q, vdot, vp, mask, N, nk, H):
+def update_out_bwd(gxo, gvo, q, vdot, vp, mask, N, nk, H, qbias=None, rows_per_bias=0):
     dev, dt = gxo.device, gxo.dtype
     gq = torch.empty(N, 3 * H, dtype=dt, device=dev)
     gvdot = torch.empty(N, H, dtype=dt, device=dev)
@@ -48,7 +51,8 @@ def update_out_bwd(gxo, gvo, q, vdot, vp, mask, N, nk, H):
     gx1 = torch.empty(N, H, dtype=dt, device=dev)
     gvec1 = torch.empty(N, 3, H, dtype=dt, device=dev)
     _lib.check(_launch("update_out_bwd", lambda: _lib.load().hermnet_update_out_bwd(
-        P(gxo), P(gvo), P(q), P(vdot), P(vp), P(mask), P(gq), P(gvdot), P(gvp), P(gx1), P(gvec1), N, nk, H,
+        P(gxo), P(gvo), P(q), P(qbias), rows_per_bias, P(vdot), P(vp), P(mask), P(gq), P(gvdot), P(gvp), P(gx1), P(gvec1),
+        N, nk, H,
         _stream())), "hermnet_update_out_bwd")
     return gq, gvdot, gvp, gx1, gvec1
 

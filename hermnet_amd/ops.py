@@ -165,7 +165,7 @@ class MessageScatter(torch.autograd.Function):
         vec1 = torch.empty(x.size(0), 3, H, dtype=x.dtype, device=x.device)
         gs, rs = graph.as_struct(), rbf.struct()
         _lib.check(_launch("message_scatter_fwd" + ("" if vec_c is not None else "_l0"), lambda: lib.hermnet_message_scatter_fwd(
-            ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), _lib.ptr(vec_c), _lib.ptr(x),
+            ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), None, _lib.ptr(vec_c), _lib.ptr(x),
             _lib.ptr(wt), _lib.ptr(brbf), _lib.ptr(edge), _lib.ptr(x1), _lib.ptr(vec1), _stream())),
             "hermnet_message_scatter_fwd")
         ctx.save_for_backward(xh, vec_c, edge, wt, brbf)
@@ -187,7 +187,7 @@ class MessageScatter(torch.autograd.Function):
         gedge = torch.zeros(H // 64, graph.E, 4, dtype=torch.float32, device=gx1.device)
         gs, rs = graph.as_struct(), rbf.struct()
         _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"), lambda: lib.hermnet_message_scatter_bwd(
-            ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), _lib.ptr(vec), _lib.ptr(wt), _lib.ptr(brbf),
+            ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), None, _lib.ptr(vec), _lib.ptr(wt), _lib.ptr(brbf),
             _lib.ptr(edge), _lib.ptr(gx1), _lib.ptr(gvec1), _lib.ptr(gxh), _lib.ptr(gvec), _lib.ptr(gx),
             _lib.ptr(gedge), split, _stream())), "hermnet_message_scatter_bwd")
         if split and gvec is not None:

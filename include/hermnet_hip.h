@@ -149,6 +149,8 @@ int hermnet_edge_geometry_bwd(const float* gD, const int* in_rowptr, const int* 
  *   (rmnet.py:168-172), in_subgraph's edge slicing (utils.py:11-24) and the residual
  *   `x = (x + dx)/sqrt(2); vec = vec + dvec` (rmnet.py:24-26).
  * xh   [T,N,3H]  xh[t] = x_proj_t(LayerNorm_t(x)) for every row (sources of relation t)
+ * xh_bias [T,3H] (NULL = none): added to every row of xh[t] on load, so that the x_proj GEMM can run
+ *                without its broadcast bias (which would cost one more write + read of xh)
  * vec  [N,3,H]   (NULL => treated as zero: layer 0, hermnet.py:124)
  * x    [N,H]
  * wt   [T,R,3H]  rbf_proj.weight of relation t, transposed;  brbf [T,3H] its bias
@@ -156,7 +158,7 @@ int hermnet_edge_geometry_bwd(const float* gD, const int* in_rowptr, const int* 
  * out: x1 [N,H], vec1 [N,3,H]; rows >= type_rowptr[T] are written as zero.
  * H must be a multiple of 64. */
 int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc* rbf, int hidden,
-                                const float* xh, const float* vec, const float* x,
+                                const float* xh, const float* xh_bias, const float* vec, const float* x,
                                 const float* wt, const float* brbf, const float* edge,
                                 float* x1, float* vec1, void* stream);
 
@@ -169,17 +171,24 @@ int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc* rbf, int h
  * split_t = 1: one relation per workgroup (3-D grid, better balance), gvec is [T,N,3,H] partial
  *              sums (slice 0 carries the residual's identity term), the caller sums over T. */
 int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc* rbf, int hidden,
-                                const float* xh, const float* vec,
+                                const float* xh, const float* xh_bias, const float* vec,
                                 const float* wt, const float* brbf, const float* edge,
                                 const float* gx1, const float* gvec1,
                                 float* gxh, float* gvec, float* gx, float* gedge, int split_t, void* stream);
 
 /* ---- node-level fused elementwise stages (A11/A12; the GEMMs between them are library calls) ----
- * ScaledSiLU (rmnet.py:110-117): a = silu(h)/0.6 over `numel` contiguous floats (multiple of 4). */
-int hermnet_ssilu_fwd(const float* h, float* a, long numel, void* stream);
-/* gh[n,t,c] = g[n*g_stride_n + t*g_stride_t + c] * d ssilu(h[n,t,c]); h, gh contiguous [N,T,C]. */
-int hermnet_ssilu_bwd(const float* g, const float* h, float* gh, int N, int T, int C,
-                      long g_stride_n, long g_stride_t, void* stream);
+ * Bias convention of these stages: the GEMM in front of a stage may run WITHOUT its bias (a GEMM with a
+ * broadcast bias writes and re-reads its whole output once more); the stage then adds it on load.
+ * `bias` (NULL = none) is [groups, cols] for a [rows, cols] operand, group = row / rows_per_bias
+ * (rows_per_bias <= 0: a single bias row) -- one group per relation block of the uniform layout.
+ *
+ * ScaledSiLU (rmnet.py:110-117): a = silu(h + bias)/0.6; h, a contiguous [rows, cols], cols % 4 == 0. */
+int hermnet_ssilu_fwd(const float* h, const float* bias, int rows_per_bias, float* a, long rows, int cols,
+                      void* stream);
+/* gh[n,t,c] = g[n*g_stride_n + t*g_stride_t + c] * d ssilu(h[n,t,c] + bias); h, gh contiguous [N,T,C];
+ * bias for the [N, T*C] view of h. */
+int hermnet_ssilu_bwd(const float* g, const float* h, const float* bias, int rows_per_bias, float* gh,
+                      int N, int T, int C, long g_stride_n, long g_stride_t, void* stream);
 /* PaiNNUpdate middle (rmnet.py:95-100): vp [rows,3,2H] = vec_proj(vec1) ->
  * vdot [rows,H] = sum_d v1 v2 / sqrt(H);  xin [rows,2H] = [x1 | sqrt(sum_d v2^2 + 1e-8)]. */
 int hermnet_update_mid(const float* vp, const float* x1, float* vdot, float* xin, int rows, int hidden,
@@ -187,12 +196,14 @@ int hermnet_update_mid(const float* vp, const float* x1, float* vdot, float* xin
 /* PaiNNUpdate tail + residual (rmnet.py:101-107,29-31) + zero rows (hermnet.py:51,56-57):
  * x_out = x1 + (q1 + q2 vdot)/sqrt2, vec_out[d] = vec1[d] + q3 v1[d]; rows >= num_known or with
  * row_mask[r] == 0 (row_mask may be NULL) are written as zero without reading the other inputs. */
-int hermnet_update_out(const float* q, const float* vdot, const float* vp, const float* x1,
+int hermnet_update_out(const float* q, const float* qbias /* [groups,3H] or NULL */, int rows_per_bias,
+                       const float* vdot, const float* vp, const float* x1,
                        const float* vec1, const float* row_mask, float* x_out, float* vec_out,
                        int num_nodes, int num_known, int hidden, void* stream);
 /* Backward of hermnet_update_out: gq [N,3H], gvdot [N,H], the v1 half of gvp [N,3,2H], and the
  * identity parts gx1 [N,H] / gvec1 [N,3,H] (masked copies of the incoming gradients). */
-int hermnet_update_out_bwd(const float* gx_out, const float* gvec_out, const float* q, const float* vdot,
+int hermnet_update_out_bwd(const float* gx_out, const float* gvec_out, const float* q,
+                           const float* qbias, int rows_per_bias, const float* vdot,
                            const float* vp, const float* row_mask, float* gq, float* gvdot, float* gvp,
                            float* gx1, float* gvec1, int num_nodes, int num_known, int hidden, void* stream);
 /* Backward of hermnet_update_mid: completes gvp (both halves) from gvdot and gxin [rows,2H] and

@@ -67,8 +67,20 @@ def message_scatter_ref(xh, vec, x, edge, wt, brbf, graph, rbf):
 # Plain-PyTorch versions of the node-level fused kernels (same contracts as hermnet_amd.nodeops)
 # and of the message kernels' forward/backward entry points used by hermnet_amd.layer.
 # ---------------------------------------------------------------------------------------------
-def ssilu_fwd(h):
-    return torch.nn.functional.silu(h) / 0.6
+def _with_bias(h, bias, rows_per_bias):
+    """h [rows, cols] + bias [groups, cols] (group = row // rows_per_bias; <= 0: one row): the kernels'
+    "bias convention" (include/hermnet_hip.h)."""
+    if bias is None:
+        return h
+    b = bias.reshape(-1, h.size(-1))
+    if rows_per_bias <= 0:
+        return h + b[0]
+    grp = torch.arange(h.size(0)) // rows_per_bias
+    return h + b[grp]
+
+
+def ssilu_fwd(h, bias=None, rows_per_bias=0):
+    return torch.nn.functional.silu(_with_bias(h, bias, rows_per_bias)) / 0.6
 
 
 def _dssilu(h):
@@ -76,9 +88,10 @@ def _dssilu(h):
     return s * (1 + h * (1 - s)) / 0.6
 
 
-def ssilu_bwd(g, h, N, T, C, gs_n, gs_t):
+def ssilu_bwd(g, h, N, T, C, gs_n, gs_t, bias=None, rows_per_bias=0):
     gg = torch.as_strided(g, (N, T, C), (gs_n, gs_t, 1))
-    return (gg * _dssilu(h.reshape(-1)[:N * T * C].view(N, T, C))).reshape(N, T * C)
+    hb = _with_bias(h.reshape(-1)[:N * T * C].view(N, T * C), bias, rows_per_bias)
+    return (gg * _dssilu(hb.view(N, T, C))).reshape(N, T * C)
 
 
 def update_mid(vp, x1, rows, H):
@@ -98,8 +111,17 @@ def _on(mask, N, nk):
     return on
 
 
-def update_out(q, vdot, vp, x1, vec1, mask, N, nk, H):
+def _q_with_bias(q, qbias, rows_per_bias, nk):
+    if qbias is None:
+        return q
+    q = q.clone()
+    q[:nk] = _with_bias(q[:nk], qbias, rows_per_bias)
+    return q
+
+
+def update_out(q, vdot, vp, x1, vec1, mask, N, nk, H, qbias=None, rows_per_bias=0):
     on = _on(mask, N, nk)
+    q = _q_with_bias(q, qbias, rows_per_bias, nk)
     q1, q2, q3 = q[:, :H], q[:, H:2 * H], q[:, 2 * H:]
     xo = x1 + (q1 + q2 * vdot) / math.sqrt(2.0)
     vo = vec1 + q3[:, None, :] * vp[..., :H]
@@ -107,8 +129,9 @@ def update_out(q, vdot, vp, x1, vec1, mask, N, nk, H):
     return torch.where(on[:, None], xo, z), torch.where(on[:, None, None], vo, z)
 
 
-def update_out_bwd(gxo, gvo, q, vdot, vp, mask, N, nk, H):
+def update_out_bwd(gxo, gvo, q, vdot, vp, mask, N, nk, H, qbias=None, rows_per_bias=0):
     on = _on(mask, N, nk)
+    q = _q_with_bias(q, qbias, rows_per_bias, nk)
     z = torch.zeros(())
     gx = torch.where(on[:, None], gxo, z)
     gv = torch.where(on[:, None, None], gvo, z)
@@ -136,14 +159,14 @@ def update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, rows, H):
 
 
 def msg_fwd(graph, rbf, H, xh, vec, x, w, edge):
-    return message_scatter_ref(xh, vec, x, edge, w.wt, w.brbf, graph, rbf)
+    return message_scatter_ref(xh + w.b2, vec, x, edge, w.wt, w.brbf, graph, rbf)     # xh_bias = w.b2 [T,1,3H]
 
 
 def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1):
     """Backward contract of hermnet_message_scatter_bwd via autograd of the dense restatement;
     the edge gradient is Cartesian (w.r.t. D = rhat * d)."""
     with torch.enable_grad():
-        xh_ = xh.detach().requires_grad_(True)
+        xh_ = (xh + w.b2).detach().requires_grad_(True)
         x_ = torch.zeros(xh.size(1), H, dtype=xh.dtype).requires_grad_(True)
         v_ = vec.detach().requires_grad_(True) if vec is not None else None
         D = (edge[:, :3] * edge[:, 3:4]).detach().requires_grad_(True)

@@ -30,6 +30,7 @@ def main():
     rnd = lambda *s: torch.randn(*s, device=dev, generator=gen)
     xh, x, vec = rnd(T, N, 3 * H), rnd(N, H), rnd(N, 3, H)
     wt, brbf = rnd(T, R, 3 * H) / 11.3, rnd(T, 3 * H) * 0.1
+    xb = rnd(T, 3 * H) * 0.1 if os.environ.get("KBENCH_XH_BIAS", "1") != "0" else None
     x1, vec1 = torch.empty_like(x), torch.empty_like(vec)
     gx1, gvec1 = rnd(N, H), rnd(N, 3, H)
     split = int(os.environ.get("HERMNET_BWD_SPLIT_T", "0") != "0")
@@ -40,11 +41,11 @@ def main():
     P = _lib.ptr
 
     def fwd(v):
-        return lib.hermnet_message_scatter_fwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(v), P(x), P(wt), P(brbf),
+        return lib.hermnet_message_scatter_fwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(xb), P(v), P(x), P(wt), P(brbf),
                                                P(edge), P(x1), P(vec1), _stream())
 
     def bwd(v):
-        return lib.hermnet_message_scatter_bwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(v), P(wt), P(brbf), P(edge),
+        return lib.hermnet_message_scatter_bwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(xb), P(v), P(wt), P(brbf), P(edge),
                                                P(gx1), P(gvec1), P(gxh), P(gvec if v is not None else None), P(gx),
                                                P(gedge), split, _stream())
 
