@@ -212,6 +212,85 @@ __global__ __launch_bounds__(256) void update_mid_bwd_kernel(
   }
 }
 
+// ---- LayerNorm without affine (the affine is folded into the following Linear, hermnet_amd/layer.py) ----
+// rmnet.py:52 `x_layernorm`; one wave per row, H <= 1024; two-pass statistics in registers.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+constexpr int kLnMaxPerLane = 4;   // float4 chunks per lane: H <= 4 * 64 * 4 = 1024
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ n,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int rows, int H, float eps) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float4 v[kLnMaxPerLane];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < kLnMaxPerLane; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    v[k] = c < H ? ld4(x + (size_t)r * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+  const float mu = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < kLnMaxPerLane; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < H) {
+      v[k] = make_float4(v[k].x - mu, v[k].y - mu, v[k].z - mu, v[k].w - mu);
+      q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+  for (int k = 0; k < kLnMaxPerLane; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < H) st4(n + (size_t)r * H + c, make_float4(v[k].x * rs, v[k].y * rs, v[k].z * rs, v[k].w * rs));
+  }
+  if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+}
+
+// gx = rstd * (g - mean(g) - nh * mean(g * nh)) + add   with nh = (x - mean) * rstd; `add` may be null
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ add, float* __restrict__ gx,
+                                                            int rows, int H) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float mu = mean[r], rs = rstd[r];
+  float4 gv[kLnMaxPerLane], nh[kLnMaxPerLane];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < kLnMaxPerLane; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    gv[k] = nh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < H) {
+      gv[k] = ld4(g + (size_t)r * H + c);
+      const float4 xv = ld4(x + (size_t)r * H + c);
+      nh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+    }
+    s1 += (gv[k].x + gv[k].y) + (gv[k].z + gv[k].w);
+    s2 += (gv[k].x * nh[k].x + gv[k].y * nh[k].y) + (gv[k].z * nh[k].z + gv[k].w * nh[k].w);
+  }
+  const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+#pragma unroll
+  for (int k = 0; k < kLnMaxPerLane; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < H) {
+      float4 o = make_float4(rs * (gv[k].x - m1 - nh[k].x * m2), rs * (gv[k].y - m1 - nh[k].y * m2),
+                             rs * (gv[k].z - m1 - nh[k].z * m2), rs * (gv[k].w - m1 - nh[k].w * m2));
+      if (add != nullptr) o = add4(o, ld4(add + (size_t)r * H + c));
+      st4(gx + (size_t)r * H + c, o);
+    }
+  }
+}
+
 inline dim3 grid_for(long n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 #define HN_LAUNCH_END return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH
 
@@ -283,5 +362,25 @@ extern "C" int hermnet_update_mid_bwd(const float* gvdot, const float* gxin, con
   if (!gvdot || !gxin || !vp || !xin || !gvp || !gx1) return HN_ERR_BAD_ARG;
   hipLaunchKernelGGL(update_mid_bwd_kernel, grid_for((long)rows * (hidden / 4), 256), dim3(256), 0,
                      (hipStream_t)stream, gvdot, gxin, vp, xin, gvp, gx1, rows, hidden);
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_layernorm_fwd(const float* x, float* n, float* mean, float* rstd, int rows, int hidden,
+                                     float eps, void* stream) {
+  if (rows < 0 || hidden <= 0 || (hidden & 3) || hidden > kLnMaxPerLane * 256) return HN_ERR_BAD_ARG;
+  if (rows == 0) return HN_OK;
+  if (!x || !n || !mean || !rstd) return HN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     x, n, mean, rstd, rows, hidden, eps);
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_layernorm_bwd(const float* g, const float* x, const float* mean, const float* rstd,
+                                     const float* add, float* gx, int rows, int hidden, void* stream) {
+  if (rows < 0 || hidden <= 0 || (hidden & 3) || hidden > kLnMaxPerLane * 256) return HN_ERR_BAD_ARG;
+  if (rows == 0) return HN_OK;
+  if (!g || !x || !mean || !rstd || !gx) return HN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     g, x, mean, rstd, add, gx, rows, hidden);
   HN_LAUNCH_END;
 }

@@ -11,7 +11,7 @@ from .relations import RelationalGraph
 from .sharding import HaloExchange, SumAcrossRanks
 import os
 
-from .layer import FusedRelationalLayer, LayerWeights
+from .layer import EdgeFanout, EdgeGradSink, FusedRelationalLayer, LayerWeights
 from .rmnet import PaiNNModule, RadialBasis, ScaledSiLU, relational_layer
 
 
@@ -40,8 +40,10 @@ class HeteroVertexConv(nn.Module):
             return data
         if self._weights is None:
             self._weights = LayerWeights(self.mods.values())
-        data.x, data.vec = FusedRelationalLayer.apply(data.x, data.vec, data._hn_edge, g, data._hn_rbf,
-                                                      self._weights.refresh())
+        handles, li = data.get("_hn_edge_handles"), data.get("_hn_layer", 0)
+        edge = data._hn_edge if handles is None else handles[li]
+        data.x, data.vec = FusedRelationalLayer.apply(data.x, data.vec, edge, g, data._hn_rbf, self._weights.refresh(),
+                                                      data.get("_hn_edge_sink"), li)
         return data
 
 
@@ -141,7 +143,13 @@ class HVNet(nn.Module):
         # rmnet.py:168-172 for the optional bases only: [E,R] basis from the kernel's distances
         data._hn_edge_embed = None if fused else self.radial_basis(edge[:, 3])
         data.x, data.vec = x, vec
+        data._hn_edge_handles = data._hn_edge_sink = None
+        if fused and edge.requires_grad and self.hidden_channels % 64 == 0 and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0":
+            # one reduction of the edge gradients per step instead of one per layer (layer.EdgeFanout)
+            data._hn_edge_sink = EdgeGradSink(len(self.hermconvs), self.hidden_channels // 64, graph.E, pos.device)
+            data._hn_edge_handles = EdgeFanout.apply(edge, data._hn_edge_sink)
         for li, conv in enumerate(self.hermconvs):
+            data._hn_layer = li
             data = conv(data)
             if row_plan is not None and li + 1 < len(self.hermconvs):
                 # one exchange per layer: (x | vec) rows of halo atoms, 4H floats each

@@ -73,14 +73,14 @@ def _msg_fwd(graph, rbf, H, xh, vec, x, w, edge):
     return x1, vec1
 
 
-def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1):
+def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge):
+    """`gedge` [H/64, E, 4] (zero-filled by the caller) receives the per-column-block Cartesian edge gradients."""
     lib = _lib.load()
     gxh = torch.empty_like(xh)
     split = _split_t(graph)
     gvec = None if vec is None else (torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
                                      if split else torch.empty_like(vec))
     gx = torch.empty_like(gx1)
-    gedge = torch.zeros(H // 64, graph.E, 4, dtype=torch.float32, device=gx1.device)
     gs, rs = graph.as_struct(), rbf.struct()
     _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"),
                        lambda: lib.hermnet_message_scatter_bwd(
@@ -89,14 +89,52 @@ def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1):
                "hermnet_message_scatter_bwd")
     if split and gvec is not None:
         gvec = gvec.sum(0)
-    return gxh, gvec, gx, gedge
+    return gxh, gvec, gx
+
+
+class EdgeGradSink(object):
+    """One buffer [layers, H/64, E, 4] for the edge gradients of a whole step: every layer's backward kernel
+    writes its slice, and `EdgeFanout.backward` reduces all slices in ONE pass (instead of a zero-fill, a
+    block sum and an autograd accumulation per layer)."""
+
+    def __init__(self, layers, nblk, E, device):
+        self.shape = (layers, nblk, E, 4)
+        self.device = device
+        self.buf = None
+
+    def slice(self, li):
+        if self.buf is None:     # edges of unknown-type / inactive targets are never written: zero once
+            self.buf = torch.zeros(self.shape, dtype=torch.float32, device=self.device)
+        return self.buf[li]
+
+
+class EdgeFanout(torch.autograd.Function):
+    """edge [E,4] -> one handle per layer, an [H/64, E, 4] stride-0 view of it (so that a layer can return its
+    per-column-block gradient slices unreduced); backward = sum over every slice of every layer."""
+
+    @staticmethod
+    def forward(ctx, edge, sink):
+        ctx.sink = sink
+        L, nblk = sink.shape[0], sink.shape[1]
+        return tuple(edge.unsqueeze(0).expand(nblk, *edge.shape) for _ in range(L))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        sink = ctx.sink
+        buf, ctx.sink.buf = sink.buf, None            # the buffer belongs to this backward pass only
+        if buf is not None and all(g is not None and g.data_ptr() == buf[i].data_ptr() for i, g in enumerate(grads)):
+            L, nblk, E, _ = sink.shape
+            return buf.view(L * nblk, E, 4).sum(0), None
+        live = [g.sum(0) for g in grads if g is not None]     # partial graphs: plain accumulation
+        return (torch.stack(live, 0).sum(0) if live else None), None
 
 
 class FusedRelationalLayer(torch.autograd.Function):
     """(x, vec, edge) -> (x_out, vec_out) for one layer, relation (row) order."""
 
     @staticmethod
-    def forward(ctx, x, vec, edge, graph, rbf, w):
+    def forward(ctx, x, vec, edge, graph, rbf, w, sink=None, li=0):
+        """`edge`: [E,4], or this layer's handle from `EdgeFanout` ([H/64,E,4] stride-0 view; same memory)."""
         N, H = x.shape
         T = graph.T
         rp = graph.type_rowptr_host
@@ -104,7 +142,7 @@ class FusedRelationalLayer(torch.autograd.Function):
         x = x.contiguous()
         vec = None if vec is None else vec.contiguous()
         # --- node projection of every relation: xh[t] = x_proj_t(LayerNorm_t(x))  (rmnet.py:52)
-        n, mean, rstd = torch.native_layer_norm(x, [H], None, None, 1e-5)
+        n, mean, rstd = nodeops.layernorm_fwd(x, 1e-5)
         h = torch.addmm(w.b1cat, n, w.w1cat.t())                                     # [N, T*H]
         a = nodeops.ssilu_fwd(h)
         # (biases that would be broadcast over a batched GEMM's rows are added by the consuming kernel
@@ -144,7 +182,7 @@ class FusedRelationalLayer(torch.autograd.Function):
         qb = dict(qbias=w.bx2_s, rows_per_bias=B) if uni else {}
         x_out, vec_out = nodeops.update_out(q, vdot, vp, x1, vec1, graph.row_active, N, nk, H, **qb)
         ctx.save_for_backward(x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q)
-        ctx.graph, ctx.rbf, ctx.w = graph, rbf, w
+        ctx.graph, ctx.rbf, ctx.w, ctx.sink, ctx.li = graph, rbf, w, sink, li
         return x_out, vec_out
 
     @staticmethod
@@ -188,14 +226,17 @@ class FusedRelationalLayer(torch.autograd.Function):
                 if hi > lo:
                     g = gvec1[lo:hi].view(-1, H)
                     torch.addmm(g, gvp[lo:hi].view(-1, 2 * H), w.wv[t], out=g)
-        gxh, gvec_in, gx_in, gedge = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1)
+        fan = edge.dim() == 3          # handle from EdgeFanout: return the slices unreduced
+        if fan and ctx.sink is not None:
+            gedge = ctx.sink.slice(ctx.li)
+        else:
+            gedge = torch.zeros(H // 64, graph.E, 4, dtype=torch.float32, device=gx1.device)
+        gxh, gvec_in, gx_in = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge)
         gx_total = None
         if ctx.needs_input_grad[0]:
             ga = torch.bmm(gxh, w.w2)                                                # [T, N, H]
             gh = nodeops.ssilu_bwd(ga, h, N, T, H, H, N * H)                         # [N, T*H]
             gn = torch.mm(gh, w.w1cat)                                               # [N, H]
-            gx_ln = torch.ops.aten.native_layer_norm_backward(gn, x, [H], mean, rstd, None, None,
-                                                              [True, False, False])[0]
-            gx_total = gx_in + gx_ln
-        ge = gedge[0] if gedge.size(0) == 1 else gedge.sum(0)
-        return gx_total, gvec_in, ge, None, None, None
+            gx_total = nodeops.layernorm_bwd(gn, x, mean, rstd, add=gx_in)
+        ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
+        return gx_total, gvec_in, ge, None, None, None, None, None

@@ -189,6 +189,14 @@ int hermnet_ssilu_fwd(const float* h, const float* bias, int rows_per_bias, floa
  * bias for the [N, T*C] view of h. */
 int hermnet_ssilu_bwd(const float* g, const float* h, const float* bias, int rows_per_bias, float* gh,
                       int N, int T, int C, long g_stride_n, long g_stride_t, void* stream);
+/* LayerNorm without affine over the last axis (`x_layernorm`, rmnet.py:52; gamma/beta are folded into the
+ * following Linear by the host): n = (x - mean) * rstd, rstd = 1/sqrt(var + eps) (biased variance).
+ * x, n [rows, hidden]; mean, rstd [rows]; hidden % 4 == 0, hidden <= 1024. */
+int hermnet_layernorm_fwd(const float* x, float* n, float* mean, float* rstd, int rows, int hidden, float eps,
+                          void* stream);
+/* gx = d(n)/d(x)^T g + add  (add [rows, hidden] may be NULL; gx may alias add). */
+int hermnet_layernorm_bwd(const float* g, const float* x, const float* mean, const float* rstd, const float* add,
+                          float* gx, int rows, int hidden, void* stream);
 /* PaiNNUpdate middle (rmnet.py:95-100): vp [rows,3,2H] = vec_proj(vec1) ->
  * vdot [rows,H] = sum_d v1 v2 / sqrt(H);  xin [rows,2H] = [x1 | sqrt(sum_d v2^2 + 1e-8)]. */
 int hermnet_update_mid(const float* vp, const float* x1, float* vdot, float* xin, int rows, int hidden,

@@ -67,6 +67,17 @@ def message_scatter_ref(xh, vec, x, edge, wt, brbf, graph, rbf):
 # Plain-PyTorch versions of the node-level fused kernels (same contracts as hermnet_amd.nodeops)
 # and of the message kernels' forward/backward entry points used by hermnet_amd.layer.
 # ---------------------------------------------------------------------------------------------
+def layernorm_fwd(x, eps=1e-5):
+    n, mean, rstd = torch.native_layer_norm(x, [x.size(-1)], None, None, eps)
+    return n, mean.reshape(-1), rstd.reshape(-1)
+
+
+def layernorm_bwd(g, x, mean, rstd, add=None):
+    gx = torch.ops.aten.native_layer_norm_backward(g, x, [x.size(-1)], mean.reshape(-1, 1), rstd.reshape(-1, 1), None, None,
+                                                   [True, False, False])[0]
+    return gx if add is None else gx + add
+
+
 def _with_bias(h, bias, rows_per_bias):
     """h [rows, cols] + bias [groups, cols] (group = row // rows_per_bias; <= 0: one row): the kernels'
     "bias convention" (include/hermnet_hip.h)."""
@@ -159,24 +170,27 @@ def update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, rows, H):
 
 
 def msg_fwd(graph, rbf, H, xh, vec, x, w, edge):
+    edge = edge[0] if edge.dim() == 3 else edge
     return message_scatter_ref(xh + w.b2, vec, x, edge, w.wt, w.brbf, graph, rbf)     # xh_bias = w.b2 [T,1,3H]
 
 
-def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1):
+def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge):
     """Backward contract of hermnet_message_scatter_bwd via autograd of the dense restatement;
     the edge gradient is Cartesian (w.r.t. D = rhat * d)."""
     with torch.enable_grad():
         xh_ = (xh + w.b2).detach().requires_grad_(True)
         x_ = torch.zeros(xh.size(1), H, dtype=xh.dtype).requires_grad_(True)
         v_ = vec.detach().requires_grad_(True) if vec is not None else None
+        if edge.dim() == 3:          # per-layer handle of EdgeFanout: [H/64, E, 4] view of the same edge array
+            edge = edge[0]
         D = (edge[:, :3] * edge[:, 3:4]).detach().requires_grad_(True)
         dn = D.norm(dim=-1)
         e_ = torch.cat([D / dn[:, None], dn[:, None]], 1)
         x1, vec1 = message_scatter_ref(xh_, v_, x_, e_, w.wt, w.brbf, graph, rbf)
         ins = [xh_, x_, D] + ([v_] if vec is not None else [])
         gr = torch.autograd.grad([x1, vec1], ins, [gx1, gvec1])
-    gedge = torch.cat([gr[2], torch.zeros(D.size(0), 1, dtype=D.dtype)], 1)[None]
-    return gr[0], (gr[3] if vec is not None else None), gr[1], gedge
+    gedge[0, :, :3] = gr[2]          # all column blocks' contributions in slice 0; the others stay zero
+    return gr[0], (gr[3] if vec is not None else None), gr[1]
 
 
 class RefEdgeGeometry(torch.autograd.Function):

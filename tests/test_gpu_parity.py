@@ -207,6 +207,23 @@ def test_node_kernels_match_pytorch_restatement():
         assert rel_err(gvp_d.cpu()[:nk], gvp[:nk]) < 1e-6 and rel_err(gx1_d.cpu(), gx1) < 1e-6
 
 
+@pytest.mark.parametrize("H", [64, 128, 320, 1024])
+def test_layernorm_kernels(H):
+    """`hermnet_layernorm_fwd/_bwd` (no affine) vs torch.native_layer_norm and its backward."""
+    from hermnet_amd import nodeops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(H)
+    rows = 203
+    x = torch.randn(rows, H, generator=gen) * 3 + 0.7
+    g, add = torch.randn(rows, H, generator=gen), torch.randn(rows, H, generator=gen)
+    n, mean, rstd = nodeops.layernorm_fwd(x.to(dev), 1e-5)
+    n_r, mean_r, rstd_r = ref_ops.layernorm_fwd(x, 1e-5)
+    assert rel_err(n.cpu(), n_r) < 2e-6 and rel_err(mean.cpu(), mean_r) < 2e-6 and rel_err(rstd.cpu(), rstd_r) < 2e-6
+    for a in (None, add):
+        gx = nodeops.layernorm_bwd(g.to(dev), x.to(dev), mean, rstd, add=None if a is None else a.to(dev))
+        assert rel_err(gx.cpu(), ref_ops.layernorm_bwd(g, x, mean_r, rstd_r, add=a)) < 2e-6
+
+
 def test_bias_on_load_equals_bias_in_operand():
     """The stages that add a GEMM's bias on load (include/hermnet_hip.h "Bias convention"): kernel(h, bias)
     must equal kernel(h + expanded bias) for the node kernels and the message kernels (xh_bias)."""

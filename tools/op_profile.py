@@ -23,3 +23,14 @@ for ev in prof.key_averages():
         rows.append((ev.device_time_total, ev.count, ev.key))
 for t, c, k in sorted(rows, reverse=True)[:28]:
     print("%8.1f us  x%3d  %s" % (t, c, k))
+print("---- device kernels ----")
+krows = {}
+for ev in prof.events():
+    if getattr(ev, "device_type", None) is not None and str(ev.device_type).endswith("CUDA"):
+        k = ev.name[:70]
+        t, c = krows.get(k, (0.0, 0))
+        krows[k] = (t + ev.device_time, c + 1)
+tot = sum(t for t, _ in krows.values())
+for k, (t, c) in sorted(krows.items(), key=lambda kv: -kv[1][0])[:40]:
+    print("%8.1f us  x%3d  %s" % (t, c, k))
+print("total device time %.1f us" % tot)
