@@ -151,7 +151,9 @@ def main():
 
     import hermnet_amd as hn
     from hermnet_amd import synth, ops, _lib
+    from hermnet_amd.utils import enable_tuned_gemms
     _lib.load()   # fail loudly if the HIP library is missing
+    tuned = os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is None and enable_tuned_gemms()
 
     elems = ["Al", "Ni", "Cu"]
     model_kw = dict(rc=5.0, num_layers=5, hidden_channels=128, num_rbf=128)
@@ -228,7 +230,7 @@ def main():
                                    "num_rbf=128 layers=5, E=%d directed edges, energy+forces per step"
                                    % (N_global, E_global),
                        "atoms_total": N_global, "atoms_owned_rank0": N - halo, "halo_atoms_rank0": halo,
-                       "edges_rank0": E,
+                       "edges_rank0": E, "tuned_gemm_table": bool(tuned),
                        "parallelism": "1 GPU" if world == 1 else
                        "atom-sharded x%d slabs, one-hop halo all-to-all per layer over %s" % (world, args.backend)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,

@@ -1,5 +1,27 @@
-"""`virial_calc` with the reference's signature and unit factors (`HermNet/utils.py:138-160`)."""
+"""`virial_calc` with the reference's signature and unit factors (`HermNet/utils.py:138-160`), and the
+GEMM-selection table for the node-level library GEMMs."""
+import os
+
 import torch
+
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gemm_gfx950.csv")
+
+
+def enable_tuned_gemms(path=TUNED_GEMMS):
+    """Use the rocBLAS / hipBLASLt solutions recorded in `tuned/gemm_gfx950.csv` (PyTorch TunableOp, tuned on
+    MI355X for the node GEMM shapes of BASELINE config 2: `PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1
+    python bench.py`).  No tuning happens here; shapes that are not in the table, and tables recorded with other
+    library versions (the file carries validators), fall back to the libraries' defaults.  Returns True when the
+    table was accepted.  Same arithmetic (fp32 MFMA GEMMs), only the tile/solution choice changes."""
+    import torch.cuda.tunable as tunable
+    if not os.path.exists(path):
+        return False
+    tunable.enable(True)
+    tunable.tuning_enable(False)
+    try:
+        return bool(tunable.read_file(path))
+    except Exception:
+        return False
 
 _NKTV2P = {"metal": 1.6021765e6, "lj": 1.0, "si": 1.0, "cgs": 1.0, "micro": 1.0, "nano": 1.0,
            "real": 68568.415, "electron": 2.94210108e13}
