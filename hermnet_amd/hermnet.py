@@ -8,7 +8,7 @@ from torch import nn
 from .elements import atomic_numbers
 from .ops import EdgeGeometry, TrueEdgeGradient
 from .relations import RelationalGraph
-from .sharding import HaloExchange, SumAcrossRanks
+from .sharding import HaloExchange, HaloExchangeFeatures, SumAcrossRanks
 import os
 
 from .layer import EdgeFanout, EdgeGradSink, FusedRelationalLayer, LayerWeights
@@ -153,11 +153,7 @@ class HVNet(nn.Module):
             data = conv(data)
             if row_plan is not None and li + 1 < len(self.hermconvs):
                 # one exchange per layer: (x | vec) rows of halo atoms, 4H floats each
-                n = data.x.size(0)
-                packed = torch.cat([data.x, data.vec.reshape(n, -1)], dim=1)
-                packed = HaloExchange.apply(packed, row_plan)
-                H = self.hidden_channels
-                data.x, data.vec = packed[:, :H], packed[:, H:].reshape(n, 3, H)
+                data.x, data.vec = HaloExchangeFeatures.apply(data.x, data.vec, row_plan)
         x = data.x
 
         e_rows = self.out_energy(x).squeeze(1)                              # hermnet.py:129, row order

@@ -78,6 +78,43 @@ class HaloExchange(torch.autograd.Function):
         return gx, None
 
 
+def _writable(g):
+    """A gradient this backward may update in place: the engine hands over the producer's fresh tensor when the
+    forward output had a single consumer (the next layer); anything that looks shared is copied first."""
+    return g if (g.is_contiguous() and g._base is None and not g.requires_grad) else g.clone(memory_format=torch.contiguous_format)
+
+
+class HaloExchangeFeatures(torch.autograd.Function):
+    """(x [N,H], vec [N,3,H]) of one layer -> the same tensors with the halo rows replaced by their owners'
+    values: ONE all-to-all of n_halo * 4H floats, halo rows written IN PLACE (no copy of the full arrays)."""
+
+    @staticmethod
+    def forward(ctx, x, vec, plan):
+        ctx.plan = plan
+        H = x.size(1)
+        send = torch.cat([x.detach().index_select(0, plan.send_idx),
+                          vec.detach().index_select(0, plan.send_idx).reshape(-1, 3 * H)], dim=1)
+        recv = _all_to_all_rows(send, plan.send_counts, plan.recv_counts, plan.group)
+        x.index_copy_(0, plan.recv_idx, recv[:, :H])
+        vec.index_copy_(0, plan.recv_idx, recv[:, H:].reshape(-1, 3, H))
+        ctx.mark_dirty(x, vec)
+        return x, vec
+
+    @staticmethod
+    def backward(ctx, gx, gvec):
+        plan = ctx.plan
+        H = gx.size(1)
+        gsend = torch.cat([gx.index_select(0, plan.recv_idx),
+                           gvec.index_select(0, plan.recv_idx).reshape(-1, 3 * H)], dim=1)
+        back = _all_to_all_rows(gsend, plan.recv_counts, plan.send_counts, plan.group)
+        gx, gvec = _writable(gx), _writable(gvec)
+        gx.index_fill_(0, plan.recv_idx, 0)          # the local halo values were overwritten in forward
+        gvec.index_fill_(0, plan.recv_idx, 0)
+        gx.index_add_(0, plan.send_idx, back[:, :H])                      # gradients of my atoms used elsewhere
+        gvec.index_add_(0, plan.send_idx, back[:, H:].reshape(-1, 3, H))
+        return gx, gvec, None
+
+
 class SumAcrossRanks(torch.autograd.Function):
     """E_total = sum_r E_r (all-reduce); d E_total / d E_r = 1 on every rank."""
 
