@@ -126,9 +126,10 @@ def training_secondary(hn, synth, dev, model_kw, num_graphs=1024, steps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline step only (profiling runs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal with several ranks sharing one GPU (exchange staged through the host)")
     args = ap.parse_args()
@@ -238,7 +239,7 @@ def main():
             "kernels": kernels,
             "energy": float(e.detach()[0]),
         }
-        if world == 1:
+        if world == 1 and not args.no_secondary:
             # secondary figure: the step INCLUDING the device-side neighbour search, i.e. what a
             # calculator does per MD step (the reference rebuilds the list on the host every step)
             from hermnet_amd.neighbor import neighbor_search

@@ -11,7 +11,7 @@ from .relations import RelationalGraph
 from .sharding import HaloExchange, HaloExchangeFeatures, SumAcrossRanks
 import os
 
-from .layer import EdgeFanout, EdgeGradSink, FusedRelationalLayer, LayerWeights
+from .layer import EdgeFanout, EdgeGradSink, EnergyHead, FusedRelationalLayer, LayerWeights
 from .rmnet import PaiNNModule, RadialBasis, ScaledSiLU, relational_layer
 
 
@@ -156,7 +156,13 @@ class HVNet(nn.Module):
                 data.x, data.vec = HaloExchangeFeatures.apply(data.x, data.vec, row_plan)
         x = data.x
 
-        e_rows = self.out_energy(x).squeeze(1)                              # hermnet.py:129, row order
+        head_params = (self.out_energy[0].weight, self.out_energy[0].bias, self.out_energy[2].weight,
+                       self.out_energy[2].bias)
+        if (train or not fused or (self.hidden_channels // 2) % 4 != 0
+                or os.environ.get("HERMNET_FUSED_LAYER", "1") == "0"):
+            e_rows = self.out_energy(x).squeeze(1)                          # hermnet.py:129, row order
+        else:
+            e_rows = EnergyHead.apply(x.contiguous(), *[p.detach() for p in head_params])
         if shard is None and graph.num_graphs == 1:
             # one graph: padding rows are masked instead of gathering back to atom order (the gather's
             # backward is an index_put, ~50 us); fixed summation order, bit-reproducible

@@ -240,3 +240,21 @@ class FusedRelationalLayer(torch.autograd.Function):
             gx_total = nodeops.layernorm_bwd(gn, x, mean, rstd, add=gx_in)
         ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
         return gx_total, gvec_in, ge, None, None, None, None, None
+
+
+class EnergyHead(torch.autograd.Function):
+    """`out_energy` (hermnet.py:113-117,129) on relation-ordered rows: Linear (library GEMM, bias in the epilogue),
+    then ScaledSiLU + the H/2 -> 1 Linear in one kernel; one autograd node with a hand-written backward.
+    Parameters are constants here (eval() mode; train() mode runs the nn.Sequential)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w2, b2):
+        h = torch.addmm(b0, x, w0.t())                       # [N, H/2]
+        w2v = w2.reshape(-1).contiguous()
+        ctx.save_for_backward(h, w0, w2v)
+        return nodeops.energy_head_fwd(h, w2v, b2)            # [N]
+
+    @staticmethod
+    def backward(ctx, ge):
+        h, w0, w2v = ctx.saved_tensors
+        return torch.mm(nodeops.energy_head_bwd(ge.contiguous(), h, w2v), w0), None, None, None, None

@@ -224,6 +224,20 @@ def test_layernorm_kernels(H):
         assert rel_err(gx.cpu(), ref_ops.layernorm_bwd(g, x, mean_r, rstd_r, add=a)) < 2e-6
 
 
+def test_energy_head_kernels():
+    """`hermnet_energy_head_fwd/_bwd` vs the PyTorch restatement (ScaledSiLU + Linear(H/2, 1))."""
+    from hermnet_amd import nodeops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(3)
+    for rows, C in [(257, 64), (31, 32), (100, 256)]:
+        h, w, b = torch.randn(rows, C, generator=gen), torch.randn(C, generator=gen), torch.randn(1, generator=gen)
+        ge = torch.randn(rows, generator=gen)
+        e = nodeops.energy_head_fwd(h.to(dev), w.to(dev), b.to(dev))
+        assert rel_err(e.cpu(), ref_ops.energy_head_fwd(h, w, b)) < 2e-6
+        gh = nodeops.energy_head_bwd(ge.to(dev), h.to(dev), w.to(dev))
+        assert rel_err(gh.cpu(), ref_ops.energy_head_bwd(ge, h, w)) < 2e-6
+
+
 def test_bias_on_load_equals_bias_in_operand():
     """The stages that add a GEMM's bias on load (include/hermnet_hip.h "Bias convention"): kernel(h, bias)
     must equal kernel(h + expanded bias) for the node kernels and the message kernels (xh_bias)."""

@@ -204,7 +204,7 @@ def test_fused_layer_orchestration_matches_golden(name, monkeypatch):
     monkeypatch.setenv("HERMNET_FUSED_LAYER", "1")
     monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
     monkeypatch.setattr(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
-    for fn in ["layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid", "update_out", "update_out_bwd",
+    for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid", "update_out", "update_out_bwd",
                "update_mid_bwd"]:
         monkeypatch.setattr(lmod.nodeops, fn, getattr(ref_ops, fn))
     monkeypatch.setattr(lmod, "_msg_fwd", ref_ops.msg_fwd)

@@ -22,7 +22,7 @@ def _patch_cpu_ops():
     import ref_ops
     hmod.HVNet._require_device = staticmethod(lambda pos: None)
     hmod.EdgeGeometry = ref_ops.RefEdgeGeometry
-    for fn in ["layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid", "update_out", "update_out_bwd",
+    for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid", "update_out", "update_out_bwd",
                "update_mid_bwd"]:
         setattr(lmod.nodeops, fn, getattr(ref_ops, fn))
     lmod._msg_fwd = ref_ops.msg_fwd
