@@ -45,7 +45,8 @@ def _launch(name, fn):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of PyTorch's current stream as an integer (the raw getter: no Stream object per launch)."""
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _require_gpu(t, what):

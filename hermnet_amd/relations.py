@@ -48,7 +48,10 @@ class RelationalGraph(object):
     __slots__ = ("N", "E", "T", "num_atoms", "uniform", "block", "node_order", "row_of_node", "z_rows",
                  "type_rowptr", "type_rowptr_host", "csr_rowptr", "csr_src", "csr_perm", "csc_rowptr", "csc_tgt",
                  "csc_pos", "out_rowptr", "out_edges", "src_id", "tgt_id", "shift", "row_active", "row_real",
-                 "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device")
+                 "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device", "_cstruct")
+
+    def __init__(self):
+        self._cstruct = None
 
     @staticmethod
     def build(atomic_number, edge_index, z_list, edge_shift=None, batch=None, rel_active=None, uniform=None):
@@ -248,6 +251,11 @@ class RelationalGraph(object):
 
     def as_struct(self):
         from . import _lib
+        if self._cstruct is None:      # the graph is immutable: build the ctypes view once, not per launch
+            self._cstruct = self._make_struct(_lib)
+        return self._cstruct
+
+    def _make_struct(self, _lib):
         return _lib.Graph(self.N, self.E, self.T, self.type_rowptr.data_ptr(), self.csr_rowptr.data_ptr(),
                           self.csr_src.data_ptr(), self.csc_rowptr.data_ptr(), self.csc_tgt.data_ptr(),
                           self.csc_pos.data_ptr())
