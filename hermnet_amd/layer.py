@@ -23,9 +23,19 @@ class LayerWeights(object):
     def __init__(self, mods):
         self.mods = list(mods)
         self.key = None
+        # (owner module, name) of every parameter, collected once: walking `module.parameters()` on every
+        # forward costs ~0.13 ms of host time per layer
+        self._slots = [(sub, name) for m in self.mods for sub in m.modules() for name in sub._parameters]
 
     def _version_key(self):
-        return tuple((p.data_ptr(), p._version) for m in self.mods for p in m.parameters())
+        # identity + version of the CURRENT parameter objects (a replaced Parameter or an in-place update both
+        # change the key); data_ptr covers `.to(device)` / `.data = ...`
+        key = []
+        for sub, name in self._slots:
+            p = sub._parameters[name]
+            if p is not None:               # e.g. vec_proj has bias=False
+                key.append((id(p), p._version, p.data_ptr()))
+        return tuple(key)
 
     @torch.no_grad()
     def refresh(self):
