@@ -15,6 +15,7 @@ _ERR = {1: "HN_ERR_BAD_ARG (unsupported shape or null pointer)",
         3: "HN_ERR_LAUNCH (kernel launch failed)"}
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers
+ABI_VERSION = 2          # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
 
 
 class RbfDesc(ctypes.Structure):
@@ -91,6 +92,9 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.hermnet_abi_version() != ABI_VERSION:
+        raise RuntimeError("hermnet_amd: %s has ABI version %d, the Python side expects %d -- rebuild it "
+                           "(`make -C hermnet_amd/csrc`)" % (LIB_PATH, lib.hermnet_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -19,6 +19,9 @@ def enable_tuned_gemms(path=TUNED_GEMMS):
     tunable.enable(True)
     tunable.tuning_enable(False)
     try:
+        import tempfile
+        # TunableOp writes its table back at exit: keep that out of the working directory
+        tunable.set_filename(os.path.join(tempfile.gettempdir(), "hermnet_tunableop_%d.csv" % os.getpid()))
         return bool(tunable.read_file(path))
     except Exception:
         return False
