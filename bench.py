@@ -89,6 +89,40 @@ def cpu_baseline(model_kw, elems, seed):
                       % (n, reps[0], reps[1], reps[2], dt, cores)}
 
 
+def other_configs_secondary(hn, synth, dev, model_kw, steps=5):
+    """configs[3] on ONE GPU (100k-atom cell, no sharding) and configs[4] (1024-molecule batch): energy + forces
+    per step incl. the relation build, neighbour list prebuilt -- the same step definition as the headline."""
+    res = {}
+    cases = [("configs[3] 100k-atom 3-element cell on 1 GPU", ["Al", "Ni", "Cu"],
+              lambda: synth.fcc_alloy(reps=(25, 25, 40), seed=0, device=dev)),
+             ("configs[4] 1024-molecule batch", ["H", "C", "O"], lambda: synth.molecule_batch(num_graphs=1024).to(dev))]
+    for name, elems, make in cases:
+        d = make()
+        model = hn.HVNet(elems, **model_kw).eval()
+        model.load_state_dict(synth.synth_state_dict(model.state_dict(), 10))
+        model = model.to(dev)
+        for p_ in model.parameters():
+            p_.requires_grad_(False)
+
+        def one():
+            d.pos.requires_grad_(True)
+            en = model(d)
+            return en, -torch.autograd.grad(en.sum(), d.pos)[0]
+
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            en, f = one()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res[name] = {"atoms": d.pos.size(0), "edges": d.edge_index.size(1), "graphs": int(en.numel()),
+                     "ms_per_step": dt * 1e3, "atom_steps_per_s": d.pos.size(0) / dt}
+        del d, model
+    return res
+
+
 def training_secondary(hn, synth, dev, model_kw, num_graphs=1024, steps=3):
     import torch.nn.functional as F
     d = synth.molecule_batch(num_graphs=num_graphs).to(dev)
@@ -264,6 +298,11 @@ def main():
             torch.cuda.synchronize()
             out["secondary"] = {"atom_steps_per_s_incl_neighbor_search": N * nmd / (time.perf_counter() - t1),
                                 "note": "device cell-list neighbour search + relation build + energy + forces per step"}
+            # secondary figures: the other single-GPU configurations of BASELINE.json at full size, same model
+            try:
+                out["secondary"]["other_configs"] = other_configs_secondary(hn, synth, dev, model_kw)
+            except Exception as ex:
+                out["secondary"]["other_configs"] = {"error": repr(ex)}
             # secondary figure: one optimisation step of `example/dist_train.py:86-99`
             # (energy + force loss with create_graph=True, backward to all parameters, Adam) on configs[4]'s
             # molecule batch; runs the differentiable device-op path of train() mode
