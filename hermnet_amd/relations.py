@@ -48,10 +48,19 @@ class RelationalGraph(object):
     __slots__ = ("N", "E", "T", "num_atoms", "uniform", "block", "node_order", "row_of_node", "z_rows",
                  "type_rowptr", "type_rowptr_host", "csr_rowptr", "csr_src", "csr_perm", "csc_rowptr", "csc_tgt",
                  "csc_pos", "out_rowptr", "out_edges", "src_id", "tgt_id", "shift", "row_active", "row_real",
-                 "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device", "_cstruct")
+                 "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device", "_cstruct", "_rel_bounds")
 
     def __init__(self):
         self._cstruct = None
+        self._rel_bounds = None
+
+    def rel_edge_bounds(self):
+        """CSR edge ranges of the relations: edges of relation t are [b[t], b[t+1]) (rows are relation-ordered and
+        CSR is row-ordered); edges to unknown-element targets follow after b[T].  One host sync per graph; used by
+        the differentiable device-op path only."""
+        if self._rel_bounds is None:
+            self._rel_bounds = self.csr_rowptr[self.type_rowptr.long()].tolist()
+        return self._rel_bounds
 
     @staticmethod
     def build(atomic_number, edge_index, z_list, edge_shift=None, batch=None, rel_active=None, uniform=None):

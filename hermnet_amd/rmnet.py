@@ -209,31 +209,36 @@ class PaiNNModule(nn.Module):
 
 def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     """Same contract as the fused kernel (rmnet.py:24-26,55-73) for a MATERIALISED basis `edge_embed`
-    [E,R] (CSR order): library GEMM per relation + gather/index_add device ops, differentiable by
-    PyTorch autograd.  Path of the optional radial bases only (API parity, not the benchmark)."""
+    [E,R] (CSR order): library GEMM per relation + gather/index_add device ops, differentiable to any order by
+    PyTorch autograd.  Path of train() mode (parameter gradients, create_graph=True) and of the optional
+    radial bases."""
     T, N, H3 = xh.shape
     H = H3 // 3
     rowptr = graph.csr_rowptr.long()
     tgt_row = torch.repeat_interleave(torch.arange(N, device=x.device), rowptr[1:] - rowptr[:-1])
     src = graph.csr_src.long()
     rel_row = torch.bucketize(torch.arange(N, device=x.device), graph.type_rowptr.long()[1:], right=True)
-    rel_e = rel_row[tgt_row]
+    # rows are relation-ordered and CSR is row-ordered: the edges of relation t are ONE contiguous CSR range
+    # (no per-relation masks or gathers of the edge arrays)
+    bounds = graph.rel_edge_bounds()
+    Ek = bounds[T]                                             # edges whose target has a known element
+    parts = []
+    for t in range(T):
+        e0, e1 = bounds[t], bounds[t + 1]
+        if e1 > e0:
+            rb = F.linear(edge_embed[e0:e1], w_rbf[t], b_rbf[t])                   # rbf_proj, rmnet.py:55
+            parts.append(xh[t].index_select(0, src[e0:e1]) * rb)                   # x_j * rbfh, rmnet.py:58,61-62
     dx = x.new_zeros(N, H)
     dv = x.new_zeros(N, 3, H)
-    rhat = edge[:, :3]
-    for t in range(T):
-        sel = torch.nonzero(rel_e == t).flatten()
-        if sel.numel() == 0:
-            continue
-        rb = F.linear(edge_embed[sel], w_rbf[t], b_rbf[t])                     # rbf_proj, rmnet.py:55
-        m = xh[t].index_select(0, src[sel]) * rb
+    if parts:
+        m = parts[0] if len(parts) == 1 else torch.cat(parts, 0)                   # [Ek, 3H]
         s_, a_, b_ = m[:, :H], m[:, H:2 * H], m[:, 2 * H:]
-        mv = b_[:, None, :] * rhat[sel][:, :, None]
+        mv = b_[:, None, :] * edge[:Ek, :3, None]                                  # rmnet.py:64-66
         if vec is not None:
-            mv = mv + vec.index_select(0, src[sel]) * (a_ * (1 / math.sqrt(3.0)))[:, None, :]
+            mv = mv + vec.index_select(0, src[:Ek]) * (a_ * (1 / math.sqrt(3.0)))[:, None, :]
         mv = mv * (1 / math.sqrt(H))
-        dx = dx.index_add(0, tgt_row[sel], s_)
-        dv = dv.index_add(0, tgt_row[sel], mv)
+        dx = dx.index_add(0, tgt_row[:Ek], s_)                                     # aggregate, rmnet.py:69-73
+        dv = dv.index_add(0, tgt_row[:Ek], mv)
     known = (rel_row < T).to(x.dtype)
     x1 = (x + dx) * (1 / math.sqrt(2.0)) * known[:, None]
     vec1 = ((vec if vec is not None else 0) + dv) * known[:, None, None]

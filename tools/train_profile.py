@@ -1,0 +1,31 @@
+"""Where the training step (train() mode, differentiable device ops) spends its time: torch.profiler, one step."""
+import sys, torch
+sys.path.insert(0, '.')
+import torch.nn.functional as F
+import hermnet_amd as hn
+from hermnet_amd import synth
+from torch.profiler import profile, ProfilerActivity
+dev = torch.device('cuda:0')
+kw = dict(rc=5.0, num_layers=5, hidden_channels=128, num_rbf=128)
+d = synth.molecule_batch(num_graphs=1024).to(dev)
+model = hn.HVNet(["H", "C", "O"], **kw)
+model.load_state_dict(synth.synth_state_dict(model.state_dict(), 12))
+model = model.to(dev).train()
+gen = torch.Generator().manual_seed(0)
+y = torch.randn(1024, generator=gen).to(dev)
+ftgt = (0.5 * torch.randn(d.pos.shape, generator=gen)).to(dev)
+def step():
+    model.zero_grad()
+    d.pos.requires_grad_(True)
+    e = model(d)
+    f = -torch.autograd.grad(e.sum(), d.pos, create_graph=True)[0]
+    loss = 0.2 * F.mse_loss(e, y) + 0.8 * F.mse_loss(f, ftgt)
+    loss.backward()
+    return loss
+for _ in range(2): step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step(); torch.cuda.synchronize()
+rows = [(ev.device_time_total, ev.count, ev.key) for ev in prof.key_averages() if ev.device_time_total > 0 and ev.key.startswith("aten::")]
+for t, c, k in sorted(rows, reverse=True)[:30]:
+    print("%9.1f us  x%4d  %s" % (t, c, k))
