@@ -76,7 +76,7 @@ class RbfDescriptor(object):
 
 
 def _split_t(graph):
-    """One relation per workgroup in the backward message kernel (env HERMNET_BWD_SPLIT_T, default on for T > 1)."""
+    """One relation per workgroup in the backward message kernel (env HERMNET_BWD_SPLIT_T=1; default off: measured slower on balanced compositions)."""
     import os
     return int(graph.T > 1 and os.environ.get("HERMNET_BWD_SPLIT_T", "0") != "0")
 
