@@ -162,6 +162,21 @@ __device__ __forceinline__ Vec<VW> groups_sum(Vec<VW> a) {
   return a;
 }
 
+// VW = 4 (four 16-lane rows): row g of the result holds the sum over the four rows of a.v[g] -- three
+// v_permlane swaps (gfx950) and three adds on the VALU instead of eight LDS-routed shuffles.  The caller then
+// owns channel `first channel + g` of the reduced vector: a dword store per lane, 256 contiguous bytes per wave.
+__device__ __forceinline__ float rows_reduce4(const Vec<4>& a) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  // permlane16_swap: odd rows of the first operand <-> even rows of the second
+  const u2 s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.v[0]), __float_as_uint(a.v[1]), false, false);
+  const u2 s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.v[2]), __float_as_uint(a.v[3]), false, false);
+  const float u = __uint_as_float(s01[0]) + __uint_as_float(s01[1]);   // rows: v0(r0+r1), v1(r0+r1), v0(r2+r3), v1(r2+r3)
+  const float w = __uint_as_float(s23[0]) + __uint_as_float(s23[1]);   //       v2(r0+r1), v3(r0+r1), v2(r2+r3), v3(r2+r3)
+  // permlane32_swap: upper half of the first operand <-> lower half of the second
+  const u2 h = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(w), false, false);
+  return __uint_as_float(h[0]) + __uint_as_float(h[1]);               // rows: sum v0, sum v1, sum v2, sum v3
+}
+
 // Sum over the 64/VW lanes of each lane group (all channels of one edge); every lane gets its group's total.
 template <int VW>
 __device__ __forceinline__ float group_allsum(float v) {
@@ -439,21 +454,33 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
         else if (it + 1 < nit) cur = load_edges(it + 1);
       }
     }
-    // combine the lane groups, then the residual epilogue (rmnet.py:24-26).  The four output rows
-    // (x1, vec1[0..2]) are spread over the lane groups (256 B per group and row).
-    ax = groups_sum<VW>(ax);
+    // combine the lane groups, then the residual epilogue (rmnet.py:24-26).
+    if constexpr (VW == 4) {
+      // rows_reduce4 leaves ONE channel (col + grp) of every reduced row in each lane: dword accesses, all lanes
+      const int c1 = col + grp;
+      const size_t xo = (size_t)r * H + c1;
+      a.x1[xo] = (a.x[xo] + rows_reduce4(ax)) * 0.70710678118654752f;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) av[d] = groups_sum<VW>(av[d]);
-    for (int o = grp; o < 4; o += VW) {     // o = 0: x1, o = 1..3: vec1[o-1]
-      if (o == 0) {
-        const size_t xo = (size_t)r * H + col;
-        v_scale(v_add(Vec<VW>::load(a.x + xo), ax), 0.70710678118654752f).store(a.x1 + xo);
-      } else {
-        const size_t vo = ((size_t)r * 3 + (o - 1)) * H + col;
-        const Vec<VW> acc = o == 1 ? av[0] : (o == 2 ? av[1] : av[2]);
-        Vec<VW> v0 = Vec<VW>::zero();
-        if (HAS_VEC) v0 = Vec<VW>::load(a.vec + vo);
-        v_add(v0, acc).store(a.vec1 + vo);
+      for (int d = 0; d < 3; ++d) {
+        const size_t vo = ((size_t)r * 3 + d) * H + c1;
+        a.vec1[vo] = (HAS_VEC ? a.vec[vo] : 0.f) + rows_reduce4(av[d]);
+      }
+    } else {
+      // the four output rows (x1, vec1[0..2]) are spread over the lane groups (256 B per group and row)
+      ax = groups_sum<VW>(ax);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) av[d] = groups_sum<VW>(av[d]);
+      for (int o = grp; o < 4; o += VW) {     // o = 0: x1, o = 1..3: vec1[o-1]
+        if (o == 0) {
+          const size_t xo = (size_t)r * H + col;
+          v_scale(v_add(Vec<VW>::load(a.x + xo), ax), 0.70710678118654752f).store(a.x1 + xo);
+        } else {
+          const size_t vo = ((size_t)r * 3 + (o - 1)) * H + col;
+          const Vec<VW> acc = o == 1 ? av[0] : (o == 2 ? av[1] : av[2]);
+          Vec<VW> v0 = Vec<VW>::zero();
+          if (HAS_VEC) v0 = Vec<VW>::load(a.vec + vo);
+          v_add(v0, acc).store(a.vec1 + vo);
+        }
       }
     }
   }
@@ -527,6 +554,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
       }
       Vec<VW> gs = Vec<VW>::zero(), ga = Vec<VW>::zero(), gb = Vec<VW>::zero();
       Vec<VW> gv[3] = {Vec<VW>::zero(), Vec<VW>::zero(), Vec<VW>::zero()};
+      // gvec[row] is read-modify-written across the relations (t = 0 starts from the residual's identity term):
+      // the old value is requested here, a whole segment ahead of its use
+      float prev1[3] = {0.f, 0.f, 0.f};
+      if (HAS_VEC && VW == 4) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const size_t vo = ((size_t)r * 3 + d) * H + col + grp;
+          if (t == 0) prev1[d] = r < nk ? a.gvec1[vo] : 0.f;
+          else if (!a.split_t) prev1[d] = a.gvec[vo];
+        }
+      }
 
       for (int base = beg; base < end; base += 64) {
         const int cnt = min(64, end - base);
@@ -635,29 +673,47 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
         }
       }
       // combine lane groups; the output rows (gxh s/a/b, gx | gvec[0..2]) are spread over the groups
-      gs = groups_sum<VW>(gs); ga = groups_sum<VW>(ga); gb = groups_sum<VW>(gb);
       const bool known = r < nk;
-      if (grp == 0) {
-        float* go = gxh_t + (size_t)r * 3 * H + col;
-        gs.store(go); ga.store(go + H); gb.store(go + 2 * H);
-        if (t == 0) {   // residual identity: gx = gx1 / sqrt2 on rows that are targets
-          const Vec<VW> g1 = known ? Vec<VW>::load(a.gx1 + (size_t)r * H + col) : Vec<VW>::zero();
-          v_scale(g1, inv_sqrt2).store(a.gx + (size_t)r * H + col);
-        }
-      }
-      if (HAS_VEC) {
+      if constexpr (VW == 4) {
+        // every lane ends up with ONE channel (col + grp) of each reduced row: dword stores, all lanes active
+        const int c1 = col + grp;
+        float* go = gxh_t + (size_t)r * 3 * H + c1;
+        go[0] = rows_reduce4(gs);
+        go[H] = rows_reduce4(ga);
+        go[2 * H] = rows_reduce4(gb);
+        if (t == 0) a.gx[(size_t)r * H + c1] = (known ? a.gx1[(size_t)r * H + c1] : 0.f) * inv_sqrt2;
+        if (HAS_VEC) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) gv[d] = groups_sum<VW>(gv[d]);
-        // gvec[d] handled by lane group (d + 1) % VW  (VW = 4: groups 1,2,3; VW = 2: groups 1,0,1)
-        for (int d = 0; d < 3; ++d) {
-          if (((d + 1) % VW) != grp) continue;
-          const size_t vo = ((size_t)r * 3 + d) * H + col;
-          Vec<VW> prev;
-          if (t == 0) prev = known ? Vec<VW>::load(a.gvec1 + vo) : Vec<VW>::zero();
-          else if (a.split_t) prev = Vec<VW>::zero();
-          else prev = Vec<VW>::load(a.gvec + vo);
-          const Vec<VW> add = d == 0 ? gv[0] : (d == 1 ? gv[1] : gv[2]);
-          v_add(prev, add).store(a.gvec + (a.split_t ? (size_t)t * a.N * 3 * H : 0) + vo);
+          for (int d = 0; d < 3; ++d) {
+            const size_t vo = ((size_t)r * 3 + d) * H + c1;
+            a.gvec[(a.split_t ? (size_t)t * a.N * 3 * H : 0) + vo] =
+                prev1[d] + rows_reduce4(gv[d]);
+          }
+        }
+      } else {
+        gs = groups_sum<VW>(gs); ga = groups_sum<VW>(ga); gb = groups_sum<VW>(gb);
+        if (grp == 0) {
+          float* go = gxh_t + (size_t)r * 3 * H + col;
+          gs.store(go); ga.store(go + H); gb.store(go + 2 * H);
+          if (t == 0) {   // residual identity: gx = gx1 / sqrt2 on rows that are targets
+            const Vec<VW> g1 = known ? Vec<VW>::load(a.gx1 + (size_t)r * H + col) : Vec<VW>::zero();
+            v_scale(g1, inv_sqrt2).store(a.gx + (size_t)r * H + col);
+          }
+        }
+        if (HAS_VEC) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) gv[d] = groups_sum<VW>(gv[d]);
+          // gvec[d] handled by lane group (d + 1) % VW  (VW = 2: groups 1,0,1)
+          for (int d = 0; d < 3; ++d) {
+            if (((d + 1) % VW) != grp) continue;
+            const size_t vo = ((size_t)r * 3 + d) * H + col;
+            Vec<VW> prev;
+            if (t == 0) prev = known ? Vec<VW>::load(a.gvec1 + vo) : Vec<VW>::zero();
+            else if (a.split_t) prev = Vec<VW>::zero();
+            else prev = Vec<VW>::load(a.gvec + vo);
+            const Vec<VW> add = d == 0 ? gv[0] : (d == 1 ? gv[1] : gv[2]);
+            v_add(prev, add).store(a.gvec + (a.split_t ? (size_t)t * a.N * 3 * H : 0) + vo);
+          }
         }
       }
     }
@@ -695,12 +751,13 @@ int num_cus() {
 
 // Rows per workgroup such that the grid is a whole number of "rounds" of one workgroup per CU
 // (the 116 KB weight tile allows one resident workgroup per CU): `work` = rows x column blocks,
-// `slack` = workgroups lost to per-relation rounding.  Targets ~32 rows per workgroup.
+// `slack` = workgroups lost to per-relation rounding.  Targets ~64 rows per workgroup (each workgroup stages
+// the 116 KB weight tile once per relation: fewer, longer workgroups amortise it; measured on config 2).
 int pick_rows(int rows, int ncb, int slack, int override_rows) {
   if (override_rows > 0) return override_rows;
   const long work = (long)rows * ncb;
   const int cus = num_cus();
-  long rounds = (work + (long)cus * 16) / ((long)cus * 32);
+  long rounds = (work + (long)cus * 32) / ((long)cus * 64);
   if (rounds < 1) rounds = 1;
   long wgs = (long)cus * rounds - slack;
   if (wgs < 1) wgs = 1;
@@ -819,7 +876,7 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   a.gedge = reinterpret_cast<float4*>(gedge);
   static const int rpb_bwd = env_int("HERMNET_BWD_ROWS", 0);
   static const int variant_vec = env_int("HERMNET_BWD_VARIANT", 8420);
-  static const int variant_l0 = env_int("HERMNET_BWD_VARIANT_L0", 16201);
+  static const int variant_l0 = env_int("HERMNET_BWD_VARIANT_L0", 8420);
   const int variant = vec ? variant_vec : variant_l0;
   a.split_t = split_t ? 1 : 0;
   a.rows_per_block = pick_rows(a.N, (hidden / HN_CB) * (a.split_t ? a.T : 1), 0, rpb_bwd) * (a.split_t ? a.T : 1);
