@@ -27,15 +27,34 @@ except Exception:  # pragma: no cover - exercised on the GPU image
             self.atoms = atoms
 
 
+_SPECIES = {}      # device -> (numpy Z, z tensor, batch tensor) of the last call
+
+
+def _species_tensors(elements, device):
+    """Atomic numbers and the (single-graph) batch vector as device tensors, REUSED while the species list is
+    unchanged: along a trajectory only the coordinates change, and the relation build skips its one host sync
+    (element counts) when it is handed the same tensor objects again (`relations._COUNT_CACHE`)."""
+    elements = np.asarray(elements)
+    key = str(device)
+    hit = _SPECIES.get(key)
+    if hit is None or hit[0].shape != elements.shape or not np.array_equal(hit[0], elements):
+        z = torch.from_numpy(elements.copy()).long()
+        batch = torch.zeros(elements.shape[0], dtype=torch.long)
+        if device is not None:
+            z, batch = z.to(device), batch.to(device)
+        hit = _SPECIES[key] = (elements.copy(), z, batch)
+    return hit[1], hit[2]
+
+
 def build_graph(cell, elements, pos, rc, device=None):
     """`calculator.py:10-27`: numpy (cell [3,3] or None, Z [N], pos [N,3]) -> `Data` with the cutoff graph.
     With `device` set to the GPU the coordinates are uploaded first and the neighbour search runs on the
     device (`csrc/neighbor_kernels.hip`) instead of the host -- the reference rebuilds the list every step."""
     pos_t = torch.from_numpy(np.asarray(pos)).float()
-    z = torch.from_numpy(np.asarray(elements)).long()
     if device is not None:
-        pos_t, z = pos_t.to(device), z.to(device)
-    data = Data(atomic_number=z, pos=pos_t, batch=torch.zeros(pos_t.size(0), dtype=torch.long, device=pos_t.device))
+        pos_t = pos_t.to(device)
+    z, batch = _species_tensors(elements, device)
+    data = Data(atomic_number=z, pos=pos_t, batch=batch)
     if cell is None or not np.any(np.asarray(cell)):
         data.edge_index = neighbor_search(pos=pos_t, rc=rc)
     else:

@@ -4,6 +4,7 @@ vendored anywhere) is imported only in `serve`; `calculator` is transport-free."
 import argparse
 
 import numpy as np
+import torch
 
 from ..elements import atomic_numbers
 from .ase_interface import build_graph, model_calc
@@ -82,7 +83,10 @@ def serve(argv=None):  # pragma: no cover - needs LAMMPS' cslib
                 box = cs.unpack(BOX, 1)
         z = lammps_types_to_numbers(types, a.elems)
         pos = np.asarray(coords, dtype=np.float64).reshape(-1, 3)
-        data = build_graph(box_to_cell(box) if pbc else None, z, pos, a.rc)
+        # GPU runs: upload the coordinates first, neighbour search on the device (the reference rebuilds the list
+        # on the host every step, lmp_calc.py:224)
+        dev = a.device if torch.device(a.device).type == 'cuda' else None
+        data = build_graph(box_to_cell(box) if pbc else None, z, pos, a.rc, device=dev)
         e, f, v = calculator(data, model, a.mean, a.device, pbc, a.units, a.ensemble)
         pack_reply(cs, msg_id, f, e, v)
     cs.send(0, 0)

@@ -100,29 +100,30 @@ class RelationalGraph(object):
         dev = atomic_number.device
         NA, E, T = int(atomic_number.numel()), int(edge_index.size(1)), len(z_list)
         g.num_atoms, g.E, g.T, g.device = NA, E, T, dev
-        z = atomic_number.long().contiguous()
         ei = edge_index.long().contiguous()
         i32, P = torch.int32, _lib.ptr
         # element counts and graph count: a host sync, skipped while the same tensors are passed again
-        # (atom types and batch assignment do not change along an MD trajectory)
-        # (identity of the tensor OBJECTS, which the cache keeps alive: an address alone could be reused by
-        # a different tensor of the same size)
+        # (atom types and batch assignment do not change along an MD trajectory).  Keyed on the identity of the
+        # caller's tensor OBJECTS, which the cache keeps alive: an address alone could be reused by a different
+        # tensor of the same size.
         hit = None
         for ent in _COUNT_CACHE:
-            if (ent[0] is z and ent[1] == z._version and ent[2] is batch
+            if (ent[0] is atomic_number and ent[1] == atomic_number._version and ent[2] is batch
                     and ent[3] == (None if batch is None else batch._version) and ent[4] == tuple(z_list)):
                 hit = ent[5]
                 break
         if hit is None:
+            z = atomic_number.long().contiguous()
             zl = torch.tensor(list(z_list), dtype=i32, device=dev)
             counts = torch.empty(T + 1, dtype=i32, device=dev)
             _lib.check(lib.hermnet_relation_counts(P(z), NA, P(zl), T, P(counts), _stream()), "hermnet_relation_counts")
             nb = batch.long().max().reshape(1) + 1 if (batch is not None and NA > 0) else torch.ones(1, dtype=torch.long, device=dev)
             host = torch.cat([counts.long(), nb]).cpu().tolist()
-            hit = (zl, host[:T + 1], int(host[-1]))
-            _COUNT_CACHE.insert(0, (z, z._version, batch, None if batch is None else batch._version, tuple(z_list), hit))
+            hit = (zl, host[:T + 1], int(host[-1]), z)
+            _COUNT_CACHE.insert(0, (atomic_number, atomic_number._version, batch,
+                                    None if batch is None else batch._version, tuple(z_list), hit))
             del _COUNT_CACHE[8:]
-        zl, cnt_host, g.num_graphs = hit
+        zl, cnt_host, g.num_graphs, z = hit
         g.uniform, g.block, starts, N = RelationalGraph._layout(cnt_host, T, uniform)
         g.N, g.type_rowptr_host = N, starts[:T + 1]
         g.type_rowptr = _cached_i32(tuple(starts[:T + 1]), dev)
