@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // ---- energy read-out head (hermnet.py:113-117,129): e[n] = sum_c ssilu(h[n,c]) w[c] + b -----------------
 // h = out_energy[0](x) comes from a library GEMM; one wave per row, C <= 1024.
 __global__ __launch_bounds__(256) void energy_head_fwd_kernel(const float* __restrict__ h, const float* __restrict__ w,
-                                                              const float* __restrict__ b, float* __restrict__ e,
+                                                              const float* __restrict__ b,
+                                                              const float* __restrict__ mask, float* __restrict__ e,
                                                               int rows, int C) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -306,19 +307,20 @@ __global__ __launch_bounds__(256) void energy_head_fwd_kernel(const float* __res
          v.w * sigmoidf_(v.w) * wv.w;
   }
   s = wave_sum(s);
-  if (lane == 0) e[r] = s * kSiluScale + (b ? b[0] : 0.f);
+  if (lane == 0) e[r] = (s * kSiluScale + (b ? b[0] : 0.f)) * (mask ? mask[r] : 1.0f);
 }
 
 // gh[n,c] = ge[n] * w[c] * d ssilu(h[n,c])
 __global__ __launch_bounds__(256) void energy_head_bwd_kernel(const float* __restrict__ ge, const float* __restrict__ h,
-                                                              const float* __restrict__ w, float* __restrict__ gh,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ mask, float* __restrict__ gh,
                                                               long n4, int C) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const int c4n = C >> 2;
   const long r = i / c4n;
   const int c = (int)(i % c4n) * 4;
-  const float g = ge[r];
+  const float g = ge[r] * (mask ? mask[r] : 1.0f);
   const float4 hv = ld4(h + 4 * i), wv = ld4(w + c);
   st4(gh + 4 * i, make_float4(g * wv.x * dssilu(hv.x), g * wv.y * dssilu(hv.y), g * wv.z * dssilu(hv.z),
                               g * wv.w * dssilu(hv.w)));
@@ -418,22 +420,23 @@ extern "C" int hermnet_layernorm_bwd(const float* g, const float* x, const float
   HN_LAUNCH_END;
 }
 
-extern "C" int hermnet_energy_head_fwd(const float* h, const float* w, const float* b, float* e, int rows, int cols,
-                                       void* stream) {
+extern "C" int hermnet_energy_head_fwd(const float* h, const float* w, const float* b, const float* row_mask, float* e,
+                                       int rows, int cols, void* stream) {
   if (rows < 0 || cols <= 0 || (cols & 3)) return HN_ERR_BAD_ARG;
   if (rows == 0) return HN_OK;
   if (!h || !w || !e) return HN_ERR_BAD_ARG;
   hipLaunchKernelGGL(energy_head_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     h, w, b, e, rows, cols);
+                     h, w, b, row_mask, e, rows, cols);
   HN_LAUNCH_END;
 }
 
-extern "C" int hermnet_energy_head_bwd(const float* ge, const float* h, const float* w, float* gh, int rows, int cols,
-                                       void* stream) {
+extern "C" int hermnet_energy_head_bwd(const float* ge, const float* h, const float* w, const float* row_mask, float* gh,
+                                       int rows, int cols, void* stream) {
   if (rows < 0 || cols <= 0 || (cols & 3)) return HN_ERR_BAD_ARG;
   if (rows == 0) return HN_OK;
   if (!ge || !h || !w || !gh) return HN_ERR_BAD_ARG;
   const long n4 = (long)rows * (cols / 4);
-  hipLaunchKernelGGL(energy_head_bwd_kernel, grid_for(n4, 256), dim3(256), 0, (hipStream_t)stream, ge, h, w, gh, n4, cols);
+  hipLaunchKernelGGL(energy_head_bwd_kernel, grid_for(n4, 256), dim3(256), 0, (hipStream_t)stream, ge, h, w, row_mask, gh, n4,
+                     cols);
   HN_LAUNCH_END;
 }

@@ -158,15 +158,19 @@ class HVNet(nn.Module):
 
         head_params = (self.out_energy[0].weight, self.out_energy[0].bias, self.out_energy[2].weight,
                        self.out_energy[2].bias)
+        single = shard is None and graph.num_graphs == 1
         if (train or not fused or (self.hidden_channels // 2) % 4 != 0
                 or os.environ.get("HERMNET_FUSED_LAYER", "1") == "0"):
             e_rows = self.out_energy(x).squeeze(1)                          # hermnet.py:129, row order
+            if single:
+                e_rows = e_rows * graph.row_real
         else:
-            e_rows = EnergyHead.apply(x.contiguous(), *[p.detach() for p in head_params])
-        if shard is None and graph.num_graphs == 1:
+            e_rows = EnergyHead.apply(x.contiguous(), *[p.detach() for p in head_params],
+                                      graph.row_real if single else None)
+        if single:
             # one graph: padding rows are masked instead of gathering back to atom order (the gather's
             # backward is an index_put, ~50 us); fixed summation order, bit-reproducible
-            energy = (e_rows * graph.row_real).sum().reshape(1)
+            energy = e_rows.sum().reshape(1)
             if self.intensive:
                 energy = energy / max(graph.num_atoms, 1)
             return energy

@@ -258,13 +258,15 @@ class EnergyHead(torch.autograd.Function):
     Parameters are constants here (eval() mode; train() mode runs the nn.Sequential)."""
 
     @staticmethod
-    def forward(ctx, x, w0, b0, w2, b2):
+    def forward(ctx, x, w0, b0, w2, b2, mask=None):
+        """`mask` [N] (optional) multiplies the per-row energies: padding rows of the relation order -> 0."""
         h = torch.addmm(b0, x, w0.t())                       # [N, H/2]
         w2v = w2.reshape(-1).contiguous()
         ctx.save_for_backward(h, w0, w2v)
-        return nodeops.energy_head_fwd(h, w2v, b2)            # [N]
+        ctx.mask = mask
+        return nodeops.energy_head_fwd(h, w2v, b2, mask)      # [N]
 
     @staticmethod
     def backward(ctx, ge):
         h, w0, w2v = ctx.saved_tensors
-        return torch.mm(nodeops.energy_head_bwd(ge.contiguous(), h, w2v), w0), None, None, None, None
+        return torch.mm(nodeops.energy_head_bwd(ge.contiguous(), h, w2v, ctx.mask), w0), None, None, None, None, None

@@ -82,18 +82,18 @@ def update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, rows, H):
         P(gvdot), P(gxin), P(vp), P(xin), P(gvp), P(gx1), rows, H, _stream())), "hermnet_update_mid_bwd")
 
 
-def energy_head_fwd(h, w, b):
-    """e[n] = sum_c ScaledSiLU(h[n,c]) w[c] + b[0]  (b: 1-element device tensor or None)."""
+def energy_head_fwd(h, w, b, mask=None):
+    """e[n] = (sum_c ScaledSiLU(h[n,c]) w[c] + b[0]) * mask[n]  (b: 1-element device tensor or None)."""
     rows, C = h.shape
     e = torch.empty(rows, dtype=h.dtype, device=h.device)
     _lib.check(_launch("energy_head_fwd", lambda: _lib.load().hermnet_energy_head_fwd(
-        P(h), P(w), P(b), P(e), rows, C, _stream())), "hermnet_energy_head_fwd")
+        P(h), P(w), P(b), P(mask), P(e), rows, C, _stream())), "hermnet_energy_head_fwd")
     return e
 
 
-def energy_head_bwd(ge, h, w):
+def energy_head_bwd(ge, h, w, mask=None):
     rows, C = h.shape
     gh = torch.empty_like(h)
     _lib.check(_launch("energy_head_bwd", lambda: _lib.load().hermnet_energy_head_bwd(
-        P(ge), P(h), P(w), P(gh), rows, C, _stream())), "hermnet_energy_head_bwd")
+        P(ge), P(h), P(w), P(mask), P(gh), rows, C, _stream())), "hermnet_energy_head_bwd")
     return gh

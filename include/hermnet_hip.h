@@ -220,13 +220,13 @@ int hermnet_update_mid_bwd(const float* gvdot, const float* gxin, const float* v
                            float* gvp, float* gx1, int rows, int hidden, void* stream);
 
 /* Energy read-out head (`out_energy`, hermnet.py:113-117,129) behind its first Linear (a library GEMM):
- * e[n] = sum_c ScaledSiLU(h[n,c]) * w[c] + b[0];   h [rows, cols], w [cols] = out_energy[2].weight, b [1] its
- * bias (device pointer, may be NULL). */
-int hermnet_energy_head_fwd(const float* h, const float* w, const float* b, float* e, int rows, int cols,
-                            void* stream);
-/* gh[n,c] = ge[n] * w[c] * d ScaledSiLU(h[n,c]). */
-int hermnet_energy_head_bwd(const float* ge, const float* h, const float* w, float* gh, int rows, int cols,
-                            void* stream);
+ * e[n] = (sum_c ScaledSiLU(h[n,c]) * w[c] + b[0]) * row_mask[n];   h [rows, cols], w [cols] = out_energy[2].weight,
+ * b [1] its bias (device pointer, may be NULL), row_mask [rows] (may be NULL: all ones) zeroes padding rows. */
+int hermnet_energy_head_fwd(const float* h, const float* w, const float* b, const float* row_mask, float* e,
+                            int rows, int cols, void* stream);
+/* gh[n,c] = ge[n] * row_mask[n] * w[c] * d ScaledSiLU(h[n,c]). */
+int hermnet_energy_head_bwd(const float* ge, const float* h, const float* w, const float* row_mask, float* gh,
+                            int rows, int cols, void* stream);
 
 /* Host-side (CPU) evaluation of the per-edge radial contraction exactly as the device code
  * computes it (banded 12-tap Gaussian window): rb[c] = b[c] + env(u) * sum_k W[c,k] g_k(u) and

@@ -78,12 +78,14 @@ def layernorm_bwd(g, x, mean, rstd, add=None):
     return gx if add is None else gx + add
 
 
-def energy_head_fwd(h, w, b):
-    return (torch.nn.functional.silu(h) / 0.6) @ w + (0 if b is None else b[0])
+def energy_head_fwd(h, w, b, mask=None):
+    e = (torch.nn.functional.silu(h) / 0.6) @ w + (0 if b is None else b[0])
+    return e if mask is None else e * mask
 
 
-def energy_head_bwd(ge, h, w):
-    return ge[:, None] * w[None, :] * _dssilu(h)
+def energy_head_bwd(ge, h, w, mask=None):
+    g = ge if mask is None else ge * mask
+    return g[:, None] * w[None, :] * _dssilu(h)
 
 
 def _with_bias(h, bias, rows_per_bias):

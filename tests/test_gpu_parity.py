@@ -254,10 +254,12 @@ def test_energy_head_kernels():
     for rows, C in [(257, 64), (31, 32), (100, 256)]:
         h, w, b = torch.randn(rows, C, generator=gen), torch.randn(C, generator=gen), torch.randn(1, generator=gen)
         ge = torch.randn(rows, generator=gen)
-        e = nodeops.energy_head_fwd(h.to(dev), w.to(dev), b.to(dev))
-        assert rel_err(e.cpu(), ref_ops.energy_head_fwd(h, w, b)) < 2e-6
-        gh = nodeops.energy_head_bwd(ge.to(dev), h.to(dev), w.to(dev))
-        assert rel_err(gh.cpu(), ref_ops.energy_head_bwd(ge, h, w)) < 2e-6
+        for mask in (None, (torch.arange(rows) % 7 != 0).float()):
+            md = None if mask is None else mask.to(dev)
+            e = nodeops.energy_head_fwd(h.to(dev), w.to(dev), b.to(dev), md)
+            assert rel_err(e.cpu(), ref_ops.energy_head_fwd(h, w, b, mask)) < 2e-6
+            gh = nodeops.energy_head_bwd(ge.to(dev), h.to(dev), w.to(dev), md)
+            assert rel_err(gh.cpu(), ref_ops.energy_head_bwd(ge, h, w, mask)) < 2e-6
 
 
 def test_bias_on_load_equals_bias_in_operand():
