@@ -1,5 +1,6 @@
 """HVNet / HeteroVertexConv with the reference's constructor, `forward(data)` signature and
 state_dict keys (`HermNet/hermnet.py`), executing the hot path on MI355X."""
+import os
 from typing import Dict, List, Union
 
 import torch
@@ -9,8 +10,6 @@ from .elements import atomic_numbers
 from .ops import EdgeGeometry, TrueEdgeGradient
 from .relations import RelationalGraph
 from .sharding import HaloExchange, HaloExchangeFeatures, SumAcrossRanks
-import os
-
 from .layer import EdgeFanout, EdgeGradSink, EnergyHead, FusedRelationalLayer, LayerWeights
 from .rmnet import PaiNNModule, RadialBasis, ScaledSiLU, relational_layer
 

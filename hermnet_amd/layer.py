@@ -7,7 +7,6 @@ are treated as constants (energy/force evaluation; parameter gradients are not p
 the training step runs through the differentiable device-op path, `HVNet.forward` in train() mode).
 """
 import ctypes
-import math
 
 import torch
 

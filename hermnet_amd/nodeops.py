@@ -1,6 +1,5 @@
 """Thin Python wrappers (allocate outputs, pass pointers) around the node-level fused
 kernels of `csrc/node_kernels.hip`.  One call = one kernel launch on the current stream."""
-import ctypes
 
 import torch
 
