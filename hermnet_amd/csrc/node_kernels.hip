@@ -326,6 +326,36 @@ __global__ __launch_bounds__(256) void energy_head_bwd_kernel(const float* __res
                               g * wv.w * dssilu(hv.w)));
 }
 
+// ---- halo exchange packing (hermnet_amd/sharding.py) -------------------------------------------------------
+// One packed row per halo atom: [ x (H) | vec (3H) ] = 4H floats; idx holds rows of x / vec.
+// MODE 0: buf[k] = rows[idx[k]]            (pack)
+// MODE 1: buf[k] = rows[idx[k]]; rows[idx[k]] = 0   (pack the gradients of overwritten halo rows, then clear them)
+// MODE 2: rows[idx[k]] = buf[k]            (unpack; idx unique)
+// MODE 3: rows[idx[k]] += buf[k]           (accumulate at the owner; idx may repeat across destination ranks)
+template <int MODE>
+__global__ __launch_bounds__(256) void halo_rows_kernel(float* __restrict__ x, float* __restrict__ vec,
+                                                        const long* __restrict__ idx, int n, int H,
+                                                        float* __restrict__ buf) {
+  const int q4 = H;                                   // float4 per packed row: 4H / 4
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n * q4) return;
+  const int k = (int)(i / q4), c = (int)(i % q4) * 4;  // c in [0, 4H)
+  const long r = idx[k];
+  float* row = c < H ? x + r * H + c : vec + r * 3 * H + (c - H);
+  float* b = buf + (long)k * 4 * H + c;
+  if (MODE == 0) {
+    st4(b, ld4(row));
+  } else if (MODE == 1) {
+    st4(b, ld4(row));
+    st4(row, make_float4(0.f, 0.f, 0.f, 0.f));
+  } else if (MODE == 2) {
+    st4(row, ld4(b));
+  } else {
+    const float4 v = ld4(b);
+    atomicAdd(row + 0, v.x); atomicAdd(row + 1, v.y); atomicAdd(row + 2, v.z); atomicAdd(row + 3, v.w);
+  }
+}
+
 inline dim3 grid_for(long n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 #define HN_LAUNCH_END return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH
 
@@ -438,5 +468,21 @@ extern "C" int hermnet_energy_head_bwd(const float* ge, const float* h, const fl
   const long n4 = (long)rows * (cols / 4);
   hipLaunchKernelGGL(energy_head_bwd_kernel, grid_for(n4, 256), dim3(256), 0, (hipStream_t)stream, ge, h, w, row_mask, gh, n4,
                      cols);
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_halo_rows(int mode, float* x, float* vec, const long* idx, int n, int hidden, float* buf,
+                                 void* stream) {
+  if (n < 0 || hidden <= 0 || (hidden & 3) || mode < 0 || mode > 3) return HN_ERR_BAD_ARG;
+  if (n == 0) return HN_OK;
+  if (!x || !vec || !idx || !buf) return HN_ERR_BAD_ARG;
+  const dim3 grid = grid_for((long)n * hidden, 256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(halo_rows_kernel<0>, grid, dim3(256), 0, s, x, vec, idx, n, hidden, buf); break;
+    case 1: hipLaunchKernelGGL(halo_rows_kernel<1>, grid, dim3(256), 0, s, x, vec, idx, n, hidden, buf); break;
+    case 2: hipLaunchKernelGGL(halo_rows_kernel<2>, grid, dim3(256), 0, s, x, vec, idx, n, hidden, buf); break;
+    default: hipLaunchKernelGGL(halo_rows_kernel<3>, grid, dim3(256), 0, s, x, vec, idx, n, hidden, buf); break;
+  }
   HN_LAUNCH_END;
 }

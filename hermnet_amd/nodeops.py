@@ -96,3 +96,14 @@ def energy_head_bwd(ge, h, w, mask=None):
     _lib.check(_launch("energy_head_bwd", lambda: _lib.load().hermnet_energy_head_bwd(
         P(ge), P(h), P(w), P(mask), P(gh), rows, C, _stream())), "hermnet_energy_head_bwd")
     return gh
+
+
+def halo_rows(mode, x, vec, idx, buf=None):
+    """Packed halo rows [n, 4H] = [x | vec] of the rows `idx` (int64): mode 0 pack, 1 pack-and-clear, 2 unpack,
+    3 accumulate (see include/hermnet_hip.h).  Returns `buf` (allocated for the packing modes)."""
+    n, H = int(idx.numel()), x.size(1)
+    if buf is None:
+        buf = torch.empty(n, 4 * H, dtype=x.dtype, device=x.device)
+    _lib.check(_launch("halo_rows", lambda: _lib.load().hermnet_halo_rows(
+        mode, P(x), P(vec), P(idx), n, H, P(buf), _stream())), "hermnet_halo_rows")
+    return buf

@@ -92,11 +92,17 @@ class HaloExchangeFeatures(torch.autograd.Function):
     def forward(ctx, x, vec, plan):
         ctx.plan = plan
         H = x.size(1)
-        send = torch.cat([x.detach().index_select(0, plan.send_idx),
-                          vec.detach().index_select(0, plan.send_idx).reshape(-1, 3 * H)], dim=1)
-        recv = _all_to_all_rows(send, plan.send_counts, plan.recv_counts, plan.group)
-        x.index_copy_(0, plan.recv_idx, recv[:, :H])
-        vec.index_copy_(0, plan.recv_idx, recv[:, H:].reshape(-1, 3, H))
+        if x.is_cuda:      # two kernels + one collective (csrc/node_kernels.hip: hermnet_halo_rows)
+            from . import nodeops
+            send = nodeops.halo_rows(0, x, vec, plan.send_idx)
+            recv = _all_to_all_rows(send, plan.send_counts, plan.recv_counts, plan.group)
+            nodeops.halo_rows(2, x, vec, plan.recv_idx, recv)
+        else:              # host tensors: planning / CPU rehearsal of the exchange logic (tests)
+            send = torch.cat([x.detach().index_select(0, plan.send_idx),
+                              vec.detach().index_select(0, plan.send_idx).reshape(-1, 3 * H)], dim=1)
+            recv = _all_to_all_rows(send, plan.send_counts, plan.recv_counts, plan.group)
+            x.index_copy_(0, plan.recv_idx, recv[:, :H])
+            vec.index_copy_(0, plan.recv_idx, recv[:, H:].reshape(-1, 3, H))
         ctx.mark_dirty(x, vec)
         return x, vec
 
@@ -104,6 +110,14 @@ class HaloExchangeFeatures(torch.autograd.Function):
     def backward(ctx, gx, gvec):
         plan = ctx.plan
         H = gx.size(1)
+        if gx.is_cuda:
+            from . import nodeops
+            gx, gvec = _writable(gx), _writable(gvec)
+            # the local halo values were overwritten in forward: their gradients go to the owners, none stays here
+            gsend = nodeops.halo_rows(1, gx, gvec, plan.recv_idx)
+            back = _all_to_all_rows(gsend, plan.recv_counts, plan.send_counts, plan.group)
+            nodeops.halo_rows(3, gx, gvec, plan.send_idx, back)          # gradients of my atoms used elsewhere
+            return gx, gvec, None
         gsend = torch.cat([gx.index_select(0, plan.recv_idx),
                            gvec.index_select(0, plan.recv_idx).reshape(-1, 3 * H)], dim=1)
         back = _all_to_all_rows(gsend, plan.recv_counts, plan.send_counts, plan.group)

@@ -228,6 +228,14 @@ int hermnet_energy_head_fwd(const float* h, const float* w, const float* b, cons
 int hermnet_energy_head_bwd(const float* ge, const float* h, const float* w, const float* row_mask, float* gh,
                             int rows, int cols, void* stream);
 
+/* Halo exchange packing for atom-sharded runs (one process per GPU; the exchange itself is an RCCL all-to-all made
+ * by the host code, hermnet_amd/sharding.py).  A packed row = [ x (H) | vec (3H) ]; idx [n] (int64) holds rows.
+ *   mode 0  buf[k] = rows[idx[k]]                         pack what the neighbours need
+ *   mode 1  buf[k] = rows[idx[k]]; rows[idx[k]] = 0       pack the gradients of my halo rows and clear them
+ *   mode 2  rows[idx[k]] = buf[k]                         unpack received halo rows (idx unique)
+ *   mode 3  rows[idx[k]] += buf[k]                        accumulate returned gradients (idx may repeat: atomics) */
+int hermnet_halo_rows(int mode, float* x, float* vec, const long* idx, int n, int hidden, float* buf, void* stream);
+
 /* Host-side (CPU) evaluation of the per-edge radial contraction exactly as the device code
  * computes it (banded 12-tap Gaussian window): rb[c] = b[c] + env(u) * sum_k W[c,k] g_k(u) and
  * its derivative d rb / d d.  Used by the CPU test-suite to check the banded formulation

@@ -262,6 +262,36 @@ def test_energy_head_kernels():
             assert rel_err(gh.cpu(), ref_ops.energy_head_bwd(ge, h, w, mask)) < 2e-6
 
 
+def test_halo_rows_kernels():
+    """`hermnet_halo_rows` (pack / pack-and-clear / unpack / accumulate) vs the torch index ops of the host path."""
+    from hermnet_amd import nodeops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(9)
+    N, H = 50, 128
+    x, vec = torch.randn(N, H, generator=gen).to(dev), torch.randn(N, 3, H, generator=gen).to(dev)
+    idx = torch.tensor([3, 7, 7, 0, 49, 21, 3], device=dev)                     # repeats: one atom, several neighbours
+    uniq = torch.tensor([5, 1, 48, 30], device=dev)
+    ref = torch.cat([x[idx], vec[idx].reshape(-1, 3 * H)], 1)
+    assert torch.equal(nodeops.halo_rows(0, x, vec, idx), ref)
+    x1, v1 = x.clone(), vec.clone()
+    buf = nodeops.halo_rows(1, x1, v1, uniq)
+    assert torch.equal(buf, torch.cat([x[uniq], vec[uniq].reshape(-1, 3 * H)], 1))
+    assert float(x1[uniq].abs().max()) == 0 and float(v1[uniq].abs().max()) == 0
+    keep = torch.ones(N, dtype=torch.bool, device=dev)
+    keep[uniq] = False
+    assert torch.equal(x1[keep], x[keep]) and torch.equal(v1[keep], vec[keep])
+    new = torch.randn(4, 4 * H, generator=gen).to(dev)
+    x2, v2 = x.clone(), vec.clone()
+    nodeops.halo_rows(2, x2, v2, uniq, new)
+    assert torch.equal(x2[uniq], new[:, :H]) and torch.equal(v2[uniq], new[:, H:].reshape(-1, 3, H))
+    add = torch.randn(7, 4 * H, generator=gen).to(dev)
+    x3, v3 = x.clone(), vec.clone()
+    nodeops.halo_rows(3, x3, v3, idx, add)
+    xr = x.clone().index_add_(0, idx, add[:, :H])
+    vr = vec.clone().index_add_(0, idx, add[:, H:].reshape(-1, 3, H))
+    assert rel_err(x3, xr) < 1e-6 and rel_err(v3, vr) < 1e-6
+
+
 def test_bias_on_load_equals_bias_in_operand():
     """The stages that add a GEMM's bias on load (include/hermnet_hip.h "Bias convention"): kernel(h, bias)
     must equal kernel(h + expanded bias) for the node kernels and the message kernels (xh_bias)."""
