@@ -182,6 +182,45 @@ def test_other_widths_match_oracle(H, R, L, elems, make):
     assert rel_err(e.detach().cpu(), e_ref) < TOL and rel_err(f.cpu(), f_ref) < TOL
 
 
+def _batch_periodic(parts):
+    """Concatenate periodic single-cell `Data` objects into one batch (cell [B,3,3], per-graph `batch`)."""
+    off, pos, z, ei, sh, cell, b = 0, [], [], [], [], [], []
+    for g, d in enumerate(parts):
+        pos.append(d.pos); z.append(d.atomic_number); ei.append(d.edge_index + off); sh.append(d.edge_shift)
+        cell.append(d.cell.reshape(1, 3, 3)); b.append(torch.full((d.pos.size(0),), g, dtype=torch.long))
+        off += d.pos.size(0)
+    return hn.Data(pos=torch.cat(pos), atomic_number=torch.cat(z), edge_index=torch.cat(ei, 1), edge_shift=torch.cat(sh),
+                   cell=torch.cat(cell), batch=torch.cat(b))
+
+
+@pytest.mark.parametrize("intensive", [False, True])
+def test_batch_of_different_periodic_cells_matches_oracle(intensive):
+    """`edge_shift @ cell[batch[j]]` (hermnet.py:139) with a different cell per graph, per-graph read-out, and the
+    cell gradient (virial path) per graph."""
+    from oracle import hermnet_oracle as orc
+    dev = _dev()
+    data = _batch_periodic([synth.si_diamond(), synth.fcc_alloy(reps=(2, 2, 3), rc=5.0), synth.si_diamond(reps=(1, 1, 2), seed=3)])
+    elems = ["Si", "Al", "Ni", "Cu"]
+    kw = dict(rc=5.0, num_layers=3, hidden_channels=128, num_rbf=64, intensive=intensive)
+    model = hn.HVNet(elems, **kw).eval()
+    sd = synth.synth_state_dict(model.state_dict(), 21)
+    model.load_state_dict(sd)
+    e_ref, f_ref = orc.energy_and_forces(sd, elems, data, **kw)
+    # oracle's cell gradient (fp32 autograd on the CPU)
+    cell_r = data.cell.clone().requires_grad_(True)
+    e_c = orc.hvnet_energy(sd, elems, data.pos, data.atomic_number, data.edge_index, data.batch, data.edge_shift, cell_r, **kw)
+    gcell_ref = torch.autograd.grad(e_c.sum(), cell_r)[0]
+    model = model.to(dev)
+    d = data.to(dev)
+    d.pos.requires_grad_(True)
+    d.cell.requires_grad_(True)
+    e = model(d)
+    f, gcell = torch.autograd.grad(e.sum(), [d.pos, d.cell])
+    assert e.shape == (3,)
+    assert rel_err(e.detach().cpu(), e_ref) < TOL and rel_err(-f.cpu(), f_ref) < TOL
+    assert rel_err(gcell.cpu(), gcell_ref) < 5 * TOL
+
+
 def test_cpu_tensor_is_refused():
     g = Golden("c1_si64")
     model = g.model()
