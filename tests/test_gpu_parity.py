@@ -160,28 +160,6 @@ def test_config2_10k_atoms_matches_reference_golden():
     assert torch.equal(e, e2) and torch.equal(f, f2), "segmented sums must be deterministic"
 
 
-@pytest.mark.parametrize("H,R,L,elems,make", [
-    (512, 128, 5, ["Al", "Ni", "Cu"], lambda: synth.fcc_alloy(reps=(3, 3, 3))),     # the reference's default width
-    (512, 50, 2, ["Si"], lambda: synth.si_diamond()),                               # PyG's default 50 Gaussians
-    (192, 20, 3, ["H", "C", "O"], lambda: synth.molecule_batch(num_graphs=4))])     # 3 column blocks, short basis
-def test_other_widths_match_oracle(H, R, L, elems, make):
-    """Widths / basis sizes without a golden fixture: the HIP path vs the (pinned) oracle on the same inputs."""
-    from oracle import hermnet_oracle as orc
-    dev = _dev()
-    data = make()
-    kw = dict(rc=5.0, num_layers=L, hidden_channels=H, num_rbf=R)
-    model = hn.HVNet(elems, **kw).eval()
-    sd = synth.synth_state_dict(model.state_dict(), 3)
-    model.load_state_dict(sd)
-    e_ref, f_ref = orc.energy_and_forces(sd, elems, data, **kw)
-    model = model.to(dev)
-    d = data.to(dev)
-    d.pos.requires_grad_(True)
-    e = model(d)
-    f = -torch.autograd.grad(e.sum(), d.pos)[0]
-    assert rel_err(e.detach().cpu(), e_ref) < TOL and rel_err(f.cpu(), f_ref) < TOL
-
-
 def _batch_periodic(parts):
     """Concatenate periodic single-cell `Data` objects into one batch (cell [B,3,3], per-graph `batch`)."""
     off, pos, z, ei, sh, cell, b = 0, [], [], [], [], [], []
