@@ -62,6 +62,40 @@ __global__ __launch_bounds__(256) void edge_geometry_bwd_kernel(
   }
 }
 
+// Same sums with the out-edges taken from the CSC order of the relation build (edges by (relation(target),
+// row(source))): the out-adjacency of row a is the union of its T CSC segments, so no third edge order is needed.
+// Edges whose target has an unknown element are in no segment; they carry no message, hence no gradient.
+__global__ __launch_bounds__(256) void edge_geometry_bwd_csc_kernel(
+    const float4* __restrict__ gD, const int* __restrict__ in_rowptr, const int* __restrict__ csc_rowptr,
+    const int* __restrict__ csc_pos, int T, int N, float* __restrict__ gpos) {
+  const int a = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (a >= N) return;
+  const int lane = threadIdx.x & 63;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const int beg = csc_rowptr[(size_t)t * N + a], end = csc_rowptr[(size_t)t * N + a + 1];
+    for (int k = beg + lane; k < end; k += 64) {
+      const float4 g = gD[csc_pos[k]];
+      sx += g.x; sy += g.y; sz += g.z;
+    }
+  }
+  for (int k = in_rowptr[a] + lane; k < in_rowptr[a + 1]; k += 64) {
+    const float4 g = gD[k];
+    sx -= g.x; sy -= g.y; sz -= g.z;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    sx += __shfl_xor(sx, m, 64);
+    sy += __shfl_xor(sy, m, 64);
+    sz += __shfl_xor(sz, m, 64);
+  }
+  if (lane == 0) {
+    gpos[3 * a + 0] = sx;
+    gpos[3 * a + 1] = sy;
+    gpos[3 * a + 2] = sz;
+  }
+}
+
 }  // namespace
 
 extern "C" int hermnet_edge_geometry_fwd(const float* pos, const int* src_id, const int* tgt_id,
@@ -89,5 +123,17 @@ extern "C" int hermnet_edge_geometry_bwd(const float* gD, const int* in_rowptr, 
   hipLaunchKernelGGL(edge_geometry_bwd_kernel, dim3((num_nodes + 3) / 4), dim3(block), 0, s,
                      reinterpret_cast<const float4*>(gD), in_rowptr, in_edges, out_rowptr, out_edges,
                      num_nodes, gpos);
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}
+
+extern "C" int hermnet_edge_geometry_bwd_csc(const float* gD, const int* csr_rowptr, const int* csc_rowptr,
+                                             const int* csc_pos, int num_rel, int num_nodes, float* gpos,
+                                             void* stream) {
+  if (num_nodes < 0 || num_rel <= 0) return HN_ERR_BAD_ARG;
+  if (num_nodes == 0) return HN_OK;
+  if (!csr_rowptr || !csc_rowptr || !gpos) return HN_ERR_BAD_ARG;   // gD / csc_pos may be NULL for an edge-less graph
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(edge_geometry_bwd_csc_kernel, dim3((num_nodes + 3) / 4), dim3(256), 0, s,
+                     reinterpret_cast<const float4*>(gD), csr_rowptr, csc_rowptr, csc_pos, num_rel, num_nodes, gpos);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }

@@ -325,8 +325,10 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
     return HN_ERR_LAUNCH;
   if (E > 0)
     hipLaunchKernelGGL(csc_tgt2_kernel, grid_for(E), dim3(kBlock), 0, s, rt_csr, out->csc_pos, E, out->csc_tgt);
-  // out adjacency: CSR positions grouped by row(source)
-  if ((rcg = group_by_key(ikey3, E, N, out->out_rowptr, out->out_edges, gw, s)) != HN_OK) return rcg;
+  // out adjacency: CSR positions grouped by row(source) -- optional: hermnet_edge_geometry_bwd_csc reads the
+  // same information from the CSC order
+  if (out->out_rowptr != nullptr && out->out_edges != nullptr)
+    if ((rcg = group_by_key(ikey3, E, N, out->out_rowptr, out->out_edges, gw, s)) != HN_OK) return rcg;
   hipLaunchKernelGGL(row_active_kernel, grid_for(N), dim3(kBlock), 0, s, out->csc_rowptr, row_start, N, T,
                      rel_active, out->row_real, out->row_active);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;

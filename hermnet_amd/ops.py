@@ -109,9 +109,14 @@ class EdgeGeometry(torch.autograd.Function):
         lib = _lib.load()
         gD = gedge.float().contiguous()
         gpos_rows = torch.empty(graph.N, 3, dtype=torch.float32, device=gD.device)
-        _lib.check(lib.hermnet_edge_geometry_bwd(
-            _lib.ptr(gD), _lib.ptr(graph.csr_rowptr), None, _lib.ptr(graph.out_rowptr),
-            _lib.ptr(graph.out_edges), graph.N, _lib.ptr(gpos_rows), _stream()), "hermnet_edge_geometry_bwd")
+        if graph.out_rowptr is None:      # device-built graphs: out-edges from the CSC order (one sort fewer)
+            _lib.check(lib.hermnet_edge_geometry_bwd_csc(
+                _lib.ptr(gD), _lib.ptr(graph.csr_rowptr), _lib.ptr(graph.csc_rowptr), _lib.ptr(graph.csc_pos),
+                graph.T, graph.N, _lib.ptr(gpos_rows), _stream()), "hermnet_edge_geometry_bwd_csc")
+        else:
+            _lib.check(lib.hermnet_edge_geometry_bwd(
+                _lib.ptr(gD), _lib.ptr(graph.csr_rowptr), None, _lib.ptr(graph.out_rowptr),
+                _lib.ptr(graph.out_edges), graph.N, _lib.ptr(gpos_rows), _stream()), "hermnet_edge_geometry_bwd")
         gcell = None
         if ctx.needs_input_grad[1] and ctx.keep[1] is not None:
             # D = ... + shift @ cell[batch[src]]  =>  dE/dcell[b] = sum_{e in b} shift_e (x) gD_e

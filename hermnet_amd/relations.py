@@ -133,7 +133,8 @@ class RelationalGraph(object):
         g.row_active = torch.empty(N, dtype=torch.float32, device=dev)
         g.csr_rowptr, g.csr_src, g.csr_perm, g.src_id, g.tgt_id = e32(N + 1), e32(E), e32(E), e32(E), e32(E)
         g.csc_rowptr, g.csc_tgt, g.csc_pos = e32(T * N + 1), e32(E), e32(E)
-        g.out_rowptr, g.out_edges = e32(N + 1), e32(E)
+        # (no out-adjacency: the position gradient reads the out-edges from the CSC order, ops.EdgeGeometry)
+        g.out_rowptr = g.out_edges = None
         shift = None if edge_shift is None else edge_shift.float().contiguous()
         g.shift = None if shift is None else torch.empty(E, 3, dtype=torch.float32, device=dev)
         act = None if rel_active is None else _cached_u8(tuple(bool(a) for a in rel_active), dev)

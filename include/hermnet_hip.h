@@ -112,7 +112,7 @@ typedef struct hn_relations_out {
   int* csc_rowptr;    /* [T*N+1] */
   int* csc_tgt;       /* [E] */
   int* csc_pos;       /* [E] */
-  int* out_rowptr;    /* [N+1]   edges by source row (position gradient) */
+  int* out_rowptr;    /* [N+1]   edges by source row (position gradient); NULL (with out_edges) = not wanted */
   int* out_edges;     /* [E]     CSR positions */
 } hn_relations_out;
 
@@ -142,6 +142,12 @@ int hermnet_edge_geometry_fwd(const float* pos, const int* src_id, const int* tg
 int hermnet_edge_geometry_bwd(const float* gD, const int* in_rowptr, const int* in_edges,
                               const int* out_rowptr, const int* out_edges,
                               int num_nodes, float* gpos, void* stream);
+/* The same sums with the out-edges read from the CSC order (hn_graph: csc_rowptr [T*N+1], csc_pos [E]) instead of
+ * a separate out-adjacency: row a's out-edges are its T segments [csc_rowptr[t*N+a], csc_rowptr[t*N+a+1]).  Edges
+ * to targets of unknown element are in no segment (they carry no message, so no gradient).  With this entry
+ * point `hermnet_build_relations` may be called with out_rowptr = out_edges = NULL (one edge order fewer). */
+int hermnet_edge_geometry_bwd_csc(const float* gD, const int* csr_rowptr, const int* csc_rowptr, const int* csc_pos,
+                                  int num_rel, int num_nodes, float* gpos, void* stream);
 
 /* ---- A3+A7(rbf_proj)+A8+A9+A10 and the residual of A6 ---------------------------------------
  * Replaces, for ALL relations of one HeteroVertexConv layer at once,
