@@ -632,6 +632,17 @@ def test_edge_cases_empty_and_degenerate_graphs():
     _oracle_vs_hip(d, ["H", "C", "O"], kw, 34)
 
 
+def test_skewed_composition_uses_tight_layout_and_matches_oracle():
+    """4/6 Al, 1/6 Ni, 1/6 Cu: padding to equal blocks would cost > 15 %, so the rows are tight and the node GEMMs
+    run per relation (biases in the GEMM epilogue instead of on load) -- the other branch of hermnet_amd/layer.py."""
+    data = synth.fcc_alloy(reps=(3, 3, 3), species=(13, 13, 13, 13, 28, 29))
+    zl = [13, 28, 29]
+    g = RelationalGraph.build(data.atomic_number.to(_dev()), data.edge_index.to(_dev()), zl, data.edge_shift.to(_dev()),
+                              data.batch.to(_dev()))
+    assert not g.uniform
+    _oracle_vs_hip(data, ["Al", "Ni", "Cu"], dict(rc=5.0, num_layers=3, hidden_channels=128, num_rbf=64), 77)
+
+
 @pytest.mark.parametrize("H,R,layers", [(512, 128, 2), (64, 20, 3), (192, 50, 2)])
 def test_other_widths_vs_oracle(H, R, layers):
     """hidden_channels = 512 is the reference default (hermnet.py:86): 8 column blocks; odd num_rbf."""
