@@ -5,6 +5,7 @@
 Tolerance (BASELINE.json north_star): energies and forces within 1e-5 relative
 (forces relative to max|F|); neighbour indices bit-exact."""
 import math
+import os
 
 import numpy as np
 
@@ -630,6 +631,24 @@ def test_edge_cases_empty_and_degenerate_graphs():
     d = hn.Data(pos=pos, atomic_number=torch.cat([mol.atomic_number, torch.tensor([1])]),
                 batch=torch.zeros(n + 1, dtype=torch.long), edge_index=mol.edge_index)
     _oracle_vs_hip(d, ["H", "C", "O"], kw, 34)
+
+
+@pytest.mark.parametrize("env", [
+    {"HERMNET_BWD_SPLIT_T": "1"},                                                        # one relation per workgroup
+    {"HERMNET_FWD_VARIANT": "16221", "HERMNET_FWD_VARIANT_L0": "16201",                  # 16-wave, 2 channels per lane
+     "HERMNET_BWD_VARIANT": "16201", "HERMNET_BWD_VARIANT_L0": "16201"},
+    {"HERMNET_FWD_VARIANT": "8410", "HERMNET_FWD_VARIANT_L0": "8420",                    # full prefetch / no prefetch
+     "HERMNET_BWD_VARIANT": "8400", "HERMNET_BWD_VARIANT_L0": "8410", "HERMNET_BWD_ROWS": "24", "HERMNET_FWD_ROWS": "17"},
+])
+def test_alternative_kernel_variants(env):
+    """The non-default template instances of the message kernels (selected by environment, once per process) must
+    give the same energies and forces: three golden cases in a child process per setting."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "variant_check.py")], env=dict(os.environ, **env),
+                         capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0 and "VARIANT_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_skewed_composition_uses_tight_layout_and_matches_oracle():
