@@ -135,3 +135,46 @@ def test_sharded_hip_path_matches_reference_golden(name, world):
         assert rel_err(torch.from_numpy(e), g.energy) < 1e-5
         forces[owned] = f
     assert rel_err(torch.from_numpy(forces), g.forces) < 1e-5
+
+
+def _rccl_worker(rank, world, name, port, out):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # "nccl" = RCCL on ROCm
+    try:
+        from hermnet_amd.sharding import partition
+        g = Golden(name)
+        model = g.model().to(dev)
+        for p in model.parameters():
+            p.requires_grad_(False)
+        local, plan = partition(g.data(), rank, world)
+        local = local.to(dev)
+        local.pos.requires_grad_(True)
+        e = model(local)
+        f_local = -torch.autograd.grad(e.sum(), local.pos)[0]
+        dist.barrier()
+        out[rank] = (e.detach().cpu().numpy(), f_local[:plan.n_owned].cpu().numpy(), plan.owned_global.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_backend_single_rank_smoke():
+    """The production backend ("nccl" = RCCL) on the one GPU of the box: world size 1, so the exchanges are empty,
+    but every collective of the sharded path (variable-size all_to_all_single on device buffers, all_reduce,
+    barrier) goes through RCCL with the same calls a multi-GPU run makes."""
+    name = "alloy108"
+    port = 35500 + os.getpid() % 2000
+    out = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(1, name, port, out), nprocs=1, join=True)
+    g = Golden(name)
+    e, f, owned = out[0]
+    forces = np.zeros_like(g.forces.numpy())
+    forces[owned] = f
+    assert rel_err(torch.from_numpy(e), g.energy) < 1e-5
+    assert rel_err(torch.from_numpy(forces), g.forces) < 1e-5
