@@ -164,12 +164,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline step only (profiling runs)")
+    ap.add_argument("--shard-anyway", action="store_true",
+                    help="take the sharded (process-group) code path even with one rank: rehearsal of the RCCL calls "
+                         "on a single GPU (launch through torch.distributed.run --nproc-per-node 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal with several ranks sharing one GPU (exchange staged through the host)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    sharded = world > 1 or args.shard_anyway
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
@@ -177,7 +181,7 @@ def main():
     ndev = torch.cuda.device_count()
     dev = torch.device("cuda", local_rank % max(ndev, 1))
     torch.cuda.set_device(dev)
-    if world > 1:
+    if sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -202,7 +206,7 @@ def main():
     # (bit-identical to the host list, tests/test_gpu_parity.py) and is outside the timed region
     gdata = synth.fcc_alloy(reps=(10, 10, 25 * world), seed=0, device=dev)
     N_global, E_global = gdata.pos.size(0), gdata.edge_index.size(1)
-    if world > 1:
+    if sharded:
         from hermnet_amd.sharding import partition
         data, plan = partition(gdata.to("cpu"), rank, world)      # host-side planning
         halo = int(plan.halo_global.numel())
@@ -224,7 +228,7 @@ def main():
     timer = ops.KernelTimer()
     ops.set_kernel_timer(timer)
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -232,12 +236,12 @@ def main():
         e, f = step()
     t_host = time.perf_counter() - t0          # host time to enqueue the K steps (the GPU may still be running)
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -313,7 +317,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_kw, elems, seed)
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

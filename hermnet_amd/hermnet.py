@@ -173,7 +173,7 @@ class HVNet(nn.Module):
             if self.intensive:
                 energy = energy / max(graph.num_atoms, 1)
             return energy
-        per_atom_energy = e_rows[graph.row_of_node]                         # back in atom order
+        per_atom_energy = e_rows.index_select(0, graph.row_of_node)         # back in atom order
         batch = data.batch.long()
         if shard is not None:
             own = shard.owned_mask.to(per_atom_energy.dtype)

@@ -129,7 +129,7 @@ class EdgeGeometry(torch.autograd.Function):
                 b = graph.batch32.long()[graph.src_id.long()]
                 gcell = torch.zeros(nb, 3, 3, dtype=gD.dtype, device=gD.device).index_add_(0, b, outer)
             gcell = gcell.reshape(ctx.cell_shape)
-        return gpos_rows[graph.row_of_node], gcell, None
+        return gpos_rows.index_select(0, graph.row_of_node), gcell, None
 
 
 class TrueEdgeGradient(torch.autograd.Function):

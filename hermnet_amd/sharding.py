@@ -38,7 +38,8 @@ class ExchangePlan(object):
 
     def remap(self, index_map):
         """Same exchange expressed in another ordering (e.g. relation rows): idx -> index_map[idx]."""
-        return ExchangePlan(index_map[self.send_idx], self.send_counts, index_map[self.recv_idx],
+        return ExchangePlan(index_map.index_select(0, self.send_idx), self.send_counts,
+                            index_map.index_select(0, self.recv_idx),
                             self.recv_counts, self.group)
 
 
@@ -58,22 +59,24 @@ def _all_to_all_rows(buf, in_counts, out_counts, group):
 
 
 class HaloExchange(torch.autograd.Function):
-    """out = x with its halo entries replaced by the owners' current values (differentiable)."""
+    """out = x with its halo entries replaced by the owners' current values (differentiable).  Used for the
+    coordinates (once per step); index_select / index_copy_ / index_fill_ only: advanced-index assignment
+    (`x[idx] = v`) costs a host synchronisation per call."""
 
     @staticmethod
     def forward(ctx, x, plan):
         ctx.plan = plan
-        recv = _all_to_all_rows(x.detach()[plan.send_idx], plan.send_counts, plan.recv_counts, plan.group)
+        recv = _all_to_all_rows(x.detach().index_select(0, plan.send_idx), plan.send_counts, plan.recv_counts, plan.group)
         out = x.detach().clone()
-        out[plan.recv_idx] = recv
+        out.index_copy_(0, plan.recv_idx, recv)
         return out
 
     @staticmethod
     def backward(ctx, g):
         plan = ctx.plan
-        back = _all_to_all_rows(g[plan.recv_idx], plan.recv_counts, plan.send_counts, plan.group)
+        back = _all_to_all_rows(g.index_select(0, plan.recv_idx), plan.recv_counts, plan.send_counts, plan.group)
         gx = g.clone()
-        gx[plan.recv_idx] = 0            # the local halo values were overwritten in forward
+        gx.index_fill_(0, plan.recv_idx, 0)            # the local halo values were overwritten in forward
         gx.index_add_(0, plan.send_idx, back)
         return gx, None
 
