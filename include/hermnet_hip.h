@@ -13,7 +13,11 @@
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work
  *     on it (no host synchronisation, graph-capturable);
  *   - return value 0 = ok, non-zero = HN_ERR_* (host code raises RuntimeError);
- *   - float = IEEE fp32 (the reference is fp32-only), indices = int32.
+ *   - float = IEEE fp32 (the reference is fp32-only), indices = int32 (int64 where a parameter says so:
+ *     the caller's edge_index / atomic_number / halo index lists arrive as torch LongTensors).
+ *
+ * ABI version 2 (`hermnet_abi_version`): v2 added the bias-on-load arguments, LayerNorm, the energy head, the
+ * CSC position gradient and the halo packing; the Python side refuses a library of another version.
  *
  * Node order.  All node-level arrays are in "relation order": atoms sorted by
  * (relation index of their element, original id); atoms whose element is not in
