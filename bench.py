@@ -190,9 +190,15 @@ def main():
 
     import hermnet_amd as hn
     from hermnet_amd import synth, ops, _lib
-    from hermnet_amd.utils import enable_tuned_gemms
+    from hermnet_amd.utils import enable_tuned_gemms, freeze_gemm_tuning
     _lib.load()   # fail loudly if the HIP library is missing
-    tuned = os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is None and enable_tuned_gemms()
+    # GEMM solution choice: the recorded table covers the single-GPU shapes; a sharded rank has its own row counts,
+    # so TunableOp times the candidates of those shapes during the (untimed) warm-up steps and is frozen before
+    # the timed region.  Set PYTORCH_TUNABLEOP_ENABLED yourself to take over.
+    tuned = online_tuning = False
+    if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is None:
+        online_tuning = sharded and args.warmup > 0
+        tuned = enable_tuned_gemms(online=online_tuning)
 
     elems = ["Al", "Ni", "Cu"]
     model_kw = dict(rc=5.0, num_layers=5, hidden_channels=128, num_rbf=128)
@@ -225,6 +231,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if online_tuning:
+        freeze_gemm_tuning()
     timer = ops.KernelTimer()
     ops.set_kernel_timer(timer)
     torch.cuda.synchronize()
@@ -271,7 +279,7 @@ def main():
                                    "num_rbf=128 layers=5, E=%d directed edges, energy+forces per step"
                                    % (N_global, E_global),
                        "atoms_total": N_global, "atoms_owned_rank0": N - halo, "halo_atoms_rank0": halo,
-                       "edges_rank0": E, "tuned_gemm_table": bool(tuned),
+                       "edges_rank0": E, "tuned_gemm_table": bool(tuned), "gemm_tuning_in_warmup": bool(online_tuning),
                        "parallelism": "1 GPU" if world == 1 else
                        "atom-sharded x%d slabs, one-hop halo all-to-all per layer over %s" % (world, args.backend)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,

@@ -17,25 +17,35 @@ def prefer_rocblas():
         pass
 
 
-def enable_tuned_gemms(path=TUNED_GEMMS):
+def enable_tuned_gemms(path=TUNED_GEMMS, online=False):
     """Use the rocBLAS / hipBLASLt solutions recorded in `tuned/gemm_gfx950.csv` (PyTorch TunableOp, tuned on
-    MI355X for the node GEMM shapes of BASELINE config 2: `PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1
-    python bench.py`).  No tuning happens here; shapes that are not in the table, and tables recorded with other
-    library versions (the file carries validators), fall back to the libraries' defaults.  Returns True when the
-    table was accepted.  Same arithmetic (fp32 MFMA GEMMs), only the tile/solution choice changes."""
+    MI355X for the node GEMM shapes of BASELINE config 2).  Tables recorded with other library versions are
+    rejected by their validators; shapes that are not in the table fall back to rocBLAS's default choice --
+    unless `online=True`: then TunableOp also times the candidates of every NEW shape the first time it is seen
+    (a few seconds in total; meant for warm-up steps, e.g. the rank-local shapes of an atom-sharded run, where the
+    default choice is up to 2x slower on the skinny K = 128/256 GEMMs of this path).  Call `freeze_gemm_tuning()`
+    afterwards so that nothing is tuned inside a timed or production region.  Returns True when the table was
+    accepted.  Same arithmetic (fp32 MFMA GEMMs) either way: only the tile / solution choice changes."""
+    import tempfile
     import torch.cuda.tunable as tunable
     prefer_rocblas()
-    if not os.path.exists(path):
-        return False
     tunable.enable(True)
-    tunable.tuning_enable(False)
+    tunable.tuning_enable(bool(online))
+    ok = False
     try:
-        import tempfile
         # TunableOp writes its table back at exit: keep that out of the working directory
         tunable.set_filename(os.path.join(tempfile.gettempdir(), "hermnet_tunableop_%d.csv" % os.getpid()))
-        return bool(tunable.read_file(path))
+        ok = os.path.exists(path) and bool(tunable.read_file(path))
     except Exception:
-        return False
+        ok = False
+    return ok
+
+
+def freeze_gemm_tuning():
+    """Stop timing new GEMM shapes (keep using what is known): end of the warm-up."""
+    import torch.cuda.tunable as tunable
+    tunable.tuning_enable(False)
+
 
 _NKTV2P = {"metal": 1.6021765e6, "lj": 1.0, "si": 1.0, "cgs": 1.0, "micro": 1.0, "nano": 1.0,
            "real": 68568.415, "electron": 2.94210108e13}
