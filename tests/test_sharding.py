@@ -48,8 +48,8 @@ def _worker(rank, world, name, port, out):
         e = model(local)
         f_local = -torch.autograd.grad(e.sum(), local.pos)[0]
         # forces of owned atoms arrive complete at their owner; halo rows carry nothing
-        assert float(f_local[plan.n_owned:].abs().max()) == 0.0 if f_local.size(0) > plan.n_owned else True
-        out[rank] = (e.detach().numpy(), plan.owned_global.numpy(), f_local[:plan.n_owned].numpy(),
+        assert float(f_local[~plan.owned_mask].abs().max()) == 0.0 if f_local.size(0) > plan.n_owned else True
+        out[rank] = (e.detach().numpy(), plan.owned_global.numpy(), f_local[plan.owned_local].numpy(),
                      int(plan.halo_global.numel()))
     finally:
         dist.destroy_process_group()
@@ -87,12 +87,17 @@ def test_partition_plans_are_consistent():
         assert plan.atom_plan.recv_counts[r] == 0 and plan.atom_plan.send_counts[r] == 0
         for p in range(world):
             # what r sends to p is what p expects from r, in the same order
-            sent = plan.owned_global[plan.atom_plan.send_idx[sum(plan.atom_plan.send_counts[:p]):
-                                                          sum(plan.atom_plan.send_counts[:p + 1])]]
+            send_idx = plan.atom_plan.send_idx[sum(plan.atom_plan.send_counts[:p]):sum(plan.atom_plan.send_counts[:p + 1])]
+            assert bool(plan.owned_mask[send_idx].all())           # only owned atoms are sent
+            sent = plan.local_global[send_idx]
             q = parts[p][1]
             off = sum(q.atom_plan.recv_counts[:r])
-            want = q.halo_global[q.atom_plan.recv_idx[off:off + q.atom_plan.recv_counts[r]] - q.n_owned]
-            assert torch.equal(sent, want)
+            recv_idx = q.atom_plan.recv_idx[off:off + q.atom_plan.recv_counts[r]]
+            assert not bool(q.owned_mask[recv_idx].any())           # only halo atoms are received
+            assert torch.equal(sent, q.local_global[recv_idx])
+        # owned and halo atoms are interleaved in ascending global id
+        assert torch.equal(plan.local_global, torch.sort(plan.local_global).values)
+        assert torch.equal(plan.local_global[plan.owned_local], plan.owned_global)
 
 
 def _gpu_worker(rank, world, name, port, out):
@@ -114,7 +119,7 @@ def _gpu_worker(rank, world, name, port, out):
         e = model(local)
         f_local = -torch.autograd.grad(e.sum(), local.pos)[0]
         out[rank] = (e.detach().cpu().numpy(), plan.owned_global.cpu().numpy(),
-                     f_local[:plan.n_owned].cpu().numpy(), int(plan.halo_global.numel()))
+                     f_local[plan.owned_local].cpu().numpy(), int(plan.halo_global.numel()))
     finally:
         dist.destroy_process_group()
 
@@ -158,7 +163,7 @@ def _rccl_worker(rank, world, name, port, out):
         e = model(local)
         f_local = -torch.autograd.grad(e.sum(), local.pos)[0]
         dist.barrier()
-        out[rank] = (e.detach().cpu().numpy(), f_local[:plan.n_owned].cpu().numpy(), plan.owned_global.cpu().numpy())
+        out[rank] = (e.detach().cpu().numpy(), f_local[plan.owned_local].cpu().numpy(), plan.owned_global.cpu().numpy())
     finally:
         dist.destroy_process_group()
 
