@@ -83,10 +83,32 @@ def cpu_baseline(model_kw, elems, seed):
         if dt > 4.0:          # the next sample costs 4-16x (the in_subgraph loop is O(N*E)): stay within ~1 min
             break
     n, dt, reps = best
+    # the same sample through the oracle's vectorised mode (one mask per relation instead of the reference's
+    # O(N*E) in_subgraph loop): the GPU/CPU ratio is not meant to be inflated by that loop
+    t0 = time.time()
+    orc.energy_and_forces(sd, elems, synth.fcc_alloy(reps=reps), mode="vectorised", **kw)
+    dt_vec = time.time() - t0
     return {"value": n / dt, "unit": "atom-steps/s", "cores": cores, "kind": "port",
+            "vectorised_value": n / dt_vec,
             "sample": "oracle mode=faithful (reference op sequence incl. in_subgraph loop), one energy+forces "
                       "step on a %d-atom slice (fcc %dx%dx%d) of the same alloy/model: %.1f s on %d threads"
                       % (n, reps[0], reps[1], reps[2], dt, cores)}
+
+
+def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=10):
+    """Device copy bandwidth of this box (read + written bytes per second of a 1 GiB buffer copy), GB/s."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    s1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (s0.elapsed_time(s1) * 1e-3) / 1e9
 
 
 def other_configs_secondary(hn, synth, dev, model_kw, steps=5):
@@ -288,6 +310,10 @@ def main():
             "energy": float(e.detach()[0]),
         }
         if world == 1 and not args.no_secondary:
+            try:   # the box's own copy bandwidth next to the 8 TB/s the roofline is priced against
+                out["roofline"]["measured_copy_GBps"] = measured_copy_bandwidth(dev)
+            except Exception as ex:
+                out["roofline"]["measured_copy_GBps"] = None
             # secondary figure: the step INCLUDING the device-side neighbour search, i.e. what a
             # calculator does per MD step (the reference rebuilds the list on the host every step)
             from hermnet_amd.neighbor import neighbor_search
