@@ -245,6 +245,46 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     return x1, vec1
 
 
+def _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed):
+    """`relational_layer` for the uniform row layout with every per-relation Linear run as ONE batched GEMM over
+    the [T, block, .] view of the rows (stacked parameters; gradients flow back through the stacking).  Same
+    arithmetic as the per-relation loop, a third of the kernel launches: the differentiable path is launch-bound."""
+    T, N, H = len(mlist), x.size(0), x.size(1)
+    B, nk = graph.block, graph.type_rowptr_host[-1]
+    ml = [m.message_layer for m in mlist]
+    ul = [m.update_layer for m in mlist]
+    st = lambda ts: torch.stack(list(ts), 0)
+    # --- x_proj(LayerNorm(x)) of every relation for every row (rmnet.py:52)
+    n = F.layer_norm(x, (H,))
+    g, b = st(m.x_layernorm.weight for m in ml), st(m.x_layernorm.bias for m in ml)                 # [T,H]
+    w1, b1 = st(m.x_proj[0].weight for m in ml), st(m.x_proj[0].bias for m in ml)                   # [T,H,H], [T,H]
+    w2, b2 = st(m.x_proj[2].weight for m in ml), st(m.x_proj[2].bias for m in ml)                   # [T,3H,H], [T,3H]
+    xn = n.unsqueeze(0) * g[:, None, :] + b[:, None, :]                                              # [T,N,H]
+    h = torch.baddbmm(b1[:, None, :], xn, w1.transpose(1, 2))
+    xh = torch.baddbmm(b2[:, None, :], F.silu(h) * ml[0].x_proj[1].scale_factor, w2.transpose(1, 2))   # [T,N,3H]
+    x1, vec1 = message_scatter_generic(xh, vec, x, edge, edge_embed, [m.rbf_proj.weight for m in ml],
+                                       [m.rbf_proj.bias for m in ml], graph)
+    # --- PaiNNUpdate on the rows of each relation (rmnet.py:94-107), blocks of B rows
+    wv = st(u.vec_proj.weight for u in ul)                                                           # [T,2H,H]
+    wx0, bx0 = st(u.xvec_proj[0].weight for u in ul), st(u.xvec_proj[0].bias for u in ul)           # [T,H,2H], [T,H]
+    wx2, bx2 = st(u.xvec_proj[2].weight for u in ul), st(u.xvec_proj[2].bias for u in ul)           # [T,3H,H], [T,3H]
+    xt, vt = x1[:nk].view(T, B, H), vec1[:nk].view(T, B, 3, H)
+    vp = torch.bmm(vt.reshape(T, B * 3, H), wv.transpose(1, 2)).view(T, B, 3, 2 * H)
+    v1, v2 = vp[..., :H], vp[..., H:]
+    vdot = (v1 * v2).sum(dim=2) * ul[0].inv_sqrt_h
+    xin = torch.cat([xt, torch.sqrt((v2 ** 2).sum(dim=2) + 1e-8)], dim=-1)                           # [T,B,2H]
+    h2 = torch.baddbmm(bx0[:, None, :], xin, wx0.transpose(1, 2))
+    q = torch.baddbmm(bx2[:, None, :], F.silu(h2) * ul[0].xvec_proj[1].scale_factor, wx2.transpose(1, 2))
+    q1, q2, q3 = q[..., :H], q[..., H:2 * H], q[..., 2 * H:]
+    xo = xt + (q1 + q2 * vdot) * ul[0].inv_sqrt_2
+    vo = vt + q3.unsqueeze(2) * v1
+    x_out, v_out = xo.reshape(nk, H), vo.reshape(nk, 3, H)
+    if nk < N:   # atoms whose element is not in `elems`: zero rows (hermnet.py:51)
+        x_out = torch.cat([x_out, x.new_zeros(N - nk, H)], 0)
+        v_out = torch.cat([v_out, x.new_zeros(N - nk, 3, H)], 0)
+    return x_out * graph.row_active[:, None], v_out * graph.row_active[:, None, None]
+
+
 def relational_layer(mods, x, vec, edge, graph, rbf, edge_embed=None):
     """One HeteroVertexConv layer in relation (row) order: `hermnet.py:37-65`.
 
@@ -252,6 +292,8 @@ def relational_layer(mods, x, vec, edge, graph, rbf, edge_embed=None):
     """
     mlist = list(mods)
     H = x.size(1)
+    if edge_embed is not None and graph.uniform and graph.type_rowptr_host[-1] > 0:
+        return _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed)
     # xh_t for every row and relation (sources of relation t carry the TARGET type's projection, SURVEY A5 i)
     xh = torch.stack([m.message_layer.node_projection(x) for m in mlist], dim=0)
     wt = torch.stack([m.message_layer.rbf_proj.weight.detach().t() for m in mlist], dim=0).contiguous()
