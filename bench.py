@@ -219,7 +219,7 @@ def main():
     # the timed region.  Set PYTORCH_TUNABLEOP_ENABLED yourself to take over.
     tuned = online_tuning = False
     if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is None:
-        online_tuning = sharded and args.warmup > 0
+        online_tuning = sharded and args.warmup > 0 and os.environ.get("HERMNET_BENCH_ONLINE_TUNING", "1") != "0"
         tuned = enable_tuned_gemms(online=online_tuning)
 
     elems = ["Al", "Ni", "Cu"]
