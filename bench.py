@@ -221,6 +221,10 @@ def main():
     if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is None:
         online_tuning = sharded and args.warmup > 0 and os.environ.get("HERMNET_BENCH_ONLINE_TUNING", "1") != "0"
         tuned = enable_tuned_gemms(online=online_tuning)
+        if not tuned and not online_tuning and args.warmup > 0 and os.environ.get("HERMNET_BENCH_ONLINE_TUNING", "1") != "0":
+            # the recorded table was rejected (other library versions): time the candidates in the warm-up instead
+            online_tuning = True
+            enable_tuned_gemms(online=True)
 
     elems = ["Al", "Ni", "Cu"]
     model_kw = dict(rc=5.0, num_layers=5, hidden_channels=128, num_rbf=128)
