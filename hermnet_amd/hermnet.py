@@ -79,11 +79,23 @@ class HVNet(nn.Module):
             nn.Linear(hidden_channels // 2, 1),
         )
 
+    # eval() treats parameters as constants (energy / force evaluation).  Set True to take the differentiable
+    # device-op path in eval() as well (fine-tuning or gradient diagnostics with dropout-free eval semantics).
+    eval_param_grads = False
+
     @staticmethod
     def _require_device(pos):
         if not pos.is_cuda:
             raise RuntimeError("hermnet_amd.HVNet runs on MI355X only (data is on %s); there is no CPU fallback"
                                % pos.device)
+
+    def _require_fp32(self, pos):
+        """The kernels read raw pointers as float32 (the reference is fp32-only too: `torch.tensor(0.0)` at
+        hermnet.py:146 breaks `.double()`), so other dtypes are refused instead of being misread."""
+        wd = self.embed.weight.dtype
+        if wd != torch.float32 or pos.dtype != torch.float32:
+            raise TypeError("hermnet_amd.HVNet computes in float32: parameters are %s, data.pos is %s "
+                            "(call model.float() / pos.float())" % (wd, pos.dtype))
 
     @staticmethod
     def _edge_geometry_autograd(pos, cell, graph):
@@ -102,12 +114,15 @@ class HVNet(nn.Module):
     def forward(self, data):
         """Two execution modes behind the same signature, chosen like any PyTorch module chooses:
         `eval()` (calculators, MD, validation -- `calculator.py:73`, `lmp_calc.py:46`, `dist_train.py:109`):
-        the fused gfx950 kernels, first-order gradients w.r.t. pos / cell.  `train()` with grad mode on
+        the fused gfx950 kernels, first-order gradients w.r.t. pos / cell; ALL parameters are constants there
+        (no parameter receives a gradient; set `model.eval_param_grads = True` to get them in eval()).
+        `train()` with grad mode on
         (`dist_train.py:81-99`): every op is a differentiable device op, so `autograd.grad(E, pos,
         create_graph=True)` and `loss.backward()` give the gradients of all parameters."""
         pos = data.pos
         self._require_device(pos)
-        train = self.training and torch.is_grad_enabled()
+        self._require_fp32(pos)
+        train = (self.training or self.eval_param_grads) and torch.is_grad_enabled()
         if data.get("batch") is None:
             # the reference fails here (scatter(..., None), hermnet.py:130); a single graph is meant
             data.batch = torch.zeros(pos.size(0), dtype=torch.long, device=pos.device)
@@ -134,7 +149,9 @@ class HVNet(nn.Module):
         else:
             edge = EdgeGeometry.apply(pos, data.get("cell"), graph)      # with_edge, hermnet.py:133-152
 
-        x = self.embed(graph.z_rows)                                        # hermnet.py:123, row order (pads: Z=0)
+        # hermnet.py:123, row order (pads: Z=0).  eval(): every parameter is a constant, the embedding included
+        # (the fused layers produce no parameter gradients; a partial set would be worse than none)
+        x = self.embed(graph.z_rows) if train else torch.nn.functional.embedding(graph.z_rows, self.embed.weight.detach())
         vec = None                                                          # zeros, hermnet.py:124
         if not fused and not train:
             edge = TrueEdgeGradient.apply(edge)      # autograd's (rhat, d) gradients -> Cartesian for the kernel

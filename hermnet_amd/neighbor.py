@@ -178,6 +178,20 @@ def _neighbor_search_device(pos, rc, cell, reference_compat):
     return (edge_index, shift) if periodic else edge_index
 
 
+def _cap_neighbors(edge_index, cap):
+    """Keep at most `cap` in-edges per target (row 1), the ones with the lowest source index: the list is sorted
+    by (target, source), so an edge's rank inside its target's run is its position minus the run's start."""
+    E = edge_index.size(1)
+    if E == 0:
+        return edge_index
+    tgt = edge_index[1]
+    pos = torch.arange(E, device=tgt.device)
+    first = torch.ones(E, dtype=torch.bool, device=tgt.device)
+    first[1:] = tgt[1:] != tgt[:-1]
+    start = torch.cummax(torch.where(first, pos, torch.zeros_like(pos)), 0).values
+    return edge_index[:, (pos - start) < cap]
+
+
 def neighbor_search(pos, rc, cell=None, reference_compat=False):
     """Drop-in for `HermNet/data.py:14-24`.
 
@@ -185,7 +199,14 @@ def neighbor_search(pos, rc, cell=None, reference_compat=False):
     Returns `edge_index` (open system) or `(edge_index, edge_shift)` (periodic),
     int64 [2,E] / float32 [E,3], exactly the reference's return shapes.  GPU tensors are searched
     on the GPU and the result stays there; host tensors take the numpy cell list below.
+
+    `reference_compat=True` reproduces the reference pipeline's edge conventions instead of the true
+    minimum-image ones: periodic `edge_shift = +S` (`data.py:19-24`, see the module docstring) and, for open
+    systems, `radius_graph`'s default cap of 32 neighbours per atom (`data.py:16`; torch_cluster keeps an
+    implementation-defined subset -- its GPU kernel the 32 lowest source indices, which is what is kept here).
     """
+    if cell is None and reference_compat:
+        return _cap_neighbors(neighbor_search(pos, rc, None, False), 32)
     if pos.is_cuda:
         out = _neighbor_search_device(pos, rc, cell, reference_compat)
         if out is not None:

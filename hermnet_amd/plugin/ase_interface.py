@@ -46,20 +46,23 @@ def _species_tensors(elements, device):
     return hit[1], hit[2]
 
 
-def build_graph(cell, elements, pos, rc, device=None):
+def build_graph(cell, elements, pos, rc, device=None, reference_compat=False):
     """`calculator.py:10-27`: numpy (cell [3,3] or None, Z [N], pos [N,3]) -> `Data` with the cutoff graph.
     With `device` set to the GPU the coordinates are uploaded first and the neighbour search runs on the
-    device (`csrc/neighbor_kernels.hip`) instead of the host -- the reference rebuilds the list every step."""
+    device (`csrc/neighbor_kernels.hip`) instead of the host -- the reference rebuilds the list every step.
+    `reference_compat`: the edge conventions of the reference's own pipeline (`neighbor.neighbor_search`),
+    for checkpoints trained through it on periodic data."""
     pos_t = torch.from_numpy(np.asarray(pos)).float()
     if device is not None:
         pos_t = pos_t.to(device)
     z, batch = _species_tensors(elements, device)
     data = Data(atomic_number=z, pos=pos_t, batch=batch)
     if cell is None or not np.any(np.asarray(cell)):
-        data.edge_index = neighbor_search(pos=pos_t, rc=rc)
+        data.edge_index = neighbor_search(pos=pos_t, rc=rc, reference_compat=reference_compat)
     else:
         cell_t = torch.from_numpy(np.asarray(cell, dtype=np.float64).reshape(3, 3)).float().to(pos_t.device)
-        data.edge_index, data.edge_shift = neighbor_search(pos=pos_t, rc=rc, cell=cell_t)
+        data.edge_index, data.edge_shift = neighbor_search(pos=pos_t, rc=rc, cell=cell_t,
+                                                            reference_compat=reference_compat)
         data.cell = cell_t.reshape(1, 3, 3)
     return data
 
@@ -91,8 +94,9 @@ class NNCalculator(_Base):
     """`calculator.py:30-57`.  `model_path=None` keeps the weights already in `model`."""
     implemented_properties = ['energy', 'free_energy', 'forces', 'stress']
 
-    def __init__(self, model, model_path, trn_mean, device_='cuda', ensemble='NVT'):
+    def __init__(self, model, model_path, trn_mean, device_='cuda', ensemble='NVT', reference_compat=False):
         super(NNCalculator, self).__init__()
+        self.reference_compat = reference_compat     # see `build_graph`
         self.device_ = device_
         device = torch.device(device_)
         self.model = model.to(device)
@@ -109,7 +113,8 @@ class NNCalculator(_Base):
         cell = np.asarray(atoms.cell if not hasattr(atoms, "todict") else atoms.todict()['cell']) if pbc else None
         elems = np.array([atomic_numbers[s] for s in atoms.get_chemical_symbols()])
         dev = self.device_ if torch.device(self.device_).type == 'cuda' else None
-        data = build_graph(cell=cell, elements=elems, pos=atoms.positions, rc=self.model.rc, device=dev)
+        data = build_graph(cell=cell, elements=elems, pos=atoms.positions, rc=self.model.rc, device=dev,
+                           reference_compat=self.reference_compat)
         energy, forces, virial = self.model_calc(data=data, device=self.device_, pbc=pbc, ensemble=self.ensemble)
         self.results['energy'] = energy
         self.results['free_energy'] = energy

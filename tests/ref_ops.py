@@ -209,7 +209,8 @@ class RefEdgeGeometry(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pos, cell, graph):
         ctx.graph = graph
-        return geometry_ref(pos.detach(), graph, cell)
+        ctx.cell_shape = None if cell is None else tuple(cell.shape)
+        return geometry_ref(pos.detach(), graph, None if cell is None else cell.detach())
 
     @staticmethod
     def backward(ctx, gedge):
@@ -217,4 +218,13 @@ class RefEdgeGeometry(torch.autograd.Function):
         gp = torch.zeros(g.num_atoms, 3, dtype=gedge.dtype)
         gp.index_add_(0, g.src_id.long(), gedge[:, :3])
         gp.index_add_(0, g.tgt_id.long(), -gedge[:, :3])
-        return gp, None, None
+        gcell = None
+        if ctx.needs_input_grad[1] and g.shift is not None and ctx.cell_shape is not None:
+            # D = ... + shift @ cell[batch[src]]  =>  dE/dcell[b] = sum_e shift_e (x) gD_e   (ops.EdgeGeometry)
+            outer = g.shift.to(gedge.dtype)[:, :, None] * gedge[:, None, :3]
+            nb = 1
+            for v in ctx.cell_shape[:-2]:
+                nb *= v
+            b = g.batch32.long()[g.src_id.long()]
+            gcell = torch.zeros(nb, 3, 3, dtype=gedge.dtype).index_add_(0, b, outer).reshape(ctx.cell_shape)
+        return gp, gcell, None

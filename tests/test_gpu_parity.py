@@ -675,3 +675,12 @@ def test_unsupported_width_is_refused_loudly():
     model = hn.HVNet(["Al", "Ni", "Cu"], num_layers=1, hidden_channels=96, num_rbf=16).to(dev).eval()
     with pytest.raises(RuntimeError, match="HN_ERR_BAD_ARG"):
         model(data)             # the fused kernels need H % 64 == 0 (train() mode has no such limit)
+
+
+def test_double_or_half_model_is_refused_on_the_gpu():
+    """`model.double()` must not hand fp64 pointers to fp32 kernels."""
+    g = Golden("alloy108")
+    d = g.data().to(_dev())
+    for cast in ("double", "half"):
+        with pytest.raises(TypeError, match="float32"):
+            getattr(g.model().to(_dev()), cast)()(d)

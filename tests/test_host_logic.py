@@ -219,8 +219,19 @@ def test_fused_layer_orchestration_matches_golden(name, monkeypatch):
 
 def test_lammps_plugin_helpers():
     from hermnet_amd.plugin import lmp_interface as L
-    a = L.parse_args(["-m", "zmq", "-p", "tcp://x", "-f", "m.pt", "-t", "Al", "Ni", "Cu", "-e", "NPT"])
-    assert a.elems == ["Al", "Ni", "Cu"] and a.rc == 5.0 and a.device == "cuda" and a.units == "metal"
+    # the reference's own command line (lmp_calc.py:89-127): long names --stats / --radius, -m / -p optional
+    a = L.parse_args(["-f", "m.pt", "--stats", "-3.5", "--radius", "5.0", "--periodic", "True",
+                      "-t", "Al", "Ni", "Cu", "-e", "NPT"])
+    assert a.elems == ["Al", "Ni", "Cu"] and a.radius == 5.0 and a.stats == -3.5 and a.units == "metal"
+    assert a.mode == "zmq" and a.ptr == "tmp.couple" and a.device == "cuda" and not a.reference_compat
+    b = L.parse_args(["-f", "m.pt", "--mean", "1", "--rc", "4", "-c", "False", "-t", "Si", "--reference-compat"])
+    assert b.stats == 1.0 and b.radius == 4.0 and b.periodic == "False" and b.reference_compat
+    for missing in (["-s", "0", "-r", "5", "-c", "True", "-t", "Si"],            # no -f
+                    ["-f", "m", "-r", "5", "-c", "True", "-t", "Si"],            # no -s
+                    ["-f", "m", "-s", "0", "-c", "True", "-t", "Si"],            # no -r
+                    ["-f", "m", "-s", "0", "-r", "5", "-t", "Si"]):              # no -c
+        with pytest.raises(SystemExit):
+            L.parse_args(missing)
     assert list(L.lammps_types_to_numbers([1, 3, 2, 1], a.elems)) == [13, 29, 28, 13]
     assert (L.SETUP, L.STEP, L.FORCES, L.ENERGY, L.VIRIAL) == (1, 2, 1, 2, 3)
 
@@ -251,3 +262,52 @@ def test_virial_units():
     assert torch.allclose(v[0, 0], torch.tensor(-0.5 * 1.6021765e6)) and torch.allclose(v, v.T)
     with pytest.raises(ValueError):
         virial_calc(None, pos, f, None, units="bogus")
+
+
+def test_non_fp32_model_or_positions_are_refused(monkeypatch):
+    """The kernels read raw pointers as float32: model.double() / .half() or fp64 coordinates must raise
+    instead of producing garbage (the reference is fp32-only as well, hermnet.py:146)."""
+    import hermnet_amd.hermnet as hmod
+    monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
+    g = Golden("alloy108")
+    d = g.data()
+    for cast in ("double", "half"):
+        with pytest.raises(TypeError, match="float32"):
+            getattr(g.model(), cast)()(d)
+    d64 = g.data()
+    d64.pos = d64.pos.double()
+    with pytest.raises(TypeError, match="float32"):
+        g.model()(d64)
+
+
+def test_eval_mode_parameters_are_constants_unless_asked(monkeypatch):
+    """eval(): no parameter receives a gradient (not even the embedding: a partial set would mislead);
+    `eval_param_grads = True` routes eval() through the differentiable path, which gives all of them."""
+    import hermnet_amd.hermnet as hmod
+    import hermnet_amd.layer as lmod
+    import hermnet_amd.rmnet as rmod
+    monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
+    monkeypatch.setattr(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
+    for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid",
+               "update_out", "update_out_bwd", "update_mid_bwd"]:
+        monkeypatch.setattr(lmod.nodeops, fn, getattr(ref_ops, fn))
+    monkeypatch.setattr(lmod, "_msg_fwd", ref_ops.msg_fwd)
+    monkeypatch.setattr(lmod, "_msg_bwd", ref_ops.msg_bwd)
+    g = Golden("alloy108")
+    model = g.model()                      # eval(), parameters require grad (the nn.Module default)
+    d = g.data()
+    d.pos.requires_grad_(True)
+    e = model(d)
+    f = -torch.autograd.grad(e.sum(), d.pos, retain_graph=True)[0]
+    assert rel_err(f, g.forces) < 1e-5
+    grads = torch.autograd.grad(e.sum(), list(model.parameters()), allow_unused=True)
+    assert all(gr is None for gr in grads)
+    # opt in: same energy, every parameter that takes part gets a gradient
+    monkeypatch.setattr(rmod, "message_scatter_generic", rmod.message_scatter_generic)
+    model.eval_param_grads = True
+    d2 = g.data()
+    d2.pos.requires_grad_(True)
+    e2 = model(d2)
+    assert rel_err(e2.detach(), g.energy) < 2e-6
+    grads = torch.autograd.grad(e2.sum(), list(model.parameters()), allow_unused=True)
+    assert sum(gr is not None for gr in grads) >= len(grads) - 4     # (unused: e.g. the last layer's update of vec)
