@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
-"""Headline benchmark: atom-steps/sec (energy + forces) of HVNet on BASELINE.json configs[1]
-(10k-atom 3-element fcc alloy, rc=5 A, hidden=128, num_rbf=128, 5 layers), fp32, synthetic data,
-random-init (seeded) weights.
+"""Headline benchmark: atom-steps/sec (energy + forces) of HVNet, fp32, synthetic data, random-init (seeded)
+weights; model of BASELINE.json configs[1]: rc=5 A, hidden=128, num_rbf=128, 5 layers, 3 elements.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config auto|c2|c4|weak] [--no-cpu-baseline]
 
-A "step" = HVNet.forward(data) + autograd.grad(E, pos) on a prebuilt `Data` (neighbour list
-excluded); the relation-ordered graph build (the replacement of
-the reference's per-layer `in_subgraph`) IS inside the step.  Inputs are resident in HBM before
-the timed region.  N > 1: one process per GPU (torchrun); ONE periodic cell of N x 10k atoms
-(fcc 10 x 10 x 25N) is sharded by atom into N slabs, each rank owns ~10k atoms plus its one-hop
-halo; per layer one RCCL all-to-all moves the halo rows (hermnet_amd/sharding.py), the energy is
-one scalar all-reduce.  Per-GPU work is fixed, so scaling is "weak".
+A "step" = HVNet.forward(data) + autograd.grad(E, pos) on a prebuilt `Data` (neighbour list excluded, as in
+SURVEY.md section 8(d)); the relation-ordered graph build (the replacement of the reference's per-layer
+`in_subgraph`) IS inside the step.  Inputs are resident in HBM before the timed region.
+
+Workloads (`--config`; `auto` = c2 on one GPU, c4 on several):
+  c2    BASELINE configs[1]: the 10,000-atom fcc alloy cell (10 x 10 x 25), the configuration the metric is quoted on.
+  c4    BASELINE configs[3]: the FIXED 100,000-atom cell (fcc 10 x 10 x 250, 36 x 36 x 900 A), sharded by atom into N
+        slabs with a one-hop halo: STRONG scaling (total work fixed).  On one GPU: the same cell unsharded.
+  weak  one cell of N x 10k atoms (fcc 10 x 10 x 25N), ~10k owned atoms per rank: weak scaling (round 1's mode).
+N > 1: one process per GPU (torchrun).  Every rank plans its slab on the device from the coordinates alone
+(`sharding.partition_slab`: owners, geometric halo, neighbour search over owned + halo atoms only); per layer one
+RCCL all-to-all moves the halo rows, the energy is one scalar all-reduce.
 
 Prints ONE JSON line on rank 0.
 """
@@ -21,13 +25,18 @@ import os
 import sys
 import time
 
+# read by the HSA runtime when it initialises (first HIP call): must be in the environment before that
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (the guide measured 6.29 TB/s for a float4 copy;
+                           # this pool's boxes measure ~5.2 TB/s: `roofline.measured_copy_GBps`)
+FP32_MFMA_PEAK_TF = 155.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, measured (157.3 spec)
 
 
 def algorithmic_bytes(E, N, H, T):
@@ -111,14 +120,16 @@ def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=10):
     return 2.0 * nbytes * reps / (s0.elapsed_time(s1) * 1e-3) / 1e9
 
 
-def other_configs_secondary(hn, synth, dev, model_kw, steps=5):
+def other_configs_secondary(hn, synth, dev, model_kw, steps=5, skip_c4=False):
     """configs[3] on ONE GPU (100k-atom cell, no sharding) and configs[4] (1024-molecule batch): energy + forces
     per step incl. the relation build, neighbour list prebuilt -- the same step definition as the headline."""
     res = {}
     cases = [("configs[3] 100k-atom 3-element cell on 1 GPU", ["Al", "Ni", "Cu"],
-              lambda: synth.fcc_alloy(reps=(25, 25, 40), seed=0, device=dev)),
+              lambda: synth.fcc_alloy(reps=(10, 10, 250), seed=0, device=dev)),
              ("configs[4] 1024-molecule batch", ["H", "C", "O"], lambda: synth.molecule_batch(num_graphs=1024).to(dev))]
     for name, elems, make in cases:
+        if skip_c4 and name.startswith("configs[3]"):
+            continue
         d = make()
         model = hn.HVNet(elems, **model_kw).eval()
         model.load_state_dict(synth.synth_state_dict(model.state_dict(), 10))
@@ -179,11 +190,23 @@ def training_secondary(hn, synth, dev, model_kw, num_graphs=1024, steps=3):
             "loss": float(loss)}
 
 
+def gemm_flops_per_step(N, nk, H, T, layers):
+    """FLOPs of the dense feature-mixing linears of one energy+forces step (forward + hand-written backward; every
+    GEMM has one backward GEMM of the same size w.r.t. its input: parameters are constants):
+      pre-message (rmnet.py:52) on all N rows:  LN -> [H -> T*H] -> SSiLU -> per relation [H -> 3H]
+      update (rmnet.py:94-107) on the nk target rows:  vec_proj 3 x [H -> 2H], [2H -> H], [H -> 3H]."""
+    pre = 2 * N * H * (T * H) + 2 * T * N * H * 3 * H
+    upd = 2 * 3 * nk * H * 2 * H + 2 * nk * 2 * H * H + 2 * nk * H * 3 * H
+    return 2 * layers * (pre + upd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c4", "weak"],
+                    help="workload (see the module docstring); auto = c2 on one GPU, c4 (strong scaling) on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline step only (profiling runs)")
     ap.add_argument("--shard-anyway", action="store_true",
@@ -200,16 +223,17 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
                          % (args.gpus, args.gpus))
+    cfg = args.config if args.config != "auto" else ("c4" if world > 1 else "c2")
     ndev = torch.cuda.device_count()
     dev = torch.device("cuda", local_rank % max(ndev, 1))
     torch.cuda.set_device(dev)
     if sharded:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
 
+    import numpy as np
     import hermnet_amd as hn
     from hermnet_amd import synth, ops, _lib
     from hermnet_amd.utils import enable_tuned_gemms, freeze_gemm_tuning
@@ -219,9 +243,10 @@ def main():
     # the timed region.  Set PYTORCH_TUNABLEOP_ENABLED yourself to take over.
     tuned = online_tuning = False
     if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is None:
-        online_tuning = sharded and args.warmup > 0 and os.environ.get("HERMNET_BENCH_ONLINE_TUNING", "1") != "0"
+        want_online = args.warmup > 0 and os.environ.get("HERMNET_BENCH_ONLINE_TUNING", "1") != "0"
+        online_tuning = (sharded or cfg != "c2") and want_online
         tuned = enable_tuned_gemms(online=online_tuning)
-        if not tuned and not online_tuning and args.warmup > 0 and os.environ.get("HERMNET_BENCH_ONLINE_TUNING", "1") != "0":
+        if not tuned and not online_tuning and want_online:
             # the recorded table was rejected (other library versions): time the candidates in the warm-up instead
             online_tuning = True
             enable_tuned_gemms(online=True)
@@ -234,26 +259,56 @@ def main():
     model = model.to(dev)
     for p_ in model.parameters():      # energy/force evaluation: no parameter gradients
         p_.requires_grad_(False)
-    # every rank builds the same global cell; its neighbour list comes from the device cell list
-    # (bit-identical to the host list, tests/test_gpu_parity.py) and is outside the timed region
-    gdata = synth.fcc_alloy(reps=(10, 10, 25 * world), seed=0, device=dev)
-    N_global, E_global = gdata.pos.size(0), gdata.edge_index.size(1)
+    reps = {"c2": (10, 10, 25), "c4": (10, 10, 250), "weak": (10, 10, 25 * world)}[cfg]
+    scaling = "weak" if cfg == "weak" else "strong"
     if sharded:
-        from hermnet_amd.sharding import partition
-        data, plan = partition(gdata.to("cpu"), rank, world)      # host-side planning
+        # every rank holds the global coordinates (what a calculator is handed per MD step) and plans ITS slab on the
+        # device: owners, geometric halo, neighbour search over owned + halo atoms only (outside the timed region,
+        # like the neighbour list of the single-GPU headline; timed separately below)
+        from hermnet_amd.sharding import partition_slab
+        pos_np, cell_np, z_np = synth.fcc_alloy_atoms(reps=reps, seed=0)
+        gpos = torch.from_numpy(pos_np.astype(np.float32)).to(dev)
+        gcell = torch.from_numpy(cell_np.astype(np.float32)).to(dev)
+        gz = torch.from_numpy(z_np).to(dev)
+        group = dist.group.WORLD
+
+        def plan_shard():
+            return partition_slab(gpos, gz, gcell, model_kw["rc"], rank, world, group=group)
+
+        data, plan = plan_shard()
         halo = int(plan.halo_global.numel())
-        data = data.to(dev)
+        N_global = int(gpos.size(0))
+        e_cnt = torch.tensor([data.edge_index.size(1)], dtype=torch.float64,
+                             device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(e_cnt)
+        E_global = int(e_cnt.item())
     else:
-        data, halo = gdata, 0
-    del gdata
+        # the neighbour list comes from the device cell list (bit-identical to the host list,
+        # tests/test_gpu_parity.py) and is outside the timed region
+        data, halo = synth.fcc_alloy(reps=reps, seed=0, device=dev), 0
+        N_global, E_global = data.pos.size(0), data.edge_index.size(1)
     N, E = data.pos.size(0), data.edge_index.size(1)                # local: owned + halo atoms, edges by owned target
     H, T = model_kw["hidden_channels"], len(elems)
 
-    def step():
-        data.pos.requires_grad_(True)
-        e = model(data)
-        f = -torch.autograd.grad(e.sum(), data.pos)[0]
+    def step(d=None):
+        d = data if d is None else d
+        d.pos.requires_grad_(True)
+        e = model(d)
+        f = -torch.autograd.grad(e.sum(), d.pos)[0]
         return e, f
+
+    def fence():
+        torch.cuda.synchronize()
+        if sharded:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(v):
+        if not sharded:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         step()
@@ -261,24 +316,52 @@ def main():
         freeze_gemm_tuning()
     timer = ops.KernelTimer()
     ops.set_kernel_timer(timer)
-    torch.cuda.synchronize()
-    if sharded:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         e, f = step()
     t_host = time.perf_counter() - t0          # host time to enqueue the K steps (the GPU may still be running)
-    torch.cuda.synchronize()
-    if sharded:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
-    if sharded:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt)
+
+    # ---- after the timed region: the dense linears, timed with HIP events in a short pass of their own (an event
+    # pair costs ~15 us of host time; ~50 of them per step inside the timed region would distort a ~3 ms step)
+    gtimer = ops.KernelTimer(prefix=("gemm", "node_"))
+    ops.set_kernel_timer(gtimer)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ops.set_kernel_timer(None)
+
+    # ---- secondary, all ranks: the step INCLUDING planning (sharded: slab plan + slab-local neighbour search;
+    # single GPU: the device neighbour search), i.e. what one MD step costs end to end
+    md = None
+    if not args.no_secondary:
+        from hermnet_amd.neighbor import neighbor_search
+        if sharded:
+            def md_step():
+                d, _ = plan_shard()
+                return step(d)
+        else:
+            pos0, cell0 = data.pos.detach(), data.cell
+
+            def md_step():
+                ei, sh = neighbor_search(pos0, model_kw["rc"], cell0)
+                d = hn.Data(pos=pos0.clone(), atomic_number=data.atomic_number, batch=data.batch,
+                            cell=cell0, edge_index=ei, edge_shift=sh)
+                return step(d)
+
+        for _ in range(2):
+            md_step()
+        fence()
+        t1 = time.perf_counter()
+        nmd = max(3, min(args.steps, 10))
+        for _ in range(nmd):
+            md_step()
+        fence()
+        md = max_over_ranks(time.perf_counter() - t1) / nmd
 
     if rank == 0:
         ksum = timer.summary()            # name -> (launches, mean ms), HIP events on the launch stream
@@ -287,62 +370,86 @@ def main():
         for name, (cnt, ms) in ksum.items():
             kernels[name] = {"launches_per_step": cnt / args.steps, "avg_ms": ms}
             if name in ab:
-                kernels[name].update({"algorithmic_GB": ab[name] / 1e9, "GBps": ab[name] / 1e9 / (ms / 1e3)})
+                kernels[name].update({"algorithmic_GB": ab[name] / 1e9, "GBps": ab[name] / 1e9 / (ms / 1e3),
+                                      "hbm_frac": ab[name] / 1e9 / (ms / 1e3) / HBM_PEAK_GBS})
         # dominant kernel = largest share of the step
         dom = max(ab, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"] if k in kernels else 0.0)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(dom)
+        # what actually limits each message kernel (profiles/README.md): the backward kernels issue
+        # VALU work (banded 12-tap contraction) for longer than their HBM time; the forward kernels' gathers are served
+        # from L2 / Infinity Cache faster than HBM could deliver the same bytes
+        limiter = {"message_scatter_fwd": "l2/infinity-cache gather", "message_scatter_fwd_l0": "l2/infinity-cache gather",
+                   "message_scatter_bwd": "valu-issue", "message_scatter_bwd_l0": "valu-issue"}
+        for k in kernels:
+            if k in limiter:
+                kernels[k]["limiter"] = limiter[k]
+        gsum = gtimer.summary()
+        gemm_ms = sum(cnt * ms for _, (cnt, ms) in gsum.items()) / 3.0          # per step
+        nk = N if not sharded else N
+        gflop = gemm_flops_per_step(N, nk, H, T, model_kw["num_layers"]) / 1e9
+        mfma = {"what": "dense feature-mixing linears (node MLPs) of one step, forward + backward",
+                "gflop_per_step": gflop, "ms_per_step": gemm_ms, "launches_per_step": sum(c for c, _ in gsum.values()) / 3.0,
+                "achieved_TFLOPs": (gflop / gemm_ms) if gemm_ms > 0 else None, "peak_TFLOPs_fp32_mfma": FP32_MFMA_PEAK_TF,
+                "mfma_util": (gflop / gemm_ms / FP32_MFMA_PEAK_TF) if gemm_ms > 0 else None}
+        names = {"c2": "configs[1]: %d-atom 3-element fcc alloy (Al/Ni/Cu)",
+                 "c4": "configs[3]: FIXED %d-atom 3-element fcc alloy cell (10x10x250, 36x36x900 A)",
+                 "weak": "weak-scaling variant: %d-atom 3-element fcc alloy cell (10x10x25N)"}
         out = {
             "metric": "atom-steps/sec (energy+forces) on 10k-atom 3-element cell; HBM GB/s vs roofline",
             "value": N_global * args.steps / dt, "unit": "atom-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak",
+            "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d-atom 3-element fcc alloy (Al/Ni/Cu), HVNet rc=5.0 hidden=128 "
-                                   "num_rbf=128 layers=5, E=%d directed edges, energy+forces per step"
-                                   % (N_global, E_global),
-                       "atoms_total": N_global, "atoms_owned_rank0": N - halo, "halo_atoms_rank0": halo,
+            "config": {"workload": (names[cfg] % N_global) + ", HVNet rc=5.0 hidden=128 num_rbf=128 layers=5, E=%d "
+                                   "directed edges, energy+forces per step" % E_global,
+                       "config": cfg, "atoms_total": N_global, "atoms_owned_rank0": N - halo, "halo_atoms_rank0": halo,
                        "edges_rank0": E, "tuned_gemm_table": bool(tuned), "gemm_tuning_in_warmup": bool(online_tuning),
                        "parallelism": "1 GPU" if world == 1 else
-                       "atom-sharded x%d slabs, one-hop halo all-to-all per layer over %s" % (world, args.backend)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic},
+                       "atom-sharded x%d slabs (slab-local planning), one-hop halo all-to-all per layer over %s"
+                       % (world, args.backend)},
+            "roofline": {"bound": limiter[dom], "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "achieved/peak/frac are ALGORITHMIC HBM bytes per launch / HIP-event time vs the 8 TB/s "
+                                 "HBM peak; `bound` names what limits the kernel in practice"},
+            "mfma": mfma,
             "kernels": kernels,
             "energy": float(e.detach()[0]),
         }
-        if world == 1 and not args.no_secondary:
+        if md is not None:
+            out["secondary"] = {"atom_steps_per_s_incl_planning": N_global / md, "ms_per_step_incl_planning": md * 1e3,
+                                "note": ("slab plan + slab-local device neighbour search + relation build + energy + "
+                                         "forces per step, max over ranks") if sharded else
+                                        "device cell-list neighbour search + relation build + energy + forces per step"}
+        if sharded and not args.no_secondary and cfg != "weak":
+            # the strong-scaling baseline inside the same run: the same cell, unsharded, on rank 0's GPU
+            try:
+                d1 = synth.fcc_alloy(reps=reps, seed=0, device=dev)
+                for _ in range(2):
+                    step(d1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    step(d1)
+                torch.cuda.synchronize()
+                one = (time.perf_counter() - t1) / 5
+                out["secondary"]["single_gpu_same_cell"] = {"ms_per_step": one * 1e3, "atom_steps_per_s": N_global / one}
+                out["secondary"]["speedup_vs_single_gpu"] = one / (dt / args.steps)
+                del d1
+            except Exception as ex:
+                out["secondary"]["single_gpu_same_cell"] = {"error": repr(ex)}
+        if world == 1 and not sharded and not args.no_secondary:
             try:   # the box's own copy bandwidth next to the 8 TB/s the roofline is priced against
                 out["roofline"]["measured_copy_GBps"] = measured_copy_bandwidth(dev)
             except Exception as ex:
                 out["roofline"]["measured_copy_GBps"] = None
-            # secondary figure: the step INCLUDING the device-side neighbour search, i.e. what a
-            # calculator does per MD step (the reference rebuilds the list on the host every step)
-            from hermnet_amd.neighbor import neighbor_search
-            pos0, cell0 = data.pos.detach(), data.cell
-
-            def md_step():
-                ei, sh = neighbor_search(pos0, model_kw["rc"], cell0)
-                d = hn.Data(pos=pos0.clone().requires_grad_(True), atomic_number=data.atomic_number, batch=data.batch,
-                            cell=cell0, edge_index=ei, edge_shift=sh)
-                en = model(d)
-                return en, -torch.autograd.grad(en.sum(), d.pos)[0]
-
-            for _ in range(2):
-                md_step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            nmd = max(3, min(args.steps, 10))
-            for _ in range(nmd):
-                md_step()
-            torch.cuda.synchronize()
-            out["secondary"] = {"atom_steps_per_s_incl_neighbor_search": N * nmd / (time.perf_counter() - t1),
-                                "note": "device cell-list neighbour search + relation build + energy + forces per step"}
             # secondary figures: the other single-GPU configurations of BASELINE.json at full size, same model
             try:
-                out["secondary"]["other_configs"] = other_configs_secondary(hn, synth, dev, model_kw)
+                out["secondary"]["other_configs"] = other_configs_secondary(hn, synth, dev, model_kw,
+                                                                            skip_c4=(cfg == "c4"))
             except Exception as ex:
                 out["secondary"]["other_configs"] = {"error": repr(ex)}
             # secondary figure: one optimisation step of `example/dist_train.py:86-99`
@@ -352,10 +459,11 @@ def main():
                 out["secondary"]["training"] = training_secondary(hn, synth, dev, model_kw)
             except Exception as ex:      # never lose the headline line over the secondary figure
                 out["secondary"]["training"] = {"error": repr(ex)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_kw, elems, seed)
         print(json.dumps(out))
     if sharded:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -15,7 +15,7 @@ _ERR = {1: "HN_ERR_BAD_ARG (unsupported shape or null pointer)",
         3: "HN_ERR_LAUNCH (kernel launch failed)"}
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers
-ABI_VERSION = 2          # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
+ABI_VERSION = 3          # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
 
 
 class RbfDesc(ctypes.Structure):
@@ -73,6 +73,7 @@ SIGNATURES = {
     "hermnet_energy_head_fwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_energy_head_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_halo_rows": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
+    "hermnet_halo_accumulate": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "hermnet_host_rbf_row": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                             ctypes.c_int, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp]),
 }

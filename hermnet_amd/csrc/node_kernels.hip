@@ -356,6 +356,28 @@ __global__ __launch_bounds__(256) void halo_rows_kernel(float* __restrict__ x, f
   }
 }
 
+// Deterministic accumulate at the owner: rows[seg_rows[u]] += sum_{q in [seg_ptr[u], seg_ptr[u+1])} buf[seg_pos[q]],
+// in list order (an owned atom can be a halo atom of several peers; a fixed order keeps the sharded step
+// bit-reproducible, which float atomics do not).
+__global__ __launch_bounds__(256) void halo_accumulate_kernel(float* __restrict__ x, float* __restrict__ vec,
+                                                              const long* __restrict__ seg_rows,
+                                                              const long* __restrict__ seg_ptr,
+                                                              const long* __restrict__ seg_pos, int nu, int H,
+                                                              const float* __restrict__ buf) {
+  const int q4 = H;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nu * q4) return;
+  const int u = (int)(i / q4), c = (int)(i % q4) * 4;
+  const long r = seg_rows[u];
+  float* row = c < H ? x + r * H + c : vec + r * 3 * H + (c - H);
+  float4 acc = ld4(row);
+  for (long q = seg_ptr[u]; q < seg_ptr[u + 1]; ++q) {
+    const float4 v = ld4(buf + seg_pos[q] * 4 * H + c);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  st4(row, acc);
+}
+
 inline dim3 grid_for(long n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 #define HN_LAUNCH_END return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH
 
@@ -484,5 +506,15 @@ extern "C" int hermnet_halo_rows(int mode, float* x, float* vec, const long* idx
     case 2: hipLaunchKernelGGL(halo_rows_kernel<2>, grid, dim3(256), 0, s, x, vec, idx, n, hidden, buf); break;
     default: hipLaunchKernelGGL(halo_rows_kernel<3>, grid, dim3(256), 0, s, x, vec, idx, n, hidden, buf); break;
   }
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_halo_accumulate(float* x, float* vec, const long* seg_rows, const long* seg_ptr,
+                                       const long* seg_pos, int num_rows, int hidden, const float* buf, void* stream) {
+  if (num_rows < 0 || hidden <= 0 || (hidden & 3)) return HN_ERR_BAD_ARG;
+  if (num_rows == 0) return HN_OK;
+  if (!x || !vec || !seg_rows || !seg_ptr || !seg_pos || !buf) return HN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(halo_accumulate_kernel, grid_for((long)num_rows * hidden, 256), dim3(256), 0, (hipStream_t)stream,
+                     x, vec, seg_rows, seg_ptr, seg_pos, num_rows, hidden, buf);
   HN_LAUNCH_END;
 }

@@ -107,3 +107,11 @@ def halo_rows(mode, x, vec, idx, buf=None):
     _lib.check(_launch("halo_rows", lambda: _lib.load().hermnet_halo_rows(
         mode, P(x), P(vec), P(idx), n, H, P(buf), _stream())), "hermnet_halo_rows")
     return buf
+
+
+def halo_accumulate(x, vec, plan, buf):
+    """rows[plan.acc_rows[u]] += sum of the packed rows `buf[plan.acc_pos[q]]` of segment u, in list order
+    (deterministic replacement of halo_rows mode 3)."""
+    rows, ptr, pos = plan.accumulate_lists()
+    _lib.check(_launch("halo_accumulate", lambda: _lib.load().hermnet_halo_accumulate(
+        P(x), P(vec), P(rows), P(ptr), P(pos), int(rows.numel()), x.size(1), P(buf), _stream())), "hermnet_halo_accumulate")

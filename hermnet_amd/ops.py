@@ -15,7 +15,8 @@ class KernelTimer(object):
 
     def __init__(self, prefix="message_scatter"):
         self.pairs = {}
-        self.prefix = prefix       # only these launches are bracketed: an event pair costs ~15 us of host time
+        # only launches whose name starts with one of these are bracketed: an event pair costs ~15 us of host time
+        self.prefix = (prefix,) if isinstance(prefix, str) else tuple(prefix)
 
     def launch(self, name, fn):
         if not name.startswith(self.prefix):

@@ -12,8 +12,15 @@ DDP for training, `example/dist_train.py:25,67`).  The build shards the hot path
   * backward mirrors it (gradients of halo rows return to the owners and are accumulated there),
     positions use the same exchange once per step, the energy is one scalar all-reduce.
 
-Every rank derives the complete plan from the global `Data` (the calculators have all
-coordinates on the host anyway), so there is no negotiation step.
+Every rank derives the complete plan from the global coordinates (the calculators have all
+coordinates anyway), so there is no negotiation step.  Two planners:
+
+  * `partition_slab` (the production path): pure geometry on the device.  Owners = equal-count slabs;
+    the halo of a rank = the atoms within rc of its slab along the slab axis (periodic); the rank runs the
+    cutoff neighbour search ONLY over its owned + halo atoms and keeps the edges whose target it owns.  Cost
+    per rank ~ N / world; nothing of size E_global is ever built.
+  * `partition` (planning from a GLOBAL edge list on the host: batches of molecules, tests): exact halos
+    (only atoms that really send an edge across).
 """
 import numpy as np
 import torch
@@ -35,12 +42,28 @@ class ExchangePlan(object):
         self.send_idx, self.send_counts = send_idx, [int(c) for c in send_counts]
         self.recv_idx, self.recv_counts = recv_idx, [int(c) for c in recv_counts]
         self.group = group
+        self._acc = None
+
+    def accumulate_lists(self):
+        """(rows [nu], ptr [nu+1], pos [n_send]) for the deterministic accumulation of returned gradients: an owned
+        entry that is sent to several peers gets its contributions summed in send-list order."""
+        if self._acc is None:
+            idx = self.send_idx
+            pos = torch.argsort(idx, stable=True)
+            rows, cnt = torch.unique_consecutive(idx[pos], return_counts=True)
+            ptr = torch.zeros(rows.numel() + 1, dtype=torch.long, device=idx.device)
+            ptr[1:] = torch.cumsum(cnt, 0)
+            self._acc = (rows.contiguous(), ptr, pos.contiguous())
+        return self._acc
 
     def remap(self, index_map):
         """Same exchange expressed in another ordering (e.g. relation rows): idx -> index_map[idx]."""
-        return ExchangePlan(index_map.index_select(0, self.send_idx), self.send_counts,
-                            index_map.index_select(0, self.recv_idx),
-                            self.recv_counts, self.group)
+        p = ExchangePlan(index_map.index_select(0, self.send_idx), self.send_counts,
+                         index_map.index_select(0, self.recv_idx),
+                         self.recv_counts, self.group)
+        rows, ptr, pos = self.accumulate_lists()       # the grouping does not depend on the (injective) ordering
+        p._acc = (index_map.index_select(0, rows), ptr, pos)
+        return p
 
 
 def _host_staged(group, t):
@@ -77,7 +100,11 @@ class HaloExchange(torch.autograd.Function):
         back = _all_to_all_rows(g.index_select(0, plan.recv_idx), plan.recv_counts, plan.send_counts, plan.group)
         gx = g.clone()
         gx.index_fill_(0, plan.recv_idx, 0)            # the local halo values were overwritten in forward
-        gx.index_add_(0, plan.send_idx, back)
+        if back.size(0) > 0:
+            # an atom that is a halo atom of several peers gets its returns summed in send-list order (no atomics)
+            rows, ptr, pos = plan.accumulate_lists()
+            seg = torch.segment_reduce(back.index_select(0, pos), "sum", lengths=ptr[1:] - ptr[:-1])
+            gx.index_add_(0, rows, seg)                # `rows` is unique
         return gx, None
 
 
@@ -119,7 +146,7 @@ class HaloExchangeFeatures(torch.autograd.Function):
             # the local halo values were overwritten in forward: their gradients go to the owners, none stays here
             gsend = nodeops.halo_rows(1, gx, gvec, plan.recv_idx)
             back = _all_to_all_rows(gsend, plan.recv_counts, plan.send_counts, plan.group)
-            nodeops.halo_rows(3, gx, gvec, plan.send_idx, back)          # gradients of my atoms used elsewhere
+            nodeops.halo_accumulate(gx, gvec, plan, back)               # gradients of my atoms used elsewhere
             return gx, gvec, None
         gsend = torch.cat([gx.index_select(0, plan.recv_idx),
                            gvec.index_select(0, plan.recv_idx).reshape(-1, 3 * H)], dim=1)
@@ -273,5 +300,133 @@ def partition(data, rank, world, axis=None, group=None):
     plan.owned_local = torch.from_numpy(np.nonzero(is_owned)[0])
     plan.local_global = torch.from_numpy(local_ids.copy())
     plan.z_with_in_edges = set(int(v) for v in np.unique(data.atomic_number.cpu().numpy()[tgt]))
+    local._hn_shard = plan
+    return local, plan
+
+
+def _axis_coordinate(pos, cell, axis):
+    """(coordinate along the slab axis in [0,1) for periodic cells / Cartesian for open systems, axis, margin):
+    `margin` = rc-independent factor such that `rc * margin` is the cutoff expressed in that coordinate."""
+    p64 = pos.detach().double()
+    if cell is not None:
+        c = cell.detach().double().reshape(-1, 3, 3)[0].cpu()
+        if axis is None:
+            axis = int(torch.argmax(c.norm(dim=1)))
+        inv = torch.linalg.inv(c)
+        col = inv[:, axis].to(p64.device)
+        # elementwise, fixed order: every rank must get bit-identical coordinates (no BLAS here)
+        frac = p64[:, 0] * col[0] + p64[:, 1] * col[1] + p64[:, 2] * col[2]
+        return frac - torch.floor(frac), axis, float(inv[:, axis].norm())     # 1 / plane spacing
+    if axis is None:
+        ext = (p64.max(0).values - p64.min(0).values) if p64.size(0) > 0 else torch.zeros(3)
+        axis = int(torch.argmax(ext))
+    return p64[:, axis].clone(), axis, 1.0
+
+
+def slab_owner_device(pos, cell, world, axis=None):
+    """Equal-count slabs along `axis` with torch ops on `pos.device` (same definition as `slab_owner`).
+    Returns (owner [N] int64, coord [N] float64, bounds (lo [world], hi [world]) of every slab, axis, margin)."""
+    coord, axis, margin = _axis_coordinate(pos, cell, axis)
+    n = coord.numel()
+    dev = coord.device
+    order = torch.argsort(coord, stable=True)
+    cuts = torch.tensor([(n * r) // world for r in range(world + 1)], dtype=torch.long, device=dev)
+    rank_of_sorted = torch.bucketize(torch.arange(n, device=dev), cuts[1:], right=True).clamp(max=world - 1)
+    owner = torch.empty(n, dtype=torch.long, device=dev)
+    owner[order] = rank_of_sorted
+    cs = coord[order]
+    nonempty = cuts[1:] > cuts[:-1]
+    lo = torch.where(nonempty, cs[cuts[:-1].clamp(max=max(n - 1, 0))], torch.full((world,), float("nan"), dtype=cs.dtype, device=dev))
+    hi = torch.where(nonempty, cs[(cuts[1:] - 1).clamp(min=0)], torch.full((world,), float("nan"), dtype=cs.dtype, device=dev))
+    return owner, coord, (lo, hi), axis, margin
+
+
+def _within_cutoff_of_slab(coord, lo, hi, reach, periodic):
+    """Atoms whose distance along the slab axis to the interval [lo, hi] is <= reach (periodic: in fractional
+    coordinates, through the cell boundary as well).  Empty slabs (lo = nan) reach nothing."""
+    inside = (coord >= lo) & (coord <= hi)
+    if periodic:
+        up = torch.remainder(lo - coord, 1.0)        # going up from the atom to the slab's lower face
+        down = torch.remainder(coord - hi, 1.0)      # going down to its upper face
+        dist = torch.minimum(up, down)
+    else:
+        dist = torch.maximum(lo - coord, coord - hi)
+    return inside | (dist <= reach)
+
+
+def partition_slab(pos, atomic_number, cell, rc, rank, world, axis=None, group=None, reference_compat=False):
+    """Slab decomposition of ONE structure from its coordinates alone (no global edge list).
+
+    pos [N,3] float32, atomic_number [N], cell [3,3] / [1,3,3] / None -- the same on every rank, on the device the
+    step will run on (host tensors work too: CPU rehearsal).  Returns (local_data, plan) with the contract of
+    `partition`: local atoms = owned + halo in ascending global id, edges = cutoff pairs whose TARGET is owned,
+    found by a neighbour search over the local atoms only.  The halo is geometric (everything within rc of the
+    slab along the slab axis), so sender and receiver derive identical exchange lists independently; it is a
+    superset of the atoms that really send an edge across (by the few with no partner inside the slab).
+    One host read (2 x world counts + the local edge count of the search)."""
+    from .neighbor import neighbor_search
+    dev = pos.device
+    n = pos.size(0)
+    owner, coord, (lo, hi), axis, margin = slab_owner_device(pos, cell, world, axis)
+    periodic = cell is not None
+    reach = float(rc) * margin * (1.0 + 1e-9) + 1e-12
+    mine = owner == rank
+    need = _within_cutoff_of_slab(coord, lo[rank], hi[rank], reach, periodic)      # owned atoms are inside
+    local_mask = mine | need
+    local_ids = torch.nonzero(local_mask).reshape(-1)                               # ascending global id
+    is_owned = mine[local_ids]
+    g2l = torch.full((n,), -1, dtype=torch.long, device=dev)
+    g2l[local_ids] = torch.arange(local_ids.numel(), device=dev)
+
+    # receive: my halo grouped by owner (ascending id inside a group); send: for every peer, the atoms I own
+    # that lie within rc of ITS slab -- the same set and order the peer derives for its receive list
+    halo = local_ids[~is_owned]
+    halo_owner = owner[halo]
+    key = torch.argsort(halo_owner, stable=True)
+    recv_idx = g2l[halo[key]]
+    send_lists, cnt = [], [torch.bincount(halo_owner, minlength=world)]
+    for p in range(world):
+        if p == rank:
+            send_lists.append(torch.zeros(0, dtype=torch.long, device=dev))
+            continue
+        m = mine & _within_cutoff_of_slab(coord, lo[p], hi[p], reach, periodic)
+        send_lists.append(g2l[torch.nonzero(m).reshape(-1)])
+    cnt.append(torch.stack([torch.tensor(s_.numel(), device=dev) for s_ in send_lists]))
+    counts = torch.stack(cnt).cpu().tolist()                                        # the one host read of the plan
+    recv_counts, send_counts = counts[0], counts[1]
+    send_idx = torch.cat(send_lists) if send_lists else torch.zeros(0, dtype=torch.long, device=dev)
+
+    # cutoff graph of the local atoms in the GLOBAL cell; keep the edges into owned atoms
+    pos_l = pos.detach()[local_ids]
+    cell_t = None if cell is None else cell.detach().reshape(-1, 3, 3)[0]
+    if periodic:
+        ei, sh = neighbor_search(pos_l, rc, cell_t, reference_compat=reference_compat)
+    else:
+        ei, sh = neighbor_search(pos_l, rc, None, reference_compat=reference_compat), None
+    keep = is_owned[ei[1]]
+    ei = ei[:, keep]
+    pos_l = torch.where(is_owned[:, None], pos_l, torch.zeros_like(pos_l))          # halo rows: filled by the exchange
+    z = atomic_number[local_ids]
+    kw = dict(pos=pos_l, atomic_number=z, edge_index=ei, batch=torch.zeros(local_ids.numel(), dtype=torch.long, device=dev))
+    if periodic:
+        kw["cell"] = cell.detach().reshape(1, 3, 3)
+        kw["edge_shift"] = sh[keep]
+    local = Data(**kw)
+    plan = ShardPlan(rank, world, local_ids[is_owned], halo, ExchangePlan(send_idx, send_counts, recv_idx, recv_counts, group),
+                     is_owned, 1, group)
+    plan.owned_local = torch.nonzero(is_owned).reshape(-1)
+    plan.local_global = local_ids
+    # hermnet.py:56-57: a relation is skipped when NO atom of its element receives an edge anywhere in the structure
+    has_in = torch.zeros(128, dtype=torch.int32, device=dev)
+    if ei.size(1) > 0:
+        has_in[z[ei[1]].clamp(max=127)] = 1
+    if world > 1 and dist.is_available() and dist.is_initialized():
+        if _host_staged(group, has_in):
+            h = has_in.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+            has_in = h
+        else:
+            dist.all_reduce(has_in, op=dist.ReduceOp.MAX, group=group)
+    plan.z_with_in_edges = set(int(v) for v in torch.nonzero(has_in).reshape(-1).cpu().tolist())
     local._hn_shard = plan
     return local, plan

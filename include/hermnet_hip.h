@@ -16,7 +16,8 @@
  *   - float = IEEE fp32 (the reference is fp32-only), indices = int32 (int64 where a parameter says so:
  *     the caller's edge_index / atomic_number / halo index lists arrive as torch LongTensors).
  *
- * ABI version 2 (`hermnet_abi_version`): v2 added the bias-on-load arguments, LayerNorm, the energy head, the
+ * ABI version 3 (`hermnet_abi_version`): v3 added the deterministic halo accumulate, separate source / target row
+ * spaces (HTNet) and the fused node-chain kernels; v2 added the bias-on-load arguments, LayerNorm, the energy head, the
  * CSC position gradient and the halo packing; the Python side refuses a library of another version.
  *
  * Node order.  All node-level arrays are in "relation order": atoms sorted by
@@ -245,6 +246,12 @@ int hermnet_energy_head_bwd(const float* ge, const float* h, const float* w, con
  *   mode 2  rows[idx[k]] = buf[k]                         unpack received halo rows (idx unique)
  *   mode 3  rows[idx[k]] += buf[k]                        accumulate returned gradients (idx may repeat: atomics) */
 int hermnet_halo_rows(int mode, float* x, float* vec, const long* idx, int n, int hidden, float* buf, void* stream);
+
+/* Deterministic form of mode 3 (what the sharded backward uses): the returned packed rows are summed per owner row in
+ * a FIXED order, rows[seg_rows[u]] += sum_{q in [seg_ptr[u], seg_ptr[u+1])} buf[seg_pos[q]]  (seg_rows unique, int64
+ * lists prepared once per exchange plan by hermnet_amd/sharding.py) -- no atomics, bit-reproducible. */
+int hermnet_halo_accumulate(float* x, float* vec, const long* seg_rows, const long* seg_ptr, const long* seg_pos,
+                            int num_rows, int hidden, const float* buf, void* stream);
 
 /* Host-side (CPU) evaluation of the per-edge radial contraction exactly as the device code
  * computes it (banded 12-tap Gaussian window): rb[c] = b[c] + env(u) * sum_k W[c,k] g_k(u) and

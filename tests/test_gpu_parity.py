@@ -308,6 +308,23 @@ def test_halo_rows_kernels():
     xr = x.clone().index_add_(0, idx, add[:, :H])
     vr = vec.clone().index_add_(0, idx, add[:, H:].reshape(-1, 3, H))
     assert rel_err(x3, xr) < 1e-6 and rel_err(v3, vr) < 1e-6
+    # the deterministic form used by the sharded backward: fixed summation order per owner row, bit-exact
+    from hermnet_amd.sharding import ExchangePlan
+    plan = ExchangePlan(idx, [3, 4], torch.zeros(0, dtype=torch.long, device=dev), [0, 0])
+    x4, v4 = x.clone(), vec.clone()
+    nodeops.halo_accumulate(x4, v4, plan, add)
+    xe, ve = x.clone().cpu().double(), vec.clone().cpu().double()
+    xs, vs = x.clone().cpu(), vec.clone().cpu()
+    for k, r in enumerate(idx.cpu().tolist()):                   # sequential fp32 adds in send-list order
+        xs[r] += add[k, :H].cpu()
+        vs[r] += add[k, H:].cpu().reshape(3, H)
+    assert torch.equal(x4.cpu(), xs) and torch.equal(v4.cpu(), vs)
+    # ... and through a re-ordering (what HVNet.forward does: atom ids -> relation rows)
+    perm = torch.randperm(N, generator=gen).to(dev)
+    x5, v5 = torch.empty_like(x), torch.empty_like(vec)
+    x5[perm], v5[perm] = x, vec
+    nodeops.halo_accumulate(x5, v5, plan.remap(perm), add)
+    assert torch.equal(x5[perm].cpu(), xs) and torch.equal(v5[perm].cpu(), vs)
 
 
 def test_bias_on_load_equals_bias_in_operand():
