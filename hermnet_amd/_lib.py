@@ -26,7 +26,8 @@ class RbfDesc(ctypes.Structure):
 class Graph(ctypes.Structure):
     _fields_ = [("num_nodes", ctypes.c_int), ("num_edges", ctypes.c_int), ("num_rel", ctypes.c_int),
                 ("type_rowptr", c_fp), ("csr_rowptr", c_fp), ("csr_src", c_fp),
-                ("csc_rowptr", c_fp), ("csc_tgt", c_fp), ("csc_pos", c_fp)]
+                ("csc_rowptr", c_fp), ("csc_tgt", c_fp), ("csc_pos", c_fp),
+                ("num_src", ctypes.c_int), ("res_row", c_fp)]
 
 
 class RelationsOut(ctypes.Structure):
@@ -46,7 +47,8 @@ SIGNATURES = {
                                                    c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "hermnet_message_scatter_bwd": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), ctypes.c_int,
                                                    c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
-                                                   c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
+                                                   c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
+    "hermnet_edge_radial_table": (ctypes.c_int, [ctypes.POINTER(RbfDesc), c_fp, ctypes.c_int, c_fp, c_fp]),
     "hermnet_neighbor_workspace": (ctypes.c_size_t, [ctypes.c_int]),
     "hermnet_neighbor_sort_workspace": (ctypes.c_size_t, [ctypes.c_long]),
     "hermnet_neighbor_count": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_double, c_fp,

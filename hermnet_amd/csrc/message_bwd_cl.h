@@ -1,0 +1,33 @@
+// Internal interface between message_kernels.hip (C-ABI entry points) and message_bwd_cl.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#define HN_EDGE_TABLE_FLOATS 32   // floats per edge record of hermnet_edge_radial_table (include/hermnet_hip.h)
+
+struct HnBwdClArgs {
+  int N, Nsrc, E, T;         // target rows, source rows, edges, relations
+  const int* type_rowptr;    // [T+1] device: rows below type_rowptr[T] are targets of a known type
+  int identity;              // 1: source and target rows coincide, the residual's identity gradient is added here
+  const int* csc_rowptr;     // [T*Nsrc+1]
+  const int* csc_tgt;        // [E]
+  const int* csc_pos;        // [E]
+  int R, H;
+  const float* table;        // [E, 32] per-edge radial record, CSR order
+  const float4* edge;        // [E] (rhat, d), CSR order
+  const float* xh;           // [T, Nsrc, 3H]
+  const float* xh_bias;      // [T, 3H] or null
+  const float* vec;          // [Nsrc, 3, H] or null
+  const float* wt;           // [T, R, 3H]
+  const float* brbf;         // [T, 3H]
+  const float* gx1;          // [N, H]
+  const float* gvec1;        // [N, 3, H]
+  float* gxh;                // [T, Nsrc, 3H]
+  float* gvec;               // [Nsrc, 3, H] or null
+  float* gx;                 // [Nsrc, H]
+  float4* gedge;             // [H/64, E]
+  int rows_per_block;
+};
+
+size_t hn_bwd_cl_lds_bytes(int R);
+int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, hipStream_t s);

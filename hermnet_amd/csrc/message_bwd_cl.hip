@@ -1,0 +1,349 @@
+// gfx950 backward (forces) message kernel, "channel per lane" form.
+//
+// Same contract as message_scatter_bwd_kernel (message_kernels.hip; reference: the backward pass of
+// rmnet.py:55-73 + 24-26 for energy/force evaluation), different mapping:
+//
+//   * a wave works on ONE edge at a time; its 64 lanes are the 64 channels of the column block.  Everything that
+//     depends only on the edge -- window start, the 12 Gaussian taps g_m and g_m (u - mu_m), envelope factors,
+//     unit vector -- is wave-uniform and arrives through the SCALAR path from a per-edge table
+//     (hermnet_edge_radial_table, computed once per step: geometry and radial basis are shared by all layers),
+//     so no vector register holds tap values and no lane evaluates an exponential here;
+//   * the banded contraction packs {value, derivative}:  (S0, S1) += (g_m, gd_m) * W[lo+m][part][c]  is one
+//     v_pk_fma_f32 with an SGPR pair and a broadcast weight; the LDS tile is laid out [tap row][channel][s,a,b,0],
+//     one conflict-free ds_read_b128 per tap;
+//   * per lane there is one channel of state, ~100 VGPRs in all, so a 1024-thread workgroup puts 4 waves on every
+//     SIMD (the VW = 4 form: 245 VGPRs, 2 waves per SIMD, each wave parked ~50 % of its life -- rocprofv3
+//     SQ_WAIT_ANY / SQ_WAVE_CYCLES, profiles/r02_v1_counters.json -- and a lone wave issues fp32 VALU at only
+//     ~40 % of the SIMD's rate);
+//   * segment sums (gxh, gvec) need no cross-lane step at all; the per-edge dE/dD (a sum over channels) is reduced
+//     for 4 edges at once with v_permlane32/16 swaps + 4 DPP steps;
+//   * source rows are handed to waves dynamically (LDS counter), so a workgroup's 16 waves stay balanced although
+//     segments are short (~14 edges) and uneven.
+//
+// No atomics on HBM, fixed summation order: bit-reproducible.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hermnet_hip.h"
+#include "hermnet_math.h"
+#include "message_bwd_cl.h"
+
+namespace {
+
+typedef float hn_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned hn_u2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(4))) const float hn_cfloat;   // constant address space: uniform loads go scalar
+
+constexpr int kRec = HN_EDGE_TABLE_FLOATS;   // floats per edge record
+// record layout: [2m], [2m+1] = g_m, g_m (u - mu_m)  (m < 12) | 24 lo (int) | 25 env | 26 c0 | 27 c1 | 28..30 rhat | 31 1/d
+
+__global__ __launch_bounds__(256) void edge_table_kernel(const float4* __restrict__ edge, int E,
+                                                         const float* __restrict__ offset, int R, float inv_rc,
+                                                         float coeff, int env_kind, int env_p,
+                                                         float* __restrict__ table) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float4 g = edge[e];
+  const float u = g.w * inv_rc;
+  const HnEnv env = hn_envelope(u, env_kind, env_p);
+  const int lo = hn_window_lo(u, R);
+  float rec[kRec];
+#pragma unroll
+  for (int m = 0; m < HN_TAPS; ++m) {
+    int k = lo + m;
+    k = k < 0 ? 0 : (k >= R ? R - 1 : k);                 // (rows outside [0, R) hold zero weights)
+    const float diff = u - offset[k];
+    const float gm = __expf(coeff * (diff * diff));        // same fp32 operation order as rmnet.py:156-172
+    rec[2 * m] = gm;
+    rec[2 * m + 1] = gm * diff;
+  }
+  rec[24] = __int_as_float(lo + HN_PAD);                  // padded tile row of tap 0
+  rec[25] = env.val;
+  rec[26] = inv_rc * env.der;                             // d rbfh / d d = c0 S0 + c1 S1
+  rec[27] = inv_rc * env.val * 2.0f * coeff;
+  rec[28] = g.x; rec[29] = g.y; rec[30] = g.z;
+  rec[31] = __builtin_amdgcn_rcpf(g.w);
+  float4* out = reinterpret_cast<float4*>(table + (size_t)e * kRec);
+#pragma unroll
+  for (int q = 0; q < kRec / 4; ++q) out[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+// 64-lane totals of one quantity of FOUR edges at once: on return every lane of 16-lane row k holds the total of
+// edge {0, 2, 1, 3}[k].
+__device__ __forceinline__ float reduce4(float e0, float e1, float e2, float e3) {
+  const hn_u2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(e0), __float_as_uint(e1), false, false);
+  const hn_u2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(e2), __float_as_uint(e3), false, false);
+  const float u = __uint_as_float(s01[0]) + __uint_as_float(s01[1]);   // halves: e0 | e1
+  const float w = __uint_as_float(s23[0]) + __uint_as_float(s23[1]);   // halves: e2 | e3
+  const hn_u2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(u), __float_as_uint(w), false, false);
+  float v = __uint_as_float(s[0]) + __uint_as_float(s[1]);             // rows: e0, e2, e1, e3
+  v += dpp_mov<0xB1>(v);    // lane ^ 1
+  v += dpp_mov<0x4E>(v);    // lane ^ 2
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
+  return v;
+}
+
+// Six consecutive tap rows of this lane's weight record, each ONE ds_read_b128 (4 LDS cycles, conflict-free).
+// Written as asm because hipcc narrows a float4 LDS load whose .w is unused to ds_read_b96 (8 LDS cycles, and the LDS
+// port is the second-busiest unit of this kernel); the wait is part of the same statement, so no use can be
+// scheduled in front of it.  `addr` = byte address in LDS (the dynamic region starts at 0: no static LDS here).
+typedef float hn_f4 __attribute__((ext_vector_type(4)));
+template <int DUMMY>
+__device__ __forceinline__ void lds_read6(unsigned addr, hn_f4 (&w)[6]) {
+  asm volatile(
+      "ds_read_b128 %0, %6\n\t"
+      "ds_read_b128 %1, %6 offset:1024\n\t"
+      "ds_read_b128 %2, %6 offset:2048\n\t"
+      "ds_read_b128 %3, %6 offset:3072\n\t"
+      "ds_read_b128 %4, %6 offset:4096\n\t"
+      "ds_read_b128 %5, %6 offset:5120\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5])
+      : "v"(addr)
+      : "memory");
+}
+static_assert(HN_CB * 16 == 1024, "lds_read6 hard-codes the 1 KiB tap-row pitch");
+
+struct EdgeIn {          // what one edge needs from memory (vector part)
+  float gx1, g0, g1, g2;
+};
+
+template <bool HAS_VEC>
+__global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdClArgs a) {
+  extern __shared__ __align__(16) float4 tile[];     // [tap row][64] of (s, a, b, 0)
+  const int tile_rows = a.R + 2 * HN_PAD + 1;
+  int* counter = reinterpret_cast<int*>(tile + (size_t)tile_rows * HN_CB);
+
+  const int cb = blockIdx.y;
+  const int r0 = blockIdx.x * a.rows_per_block;
+  const int r1 = min(r0 + a.rows_per_block, a.Nsrc);
+  const int lane = threadIdx.x & 63;
+  const int H = a.H;
+  const int c = cb * HN_CB + lane;                   // this lane's channel
+  const int nk = a.type_rowptr[a.T];                 // rows below nk are targets of a known type
+  const float inv_sqrt3h = 0.57735026918962576f * rsqrtf((float)H);
+  const float inv_sqrth = rsqrtf((float)H);
+  const float inv_sqrt2 = 0.70710678118654752f;
+  float4* gedge = a.gedge + (size_t)cb * a.E;
+  const int row16 = lane >> 4;                       // DPP row of this lane
+  // LDS byte address of this lane's record in tap row 0 (the tile starts the dynamic region)
+  const unsigned tile_lane = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)tile) + (unsigned)lane * 16u;
+
+  for (int t = 0; t < a.T; ++t) {
+    __syncthreads();                                 // previous tile and counter no longer in use
+    // ---- stage the weight tile of (relation t, column block cb): rows outside [0, R) are zero
+    for (int idx = threadIdx.x; idx < tile_rows * HN_CB; idx += blockDim.x) {
+      const int k = idx / HN_CB - HN_PAD, ch = idx % HN_CB;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k >= 0 && k < a.R) {
+        const float* w = a.wt + ((size_t)(t * a.R + k) * 3 * H + cb * HN_CB + ch);
+        v = make_float4(w[0], w[H], w[2 * H], 0.f);
+      }
+      tile[idx] = v;
+    }
+    if (threadIdx.x == 0) *counter = 0;
+    __syncthreads();
+
+    const float* xh_t = a.xh + (size_t)t * a.Nsrc * 3 * H;
+    float* gxh_t = a.gxh + (size_t)t * a.Nsrc * 3 * H;
+    const int* rowptr_t = a.csc_rowptr + (size_t)t * a.Nsrc;
+    const float bs = a.brbf[(size_t)t * 3 * H + c], ba = a.brbf[(size_t)t * 3 * H + H + c],
+                bb = a.brbf[(size_t)t * 3 * H + 2 * H + c];
+    float xbs = 0.f, xba = 0.f, xbb = 0.f;
+    if (a.xh_bias) {
+      xbs = a.xh_bias[(size_t)t * 3 * H + c]; xba = a.xh_bias[(size_t)t * 3 * H + H + c];
+      xbb = a.xh_bias[(size_t)t * 3 * H + 2 * H + c];
+    }
+
+    // ---- source rows are pulled from a workgroup-wide counter (wave-uniform)
+    int rr = 0;
+    if (lane == 0) rr = atomicAdd(counter, 1);
+    rr = __builtin_amdgcn_readfirstlane(rr);
+    while (r0 + rr < r1) {
+      const int r = r0 + rr;
+      int rr_next = 0;
+      if (lane == 0) rr_next = atomicAdd(counter, 1);             // the next row's index: its latency hides below
+      const int beg = rowptr_t[r], end = rowptr_t[r + 1];
+      const float* xr = xh_t + (size_t)r * 3 * H + c;
+      const float xs = xr[0] + xbs, xa = xr[H] + xba, xb = xr[2 * H] + xbb;
+      float vj0 = 0.f, vj1 = 0.f, vj2 = 0.f;
+      if (HAS_VEC) {
+        const float* vr = a.vec + (size_t)r * 3 * H + c;
+        vj0 = vr[0]; vj1 = vr[H]; vj2 = vr[2 * H];
+      }
+      // gvec[row] is read-modify-written across the relations (t = 0 starts from the residual's identity term)
+      float prev0 = 0.f, prev1 = 0.f, prev2 = 0.f;
+      if (HAS_VEC) {
+        const size_t vo = (size_t)r * 3 * H + c;
+        if (t == 0) {
+          if (a.identity && r < nk) { prev0 = a.gvec1[vo]; prev1 = a.gvec1[vo + H]; prev2 = a.gvec1[vo + 2 * H]; }
+        } else {
+          prev0 = a.gvec[vo]; prev1 = a.gvec[vo + H]; prev2 = a.gvec[vo + 2 * H];
+        }
+      }
+      float gs = 0.f, ga = 0.f, gb = 0.f, gv0 = 0.f, gv1 = 0.f, gv2 = 0.f;
+
+      for (int base = beg; base < end; base += 64) {
+        const int cnt = min(64, end - base);
+        // one coalesced index load per 64 edges; an edge's indices are then wave-uniform (v_readlane)
+        const int my_tgt = lane < cnt ? a.csc_tgt[base + lane] : 0;
+        const int my_pos = lane < cnt ? a.csc_pos[base + lane] : 0;
+
+        auto load_edge = [&](int k) {
+          const int i = __builtin_amdgcn_readlane(my_tgt, k);
+          EdgeIn in;
+          in.gx1 = a.gx1[(size_t)i * H + c];
+          const float* gvr = a.gvec1 + (size_t)i * 3 * H + c;
+          in.g0 = gvr[0]; in.g1 = gvr[H]; in.g2 = gvr[2 * H];
+          return in;
+        };
+
+        EdgeIn cur = load_edge(0);
+        for (int k4 = 0; k4 < cnt; k4 += 4) {
+          float pd[4], px[4], py[4], pz[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            pd[j] = 0.f; px[j] = 0.f; py[j] = 0.f; pz[j] = 0.f;
+            const int k = k4 + j;
+            if (k < cnt) {                                          // wave-uniform
+              const EdgeIn nxt = load_edge(min(k + 1, cnt - 1));    // the next edge's rows fly during this edge's math
+              const int p = __builtin_amdgcn_readlane(my_pos, k);
+              // the record is wave-uniform and read-only here: through the constant address space its loads are
+              // scalar (s_load_dwordx8 into SGPRs), not 64 lanes fetching the same bytes
+              const hn_cfloat* rec = (const hn_cfloat*)(a.table + (size_t)p * kRec);
+              const int row = __float_as_int(rec[24]);
+              const float envv = rec[25], c0 = rec[26], c1 = rec[27], rx = rec[28], ry = rec[29], rz = rec[30];
+              // (S0, S1) of the three parts: 12 taps, one LDS read each
+              hn_f2 Ss = {0.f, 0.f}, Sa = {0.f, 0.f}, Sb = {0.f, 0.f};
+              const unsigned waddr = (unsigned)row * (HN_CB * 16) + tile_lane;
+#pragma unroll
+              for (int m0 = 0; m0 < HN_TAPS; m0 += 6) {
+                hn_f4 w[6];
+                lds_read6<0>(waddr + m0 * (HN_CB * 16), w);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                  const hn_f2 g = {rec[2 * (m0 + q)], rec[2 * (m0 + q) + 1]};
+                  Ss = __builtin_elementwise_fma(g, hn_f2{w[q].x, w[q].x}, Ss);
+                  if (HAS_VEC) Sa = __builtin_elementwise_fma(g, hn_f2{w[q].y, w[q].y}, Sa);
+                  Sb = __builtin_elementwise_fma(g, hn_f2{w[q].z, w[q].z}, Sb);
+                }
+              }
+              const float gdx = cur.gx1 * inv_sqrt2;
+              const float g0 = cur.g0, g1 = cur.g1, g2 = cur.g2;
+              // ---- part s: dx = sum xs * rs
+              const float rs = fmaf(envv, Ss.x, bs);
+              const float drs = fmaf(c0, Ss.x, c1 * Ss.y);
+              gs = fmaf(gdx, rs, gs);
+              float pdv = gdx * xs * drs;
+              // ---- part a: dvec += vec_j * (xa * ra) / sqrt(3H)
+              if (HAS_VEC) {
+                const float ra = fmaf(envv, Sa.x, ba);
+                const float dra = fmaf(c0, Sa.x, c1 * Sa.y);
+                const float A = fmaf(g0, vj0, fmaf(g1, vj1, g2 * vj2)) * inv_sqrt3h;
+                ga = fmaf(A, ra, ga);
+                const float w = xa * ra * inv_sqrt3h;
+                gv0 = fmaf(g0, w, gv0); gv1 = fmaf(g1, w, gv1); gv2 = fmaf(g2, w, gv2);
+                pdv = fmaf(A * xa, dra, pdv);
+              }
+              // ---- part b: dvec += rhat * (xb * rb) / sqrt(H)
+              const float rb = fmaf(envv, Sb.x, bb);
+              const float drb = fmaf(c0, Sb.x, c1 * Sb.y);
+              const float B = fmaf(rx, g0, fmaf(ry, g1, rz * g2)) * inv_sqrth;
+              gb = fmaf(B, rb, gb);
+              pdv = fmaf(B * xb, drb, pdv);
+              const float q = xb * rb * inv_sqrth;
+              pd[j] = pdv; px[j] = g0 * q; py[j] = g1 * q; pz[j] = g2 * q;   // per channel: dE/dd, dE/drhat
+              cur = nxt;
+            }
+          }
+          // ---- dE/dD of these (up to) four edges: channel sums, then Cartesian form, one 16-byte store per edge
+          const float sd = reduce4(pd[0], pd[1], pd[2], pd[3]);
+          const float sx = reduce4(px[0], px[1], px[2], px[3]);
+          const float sy = reduce4(py[0], py[1], py[2], py[3]);
+          const float sz = reduce4(pz[0], pz[1], pz[2], pz[3]);
+          const int je = (row16 == 0) ? 0 : (row16 == 1 ? 2 : (row16 == 2 ? 1 : 3));   // edge held by this DPP row
+          const int p = __shfl(my_pos, min(k4 + je, cnt - 1), 64);                      // (all lanes active here)
+          if ((lane & 15) == 0 && k4 + je < cnt) {
+            const float4 g = a.edge[p];
+            const float invd = __builtin_amdgcn_rcpf(g.w);
+            const float dotp = sx * g.x + sy * g.y + sz * g.z;
+            // d = |D|, rhat = D/d:  gD = pd rhat + (pr - (pr.rhat) rhat) / d
+            const float tpar = sd - dotp * invd;
+            gedge[p] = make_float4(fmaf(tpar, g.x, sx * invd), fmaf(tpar, g.y, sy * invd), fmaf(tpar, g.z, sz * invd), 0.f);
+          }
+        }
+      }
+      // ---- segment epilogue: every lane owns its channel, plain coalesced stores
+      float* go = gxh_t + (size_t)r * 3 * H + c;
+      go[0] = gs; go[H] = ga; go[2 * H] = gb;
+      if (t == 0) a.gx[(size_t)r * H + c] = (a.identity && r < nk) ? a.gx1[(size_t)r * H + c] * inv_sqrt2 : 0.f;
+      if (HAS_VEC) {
+        float* gvo = a.gvec + (size_t)r * 3 * H + c;
+        gvo[0] = prev0 + gv0; gvo[H] = prev1 + gv1; gvo[2 * H] = prev2 + gv2;
+      }
+      rr = __builtin_amdgcn_readfirstlane(rr_next);
+    }
+  }
+}
+
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
+}  // namespace
+
+size_t hn_bwd_cl_lds_bytes(int R) {
+  return (size_t)(R + 2 * HN_PAD + 1) * HN_CB * sizeof(float4) + 64;
+}
+
+int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, hipStream_t s) {
+  const size_t lds = hn_bwd_cl_lds_bytes(a.R);
+  if (lds > 160 * 1024) return HN_ERR_LDS;
+  typedef void (*kern_t)(HnBwdClArgs);
+  kern_t k = has_vec ? message_scatter_bwd_cl_kernel<true> : message_scatter_bwd_cl_kernel<false>;
+  static bool done[2] = {false, false};
+  if (!done[has_vec]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return HN_ERR_LDS;
+    done[has_vec] = true;
+  }
+  // one workgroup per CU and round: rows per workgroup such that the grid is a whole number of rounds
+  const int ncb = a.H / HN_CB;
+  int rpb = rows_override;
+  if (rpb <= 0) {
+    const long work = (long)a.Nsrc * ncb;
+    const int cus = num_cus();
+    long rounds = (work + (long)cus * 64) / ((long)cus * 128);     // ~128 rows per workgroup (16 waves)
+    if (rounds < 1) rounds = 1;
+    rpb = (int)((work + cus * rounds - 1) / (cus * rounds));
+    if (rpb < 16) rpb = 16;
+  }
+  a.rows_per_block = rpb;
+  dim3 grid((unsigned)((a.Nsrc + rpb - 1) / rpb), (unsigned)ncb);
+  hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, a);
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}
+
+extern "C" int hermnet_edge_radial_table(const hn_rbf_desc* rbf, const float* edge, int num_edges, float* table,
+                                         void* stream) {
+  if (!rbf || rbf->num_rbf < 2 || num_edges < 0) return HN_ERR_BAD_ARG;
+  if (num_edges == 0) return HN_OK;
+  if (!edge || !table || !rbf->offset) return HN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(edge_table_kernel, dim3((num_edges + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(edge), num_edges, rbf->offset, rbf->num_rbf, rbf->inv_rc, rbf->coeff,
+                     rbf->env_kind, rbf->env_p, table);
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}

@@ -23,12 +23,22 @@
 #include <stdlib.h>
 #include "../../include/hermnet_hip.h"
 #include "hermnet_math.h"
+#include "message_bwd_cl.h"
 
 #define HN_LDS_ROW (3 * HN_CB)      // floats per tap row in LDS: [part][64]
 // Phase fence for the instruction scheduler: without it hipcc hoists the LDS reads of all three
 // parts (and the next edges' loads) to the top of the iteration and spills.
 #ifndef HN_SB
 #define HN_SB __builtin_amdgcn_sched_barrier(0)
+#endif
+
+#if defined(HN_STAMPS)
+// Diagnostic build only (tools/build_variant.sh stamps -DHN_STAMPS): per-phase cycle sums of the backward kernel,
+// read back with hermnet_debug_stamps().  The stamps drain outstanding memory operations, so such a build says
+// where the cycles go, not how long the real kernel runs.
+__device__ unsigned long long hn_dbg[8];
+#define HN_T(var) unsigned long long var; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define HN_TNW(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
 #endif
 
 namespace {
@@ -262,6 +272,20 @@ __device__ __forceinline__ void rbf_part(const float* wcol, const float (&g)[HN_
     const Vec<VW> w = Vec<VW>::load(wcol + m * HN_LDS_ROW);
     S0 = v_sfma(g[m], w, S0);
     if (WITH_DER) S1 = v_sfma(gd[m], w, S1);
+  }
+#elif defined(HN_BURST_PART)
+  // all HN_BURST_PART reads of a group in flight before the first FMA: the LDS latency is paid once per group
+  // instead of once per tap (the double-buffered form below waits on every read one tap after issuing it)
+#pragma unroll
+  for (int m0 = 0; m0 < HN_TAPS; m0 += HN_BURST_PART) {
+    Vec<VW> w[HN_BURST_PART];
+#pragma unroll
+    for (int q = 0; q < HN_BURST_PART; ++q) w[q] = Vec<VW>::load(wcol + (m0 + q) * HN_LDS_ROW);
+#pragma unroll
+    for (int q = 0; q < HN_BURST_PART; ++q) {
+      S0 = v_sfma(g[m0 + q], w[q], S0);
+      if (WITH_DER) S1 = v_sfma(gd[m0 + q], w[q], S1);
+    }
   }
 #else
   Vec<VW> wa = Vec<VW>::load(wcol), wb;
@@ -528,10 +552,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
   float4* gedge = a.gedge + (size_t)cb * a.E;
 
   const int t_lo = a.split_t ? blockIdx.z : 0, t_hi = a.split_t ? blockIdx.z + 1 : a.T;
+#if defined(HN_STAMPS)
+  unsigned long long st_stage = 0, st_pro = 0, st_iter = 0, st_epi = 0, st_segs = 0;
+  HN_T(st_k0);
+#endif
   for (int t = t_lo; t < t_hi; ++t) {
+#if defined(HN_STAMPS)
+    HN_T(st_s0);
+#endif
     __syncthreads();   // previous tile no longer in use
     stage_weights<NW * 64>(a, t, cb, wl, mu);
     __syncthreads();
+#if defined(HN_STAMPS)
+    HN_T(st_s1);
+    st_stage += st_s1 - st_s0;
+#endif
     const float* xh_t = a.xh + (size_t)t * a.N * 3 * H;
     float* gxh_t = a.gxh + (size_t)t * a.N * 3 * H;
     Vec<VW> bias[3];
@@ -539,6 +574,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
     for (int p = 0; p < 3; ++p) bias[p] = Vec<VW>::load(a.brbf + (size_t)t * 3 * H + p * H + col);
 
     for (int r = r0 + wave; r < r1; r += NW) {
+#if defined(HN_STAMPS)
+      HN_T(st_a);
+#endif
       const int beg = a.csc_rowptr[(size_t)t * a.N + r], end = a.csc_rowptr[(size_t)t * a.N + r + 1];
       const float* xr = xh_t + (size_t)r * 3 * H + col;
       Vec<VW> xs = Vec<VW>::load(xr), xa = Vec<VW>::load(xr + H), xb = Vec<VW>::load(xr + 2 * H);
@@ -593,6 +631,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
         };
 
         BwdIn<VW> cur = load_edges(0);
+#if defined(HN_STAMPS)
+        HN_T(st_b);
+        st_pro += st_b - st_a;
+#endif
         for (int it = 0; it < nit; ++it) {
           BwdIn<VW> nxt;
           if (PF == 1) {
@@ -671,6 +713,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
           else if (PF == 2) { load_rows(min(it + 1, nit - 1), cur); cur.g = nxt.g; cur.pos = nxt.pos; cur.live = nxt.live; }
           else if (it + 1 < nit) cur = load_edges(it + 1);
         }
+#if defined(HN_STAMPS)
+        HN_T(st_c);
+        st_iter += st_c - st_b;
+        st_a = st_c;
+#endif
       }
       // combine lane groups; the output rows (gxh s/a/b, gx | gvec[0..2]) are spread over the groups
       const bool known = r < nk;
@@ -716,8 +763,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
           }
         }
       }
+#if defined(HN_STAMPS)
+      HN_TNW(st_d);
+      st_epi += st_d - st_a;
+      st_segs += 1;
+#endif
     }
   }
+#if defined(HN_STAMPS)
+  HN_T(st_k1);
+  if (lane == 0) {
+    atomicAdd(&hn_dbg[0], st_k1 - st_k0); atomicAdd(&hn_dbg[1], st_stage); atomicAdd(&hn_dbg[2], st_pro);
+    atomicAdd(&hn_dbg[3], st_iter); atomicAdd(&hn_dbg[4], st_epi); atomicAdd(&hn_dbg[5], st_segs);
+    atomicAdd(&hn_dbg[6], 1ull);
+  }
+#endif
 }
 
 int fill_args(const hn_graph* g, const hn_rbf_desc* rbf, int hidden, MsgArgs& a) {
@@ -862,7 +922,7 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
                                            const float* wt, const float* brbf, const float* edge,
                                            const float* gx1, const float* gvec1,
                                            float* gxh, float* gvec, float* gx, float* gedge,
-                                           int split_t, void* stream) {
+                                           int split_t, const float* edge_table, void* stream) {
   MsgArgs a = {};
   int rc = fill_args(g, rbf, hidden, a);
   if (rc) return rc;
@@ -870,6 +930,21 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   if (vec && !gvec) return HN_ERR_BAD_ARG;
   if (g->num_edges > 0 && !edge) return HN_ERR_BAD_ARG;
   if (a.N == 0) return HN_OK;
+  static const int use_cl = env_int("HERMNET_BWD_CL", 1);
+  const bool virtual_targets = g->num_src > 0 || g->res_row != nullptr;
+  if (virtual_targets && !edge_table) return HN_ERR_BAD_ARG;      // separate source rows: channel-per-lane form only
+  if (edge_table && (use_cl || virtual_targets) && !split_t) {
+    HnBwdClArgs b = {};
+    b.N = a.N; b.Nsrc = g->num_src > 0 ? g->num_src : a.N; b.E = a.E; b.T = a.T;
+    b.identity = virtual_targets ? 0 : 1;
+    b.csc_rowptr = a.csc_rowptr; b.csc_tgt = a.csc_tgt; b.csc_pos = a.csc_pos;
+    b.R = a.R; b.H = hidden; b.table = edge_table; b.edge = reinterpret_cast<const float4*>(edge);
+    b.xh = xh; b.xh_bias = xh_bias; b.vec = vec; b.wt = wt; b.brbf = brbf; b.gx1 = gx1; b.gvec1 = gvec1;
+    b.gxh = gxh; b.gvec = gvec; b.gx = gx; b.gedge = reinterpret_cast<float4*>(gedge);
+    b.type_rowptr = g->type_rowptr;
+    static const int rpb_cl = env_int("HERMNET_BWD_CL_ROWS", 0);
+    return hn_bwd_cl_launch(b, vec != nullptr, rpb_cl, reinterpret_cast<hipStream_t>(stream));
+  }
   a.xh = xh; a.xh_bias = xh_bias; a.vec = vec; a.wt = wt; a.brbf = brbf;
   a.edge = reinterpret_cast<const float4*>(edge);
   a.gx1 = gx1; a.gvec1 = gvec1; a.gxh = gxh; a.gvec = gvec; a.gx = gx;
@@ -891,3 +966,15 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   hipLaunchKernelGGL(k, grid, dim3(nw * 64), lds, s, a);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
+
+#if defined(HN_STAMPS)
+// diagnostic builds only: read and reset the stamp sums (total, staging, segment prologue, iterations, epilogue,
+// segments, waves)
+extern "C" int hermnet_debug_stamps(unsigned long long* out8) {
+  if (hipDeviceSynchronize() != hipSuccess) return HN_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hn_dbg), 8 * sizeof(unsigned long long)) != hipSuccess) return HN_ERR_LAUNCH;
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(hn_dbg), z, sizeof(z)) != hipSuccess) return HN_ERR_LAUNCH;
+  return HN_OK;
+}
+#endif

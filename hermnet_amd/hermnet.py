@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 from .elements import atomic_numbers
-from .ops import EdgeGeometry, TrueEdgeGradient
+from .ops import EdgeGeometry, TrueEdgeGradient, edge_radial_table
 from .relations import RelationalGraph
 from .sharding import HaloExchange, HaloExchangeFeatures, SumAcrossRanks
 from .layer import EdgeFanout, EdgeGradSink, EnergyHead, FusedRelationalLayer, LayerWeights
@@ -156,6 +156,9 @@ class HVNet(nn.Module):
         if not fused and not train:
             edge = TrueEdgeGradient.apply(edge)      # autograd's (rhat, d) gradients -> Cartesian for the kernel
         data._hn_graph, data._hn_edge, data._hn_rbf = graph, edge, rbf
+        if fused and edge.requires_grad and edge.is_cuda:
+            # forces wanted: the backward message kernels read the radial quantities of an edge from this table
+            graph.edge_table = edge_radial_table(rbf, edge.detach())
         # rmnet.py:168-172 for the optional bases only: [E,R] basis from the kernel's distances
         data._hn_edge_embed = None if fused else self.radial_basis(edge[:, 3])
         data.x, data.vec = x, vec
@@ -195,10 +198,13 @@ class HVNet(nn.Module):
         if shard is not None:
             own = shard.owned_mask.to(per_atom_energy.dtype)
             e_own = per_atom_energy * own
-            energy = torch.zeros(shard.num_graphs, dtype=e_own.dtype, device=x.device).index_add(0, batch, e_own)
+            if shard.num_graphs == 1:      # one structure (the sharded MD case): ordered sums, bit-reproducible
+                energy, cnt = e_own.sum().reshape(1), own.sum().reshape(1)
+            else:                          # (index_add accumulates with atomics: order-dependent last bits)
+                energy = torch.zeros(shard.num_graphs, dtype=e_own.dtype, device=x.device).index_add(0, batch, e_own)
+                cnt = torch.zeros(shard.num_graphs, dtype=e_own.dtype, device=x.device).index_add(0, batch, own)
             energy = SumAcrossRanks.apply(energy, shard.group)
             if self.intensive:
-                cnt = torch.zeros(shard.num_graphs, dtype=e_own.dtype, device=x.device).index_add(0, batch, own)
                 energy = energy / SumAcrossRanks.apply(cnt, shard.group).clamp(min=1)
             return energy
         # scatter(per_atom_energy, batch, reduce=sum|mean) (hermnet.py:130) as an ordered segment

@@ -94,7 +94,7 @@ def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge):
     _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"),
                        lambda: lib.hermnet_message_scatter_bwd(
                            ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(w.b2), P(vec), P(w.wt), P(w.brbf), P(edge),
-                           P(gx1), P(gvec1), P(gxh), P(gvec), P(gx), P(gedge), split, _stream())),
+                           P(gx1), P(gvec1), P(gxh), P(gvec), P(gx), P(gedge), split, P(graph.edge_table), _stream())),
                "hermnet_message_scatter_bwd")
     if split and gvec is not None:
         gvec = gvec.sum(0)

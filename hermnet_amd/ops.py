@@ -196,7 +196,19 @@ class MessageScatter(torch.autograd.Function):
         _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"), lambda: lib.hermnet_message_scatter_bwd(
             ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), None, _lib.ptr(vec), _lib.ptr(wt), _lib.ptr(brbf),
             _lib.ptr(edge), _lib.ptr(gx1), _lib.ptr(gvec1), _lib.ptr(gxh), _lib.ptr(gvec), _lib.ptr(gx),
-            _lib.ptr(gedge), split, _stream())), "hermnet_message_scatter_bwd")
+            _lib.ptr(gedge), split, _lib.ptr(graph.edge_table), _stream())), "hermnet_message_scatter_bwd")
         if split and gvec is not None:
             gvec = gvec.sum(0)
         return gxh, gvec, gx, gedge.sum(0), None, None, None, None
+
+
+def edge_radial_table(rbf, edge):
+    """[E,32] per-edge radial record (window start, 12 tap pairs, envelope factors, unit vector) for the
+    channel-per-lane backward kernel; ONE launch per step -- geometry and radial basis are the same for every layer
+    (`include/hermnet_hip.h`: hermnet_edge_radial_table)."""
+    E = edge.size(0)
+    table = torch.empty(E, 32, dtype=torch.float32, device=edge.device)
+    rs = rbf.struct()
+    _lib.check(_launch("edge_radial_table", lambda: _lib.load().hermnet_edge_radial_table(
+        ctypes.byref(rs), _lib.ptr(edge), E, _lib.ptr(table), _stream())), "hermnet_edge_radial_table")
+    return table

@@ -48,11 +48,15 @@ class RelationalGraph(object):
     __slots__ = ("N", "E", "T", "num_atoms", "uniform", "block", "node_order", "row_of_node", "z_rows",
                  "type_rowptr", "type_rowptr_host", "csr_rowptr", "csr_src", "csr_perm", "csc_rowptr", "csc_tgt",
                  "csc_pos", "out_rowptr", "out_edges", "src_id", "tgt_id", "shift", "row_active", "row_real",
-                 "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device", "_cstruct", "_rel_bounds")
+                 "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device", "_cstruct", "_rel_bounds",
+                 "edge_table", "num_src", "res_row")
 
     def __init__(self):
         self._cstruct = None
         self._rel_bounds = None
+        self.edge_table = None     # [E,32] per-edge radial record of the current step (set by HVNet.forward)
+        self.num_src = 0           # separate source-row space (HTNet): rows of xh / vec; 0 = same rows as the targets
+        self.res_row = None        # [N] int32 source row feeding the residual of each target row, or None
 
     def rel_edge_bounds(self):
         """CSR edge ranges of the relations: edges of relation t are [b[t], b[t+1]) (rows are relation-ordered and
@@ -269,4 +273,4 @@ class RelationalGraph(object):
     def _make_struct(self, _lib):
         return _lib.Graph(self.N, self.E, self.T, self.type_rowptr.data_ptr(), self.csr_rowptr.data_ptr(),
                           self.csr_src.data_ptr(), self.csc_rowptr.data_ptr(), self.csc_tgt.data_ptr(),
-                          self.csc_pos.data_ptr())
+                          self.csc_pos.data_ptr(), self.num_src, None if self.res_row is None else self.res_row.data_ptr())

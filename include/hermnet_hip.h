@@ -73,6 +73,10 @@ typedef struct hn_graph {
   const int* csc_rowptr;      /* [T*N+1] by (relation(target), source row) */
   const int* csc_tgt;         /* [E]    target row of each CSC edge */
   const int* csc_pos;         /* [E]    CSR position of each CSC edge */
+  /* Separate source-row space (HTNet: a target atom appears once per triadic relation, "virtual" target rows,
+   * while sources stay one row per atom).  num_src = 0 and res_row = NULL: sources and targets share rows (HVNet). */
+  int num_src;                /* rows of xh / vec / gxh / gvec and of csr_src, csc_rowptr ([T*num_src+1]); 0 = num_nodes */
+  const int* res_row;         /* [N] source row whose (x, vec) enter the residual of target row r (rmnet.py:24-26), or NULL = r */
 } hn_graph;
 
 /* ---- A16 / K18-K19: neighbor_search (data.py:14-24; ase primitive_neighbor_list / torch_cluster
@@ -185,7 +189,17 @@ int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc* rbf, int h
                                 const float* xh, const float* xh_bias, const float* vec,
                                 const float* wt, const float* brbf, const float* edge,
                                 const float* gx1, const float* gvec1,
-                                float* gxh, float* gvec, float* gx, float* gedge, int split_t, void* stream);
+                                float* gxh, float* gvec, float* gx, float* gedge, int split_t,
+                                const float* edge_table, void* stream);
+
+/* Per-edge radial record, computed ONCE per step (geometry and radial basis are shared by every layer and by both
+ * directions): table [E, 32] floats in CSR order =
+ *   [2m], [2m+1]  g_m = exp(coeff (u - mu_{lo+m})^2), g_m (u - mu_{lo+m})   for the 12 taps m of the edge's window
+ *   [24] padded tile row of tap 0 (int bits) | [25] env(u) | [26] env'(u)/rc | [27] 2 coeff env(u)/rc | [28..30] rhat | [31] 1/d
+ * (rmnet.py:156-193 evaluated exactly as the message kernels do in registers).  When `edge_table` is handed to
+ * hermnet_message_scatter_bwd (NULL = not available) the backward runs in its channel-per-lane form, which reads
+ * the record through the scalar path: a wave works on one edge, its taps sit in SGPRs (csrc/message_bwd_cl.hip). */
+int hermnet_edge_radial_table(const hn_rbf_desc* rbf, const float* edge, int num_edges, float* table, void* stream);
 
 /* ---- node-level fused elementwise stages (A11/A12; the GEMMs between them are library calls) ----
  * Bias convention of these stages: the GEMM in front of a stage may run WITHOUT its bias (a GEMM with a

@@ -56,11 +56,14 @@ def test_edge_geometry_fwd_bwd(name):
     assert rel_err(gp, ref) < 1e-5
 
 
+@pytest.mark.parametrize("bwd_form", ["channel-per-lane", "vw"])
 @pytest.mark.parametrize("name,has_vec", [("c1_si64", True), ("c1_si64", False), ("c1_si64_refcompat", True),
                                           ("alloy108", True), ("alloy108_unknown_type", True),
                                           ("alloy108_h64", True), ("alloy32_h256", True), ("mol16", True)])
-def test_message_scatter_op(name, has_vec):
-    """Forward and backward of the fused operator vs the dense PyTorch restatement (fp64 reference)."""
+def test_message_scatter_op(name, has_vec, bwd_form):
+    """Forward and backward of the fused operator vs the dense PyTorch restatement (fp64 reference); both forms of
+    the backward kernel (with the per-edge radial table: one edge per wave, taps in SGPRs; without: 16 lanes per edge)."""
+    from hermnet_amd.ops import edge_radial_table
     dev = _dev()
     g = Golden(name)
     d, graph = _graph(g, dev)
@@ -74,6 +77,7 @@ def test_message_scatter_op(name, has_vec):
     wt = (rnd(T, R, 3 * H) / math.sqrt(R)).contiguous()
     brbf = (0.1 * rnd(T, 3 * H)).contiguous()
     edge = EdgeGeometry.apply(d.pos, d.get("cell"), graph)
+    graph.edge_table = edge_radial_table(rbf, edge) if bwd_form == "channel-per-lane" else None
 
     xh.requires_grad_(True); x.requires_grad_(True)
     if has_vec:
@@ -380,7 +384,10 @@ def test_bias_on_load_equals_bias_in_operand():
     lib, P = _lib.load(), _lib.ptr
     gs, rs = graph.as_struct(), rbf.struct()
 
-    def run(xh_in, bias, v):
+    from hermnet_amd.ops import edge_radial_table
+    table = edge_radial_table(rbf, edge)
+
+    def run(xh_in, bias, v, tab=None):
         x1, vec1 = torch.empty_like(x), torch.empty(N, 3, H, device=dev)
         assert lib.hermnet_message_scatter_fwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh_in), P(bias), P(v), P(x), P(wt),
                                                P(brbf), P(edge), P(x1), P(vec1), _stream()) == 0
@@ -388,12 +395,16 @@ def test_bias_on_load_equals_bias_in_operand():
         gedge = torch.zeros(H // 64, graph.E, 4, device=dev)
         assert lib.hermnet_message_scatter_bwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh_in), P(bias), P(v), P(wt), P(brbf),
                                                P(edge), P(gx1), P(gv1), P(gxh), P(gvec if v is not None else None), P(gx),
-                                               P(gedge), 0, _stream()) == 0
+                                               P(gedge), 0, P(tab), _stream()) == 0
         return [x1, vec1, gxh, gx, gedge.sum(0)] + ([gvec] if v is not None else [])
 
     for v in (vec, None):
-        for a, b in zip(run(xh, xb, v), run(xh + xb[:, None, :], None, v)):
-            assert rel_err(a, b) < 1e-6
+        for tab in (None, table):
+            for a, b in zip(run(xh, xb, v, tab), run(xh + xb[:, None, :], None, v, tab)):
+                assert rel_err(a, b) < 1e-6
+        # the two forms of the backward kernel agree with each other (different summation orders: not bit for bit)
+        for a, b in zip(run(xh, xb, v, None), run(xh, xb, v, table)):
+            assert rel_err(a, b) < 2e-6
 
 
 @pytest.mark.parametrize("name", ["alloy108", "alloy108_unknown_type", "mol16"])

@@ -16,17 +16,19 @@ from helpers import Golden, rel_err
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _patch_cpu_ops():
+def _patch_cpu_ops(monkeypatch=None):
+    """Kernels -> PyTorch restatements.  Worker processes patch for good; the pytest process passes `monkeypatch`."""
     import hermnet_amd.hermnet as hmod
     import hermnet_amd.layer as lmod
     import ref_ops
-    hmod.HVNet._require_device = staticmethod(lambda pos: None)
-    hmod.EdgeGeometry = ref_ops.RefEdgeGeometry
+    put = (lambda o, n, v: setattr(o, n, v)) if monkeypatch is None else monkeypatch.setattr
+    put(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
+    put(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
     for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid", "update_out", "update_out_bwd",
                "update_mid_bwd"]:
-        setattr(lmod.nodeops, fn, getattr(ref_ops, fn))
-    lmod._msg_fwd = ref_ops.msg_fwd
-    lmod._msg_bwd = ref_ops.msg_bwd
+        put(lmod.nodeops, fn, getattr(ref_ops, fn))
+    put(lmod, "_msg_fwd", ref_ops.msg_fwd)
+    put(lmod, "_msg_bwd", ref_ops.msg_bwd)
 
 
 def _worker(rank, world, name, port, out):
@@ -270,7 +272,7 @@ def _slab_worker(rank, world, port, out):
 SLAB_KW = dict(rc=5.0, num_layers=3, hidden_channels=64, num_rbf=32)
 
 
-def test_slab_partition_world8_gloo_matches_single_process():
+def test_slab_partition_world8_gloo_matches_single_process(monkeypatch):
     """BASELINE configs[3]'s plan at world size 8 on CPU (gloo): an fcc 3x3x24 cell in 8 slabs of 10.8 A, every
     rank plans from the coordinates alone and searches only its slab; energy and forces must equal the
     single-process evaluation of the whole cell (same host pipeline, kernels restated in PyTorch)."""
@@ -280,7 +282,7 @@ def test_slab_partition_world8_gloo_matches_single_process():
     port = 33500 + os.getpid() % 2000
     out = mp.Manager().dict()
     mp.spawn(_slab_worker, args=(world, port, out), nprocs=world, join=True)
-    _patch_cpu_ops()
+    _patch_cpu_ops(monkeypatch)
     d = synth.fcc_alloy(reps=(3, 3, 24))
     model = hn.HVNet(["Al", "Ni", "Cu"], **SLAB_KW).eval()
     model.load_state_dict(synth.synth_state_dict(model.state_dict(), 3))

@@ -44,10 +44,14 @@ def main():
         return lib.hermnet_message_scatter_fwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(xb), P(v), P(x), P(wt), P(brbf),
                                                P(edge), P(x1), P(vec1), _stream())
 
+    # KBENCH_TABLE=0: without the per-edge radial table the backward takes its 16-lanes-per-edge (VW) form
+    from hermnet_amd.ops import edge_radial_table
+    table = edge_radial_table(rbf, edge) if os.environ.get("KBENCH_TABLE", "1") != "0" else None
+
     def bwd(v):
         return lib.hermnet_message_scatter_bwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(xb), P(v), P(wt), P(brbf), P(edge),
                                                P(gx1), P(gvec1), P(gxh), P(gvec if v is not None else None), P(gx),
-                                               P(gedge), split, _stream())
+                                               P(gedge), split, P(table), _stream())
 
     ab = algorithmic_bytes(E, N, H, T)
     res = {}
@@ -65,7 +69,16 @@ def main():
         ms = a.elapsed_time(b) / iters
         res[name] = ms
         print("%-24s %8.3f ms  %7.1f GB/s (algorithmic)" % (name, ms, ab[name] / 1e6 / ms))
-    knobs = {k: v for k, v in os.environ.items() if k.startswith("HERMNET_")}
+        if hasattr(lib, "hermnet_debug_stamps") and "bwd" in name:      # diagnostic build (-DHN_STAMPS)
+            buf = (ctypes.c_ulonglong * 8)()
+            lib.hermnet_debug_stamps(buf)
+            tot, stage, pro, it, epi, segs, waves = [float(v) for v in buf[:7]]
+            if tot > 0:
+                print("   stamps: per wave %.0f cycles; staging %.1f%% | segment prologue %.1f%% | iterations %.1f%% | "
+                      "epilogue %.1f%% | other %.1f%%; per segment: prologue %.0f, iterations %.0f, epilogue %.0f cycles"
+                      % (tot / waves, 100 * stage / tot, 100 * pro / tot, 100 * it / tot, 100 * epi / tot,
+                         100 * (tot - stage - pro - it - epi) / tot, pro / segs, it / segs, epi / segs))
+    knobs = {k: v for k, v in os.environ.items() if k.startswith("HERMNET_") or k.startswith("KBENCH_")}
     print("knobs", knobs, "checksum", float(x1.sum() + vec1.sum()), float(gxh.sum() + gvec.sum() + gedge.sum()))
 
 
