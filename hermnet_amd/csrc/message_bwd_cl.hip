@@ -27,6 +27,13 @@
 #include "hermnet_math.h"
 #include "message_bwd_cl.h"
 
+#if defined(HN_STAMPS)
+// Diagnostic build only (tools/build_variant.sh <name> -DHN_STAMPS): cycle sums per phase, read with hermnet_debug_stamps_cl.
+__device__ unsigned long long hn_dbg_cl[12];
+#define HN_TS(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define HN_TSV(var) unsigned long long var; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#endif
+
 namespace {
 
 typedef float hn_f2 __attribute__((ext_vector_type(2)));
@@ -88,26 +95,32 @@ __device__ __forceinline__ float reduce4(float e0, float e1, float e2, float e3)
   return v;
 }
 
-// Six consecutive tap rows of this lane's weight record, each ONE ds_read_b128 (4 LDS cycles, conflict-free).
-// Written as asm because hipcc narrows a float4 LDS load whose .w is unused to ds_read_b96 (8 LDS cycles, and the LDS
-// port is the second-busiest unit of this kernel); the wait is part of the same statement, so no use can be
-// scheduled in front of it.  `addr` = byte address in LDS (the dynamic region starts at 0: no static LDS here).
+// The 12 tap rows of this lane's weight record are fetched in three groups of four, each row ONE ds_read_b128
+// (4 LDS cycles, conflict-free), two groups in flight: group g+1 is requested before group g is waited for, so only
+// the first group's LDS latency is exposed.  Written as asm because (i) hipcc narrows a float4 LDS load whose .w is
+// unused to ds_read_b96 (8 LDS cycles; the LDS port is the second-busiest unit of this kernel) and (ii) the counted
+// waits must sit exactly between the groups.  No scalar-memory load is in flight while these run (the next edge's
+// record is requested after the contraction), so lgkmcnt counts LDS reads only and they return in order.
+// Every wait statement takes the registers it releases as "+v" operands: no use can be scheduled in front of it.
 typedef float hn_f4 __attribute__((ext_vector_type(4)));
-template <int DUMMY>
-__device__ __forceinline__ void lds_read6(unsigned addr, hn_f4 (&w)[6]) {
+__device__ __forceinline__ void lds_issue4(unsigned addr, hn_f4 (&w)[4]) {
   asm volatile(
-      "ds_read_b128 %0, %6\n\t"
-      "ds_read_b128 %1, %6 offset:1024\n\t"
-      "ds_read_b128 %2, %6 offset:2048\n\t"
-      "ds_read_b128 %3, %6 offset:3072\n\t"
-      "ds_read_b128 %4, %6 offset:4096\n\t"
-      "ds_read_b128 %5, %6 offset:5120\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5])
+      "ds_read_b128 %0, %4\n\t"
+      "ds_read_b128 %1, %4 offset:1024\n\t"
+      "ds_read_b128 %2, %4 offset:2048\n\t"
+      "ds_read_b128 %3, %4 offset:3072"
+      : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
       : "v"(addr)
       : "memory");
 }
-static_assert(HN_CB * 16 == 1024, "lds_read6 hard-codes the 1 KiB tap-row pitch");
+template <int PENDING>   // wait until at most PENDING newer LDS reads are outstanding; releases w
+__device__ __forceinline__ void lds_wait(hn_f4 (&w)[4]) {
+  if (PENDING == 4)
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) :: "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) :: "memory");
+}
+static_assert(HN_CB * 16 == 1024 && HN_TAPS == 12, "the tap reader hard-codes the 1 KiB row pitch and 3 x 4 taps");
 
 struct EdgeIn {          // what one edge needs from memory (vector part)
   float gx1, g0, g1, g2;
@@ -134,7 +147,14 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
   // LDS byte address of this lane's record in tap row 0 (the tile starts the dynamic region)
   const unsigned tile_lane = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)tile) + (unsigned)lane * 16u;
 
+#if defined(HN_STAMPS)
+  unsigned long long st_stage = 0, st_pro = 0, st_rec = 0, st_con = 0, st_alg = 0, st_red = 0, st_epi = 0, st_edges = 0, st_segs = 0;
+  HN_TS(st_k0);
+#endif
   for (int t = 0; t < a.T; ++t) {
+#if defined(HN_STAMPS)
+    HN_TS(st_s0);
+#endif
     __syncthreads();                                 // previous tile and counter no longer in use
     // ---- stage the weight tile of (relation t, column block cb): rows outside [0, R) are zero
     for (int idx = threadIdx.x; idx < tile_rows * HN_CB; idx += blockDim.x) {
@@ -148,6 +168,10 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
     }
     if (threadIdx.x == 0) *counter = 0;
     __syncthreads();
+#if defined(HN_STAMPS)
+    HN_TS(st_s1);
+    st_stage += st_s1 - st_s0;
+#endif
 
     const float* xh_t = a.xh + (size_t)t * a.Nsrc * 3 * H;
     float* gxh_t = a.gxh + (size_t)t * a.Nsrc * 3 * H;
@@ -166,6 +190,9 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
     rr = __builtin_amdgcn_readfirstlane(rr);
     while (r0 + rr < r1) {
       const int r = r0 + rr;
+#if defined(HN_STAMPS)
+      HN_TS(st_a);
+#endif
       int rr_next = 0;
       if (lane == 0) rr_next = atomicAdd(counter, 1);             // the next row's index: its latency hides below
       const int beg = rowptr_t[r], end = rowptr_t[r + 1];
@@ -202,37 +229,75 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
           in.g0 = gvr[0]; in.g1 = gvr[H]; in.g2 = gvr[2 * H];
           return in;
         };
+        // the record of an edge is wave-uniform and read-only here: through the constant address space its loads
+        // are scalar (s_load_dwordx8 into SGPRs), not 64 lanes fetching the same bytes
+        auto load_record = [&](int k, float (&rec)[kRec]) {
+          const int p = __builtin_amdgcn_readlane(my_pos, k);
+          const hn_cfloat* rp = (const hn_cfloat*)(a.table + (size_t)p * kRec);
+#pragma unroll
+          for (int q = 0; q < kRec; ++q) rec[q] = rp[q];
+        };
 
         EdgeIn cur = load_edge(0);
+        float rec[kRec];
+        load_record(0, rec);
+#if defined(HN_STAMPS)
+        HN_TSV(st_b);
+        st_pro += st_b - st_a;
+#endif
         for (int k4 = 0; k4 < cnt; k4 += 4) {
           float pd[4], px[4], py[4], pz[4];
+          // geometry of the edge this DPP row will write (rows hold edges 0, 2, 1, 3 of the group): requested now,
+          // used after the group's arithmetic
+          const int je = (row16 == 0) ? 0 : (row16 == 1 ? 2 : (row16 == 2 ? 1 : 3));
+          const int pw = __shfl(my_pos, min(k4 + je, cnt - 1), 64);
+          const float4 gw = a.edge[pw];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             pd[j] = 0.f; px[j] = 0.f; py[j] = 0.f; pz[j] = 0.f;
             const int k = k4 + j;
             if (k < cnt) {                                          // wave-uniform
               const EdgeIn nxt = load_edge(min(k + 1, cnt - 1));    // the next edge's rows fly during this edge's math
-              const int p = __builtin_amdgcn_readlane(my_pos, k);
-              // the record is wave-uniform and read-only here: through the constant address space its loads are
-              // scalar (s_load_dwordx8 into SGPRs), not 64 lanes fetching the same bytes
-              const hn_cfloat* rec = (const hn_cfloat*)(a.table + (size_t)p * kRec);
-              const int row = __float_as_int(rec[24]);
-              const float envv = rec[25], c0 = rec[26], c1 = rec[27], rx = rec[28], ry = rec[29], rz = rec[30];
-              // (S0, S1) of the three parts: 12 taps, one LDS read each
+#if defined(HN_STAMPS)
+              HN_TS(st_e0);
+              asm volatile("" :: "s"(rec[24]), "s"(rec[25]), "s"(rec[30]));          // the record has arrived
+              HN_TS(st_e1);
+              st_rec += st_e1 - st_e0;
+#endif
+              // ---- (S0, S1) of the three parts: 12 taps, one LDS read each, in three pipelined groups
+              const unsigned waddr = (unsigned)__float_as_int(rec[24]) * (HN_CB * 16) + tile_lane;
               hn_f2 Ss = {0.f, 0.f}, Sa = {0.f, 0.f}, Sb = {0.f, 0.f};
-              const unsigned waddr = (unsigned)row * (HN_CB * 16) + tile_lane;
+              hn_f4 wA[4], wB[4];
+              auto taps4 = [&](int m0, const hn_f4 (&w)[4]) {
 #pragma unroll
-              for (int m0 = 0; m0 < HN_TAPS; m0 += 6) {
-                hn_f4 w[6];
-                lds_read6<0>(waddr + m0 * (HN_CB * 16), w);
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
+                for (int q = 0; q < 4; ++q) {
                   const hn_f2 g = {rec[2 * (m0 + q)], rec[2 * (m0 + q) + 1]};
                   Ss = __builtin_elementwise_fma(g, hn_f2{w[q].x, w[q].x}, Ss);
                   if (HAS_VEC) Sa = __builtin_elementwise_fma(g, hn_f2{w[q].y, w[q].y}, Sa);
                   Sb = __builtin_elementwise_fma(g, hn_f2{w[q].z, w[q].z}, Sb);
                 }
-              }
+              };
+              lds_issue4(waddr, wA);
+              lds_issue4(waddr + 4 * (HN_CB * 16), wB);
+              lds_wait<4>(wA);
+              taps4(0, wA);
+              asm volatile("" : "+v"(Ss), "+v"(Sb));                // taps 0-3 are consumed before wA is refilled
+              lds_issue4(waddr + 8 * (HN_CB * 16), wA);
+              lds_wait<4>(wB);
+              taps4(4, wB);
+              lds_wait<0>(wA);
+              taps4(8, wA);
+              const float envv = rec[25], c0 = rec[26], c1 = rec[27], rx = rec[28], ry = rec[29], rz = rec[30];
+#if defined(HN_STAMPS)
+              asm volatile("" :: "v"(Ss), "v"(Sb));
+              HN_TS(st_e2);
+              st_con += st_e2 - st_e1;
+#endif
+              // the taps are consumed: request the NEXT edge's record into the same scalar registers; its latency
+              // hides behind the rest of this edge (the six scalars still needed were copied above)
+              __builtin_amdgcn_sched_barrier(0);
+              load_record(min(k + 1, cnt - 1), rec);
+              __builtin_amdgcn_sched_barrier(0);
               const float gdx = cur.gx1 * inv_sqrt2;
               const float g0 = cur.g0, g1 = cur.g1, g2 = cur.g2;
               // ---- part s: dx = sum xs * rs
@@ -258,25 +323,38 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
               pdv = fmaf(B * xb, drb, pdv);
               const float q = xb * rb * inv_sqrth;
               pd[j] = pdv; px[j] = g0 * q; py[j] = g1 * q; pz[j] = g2 * q;   // per channel: dE/dd, dE/drhat
+#if defined(HN_STAMPS)
+              asm volatile("" :: "v"(pd[j]), "v"(px[j]), "v"(gb));
+              HN_TS(st_e3);
+              st_alg += st_e3 - st_e2;
+              st_edges += 1;
+#endif
               cur = nxt;
             }
           }
           // ---- dE/dD of these (up to) four edges: channel sums, then Cartesian form, one 16-byte store per edge
+#if defined(HN_STAMPS)
+          HN_TS(st_r0);
+#endif
           const float sd = reduce4(pd[0], pd[1], pd[2], pd[3]);
           const float sx = reduce4(px[0], px[1], px[2], px[3]);
           const float sy = reduce4(py[0], py[1], py[2], py[3]);
           const float sz = reduce4(pz[0], pz[1], pz[2], pz[3]);
-          const int je = (row16 == 0) ? 0 : (row16 == 1 ? 2 : (row16 == 2 ? 1 : 3));   // edge held by this DPP row
-          const int p = __shfl(my_pos, min(k4 + je, cnt - 1), 64);                      // (all lanes active here)
           if ((lane & 15) == 0 && k4 + je < cnt) {
-            const float4 g = a.edge[p];
-            const float invd = __builtin_amdgcn_rcpf(g.w);
-            const float dotp = sx * g.x + sy * g.y + sz * g.z;
+            const float invd = __builtin_amdgcn_rcpf(gw.w);
+            const float dotp = sx * gw.x + sy * gw.y + sz * gw.z;
             // d = |D|, rhat = D/d:  gD = pd rhat + (pr - (pr.rhat) rhat) / d
             const float tpar = sd - dotp * invd;
-            gedge[p] = make_float4(fmaf(tpar, g.x, sx * invd), fmaf(tpar, g.y, sy * invd), fmaf(tpar, g.z, sz * invd), 0.f);
+            gedge[pw] = make_float4(fmaf(tpar, gw.x, sx * invd), fmaf(tpar, gw.y, sy * invd), fmaf(tpar, gw.z, sz * invd), 0.f);
           }
+#if defined(HN_STAMPS)
+          HN_TS(st_r1);
+          st_red += st_r1 - st_r0;
+#endif
         }
+#if defined(HN_STAMPS)
+        { HN_TS(st_c); st_a = st_c; }
+#endif
       }
       // ---- segment epilogue: every lane owns its channel, plain coalesced stores
       float* go = gxh_t + (size_t)r * 3 * H + c;
@@ -287,8 +365,22 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
         gvo[0] = prev0 + gv0; gvo[H] = prev1 + gv1; gvo[2 * H] = prev2 + gv2;
       }
       rr = __builtin_amdgcn_readfirstlane(rr_next);
+#if defined(HN_STAMPS)
+      HN_TS(st_d);
+      st_epi += st_d - st_a;
+      st_segs += 1;
+#endif
     }
   }
+#if defined(HN_STAMPS)
+  HN_TSV(st_k1);
+  if (lane == 0) {
+    atomicAdd(&hn_dbg_cl[0], st_k1 - st_k0); atomicAdd(&hn_dbg_cl[1], st_stage); atomicAdd(&hn_dbg_cl[2], st_pro);
+    atomicAdd(&hn_dbg_cl[3], st_rec); atomicAdd(&hn_dbg_cl[4], st_con); atomicAdd(&hn_dbg_cl[5], st_alg);
+    atomicAdd(&hn_dbg_cl[6], st_red); atomicAdd(&hn_dbg_cl[7], st_epi); atomicAdd(&hn_dbg_cl[8], st_edges);
+    atomicAdd(&hn_dbg_cl[9], st_segs); atomicAdd(&hn_dbg_cl[10], 1ull);
+  }
+#endif
 }
 
 int num_cus() {
@@ -347,3 +439,13 @@ extern "C" int hermnet_edge_radial_table(const hn_rbf_desc* rbf, const float* ed
                      rbf->env_kind, rbf->env_p, table);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
+
+#if defined(HN_STAMPS)
+extern "C" int hermnet_debug_stamps_cl(unsigned long long* out12) {
+  if (hipDeviceSynchronize() != hipSuccess) return HN_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(hn_dbg_cl), 12 * sizeof(unsigned long long)) != hipSuccess) return HN_ERR_LAUNCH;
+  unsigned long long z[12] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(hn_dbg_cl), z, sizeof(z)) != hipSuccess) return HN_ERR_LAUNCH;
+  return HN_OK;
+}
+#endif

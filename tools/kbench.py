@@ -69,7 +69,18 @@ def main():
         ms = a.elapsed_time(b) / iters
         res[name] = ms
         print("%-24s %8.3f ms  %7.1f GB/s (algorithmic)" % (name, ms, ab[name] / 1e6 / ms))
-        if hasattr(lib, "hermnet_debug_stamps") and "bwd" in name:      # diagnostic build (-DHN_STAMPS)
+        if hasattr(lib, "hermnet_debug_stamps_cl") and "bwd" in name and table is not None:
+            buf = (ctypes.c_ulonglong * 12)()
+            lib.hermnet_debug_stamps_cl(buf)
+            tot, stage, pro, rec, con, alg, red, epi, edges, segs, waves = [float(v) for v in buf[:11]]
+            if tot > 0:
+                print("   stamps(cl): per wave %.0f cycles; staging %.1f%% | seg prologue %.1f%% | record wait %.1f%% | contraction "
+                      "%.1f%% | algebra %.1f%% | reduce+store %.1f%% | epilogue+tail %.1f%%;  per edge: record %.0f, "
+                      "contraction %.0f, algebra %.0f, reduce %.0f; per segment: prologue %.0f, epilogue %.0f; edges/seg %.1f"
+                      % (tot / waves, 100 * stage / tot, 100 * pro / tot, 100 * rec / tot, 100 * con / tot, 100 * alg / tot,
+                         100 * red / tot, 100 * epi / tot, rec / edges, con / edges, alg / edges, red / edges, pro / segs,
+                         epi / segs, edges / segs))
+        elif hasattr(lib, "hermnet_debug_stamps") and "bwd" in name:      # diagnostic build (-DHN_STAMPS)
             buf = (ctypes.c_ulonglong * 8)()
             lib.hermnet_debug_stamps(buf)
             tot, stage, pro, it, epi, segs, waves = [float(v) for v in buf[:7]]
