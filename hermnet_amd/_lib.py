@@ -47,7 +47,7 @@ SIGNATURES = {
                                                    c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "hermnet_message_scatter_bwd": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), ctypes.c_int,
                                                    c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
-                                                   c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
+                                                   c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),
     "hermnet_edge_radial_table": (ctypes.c_int, [ctypes.POINTER(RbfDesc), c_fp, ctypes.c_int, c_fp, c_fp]),
     "hermnet_neighbor_workspace": (ctypes.c_size_t, [ctypes.c_int]),
     "hermnet_neighbor_sort_workspace": (ctypes.c_size_t, [ctypes.c_long]),

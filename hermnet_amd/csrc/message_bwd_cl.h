@@ -7,8 +7,8 @@
 
 struct HnBwdClArgs {
   int N, Nsrc, E, T;         // target rows, source rows, edges, relations
-  const int* type_rowptr;    // [T+1] device: rows below type_rowptr[T] are targets of a known type
   int identity;              // 1: source and target rows coincide, the residual's identity gradient is added here
+  const int* type_rowptr;    // [T+1] device: rows below type_rowptr[T] are targets of a known type
   const int* csc_rowptr;     // [T*Nsrc+1]
   const int* csc_tgt;        // [E]
   const int* csc_pos;        // [E]
@@ -23,7 +23,8 @@ struct HnBwdClArgs {
   const float* gx1;          // [N, H]
   const float* gvec1;        // [N, 3, H]
   float* gxh;                // [T, Nsrc, 3H]
-  float* gvec;               // [Nsrc, 3, H] or null
+  float* gvec;               // workspace [T, Nsrc, 3, H] partial sums per relation (null when vec is null)
+  float* gvec_out;           // [Nsrc, 3, H] or null
   float* gx;                 // [Nsrc, H]
   float4* gedge;             // [H/64, E]
   int rows_per_block;

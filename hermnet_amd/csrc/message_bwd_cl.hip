@@ -27,13 +27,6 @@
 #include "hermnet_math.h"
 #include "message_bwd_cl.h"
 
-#if defined(HN_STAMPS)
-// Diagnostic build only (tools/build_variant.sh <name> -DHN_STAMPS): cycle sums per phase, read with hermnet_debug_stamps_cl.
-__device__ unsigned long long hn_dbg_cl[12];
-#define HN_TS(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
-#define HN_TSV(var) unsigned long long var; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
-#endif
-
 namespace {
 
 typedef float hn_f2 __attribute__((ext_vector_type(2)));
@@ -79,13 +72,14 @@ __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
 
-// 64-lane totals of one quantity of FOUR edges at once: on return every lane of 16-lane row k holds the total of
-// edge {0, 2, 1, 3}[k].
-__device__ __forceinline__ float reduce4(float e0, float e1, float e2, float e3) {
-  const hn_u2 s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(e0), __float_as_uint(e1), false, false);
-  const hn_u2 s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(e2), __float_as_uint(e3), false, false);
-  const float u = __uint_as_float(s01[0]) + __uint_as_float(s01[1]);   // halves: e0 | e1
-  const float w = __uint_as_float(s23[0]) + __uint_as_float(s23[1]);   // halves: e2 | e3
+// 64-lane totals of one quantity of FOUR edges, in two stages so that only one register per quantity stays live
+// between edge pairs: pair_fold(e0, e1) -> halves hold 32-lane partial sums of e0 | e1; quad_total(u01, u23) -> every
+// lane of 16-lane row k holds the total of edge {0, 2, 1, 3}[k].
+__device__ __forceinline__ float pair_fold(float e0, float e1) {
+  const hn_u2 s = __builtin_amdgcn_permlane32_swap(__float_as_uint(e0), __float_as_uint(e1), false, false);
+  return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+__device__ __forceinline__ float quad_total(float u, float w) {
   const hn_u2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(u), __float_as_uint(w), false, false);
   float v = __uint_as_float(s[0]) + __uint_as_float(s[1]);             // rows: e0, e2, e1, e3
   v += dpp_mov<0xB1>(v);    // lane ^ 1
@@ -122,23 +116,40 @@ __device__ __forceinline__ void lds_wait(hn_f4 (&w)[4]) {
 }
 static_assert(HN_CB * 16 == 1024 && HN_TAPS == 12, "the tap reader hard-codes the 1 KiB row pitch and 3 x 4 taps");
 
+typedef __amdgpu_buffer_rsrc_t hn_rsrc;
+__device__ __forceinline__ float buf_load(hn_rsrc r, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 struct EdgeIn {          // what one edge needs from memory (vector part)
   float gx1, g0, g1, g2;
 };
 
+// One workgroup = (relation t, 64-channel column block, chunk of SOURCE rows): it stages the relation's weight tile
+// once and never synchronises again.  Its 16 waves split the chunk's CSC edge range into 16 equal shares at row
+// boundaries (a row belongs to the wave in whose share its first edge lies), so the waves are balanced to within one
+// segment without a queue, and each wave walks its edges as ONE continuous stream: the per-edge prefetch pipeline
+// (indices 64 at a time, target rows and the scalar record one edge ahead) does not drain at the row boundaries --
+// segments are short (~14 edges), and a wave that restarts its loads per segment spends a third of its time in
+// dependent round trips.  Rows switch in-line: epilogue of the finished row, then the new row's own values.
+// gvec is written per relation ([T, Nsrc, 3, H] partial sums: three workgroups never read-modify-write the same row);
+// message_bwd_finish_kernel adds the T slices in a fixed order together with the residual's identity terms
+// (rmnet.py:24-26: gx = gx1 / sqrt2, gvec += gvec1 on target rows).
 template <bool HAS_VEC>
 __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdClArgs a) {
   extern __shared__ __align__(16) float4 tile[];     // [tap row][64] of (s, a, b, 0)
   const int tile_rows = a.R + 2 * HN_PAD + 1;
-  int* counter = reinterpret_cast<int*>(tile + (size_t)tile_rows * HN_CB);
 
+  const int t = blockIdx.z;
   const int cb = blockIdx.y;
   const int r0 = blockIdx.x * a.rows_per_block;
   const int r1 = min(r0 + a.rows_per_block, a.Nsrc);
   const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
   const int H = a.H;
-  const int c = cb * HN_CB + lane;                   // this lane's channel
-  const int nk = a.type_rowptr[a.T];                 // rows below nk are targets of a known type
+  const unsigned c = (unsigned)(cb * HN_CB + lane);  // this lane's channel (unsigned: zero-extended lane offset, so that
+                                                     // `uniform_base[c]` is a scalar-base + 32-bit-offset access)
   const float inv_sqrt3h = 0.57735026918962576f * rsqrtf((float)H);
   const float inv_sqrth = rsqrtf((float)H);
   const float inv_sqrt2 = 0.70710678118654752f;
@@ -147,240 +158,248 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
   // LDS byte address of this lane's record in tap row 0 (the tile starts the dynamic region)
   const unsigned tile_lane = (unsigned)(unsigned long long)((__attribute__((address_space(3))) char*)tile) + (unsigned)lane * 16u;
 
-#if defined(HN_STAMPS)
-  unsigned long long st_stage = 0, st_pro = 0, st_rec = 0, st_con = 0, st_alg = 0, st_red = 0, st_epi = 0, st_edges = 0, st_segs = 0;
-  HN_TS(st_k0);
-#endif
-  for (int t = 0; t < a.T; ++t) {
-#if defined(HN_STAMPS)
-    HN_TS(st_s0);
-#endif
-    __syncthreads();                                 // previous tile and counter no longer in use
-    // ---- stage the weight tile of (relation t, column block cb): rows outside [0, R) are zero
-    for (int idx = threadIdx.x; idx < tile_rows * HN_CB; idx += blockDim.x) {
-      const int k = idx / HN_CB - HN_PAD, ch = idx % HN_CB;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k >= 0 && k < a.R) {
-        const float* w = a.wt + ((size_t)(t * a.R + k) * 3 * H + cb * HN_CB + ch);
-        v = make_float4(w[0], w[H], w[2 * H], 0.f);
-      }
-      tile[idx] = v;
+  // gathered target rows go through buffer descriptors (the host guarantees both arrays are < 4 GiB)
+  const hn_rsrc rs_gx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gx1), 0, (int)((size_t)a.N * H * 4), 0x00020000);
+  const hn_rsrc rs_gvec1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gvec1), 0, (int)((size_t)a.N * 3 * H * 4), 0x00020000);
+  const unsigned c4 = c * 4u;
+
+  // ---- stage the weight tile of (relation t, column block cb): rows outside [0, R) are zero
+  for (int idx = threadIdx.x; idx < tile_rows * HN_CB; idx += blockDim.x) {
+    const int k = idx / HN_CB - HN_PAD, ch = idx % HN_CB;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k >= 0 && k < a.R) {
+      const float* w = a.wt + ((size_t)(t * a.R + k) * 3 * H + cb * HN_CB + ch);
+      v = make_float4(w[0], w[H], w[2 * H], 0.f);
     }
-    if (threadIdx.x == 0) *counter = 0;
-    __syncthreads();
-#if defined(HN_STAMPS)
-    HN_TS(st_s1);
-    st_stage += st_s1 - st_s0;
-#endif
+    tile[idx] = v;
+  }
 
-    const float* xh_t = a.xh + (size_t)t * a.Nsrc * 3 * H;
-    float* gxh_t = a.gxh + (size_t)t * a.Nsrc * 3 * H;
-    const int* rowptr_t = a.csc_rowptr + (size_t)t * a.Nsrc;
-    const float bs = a.brbf[(size_t)t * 3 * H + c], ba = a.brbf[(size_t)t * 3 * H + H + c],
-                bb = a.brbf[(size_t)t * 3 * H + 2 * H + c];
-    float xbs = 0.f, xba = 0.f, xbb = 0.f;
-    if (a.xh_bias) {
-      xbs = a.xh_bias[(size_t)t * 3 * H + c]; xba = a.xh_bias[(size_t)t * 3 * H + H + c];
-      xbb = a.xh_bias[(size_t)t * 3 * H + 2 * H + c];
-    }
+  const float* xh_t = a.xh + (size_t)t * a.Nsrc * 3 * H;
+  float* gxh_t = a.gxh + (size_t)t * a.Nsrc * 3 * H;
+  float* gvec_t = HAS_VEC ? a.gvec + (size_t)t * a.Nsrc * 3 * H : nullptr;
+  const int* rowptr_t = a.csc_rowptr + (size_t)t * a.Nsrc;
+  const float* brow = a.brbf + (size_t)t * 3 * H;
+  const float bs = brow[c], ba = (brow + H)[c], bb = (brow + 2 * H)[c];
+  float xbs = 0.f, xba = 0.f, xbb = 0.f;
+  if (a.xh_bias) {
+    const float* xrow = a.xh_bias + (size_t)t * 3 * H;
+    xbs = xrow[c]; xba = (xrow + H)[c]; xbb = (xrow + 2 * H)[c];
+  }
 
-    // ---- source rows are pulled from a workgroup-wide counter (wave-uniform)
-    int rr = 0;
-    if (lane == 0) rr = atomicAdd(counter, 1);
-    rr = __builtin_amdgcn_readfirstlane(rr);
-    while (r0 + rr < r1) {
-      const int r = r0 + rr;
-#if defined(HN_STAMPS)
-      HN_TS(st_a);
-#endif
-      int rr_next = 0;
-      if (lane == 0) rr_next = atomicAdd(counter, 1);             // the next row's index: its latency hides below
-      const int beg = rowptr_t[r], end = rowptr_t[r + 1];
-      const float* xr = xh_t + (size_t)r * 3 * H + c;
-      const float xs = xr[0] + xbs, xa = xr[H] + xba, xb = xr[2 * H] + xbb;
-      float vj0 = 0.f, vj1 = 0.f, vj2 = 0.f;
-      if (HAS_VEC) {
-        const float* vr = a.vec + (size_t)r * 3 * H + c;
-        vj0 = vr[0]; vj1 = vr[H]; vj2 = vr[2 * H];
+  // ---- this wave's rows: those whose first edge lies in its share [es, ee) of the chunk's edge range
+  const int E0 = rowptr_t[r0], E1 = rowptr_t[r1];
+  const long span = (long)E1 - E0;
+  const int es = E0 + (int)(span * wave / nwaves);
+  const int ee = (wave + 1 == nwaves) ? E1 + 1 : E0 + (int)(span * (wave + 1) / nwaves);
+  int ra = r0, rb = r0;                              // rows [ra, rb): counts of rows starting below es / ee
+  for (int q = r0; q < r1; q += 64) {
+    const int rq = q + lane;
+    const int start = rq < r1 ? rowptr_t[rq] : 0x7fffffff;
+    ra += __popcll(__ballot(start < es));
+    rb += __popcll(__ballot(start < ee));
+  }
+  __syncthreads();                                   // the tile is staged
+
+  if (ra < rb) {
+    // row pointers of up to 64 rows at a time live in one VGPR (lane q: rowptr[row_base + q]); v_readlane on demand
+    int row_base = ra;
+    int rp_vec = rowptr_t[min(row_base + lane, a.Nsrc)];
+    auto rowptr_of = [&](int r) {
+      if (r - row_base >= 64) {
+        row_base = r;
+        rp_vec = rowptr_t[min(row_base + lane, a.Nsrc)];
       }
-      // gvec[row] is read-modify-written across the relations (t = 0 starts from the residual's identity term)
-      float prev0 = 0.f, prev1 = 0.f, prev2 = 0.f;
+      return __builtin_amdgcn_readlane(rp_vec, r - row_base);
+    };
+
+    int row = ra;
+    const int e_begin = rowptr_of(ra);
+    const int e_end = rowptr_t[rb];                  // (scalar load, once)
+    int row_end = rowptr_of(row + 1);
+
+    float xs, xa, xb, vj0 = 0.f, vj1 = 0.f, vj2 = 0.f;
+    float gs = 0.f, ga = 0.f, gb = 0.f, gv0 = 0.f, gv1 = 0.f, gv2 = 0.f;
+    auto row_prologue = [&](int r) {
+      // (wave-uniform base + this lane's channel: the base stays in SGPRs, one lane-offset register serves all arrays)
+      const float* xr = xh_t + (size_t)r * 3 * H;
+      xs = xr[c] + xbs; xa = (xr + H)[c] + xba; xb = (xr + 2 * H)[c] + xbb;
       if (HAS_VEC) {
-        const size_t vo = (size_t)r * 3 * H + c;
-        if (t == 0) {
-          if (a.identity && r < nk) { prev0 = a.gvec1[vo]; prev1 = a.gvec1[vo + H]; prev2 = a.gvec1[vo + 2 * H]; }
-        } else {
-          prev0 = a.gvec[vo]; prev1 = a.gvec[vo + H]; prev2 = a.gvec[vo + 2 * H];
-        }
+        const float* vr = a.vec + (size_t)r * 3 * H;
+        vj0 = vr[c]; vj1 = (vr + H)[c]; vj2 = (vr + 2 * H)[c];
       }
-      float gs = 0.f, ga = 0.f, gb = 0.f, gv0 = 0.f, gv1 = 0.f, gv2 = 0.f;
+      gs = 0.f; ga = 0.f; gb = 0.f; gv0 = 0.f; gv1 = 0.f; gv2 = 0.f;
+    };
+    auto row_epilogue = [&](int r) {                 // every lane owns its channel: plain coalesced stores
+      float* go = gxh_t + (size_t)r * 3 * H;
+      go[c] = gs; (go + H)[c] = ga; (go + 2 * H)[c] = gb;
+      if (HAS_VEC) {
+        float* gvo = gvec_t + (size_t)r * 3 * H;
+        gvo[c] = gv0; (gvo + H)[c] = gv1; (gvo + 2 * H)[c] = gv2;
+      }
+    };
+    row_prologue(row);
 
-      for (int base = beg; base < end; base += 64) {
-        const int cnt = min(64, end - base);
-        // one coalesced index load per 64 edges; an edge's indices are then wave-uniform (v_readlane)
-        const int my_tgt = lane < cnt ? a.csc_tgt[base + lane] : 0;
-        const int my_pos = lane < cnt ? a.csc_pos[base + lane] : 0;
+    for (int base = e_begin; base < e_end; base += 64) {
+      const int cnt = min(64, e_end - base);
+      // one coalesced index load per 64 edges; an edge's indices are then wave-uniform (v_readlane)
+      const int my_tgt = lane < cnt ? a.csc_tgt[base + lane] : 0;
+      const int my_pos = lane < cnt ? a.csc_pos[base + lane] : 0;
 
-        auto load_edge = [&](int k) {
-          const int i = __builtin_amdgcn_readlane(my_tgt, k);
-          EdgeIn in;
-          in.gx1 = a.gx1[(size_t)i * H + c];
-          const float* gvr = a.gvec1 + (size_t)i * 3 * H + c;
-          in.g0 = gvr[0]; in.g1 = gvr[H]; in.g2 = gvr[2 * H];
-          return in;
-        };
-        // the record of an edge is wave-uniform and read-only here: through the constant address space its loads
-        // are scalar (s_load_dwordx8 into SGPRs), not 64 lanes fetching the same bytes
-        auto load_record = [&](int k, float (&rec)[kRec]) {
-          const int p = __builtin_amdgcn_readlane(my_pos, k);
-          const hn_cfloat* rp = (const hn_cfloat*)(a.table + (size_t)p * kRec);
+      auto load_edge = [&](int k) {
+        const int i = __builtin_amdgcn_readlane(my_tgt, k);
+        EdgeIn in;
+        // buffer loads: descriptor + scalar row offset + this lane's channel offset -- no per-lane 64-bit address math
+        const unsigned so = (unsigned)i * (unsigned)(H * 4);
+        in.gx1 = buf_load(rs_gx1, c4, so);
+        in.g0 = buf_load(rs_gvec1, c4, 3u * so);
+        in.g1 = buf_load(rs_gvec1, c4, 3u * so + (unsigned)(H * 4));
+        in.g2 = buf_load(rs_gvec1, c4, 3u * so + (unsigned)(2 * H * 4));
+        return in;
+      };
+      // the record of an edge is wave-uniform and read-only here: through the constant address space its loads
+      // are scalar (s_load_dwordx8 into SGPRs), not 64 lanes fetching the same bytes
+      auto load_record = [&](int k, float (&rec)[kRec]) {
+        const int p = __builtin_amdgcn_readlane(my_pos, k);
+        const hn_cfloat* rp = (const hn_cfloat*)(a.table + (size_t)p * kRec);
 #pragma unroll
-          for (int q = 0; q < kRec; ++q) rec[q] = rp[q];
-        };
+        for (int q = 0; q < kRec; ++q) rec[q] = rp[q];
+      };
 
-        EdgeIn cur = load_edge(0);
-        float rec[kRec];
-        load_record(0, rec);
-#if defined(HN_STAMPS)
-        HN_TSV(st_b);
-        st_pro += st_b - st_a;
-#endif
-        for (int k4 = 0; k4 < cnt; k4 += 4) {
-          float pd[4], px[4], py[4], pz[4];
-          // geometry of the edge this DPP row will write (rows hold edges 0, 2, 1, 3 of the group): requested now,
-          // used after the group's arithmetic
-          const int je = (row16 == 0) ? 0 : (row16 == 1 ? 2 : (row16 == 2 ? 1 : 3));
-          const int pw = __shfl(my_pos, min(k4 + je, cnt - 1), 64);
-          const float4 gw = a.edge[pw];
+      EdgeIn cur = load_edge(0);
+      float rec[kRec];
+      load_record(0, rec);
+      for (int k4 = 0; k4 < cnt; k4 += 4) {
+        float pd[2], px[2], py[2], pz[2];                  // the current pair's per-channel dE/dd, dE/drhat
+        float ud[2], ux[2], uy[2], uz[2];                  // folded pairs (32-lane partial sums)
+        // geometry of the edge this DPP row will write (rows hold edges 0, 2, 1, 3 of the group): requested now,
+        // used after the group's arithmetic
+        const int je = (row16 == 0) ? 0 : (row16 == 1 ? 2 : (row16 == 2 ? 1 : 3));
+        const int pw = __shfl(my_pos, min(k4 + je, cnt - 1), 64);
+        const float4 gw = a.edge[pw];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            pd[j] = 0.f; px[j] = 0.f; py[j] = 0.f; pz[j] = 0.f;
-            const int k = k4 + j;
-            if (k < cnt) {                                          // wave-uniform
-              const EdgeIn nxt = load_edge(min(k + 1, cnt - 1));    // the next edge's rows fly during this edge's math
-#if defined(HN_STAMPS)
-              HN_TS(st_e0);
-              asm volatile("" :: "s"(rec[24]), "s"(rec[25]), "s"(rec[30]));          // the record has arrived
-              HN_TS(st_e1);
-              st_rec += st_e1 - st_e0;
-#endif
-              // ---- (S0, S1) of the three parts: 12 taps, one LDS read each, in three pipelined groups
-              const unsigned waddr = (unsigned)__float_as_int(rec[24]) * (HN_CB * 16) + tile_lane;
-              hn_f2 Ss = {0.f, 0.f}, Sa = {0.f, 0.f}, Sb = {0.f, 0.f};
-              hn_f4 wA[4], wB[4];
-              auto taps4 = [&](int m0, const hn_f4 (&w)[4]) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  const hn_f2 g = {rec[2 * (m0 + q)], rec[2 * (m0 + q) + 1]};
-                  Ss = __builtin_elementwise_fma(g, hn_f2{w[q].x, w[q].x}, Ss);
-                  if (HAS_VEC) Sa = __builtin_elementwise_fma(g, hn_f2{w[q].y, w[q].y}, Sa);
-                  Sb = __builtin_elementwise_fma(g, hn_f2{w[q].z, w[q].z}, Sb);
-                }
-              };
-              lds_issue4(waddr, wA);
-              lds_issue4(waddr + 4 * (HN_CB * 16), wB);
-              lds_wait<4>(wA);
-              taps4(0, wA);
-              asm volatile("" : "+v"(Ss), "+v"(Sb));                // taps 0-3 are consumed before wA is refilled
-              lds_issue4(waddr + 8 * (HN_CB * 16), wA);
-              lds_wait<4>(wB);
-              taps4(4, wB);
-              lds_wait<0>(wA);
-              taps4(8, wA);
-              const float envv = rec[25], c0 = rec[26], c1 = rec[27], rx = rec[28], ry = rec[29], rz = rec[30];
-#if defined(HN_STAMPS)
-              asm volatile("" :: "v"(Ss), "v"(Sb));
-              HN_TS(st_e2);
-              st_con += st_e2 - st_e1;
-#endif
-              // the taps are consumed: request the NEXT edge's record into the same scalar registers; its latency
-              // hides behind the rest of this edge (the six scalars still needed were copied above)
-              __builtin_amdgcn_sched_barrier(0);
-              load_record(min(k + 1, cnt - 1), rec);
-              __builtin_amdgcn_sched_barrier(0);
-              const float gdx = cur.gx1 * inv_sqrt2;
-              const float g0 = cur.g0, g1 = cur.g1, g2 = cur.g2;
-              // ---- part s: dx = sum xs * rs
-              const float rs = fmaf(envv, Ss.x, bs);
-              const float drs = fmaf(c0, Ss.x, c1 * Ss.y);
-              gs = fmaf(gdx, rs, gs);
-              float pdv = gdx * xs * drs;
-              // ---- part a: dvec += vec_j * (xa * ra) / sqrt(3H)
-              if (HAS_VEC) {
-                const float ra = fmaf(envv, Sa.x, ba);
-                const float dra = fmaf(c0, Sa.x, c1 * Sa.y);
-                const float A = fmaf(g0, vj0, fmaf(g1, vj1, g2 * vj2)) * inv_sqrt3h;
-                ga = fmaf(A, ra, ga);
-                const float w = xa * ra * inv_sqrt3h;
-                gv0 = fmaf(g0, w, gv0); gv1 = fmaf(g1, w, gv1); gv2 = fmaf(g2, w, gv2);
-                pdv = fmaf(A * xa, dra, pdv);
-              }
-              // ---- part b: dvec += rhat * (xb * rb) / sqrt(H)
-              const float rb = fmaf(envv, Sb.x, bb);
-              const float drb = fmaf(c0, Sb.x, c1 * Sb.y);
-              const float B = fmaf(rx, g0, fmaf(ry, g1, rz * g2)) * inv_sqrth;
-              gb = fmaf(B, rb, gb);
-              pdv = fmaf(B * xb, drb, pdv);
-              const float q = xb * rb * inv_sqrth;
-              pd[j] = pdv; px[j] = g0 * q; py[j] = g1 * q; pz[j] = g2 * q;   // per channel: dE/dd, dE/drhat
-#if defined(HN_STAMPS)
-              asm volatile("" :: "v"(pd[j]), "v"(px[j]), "v"(gb));
-              HN_TS(st_e3);
-              st_alg += st_e3 - st_e2;
-              st_edges += 1;
-#endif
-              cur = nxt;
+        for (int j = 0; j < 4; ++j) {
+          pd[j & 1] = 0.f; px[j & 1] = 0.f; py[j & 1] = 0.f; pz[j & 1] = 0.f;
+          const int k = k4 + j;
+          if (k < cnt) {                                          // wave-uniform
+            while (base + k >= row_end) {                         // (wave-uniform) the stream enters the next row
+              row_epilogue(row);
+              ++row;
+              row_end = rowptr_of(row + 1);
+              row_prologue(row);
             }
+            const EdgeIn nxt = load_edge(min(k + 1, cnt - 1));    // the next edge's rows fly during this edge's math
+            // ---- (S0, S1) of the three parts: 12 taps, one LDS read each, in three pipelined groups
+            const unsigned waddr = (unsigned)__float_as_int(rec[24]) * (HN_CB * 16) + tile_lane;
+            hn_f2 Ss = {0.f, 0.f}, Sa = {0.f, 0.f}, Sb = {0.f, 0.f};
+            hn_f4 wA[4], wB[4];
+            auto taps4 = [&](int m0, const hn_f4 (&w)[4]) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const hn_f2 g = {rec[2 * (m0 + q)], rec[2 * (m0 + q) + 1]};
+                Ss = __builtin_elementwise_fma(g, hn_f2{w[q].x, w[q].x}, Ss);
+                if (HAS_VEC) Sa = __builtin_elementwise_fma(g, hn_f2{w[q].y, w[q].y}, Sa);
+                Sb = __builtin_elementwise_fma(g, hn_f2{w[q].z, w[q].z}, Sb);
+              }
+            };
+            lds_issue4(waddr, wA);
+            lds_issue4(waddr + 4 * (HN_CB * 16), wB);
+            lds_wait<4>(wA);
+            taps4(0, wA);
+            asm volatile("" : "+v"(Ss), "+v"(Sb));                // taps 0-3 are consumed before wA is refilled
+            lds_issue4(waddr + 8 * (HN_CB * 16), wA);
+            lds_wait<4>(wB);
+            taps4(4, wB);
+            lds_wait<0>(wA);
+            taps4(8, wA);
+            const float envv = rec[25], c0 = rec[26], c1 = rec[27], rx = rec[28], ry = rec[29], rz = rec[30];
+            // the taps are consumed: request the NEXT edge's record into the same scalar registers; its latency
+            // hides behind the rest of this edge (the six scalars still needed were copied above)
+            __builtin_amdgcn_sched_barrier(0);
+            load_record(min(k + 1, cnt - 1), rec);
+            __builtin_amdgcn_sched_barrier(0);
+            const float gdx = cur.gx1 * inv_sqrt2;
+            const float g0 = cur.g0, g1 = cur.g1, g2 = cur.g2;
+            // ---- part s: dx = sum xs * rs
+            const float rs = fmaf(envv, Ss.x, bs);
+            const float drs = fmaf(c0, Ss.x, c1 * Ss.y);
+            gs = fmaf(gdx, rs, gs);
+            float pdv = gdx * xs * drs;
+            // ---- part a: dvec += vec_j * (xa * ra) / sqrt(3H)
+            if (HAS_VEC) {
+              const float ra_ = fmaf(envv, Sa.x, ba);
+              const float dra = fmaf(c0, Sa.x, c1 * Sa.y);
+              const float A = fmaf(g0, vj0, fmaf(g1, vj1, g2 * vj2)) * inv_sqrt3h;
+              ga = fmaf(A, ra_, ga);
+              const float w = xa * ra_ * inv_sqrt3h;
+              gv0 = fmaf(g0, w, gv0); gv1 = fmaf(g1, w, gv1); gv2 = fmaf(g2, w, gv2);
+              pdv = fmaf(A * xa, dra, pdv);
+            }
+            // ---- part b: dvec += rhat * (xb * rb) / sqrt(H)
+            const float rb_ = fmaf(envv, Sb.x, bb);
+            const float drb = fmaf(c0, Sb.x, c1 * Sb.y);
+            const float B = fmaf(rx, g0, fmaf(ry, g1, rz * g2)) * inv_sqrth;
+            gb = fmaf(B, rb_, gb);
+            pdv = fmaf(B * xb, drb, pdv);
+            const float q = xb * rb_ * inv_sqrth;
+            pd[j & 1] = pdv; px[j & 1] = g0 * q; py[j & 1] = g1 * q; pz[j & 1] = g2 * q;
+            cur = nxt;
           }
-          // ---- dE/dD of these (up to) four edges: channel sums, then Cartesian form, one 16-byte store per edge
-#if defined(HN_STAMPS)
-          HN_TS(st_r0);
-#endif
-          const float sd = reduce4(pd[0], pd[1], pd[2], pd[3]);
-          const float sx = reduce4(px[0], px[1], px[2], px[3]);
-          const float sy = reduce4(py[0], py[1], py[2], py[3]);
-          const float sz = reduce4(pz[0], pz[1], pz[2], pz[3]);
-          if ((lane & 15) == 0 && k4 + je < cnt) {
-            const float invd = __builtin_amdgcn_rcpf(gw.w);
-            const float dotp = sx * gw.x + sy * gw.y + sz * gw.z;
-            // d = |D|, rhat = D/d:  gD = pd rhat + (pr - (pr.rhat) rhat) / d
-            const float tpar = sd - dotp * invd;
-            gedge[pw] = make_float4(fmaf(tpar, gw.x, sx * invd), fmaf(tpar, gw.y, sy * invd), fmaf(tpar, gw.z, sz * invd), 0.f);
+          if (j & 1) {
+            ud[j >> 1] = pair_fold(pd[0], pd[1]); ux[j >> 1] = pair_fold(px[0], px[1]);
+            uy[j >> 1] = pair_fold(py[0], py[1]); uz[j >> 1] = pair_fold(pz[0], pz[1]);
           }
-#if defined(HN_STAMPS)
-          HN_TS(st_r1);
-          st_red += st_r1 - st_r0;
-#endif
         }
-#if defined(HN_STAMPS)
-        { HN_TS(st_c); st_a = st_c; }
-#endif
+        // ---- dE/dD of these (up to) four edges: channel sums, then Cartesian form, one 16-byte store per edge
+        const float sd = quad_total(ud[0], ud[1]), sx = quad_total(ux[0], ux[1]);
+        const float sy = quad_total(uy[0], uy[1]), sz = quad_total(uz[0], uz[1]);
+        if ((lane & 15) == 0 && k4 + je < cnt) {
+          const float invd = __builtin_amdgcn_rcpf(gw.w);
+          const float dotp = sx * gw.x + sy * gw.y + sz * gw.z;
+          // d = |D|, rhat = D/d:  gD = pd rhat + (pr - (pr.rhat) rhat) / d
+          const float tpar = sd - dotp * invd;
+          gedge[pw] = make_float4(fmaf(tpar, gw.x, sx * invd), fmaf(tpar, gw.y, sy * invd), fmaf(tpar, gw.z, sz * invd), 0.f);
+        }
       }
-      // ---- segment epilogue: every lane owns its channel, plain coalesced stores
-      float* go = gxh_t + (size_t)r * 3 * H + c;
-      go[0] = gs; go[H] = ga; go[2 * H] = gb;
-      if (t == 0) a.gx[(size_t)r * H + c] = (a.identity && r < nk) ? a.gx1[(size_t)r * H + c] * inv_sqrt2 : 0.f;
-      if (HAS_VEC) {
-        float* gvo = a.gvec + (size_t)r * 3 * H + c;
-        gvo[0] = prev0 + gv0; gvo[H] = prev1 + gv1; gvo[2 * H] = prev2 + gv2;
-      }
-      rr = __builtin_amdgcn_readfirstlane(rr_next);
-#if defined(HN_STAMPS)
-      HN_TS(st_d);
-      st_epi += st_d - st_a;
-      st_segs += 1;
-#endif
+    }
+    // ---- the stream is exhausted: finish the current row and the rows without edges behind it
+    for (;;) {
+      row_epilogue(row);
+      if (++row >= rb) break;
+      row_prologue(row);
     }
   }
-#if defined(HN_STAMPS)
-  HN_TSV(st_k1);
-  if (lane == 0) {
-    atomicAdd(&hn_dbg_cl[0], st_k1 - st_k0); atomicAdd(&hn_dbg_cl[1], st_stage); atomicAdd(&hn_dbg_cl[2], st_pro);
-    atomicAdd(&hn_dbg_cl[3], st_rec); atomicAdd(&hn_dbg_cl[4], st_con); atomicAdd(&hn_dbg_cl[5], st_alg);
-    atomicAdd(&hn_dbg_cl[6], st_red); atomicAdd(&hn_dbg_cl[7], st_epi); atomicAdd(&hn_dbg_cl[8], st_edges);
-    atomicAdd(&hn_dbg_cl[9], st_segs); atomicAdd(&hn_dbg_cl[10], 1ull);
+}
+
+// gvec[r] = sum_t part[t][r] (+ gvec1[r] on target rows), gx[r] = gx1[r] / sqrt2 on target rows, 0 elsewhere.
+__global__ __launch_bounds__(256) void message_bwd_finish_kernel(const float4* __restrict__ part, int T, long n4_vec,
+                                                                 const float4* __restrict__ gvec1,
+                                                                 const float4* __restrict__ gx1,
+                                                                 const int* __restrict__ type_rowptr, int identity,
+                                                                 int H, float4* __restrict__ gvec, float4* __restrict__ gx,
+                                                                 long n4_x) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int identity_rows = identity ? type_rowptr[T] : 0;      // rows below are targets of a known type
+  if (part && i < n4_vec) {
+    float4 acc = part[i];
+    for (int t = 1; t < T; ++t) {
+      const float4 v = part[(long)t * n4_vec + i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (i / (3 * H / 4) < identity_rows) {
+      const float4 v = gvec1[i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    gvec[i] = acc;
   }
-#endif
+  if (i < n4_x) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i / (H / 4) < identity_rows) {
+      const float4 g = gx1[i];
+      const float s = 0.70710678118654752f;
+      v = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
+    }
+    gx[i] = v;
+  }
 }
 
 int num_cus() {
@@ -397,7 +416,7 @@ int num_cus() {
 }  // namespace
 
 size_t hn_bwd_cl_lds_bytes(int R) {
-  return (size_t)(R + 2 * HN_PAD + 1) * HN_CB * sizeof(float4) + 64;
+  return (size_t)(R + 2 * HN_PAD + 1) * HN_CB * sizeof(float4);
 }
 
 int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, hipStream_t s) {
@@ -412,20 +431,31 @@ int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, hipStream_t
       return HN_ERR_LDS;
     done[has_vec] = true;
   }
-  // one workgroup per CU and round: rows per workgroup such that the grid is a whole number of rounds
+  // one (relation, column block, row chunk) per workgroup; the chunk is sized for a whole number of rounds of one
+  // workgroup per CU (the 154 KB tile allows one resident workgroup): ~256 rows = 16 rows per wave
   const int ncb = a.H / HN_CB;
   int rpb = rows_override;
   if (rpb <= 0) {
-    const long work = (long)a.Nsrc * ncb;
+    const long work = (long)a.Nsrc * ncb * a.T;
     const int cus = num_cus();
-    long rounds = (work + (long)cus * 64) / ((long)cus * 128);     // ~128 rows per workgroup (16 waves)
+    long rounds = (work + (long)cus * 128) / ((long)cus * 256);
     if (rounds < 1) rounds = 1;
-    rpb = (int)((work + cus * rounds - 1) / (cus * rounds));
+    long wgs_per_tc = cus * rounds / ((long)ncb * a.T);     // chunks per (t, cb), rounded DOWN: a grid one workgroup
+    if (wgs_per_tc < 1) wgs_per_tc = 1;                      // over a whole round would double the kernel's time
+    rpb = (int)((a.Nsrc + wgs_per_tc - 1) / wgs_per_tc);
     if (rpb < 16) rpb = 16;
   }
   a.rows_per_block = rpb;
-  dim3 grid((unsigned)((a.Nsrc + rpb - 1) / rpb), (unsigned)ncb);
+  dim3 grid((unsigned)((a.Nsrc + rpb - 1) / rpb), (unsigned)ncb, (unsigned)a.T);
   hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, a);
+  // partial sums over the relations + identity terms -> gvec, gx
+  const long n4v = has_vec ? (long)a.Nsrc * 3 * a.H / 4 : 0, n4x = (long)a.Nsrc * a.H / 4;
+  const long n4 = n4v > n4x ? n4v : n4x;
+  hipLaunchKernelGGL(message_bwd_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
+                     has_vec ? reinterpret_cast<const float4*>(a.gvec) : nullptr, a.T, n4v,
+                     reinterpret_cast<const float4*>(a.gvec1), reinterpret_cast<const float4*>(a.gx1),
+                     a.type_rowptr, a.identity, a.H, reinterpret_cast<float4*>(a.gvec_out),
+                     reinterpret_cast<float4*>(a.gx), n4x);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
 
@@ -440,12 +470,3 @@ extern "C" int hermnet_edge_radial_table(const hn_rbf_desc* rbf, const float* ed
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
 
-#if defined(HN_STAMPS)
-extern "C" int hermnet_debug_stamps_cl(unsigned long long* out12) {
-  if (hipDeviceSynchronize() != hipSuccess) return HN_ERR_LAUNCH;
-  if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(hn_dbg_cl), 12 * sizeof(unsigned long long)) != hipSuccess) return HN_ERR_LAUNCH;
-  unsigned long long z[12] = {0};
-  if (hipMemcpyToSymbol(HIP_SYMBOL(hn_dbg_cl), z, sizeof(z)) != hipSuccess) return HN_ERR_LAUNCH;
-  return HN_OK;
-}
-#endif

@@ -922,7 +922,7 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
                                            const float* wt, const float* brbf, const float* edge,
                                            const float* gx1, const float* gvec1,
                                            float* gxh, float* gvec, float* gx, float* gedge,
-                                           int split_t, const float* edge_table, void* stream) {
+                                           int split_t, const float* edge_table, float* gvec_partials, void* stream) {
   MsgArgs a = {};
   int rc = fill_args(g, rbf, hidden, a);
   if (rc) return rc;
@@ -932,15 +932,19 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   if (a.N == 0) return HN_OK;
   static const int use_cl = env_int("HERMNET_BWD_CL", 1);
   const bool virtual_targets = g->num_src > 0 || g->res_row != nullptr;
-  if (virtual_targets && !edge_table) return HN_ERR_BAD_ARG;      // separate source rows: channel-per-lane form only
-  if (edge_table && (use_cl || virtual_targets) && !split_t) {
+  const size_t gather_bytes = (size_t)a.N * 3 * hidden * sizeof(float);      // the channel-per-lane form gathers through
+  const bool cl_ok = edge_table && !split_t && gather_bytes < 0xffffffffull &&  // 32-bit buffer offsets
+                     (!vec || a.T == 1 || gvec_partials);
+  if (virtual_targets && !cl_ok) return HN_ERR_BAD_ARG;
+  if (cl_ok && (use_cl || virtual_targets)) {
     HnBwdClArgs b = {};
     b.N = a.N; b.Nsrc = g->num_src > 0 ? g->num_src : a.N; b.E = a.E; b.T = a.T;
     b.identity = virtual_targets ? 0 : 1;
     b.csc_rowptr = a.csc_rowptr; b.csc_tgt = a.csc_tgt; b.csc_pos = a.csc_pos;
     b.R = a.R; b.H = hidden; b.table = edge_table; b.edge = reinterpret_cast<const float4*>(edge);
     b.xh = xh; b.xh_bias = xh_bias; b.vec = vec; b.wt = wt; b.brbf = brbf; b.gx1 = gx1; b.gvec1 = gvec1;
-    b.gxh = gxh; b.gvec = gvec; b.gx = gx; b.gedge = reinterpret_cast<float4*>(gedge);
+    b.gxh = gxh; b.gvec = (a.T == 1) ? gvec : gvec_partials; b.gvec_out = gvec; b.gx = gx;
+    b.gedge = reinterpret_cast<float4*>(gedge);
     b.type_rowptr = g->type_rowptr;
     static const int rpb_cl = env_int("HERMNET_BWD_CL_ROWS", 0);
     return hn_bwd_cl_launch(b, vec != nullptr, rpb_cl, reinterpret_cast<hipStream_t>(stream));

@@ -90,11 +90,16 @@ def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge):
     gvec = None if vec is None else (torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
                                      if split else torch.empty_like(vec))
     gx = torch.empty_like(gx1)
+    # workspace of the channel-per-lane form: per-relation partial sums of gvec
+    part = None
+    if graph.edge_table is not None and vec is not None and graph.T > 1 and not split:
+        part = torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
     gs, rs = graph.as_struct(), rbf.struct()
     _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"),
                        lambda: lib.hermnet_message_scatter_bwd(
                            ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(w.b2), P(vec), P(w.wt), P(w.brbf), P(edge),
-                           P(gx1), P(gvec1), P(gxh), P(gvec), P(gx), P(gedge), split, P(graph.edge_table), _stream())),
+                           P(gx1), P(gvec1), P(gxh), P(gvec), P(gx), P(gedge), split, P(graph.edge_table), P(part),
+                           _stream())),
                "hermnet_message_scatter_bwd")
     if split and gvec is not None:
         gvec = gvec.sum(0)

@@ -192,11 +192,14 @@ class MessageScatter(torch.autograd.Function):
                                          if split else torch.empty_like(vec))
         gx = torch.empty_like(gx1)
         gedge = torch.zeros(H // 64, graph.E, 4, dtype=torch.float32, device=gx1.device)
+        part = None
+        if graph.edge_table is not None and vec is not None and graph.T > 1 and not split:
+            part = torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
         gs, rs = graph.as_struct(), rbf.struct()
         _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"), lambda: lib.hermnet_message_scatter_bwd(
             ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), None, _lib.ptr(vec), _lib.ptr(wt), _lib.ptr(brbf),
             _lib.ptr(edge), _lib.ptr(gx1), _lib.ptr(gvec1), _lib.ptr(gxh), _lib.ptr(gvec), _lib.ptr(gx),
-            _lib.ptr(gedge), split, _lib.ptr(graph.edge_table), _stream())), "hermnet_message_scatter_bwd")
+            _lib.ptr(gedge), split, _lib.ptr(graph.edge_table), _lib.ptr(part), _stream())), "hermnet_message_scatter_bwd")
         if split and gvec is not None:
             gvec = gvec.sum(0)
         return gxh, gvec, gx, gedge.sum(0), None, None, None, None

@@ -190,7 +190,7 @@ int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc* rbf, int h
                                 const float* wt, const float* brbf, const float* edge,
                                 const float* gx1, const float* gvec1,
                                 float* gxh, float* gvec, float* gx, float* gedge, int split_t,
-                                const float* edge_table, void* stream);
+                                const float* edge_table, float* gvec_partials, void* stream);
 
 /* Per-edge radial record, computed ONCE per step (geometry and radial basis are shared by every layer and by both
  * directions): table [E, 32] floats in CSR order =
@@ -198,7 +198,10 @@ int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc* rbf, int h
  *   [24] padded tile row of tap 0 (int bits) | [25] env(u) | [26] env'(u)/rc | [27] 2 coeff env(u)/rc | [28..30] rhat | [31] 1/d
  * (rmnet.py:156-193 evaluated exactly as the message kernels do in registers).  When `edge_table` is handed to
  * hermnet_message_scatter_bwd (NULL = not available) the backward runs in its channel-per-lane form, which reads
- * the record through the scalar path: a wave works on one edge, its taps sit in SGPRs (csrc/message_bwd_cl.hip). */
+ * the record through the scalar path: a wave works on one edge, its taps sit in SGPRs (csrc/message_bwd_cl.hip).
+ * That form runs one workgroup per (relation, column block, row chunk) and needs `gvec_partials`, a caller-owned
+ * workspace [T, N, 3, H] (per-relation partial sums of gvec, added up in a fixed order by a second small launch;
+ * not needed when T = 1 or vec is NULL); without it, or with split_t = 1, the 16-lanes-per-edge form runs. */
 int hermnet_edge_radial_table(const hn_rbf_desc* rbf, const float* edge, int num_edges, float* table, void* stream);
 
 /* ---- node-level fused elementwise stages (A11/A12; the GEMMs between them are library calls) ----

@@ -386,6 +386,7 @@ def test_bias_on_load_equals_bias_in_operand():
 
     from hermnet_amd.ops import edge_radial_table
     table = edge_radial_table(rbf, edge)
+    part = torch.empty(T, N, 3, H, device=dev)
 
     def run(xh_in, bias, v, tab=None):
         x1, vec1 = torch.empty_like(x), torch.empty(N, 3, H, device=dev)
@@ -395,7 +396,7 @@ def test_bias_on_load_equals_bias_in_operand():
         gedge = torch.zeros(H // 64, graph.E, 4, device=dev)
         assert lib.hermnet_message_scatter_bwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh_in), P(bias), P(v), P(wt), P(brbf),
                                                P(edge), P(gx1), P(gv1), P(gxh), P(gvec if v is not None else None), P(gx),
-                                               P(gedge), 0, P(tab), _stream()) == 0
+                                               P(gedge), 0, P(tab), P(part if tab is not None else None), _stream()) == 0
         return [x1, vec1, gxh, gx, gedge.sum(0)] + ([gvec] if v is not None else [])
 
     for v in (vec, None):

@@ -48,10 +48,12 @@ def main():
     from hermnet_amd.ops import edge_radial_table
     table = edge_radial_table(rbf, edge) if os.environ.get("KBENCH_TABLE", "1") != "0" else None
 
+    part = torch.empty(T, N, 3, H, device=dev) if table is not None else None
+
     def bwd(v):
         return lib.hermnet_message_scatter_bwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(xb), P(v), P(wt), P(brbf), P(edge),
                                                P(gx1), P(gvec1), P(gxh), P(gvec if v is not None else None), P(gx),
-                                               P(gedge), split, P(table), _stream())
+                                               P(gedge), split, P(table), P(part), _stream())
 
     ab = algorithmic_bytes(E, N, H, T)
     res = {}
