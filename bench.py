@@ -124,14 +124,17 @@ def other_configs_secondary(hn, synth, dev, model_kw, steps=5, skip_c4=False):
     """configs[3] on ONE GPU (100k-atom cell, no sharding) and configs[4] (1024-molecule batch): energy + forces
     per step incl. the relation build, neighbour list prebuilt -- the same step definition as the headline."""
     res = {}
-    cases = [("configs[3] 100k-atom 3-element cell on 1 GPU", ["Al", "Ni", "Cu"],
-              lambda: synth.fcc_alloy(reps=(10, 10, 250), seed=0, device=dev)),
-             ("configs[4] 1024-molecule batch", ["H", "C", "O"], lambda: synth.molecule_batch(num_graphs=1024).to(dev))]
-    for name, elems, make in cases:
+    cases = [("configs[2] 10k-atom 3-element cell, HTNet (18 triadic relations; build-defined model, the reference's "
+              "class is a stub)", ["Al", "Ni", "Cu"], lambda: synth.fcc_alloy(reps=(10, 10, 25), seed=0, device=dev), hn.HTNet),
+             ("configs[3] 100k-atom 3-element cell on 1 GPU", ["Al", "Ni", "Cu"],
+              lambda: synth.fcc_alloy(reps=(10, 10, 250), seed=0, device=dev), hn.HVNet),
+             ("configs[4] 1024-molecule batch", ["H", "C", "O"], lambda: synth.molecule_batch(num_graphs=1024).to(dev),
+              hn.HVNet)]
+    for name, elems, make, cls in cases:
         if skip_c4 and name.startswith("configs[3]"):
             continue
         d = make()
-        model = hn.HVNet(elems, **model_kw).eval()
+        model = cls(elems, **model_kw).eval()
         model.load_state_dict(synth.synth_state_dict(model.state_dict(), 10))
         model = model.to(dev)
         for p_ in model.parameters():

@@ -46,6 +46,8 @@ namespace {
 struct MsgArgs {
   // graph
   int N, E, T;
+  int Nsrc;              // rows of the source space (xh, vec gathers); = N unless the targets are virtual rows (HTNet)
+  const int* res_row;    // [N] source row entering the residual of target row r, or null (= r)
   const int* type_rowptr;
   const int* csr_rowptr;
   const int* csr_src;
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
   const int col = cb * HN_CB + VW * gl;  // first of this lane's VW channels
   const float inv_sqrt3h = 0.57735026918962576f * rsqrtf((float)H);  // (1/sqrt3)(1/sqrtH)
   const float inv_sqrth = rsqrtf((float)H);
-  const float* xh_t = a.xh + (size_t)t * a.N * 3 * H;
+  const float* xh_t = a.xh + (size_t)t * a.Nsrc * 3 * H;
 
   Vec<VW> bias[3], xbias[3];
 #pragma unroll
@@ -479,15 +481,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
       }
     }
     // combine the lane groups, then the residual epilogue (rmnet.py:24-26).
+    const int rres = a.res_row ? a.res_row[r] : r;      // row of (x, vec) that enters the residual
     if constexpr (VW == 4) {
       // rows_reduce4 leaves ONE channel (col + grp) of every reduced row in each lane: dword accesses, all lanes
       const int c1 = col + grp;
       const size_t xo = (size_t)r * H + c1;
-      a.x1[xo] = (a.x[xo] + rows_reduce4(ax)) * 0.70710678118654752f;
+      a.x1[xo] = (a.x[(size_t)rres * H + c1] + rows_reduce4(ax)) * 0.70710678118654752f;
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         const size_t vo = ((size_t)r * 3 + d) * H + c1;
-        a.vec1[vo] = (HAS_VEC ? a.vec[vo] : 0.f) + rows_reduce4(av[d]);
+        a.vec1[vo] = (HAS_VEC ? a.vec[((size_t)rres * 3 + d) * H + c1] : 0.f) + rows_reduce4(av[d]);
       }
     } else {
       // the four output rows (x1, vec1[0..2]) are spread over the lane groups (256 B per group and row)
@@ -497,12 +500,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
       for (int o = grp; o < 4; o += VW) {     // o = 0: x1, o = 1..3: vec1[o-1]
         if (o == 0) {
           const size_t xo = (size_t)r * H + col;
-          v_scale(v_add(Vec<VW>::load(a.x + xo), ax), 0.70710678118654752f).store(a.x1 + xo);
+          v_scale(v_add(Vec<VW>::load(a.x + (size_t)rres * H + col), ax), 0.70710678118654752f).store(a.x1 + xo);
         } else {
           const size_t vo = ((size_t)r * 3 + (o - 1)) * H + col;
           const Vec<VW> acc = o == 1 ? av[0] : (o == 2 ? av[1] : av[2]);
           Vec<VW> v0 = Vec<VW>::zero();
-          if (HAS_VEC) v0 = Vec<VW>::load(a.vec + vo);
+          if (HAS_VEC) v0 = Vec<VW>::load(a.vec + ((size_t)rres * 3 + (o - 1)) * H + col);
           v_add(v0, acc).store(a.vec1 + vo);
         }
       }
@@ -784,6 +787,7 @@ int fill_args(const hn_graph* g, const hn_rbf_desc* rbf, int hidden, MsgArgs& a)
   if (!g || !rbf || hidden <= 0 || hidden % HN_CB != 0) return HN_ERR_BAD_ARG;
   if (g->num_rel <= 0 || rbf->num_rbf < 2) return HN_ERR_BAD_ARG;
   a.N = g->num_nodes; a.E = g->num_edges; a.T = g->num_rel;
+  a.Nsrc = g->num_src > 0 ? g->num_src : g->num_nodes; a.res_row = g->res_row;
   a.type_rowptr = g->type_rowptr; a.csr_rowptr = g->csr_rowptr; a.csr_src = g->csr_src;
   a.csc_rowptr = g->csc_rowptr; a.csc_tgt = g->csc_tgt; a.csc_pos = g->csc_pos;
   a.offset = rbf->offset; a.R = rbf->num_rbf; a.inv_rc = rbf->inv_rc; a.coeff = rbf->coeff;

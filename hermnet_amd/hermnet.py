@@ -97,6 +97,13 @@ class HVNet(nn.Module):
             raise TypeError("hermnet_amd.HVNet computes in float32: parameters are %s, data.pos is %s "
                             "(call model.float() / pos.float())" % (wd, pos.dtype))
 
+    def _build_graph(self, data, zl, shard):
+        """Relation-ordered graph of this neighbour list (the replacement of `in_subgraph`, utils.py:11-24)."""
+        rel_active = None if shard is None else [z in shard.z_with_in_edges for z in zl]
+        return RelationalGraph.build(data.atomic_number, data.edge_index, zl,
+                                     edge_shift=data.get("edge_shift") if data.get("cell") is not None else None,
+                                     batch=data.batch, rel_active=rel_active)
+
     @staticmethod
     def _edge_geometry_autograd(pos, cell, graph):
         """`with_edge` (hermnet.py:133-152) as differentiable device ops, CSR order -> edge[E,4] = (rhat, d).
@@ -129,10 +136,7 @@ class HVNet(nn.Module):
         zl = [atomic_numbers[el] for el in self.elems]
         # atom-sharded evaluation (hermnet_amd/sharding.py): this rank's atoms + one-hop halo
         shard = data.get("_hn_shard")
-        rel_active = None if shard is None else [z in shard.z_with_in_edges for z in zl]
-        graph = RelationalGraph.build(data.atomic_number, data.edge_index, zl,
-                                      edge_shift=data.get("edge_shift") if data.get("cell") is not None else None,
-                                      batch=data.batch, rel_active=rel_active)
+        graph = self._build_graph(data, zl, shard)
         fused = self.radial_basis.fused and not train
         rbf = self.radial_basis.descriptor() if fused else None
         row_plan = None
@@ -218,8 +222,66 @@ class HVNet(nn.Module):
         return energy
 
 
-class HTNet(nn.Module):
-    """`hermnet.py:155-157`: not implemented in the reference either."""
+def triadic_relations(elems):
+    """[(module key, centre element, (p, q))] in module order: centres in `elems` order, unordered neighbour pairs
+    p <= q in `elems` order -- T * T(T+1)/2 relations (figs/subgraph.svg (c): "A->A<-A", "B->A<-C")."""
+    out = []
+    for c in elems:
+        for i, p in enumerate(elems):
+            for q in elems[i:]:
+                out.append(("%s_%s-%s" % (c, p, q), c, (p, q)))
+    return out
 
-    def __init__(self):
-        raise NotImplementedError
+
+class HeteroTriadicConv(HeteroVertexConv):
+    """HTNet's layer: the loop of `hermnet.py:51-61` over triadic relations.  Relation (c; p, q) owns a PaiNNModule
+    and sees the edges j -> i with element(i) = c and element(j) in {p, q}; a centre's T(T+1)/2 results are
+    averaged.  All relations run in the same fused launches as HVNet's: the graph has one TARGET row per atom and
+    pair relation (relations.build_triadic), the kernels gather from the atom-ordered SOURCE rows."""
+
+    def forward(self, data):
+        data = super().forward(data)                   # (x, vec) in target rows [T * P * B, ...]
+        g = data._hn_graph
+        P_, B_, Te = g.triadic_pairs, g.block, g.T // g.triadic_pairs
+        H = data.x.size(1)
+        x = data.x.view(Te, P_, B_, H).mean(1).reshape(Te * B_, H)
+        vec = data.vec.view(Te, P_, B_, 3, H).mean(1).reshape(Te * B_, 3, H)
+        pad = g.num_src - Te * B_                      # atoms of elements outside `elems`: zero rows (hermnet.py:51)
+        if pad > 0:
+            x = torch.cat([x, x.new_zeros(pad, H)], 0)
+            vec = torch.cat([vec, vec.new_zeros(pad, 3, H)], 0)
+        data.x, data.vec = x, vec
+        return data
+
+
+class HTNet(HVNet):
+    """Heterogeneous Triadic Network (`README.md:27`, `figs/subgraph.svg` (c)).  The reference's class is a stub that
+    raises NotImplementedError (`hermnet.py:155-157`); this is the BUILD-DEFINED model specified in DESIGN.md
+    ("HTNet"), with HVNet's constructor and `forward(data)`: one PaiNNModule per (centre element, unordered pair of
+    neighbour elements), `hermconvs.{l}.mods.{c}_{p}-{q}.*` in the state_dict.  With a single element it IS HVNet.
+    Energy / force evaluation (eval()) only; parity is checked against `oracle.htnet_energy` ("parity unpinned")."""
+
+    def __init__(self, elems: Union[str, List[str]], rc: float = 5., intensive: bool = False, num_layers: int = 5,
+                 hidden_channels: int = 512, num_rbf: int = 128, rbf={"name": "gaussian"},
+                 envelope={"name": "polynomial", "exponent": 5}):
+        super().__init__(elems, rc=rc, intensive=intensive, num_layers=0, hidden_channels=hidden_channels,
+                         num_rbf=num_rbf, rbf=rbf, envelope=envelope)
+        self.num_layers = num_layers
+        keys = [k for k, _, _ in triadic_relations(self.elems)]
+        for _ in range(num_layers):
+            self.hermconvs.append(HeteroTriadicConv(
+                mods={k: PaiNNModule(hidden_channels=hidden_channels, num_rbf=num_rbf) for k in keys}))
+
+    def _build_graph(self, data, zl, shard):
+        if shard is not None:
+            raise NotImplementedError("atom-sharded evaluation is implemented for HVNet")
+        return RelationalGraph.build_triadic(data.atomic_number, data.edge_index, zl,
+                                             edge_shift=data.get("edge_shift") if data.get("cell") is not None else None,
+                                             batch=data.batch)
+
+    def forward(self, data):
+        if (self.training or self.eval_param_grads) and torch.is_grad_enabled():
+            raise NotImplementedError("HTNet: energy / force evaluation (eval()) only")
+        if not self.radial_basis.fused or self.hidden_channels % 64 != 0:
+            raise NotImplementedError("HTNet runs on the fused kernels: Gaussian basis, hidden_channels % 64 == 0")
+        return super().forward(data)

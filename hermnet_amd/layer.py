@@ -72,8 +72,8 @@ class LayerWeights(object):
 
 def _msg_fwd(graph, rbf, H, xh, vec, x, w, edge):
     lib = _lib.load()
-    x1 = torch.empty_like(x)
-    vec1 = torch.empty(x.size(0), 3, H, dtype=x.dtype, device=x.device)
+    x1 = torch.empty(graph.N, H, dtype=x.dtype, device=x.device)          # target rows (= source rows unless HTNet)
+    vec1 = torch.empty(graph.N, 3, H, dtype=x.dtype, device=x.device)
     gs, rs = graph.as_struct(), rbf.struct()
     _lib.check(_launch("message_scatter_fwd" + ("" if vec is not None else "_l0"),
                        lambda: lib.hermnet_message_scatter_fwd(
@@ -89,7 +89,7 @@ def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge):
     split = _split_t(graph)
     gvec = None if vec is None else (torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
                                      if split else torch.empty_like(vec))
-    gx = torch.empty_like(gx1)
+    gx = torch.empty(xh.size(1), H, dtype=gx1.dtype, device=gx1.device)   # source rows
     # workspace of the channel-per-lane form: per-relation partial sums of gvec
     part = None
     if graph.edge_table is not None and vec is not None and graph.T > 1 and not split:
@@ -148,8 +148,11 @@ class FusedRelationalLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, vec, edge, graph, rbf, w, sink=None, li=0):
-        """`edge`: [E,4], or this layer's handle from `EdgeFanout` ([H/64,E,4] stride-0 view; same memory)."""
-        N, H = x.shape
+        """`edge`: [E,4], or this layer's handle from `EdgeFanout` ([H/64,E,4] stride-0 view; same memory).
+        x / vec live in SOURCE rows, the outputs in TARGET rows; the two coincide for HVNet and differ for HTNet
+        (`graph.num_src`: one target row per atom and pair relation, relations.build_triadic)."""
+        Ns, H = x.shape
+        N = graph.N
         T = graph.T
         rp = graph.type_rowptr_host
         nk = rp[-1]
@@ -157,11 +160,11 @@ class FusedRelationalLayer(torch.autograd.Function):
         vec = None if vec is None else vec.contiguous()
         # --- node projection of every relation: xh[t] = x_proj_t(LayerNorm_t(x))  (rmnet.py:52)
         n, mean, rstd = nodeops.layernorm_fwd(x, 1e-5)
-        h = _launch("gemm", lambda: torch.addmm(w.b1cat, n, w.w1cat.t()))                                     # [N, T*H]
+        h = _launch("gemm", lambda: torch.addmm(w.b1cat, n, w.w1cat.t()))                                     # [Ns, T*H]
         a = nodeops.ssilu_fwd(h)
         # (biases that would be broadcast over a batched GEMM's rows are added by the consuming kernel
         # instead: baddbmm with a broadcast bias first copies it over the whole output)
-        xh = _launch("gemm", lambda: torch.bmm(a.view(N, T, H).transpose(0, 1), w.w2t))                       # [T, N, 3H], + b2 on load
+        xh = _launch("gemm", lambda: torch.bmm(a.view(Ns, T, H).transpose(0, 1), w.w2t))                      # [T, Ns, 3H], + b2 on load
         # --- fused edge part + residual (rmnet.py:55-73, 24-26)
         x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge)
         # --- PaiNNUpdate on the rows of each relation (rmnet.py:94-107)
@@ -203,7 +206,8 @@ class FusedRelationalLayer(torch.autograd.Function):
     def backward(ctx, gxo, gvo):
         x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q = ctx.saved_tensors
         graph, rbf, w = ctx.graph, ctx.rbf, ctx.w
-        N, H = x.shape
+        Ns, H = x.shape
+        N = graph.N
         T = graph.T
         rp = graph.type_rowptr_host
         nk = rp[-1]
@@ -246,10 +250,17 @@ class FusedRelationalLayer(torch.autograd.Function):
         else:
             gedge = torch.zeros(H // 64, graph.E, 4, dtype=torch.float32, device=gx1.device)
         gxh, gvec_in, gx_in = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge)
+        if graph.num_src:
+            # HTNet: the residual (rmnet.py:24-26) reads the atom's own row from each of its P virtual target rows;
+            # its gradient returns as the sum over those rows (the kernel adds no identity term in this mode)
+            P_, B_, Te = graph.triadic_pairs, graph.block, graph.T // graph.triadic_pairs
+            gx_in[:Te * B_] += gx1.view(Te, P_, B_, H).sum(1).reshape(Te * B_, H) * (0.5 ** 0.5)
+            if gvec_in is not None:
+                gvec_in[:Te * B_] += gvec1.view(Te, P_, B_, 3, H).sum(1).reshape(Te * B_, 3, H)
         gx_total = None
         if ctx.needs_input_grad[0]:
-            ga = _launch("gemm", lambda: torch.bmm(gxh, w.w2))                                                # [T, N, H]
-            gh = nodeops.ssilu_bwd(ga, h, N, T, H, H, N * H)                         # [N, T*H]
+            ga = _launch("gemm", lambda: torch.bmm(gxh, w.w2))                                                # [T, Ns, H]
+            gh = nodeops.ssilu_bwd(ga, h, Ns, T, H, H, Ns * H)                       # [Ns, T*H]
             gn = _launch("gemm", lambda: torch.mm(gh, w.w1cat))                                               # [N, H]
             gx_total = nodeops.layernorm_bwd(gn, x, mean, rstd, add=gx_in)
         ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))

@@ -109,8 +109,19 @@ class EdgeGeometry(torch.autograd.Function):
         graph = ctx.graph
         lib = _lib.load()
         gD = gedge.float().contiguous()
-        gpos_rows = torch.empty(graph.N, 3, dtype=torch.float32, device=gD.device)
-        if graph.out_rowptr is None:      # device-built graphs: out-edges from the CSC order (one sort fewer)
+        gpos_rows = torch.empty(graph.num_src or graph.N, 3, dtype=torch.float32, device=gD.device)
+        if graph.num_src:
+            # HTNet graph (virtual target rows): ordered segment sums, no atomics.  dE/dpos[i] = sum over the
+            # edges leaving i of gD - sum over the edges entering i of gD.
+            P_, B_, Te, TR = graph.triadic_pairs, graph.block, graph.T // graph.triadic_pairs, graph.T
+            g3 = gD[:, :3].contiguous()
+            rp_t, rp_s = graph.csr_rowptr.long(), graph.csc_rowptr.long()
+            into = torch.segment_reduce(g3, "sum", lengths=rp_t[1:] - rp_t[:-1], unsafe=True)            # [Nt,3]
+            outof = torch.segment_reduce(g3.index_select(0, graph.csc_pos.long()), "sum",
+                                         lengths=rp_s[1:] - rp_s[:-1], unsafe=True)                      # [TR*Ns,3]
+            gpos_rows = outof.view(TR, graph.num_src, 3).sum(0)
+            gpos_rows[:Te * B_] -= into.view(Te, P_, B_, 3).sum(1).reshape(Te * B_, 3)
+        elif graph.out_rowptr is None:      # device-built graphs: out-edges from the CSC order (one sort fewer)
             _lib.check(lib.hermnet_edge_geometry_bwd_csc(
                 _lib.ptr(gD), _lib.ptr(graph.csr_rowptr), _lib.ptr(graph.csc_rowptr), _lib.ptr(graph.csc_pos),
                 graph.T, graph.N, _lib.ptr(gpos_rows), _stream()), "hermnet_edge_geometry_bwd_csc")

@@ -49,7 +49,7 @@ class RelationalGraph(object):
                  "type_rowptr", "type_rowptr_host", "csr_rowptr", "csr_src", "csr_perm", "csc_rowptr", "csc_tgt",
                  "csc_pos", "out_rowptr", "out_edges", "src_id", "tgt_id", "shift", "row_active", "row_real",
                  "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device", "_cstruct", "_rel_bounds",
-                 "edge_table", "num_src", "res_row")
+                 "edge_table", "num_src", "res_row", "triadic_pairs", "src_real")
 
     def __init__(self):
         self._cstruct = None
@@ -57,6 +57,8 @@ class RelationalGraph(object):
         self.edge_table = None     # [E,32] per-edge radial record of the current step (set by HVNet.forward)
         self.num_src = 0           # separate source-row space (HTNet): rows of xh / vec; 0 = same rows as the targets
         self.res_row = None        # [N] int32 source row feeding the residual of each target row, or None
+        self.triadic_pairs = 0     # HTNet: pair relations per centre element (target rows = T_elem * pairs * block)
+        self.src_real = None       # HTNet: [num_src] 1 for source rows that hold an atom
 
     def rel_edge_bounds(self):
         """CSR edge ranges of the relations: edges of relation t are [b[t], b[t+1]) (rows are relation-ordered and
@@ -255,6 +257,112 @@ class RelationalGraph(object):
             g.batch_rows = torch.zeros(N, dtype=torch.long, device=dev)
             g.batch_rows[g.row_of_node] = batch.long()
         # deterministic per-graph read-out: atoms grouped by graph (stable) + segment lengths
+        if batch is not None and g.num_graphs > 1:
+            g.graph_perm = torch.argsort(batch.long(), stable=True)
+            g.graph_lengths = torch.zeros(g.num_graphs, dtype=torch.long, device=dev).index_add_(
+                0, batch.long(), torch.ones_like(batch.long()))
+        else:
+            g.graph_perm = None
+            g.graph_lengths = None
+        return g
+
+    @staticmethod
+    def build_triadic(atomic_number, edge_index, z_list, edge_shift=None, batch=None):
+        """HTNet's relation-ordered graph (DESIGN.md "HTNet"): relation rho = (centre element c, unordered pair
+        {p, q} of neighbour elements), T * T(T+1)/2 of them.
+
+        Two row spaces.  SOURCE rows: the atoms ordered by (element, id), every element padded to `block` rows (the
+        HVNet order); unknown elements behind.  TARGET rows: one block of `block` rows per relation, block (c, k)
+        holding the atoms of element c in the same order -- an atom is a target once per pair relation of its
+        element ("virtual" rows; `res_row` maps them back to the atom's source row).  A directed edge j -> i appears
+        once for every pair that contains element(j), i.e. T times: CSR by target row, CSC by (relation, SOURCE row),
+        which is exactly the layout the message kernels consume with `num_src` / `res_row` set.
+
+        Built with device-side torch ops (three stable sorts per neighbour list; HTNet is a secondary path -- the
+        HVNet build has its own kernels)."""
+        g = RelationalGraph()
+        dev = atomic_number.device
+        NA, E0, T = int(atomic_number.numel()), int(edge_index.size(1)), len(z_list)
+        pairs = [(p, q) for p in range(T) for q in range(p, T)]
+        P = len(pairs)
+        TR = T * P
+        z = atomic_number.long()
+        zl = torch.tensor(list(z_list), dtype=torch.long, device=dev)
+        eq = z[:, None] == zl[None, :]
+        rel = torch.where(eq.any(1), eq.int().argmax(1), torch.full((NA,), T, dtype=torch.long, device=dev))
+        counts = torch.zeros(T + 1, dtype=torch.long, device=dev).index_add_(0, rel, torch.ones_like(rel))
+        nb = batch.long().max().reshape(1) + 1 if (batch is not None and NA > 0) else torch.ones(1, dtype=torch.long, device=dev)
+        host = torch.cat([counts, nb]).cpu().tolist()          # the one host sync of the build
+        cnt_host, g.num_graphs = host[:T + 1], int(host[-1])
+        B = max(cnt_host[:T]) if T > 0 else 0
+        Ns, Nt = T * B + cnt_host[T], TR * B
+        g.num_atoms, g.T, g.device, g.uniform, g.block = NA, TR, dev, True, B
+        g.N, g.num_src, g.triadic_pairs = Nt, Ns, P
+        g.type_rowptr_host = [r * B for r in range(TR + 1)]
+        i32 = torch.int32
+        g.type_rowptr = torch.tensor(g.type_rowptr_host, dtype=i32, device=dev)
+
+        # source rows: (element, id) order, element blocks of B rows, unknown elements behind
+        g.node_order = torch.sort(rel.to(i32), stable=True).indices
+        first_sorted = torch.zeros(T + 1, dtype=torch.long, device=dev)
+        first_sorted[1:] = torch.cumsum(counts[:T], 0)
+        rel_sorted = rel[g.node_order]
+        local_sorted = torch.arange(NA, device=dev) - first_sorted[rel_sorted]
+        rows_sorted = local_sorted + rel_sorted * B
+        g.row_of_node = torch.empty_like(g.node_order)
+        g.row_of_node[g.node_order] = rows_sorted
+        local = torch.empty_like(g.node_order)
+        local[g.node_order] = local_sorted
+        g.z_rows = torch.zeros(Ns, dtype=torch.long, device=dev)
+        g.z_rows[g.row_of_node] = z
+        g.src_real = torch.zeros(Ns, dtype=torch.float32, device=dev)
+        g.src_real[g.row_of_node] = 1.0
+        g.row_real = g.src_real                                   # energy read-out masks SOURCE rows
+
+        # expanded edge list: edge (j -> i) once per pair containing element(j)
+        pair_of = torch.full((T + 1, T), -1, dtype=torch.long, device=dev)      # element -> its T pair indices
+        for e_ in range(T):
+            ks = [k for k, (p, q) in enumerate(pairs) if e_ in (p, q)]
+            pair_of[e_] = torch.tensor(ks, dtype=torch.long, device=dev)
+        src, tgt = edge_index[0].long(), edge_index[1].long()
+        tj, ti = rel[src], rel[tgt]
+        ok = (tj < T) & (ti < T)
+        eid = torch.nonzero(ok).reshape(-1)
+        eid_x = eid.repeat_interleave(T)                           # expanded: (edge id major, pair minor)
+        k_x = pair_of[tj[eid]].reshape(-1)
+        ti_x = ti[eid_x]
+        rel_x = ti_x * P + k_x
+        vt_x = rel_x * B + local[tgt[eid_x]]                       # virtual target row
+        rs_x = g.row_of_node[src[eid_x]]                           # source row
+        E = int(eid_x.numel())
+        g.E = E
+        big = TR * max(Ns, 1) + 1 >= 2 ** 31
+        kt = torch.long if big else i32
+        vt_s, csr_perm = torch.sort(vt_x.to(kt), stable=True)
+        vt_s = vt_s.long()
+        csr_src = rs_x[csr_perm]
+        ar = lambda n: torch.arange(n + 1, device=dev)
+        csr_rowptr = torch.searchsorted(vt_s, ar(Nt))
+        key2 = (rel_x[csr_perm] * Ns + csr_src)
+        key2_s, csc_pos = torch.sort(key2.to(kt), stable=True)
+        csc_rowptr = torch.searchsorted(key2_s.long(), ar(TR * Ns))
+        g.csr_rowptr, g.csr_src, g.csr_perm = csr_rowptr.to(i32), csr_src.to(i32), eid_x[csr_perm]
+        g.csc_rowptr, g.csc_pos, g.csc_tgt = csc_rowptr.to(i32), csc_pos.to(i32), vt_s[csc_pos].to(i32)
+        g.out_rowptr = g.out_edges = None
+        g.src_id, g.tgt_id = src[g.csr_perm].to(i32), tgt[g.csr_perm].to(i32)
+        g.shift = None if edge_shift is None else edge_shift[g.csr_perm].float().contiguous()
+        # target rows: real = the atom exists; active = its relation has at least one edge (hermnet.py:56-57)
+        rows = torch.arange(Nt, device=dev)
+        r_rel, r_loc = rows // max(B, 1), rows % max(B, 1)
+        r_el = r_rel // P
+        cnt_d = counts[:T]
+        row_real = (r_loc < cnt_d[r_el.clamp(max=max(T - 1, 0))]).float() if Nt > 0 else torch.zeros(0, device=dev)
+        tn = torch.arange(TR + 1, device=dev) * B
+        rel_edges = csr_rowptr[tn[1:]] - csr_rowptr[tn[:-1]] if TR > 0 else torch.zeros(0, dtype=torch.long, device=dev)
+        g.row_active = (rel_edges > 0)[r_rel].float() * row_real if Nt > 0 else row_real
+        g.res_row = (r_el * B + r_loc).to(i32)
+        g.batch32 = None if batch is None else batch.to(i32).contiguous()
+        g.batch_rows = None
         if batch is not None and g.num_graphs > 1:
             g.graph_perm = torch.argsort(batch.long(), stable=True)
             g.graph_lengths = torch.zeros(g.num_graphs, dtype=torch.long, device=dev).index_add_(

@@ -223,6 +223,89 @@ def hvnet_energy(sd, elems, pos, z, edge_index, batch, edge_shift=None, cell=Non
     return energy
 
 
+# ---------------------------------------------------------------------------------------------
+# HTNet (Heterogeneous Triadic Network) -- PARITY UNPINNED.
+# The reference names the model (`README.md:27`) and draws its subgraphs (`figs/subgraph.svg`, panel (c):
+# "A->A<-A:", "B->A<-C:"), but its class is a stub that raises NotImplementedError
+# (`HermNet/hermnet.py:155-157`), so there is nothing to pin against.  What follows restates the BUILD-DEFINED
+# specification in DESIGN.md ("HTNet"): it is the checker of the HIP path for BASELINE configs[2], not a
+# statement about the reference's numerics.
+# ---------------------------------------------------------------------------------------------
+def triadic_relations(elems):
+    """[(key, centre, (p, q))]: one relation per centre element and UNORDERED pair of neighbour elements, in
+    module order: centres in `elems` order, pairs (p <= q) in `elems` order.  T * T(T+1)/2 relations (18 for T = 3)."""
+    out = []
+    for c in elems:
+        for i, p in enumerate(elems):
+            for q in elems[i:]:
+                out.append(("%s_%s-%s" % (c, p, q), c, (p, q)))
+    return out
+
+
+def triadic_layer(sd, layer, elems, x, vec, z, edge_index, edge_embed, edge_vec, H):
+    """One heterogeneous triadic layer: the loop of `hermnet.py:51-61` over triadic relations instead of
+    elements.  Relation (c; p, q) owns a PaiNNModule; its subgraph = the edges j -> i with element(i) = c and
+    element(j) in {p, q} (`in_subgraph` restricted by source element, figs/subgraph.svg (c)); relations without an
+    edge are skipped (`hermnet.py:56-57`); the results of a centre's T(T+1)/2 relations are AVERAGED (the
+    reference accumulates with `+=`, `hermnet.py:60-61`; the fixed 1/P keeps activations at the scale of HVNet and
+    makes HTNet with one element identical to HVNet)."""
+    T = len(elems)
+    P = T * (T + 1) // 2
+    x_out = torch.zeros_like(x)
+    v_out = torch.zeros_like(vec)
+    src_all, tgt_all = edge_index[0], edge_index[1]
+    for key, c, (p, q) in triadic_relations(elems):
+        is_c = z == ATOMIC_NUMBERS[c]
+        from_pq = (z == ATOMIC_NUMBERS[p]) | (z == ATOMIC_NUMBERS[q])
+        emask = torch.where(is_c[tgt_all] & from_pq[src_all])[0]
+        if emask.numel() == 0:
+            continue
+        nid = torch.where(is_c)[0]
+        prm = _module_params(sd, layer, key)
+        dx, dvec = painn_message(prm, x, vec, src_all[emask], tgt_all[emask], edge_embed[emask], edge_vec[emask], H,
+                                 x.size(0))
+        x1 = (x[nid] + dx[nid]) * (1.0 / math.sqrt(2.0))
+        v1 = vec[nid] + dvec[nid]
+        dx2, dv2 = painn_update(prm, x1, v1, H)
+        x_out = x_out.index_add(0, nid, (x1 + dx2) * (1.0 / P))
+        v_out = v_out.index_add(0, nid, (v1 + dv2) * (1.0 / P))
+    return x_out, v_out
+
+
+def htnet_energy(sd, elems, pos, z, edge_index, batch, edge_shift=None, cell=None, *, rc=5.0, intensive=False,
+                 num_layers=5, hidden_channels=128, num_rbf=128, rbf=None, envelope_spec=None):
+    """Energy per graph of the build-defined HTNet: `hvnet_energy` with triadic layers."""
+    rbf = rbf or {"name": "gaussian"}
+    envelope_spec = envelope_spec or {"name": "polynomial", "exponent": 5}
+    if isinstance(elems, str):
+        elems = [elems]
+    H = hidden_channels
+    dist, evec = edge_geometry(pos, edge_index, edge_shift, cell, batch)
+    eemb = radial_basis(dist, sd, rc, num_rbf, rbf, envelope_spec)
+    x = sd["embed.weight"][z.long()]
+    vec = torch.zeros(x.size(0), 3, H, dtype=x.dtype)
+    for l in range(num_layers):
+        x, vec = triadic_layer(sd, l, elems, x, vec, z, edge_index, eemb, evec, H)
+    e_atom = F.linear(scaled_silu(F.linear(x, sd["out_energy.0.weight"], sd["out_energy.0.bias"])),
+                      sd["out_energy.2.weight"], sd["out_energy.2.bias"]).squeeze(1)
+    ng = int(batch.max()) + 1 if batch.numel() else 0
+    energy = torch.zeros(ng, dtype=e_atom.dtype).index_add_(0, batch, e_atom)
+    if intensive:
+        cnt = torch.zeros(ng, dtype=e_atom.dtype).index_add_(0, batch, torch.ones_like(e_atom)).clamp_(min=1)
+        energy = energy / cnt
+    return energy
+
+
+def htnet_energy_and_forces(sd, elems, data, **kw):
+    pos = data.pos.detach().clone().requires_grad_(True)
+    e = htnet_energy(sd, elems, pos, data.atomic_number, data.edge_index, data.batch,
+                     data.get("edge_shift"), data.get("cell"), **kw)
+    if not e.requires_grad:
+        return e.detach(), torch.zeros_like(pos)
+    g = torch.autograd.grad(e.sum(), pos, allow_unused=True)[0]
+    return e.detach(), (torch.zeros_like(pos) if g is None else -g)
+
+
 def energy_and_forces(sd, elems, data, **kw):
     """Energy [num_graphs] and forces [N,3] = -d(sum E)/d pos (`calculator.py:75-83`)."""
     pos = data.pos.detach().clone().requires_grad_(True)

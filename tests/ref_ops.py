@@ -28,8 +28,10 @@ def envelope_ref(u, kind, p):
 
 
 def message_scatter_ref(xh, vec, x, edge, wt, brbf, graph, rbf):
-    """Same contract as hermnet_message_scatter_fwd.  xh [T,N,3H]; wt [T,R,3H]."""
-    T, N, H3 = xh.shape
+    """Same contract as hermnet_message_scatter_fwd.  xh [T,Ns,3H]; wt [T,R,3H]; outputs in TARGET rows
+    (graph.N; = source rows unless graph.num_src / graph.res_row are set: HTNet's virtual target rows)."""
+    T, _, H3 = xh.shape
+    N = graph.N
     H = H3 // 3
     dt = x.dtype
     rowptr = graph.csr_rowptr.long()
@@ -57,8 +59,10 @@ def message_scatter_ref(xh, vec, x, edge, wt, brbf, graph, rbf):
     dx = torch.zeros(N, H, dtype=dt, device=x.device).index_add_(0, tgt_row, s * kf[:, None])
     dv = torch.zeros(N, 3, H, dtype=dt, device=x.device).index_add_(0, tgt_row, mv * kf[:, None, None])
     rk = (rel_row < T).to(dt)
-    x1 = (x + dx) * (1 / math.sqrt(2.0)) * rk[:, None]
-    v0 = vec if vec is not None else torch.zeros_like(dv)
+    res = getattr(graph, "res_row", None)
+    xr = x if res is None else x[res.long()]
+    x1 = (xr + dx) * (1 / math.sqrt(2.0)) * rk[:, None]
+    v0 = torch.zeros_like(dv) if vec is None else (vec if res is None else vec[res.long()])
     vec1 = (v0 + dv) * rk[:, None, None]
     return x1, vec1
 
@@ -200,7 +204,16 @@ def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge):
         ins = [xh_, x_, D] + ([v_] if vec is not None else [])
         gr = torch.autograd.grad([x1, vec1], ins, [gx1, gvec1])
     gedge[0, :, :3] = gr[2]          # all column blocks' contributions in slice 0; the others stay zero
-    return gr[0], (gr[3] if vec is not None else None), gr[1]
+    gxh, gv, gx = gr[0], (gr[3] if vec is not None else None), gr[1]
+    res = getattr(graph, "res_row", None)
+    if res is not None:
+        # kernel contract with virtual target rows: NO identity (residual) term in gx / gvec -- the host adds it
+        T = xh.size(0)
+        rk = (torch.arange(graph.N) < int(graph.type_rowptr[T])).to(xh.dtype)
+        gx = gx - torch.zeros_like(gx).index_add_(0, res.long(), gx1 * rk[:, None] * (1 / math.sqrt(2.0)))
+        if gv is not None:
+            gv = gv - torch.zeros_like(gv).index_add_(0, res.long(), gvec1 * rk[:, None, None])
+    return gxh, gv, gx
 
 
 class RefEdgeGeometry(torch.autograd.Function):
