@@ -159,6 +159,34 @@ def other_configs_secondary(hn, synth, dev, model_kw, steps=5, skip_c4=False):
     return res
 
 
+def graph_replay_secondary(hn, synth, dev, model, data, model_kw, steps=20):
+    """ms per step of whole-step hipGraph replay: the headline workload and the 1024-molecule batch (launch-bound
+    when enqueued eagerly)."""
+    from hermnet_amd.graph import GraphedStep
+    res = {}
+    cases = [("headline workload", model, hn.Data(**{k: v for k, v in data if not k.startswith("_hn")}))]
+    mol = synth.molecule_batch(num_graphs=1024).to(dev)
+    m2 = hn.HVNet(["H", "C", "O"], **model_kw).eval()
+    m2.load_state_dict(synth.synth_state_dict(m2.state_dict(), 10))
+    m2 = m2.to(dev)
+    for p_ in m2.parameters():
+        p_.requires_grad_(False)
+    cases.append(("configs[4] 1024-molecule batch", m2, mol))
+    for name, m, d in cases:
+        d.pos = d.pos.detach()
+        step = GraphedStep(m, d)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res[name] = {"ms_per_step": dt * 1e3, "atom_steps_per_s": d.pos.size(0) / dt}
+    return res
+
+
 def training_secondary(hn, synth, dev, model_kw, num_graphs=1024, steps=3):
     import torch.nn.functional as F
     d = synth.molecule_batch(num_graphs=num_graphs).to(dev)
@@ -445,6 +473,12 @@ def main():
             except Exception as ex:
                 out["secondary"]["single_gpu_same_cell"] = {"error": repr(ex)}
         if world == 1 and not sharded and not args.no_secondary:
+            # the same step captured once and replayed as ONE hipGraph launch (valid while the neighbour list is
+            # unchanged, hermnet_amd/graph.py): what the GPU needs when the host is out of the loop
+            try:
+                out["secondary"]["graph_replay"] = graph_replay_secondary(hn, synth, dev, model, data, model_kw)
+            except Exception as ex:
+                out["secondary"]["graph_replay"] = {"error": repr(ex)}
             try:   # the box's own copy bandwidth next to the 8 TB/s the roofline is priced against
                 out["roofline"]["measured_copy_GBps"] = measured_copy_bandwidth(dev)
             except Exception as ex:

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/hermnet_hip.h"
 
 namespace {
@@ -165,6 +166,92 @@ __global__ __launch_bounds__(kBlock) void group_rank_sort_kernel(const int* __re
   }
 }
 
+// ---- exclusive prefix sum of int32, three plain launches (block sums, scan of the block sums, local scan + offset).
+// Deliberately not hipcub::DeviceScan: a captured step is replayed as a hipGraph, and the library scan's look-back
+// state did not survive replays that were interleaved with eager runs (second replay: garbage row pointers ->
+// out-of-bounds scatter).  These kernels keep all their state in `temp`, rewritten on every run.
+constexpr int kScanTile = 1024;           // elements per block (256 threads x 4)
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* lds, int& total) {
+  // 256 threads: wave scans with shuffles, wave totals through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += u;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += lds[w];
+  total = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(kBlock) void scan_block_sums_kernel(const int* __restrict__ in, int n, int* __restrict__ sums) {
+  __shared__ int lds[4];
+  const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  int v = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v += (base + q < n) ? in[base + q] : 0;
+  int total;
+  (void)block_exclusive_scan(v, lds, total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void scan_sums_kernel(int* __restrict__ sums, int nb) {
+  // one block: every thread owns a contiguous chunk of the block sums
+  __shared__ int lds[4];
+  const int per = (nb + kBlock - 1) / kBlock;
+  const int lo = threadIdx.x * per, hi = min(lo + per, nb);
+  int v = 0;
+  for (int i = lo; i < hi; ++i) v += sums[i];
+  int total;
+  int run = block_exclusive_scan(v, lds, total);
+  for (int i = lo; i < hi; ++i) { const int x = sums[i]; sums[i] = run; run += x; }
+}
+
+__global__ __launch_bounds__(kBlock) void scan_apply_kernel(const int* __restrict__ in, int n, const int* __restrict__ sums,
+                                                           int* __restrict__ out) {
+  __shared__ int lds[4];
+  const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  int x[4], v = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { x[q] = (base + q < n) ? in[base + q] : 0; v += x[q]; }
+  int total;
+  int run = block_exclusive_scan(v, lds, total) + sums[blockIdx.x];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { if (base + q < n) out[base + q] = run; run += x[q]; }
+}
+
+size_t scan_temp_bytes(int n) { return ((size_t)(n + kScanTile - 1) / kScanTile + 1) * sizeof(int); }
+
+int exclusive_scan_i32(const int* in, int* out, int n, void* temp, size_t temp_bytes, hipStream_t s) {
+  if (n <= 0) return HN_OK;
+  const int nb = (n + kScanTile - 1) / kScanTile;
+  if (temp_bytes < scan_temp_bytes(n)) return HN_ERR_BAD_ARG;
+  int* sums = reinterpret_cast<int*>(temp);
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(kBlock), 0, s, in, n, sums);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, s, sums, nb);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, s, in, n, sums, out);
+  return HN_OK;
+}
+
+// Zero fill and copy as kernels, not hipMemsetAsync / hipMemcpyAsync: under hipGraph replay (ROCm 7.2) the captured
+// memset nodes of this build did not survive eager memsets issued between two replays -- the second replay left the
+// histogram un-zeroed (bisected with tools/graph_probe.py: garbage row pointers, then an out-of-bounds rank sort).
+__global__ __launch_bounds__(kBlock) void zero_i32_kernel(int* __restrict__ dst, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void copy_i32_kernel(const int* __restrict__ src, int n, int* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 struct GroupWork {
   int* cursor;      // [max keys + 1]
   int* slots;       // [n]
@@ -174,14 +261,18 @@ struct GroupWork {
 
 // rowptr [nkeys+1], out [n]
 int group_by_key(const int* key, int n, int nkeys, int* rowptr, int* out, const GroupWork& w, hipStream_t s) {
-  if (hipMemsetAsync(w.cursor, 0, sizeof(int) * (size_t)(nkeys + 1), s) != hipSuccess) return HN_ERR_LAUNCH;
+  static const int probe = getenv("HERMNET_PROBE_GROUP") ? atoi(getenv("HERMNET_PROBE_GROUP")) : 99;
+  hipLaunchKernelGGL(zero_i32_kernel, grid_for((long)nkeys + 1), dim3(kBlock), 0, s, w.cursor, (long)nkeys + 1);
+  if (probe <= 1) return HN_OK;
   if (n > 0) hipLaunchKernelGGL(hist_kernel, grid_for(n), dim3(kBlock), 0, s, key, n, w.cursor);
-  size_t sb = w.scan_bytes;
-  if (hipcub::DeviceScan::ExclusiveSum(w.scan_temp, sb, w.cursor, rowptr, nkeys + 1, s) != hipSuccess) return HN_ERR_LAUNCH;
+  if (probe <= 2) return HN_OK;
+  if (exclusive_scan_i32(w.cursor, rowptr, nkeys + 1, w.scan_temp, w.scan_bytes, s) != HN_OK) return HN_ERR_LAUNCH;
   if (n == 0) return HN_OK;
-  if (hipMemcpyAsync(w.cursor, rowptr, sizeof(int) * (size_t)nkeys, hipMemcpyDeviceToDevice, s) != hipSuccess)
-    return HN_ERR_LAUNCH;
+  if (probe <= 3) return HN_OK;
+  hipLaunchKernelGGL(copy_i32_kernel, grid_for(nkeys), dim3(kBlock), 0, s, rowptr, nkeys, w.cursor);
+  if (probe <= 4) return HN_OK;
   hipLaunchKernelGGL(scatter_kernel, grid_for(n), dim3(kBlock), 0, s, key, n, w.cursor, w.slots);
+  if (probe <= 5) return HN_OK;
   hipLaunchKernelGGL(group_rank_sort_kernel, dim3((unsigned)((nkeys + 3) / 4)), dim3(kBlock), 0, s, rowptr, nkeys, w.slots, out);
   return HN_OK;
 }
@@ -237,8 +328,7 @@ size_t sort_temp_bytes(int n) {
 }
 
 size_t work_temp_bytes(int n, int nkeys) {
-  size_t a = sort_temp_bytes(n), b = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const int*)nullptr, (int*)nullptr, nkeys + 1, (hipStream_t)0);
+  const size_t a = sort_temp_bytes(n), b = ((size_t)(nkeys + 1 + 1023) / 1024 + 1) * sizeof(int);   // = scan_temp_bytes
   return a > b ? a : b;
 }
 
@@ -250,7 +340,7 @@ extern "C" int hermnet_relation_counts(const long* atomic_number, int num_atoms,
                                        int* counts, void* stream) {
   if (num_atoms < 0 || num_rel <= 0 || !z_list || !counts) return HN_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(counts, 0, sizeof(int) * (num_rel + 1), s) != hipSuccess) return HN_ERR_LAUNCH;
+  hipLaunchKernelGGL(zero_i32_kernel, grid_for(num_rel + 1), dim3(kBlock), 0, s, counts, (long)num_rel + 1);
   if (num_atoms == 0) return HN_OK;
   if (!atomic_number) return HN_ERR_BAD_ARG;
   hipLaunchKernelGGL(count_relations_kernel, grid_for(num_atoms), dim3(kBlock), 0, s, atomic_number, num_atoms,
@@ -287,13 +377,17 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
   unsigned* rt_sorted = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
   size_t tbytes = tb;
 
+  static const int probe = getenv("HERMNET_PROBE_BUILD_PHASES") ? atoi(getenv("HERMNET_PROBE_BUILD_PHASES")) : 99;
   // ---- rows
-  if (hipMemsetAsync(out->z_rows, 0, sizeof(int) * N, s) != hipSuccess) return HN_ERR_LAUNCH;
-  if (hipMemsetAsync(out->row_real, 0, sizeof(float) * N, s) != hipSuccess) return HN_ERR_LAUNCH;
+  hipLaunchKernelGGL(zero_i32_kernel, grid_for(N), dim3(kBlock), 0, s, out->z_rows, (long)N);
+  hipLaunchKernelGGL(zero_i32_kernel, grid_for(N), dim3(kBlock), 0, s, reinterpret_cast<int*>(out->row_real), (long)N);
+  if (probe <= 1) return HN_OK;
   if (NA > 0) {
     hipLaunchKernelGGL(atom_keys_kernel, grid_for(NA), dim3(kBlock), 0, s, atomic_number, NA, z_list, T, keyA, valA);
+    if (probe <= 2) return HN_OK;
     if (hipcub::DeviceRadixSort::SortPairs(temp, tbytes, keyA, keyB, valA, out->node_order, NA, 0, bits_for(T + 1), s)
         != hipSuccess) return HN_ERR_LAUNCH;
+    if (probe <= 3) return HN_OK;
     hipLaunchKernelGGL(assign_rows_kernel, grid_for(NA), dim3(kBlock), 0, s, keyB, out->node_order, NA, row_start,
                        T, atomic_number, out->row_of_node, out->z_rows, out->row_real);
   }
@@ -312,7 +406,9 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
   // CSR: edges grouped by row(target), ascending edge id
   if (E > 0)
     hipLaunchKernelGGL(edge_target_row_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, E, out->row_of_node, ikeyA);
+  if (probe <= 4) return HN_OK;
   if ((rcg = group_by_key(ikeyA, E, N, out->csr_rowptr, out->csr_perm, gw, s)) != HN_OK) return rcg;
+  if (probe <= 5) return HN_OK;
   if (E > 0)
     hipLaunchKernelGGL(csr_gather2_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, shift, E, N, T, out->row_of_node,
                        row_start, out->csr_perm, out->csr_src, out->src_id, out->tgt_id, out->shift_csr, rt_csr, ikey2,
@@ -320,9 +416,8 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
   // CSC: CSR positions grouped by (relation(target), row(source)); edges to unknown-element targets fall
   // into the extra key range [T*N, (T+1)*N) and are simply not covered by csc_rowptr[0 .. T*N]
   if ((rcg = group_by_key(ikey2, E, (T + 1) * N, csc_rowptr_full, out->csc_pos, gw, s)) != HN_OK) return rcg;
-  if (hipMemcpyAsync(out->csc_rowptr, csc_rowptr_full, sizeof(int) * ((size_t)T * N + 1), hipMemcpyDeviceToDevice, s) !=
-      hipSuccess)
-    return HN_ERR_LAUNCH;
+  hipLaunchKernelGGL(copy_i32_kernel, grid_for((long)T * N + 1), dim3(kBlock), 0, s, csc_rowptr_full, T * N + 1,
+                     out->csc_rowptr);
   if (E > 0)
     hipLaunchKernelGGL(csc_tgt2_kernel, grid_for(E), dim3(kBlock), 0, s, rt_csr, out->csc_pos, E, out->csc_tgt);
   // out adjacency: CSR positions grouped by row(source) -- optional: hermnet_edge_geometry_bwd_csc reads the

@@ -1,0 +1,63 @@
+"""Whole-step hipGraph replay: energy + forces of a FIXED neighbour list as one graph launch.
+
+A step is ~200 kernel launches; eager enqueueing costs 2.7 ms of host time for a 3.8 ms step at 10k atoms, and is the
+limit for small systems (a 1024-molecule batch: ~7 ms eager for ~2.5 ms of GPU work).  Capturing relation build +
+forward + force backward once and replaying it removes the host from the loop.
+
+Scope: the graph bakes in every launch geometry, so it is valid while `edge_index` (hence E and the relation layout)
+stays the same -- repeated evaluation on one list (benchmarks, line searches, finite differences, several MD steps on a
+list that is rebuilt every k steps).  The reference rebuilds the list every step (`calculator.py:49`), and beyond-cutoff
+edges still send the `rbf_proj` bias, so a calculator may only reuse a graph while its list is unchanged;
+`GraphedStep.matches(data)` is the check.
+
+What made replay work (ROCm 7.2, bisected with tools/graph_probe.py): captured `hipMemsetAsync` nodes do not survive
+eager memsets issued between two replays (the second replay skips / mis-addresses the fill), so nothing on the step
+path uses hipMemsetAsync / hipMemcpyAsync any more (csrc/relation_kernels.hip: zero / copy / scan kernels).
+"""
+import torch
+
+
+class GraphedStep(object):
+    """energy, forces = step(pos) for a fixed graph topology.
+
+    model: HVNet / HTNet in eval() with parameters that do not require grad; data: `Data` on the GPU with
+    `edge_index` (and `cell` / `edge_shift`) already built.  Construction runs `warmup` eager steps on a side stream,
+    then captures one step.  `__call__(pos=None)` copies `pos` into the static input (if given), replays, and returns
+    the static output tensors (valid until the next call; clone them to keep them)."""
+
+    def __init__(self, model, data, warmup=3):
+        if not data.pos.is_cuda:
+            raise RuntimeError("GraphedStep needs GPU tensors")
+        if model.training:
+            raise RuntimeError("GraphedStep captures the eval() path")
+        self.model, self.data = model, data
+        self.pos = data.pos.detach().clone().requires_grad_(True)      # static input
+        data.pos = self.pos
+        self._key = (data.edge_index.data_ptr(), data.edge_index.size(1), data.atomic_number.data_ptr())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                                      # caches, weights, library workspaces
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.energy, self.forces = self._eager()
+        torch.cuda.synchronize()
+
+    def _eager(self):
+        e = self.model(self.data)
+        f = -torch.autograd.grad(e.sum(), self.pos)[0]
+        return e.detach(), f
+
+    def matches(self, data):
+        """True while `data` carries the neighbour list this graph was captured for."""
+        return (data.edge_index.data_ptr(), data.edge_index.size(1), data.atomic_number.data_ptr()) == self._key
+
+    def __call__(self, pos=None):
+        if pos is not None:
+            with torch.no_grad():
+                self.pos.copy_(pos)
+        self.graph.replay()
+        return self.energy, self.forces

@@ -713,3 +713,38 @@ def test_double_or_half_model_is_refused_on_the_gpu():
     for cast in ("double", "half"):
         with pytest.raises(TypeError, match="float32"):
             getattr(g.model().to(_dev()), cast)()(d)
+
+
+def test_whole_step_graph_replay_100_steps_bit_identical_to_eager():
+    """relation build + forward + force backward captured once and replayed as one hipGraph.
+    100 replays -- with eager steps and other device work in between, and with the coordinates changing -- must equal
+    the eager step bit for bit (the single-GPU path has no atomics on floats, so eager itself is reproducible)."""
+    from hermnet_amd.graph import GraphedStep
+    dev = _dev()
+    g = Golden("alloy108")
+    model = g.model().to(dev)
+    for p in model.parameters():
+        p.requires_grad_(False)
+
+    def eager(pos):
+        d = g.data().to(dev)
+        d.pos = pos.clone().requires_grad_(True)
+        e = model(d)
+        return e.detach(), -torch.autograd.grad(e.sum(), d.pos)[0]
+
+    data = g.data().to(dev)
+    pos0 = data.pos.clone()
+    step = GraphedStep(model, data)
+    assert step.matches(data)
+    gen = torch.Generator().manual_seed(4)
+    for k in range(100):
+        # small displacements: the neighbour LIST stays as captured (what the graph is valid for)
+        pos = pos0 + 1e-3 * torch.randn(pos0.shape, generator=gen).to(dev)
+        e, f = step(pos)
+        e, f = e.clone(), f.clone()
+        if k % 10 == 0:
+            e_ref, f_ref = eager(pos)            # an eager step in between (this used to break the next replay)
+            assert torch.equal(e, e_ref) and torch.equal(f, f_ref), k
+            torch.zeros(1 << 20, device=dev).sum()      # unrelated memsets / reductions between replays
+    e, f = step(pos0)
+    assert rel_err(e.cpu(), g.energy) < 1e-5 and rel_err(f.cpu(), g.forces) < 1e-5
