@@ -216,7 +216,9 @@ class HVNet(nn.Module):
         if train:   # segment_reduce has no second derivative
             energy = torch.zeros(graph.num_graphs, dtype=x.dtype, device=x.device).index_add(0, batch, per_atom_energy)
         else:
-            energy = torch.segment_reduce(per_atom_energy[graph.graph_perm], "sum", lengths=graph.graph_lengths)
+            # (unsafe=True: no host-side validation of `lengths` -- they come from the same `batch` vector; the check
+            # would synchronise, which also forbids capturing the step into a hipGraph)
+            energy = torch.segment_reduce(per_atom_energy[graph.graph_perm], "sum", lengths=graph.graph_lengths, unsafe=True)
         if self.intensive:
             energy = energy / graph.graph_lengths.clamp(min=1).to(energy.dtype)
         return energy

@@ -715,13 +715,14 @@ def test_double_or_half_model_is_refused_on_the_gpu():
             getattr(g.model().to(_dev()), cast)()(d)
 
 
-def test_whole_step_graph_replay_100_steps_bit_identical_to_eager():
+@pytest.mark.parametrize("name", ["alloy108", "mol16"])
+def test_whole_step_graph_replay_100_steps_bit_identical_to_eager(name):
     """relation build + forward + force backward captured once and replayed as one hipGraph.
     100 replays -- with eager steps and other device work in between, and with the coordinates changing -- must equal
     the eager step bit for bit (the single-GPU path has no atomics on floats, so eager itself is reproducible)."""
     from hermnet_amd.graph import GraphedStep
     dev = _dev()
-    g = Golden("alloy108")
+    g = Golden(name)
     model = g.model().to(dev)
     for p in model.parameters():
         p.requires_grad_(False)
