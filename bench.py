@@ -172,6 +172,13 @@ def graph_replay_secondary(hn, synth, dev, model, data, model_kw, steps=20):
     for p_ in m2.parameters():
         p_.requires_grad_(False)
     cases.append(("configs[4] 1024-molecule batch", m2, mol))
+    # a launch-bound case: configs[0]'s 64-atom Si cell (2 layers) -- eager enqueueing, not the GPU, sets its step time
+    m3 = hn.HVNet(["Si"], rc=5.0, num_layers=2, hidden_channels=128, num_rbf=128).eval()
+    m3.load_state_dict(synth.synth_state_dict(m3.state_dict(), 1))
+    m3 = m3.to(dev)
+    for p_ in m3.parameters():
+        p_.requires_grad_(False)
+    cases.append(("configs[0] 64-atom Si cell", m3, synth.si_diamond().to(dev)))
     for _, _, d in cases:
         d.pos = d.pos.detach()
     import torch.cuda.tunable as tunable
@@ -182,15 +189,18 @@ def graph_replay_secondary(hn, synth, dev, model, data, model_kw, steps=20):
     finally:
         tunable.enable(was)
     for name, step, d in steps_:
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        res[name] = {"ms_per_step": dt * 1e3, "atom_steps_per_s": d.pos.size(0) / dt}
+        t = {}
+        for kind, fn in (("graph", step), ("eager", step._eager)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            t[kind] = (time.perf_counter() - t0) / steps
+        res[name] = {"ms_per_step": t["graph"] * 1e3, "atom_steps_per_s": d.pos.size(0) / t["graph"],
+                     "eager_ms_per_step_same_settings": t["eager"] * 1e3}
     res["note"] = ("one hipGraph launch per step (relation build + forward + force backward captured once); valid while "
                    "the neighbour list is unchanged; library-default GEMM solutions")
     return res
