@@ -74,6 +74,10 @@ SIGNATURES = {
     "hermnet_update_mid_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_energy_head_fwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_energy_head_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_node_gemm": (ctypes.c_int, [c_fp, ctypes.c_long, ctypes.c_long, c_fp, ctypes.c_long, ctypes.c_long,
+                                         c_fp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_long, ctypes.c_int, c_fp, ctypes.c_long,
+                                         c_fp, ctypes.c_long, ctypes.c_long, c_fp]),
     "hermnet_halo_rows": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "hermnet_halo_accumulate": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "hermnet_host_rbf_row": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,

@@ -15,6 +15,12 @@ from .ops import _launch, _split_t, _stream
 
 P = _lib.ptr
 
+import os as _os
+# Node-level linears on the build's own fp32 MFMA GEMM with ScaledSiLU (forward and backward) fused into the operand
+# load / result store (csrc/node_gemm.hip) instead of library GEMMs + separate elementwise launches.  Uniform row
+# layout only (one batched launch per stage); HERMNET_NODE_GEMM=0 selects the library path.
+_NODE_GEMM = _os.environ.get("HERMNET_NODE_GEMM", "1") != "0"
+
 
 class LayerWeights(object):
     """Kernel-ready views of one HeteroVertexConv's parameters, rebuilt when they change."""
@@ -48,6 +54,7 @@ class LayerWeights(object):
         b1 = [m.x_proj[0].weight @ m.x_layernorm.bias + m.x_proj[0].bias for m in ml]
         self.w1cat = torch.cat(w1, 0).contiguous()                                  # [T*H, H]
         self.b1cat = torch.cat(b1, 0).contiguous()                                  # [T*H]
+        self.w1cat_t = self.w1cat.t().contiguous()                                  # [H, T*H]
         self.w2 = torch.stack([m.x_proj[2].weight for m in ml], 0).contiguous()     # [T, 3H, H]
         self.w2t = self.w2.transpose(1, 2).contiguous()                             # [T, H, 3H]
         self.b2 = torch.stack([m.x_proj[2].bias for m in ml], 0)[:, None, :].contiguous()   # [T,1,3H]
@@ -159,19 +166,38 @@ class FusedRelationalLayer(torch.autograd.Function):
         x = x.contiguous()
         vec = None if vec is None else vec.contiguous()
         # --- node projection of every relation: xh[t] = x_proj_t(LayerNorm_t(x))  (rmnet.py:52)
+        uni, B = graph.uniform and nk > 0, graph.block
+        fused_gemm = _NODE_GEMM and uni and x.is_cuda
         n, mean, rstd = nodeops.layernorm_fwd(x, 1e-5)
-        h = _launch("gemm", lambda: torch.addmm(w.b1cat, n, w.w1cat.t()))                                     # [Ns, T*H]
-        a = nodeops.ssilu_fwd(h)
-        # (biases that would be broadcast over a batched GEMM's rows are added by the consuming kernel
-        # instead: baddbmm with a broadcast bias first copies it over the whole output)
-        xh = _launch("gemm", lambda: torch.bmm(a.view(Ns, T, H).transpose(0, 1), w.w2t))                      # [T, Ns, 3H], + b2 on load
+        if fused_gemm:
+            h = torch.empty(Ns, T * H, dtype=x.dtype, device=x.device)
+            nodeops.gemm(n, w.w1cat, h, Ns, T * H, H, bias=w.b1cat)                                           # [Ns, T*H]
+            xh = torch.empty(T, Ns, 3 * H, dtype=x.dtype, device=x.device)
+            # ScaledSiLU applied while the operand tile is staged: the activation is never materialised
+            nodeops.gemm(h, w.w2, xh, Ns, 3 * H, H, batch=T, lda=T * H, sA=H, sB=3 * H * H, sC=Ns * 3 * H, prologue=1)
+        else:
+            h = _launch("gemm", lambda: torch.addmm(w.b1cat, n, w.w1cat.t()))                                 # [Ns, T*H]
+            a = nodeops.ssilu_fwd(h)
+            # (biases that would be broadcast over a batched GEMM's rows are added by the consuming kernel
+            # instead: baddbmm with a broadcast bias first copies it over the whole output)
+            xh = _launch("gemm", lambda: torch.bmm(a.view(Ns, T, H).transpose(0, 1), w.w2t))                  # [T, Ns, 3H], + b2 on load
         # --- fused edge part + residual (rmnet.py:55-73, 24-26)
         x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge)
         # --- PaiNNUpdate on the rows of each relation (rmnet.py:94-107)
         vp = torch.empty(N, 3, 2 * H, dtype=x.dtype, device=x.device)
         h2 = torch.empty(N, H, dtype=x.dtype, device=x.device)
         q = torch.empty(N, 3 * H, dtype=x.dtype, device=x.device)
-        uni, B = graph.uniform and nk > 0, graph.block
+        if fused_gemm:
+            nodeops.gemm(vec1, w.wv_s, vp, 3 * B, 2 * H, H, batch=T, sA=3 * B * H, sB=2 * H * H, sC=3 * B * 2 * H)
+            vdot, xin = nodeops.update_mid(vp, x1, nk, H)
+            nodeops.gemm(xin, w.wx0_s, h2, B, H, 2 * H, batch=T, sA=B * 2 * H, sB=H * 2 * H, sC=B * H)
+            nodeops.gemm(h2, w.wx2_s, q, B, 3 * H, H, batch=T, sA=B * H, sB=3 * H * H, sC=B * 3 * H,
+                         prologue=1, pbias=w.bx0_s, s_pbias=H)
+            x_out, vec_out = nodeops.update_out(q, vdot, vp, x1, vec1, graph.row_active, N, nk, H, qbias=w.bx2_s,
+                                                rows_per_bias=B)
+            ctx.save_for_backward(x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q)
+            ctx.graph, ctx.rbf, ctx.w, ctx.sink, ctx.li = graph, rbf, w, sink, li
+            return x_out, vec_out
         if uni:   # every relation owns `B` rows: one batched GEMM per stage
             _launch("gemm", lambda: torch.bmm(vec1[:nk].view(T, 3 * B, H), w.wvt_s, out=vp[:nk].view(T, 3 * B, 2 * H)))
         else:
@@ -217,33 +243,44 @@ class FusedRelationalLayer(torch.autograd.Function):
         qb = dict(qbias=w.bx2_s, rows_per_bias=B) if uni else {}
         kb = dict(bias=w.bx0_s, rows_per_bias=B) if uni else {}
         gq, gvdot, gvp, gx1, gvec1 = nodeops.update_out_bwd(gxo, gvo, q, vdot, vp, graph.row_active, N, nk, H, **qb)
-        ga2 = torch.empty(N, H, dtype=x.dtype, device=x.device)
+        fused_gemm = _NODE_GEMM and uni and x.is_cuda
         gxin = torch.empty(N, 2 * H, dtype=x.dtype, device=x.device)
-        if uni:
-            _launch("gemm", lambda: torch.bmm(gq[:nk].view(T, B, 3 * H), w.wx2_s, out=ga2[:nk].view(T, B, H)))
+        if fused_gemm:
+            # (gq Wx2) * ScaledSiLU'(h2 + bx0): the activation's backward rides in the GEMM's epilogue
+            gh2 = torch.empty(nk, H, dtype=x.dtype, device=x.device)
+            nodeops.gemm(gq, w.wx2t_s, gh2, B, H, 3 * H, batch=T, sA=B * 3 * H, sB=H * 3 * H, sC=B * H,
+                         epilogue=1, bias=w.bx0_s, s_bias=H, E=h2, lde=H, sE=B * H)
+            nodeops.gemm(gh2, w.wx0t_s, gxin, B, 2 * H, H, batch=T, sA=B * H, sB=2 * H * H, sC=B * 2 * H)
+            nodeops.update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, nk, H)
+            nodeops.gemm(gvp, w.wvt_s, gvec1, 3 * B, H, 2 * H, batch=T, sA=3 * B * 2 * H, sB=H * 2 * H, sC=3 * B * H,
+                         epilogue=2)                                                           # gvec1 += gvp Wv
         else:
-            for t in range(T):
-                lo, hi = rp[t], rp[t + 1]
-                if hi > lo:
-                    _launch("gemm", lambda: torch.mm(gq[lo:hi], w.wx2[t], out=ga2[lo:hi]))
-        gh2 = nodeops.ssilu_bwd(ga2, h2, nk, 1, H, H, H, **kb) if nk > 0 else ga2[:0]
-        if uni:
-            _launch("gemm", lambda: torch.bmm(gh2.view(T, B, H), w.wx0_s, out=gxin[:nk].view(T, B, 2 * H)))
-        else:
-            for t in range(T):
-                lo, hi = rp[t], rp[t + 1]
-                if hi > lo:
-                    _launch("gemm", lambda: torch.mm(gh2[lo:hi], w.wx0[t], out=gxin[lo:hi]))
-        nodeops.update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, nk, H)
-        if uni:
-            gv = gvec1[:nk].view(T, 3 * B, H)
-            _launch("gemm", lambda: torch.baddbmm(gv, gvp[:nk].view(T, 3 * B, 2 * H), w.wv_s, out=gv))
-        else:
-            for t in range(T):
-                lo, hi = rp[t], rp[t + 1]
-                if hi > lo:
-                    g = gvec1[lo:hi].view(-1, H)
-                    _launch("gemm", lambda: torch.addmm(g, gvp[lo:hi].view(-1, 2 * H), w.wv[t], out=g))
+            ga2 = torch.empty(N, H, dtype=x.dtype, device=x.device)
+            if uni:
+                _launch("gemm", lambda: torch.bmm(gq[:nk].view(T, B, 3 * H), w.wx2_s, out=ga2[:nk].view(T, B, H)))
+            else:
+                for t in range(T):
+                    lo, hi = rp[t], rp[t + 1]
+                    if hi > lo:
+                        _launch("gemm", lambda: torch.mm(gq[lo:hi], w.wx2[t], out=ga2[lo:hi]))
+            gh2 = nodeops.ssilu_bwd(ga2, h2, nk, 1, H, H, H, **kb) if nk > 0 else ga2[:0]
+            if uni:
+                _launch("gemm", lambda: torch.bmm(gh2.view(T, B, H), w.wx0_s, out=gxin[:nk].view(T, B, 2 * H)))
+            else:
+                for t in range(T):
+                    lo, hi = rp[t], rp[t + 1]
+                    if hi > lo:
+                        _launch("gemm", lambda: torch.mm(gh2[lo:hi], w.wx0[t], out=gxin[lo:hi]))
+            nodeops.update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, nk, H)
+            if uni:
+                gv = gvec1[:nk].view(T, 3 * B, H)
+                _launch("gemm", lambda: torch.baddbmm(gv, gvp[:nk].view(T, 3 * B, 2 * H), w.wv_s, out=gv))
+            else:
+                for t in range(T):
+                    lo, hi = rp[t], rp[t + 1]
+                    if hi > lo:
+                        g = gvec1[lo:hi].view(-1, H)
+                        _launch("gemm", lambda: torch.addmm(g, gvp[lo:hi].view(-1, 2 * H), w.wv[t], out=g))
         fan = edge.dim() == 3          # handle from EdgeFanout: return the slices unreduced
         if fan and ctx.sink is not None:
             gedge = ctx.sink.slice(ctx.li)
@@ -259,9 +296,16 @@ class FusedRelationalLayer(torch.autograd.Function):
                 gvec_in[:Te * B_] += gvec1.view(Te, P_, B_, 3, H).sum(1).reshape(Te * B_, 3, H)
         gx_total = None
         if ctx.needs_input_grad[0]:
-            ga = _launch("gemm", lambda: torch.bmm(gxh, w.w2))                                                # [T, Ns, H]
-            gh = nodeops.ssilu_bwd(ga, h, Ns, T, H, H, Ns * H)                       # [Ns, T*H]
-            gn = _launch("gemm", lambda: torch.mm(gh, w.w1cat))                                               # [N, H]
+            if fused_gemm:
+                gh = torch.empty(Ns, T * H, dtype=x.dtype, device=x.device)
+                nodeops.gemm(gxh, w.w2t, gh, Ns, H, 3 * H, batch=T, sA=Ns * 3 * H, sB=H * 3 * H, ldc=T * H, sC=H,
+                             epilogue=1, E=h, lde=T * H, sE=H)                   # (gxh W2) * ScaledSiLU'(h)
+                gn = torch.empty(Ns, H, dtype=x.dtype, device=x.device)
+                nodeops.gemm(gh, w.w1cat_t, gn, Ns, H, T * H)
+            else:
+                ga = _launch("gemm", lambda: torch.bmm(gxh, w.w2))                                            # [T, Ns, H]
+                gh = nodeops.ssilu_bwd(ga, h, Ns, T, H, H, Ns * H)                   # [Ns, T*H]
+                gn = _launch("gemm", lambda: torch.mm(gh, w.w1cat))                                           # [N, H]
             gx_total = nodeops.layernorm_bwd(gn, x, mean, rstd, add=gx_in)
         ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
         return gx_total, gvec_in, ge, None, None, None, None, None

@@ -115,3 +115,16 @@ def halo_accumulate(x, vec, plan, buf):
     rows, ptr, pos = plan.accumulate_lists()
     _lib.check(_launch("halo_accumulate", lambda: _lib.load().hermnet_halo_accumulate(
         P(x), P(vec), P(rows), P(ptr), P(pos), int(rows.numel()), x.size(1), P(buf), _stream())), "hermnet_halo_accumulate")
+
+
+def gemm(A, Bt, C, M, N, K, batch=1, lda=None, ldb=None, ldc=None, sA=0, sB=0, sC=0,
+         prologue=0, pbias=None, s_pbias=0, epilogue=0, bias=None, s_bias=0, E=None, lde=0, sE=0, a_off=0, c_off=0, e_off=0):
+    """C[b] = epilogue(prologue(A[b]) @ Bt[b]^T) on the fp32 matrix pipe with the neighbouring elementwise stage fused
+    (include/hermnet_hip.h: hermnet_node_gemm).  Tensors are passed with explicit leading dimensions / batch strides
+    (in elements) so that column slices and relation blocks of larger arrays need no copies; `*_off` = element offsets."""
+    fp = lambda t, off=0: None if t is None else t.data_ptr() + 4 * off
+    _lib.check(_launch("node_gemm", lambda: _lib.load().hermnet_node_gemm(
+        fp(A, a_off), lda if lda is not None else K, sA, fp(Bt), ldb if ldb is not None else K, sB,
+        fp(C, c_off), ldc if ldc is not None else N, sC, M, N, K, batch, prologue, fp(pbias), s_pbias,
+        epilogue, fp(bias), s_bias, fp(E, e_off), lde, sE, _stream())), "hermnet_node_gemm")
+    return C

@@ -256,6 +256,21 @@ int hermnet_energy_head_fwd(const float* h, const float* w, const float* b, cons
 int hermnet_energy_head_bwd(const float* ge, const float* h, const float* w, const float* row_mask, float* gh,
                             int rows, int cols, void* stream);
 
+/* fp32 MFMA GEMM of the node-level linears (rmnet.py:52 x_proj, rmnet.py:94-107 vec_proj / xvec_proj and their input
+ * gradients) with the neighbouring elementwise stage fused in (csrc/node_gemm.hip):
+ *     C[b][M, N] = epilogue( prologue(A[b])[M, K] . Bt[b][N, K]^T ),   b < batch (relation blocks; strides in elements)
+ * A, Bt are K-contiguous (lda, ldb multiples of 4; K a multiple of 64); Bt is an nn.Linear weight [out, in] (or the
+ * transposed copy the host keeps for backward products).
+ *   prologue 0: none            1: A := ScaledSiLU(A + pbias[b][k])   (pbias may be NULL)
+ *   epilogue 0: C = acc + bias[b][n] (bias may be NULL)
+ *            1: C = acc * ScaledSiLU'(E[b][m, n] + bias[b][n])   (backward of the activation; bias may be NULL)
+ *            2: C += acc */
+int hermnet_node_gemm(const float* A, long lda, long strideA, const float* Bt, long ldb, long strideB,
+                      float* C, long ldc, long strideC, int M, int N, int K, int batch,
+                      int prologue, const float* pbias, long stridePbias,
+                      int epilogue, const float* bias, long strideBias,
+                      const float* E, long lde, long strideE, void* stream);
+
 /* Halo exchange packing for atom-sharded runs (one process per GPU; the exchange itself is an RCCL all-to-all made
  * by the host code, hermnet_amd/sharding.py).  A packed row = [ x (H) | vec (3H) ]; idx [n] (int64) holds rows.
  *   mode 0  buf[k] = rows[idx[k]]                         pack what the neighbours need
