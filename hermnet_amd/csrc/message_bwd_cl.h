@@ -28,6 +28,7 @@ struct HnBwdClArgs {
   float* gx;                 // [Nsrc, H]
   float4* gedge;             // [H/64, E]
   int rows_per_block;
+  int xcd_remap;             // 1 = XCD-contiguous workgroup order (message_kernels.hip: xcd_contiguous)
 };
 
 size_t hn_bwd_cl_lds_bytes(int R);

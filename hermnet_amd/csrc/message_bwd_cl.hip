@@ -140,9 +140,21 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
   extern __shared__ __align__(16) float4 tile[];     // [tap row][64] of (s, a, b, 0)
   const int tile_rows = a.R + 2 * HN_PAD + 1;
 
-  const int t = blockIdx.z;
-  const int cb = blockIdx.y;
-  const int r0 = blockIdx.x * a.rows_per_block;
+  // XCD-aware order (see message_kernels.hip: xcd_contiguous): the dispatcher deals the linearised grid round-robin over
+  // the 8 XCDs; XCD k gets the k-th contiguous eighth of (relation, column block, row chunk), i.e. a slab of source rows
+  // whose targets' gradient rows (the gathers) are mostly its own slab's atoms.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd_remap) {
+    const int total = gridDim.x * gridDim.y * gridDim.z, per = total >> 3;
+    int L = bx + gridDim.x * (by + gridDim.y * bz);
+    if (L < per * 8) {
+      L = (L & 7) * per + (L >> 3);
+      bx = L % gridDim.x; by = (L / gridDim.x) % gridDim.y; bz = L / (gridDim.x * gridDim.y);
+    }
+  }
+  const int t = bz;
+  const int cb = by;
+  const int r0 = bx * a.rows_per_block;
   const int r1 = min(r0 + a.rows_per_block, a.Nsrc);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

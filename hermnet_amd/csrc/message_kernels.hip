@@ -77,6 +77,7 @@ struct MsgArgs {
   float* gx;           // bwd out [N,H]
   float4* gedge;       // bwd out [H/64,E]
   int rows_per_block;
+  int xcd_remap;       // 1 = XCD-contiguous block order (see xcd_contiguous)
   int split_t;         // bwd: 1 = one relation per workgroup (blockIdx.z), gvec is [T,N,3,H] partial sums
 };
 
@@ -321,6 +322,17 @@ __device__ __forceinline__ void rbf_all(const float* wcol, const float2* tb, Vec
   }
 }
 
+// XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an XCD and its
+// 4 MiB L2), so with the identity mapping every XCD walks the WHOLE row range and sees every gather table in full
+// (15-46 MB at config 2: L2 misses, Infinity-Cache hits).  Rows are in (relation, atom id) order and atom ids of a
+// structure are spatially coherent, so giving XCD k the k-th contiguous eighth of the blocks confines its gathers to
+// the rows near one slab of the structure -- a few MB that its L2 can hold.  Speed only; any mapping is correct.
+__device__ __forceinline__ int xcd_contiguous(int b, int nb, int on) {
+  const int per = nb >> 3;
+  if (!on || b >= per * 8) return b;        // (the nb % 8 trailing blocks keep their place)
+  return (b & 7) * per + (b >> 3);
+}
+
 // Decode blockIdx.x -> (relation t, first row, one-past-last row) for blocks of `rpb` rows
 // laid out relation after relation.  Returns -1 for a work block, else the index of the
 // surplus block (0, 1, ...) past the last work block.
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
 
   const int cb = blockIdx.y;
   int t, r0, r1;
-  const int surplus = decode_block(a, blockIdx.x, t, r0, r1);
+  const int surplus = decode_block(a, xcd_contiguous(blockIdx.x, gridDim.x, a.xcd_remap), t, r0, r1);
   if (surplus >= 0) {
     // the first surplus block zeroes the rows of unknown-type atoms (they are never targets)
     if (surplus == 0) {
@@ -909,6 +921,8 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   static const int variant_l0 = env_int("HERMNET_FWD_VARIANT_L0", 8400);
   const int variant = vec ? variant_vec : variant_l0;
   a.rows_per_block = pick_rows(a.N, hidden / HN_CB, a.T * (hidden / HN_CB), rpb_fwd);
+  static const int xcd = env_int("HERMNET_XCD_REMAP", 1);
+  a.xcd_remap = xcd;
   const size_t lds = lds_bytes(a.R);
   if (lds > 160 * 1024) return HN_ERR_LDS;
   // blocks: sum_t ceil(N_t / rpb) <= N / rpb + T, plus one surplus block that zeroes unknown rows
@@ -951,6 +965,8 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
     b.gedge = reinterpret_cast<float4*>(gedge);
     b.type_rowptr = g->type_rowptr;
     static const int rpb_cl = env_int("HERMNET_BWD_CL_ROWS", 0);
+    static const int xcd_cl = env_int("HERMNET_XCD_REMAP", 1);
+    b.xcd_remap = xcd_cl;
     return hn_bwd_cl_launch(b, vec != nullptr, rpb_cl, reinterpret_cast<hipStream_t>(stream));
   }
   a.xh = xh; a.xh_bias = xh_bias; a.vec = vec; a.wt = wt; a.brbf = brbf;

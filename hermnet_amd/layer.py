@@ -16,10 +16,12 @@ from .ops import _launch, _split_t, _stream
 P = _lib.ptr
 
 import os as _os
-# Node-level linears on the build's own fp32 MFMA GEMM with ScaledSiLU (forward and backward) fused into the operand
-# load / result store (csrc/node_gemm.hip) instead of library GEMMs + separate elementwise launches.  Uniform row
-# layout only (one batched launch per stage); HERMNET_NODE_GEMM=0 selects the library path.
-_NODE_GEMM = _os.environ.get("HERMNET_NODE_GEMM", "1") != "0"
+# HERMNET_NODE_GEMM=1: node-level linears on the build's own fp32 MFMA GEMM with ScaledSiLU (forward and backward)
+# fused into the operand load / result store (csrc/node_gemm.hip) instead of library GEMMs + separate elementwise
+# launches (uniform row layout only).  OFF by default: measured on config 2 it enqueues faster (2.06 vs 2.71 ms of host
+# time per step) but runs slower on the GPU (4.40 vs 3.88 ms/step) -- its 64 x 64 tiles reach 45-75 TF against the
+# library's 57-81 TF on these skinny shapes, and a prologue-fused activation is re-evaluated by every column tile.
+_NODE_GEMM = _os.environ.get("HERMNET_NODE_GEMM", "0") != "0"
 
 
 class LayerWeights(object):
