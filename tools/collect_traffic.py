@@ -15,8 +15,11 @@ import sys
 
 
 def kernel_key(name):
-    if "message_scatter" not in name:
+    """message_scatter_{fwd,bwd}[_l0]; the channel-per-lane backward and its finish launch count as one operator."""
+    if "message_scatter" not in name and "message_bwd_finish" not in name:
         return None
+    if "message_bwd_finish" in name:
+        return "message_bwd_finish"
     base = "message_scatter_fwd" if "fwd" in name else "message_scatter_bwd"
     has_vec = "<true" in name or "ILb1" in name
     return base + ("" if has_vec else "_l0")
