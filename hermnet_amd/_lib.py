@@ -64,8 +64,9 @@ SIGNATURES = {
     "hermnet_ssilu_fwd": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_long, ctypes.c_int, c_fp]),
     "hermnet_ssilu_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_long, ctypes.c_long, c_fp]),
-    "hermnet_layernorm_fwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_fp]),
-    "hermnet_layernorm_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_layernorm_fwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_float, c_fp]),
+    "hermnet_layernorm_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_update_mid": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_update_out": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int] + [c_fp] * 7 +
                            [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),

@@ -222,9 +222,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 constexpr int kLnMaxPerLane = 4;   // float4 chunks per lane: H <= 4 * 64 * 4 = 1024
 
+// Rows are H floats apart; the statistics run over the first Hr channels only (Hr < H: the row is zero-padded to a
+// multiple of 64 channels for the message kernels' column blocks, hermnet_amd/layer.py; padded outputs are zero).
+__device__ __forceinline__ float4 chan_mask4(int c, int Hr) {
+  return make_float4(c < Hr ? 1.f : 0.f, c + 1 < Hr ? 1.f : 0.f, c + 2 < Hr ? 1.f : 0.f, c + 3 < Hr ? 1.f : 0.f);
+}
+
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ n,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
-                                                            int rows, int H, float eps) {
+                                                            int rows, int H, int Hr, float eps) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -234,19 +240,22 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   for (int k = 0; k < kLnMaxPerLane; ++k) {
     const int c = (k * 64 + lane) * 4;
     v[k] = c < H ? ld4(x + (size_t)r * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 m = chan_mask4(c, Hr);
+    v[k] = make_float4(v[k].x * m.x, v[k].y * m.y, v[k].z * m.z, v[k].w * m.w);
     s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
   }
-  const float mu = wave_sum(s) / (float)H;
+  const float mu = wave_sum(s) / (float)Hr;
   float q = 0.f;
 #pragma unroll
   for (int k = 0; k < kLnMaxPerLane; ++k) {
     const int c = (k * 64 + lane) * 4;
     if (c < H) {
-      v[k] = make_float4(v[k].x - mu, v[k].y - mu, v[k].z - mu, v[k].w - mu);
+      const float4 m = chan_mask4(c, Hr);
+      v[k] = make_float4((v[k].x - mu) * m.x, (v[k].y - mu) * m.y, (v[k].z - mu) * m.z, (v[k].w - mu) * m.w);
       q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
     }
   }
-  const float rs = rsqrtf(wave_sum(q) / (float)H + eps);
+  const float rs = rsqrtf(wave_sum(q) / (float)Hr + eps);
 #pragma unroll
   for (int k = 0; k < kLnMaxPerLane; ++k) {
     const int c = (k * 64 + lane) * 4;
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ add, float* __restrict__ gx,
-                                                            int rows, int H) {
+                                                            int rows, int H, int Hr) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -271,20 +280,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const int c = (k * 64 + lane) * 4;
     gv[k] = nh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < H) {
-      gv[k] = ld4(g + (size_t)r * H + c);
+      const float4 m = chan_mask4(c, Hr);
+      const float4 gg = ld4(g + (size_t)r * H + c);
+      gv[k] = make_float4(gg.x * m.x, gg.y * m.y, gg.z * m.z, gg.w * m.w);
       const float4 xv = ld4(x + (size_t)r * H + c);
-      nh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+      nh[k] = make_float4((xv.x - mu) * rs * m.x, (xv.y - mu) * rs * m.y, (xv.z - mu) * rs * m.z, (xv.w - mu) * rs * m.w);
     }
     s1 += (gv[k].x + gv[k].y) + (gv[k].z + gv[k].w);
     s2 += (gv[k].x * nh[k].x + gv[k].y * nh[k].y) + (gv[k].z * nh[k].z + gv[k].w * nh[k].w);
   }
-  const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+  const float m1 = wave_sum(s1) / (float)Hr, m2 = wave_sum(s2) / (float)Hr;
 #pragma unroll
   for (int k = 0; k < kLnMaxPerLane; ++k) {
     const int c = (k * 64 + lane) * 4;
     if (c < H) {
-      float4 o = make_float4(rs * (gv[k].x - m1 - nh[k].x * m2), rs * (gv[k].y - m1 - nh[k].y * m2),
-                             rs * (gv[k].z - m1 - nh[k].z * m2), rs * (gv[k].w - m1 - nh[k].w * m2));
+      const float4 m = chan_mask4(c, Hr);
+      float4 o = make_float4(rs * (gv[k].x - m1 - nh[k].x * m2) * m.x, rs * (gv[k].y - m1 - nh[k].y * m2) * m.y,
+                             rs * (gv[k].z - m1 - nh[k].z * m2) * m.z, rs * (gv[k].w - m1 - nh[k].w * m2) * m.w);
       if (add != nullptr) o = add4(o, ld4(add + (size_t)r * H + c));
       st4(gx + (size_t)r * H + c, o);
     }
@@ -453,22 +465,24 @@ extern "C" int hermnet_update_mid_bwd(const float* gvdot, const float* gxin, con
 }
 
 extern "C" int hermnet_layernorm_fwd(const float* x, float* n, float* mean, float* rstd, int rows, int hidden,
-                                     float eps, void* stream) {
-  if (rows < 0 || hidden <= 0 || (hidden & 3) || hidden > kLnMaxPerLane * 256) return HN_ERR_BAD_ARG;
+                                     int hidden_real, float eps, void* stream) {
+  if (hidden_real <= 0) hidden_real = hidden;
+  if (rows < 0 || hidden <= 0 || (hidden & 3) || hidden > kLnMaxPerLane * 256 || hidden_real > hidden) return HN_ERR_BAD_ARG;
   if (rows == 0) return HN_OK;
   if (!x || !n || !mean || !rstd) return HN_ERR_BAD_ARG;
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     x, n, mean, rstd, rows, hidden, eps);
+                     x, n, mean, rstd, rows, hidden, hidden_real, eps);
   HN_LAUNCH_END;
 }
 
 extern "C" int hermnet_layernorm_bwd(const float* g, const float* x, const float* mean, const float* rstd,
-                                     const float* add, float* gx, int rows, int hidden, void* stream) {
-  if (rows < 0 || hidden <= 0 || (hidden & 3) || hidden > kLnMaxPerLane * 256) return HN_ERR_BAD_ARG;
+                                     const float* add, float* gx, int rows, int hidden, int hidden_real, void* stream) {
+  if (hidden_real <= 0) hidden_real = hidden;
+  if (rows < 0 || hidden <= 0 || (hidden & 3) || hidden > kLnMaxPerLane * 256 || hidden_real > hidden) return HN_ERR_BAD_ARG;
   if (rows == 0) return HN_OK;
   if (!g || !x || !mean || !rstd || !gx) return HN_ERR_BAD_ARG;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     g, x, mean, rstd, add, gx, rows, hidden);
+                     g, x, mean, rstd, add, gx, rows, hidden, hidden_real);
   HN_LAUNCH_END;
 }
 

@@ -156,6 +156,11 @@ class HVNet(nn.Module):
         # hermnet.py:123, row order (pads: Z=0).  eval(): every parameter is a constant, the embedding included
         # (the fused layers produce no parameter gradients; a partial set would be worse than none)
         x = self.embed(graph.z_rows) if train else torch.nn.functional.embedding(graph.z_rows, self.embed.weight.detach())
+        H = self.hidden_channels
+        Hp = (H + 63) // 64 * 64 if (fused and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0") else H
+        if Hp != H:
+            # widths that are not a multiple of 64 run on the same kernels with zero-padded channels (layer.LayerWeights)
+            x = torch.nn.functional.pad(x, (0, Hp - H))
         vec = None                                                          # zeros, hermnet.py:124
         if not fused and not train:
             edge = TrueEdgeGradient.apply(edge)      # autograd's (rhat, d) gradients -> Cartesian for the kernel
@@ -167,9 +172,9 @@ class HVNet(nn.Module):
         data._hn_edge_embed = None if fused else self.radial_basis(edge[:, 3])
         data.x, data.vec = x, vec
         data._hn_edge_handles = data._hn_edge_sink = None
-        if fused and edge.requires_grad and self.hidden_channels % 64 == 0 and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0":
+        if fused and edge.requires_grad and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0":
             # one reduction of the edge gradients per step instead of one per layer (layer.EdgeFanout)
-            data._hn_edge_sink = EdgeGradSink(len(self.hermconvs), self.hidden_channels // 64, graph.E, pos.device)
+            data._hn_edge_sink = EdgeGradSink(len(self.hermconvs), Hp // 64, graph.E, pos.device)
             data._hn_edge_handles = EdgeFanout.apply(edge, data._hn_edge_sink)
         for li, conv in enumerate(self.hermconvs):
             data._hn_layer = li
@@ -178,6 +183,8 @@ class HVNet(nn.Module):
                 # one exchange per layer: (x | vec) rows of halo atoms, 4H floats each
                 data.x, data.vec = HaloExchangeFeatures.apply(data.x, data.vec, row_plan)
         x = data.x
+        if Hp != H:
+            x = x[:, :H]                                                    # the read-out sees the real channels
 
         head_params = (self.out_energy[0].weight, self.out_energy[0].bias, self.out_energy[2].weight,
                        self.out_energy[2].bias)
@@ -284,6 +291,6 @@ class HTNet(HVNet):
     def forward(self, data):
         if (self.training or self.eval_param_grads) and torch.is_grad_enabled():
             raise NotImplementedError("HTNet: energy / force evaluation (eval()) only")
-        if not self.radial_basis.fused or self.hidden_channels % 64 != 0:
-            raise NotImplementedError("HTNet runs on the fused kernels: Gaussian basis, hidden_channels % 64 == 0")
+        if not self.radial_basis.fused:
+            raise NotImplementedError("HTNet runs on the fused kernels: Gaussian radial basis")
         return super().forward(data)

@@ -44,32 +44,63 @@ class LayerWeights(object):
                 key.append((id(p), p._version, p.data_ptr()))
         return tuple(key)
 
+    @staticmethod
+    def _pad(w, dim, parts, H, Hp, scale=None):
+        """Zero-pad `parts` consecutive blocks of H entries along `dim` to Hp entries each; `scale[k]` multiplies
+        block k first."""
+        if scale is not None:
+            w = w.clone()
+            for k, f in enumerate(scale):
+                if f != 1.0:
+                    w.narrow(dim, k * H, H).mul_(f)
+        if Hp == H:
+            return w
+        shp = list(w.shape)
+        shp[dim] = parts * Hp
+        out = w.new_zeros(shp)
+        for k in range(parts):
+            out.narrow(dim, k * Hp, H).copy_(w.narrow(dim, k * H, H))
+        return out
+
     @torch.no_grad()
     def refresh(self):
+        """Widths that are not a multiple of 64 (the reference accepts any, hermnet.py:84-88): every channel axis is
+        zero-padded to Hp = next multiple of 64, the column-block width of the message kernels.  Padded channels are
+        exactly zero everywhere (zero weight rows/columns and biases; LayerNorm statistics over the real H,
+        `h_real`), and the kernels' 1/sqrt(Hp) factors are turned back into 1/sqrt(H) by scaling the weights that
+        feed them linearly by s = sqrt(Hp/H): the `a` and `b` thirds of x_proj[2] (message, rmnet.py:63-66) and the
+        middle third of xvec_proj[2] (the factor of `vdot`, rmnet.py:97,104)."""
         key = self._version_key()
         if key == self.key:
             return self
         ml = [m.message_layer for m in self.mods]
         ul = [m.update_layer for m in self.mods]
+        H = ml[0].x_proj[0].weight.size(0)
+        Hp = (H + 63) // 64 * 64
+        s = (Hp / H) ** 0.5
+        self.h_real = H if Hp != H else 0
+        pad = lambda w, dim, parts, scale=None: self._pad(w, dim, parts, H, Hp, scale)
         # LayerNorm affine folded into the first Linear: (n*g + b) W1^T + b1 = n (W1*g)^T + (W1 b + b1)
-        w1 = [m.x_proj[0].weight * m.x_layernorm.weight[None, :] for m in ml]
-        b1 = [m.x_proj[0].weight @ m.x_layernorm.bias + m.x_proj[0].bias for m in ml]
+        w1 = [pad(pad(m.x_proj[0].weight * m.x_layernorm.weight[None, :], 0, 1), 1, 1) for m in ml]
+        b1 = [pad(m.x_proj[0].weight @ m.x_layernorm.bias + m.x_proj[0].bias, 0, 1) for m in ml]
         self.w1cat = torch.cat(w1, 0).contiguous()                                  # [T*H, H]
         self.b1cat = torch.cat(b1, 0).contiguous()                                  # [T*H]
         self.w1cat_t = self.w1cat.t().contiguous()                                  # [H, T*H]
-        self.w2 = torch.stack([m.x_proj[2].weight for m in ml], 0).contiguous()     # [T, 3H, H]
+        sab = None if Hp == H else (1.0, s, s)
+        self.w2 = torch.stack([pad(pad(m.x_proj[2].weight, 0, 3, sab), 1, 1) for m in ml], 0).contiguous()   # [T, 3H, H]
         self.w2t = self.w2.transpose(1, 2).contiguous()                             # [T, H, 3H]
-        self.b2 = torch.stack([m.x_proj[2].bias for m in ml], 0)[:, None, :].contiguous()   # [T,1,3H]
-        self.wt = torch.stack([m.rbf_proj.weight.t() for m in ml], 0).contiguous()  # [T, R, 3H]
-        self.brbf = torch.stack([m.rbf_proj.bias for m in ml], 0).contiguous()      # [T, 3H]
-        self.wv = [u.vec_proj.weight.contiguous() for u in ul]                      # [2H, H]
+        self.b2 = torch.stack([pad(m.x_proj[2].bias, 0, 3, sab) for m in ml], 0)[:, None, :].contiguous()     # [T,1,3H]
+        self.wt = torch.stack([pad(m.rbf_proj.weight.t(), 1, 3) for m in ml], 0).contiguous()  # [T, R, 3H]
+        self.brbf = torch.stack([pad(m.rbf_proj.bias, 0, 3) for m in ml], 0).contiguous()      # [T, 3H]
+        self.wv = [pad(pad(u.vec_proj.weight, 0, 2), 1, 1).contiguous() for u in ul]           # [2H, H]
         self.wvt = [w.t().contiguous() for w in self.wv]                            # [H, 2H]
-        self.wx0 = [u.xvec_proj[0].weight.contiguous() for u in ul]                 # [H, 2H]
+        self.wx0 = [pad(pad(u.xvec_proj[0].weight, 0, 1), 1, 2).contiguous() for u in ul]      # [H, 2H]
         self.wx0t = [w.t().contiguous() for w in self.wx0]
-        self.bx0 = [u.xvec_proj[0].bias for u in ul]
-        self.wx2 = [u.xvec_proj[2].weight.contiguous() for u in ul]                 # [3H, H]
+        self.bx0 = [pad(u.xvec_proj[0].bias, 0, 1) for u in ul]
+        sq = None if Hp == H else (1.0, s, 1.0)
+        self.wx2 = [pad(pad(u.xvec_proj[2].weight, 0, 3, sq), 1, 1).contiguous() for u in ul]  # [3H, H]
         self.wx2t = [w.t().contiguous() for w in self.wx2]
-        self.bx2 = [u.xvec_proj[2].bias for u in ul]
+        self.bx2 = [pad(u.xvec_proj[2].bias, 0, 3, sq) for u in ul]
         # stacked copies for the uniform-block layout (one batched GEMM per stage)
         st = lambda lst: torch.stack(lst, 0).contiguous()
         self.wv_s, self.wvt_s = st(self.wv), st(self.wvt)
@@ -170,7 +201,7 @@ class FusedRelationalLayer(torch.autograd.Function):
         # --- node projection of every relation: xh[t] = x_proj_t(LayerNorm_t(x))  (rmnet.py:52)
         uni, B = graph.uniform and nk > 0, graph.block
         fused_gemm = _NODE_GEMM and uni and x.is_cuda
-        n, mean, rstd = nodeops.layernorm_fwd(x, 1e-5)
+        n, mean, rstd = nodeops.layernorm_fwd(x, 1e-5, h_real=w.h_real)
         if fused_gemm:
             h = torch.empty(Ns, T * H, dtype=x.dtype, device=x.device)
             nodeops.gemm(n, w.w1cat, h, Ns, T * H, H, bias=w.b1cat)                                           # [Ns, T*H]
@@ -308,7 +339,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                 ga = _launch("gemm", lambda: torch.bmm(gxh, w.w2))                                            # [T, Ns, H]
                 gh = nodeops.ssilu_bwd(ga, h, Ns, T, H, H, Ns * H)                   # [Ns, T*H]
                 gn = _launch("gemm", lambda: torch.mm(gh, w.w1cat))                                           # [N, H]
-            gx_total = nodeops.layernorm_bwd(gn, x, mean, rstd, add=gx_in)
+            gx_total = nodeops.layernorm_bwd(gn, x, mean, rstd, add=gx_in, h_real=w.h_real)
         ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
         return gx_total, gvec_in, ge, None, None, None, None, None
 

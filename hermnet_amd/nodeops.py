@@ -9,23 +9,24 @@ from .ops import _launch, _stream
 P = _lib.ptr
 
 
-def layernorm_fwd(x, eps=1e-5):
-    """LayerNorm without affine over the last axis -> (n, mean [rows], rstd [rows])."""
+def layernorm_fwd(x, eps=1e-5, h_real=0):
+    """LayerNorm without affine over the last axis -> (n, mean [rows], rstd [rows]).  `h_real` (0 = all): width of
+    the statistics when the rows are zero-padded (padded outputs are zero)."""
     rows, H = x.shape
     n = torch.empty_like(x)
     mean = torch.empty(rows, dtype=x.dtype, device=x.device)
     rstd = torch.empty(rows, dtype=x.dtype, device=x.device)
     _lib.check(_launch("layernorm_fwd", lambda: _lib.load().hermnet_layernorm_fwd(
-        P(x), P(n), P(mean), P(rstd), rows, H, eps, _stream())), "hermnet_layernorm_fwd")
+        P(x), P(n), P(mean), P(rstd), rows, H, h_real, eps, _stream())), "hermnet_layernorm_fwd")
     return n, mean, rstd
 
 
-def layernorm_bwd(g, x, mean, rstd, add=None):
+def layernorm_bwd(g, x, mean, rstd, add=None, h_real=0):
     """Gradient of layernorm_fwd w.r.t. x, plus `add`."""
     rows, H = x.shape
     gx = torch.empty_like(x)
     _lib.check(_launch("layernorm_bwd", lambda: _lib.load().hermnet_layernorm_bwd(
-        P(g), P(x), P(mean), P(rstd), P(add), P(gx), rows, H, _stream())), "hermnet_layernorm_bwd")
+        P(g), P(x), P(mean), P(rstd), P(add), P(gx), rows, H, h_real, _stream())), "hermnet_layernorm_bwd")
     return gx
 
 

@@ -219,12 +219,15 @@ int hermnet_ssilu_bwd(const float* g, const float* h, const float* bias, int row
                       int N, int T, int C, long g_stride_n, long g_stride_t, void* stream);
 /* LayerNorm without affine over the last axis (`x_layernorm`, rmnet.py:52; gamma/beta are folded into the
  * following Linear by the host): n = (x - mean) * rstd, rstd = 1/sqrt(var + eps) (biased variance).
- * x, n [rows, hidden]; mean, rstd [rows]; hidden % 4 == 0, hidden <= 1024. */
-int hermnet_layernorm_fwd(const float* x, float* n, float* mean, float* rstd, int rows, int hidden, float eps,
-                          void* stream);
+ * x, n [rows, hidden]; mean, rstd [rows]; hidden % 4 == 0, hidden <= 1024.  `hidden_real` (0 = hidden): the
+ * statistics run over the first hidden_real channels only and the remaining outputs are zero -- rows of a model
+ * whose hidden_channels is not a multiple of 64 are zero-padded to the next multiple for the message kernels' column
+ * blocks (the reference accepts any width, hermnet.py:84-88). */
+int hermnet_layernorm_fwd(const float* x, float* n, float* mean, float* rstd, int rows, int hidden, int hidden_real,
+                          float eps, void* stream);
 /* gx = d(n)/d(x)^T g + add  (add [rows, hidden] may be NULL; gx may alias add). */
 int hermnet_layernorm_bwd(const float* g, const float* x, const float* mean, const float* rstd, const float* add,
-                          float* gx, int rows, int hidden, void* stream);
+                          float* gx, int rows, int hidden, int hidden_real, void* stream);
 /* PaiNNUpdate middle (rmnet.py:95-100): vp [rows,3,2H] = vec_proj(vec1) ->
  * vdot [rows,H] = sum_d v1 v2 / sqrt(H);  xin [rows,2H] = [x1 | sqrt(sum_d v2^2 + 1e-8)]. */
 int hermnet_update_mid(const float* vp, const float* x1, float* vdot, float* xin, int rows, int hidden,

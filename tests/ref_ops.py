@@ -71,14 +71,20 @@ def message_scatter_ref(xh, vec, x, edge, wt, brbf, graph, rbf):
 # Plain-PyTorch versions of the node-level fused kernels (same contracts as hermnet_amd.nodeops)
 # and of the message kernels' forward/backward entry points used by hermnet_amd.layer.
 # ---------------------------------------------------------------------------------------------
-def layernorm_fwd(x, eps=1e-5):
-    n, mean, rstd = torch.native_layer_norm(x, [x.size(-1)], None, None, eps)
+def layernorm_fwd(x, eps=1e-5, h_real=0):
+    Hr = h_real or x.size(-1)
+    n, mean, rstd = torch.native_layer_norm(x[:, :Hr].contiguous(), [Hr], None, None, eps)
+    if Hr < x.size(-1):
+        n = torch.nn.functional.pad(n, (0, x.size(-1) - Hr))
     return n, mean.reshape(-1), rstd.reshape(-1)
 
 
-def layernorm_bwd(g, x, mean, rstd, add=None):
-    gx = torch.ops.aten.native_layer_norm_backward(g, x, [x.size(-1)], mean.reshape(-1, 1), rstd.reshape(-1, 1), None, None,
-                                                   [True, False, False])[0]
+def layernorm_bwd(g, x, mean, rstd, add=None, h_real=0):
+    Hr = h_real or x.size(-1)
+    gx = torch.ops.aten.native_layer_norm_backward(g[:, :Hr].contiguous(), x[:, :Hr].contiguous(), [Hr], mean.reshape(-1, 1),
+                                                   rstd.reshape(-1, 1), None, None, [True, False, False])[0]
+    if Hr < x.size(-1):
+        gx = torch.nn.functional.pad(gx, (0, x.size(-1) - Hr))
     return gx if add is None else gx + add
 
 

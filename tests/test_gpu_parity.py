@@ -691,19 +691,32 @@ def test_skewed_composition_uses_tight_layout_and_matches_oracle():
     _oracle_vs_hip(data, ["Al", "Ni", "Cu"], dict(rc=5.0, num_layers=3, hidden_channels=128, num_rbf=64), 77)
 
 
-@pytest.mark.parametrize("H,R,layers", [(512, 128, 2), (64, 20, 3), (192, 50, 2)])
+@pytest.mark.parametrize("H,R,layers", [(512, 128, 2), (64, 20, 3), (192, 50, 2), (96, 16, 2), (100, 32, 3), (50, 20, 2)])
 def test_other_widths_vs_oracle(H, R, layers):
-    """hidden_channels = 512 is the reference default (hermnet.py:86): 8 column blocks; odd num_rbf."""
+    """hidden_channels = 512 is the reference default (hermnet.py:86): 8 column blocks; odd num_rbf; and widths that
+    are NOT a multiple of 64 (the reference accepts any, hermnet.py:84-88): 96, 100 and 50 run on the same kernels with
+    zero-padded channels (layer.LayerWeights.refresh)."""
     data = synth.fcc_alloy(reps=(2, 2, 3))
     _oracle_vs_hip(data, ["Al", "Ni", "Cu"], dict(rc=5.0, num_layers=layers, hidden_channels=H, num_rbf=R), 40 + H)
 
 
-def test_unsupported_width_is_refused_loudly():
-    dev = _dev()
-    data = synth.fcc_alloy(reps=(2, 2, 2)).to(dev)
-    model = hn.HVNet(["Al", "Ni", "Cu"], num_layers=1, hidden_channels=96, num_rbf=16).to(dev).eval()
-    with pytest.raises(RuntimeError, match="HN_ERR_BAD_ARG"):
-        model(data)             # the fused kernels need H % 64 == 0 (train() mode has no such limit)
+def test_width_not_multiple_of_64_molecule_batch_and_htnet():
+    """any `hidden_channels` runs fused -- also for batches (intensive read-out) and HTNet."""
+    data = synth.molecule_batch(num_graphs=6, seed=2)
+    _oracle_vs_hip(data, ["H", "C", "O"], dict(rc=5.0, num_layers=2, hidden_channels=72, num_rbf=24, intensive=True), 5)
+    from oracle import hermnet_oracle as orc
+    kw = dict(rc=5.0, num_layers=2, hidden_channels=40, num_rbf=16)
+    m = hn.HTNet(["H", "C", "O"], **kw).eval()
+    sd = synth.synth_state_dict(m.state_dict(), 3)
+    m.load_state_dict(sd)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    e_ref, f_ref = orc.htnet_energy_and_forces(sd, ["H", "C", "O"], data, **kw)
+    d = hn.Data(**{k: v.clone() for k, v in data}).to(_dev())
+    d.pos.requires_grad_(True)
+    e = m.to(_dev())(d)
+    f = -torch.autograd.grad(e.sum(), d.pos)[0]
+    assert rel_err(e.detach().cpu(), e_ref) < TOL and rel_err(f.cpu(), f_ref) < TOL
 
 
 def test_double_or_half_model_is_refused_on_the_gpu():

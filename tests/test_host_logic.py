@@ -311,3 +311,35 @@ def test_eval_mode_parameters_are_constants_unless_asked(monkeypatch):
     assert rel_err(e2.detach(), g.energy) < 2e-6
     grads = torch.autograd.grad(e2.sum(), list(model.parameters()), allow_unused=True)
     assert sum(gr is not None for gr in grads) >= len(grads) - 4     # (unused: e.g. the last layer's update of vec)
+
+
+@pytest.mark.parametrize("H", [100, 50, 24])
+def test_width_not_multiple_of_64_runs_on_zero_padded_channels(H, monkeypatch):
+    """hidden_channels the reference accepts but the column-block kernels do not (H % 64 != 0): LayerWeights pads every
+    channel axis to the next multiple of 64 and rescales the weights that meet a 1/sqrt(H) factor; with the kernels
+    replaced by their PyTorch restatements (which, like the kernels, only see the padded width) the result must equal
+    the oracle at the real width."""
+    import hermnet_amd.hermnet as hmod
+    import hermnet_amd.layer as lmod
+    from hermnet_amd import synth
+    from oracle import hermnet_oracle as orc
+    monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
+    monkeypatch.setattr(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
+    for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid",
+               "update_out", "update_out_bwd", "update_mid_bwd"]:
+        monkeypatch.setattr(lmod.nodeops, fn, getattr(ref_ops, fn))
+    monkeypatch.setattr(lmod, "_msg_fwd", ref_ops.msg_fwd)
+    monkeypatch.setattr(lmod, "_msg_bwd", ref_ops.msg_bwd)
+    g = Golden("alloy108")
+    kw = dict(rc=5.0, num_layers=2, hidden_channels=H, num_rbf=16)
+    model = hn.HVNet(g.elems, **kw).eval()
+    sd = synth.synth_state_dict(model.state_dict(), 21)
+    model.load_state_dict(sd)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    e_ref, f_ref = orc.energy_and_forces(sd, g.elems, g.data(), **kw)
+    d = g.data()
+    d.pos.requires_grad_(True)
+    e = model(d)
+    f = -torch.autograd.grad(e.sum(), d.pos)[0]
+    assert rel_err(e.detach(), e_ref) < 5e-6 and rel_err(f, f_ref) < 1e-5
