@@ -34,7 +34,12 @@ typedef unsigned hn_u2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(4))) const float hn_cfloat;   // constant address space: uniform loads go scalar
 
 constexpr int kRec = HN_EDGE_TABLE_FLOATS;   // floats per edge record
-// record layout: [2m], [2m+1] = g_m, g_m (u - mu_m)  (m < 12) | 24 lo (int) | 25 env | 26 c0 | 27 c1 | 28..30 rhat | 31 1/d
+// record layout (m < 12, g_m = exp(coeff (u - mu_m)^2)):
+//   [2m]   = env(u) g_m                                   -> sum_m [2m]   W_m = rbfh - bias            (rmnet.py:55,168-172)
+//   [2m+1] = (env'(u) g_m + 2 coeff env(u) g_m (u - mu_m)) / rc  -> sum_m [2m+1] W_m = d rbfh / d d
+//   [24] padded tile row of tap 0 (int bits) | [25] env | [26] env'/rc | [27] 2 coeff env / rc | [28..30] rhat | [31] 1/d
+// The envelope factors are folded into the tap pairs, so the contraction yields rbfh and its distance derivative
+// directly (no per-channel envelope arithmetic in the message kernel).
 
 __global__ __launch_bounds__(256) void edge_table_kernel(const float4* __restrict__ edge, int E,
                                                          const float* __restrict__ offset, int R, float inv_rc,
@@ -47,19 +52,20 @@ __global__ __launch_bounds__(256) void edge_table_kernel(const float4* __restric
   const HnEnv env = hn_envelope(u, env_kind, env_p);
   const int lo = hn_window_lo(u, R);
   float rec[kRec];
+  const float c0 = inv_rc * env.der, c1 = inv_rc * env.val * 2.0f * coeff;    // d rbfh / d d = c0 S0 + c1 S1
 #pragma unroll
   for (int m = 0; m < HN_TAPS; ++m) {
     int k = lo + m;
     k = k < 0 ? 0 : (k >= R ? R - 1 : k);                 // (rows outside [0, R) hold zero weights)
     const float diff = u - offset[k];
     const float gm = __expf(coeff * (diff * diff));        // same fp32 operation order as rmnet.py:156-172
-    rec[2 * m] = gm;
-    rec[2 * m + 1] = gm * diff;
+    rec[2 * m] = env.val * gm;
+    rec[2 * m + 1] = c0 * gm + c1 * (gm * diff);
   }
   rec[24] = __int_as_float(lo + HN_PAD);                  // padded tile row of tap 0
   rec[25] = env.val;
-  rec[26] = inv_rc * env.der;                             // d rbfh / d d = c0 S0 + c1 S1
-  rec[27] = inv_rc * env.val * 2.0f * coeff;
+  rec[26] = c0;
+  rec[27] = c1;
   rec[28] = g.x; rec[29] = g.y; rec[30] = g.z;
   rec[31] = __builtin_amdgcn_rcpf(g.w);
   float4* out = reinterpret_cast<float4*>(table + (size_t)e * kRec);
@@ -229,21 +235,24 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
     const int e_end = rowptr_t[rb];                  // (scalar load, once)
     int row_end = rowptr_of(row + 1);
 
-    float xs, xa, xb, vj0 = 0.f, vj1 = 0.f, vj2 = 0.f;
+    // row values, pre-multiplied by the constant factors they always meet (rmnet.py:24,63-66): xs / sqrt2,
+    // xa / sqrt(3H) (and xa itself), xb / sqrt(H), vec_j / sqrt(3H); gs and gb are rescaled once per row
+    float xs, xa, xas, xb, vj0 = 0.f, vj1 = 0.f, vj2 = 0.f;
     float gs = 0.f, ga = 0.f, gb = 0.f, gv0 = 0.f, gv1 = 0.f, gv2 = 0.f;
     auto row_prologue = [&](int r) {
       // (wave-uniform base + this lane's channel: the base stays in SGPRs, one lane-offset register serves all arrays)
       const float* xr = xh_t + (size_t)r * 3 * H;
-      xs = xr[c] + xbs; xa = (xr + H)[c] + xba; xb = (xr + 2 * H)[c] + xbb;
+      xs = (xr[c] + xbs) * inv_sqrt2; xa = (xr + H)[c] + xba; xb = ((xr + 2 * H)[c] + xbb) * inv_sqrth;
+      xas = xa * inv_sqrt3h;
       if (HAS_VEC) {
         const float* vr = a.vec + (size_t)r * 3 * H;
-        vj0 = vr[c]; vj1 = (vr + H)[c]; vj2 = (vr + 2 * H)[c];
+        vj0 = vr[c] * inv_sqrt3h; vj1 = (vr + H)[c] * inv_sqrt3h; vj2 = (vr + 2 * H)[c] * inv_sqrt3h;
       }
       gs = 0.f; ga = 0.f; gb = 0.f; gv0 = 0.f; gv1 = 0.f; gv2 = 0.f;
     };
     auto row_epilogue = [&](int r) {                 // every lane owns its channel: plain coalesced stores
       float* go = gxh_t + (size_t)r * 3 * H;
-      go[c] = gs; (go + H)[c] = ga; (go + 2 * H)[c] = gb;
+      go[c] = gs * inv_sqrt2; (go + H)[c] = ga; (go + 2 * H)[c] = gb * inv_sqrth;
       if (HAS_VEC) {
         float* gvo = gvec_t + (size_t)r * 3 * H;
         gvo[c] = gv0; (gvo + H)[c] = gv1; (gvo + 2 * H)[c] = gv2;
@@ -323,36 +332,33 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
             taps4(4, wB);
             lds_wait<0>(wA);
             taps4(8, wA);
-            const float envv = rec[25], c0 = rec[26], c1 = rec[27], rx = rec[28], ry = rec[29], rz = rec[30];
+            const float rx = rec[28], ry = rec[29], rz = rec[30];
             // the taps are consumed: request the NEXT edge's record into the same scalar registers; its latency
             // hides behind the rest of this edge (the six scalars still needed were copied above)
             __builtin_amdgcn_sched_barrier(0);
             load_record(min(k + 1, cnt - 1), rec);
             __builtin_amdgcn_sched_barrier(0);
-            const float gdx = cur.gx1 * inv_sqrt2;
-            const float g0 = cur.g0, g1 = cur.g1, g2 = cur.g2;
+            const float gx1 = cur.gx1, g0 = cur.g0, g1 = cur.g1, g2 = cur.g2;
+            // (the .x sums are rbfh - bias, the .y sums d rbfh / d d: see the record layout)
             // ---- part s: dx = sum xs * rs
-            const float rs = fmaf(envv, Ss.x, bs);
-            const float drs = fmaf(c0, Ss.x, c1 * Ss.y);
-            gs = fmaf(gdx, rs, gs);
-            float pdv = gdx * xs * drs;
+            const float rs = Ss.x + bs;
+            gs = fmaf(gx1, rs, gs);
+            float pdv = gx1 * xs * Ss.y;
             // ---- part a: dvec += vec_j * (xa * ra) / sqrt(3H)
             if (HAS_VEC) {
-              const float ra_ = fmaf(envv, Sa.x, ba);
-              const float dra = fmaf(c0, Sa.x, c1 * Sa.y);
-              const float A = fmaf(g0, vj0, fmaf(g1, vj1, g2 * vj2)) * inv_sqrt3h;
+              const float ra_ = Sa.x + ba;
+              const float A = fmaf(g0, vj0, fmaf(g1, vj1, g2 * vj2));
               ga = fmaf(A, ra_, ga);
-              const float w = xa * ra_ * inv_sqrt3h;
+              const float w = xas * ra_;
               gv0 = fmaf(g0, w, gv0); gv1 = fmaf(g1, w, gv1); gv2 = fmaf(g2, w, gv2);
-              pdv = fmaf(A * xa, dra, pdv);
+              pdv = fmaf(A * xa, Sa.y, pdv);
             }
             // ---- part b: dvec += rhat * (xb * rb) / sqrt(H)
-            const float rb_ = fmaf(envv, Sb.x, bb);
-            const float drb = fmaf(c0, Sb.x, c1 * Sb.y);
-            const float B = fmaf(rx, g0, fmaf(ry, g1, rz * g2)) * inv_sqrth;
+            const float rb_ = Sb.x + bb;
+            const float B = fmaf(rx, g0, fmaf(ry, g1, rz * g2));
             gb = fmaf(B, rb_, gb);
-            pdv = fmaf(B * xb, drb, pdv);
-            const float q = xb * rb_ * inv_sqrth;
+            pdv = fmaf(B * xb, Sb.y, pdv);
+            const float q = xb * rb_;
             pd[j & 1] = pdv; px[j & 1] = g0 * q; py[j & 1] = g1 * q; pz[j & 1] = g2 * q;
             cur = nxt;
           }

@@ -194,7 +194,9 @@ int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc* rbf, int h
 
 /* Per-edge radial record, computed ONCE per step (geometry and radial basis are shared by every layer and by both
  * directions): table [E, 32] floats in CSR order =
- *   [2m], [2m+1]  g_m = exp(coeff (u - mu_{lo+m})^2), g_m (u - mu_{lo+m})   for the 12 taps m of the edge's window
+ *   [2m], [2m+1]  env(u) g_m  and  (env'(u) g_m + 2 coeff env(u) g_m (u - mu_{lo+m})) / rc   for the 12 taps m of the
+ *                 edge's window, g_m = exp(coeff (u - mu_{lo+m})^2): contracted with the rbf_proj rows they give
+ *                 rbfh - bias and d rbfh / d d
  *   [24] padded tile row of tap 0 (int bits) | [25] env(u) | [26] env'(u)/rc | [27] 2 coeff env(u)/rc | [28..30] rhat | [31] 1/d
  * (rmnet.py:156-193 evaluated exactly as the message kernels do in registers).  When `edge_table` is handed to
  * hermnet_message_scatter_bwd (NULL = not available) the backward runs in its channel-per-lane form, which reads
