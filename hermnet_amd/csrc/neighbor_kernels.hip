@@ -94,8 +94,11 @@ __global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restr
                                                           const long* __restrict__ offset, int* __restrict__ count,
                                                           unsigned long long* __restrict__ keys,
                                                           int* __restrict__ overflow) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // one WAVE per atom: the lanes share the candidates of a bin (one atom per thread left the chip at 40 workgroups
+  // for 10k atoms, each thread walking ~200 candidates serially: 0.2 ms per pass)
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= N) return;
+  const int lane = threadIdx.x & 63;
   const double fi[3] = {fw[3 * i], fw[3 * i + 1], fw[3 * i + 2]};
   double pi[3];
   if (g.periodic) cart_of(g, fi, pi); else { pi[0] = fi[0]; pi[1] = fi[1]; pi[2] = fi[2]; }
@@ -125,16 +128,22 @@ __global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restr
         }
         if (!ok) continue;
         const int b = (tb[0] * g.nbins[1] + tb[1]) * g.nbins[2] + tb[2];
-        for (int s = bin_start[b]; s < bin_start[b + 1]; ++s) {
-          const int j = sorted_ids[s];
-          double fj[3] = {fw[3 * j] + img[0], fw[3 * j + 1] + img[1], fw[3 * j + 2] + img[2]};
-          double pj[3];
-          if (g.periodic) cart_of(g, fj, pj); else { pj[0] = fj[0]; pj[1] = fj[1]; pj[2] = fj[2]; }
-          const double dx = pj[0] - pi[0], dy = pj[1] - pi[1], dz = pj[2] - pi[2];
-          const double d2 = dx * dx + dy * dy + dz * dz;
-          if (!(d2 < g.rc2)) continue;
-          if (j == i && img[0] == 0 && img[1] == 0 && img[2] == 0) continue;
-          if (FILL) {
+        const int s_end = bin_start[b + 1];
+        for (int s0 = bin_start[b]; s0 < s_end; s0 += 64) {      // (wave-uniform loop: ballots are well defined)
+          const int s = s0 + lane;
+          bool hit = false;
+          int j = 0;
+          if (s < s_end) {
+            j = sorted_ids[s];
+            double fj[3] = {fw[3 * j] + img[0], fw[3 * j + 1] + img[1], fw[3 * j + 2] + img[2]};
+            double pj[3];
+            if (g.periodic) cart_of(g, fj, pj); else { pj[0] = fj[0]; pj[1] = fj[1]; pj[2] = fj[2]; }
+            const double dx = pj[0] - pi[0], dy = pj[1] - pi[1], dz = pj[2] - pi[2];
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            hit = (d2 < g.rc2) && !(j == i && img[0] == 0 && img[1] == 0 && img[2] == 0);
+          }
+          const unsigned long long m = __ballot(hit);
+          if (FILL && hit) {
             const int S[3] = {img[0] - wrap[3 * j] + wrap[3 * i], img[1] - wrap[3 * j + 1] + wrap[3 * i + 1],
                               img[2] - wrap[3 * j + 2] + wrap[3 * i + 2]};
             if (S[0] < -kMaxImg || S[0] > kMaxImg || S[1] < -kMaxImg || S[1] > kMaxImg || S[2] < -kMaxImg ||
@@ -142,14 +151,18 @@ __global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restr
               atomicOr(overflow, 1);
             const unsigned long long code =
                 (unsigned long long)(((S[0] + kMaxImg) * kCode + (S[1] + kMaxImg)) * kCode + (S[2] + kMaxImg));
-            keys[out++] = ((unsigned long long)i * (unsigned long long)N + (unsigned long long)j) *
-                              (unsigned long long)(kCode * kCode * kCode) + code;
-          } else {
-            ++n;
+            // position inside the atom's key range: hits of earlier lanes first (the keys are sorted afterwards,
+            // so only "each slot written once" matters)
+            const int slot = __popcll(m & ((1ull << lane) - 1ull));
+            keys[out + slot] = ((unsigned long long)i * (unsigned long long)N + (unsigned long long)j) *
+                                   (unsigned long long)(kCode * kCode * kCode) + code;
           }
+          const int nh = __popcll(m);
+          out += nh;
+          n += nh;
         }
       }
-  if (!FILL) count[i] = n;
+  if (!FILL && lane == 0) count[i] = n;
 }
 
 // sorted keys -> edge_index [2,E] int64 ([i; j]) and shifts [E,3] float32 (sign * S)
@@ -309,7 +322,7 @@ extern "C" int hermnet_neighbor_count(const float* pos, int num_atoms, const dou
     return HN_ERR_LAUNCH;
   hipLaunchKernelGGL(nbr_binstart_kernel, grid_for(nbins + 1), dim3(kBlock), 0, s, w.bin_sorted, N, (int)nbins, w.bin_start);
   if (hipMemsetAsync(w.count + N, 0, sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
-  hipLaunchKernelGGL(nbr_pairs_kernel<false>, grid_for(N), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N,
+  hipLaunchKernelGGL(nbr_pairs_kernel<false>, grid_for((long)N * 64), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N,
                      g, (const long*)nullptr, w.count, (unsigned long long*)nullptr, w.overflow);
   tb = w.temp_bytes;
   if (hipcub::DeviceScan::ExclusiveSum(w.temp, tb, w.count, w.offset, N + 1, s) != hipSuccess) return HN_ERR_LAUNCH;
@@ -347,7 +360,7 @@ extern "C" int hermnet_neighbor_fill(const float* pos, int num_atoms, const doub
   NbrWork w;
   carve(workspace, N, 8l * N + 64, w);
   w.temp_bytes = workspace_bytes - (size_t)((char*)w.temp - (char*)workspace);
-  hipLaunchKernelGGL(nbr_pairs_kernel<true>, grid_for(N), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N, g,
+  hipLaunchKernelGGL(nbr_pairs_kernel<true>, grid_for((long)N * 64), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N, g,
                      w.offset, (int*)nullptr, keys_a, overflow_device);
   size_t tb = sort_workspace_bytes;
   if (hipcub::DeviceRadixSort::SortKeys(sort_workspace, tb, keys_a, keys_b, (int)num_edges, 0, key_bits(N), s) != hipSuccess)
