@@ -21,7 +21,19 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.load()
     d = synth.fcc_alloy().to(dev)
+    # KBENCH_ORDER=x|y|z: renumber the atoms along one axis first (row order = locality of the gathers)
+    axis = os.environ.get("KBENCH_ORDER", "")
+    if axis:
+        perm = torch.argsort(d.pos[:, "xyz".index(axis)], stable=True)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel(), device=dev)
+        d.pos, d.atomic_number, d.edge_index = d.pos[perm].contiguous(), d.atomic_number[perm].contiguous(), inv[d.edge_index]
     g = RelationalGraph.build(d.atomic_number, d.edge_index, [13, 28, 29], d.edge_shift, d.batch)
+    # KBENCH_LOCAL=K: fold every gather index into K rows (WRONG results; the run time with every gather an L2 hit)
+    fold = int(os.environ.get("KBENCH_LOCAL", "0"))
+    if fold:
+        g.csc_tgt.remainder_(fold)
+        g.csr_src.remainder_(fold)
     model = hn.HVNet(["Al", "Ni", "Cu"], rc=5.0, num_layers=1, hidden_channels=128, num_rbf=128).to(dev)
     rbf = model.radial_basis.descriptor()
     N, E, T, H, R = g.N, g.E, g.T, 128, 128
