@@ -34,6 +34,11 @@ def main():
     if fold:
         g.csc_tgt.remainder_(fold)
         g.csr_src.remainder_(fold)
+    # KBENCH_LOCAL_REC=K: every backward edge reads one of K radial records (WRONG results; the run time with the
+    # scalar-path record loads served by the scalar cache)
+    fold_rec = int(os.environ.get("KBENCH_LOCAL_REC", "0"))
+    if fold_rec:
+        g.csc_pos.remainder_(fold_rec)
     model = hn.HVNet(["Al", "Ni", "Cu"], rc=5.0, num_layers=1, hidden_channels=128, num_rbf=128).to(dev)
     rbf = model.radial_basis.descriptor()
     N, E, T, H, R = g.N, g.E, g.T, 128, 128
