@@ -15,7 +15,7 @@ _ERR = {1: "HN_ERR_BAD_ARG (unsupported shape or null pointer)",
         3: "HN_ERR_LAUNCH (kernel launch failed)"}
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers
-ABI_VERSION = 3          # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
+ABI_VERSION = 4          # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
 
 
 class RbfDesc(ctypes.Structure):
@@ -48,7 +48,7 @@ SIGNATURES = {
     "hermnet_message_scatter_bwd": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), ctypes.c_int,
                                                    c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                                    c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),
-    "hermnet_edge_radial_table": (ctypes.c_int, [ctypes.POINTER(RbfDesc), c_fp, ctypes.c_int, c_fp, c_fp]),
+    "hermnet_edge_radial_table": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), c_fp, c_fp, c_fp]),
     "hermnet_neighbor_workspace": (ctypes.c_size_t, [ctypes.c_int]),
     "hermnet_neighbor_sort_workspace": (ctypes.c_size_t, [ctypes.c_long]),
     "hermnet_neighbor_count": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_double, c_fp,

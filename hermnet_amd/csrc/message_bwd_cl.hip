@@ -11,14 +11,16 @@
 //   * the banded contraction packs {value, derivative}:  (S0, S1) += (g_m, gd_m) * W[lo+m][part][c]  is one
 //     v_pk_fma_f32 with an SGPR pair and a broadcast weight; the LDS tile is laid out [tap row][channel][s,a,b,0],
 //     one conflict-free ds_read_b128 per tap;
-//   * per lane there is one channel of state, ~100 VGPRs in all, so a 1024-thread workgroup puts 4 waves on every
+//   * per lane there is one channel of state, ~107 VGPRs in all, so a 1024-thread workgroup puts 4 waves on every
 //     SIMD (the VW = 4 form: 245 VGPRs, 2 waves per SIMD, each wave parked ~50 % of its life -- rocprofv3
 //     SQ_WAIT_ANY / SQ_WAVE_CYCLES, profiles/r02_v1_counters.json -- and a lone wave issues fp32 VALU at only
 //     ~40 % of the SIMD's rate);
-//   * segment sums (gxh, gvec) need no cross-lane step at all; the per-edge dE/dD (a sum over channels) is reduced
-//     for 4 edges at once with v_permlane32/16 swaps + 4 DPP steps;
-//   * source rows are handed to waves dynamically (LDS counter), so a workgroup's 16 waves stay balanced although
-//     segments are short (~14 edges) and uneven.
+//   * segment sums (gxh, gvec) need no cross-lane step at all; the per-edge dE/dD (a sum over channels) is converted
+//     to Cartesian per channel (rhat, 1/d are scalars of the edge) and reduced for 4 edges at once with
+//     v_permlane32/16 swaps + 4 DPP steps;
+//   * a wave walks its share of the chunk's CSC edges as ONE software-pipelined stream: the next edge's record
+//     (sequential: the table is in CSC order), its twelve weight rows and its target rows are requested while the
+//     current edge is in its channel algebra; row switches cost scalar loads and buffer operations only.
 //
 // No atomics on HBM, fixed summation order: bit-reproducible.
 #include <hip/hip_runtime.h>
@@ -32,22 +34,26 @@ namespace {
 typedef float hn_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned hn_u2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(4))) const float hn_cfloat;   // constant address space: uniform loads go scalar
+typedef __attribute__((address_space(4))) const int hn_cint;
 
 constexpr int kRec = HN_EDGE_TABLE_FLOATS;   // floats per edge record
-// record layout (m < 12, g_m = exp(coeff (u - mu_m)^2)):
+// The table is in CSC order (the order the backward walks): record q belongs to CSC edge q = CSR edge csc_pos[q], so a
+// wave's records are one sequential stream.  Layout (m < 12, g_m = exp(coeff (u - mu_m)^2)):
 //   [2m]   = env(u) g_m                                   -> sum_m [2m]   W_m = rbfh - bias            (rmnet.py:55,168-172)
 //   [2m+1] = (env'(u) g_m + 2 coeff env(u) g_m (u - mu_m)) / rc  -> sum_m [2m+1] W_m = d rbfh / d d
-//   [24] padded tile row of tap 0 (int bits) | [25] env | [26] env'/rc | [27] 2 coeff env / rc | [28..30] rhat | [31] 1/d
+//   [24] padded tile row of tap 0 (int bits) | [25] the same of CSC edge q+1 (the kernel requests that edge's weight
+//   rows while it still works on edge q) | [26,27] 0 | [28..30] rhat | [31] 1/d
 // The envelope factors are folded into the tap pairs, so the contraction yields rbfh and its distance derivative
 // directly (no per-channel envelope arithmetic in the message kernel).
 
-__global__ __launch_bounds__(256) void edge_table_kernel(const float4* __restrict__ edge, int E,
-                                                         const float* __restrict__ offset, int R, float inv_rc,
+__global__ __launch_bounds__(256) void edge_table_kernel(const float4* __restrict__ edge, const int* __restrict__ csc_pos,
+                                                         int E, const float* __restrict__ offset, int R, float inv_rc,
                                                          float coeff, int env_kind, int env_p,
                                                          float* __restrict__ table) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  const float4 g = edge[e];
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= E) return;
+  const float4 g = edge[csc_pos[q]];
+  const float d_next = edge[csc_pos[min(q + 1, E - 1)]].w;
   const float u = g.w * inv_rc;
   const HnEnv env = hn_envelope(u, env_kind, env_p);
   const int lo = hn_window_lo(u, R);
@@ -63,14 +69,14 @@ __global__ __launch_bounds__(256) void edge_table_kernel(const float4* __restric
     rec[2 * m + 1] = c0 * gm + c1 * (gm * diff);
   }
   rec[24] = __int_as_float(lo + HN_PAD);                  // padded tile row of tap 0
-  rec[25] = env.val;
-  rec[26] = c0;
-  rec[27] = c1;
+  rec[25] = __int_as_float(hn_window_lo(d_next * inv_rc, R) + HN_PAD);
+  rec[26] = 0.f;
+  rec[27] = 0.f;
   rec[28] = g.x; rec[29] = g.y; rec[30] = g.z;
   rec[31] = __builtin_amdgcn_rcpf(g.w);
-  float4* out = reinterpret_cast<float4*>(table + (size_t)e * kRec);
+  float4* out = reinterpret_cast<float4*>(table + (size_t)q * kRec);
 #pragma unroll
-  for (int q = 0; q < kRec / 4; ++q) out[q] = make_float4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
+  for (int w = 0; w < kRec / 4; ++w) out[w] = make_float4(rec[4 * w], rec[4 * w + 1], rec[4 * w + 2], rec[4 * w + 3]);
 }
 
 template <int CTRL>
@@ -95,13 +101,11 @@ __device__ __forceinline__ float quad_total(float u, float w) {
   return v;
 }
 
-// The 12 tap rows of this lane's weight record are fetched in three groups of four, each row ONE ds_read_b128
-// (4 LDS cycles, conflict-free), two groups in flight: group g+1 is requested before group g is waited for, so only
-// the first group's LDS latency is exposed.  Written as asm because (i) hipcc narrows a float4 LDS load whose .w is
-// unused to ds_read_b96 (8 LDS cycles; the LDS port is the second-busiest unit of this kernel) and (ii) the counted
-// waits must sit exactly between the groups.  No scalar-memory load is in flight while these run (the next edge's
-// record is requested after the contraction), so lgkmcnt counts LDS reads only and they return in order.
-// Every wait statement takes the registers it releases as "+v" operands: no use can be scheduled in front of it.
+// The 12 tap rows of this lane's weight record are fetched as twelve ds_read_b128 (4 LDS cycles each, conflict-free) in
+// three groups of four registers, all requested one edge AHEAD (see the kernel).  Written as asm because hipcc narrows a
+// float4 LDS load whose .w is unused to ds_read_b96 (8 LDS cycles), and because the data must stay untouched in its
+// registers until the one wait at the top of the next edge: that wait names all twelve registers as "+v" operands, so no
+// use can be scheduled in front of it (and the generated code is checked for copies of registers in flight).
 typedef float hn_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lds_issue4(unsigned addr, hn_f4 (&w)[4]) {
   asm volatile(
@@ -113,18 +117,37 @@ __device__ __forceinline__ void lds_issue4(unsigned addr, hn_f4 (&w)[4]) {
       : "v"(addr)
       : "memory");
 }
-template <int PENDING>   // wait until at most PENDING newer LDS reads are outstanding; releases w
-__device__ __forceinline__ void lds_wait(hn_f4 (&w)[4]) {
-  if (PENDING == 4)
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) :: "memory");
-  else
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) :: "memory");
+// everything this wave has in flight on the LDS / scalar-memory counter has landed (the edge's record and its first two
+// tap groups, requested during the previous edge); releases both groups
+__device__ __forceinline__ void lds_wait_all(hn_f4 (&wa)[4], hn_f4 (&wb)[4], hn_f4 (&wc)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(wa[0]), "+v"(wa[1]), "+v"(wa[2]), "+v"(wa[3]), "+v"(wb[0]), "+v"(wb[1]), "+v"(wb[2]), "+v"(wb[3]),
+                 "+v"(wc[0]), "+v"(wc[1]), "+v"(wc[2]), "+v"(wc[3])
+               :: "memory");
 }
 static_assert(HN_CB * 16 == 1024 && HN_TAPS == 12, "the tap reader hard-codes the 1 KiB row pitch and 3 x 4 taps");
 
 typedef __amdgpu_buffer_rsrc_t hn_rsrc;
 __device__ __forceinline__ float buf_load(hn_rsrc r, unsigned voff, unsigned soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+__device__ __forceinline__ void buf_store(hn_rsrc r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+// descriptor of ONE row of a [rows, 3, H] array (wave-uniform base, 3H floats): the row's three parts are then
+// addressed by scalar offsets and this lane's channel offset -- no per-lane 64-bit address arithmetic
+__device__ __forceinline__ hn_rsrc row_rsrc(unsigned long long base, unsigned row_offset_elems, int H) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (unsigned long long)row_offset_elems * 4ull), 0, 3 * H * 4, 0x00020000);
+}
+// address of a wave-uniform pointer, pinned into scalar registers (hipcc does 64-bit multiplies of the relation / row
+// offsets on the vector ALU; everything derived from the product would then live in VGPRs and every descriptor built
+// from it would be wrapped in a waterfall loop)
+__device__ __forceinline__ unsigned long long uniform_addr(const void* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 struct EdgeIn {          // what one edge needs from memory (vector part)
@@ -158,9 +181,9 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
       bx = L % gridDim.x; by = (L / gridDim.x) % gridDim.y; bz = L / (gridDim.x * gridDim.y);
     }
   }
-  const int t = bz;
-  const int cb = by;
-  const int r0 = bx * a.rows_per_block;
+  const int t = __builtin_amdgcn_readfirstlane(bz);
+  const int cb = __builtin_amdgcn_readfirstlane(by);
+  const int r0 = __builtin_amdgcn_readfirstlane(bx) * a.rows_per_block;
   const int r1 = min(r0 + a.rows_per_block, a.Nsrc);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -192,9 +215,10 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
     tile[idx] = v;
   }
 
-  const float* xh_t = a.xh + (size_t)t * a.Nsrc * 3 * H;
-  float* gxh_t = a.gxh + (size_t)t * a.Nsrc * 3 * H;
-  float* gvec_t = HAS_VEC ? a.gvec + (size_t)t * a.Nsrc * 3 * H : nullptr;
+  const unsigned long long xh_t = uniform_addr(a.xh + (size_t)t * a.Nsrc * 3 * H);
+  const unsigned long long gxh_t = uniform_addr(a.gxh + (size_t)t * a.Nsrc * 3 * H);
+  const unsigned long long gvec_t = HAS_VEC ? uniform_addr(a.gvec + (size_t)t * a.Nsrc * 3 * H) : 0ull;
+  const unsigned long long vec_a = HAS_VEC ? uniform_addr(a.vec) : 0ull;
   const int* rowptr_t = a.csc_rowptr + (size_t)t * a.Nsrc;
   const float* brow = a.brbf + (size_t)t * 3 * H;
   const float bs = brow[c], ba = (brow + H)[c], bb = (brow + 2 * H)[c];
@@ -219,47 +243,72 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
   __syncthreads();                                   // the tile is staged
 
   if (ra < rb) {
-    // row pointers of up to 64 rows at a time live in one VGPR (lane q: rowptr[row_base + q]); v_readlane on demand
-    int row_base = ra;
-    int rp_vec = rowptr_t[min(row_base + lane, a.Nsrc)];
-    auto rowptr_of = [&](int r) {
-      if (r - row_base >= 64) {
-        row_base = r;
-        rp_vec = rowptr_t[min(row_base + lane, a.Nsrc)];
-      }
-      return __builtin_amdgcn_readlane(rp_vec, r - row_base);
-    };
-
+    // row pointers through the scalar path, requested one row ahead: a row switch then costs no vector-memory wait
+    // (a vector load + v_readlane made every switch drain the whole vector-memory queue, the gathers in flight included)
+    const hn_cint* rowptr_c = (const hn_cint*)uniform_addr(rowptr_t);
     int row = ra;
-    const int e_begin = rowptr_of(ra);
-    const int e_end = rowptr_t[rb];                  // (scalar load, once)
-    int row_end = rowptr_of(row + 1);
+    const int e_begin = rowptr_c[ra];
+    const int e_end = rowptr_c[rb];
+    int row_end = rowptr_c[row + 1];
+    int row_end2 = rowptr_c[min(row + 2, a.Nsrc)];
 
     // row values, pre-multiplied by the constant factors they always meet (rmnet.py:24,63-66): xs / sqrt2,
-    // xa / sqrt(3H) (and xa itself), xb / sqrt(H), vec_j / sqrt(3H); gs and gb are rescaled once per row
-    float xs, xa, xas, xb, vj0 = 0.f, vj1 = 0.f, vj2 = 0.f;
+    // xa / sqrt(3H) (and xa itself), xb / sqrt(H), vec_j / sqrt(3H); gs and gb are rescaled once per row.
+    // A new row's values are only REQUESTED at the switch (raw registers); they are scaled after the first edge's
+    // contraction, which needs none of them -- scaling at once would wait for the loads on the spot.
+    float xs = 0.f, xa = 0.f, xas = 0.f, xb = 0.f, vj0 = 0.f, vj1 = 0.f, vj2 = 0.f;
+    float raw_s = 0.f, raw_a = 0.f, raw_b = 0.f, raw_v0 = 0.f, raw_v1 = 0.f, raw_v2 = 0.f;
+    bool fresh = false;
     float gs = 0.f, ga = 0.f, gb = 0.f, gv0 = 0.f, gv1 = 0.f, gv2 = 0.f;
-    auto row_prologue = [&](int r) {
-      // (wave-uniform base + this lane's channel: the base stays in SGPRs, one lane-offset register serves all arrays)
-      const float* xr = xh_t + (size_t)r * 3 * H;
-      xs = (xr[c] + xbs) * inv_sqrt2; xa = (xr + H)[c] + xba; xb = ((xr + 2 * H)[c] + xbb) * inv_sqrth;
-      xas = xa * inv_sqrt3h;
+    const unsigned h4 = (unsigned)(H * 4);
+    auto row_request = [&](int r) {
+      // (row offsets in 32 bits: the host routes larger arrays to the other kernel form)
+      const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(r * (3 * H));
+      const hn_rsrc xr = row_rsrc(xh_t, ro, H);
+      raw_s = buf_load(xr, c4, 0); raw_a = buf_load(xr, c4, h4); raw_b = buf_load(xr, c4, 2 * h4);
       if (HAS_VEC) {
-        const float* vr = a.vec + (size_t)r * 3 * H;
-        vj0 = vr[c] * inv_sqrt3h; vj1 = (vr + H)[c] * inv_sqrt3h; vj2 = (vr + 2 * H)[c] * inv_sqrt3h;
+        const hn_rsrc vr = row_rsrc(vec_a, ro, H);
+        raw_v0 = buf_load(vr, c4, 0); raw_v1 = buf_load(vr, c4, h4); raw_v2 = buf_load(vr, c4, 2 * h4);
       }
       gs = 0.f; ga = 0.f; gb = 0.f; gv0 = 0.f; gv1 = 0.f; gv2 = 0.f;
+      fresh = true;
+    };
+    auto row_scale = [&]() {
+      xs = (raw_s + xbs) * inv_sqrt2; xa = raw_a + xba; xb = (raw_b + xbb) * inv_sqrth;
+      xas = xa * inv_sqrt3h;
+      if (HAS_VEC) { vj0 = raw_v0 * inv_sqrt3h; vj1 = raw_v1 * inv_sqrt3h; vj2 = raw_v2 * inv_sqrt3h; }
+      fresh = false;
     };
     auto row_epilogue = [&](int r) {                 // every lane owns its channel: plain coalesced stores
-      float* go = gxh_t + (size_t)r * 3 * H;
-      go[c] = gs * inv_sqrt2; (go + H)[c] = ga; (go + 2 * H)[c] = gb * inv_sqrth;
+      const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(r * (3 * H));
+      const hn_rsrc go = row_rsrc(gxh_t, ro, H);
+      buf_store(go, c4, 0, gs * inv_sqrt2); buf_store(go, c4, h4, ga); buf_store(go, c4, 2 * h4, gb * inv_sqrth);
       if (HAS_VEC) {
-        float* gvo = gvec_t + (size_t)r * 3 * H;
-        gvo[c] = gv0; (gvo + H)[c] = gv1; (gvo + 2 * H)[c] = gv2;
+        const hn_rsrc gvo = row_rsrc(gvec_t, ro, H);
+        buf_store(gvo, c4, 0, gv0); buf_store(gvo, c4, h4, gv1); buf_store(gvo, c4, 2 * h4, gv2);
       }
     };
-    row_prologue(row);
+    row_request(row);
 
+    // The record stream and the weight-row reads run CONTINUOUSLY over the wave's edges: while edge q is in its channel
+    // algebra, edge q+1's record (scalar loads; the table is in CSC order, so it is the next 128 bytes) and its twelve
+    // weight rows (ds_read_b128; the tile row comes from record q, slot 25) are already in flight.  A wave then meets ONE
+    // LDS / scalar-memory wait per edge, for data requested a whole algebra section earlier.
+    float rec[kRec];
+    hn_f4 wA[4], wB[4], wC[4];
+    auto load_record = [&](int q) {
+      // wave-uniform and read-only: through the constant address space these are scalar loads into SGPRs
+      const hn_cfloat* rp = (const hn_cfloat*)(a.table + (size_t)q * kRec);
+#pragma unroll
+      for (int w = 0; w < kRec; ++w) rec[w] = rp[w];
+    };
+    if (e_begin < e_end) {
+      load_record(e_begin);
+      const unsigned waddr = (unsigned)__float_as_int(rec[24]) * (HN_CB * 16) + tile_lane;
+      lds_issue4(waddr, wA);
+      lds_issue4(waddr + 4 * (HN_CB * 16), wB);
+      lds_issue4(waddr + 8 * (HN_CB * 16), wC);
+    }
     for (int base = e_begin; base < e_end; base += 64) {
       const int cnt = min(64, e_end - base);
       // one coalesced index load per 64 edges; an edge's indices are then wave-uniform (v_readlane)
@@ -277,42 +326,30 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
         in.g2 = buf_load(rs_gvec1, c4, 3u * so + (unsigned)(2 * H * 4));
         return in;
       };
-      // the record of an edge is wave-uniform and read-only here: through the constant address space its loads
-      // are scalar (s_load_dwordx8 into SGPRs), not 64 lanes fetching the same bytes
-      auto load_record = [&](int k, float (&rec)[kRec]) {
-        const int p = __builtin_amdgcn_readlane(my_pos, k);
-        const hn_cfloat* rp = (const hn_cfloat*)(a.table + (size_t)p * kRec);
-#pragma unroll
-        for (int q = 0; q < kRec; ++q) rec[q] = rp[q];
-      };
 
-      EdgeIn cur = load_edge(0);
-      float rec[kRec];
-      load_record(0, rec);
+      // two named buffers, alternating with the parity of the (unrolled) edge slot: no register moves to rotate them
+      EdgeIn in0 = load_edge(0), in1 = in0;
       for (int k4 = 0; k4 < cnt; k4 += 4) {
-        float pd[2], px[2], py[2], pz[2];                  // the current pair's per-channel dE/dd, dE/drhat
-        float ud[2], ux[2], uy[2], uz[2];                  // folded pairs (32-lane partial sums)
-        // geometry of the edge this DPP row will write (rows hold edges 0, 2, 1, 3 of the group): requested now,
-        // used after the group's arithmetic
-        const int je = (row16 == 0) ? 0 : (row16 == 1 ? 2 : (row16 == 2 ? 1 : 3));
-        const int pw = __shfl(my_pos, min(k4 + je, cnt - 1), 64);
-        const float4 gw = a.edge[pw];
+        // per-channel Cartesian dE/dD of the current pair of edges / folded pairs (32-lane partial sums)
+        float px[2], py[2], pz[2];
+        float ux[2], uy[2], uz[2];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          pd[j & 1] = 0.f; px[j & 1] = 0.f; py[j & 1] = 0.f; pz[j & 1] = 0.f;
+          px[j & 1] = 0.f; py[j & 1] = 0.f; pz[j & 1] = 0.f;
           const int k = k4 + j;
           if (k < cnt) {                                          // wave-uniform
             while (base + k >= row_end) {                         // (wave-uniform) the stream enters the next row
               row_epilogue(row);
               ++row;
-              row_end = rowptr_of(row + 1);
-              row_prologue(row);
+              row_end = row_end2;
+              row_end2 = rowptr_c[min(row + 2, a.Nsrc)];
+              row_request(row);
             }
-            const EdgeIn nxt = load_edge(min(k + 1, cnt - 1));    // the next edge's rows fly during this edge's math
-            // ---- (S0, S1) of the three parts: 12 taps, one LDS read each, in three pipelined groups
-            const unsigned waddr = (unsigned)__float_as_int(rec[24]) * (HN_CB * 16) + tile_lane;
+            // the next edge's rows fly during this edge's math
+            if (j & 1) in0 = load_edge(min(k + 1, cnt - 1)); else in1 = load_edge(min(k + 1, cnt - 1));
+            const EdgeIn& cur = (j & 1) ? in1 : in0;
+            // ---- (S0, S1) of the three parts: 12 taps, one LDS read each, requested during the previous edge
             hn_f2 Ss = {0.f, 0.f}, Sa = {0.f, 0.f}, Sb = {0.f, 0.f};
-            hn_f4 wA[4], wB[4];
             auto taps4 = [&](int m0, const hn_f4 (&w)[4]) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
@@ -322,22 +359,22 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
                 Sb = __builtin_elementwise_fma(g, hn_f2{w[q].z, w[q].z}, Sb);
               }
             };
-            lds_issue4(waddr, wA);
-            lds_issue4(waddr + 4 * (HN_CB * 16), wB);
-            lds_wait<4>(wA);
+            lds_wait_all(wA, wB, wC);
             taps4(0, wA);
-            asm volatile("" : "+v"(Ss), "+v"(Sb));                // taps 0-3 are consumed before wA is refilled
-            lds_issue4(waddr + 8 * (HN_CB * 16), wA);
-            lds_wait<4>(wB);
             taps4(4, wB);
-            lds_wait<0>(wA);
-            taps4(8, wA);
-            const float rx = rec[28], ry = rec[29], rz = rec[30];
-            // the taps are consumed: request the NEXT edge's record into the same scalar registers; its latency
-            // hides behind the rest of this edge (the six scalars still needed were copied above)
+            taps4(8, wC);
+            const float rx = rec[28], ry = rec[29], rz = rec[30], invd = rec[31];
+            const unsigned waddr_next = (unsigned)__float_as_int(rec[25]) * (HN_CB * 16) + tile_lane;
+            // the taps are consumed: request the NEXT edge's record into the same scalar registers and its weight rows
+            // into the same vector registers; their latency hides behind the rest of this edge
             __builtin_amdgcn_sched_barrier(0);
-            load_record(min(k + 1, cnt - 1), rec);
+            asm volatile("" : "+v"(Ss), "+v"(Sa), "+v"(Sb));      // (every tap of this edge has been issued)
+            load_record(min(base + k + 1, a.E - 1));
+            lds_issue4(waddr_next, wA);
+            lds_issue4(waddr_next + 4 * (HN_CB * 16), wB);
+            lds_issue4(waddr_next + 8 * (HN_CB * 16), wC);
             __builtin_amdgcn_sched_barrier(0);
+            if (fresh) row_scale();                               // (wave-uniform) first edge of a row
             const float gx1 = cur.gx1, g0 = cur.g0, g1 = cur.g1, g2 = cur.g2;
             // (the .x sums are rbfh - bias, the .y sums d rbfh / d d: see the record layout)
             // ---- part s: dx = sum xs * rs
@@ -358,32 +395,30 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
             const float B = fmaf(rx, g0, fmaf(ry, g1, rz * g2));
             gb = fmaf(B, rb_, gb);
             pdv = fmaf(B * xb, Sb.y, pdv);
-            const float q = xb * rb_;
-            pd[j & 1] = pdv; px[j & 1] = g0 * q; py[j & 1] = g1 * q; pz[j & 1] = g2 * q;
-            cur = nxt;
+            // ---- this channel's share of dE/dD, already Cartesian (rhat and 1/d are wave-uniform scalars here):
+            // d = |D|, rhat = D/d:  gD = pd rhat + (pr - (pr.rhat) rhat) / d  with  pr = q (g0,g1,g2), pr.rhat = q B
+            const float qi = xb * rb_ * invd;
+            const float tpar = fmaf(-B, qi, pdv);
+            px[j & 1] = fmaf(tpar, rx, g0 * qi); py[j & 1] = fmaf(tpar, ry, g1 * qi); pz[j & 1] = fmaf(tpar, rz, g2 * qi);
           }
           if (j & 1) {
-            ud[j >> 1] = pair_fold(pd[0], pd[1]); ux[j >> 1] = pair_fold(px[0], px[1]);
-            uy[j >> 1] = pair_fold(py[0], py[1]); uz[j >> 1] = pair_fold(pz[0], pz[1]);
+            ux[j >> 1] = pair_fold(px[0], px[1]); uy[j >> 1] = pair_fold(py[0], py[1]); uz[j >> 1] = pair_fold(pz[0], pz[1]);
           }
         }
-        // ---- dE/dD of these (up to) four edges: channel sums, then Cartesian form, one 16-byte store per edge
-        const float sd = quad_total(ud[0], ud[1]), sx = quad_total(ux[0], ux[1]);
-        const float sy = quad_total(uy[0], uy[1]), sz = quad_total(uz[0], uz[1]);
-        if ((lane & 15) == 0 && k4 + je < cnt) {
-          const float invd = __builtin_amdgcn_rcpf(gw.w);
-          const float dotp = sx * gw.x + sy * gw.y + sz * gw.z;
-          // d = |D|, rhat = D/d:  gD = pd rhat + (pr - (pr.rhat) rhat) / d
-          const float tpar = sd - dotp * invd;
-          gedge[pw] = make_float4(fmaf(tpar, gw.x, sx * invd), fmaf(tpar, gw.y, sy * invd), fmaf(tpar, gw.z, sz * invd), 0.f);
-        }
+        // ---- channel sums of these (up to) four edges, one 16-byte store per edge (DPP row k holds edge {0,2,1,3}[k])
+        const float sx = quad_total(ux[0], ux[1]), sy = quad_total(uy[0], uy[1]), sz = quad_total(uz[0], uz[1]);
+        const int je = (row16 == 0) ? 0 : (row16 == 1 ? 2 : (row16 == 2 ? 1 : 3));
+        const int p0 = __builtin_amdgcn_readlane(my_pos, k4), p1 = __builtin_amdgcn_readlane(my_pos, min(k4 + 1, cnt - 1));
+        const int p2 = __builtin_amdgcn_readlane(my_pos, min(k4 + 2, cnt - 1)), p3 = __builtin_amdgcn_readlane(my_pos, min(k4 + 3, cnt - 1));
+        const int pw = (row16 == 0) ? p0 : (row16 == 1 ? p2 : (row16 == 2 ? p1 : p3));
+        if ((lane & 15) == 0 && k4 + je < cnt) gedge[pw] = make_float4(sx, sy, sz, 0.f);
       }
     }
     // ---- the stream is exhausted: finish the current row and the rows without edges behind it
     for (;;) {
       row_epilogue(row);
       if (++row >= rb) break;
-      row_prologue(row);
+      gs = 0.f; ga = 0.f; gb = 0.f; gv0 = 0.f; gv1 = 0.f; gv2 = 0.f;
     }
   }
 }
@@ -477,14 +512,14 @@ int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, hipStream_t
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
 
-extern "C" int hermnet_edge_radial_table(const hn_rbf_desc* rbf, const float* edge, int num_edges, float* table,
+extern "C" int hermnet_edge_radial_table(const hn_graph* g, const hn_rbf_desc* rbf, const float* edge, float* table,
                                          void* stream) {
-  if (!rbf || rbf->num_rbf < 2 || num_edges < 0) return HN_ERR_BAD_ARG;
+  if (!g || !rbf || rbf->num_rbf < 2 || g->num_edges < 0) return HN_ERR_BAD_ARG;
+  const int num_edges = g->num_edges;
   if (num_edges == 0) return HN_OK;
-  if (!edge || !table || !rbf->offset) return HN_ERR_BAD_ARG;
+  if (!edge || !table || !rbf->offset || !g->csc_pos) return HN_ERR_BAD_ARG;
   hipLaunchKernelGGL(edge_table_kernel, dim3((num_edges + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const float4*>(edge), num_edges, rbf->offset, rbf->num_rbf, rbf->inv_rc, rbf->coeff,
-                     rbf->env_kind, rbf->env_p, table);
+                     reinterpret_cast<const float4*>(edge), g->csc_pos, num_edges, rbf->offset, rbf->num_rbf, rbf->inv_rc,
+                     rbf->coeff, rbf->env_kind, rbf->env_p, table);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
-

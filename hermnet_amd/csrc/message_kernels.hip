@@ -951,7 +951,9 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   static const int use_cl = env_int("HERMNET_BWD_CL", 1);
   const bool virtual_targets = g->num_src > 0 || g->res_row != nullptr;
   const size_t gather_bytes = (size_t)a.N * 3 * hidden * sizeof(float);      // the channel-per-lane form gathers through
+  const size_t src_rows = g->num_src > 0 ? (size_t)g->num_src : (size_t)a.N;
   const bool cl_ok = edge_table && !split_t && gather_bytes < 0xffffffffull &&  // 32-bit buffer offsets
+                     src_rows * 3 * hidden < 0x7fffffffull &&                   // 32-bit row offsets (elements)
                      (!vec || a.T == 1 || gvec_partials);
   if (virtual_targets && !cl_ok) return HN_ERR_BAD_ARG;
   if (cl_ok && (use_cl || virtual_targets)) {

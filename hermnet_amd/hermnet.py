@@ -167,7 +167,7 @@ class HVNet(nn.Module):
         data._hn_graph, data._hn_edge, data._hn_rbf = graph, edge, rbf
         if fused and edge.requires_grad and edge.is_cuda:
             # forces wanted: the backward message kernels read the radial quantities of an edge from this table
-            graph.edge_table = edge_radial_table(rbf, edge.detach())
+            graph.edge_table = edge_radial_table(graph, rbf, edge.detach())
         # rmnet.py:168-172 for the optional bases only: [E,R] basis from the kernel's distances
         data._hn_edge_embed = None if fused else self.radial_basis(edge[:, 3])
         data.x, data.vec = x, vec

@@ -216,13 +216,13 @@ class MessageScatter(torch.autograd.Function):
         return gxh, gvec, gx, gedge.sum(0), None, None, None, None
 
 
-def edge_radial_table(rbf, edge):
-    """[E,32] per-edge radial record (window start, 12 tap pairs, envelope factors, unit vector) for the
-    channel-per-lane backward kernel; ONE launch per step -- geometry and radial basis are the same for every layer
-    (`include/hermnet_hip.h`: hermnet_edge_radial_table)."""
+def edge_radial_table(graph, rbf, edge):
+    """[E,32] per-edge radial record (window start, 12 tap pairs, unit vector) in CSC order -- the order the
+    channel-per-lane backward kernel walks --; ONE launch per step: geometry and radial basis are the same for every
+    layer (`include/hermnet_hip.h`: hermnet_edge_radial_table)."""
     E = edge.size(0)
     table = torch.empty(E, 32, dtype=torch.float32, device=edge.device)
-    rs = rbf.struct()
+    gs, rs = graph.as_struct(), rbf.struct()
     _lib.check(_launch("edge_radial_table", lambda: _lib.load().hermnet_edge_radial_table(
-        ctypes.byref(rs), _lib.ptr(edge), E, _lib.ptr(table), _stream())), "hermnet_edge_radial_table")
+        ctypes.byref(gs), ctypes.byref(rs), _lib.ptr(edge), _lib.ptr(table), _stream())), "hermnet_edge_radial_table")
     return table

@@ -16,7 +16,8 @@
  *   - float = IEEE fp32 (the reference is fp32-only), indices = int32 (int64 where a parameter says so:
  *     the caller's edge_index / atomic_number / halo index lists arrive as torch LongTensors).
  *
- * ABI version 3 (`hermnet_abi_version`): v3 added the deterministic halo accumulate, separate source / target row
+ * ABI version 4 (`hermnet_abi_version`): v4 puts the radial table in CSC order (hermnet_edge_radial_table takes the
+ * graph); v3 added the deterministic halo accumulate, separate source / target row
  * spaces (HTNet) and the fused node-chain kernels; v2 added the bias-on-load arguments, LayerNorm, the energy head, the
  * CSC position gradient and the halo packing; the Python side refuses a library of another version.
  *
@@ -192,19 +193,20 @@ int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc* rbf, int h
                                 float* gxh, float* gvec, float* gx, float* gedge, int split_t,
                                 const float* edge_table, float* gvec_partials, void* stream);
 
-/* Per-edge radial record, computed ONCE per step (geometry and radial basis are shared by every layer and by both
- * directions): table [E, 32] floats in CSR order =
+/* Per-edge radial record, computed ONCE per step (geometry and radial basis are shared by every layer):
+ * table [E, 32] floats in CSC order -- record q belongs to CSC edge q, i.e. CSR edge csc_pos[q]; `edge` stays in CSR
+ * order --, so the backward, which walks the CSC segments, reads one sequential stream:
  *   [2m], [2m+1]  env(u) g_m  and  (env'(u) g_m + 2 coeff env(u) g_m (u - mu_{lo+m})) / rc   for the 12 taps m of the
  *                 edge's window, g_m = exp(coeff (u - mu_{lo+m})^2): contracted with the rbf_proj rows they give
  *                 rbfh - bias and d rbfh / d d
- *   [24] padded tile row of tap 0 (int bits) | [25] env(u) | [26] env'(u)/rc | [27] 2 coeff env(u)/rc | [28..30] rhat | [31] 1/d
+ *   [24] padded tile row of tap 0 (int bits) | [25] the same of CSC edge q+1 | [26,27] 0 | [28..30] rhat | [31] 1/d
  * (rmnet.py:156-193 evaluated exactly as the message kernels do in registers).  When `edge_table` is handed to
  * hermnet_message_scatter_bwd (NULL = not available) the backward runs in its channel-per-lane form, which reads
  * the record through the scalar path: a wave works on one edge, its taps sit in SGPRs (csrc/message_bwd_cl.hip).
  * That form runs one workgroup per (relation, column block, row chunk) and needs `gvec_partials`, a caller-owned
  * workspace [T, N, 3, H] (per-relation partial sums of gvec, added up in a fixed order by a second small launch;
  * not needed when T = 1 or vec is NULL); without it, or with split_t = 1, the 16-lanes-per-edge form runs. */
-int hermnet_edge_radial_table(const hn_rbf_desc* rbf, const float* edge, int num_edges, float* table, void* stream);
+int hermnet_edge_radial_table(const hn_graph* g, const hn_rbf_desc* rbf, const float* edge, float* table, void* stream);
 
 /* ---- node-level fused elementwise stages (A11/A12; the GEMMs between them are library calls) ----
  * Bias convention of these stages: the GEMM in front of a stage may run WITHOUT its bias (a GEMM with a

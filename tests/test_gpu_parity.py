@@ -77,7 +77,7 @@ def test_message_scatter_op(name, has_vec, bwd_form):
     wt = (rnd(T, R, 3 * H) / math.sqrt(R)).contiguous()
     brbf = (0.1 * rnd(T, 3 * H)).contiguous()
     edge = EdgeGeometry.apply(d.pos, d.get("cell"), graph)
-    graph.edge_table = edge_radial_table(rbf, edge) if bwd_form == "channel-per-lane" else None
+    graph.edge_table = edge_radial_table(graph, rbf, edge) if bwd_form == "channel-per-lane" else None
 
     xh.requires_grad_(True); x.requires_grad_(True)
     if has_vec:
@@ -385,7 +385,7 @@ def test_bias_on_load_equals_bias_in_operand():
     gs, rs = graph.as_struct(), rbf.struct()
 
     from hermnet_amd.ops import edge_radial_table
-    table = edge_radial_table(rbf, edge)
+    table = edge_radial_table(graph, rbf, edge)
     part = torch.empty(T, N, 3, H, device=dev)
 
     def run(xh_in, bias, v, tab=None):

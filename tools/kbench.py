@@ -63,7 +63,7 @@ def main():
 
     # KBENCH_TABLE=0: without the per-edge radial table the backward takes its 16-lanes-per-edge (VW) form
     from hermnet_amd.ops import edge_radial_table
-    table = edge_radial_table(rbf, edge) if os.environ.get("KBENCH_TABLE", "1") != "0" else None
+    table = edge_radial_table(g, rbf, edge) if os.environ.get("KBENCH_TABLE", "1") != "0" else None
 
     part = torch.empty(T, N, 3, H, device=dev) if table is not None else None
 
