@@ -385,6 +385,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
     return;
   }
   stage_weights<NW * 64>(a, t, cb, wl, mu);
+  // more than 8 waves per workgroup live on <= 168 VGPRs: with vec rows in flight the six bias vectors (24 registers
+  // at VW = 4) then stay in LDS and are re-read where they are used (layer 0, without vec rows, fits 16 waves as is)
+  constexpr bool LEAN = HAS_VEC && NW > 8 && VW == 4;
+  float* lbias = reinterpret_cast<float*>(tapbase + 16 * 4 * 16);
+  if (LEAN && threadIdx.x < HN_CB) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const size_t o = (size_t)t * 3 * a.H + p * a.H + cb * HN_CB + threadIdx.x;
+      lbias[p * HN_CB + threadIdx.x] = a.brbf[o];
+      lbias[(3 + p) * HN_CB + threadIdx.x] = a.xh_bias ? a.xh_bias[o] : 0.f;
+    }
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -398,12 +410,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
   const float inv_sqrth = rsqrtf((float)H);
   const float* xh_t = a.xh + (size_t)t * a.Nsrc * 3 * H;
 
-  Vec<VW> bias[3], xbias[3];
+  Vec<VW> bias_r[3], xbias_r[3];
+  if (!LEAN) {
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    bias[p] = Vec<VW>::load(a.brbf + (size_t)t * 3 * H + p * H + col);
-    xbias[p] = a.xh_bias ? Vec<VW>::load(a.xh_bias + (size_t)t * 3 * H + p * H + col) : Vec<VW>::zero();
+    for (int p = 0; p < 3; ++p) {
+      bias_r[p] = Vec<VW>::load(a.brbf + (size_t)t * 3 * H + p * H + col);
+      xbias_r[p] = a.xh_bias ? Vec<VW>::load(a.xh_bias + (size_t)t * 3 * H + p * H + col) : Vec<VW>::zero();
+    }
   }
+  auto bias_of = [&](int p) { return LEAN ? Vec<VW>::load(lbias + p * HN_CB + VW * gl) : bias_r[p]; };
+  auto xbias_of = [&](int p) { return LEAN ? Vec<VW>::load(lbias + (3 + p) * HN_CB + VW * gl) : xbias_r[p]; };
 
   for (int r = r0 + wave; r < r1; r += NW) {
     const int beg = a.csr_rowptr[r], end = a.csr_rowptr[r + 1];
@@ -472,17 +488,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
         Vec<VW> S0, S1;
         // message (rmnet.py:61-67), one part at a time to keep the register footprint small
         if (FUSED) S0 = S0p[0]; else rbf_part<false, VW>(wcol, g, gd, S0, S1);   // part s -> dx
-        ax = v_fma(v_add(cur.xs, xbias[0]), v_sfma(ev, S0, v_scale(bias[0], lv)), ax);
+        ax = v_fma(v_add(cur.xs, xbias_of(0)), v_sfma(ev, S0, v_scale(bias_of(0), lv)), ax);
         HN_SB;
         if (FUSED) S0 = S0p[2]; else rbf_part<false, VW>(wcol + 2 * HN_CB, g, gd, S0, S1);   // part b -> rhat term
-        const Vec<VW> mb = v_scale(v_mul(v_add(cur.xb, xbias[2]), v_sfma(ev, S0, v_scale(bias[2], lv))), inv_sqrth);
+        const Vec<VW> mb = v_scale(v_mul(v_add(cur.xb, xbias_of(2)), v_sfma(ev, S0, v_scale(bias_of(2), lv))), inv_sqrth);
         av[0] = v_sfma(cur.g.x, mb, av[0]);
         av[1] = v_sfma(cur.g.y, mb, av[1]);
         av[2] = v_sfma(cur.g.z, mb, av[2]);
         HN_SB;
         if (HAS_VEC) {
           if (FUSED) S0 = S0p[1]; else rbf_part<false, VW>(wcol + HN_CB, g, gd, S0, S1);   // part a -> vec_j term
-          const Vec<VW> ma = v_scale(v_mul(v_add(cur.xa, xbias[1]), v_sfma(ev, S0, v_scale(bias[1], lv))), inv_sqrt3h);
+          const Vec<VW> ma = v_scale(v_mul(v_add(cur.xa, xbias_of(1)), v_sfma(ev, S0, v_scale(bias_of(1), lv))), inv_sqrt3h);
 #pragma unroll
           for (int d = 0; d < 3; ++d) av[d] = v_fma(cur.vj[d], ma, av[d]);
         }
@@ -846,7 +862,8 @@ int pick_rows(int rows, int ncb, int slack, int override_rows) {
 // (float2 {g, g*diff} x 16 per lane group).
 size_t lds_bytes(int R) {
   const size_t rows = (size_t)(R + 2 * HN_PAD + 1);
-  return (rows * HN_LDS_ROW + ((rows + 3) & ~(size_t)3)) * sizeof(float) + 16 * 4 * 16 * sizeof(float2);
+  return (rows * HN_LDS_ROW + ((rows + 3) & ~(size_t)3)) * sizeof(float) + 16 * 4 * 16 * sizeof(float2) +
+         6 * HN_CB * sizeof(float);      // + the column block's rbf_proj / x_proj biases (register-lean variants)
 }
 
 typedef void (*kern_t)(MsgArgs);
@@ -878,6 +895,12 @@ kern_t pick_fwd(int variant, int& nw) {
     case 8210:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 2, 1, false>;
     case 8400:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, 0, false>;
     case 8420:  nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, 2, false>;
+    case 12420: nw = 12; return message_scatter_fwd_kernel<HAS_VEC, 12, 4, 2, false>;
+    case 12400: nw = 12; return message_scatter_fwd_kernel<HAS_VEC, 12, 4, 0, false>;
+    case 12421: nw = 12; return message_scatter_fwd_kernel<HAS_VEC, 12, 4, 2, true>;
+    case 12410: nw = 12; return message_scatter_fwd_kernel<HAS_VEC, 12, 4, 1, false>;
+    case 16420: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 4, 2, false>;
+    case 16400: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 4, 0, false>;
     case 16221: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, 2, true>;
     case 16220: nw = 16; return message_scatter_fwd_kernel<HAS_VEC, 16, 2, 2, false>;
     default:    nw = 8;  return message_scatter_fwd_kernel<HAS_VEC, 8, 4, 1, false>;    // 8410
@@ -918,7 +941,7 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   static const int rpb_fwd = env_int("HERMNET_FWD_ROWS", 0);
   // defaults from tools/kbench.py on MI355X (config 2): see DESIGN.md "Kernel variants"
   static const int variant_vec = env_int("HERMNET_FWD_VARIANT", 8420);
-  static const int variant_l0 = env_int("HERMNET_FWD_VARIANT_L0", 8400);
+  static const int variant_l0 = env_int("HERMNET_FWD_VARIANT_L0", 16420);
   const int variant = vec ? variant_vec : variant_l0;
   a.rows_per_block = pick_rows(a.N, hidden / HN_CB, a.T * (hidden / HN_CB), rpb_fwd);
   static const int xcd = env_int("HERMNET_XCD_REMAP", 1);
