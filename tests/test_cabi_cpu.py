@@ -104,3 +104,25 @@ def test_banded_rbf_derivative_vs_finite_difference():
         rm, _ = _dense(offset, 1 / rc, coeff, 0, 5, wt, b, d - h)
         _, dr = _dense(offset, 1 / rc, coeff, 0, 5, wt, b, d)
         assert np.allclose((rp - rm) / (2 * h), dr, rtol=1e-5, atol=1e-7)
+
+
+def test_default_message_kernels_fit_their_register_budget(tmp_path):
+    """The channel-per-lane backward must stay at 4 waves per SIMD (<= 128 VGPRs at 1024 threads) without scratch:
+    a spill or a fifth-wave-less build is a silent 2x.  Checked on the code hipcc generates for gfx950 (no GPU)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    src = os.path.join(ROOT, "hermnet_amd", "csrc", "message_bwd_cl.hip")
+    out = str(tmp_path / "cl.s")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-S", "--cuda-device-only",
+                    src, "-o", out], check=True, capture_output=True, timeout=600)
+    text = open(out).read()
+    kernels = re.findall(r"\.name:\s+(\S*message_scatter_bwd_cl_kernel\S*)(.*?)\.wavefront_size", text, flags=re.S)
+    assert len(kernels) == 2
+    for name, meta in kernels:
+        get = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, meta).group(1))
+        assert get("vgpr_count") <= 128, (name, get("vgpr_count"))
+        assert get("vgpr_spill_count") == 0 and get("sgpr_spill_count") == 0, name
+        assert get("private_segment_fixed_size") == 0, name
