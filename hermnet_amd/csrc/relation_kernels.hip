@@ -261,18 +261,12 @@ struct GroupWork {
 
 // rowptr [nkeys+1], out [n]
 int group_by_key(const int* key, int n, int nkeys, int* rowptr, int* out, const GroupWork& w, hipStream_t s) {
-  static const int probe = getenv("HERMNET_PROBE_GROUP") ? atoi(getenv("HERMNET_PROBE_GROUP")) : 99;
   hipLaunchKernelGGL(zero_i32_kernel, grid_for((long)nkeys + 1), dim3(kBlock), 0, s, w.cursor, (long)nkeys + 1);
-  if (probe <= 1) return HN_OK;
   if (n > 0) hipLaunchKernelGGL(hist_kernel, grid_for(n), dim3(kBlock), 0, s, key, n, w.cursor);
-  if (probe <= 2) return HN_OK;
   if (exclusive_scan_i32(w.cursor, rowptr, nkeys + 1, w.scan_temp, w.scan_bytes, s) != HN_OK) return HN_ERR_LAUNCH;
   if (n == 0) return HN_OK;
-  if (probe <= 3) return HN_OK;
   hipLaunchKernelGGL(copy_i32_kernel, grid_for(nkeys), dim3(kBlock), 0, s, rowptr, nkeys, w.cursor);
-  if (probe <= 4) return HN_OK;
   hipLaunchKernelGGL(scatter_kernel, grid_for(n), dim3(kBlock), 0, s, key, n, w.cursor, w.slots);
-  if (probe <= 5) return HN_OK;
   hipLaunchKernelGGL(group_rank_sort_kernel, dim3((unsigned)((nkeys + 3) / 4)), dim3(kBlock), 0, s, rowptr, nkeys, w.slots, out);
   return HN_OK;
 }
@@ -377,17 +371,13 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
   unsigned* rt_sorted = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
   size_t tbytes = tb;
 
-  static const int probe = getenv("HERMNET_PROBE_BUILD_PHASES") ? atoi(getenv("HERMNET_PROBE_BUILD_PHASES")) : 99;
   // ---- rows
   hipLaunchKernelGGL(zero_i32_kernel, grid_for(N), dim3(kBlock), 0, s, out->z_rows, (long)N);
   hipLaunchKernelGGL(zero_i32_kernel, grid_for(N), dim3(kBlock), 0, s, reinterpret_cast<int*>(out->row_real), (long)N);
-  if (probe <= 1) return HN_OK;
   if (NA > 0) {
     hipLaunchKernelGGL(atom_keys_kernel, grid_for(NA), dim3(kBlock), 0, s, atomic_number, NA, z_list, T, keyA, valA);
-    if (probe <= 2) return HN_OK;
     if (hipcub::DeviceRadixSort::SortPairs(temp, tbytes, keyA, keyB, valA, out->node_order, NA, 0, bits_for(T + 1), s)
         != hipSuccess) return HN_ERR_LAUNCH;
-    if (probe <= 3) return HN_OK;
     hipLaunchKernelGGL(assign_rows_kernel, grid_for(NA), dim3(kBlock), 0, s, keyB, out->node_order, NA, row_start,
                        T, atomic_number, out->row_of_node, out->z_rows, out->row_real);
   }
@@ -406,9 +396,7 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
   // CSR: edges grouped by row(target), ascending edge id
   if (E > 0)
     hipLaunchKernelGGL(edge_target_row_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, E, out->row_of_node, ikeyA);
-  if (probe <= 4) return HN_OK;
   if ((rcg = group_by_key(ikeyA, E, N, out->csr_rowptr, out->csr_perm, gw, s)) != HN_OK) return rcg;
-  if (probe <= 5) return HN_OK;
   if (E > 0)
     hipLaunchKernelGGL(csr_gather2_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, shift, E, N, T, out->row_of_node,
                        row_start, out->csr_perm, out->csr_src, out->src_id, out->tgt_id, out->shift_csr, rt_csr, ikey2,
