@@ -331,6 +331,63 @@ def test_halo_rows_kernels():
     assert torch.equal(x5[perm].cpu(), xs) and torch.equal(v5[perm].cpu(), vs)
 
 
+@pytest.mark.parametrize("seed,NA,T,H,R,hub", [(0, 300, 3, 128, 128, 700), (1, 257, 2, 64, 20, 130), (2, 64, 1, 128, 50, 63),
+                                                 (3, 500, 3, 64, 128, 1500)])
+@pytest.mark.parametrize("bwd_form", ["channel-per-lane", "vw"])
+def test_message_scatter_op_on_skewed_random_graphs(seed, NA, T, H, R, hub, bwd_form):
+    """The pipelined edge streams of the message kernels on graphs unlike a crystal: a few hub atoms with hundreds of
+    in- AND out-edges (segments far longer than the 64-edge index batches), most atoms with a handful, some with none,
+    atoms of an element the model does not know, repeated (source, target) pairs at different distances.  Forward and
+    backward vs the fp64 restatement."""
+    from hermnet_amd.ops import edge_radial_table
+    dev = _dev()
+    gen = torch.Generator(device="cpu").manual_seed(100 + seed)
+    elems = ["Al", "Ni", "Cu"][:T]
+    zl = [atomic_numbers[e] for e in elems]
+    z = torch.tensor(zl + [14])[torch.randint(0, T + 1, (NA,), generator=gen)]          # Si: not in `elems`
+    z[:T] = torch.tensor(zl)                                                              # every element present
+    hubs = torch.randint(0, NA, (3,), generator=gen)
+    src = [torch.randint(0, NA, (hub,), generator=gen), hubs[torch.randint(0, 3, (hub,), generator=gen)],
+           torch.randint(0, NA, (4 * NA,), generator=gen)]
+    tgt = [hubs[torch.randint(0, 3, (hub,), generator=gen)], torch.randint(0, NA, (hub,), generator=gen),
+           torch.randint(0, NA // 2, (4 * NA,), generator=gen)]                           # the upper half: few in-edges
+    ei = torch.stack([torch.cat(src), torch.cat(tgt)])
+    ei = ei[:, ei[0] != ei[1]]
+    E = ei.size(1)
+    graph = RelationalGraph.build(z.to(dev), ei.to(dev), zl, edge_shift=None, batch=torch.zeros(NA, dtype=torch.long, device=dev))
+    model = hn.HVNet(elems, rc=5.0, num_layers=1, hidden_channels=H, num_rbf=R).to(dev)
+    rbf = model.radial_basis.descriptor()
+    N = graph.N
+    rnd = lambda *s_: torch.randn(*s_, generator=gen).to(dev)
+    # geometry in CSR order: unit vectors and distances spread over (0, rc), a few beyond the cutoff
+    D = torch.randn(E, 3, generator=gen)
+    dist = (torch.rand(E, generator=gen) * 5.4 + 0.05)
+    edge = torch.cat([D / D.norm(dim=1, keepdim=True), dist[:, None]], 1).float().to(dev).contiguous()
+    xh, x, vec = rnd(T, N, 3 * H), rnd(N, H), rnd(N, 3, H)
+    wt = (rnd(T, R, 3 * H) / math.sqrt(R)).contiguous()
+    brbf = (0.1 * rnd(T, 3 * H)).contiguous()
+    graph.edge_table = edge_radial_table(graph, rbf, edge) if bwd_form == "channel-per-lane" else None
+    xh.requires_grad_(True); x.requires_grad_(True); vec.requires_grad_(True)
+    edge_in = edge.detach().clone().requires_grad_(True)
+    x1, vec1 = MessageScatter.apply(xh, vec, x, edge_in, wt, brbf, graph, rbf)
+
+    D64 = (edge[:, :3] * edge[:, 3:4]).double().detach().requires_grad_(True)
+    dn = D64.norm(dim=-1)
+    e64 = torch.cat([D64 / dn[:, None], dn[:, None]], 1)
+    xh64, x64, v64 = [t_.detach().double().requires_grad_(True) for t_ in (xh, x, vec)]
+
+    class R64:
+        inv_rc, env_kind, env_p, offset = rbf.inv_rc, rbf.env_kind, rbf.env_p, rbf.offset.double()
+    x1r, vec1r = ref_ops.message_scatter_ref(xh64, v64, x64, e64, wt.double(), brbf.double(), graph, R64)
+    assert rel_err(x1.double(), x1r) < TOL and rel_err(vec1.double(), vec1r) < TOL
+    gx1, gv1 = rnd(N, H), rnd(N, 3, H)
+    grads = torch.autograd.grad([x1, vec1], [xh, x, edge_in, vec], [gx1, gv1])
+    grads_r = torch.autograd.grad([x1r, vec1r], [xh64, x64, D64, v64], [gx1.double(), gv1.double()])
+    for nm, a, b in zip(["gxh", "gx", "gD", "gvec"], grads, grads_r):
+        a = a[:, :3] if nm == "gD" else a
+        assert rel_err(a.double(), b) < 2 * TOL, nm
+
+
 def test_bias_on_load_equals_bias_in_operand():
     """The stages that add a GEMM's bias on load (include/hermnet_hip.h "Bias convention"): kernel(h, bias)
     must equal kernel(h + expanded bias) for the node kernels and the message kernels (xh_bias)."""
