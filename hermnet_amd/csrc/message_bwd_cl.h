@@ -13,7 +13,7 @@ struct HnBwdClArgs {
   const int* csc_tgt;        // [E]
   const int* csc_pos;        // [E]
   int R, H;
-  const float* table;        // [E, 32] per-edge radial record, CSR order
+  const float* table;        // [E + 1, 32] per-edge radial record, CSC order (record E repeats E-1)
   const float4* edge;        // [E] (rhat, d), CSR order
   const float* xh;           // [T, Nsrc, 3H]
   const float* xh_bias;      // [T, 3H] or null

@@ -25,6 +25,7 @@
 // No atomics on HBM, fixed summation order: bit-reproducible.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/hermnet_hip.h"
 #include "hermnet_math.h"
 #include "message_bwd_cl.h"
@@ -77,6 +78,10 @@ __global__ __launch_bounds__(256) void edge_table_kernel(const float4* __restric
   float4* out = reinterpret_cast<float4*>(table + (size_t)q * kRec);
 #pragma unroll
   for (int w = 0; w < kRec / 4; ++w) out[w] = make_float4(rec[4 * w], rec[4 * w + 1], rec[4 * w + 2], rec[4 * w + 3]);
+  if (q == E - 1) {       // record E: a copy of the last one -- the kernel requests record q+1 without a bounds check
+#pragma unroll
+    for (int w = 0; w < kRec / 4; ++w) out[kRec / 4 + w] = make_float4(rec[4 * w], rec[4 * w + 1], rec[4 * w + 2], rec[4 * w + 3]);
+  }
 }
 
 template <int CTRL>
@@ -294,124 +299,150 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
     // algebra, edge q+1's record (scalar loads; the table is in CSC order, so it is the next 128 bytes) and its twelve
     // weight rows (ds_read_b128; the tile row comes from record q, slot 25) are already in flight.  A wave then meets ONE
     // LDS / scalar-memory wait per edge, for data requested a whole algebra section earlier.
-    float rec[kRec];
+    // Instruction diet (the kernel's time is ~ instructions per edge x 3.8 cycles per SIMD): the record pointer is a
+    // running scalar (the table has one spare record, so no clamp), the record's tail (next tile row, rhat, 1/d) lands
+    // in one of two scalar sets by edge parity so that the algebra still reads edge q's tail while q+1's arrives,
+    // gather offsets are pre-multiplied once per 64-edge batch, and whole groups of four edges run without
+    // per-edge bounds checks.
+    float rec[24];                                     // the 12 {value, derivative} tap pairs of the current edge
+    float tl0[5], tl1[5];                              // (next tile row, rhat x y z, 1/d) of even / odd edges
     hn_f4 wA[4], wB[4], wC[4];
-    auto load_record = [&](int q) {
+    const hn_cfloat* rp = (const hn_cfloat*)(a.table + (size_t)e_begin * kRec);
+    auto load_record = [&](float (&tl)[5]) {
       // wave-uniform and read-only: through the constant address space these are scalar loads into SGPRs
-      const hn_cfloat* rp = (const hn_cfloat*)(a.table + (size_t)q * kRec);
 #pragma unroll
-      for (int w = 0; w < kRec; ++w) rec[w] = rp[w];
+      for (int w = 0; w < 24; ++w) rec[w] = rp[w];
+      tl[0] = rp[25];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) tl[1 + w] = rp[28 + w];
     };
-    if (e_begin < e_end) {
-      load_record(e_begin);
-      const unsigned waddr = (unsigned)__float_as_int(rec[24]) * (HN_CB * 16) + tile_lane;
+    auto issue_weights = [&](unsigned waddr) {
       lds_issue4(waddr, wA);
       lds_issue4(waddr + 4 * (HN_CB * 16), wB);
       lds_issue4(waddr + 8 * (HN_CB * 16), wC);
+    };
+    if (e_begin < e_end) {
+      load_record(tl0);
+      issue_weights((unsigned)__float_as_int(rp[24]) * (HN_CB * 16) + tile_lane);
     }
     for (int base = e_begin; base < e_end; base += 64) {
       const int cnt = min(64, e_end - base);
       // one coalesced index load per 64 edges; an edge's indices are then wave-uniform (v_readlane)
-      const int my_tgt = lane < cnt ? a.csc_tgt[base + lane] : 0;
+      const unsigned my_off = lane < cnt ? (unsigned)a.csc_tgt[base + lane] * (unsigned)(H * 4) : 0u;   // byte offset in gx1
       const int my_pos = lane < cnt ? a.csc_pos[base + lane] : 0;
 
       auto load_edge = [&](int k) {
-        const int i = __builtin_amdgcn_readlane(my_tgt, k);
         EdgeIn in;
         // buffer loads: descriptor + scalar row offset + this lane's channel offset -- no per-lane 64-bit address math
-        const unsigned so = (unsigned)i * (unsigned)(H * 4);
+        const unsigned so = (unsigned)__builtin_amdgcn_readlane((int)my_off, k);
         in.gx1 = buf_load(rs_gx1, c4, so);
         in.g0 = buf_load(rs_gvec1, c4, 3u * so);
-        in.g1 = buf_load(rs_gvec1, c4, 3u * so + (unsigned)(H * 4));
-        in.g2 = buf_load(rs_gvec1, c4, 3u * so + (unsigned)(2 * H * 4));
+        in.g1 = buf_load(rs_gvec1, c4, 3u * so + h4);
+        in.g2 = buf_load(rs_gvec1, c4, 3u * so + 2 * h4);
         return in;
       };
 
       // two named buffers, alternating with the parity of the (unrolled) edge slot: no register moves to rotate them
       EdgeIn in0 = load_edge(0), in1 = in0;
-      for (int k4 = 0; k4 < cnt; k4 += 4) {
-        // per-channel Cartesian dE/dD of the current pair of edges / folded pairs (32-lane partial sums)
-        float px[2], py[2], pz[2];
-        float ux[2], uy[2], uz[2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          px[j & 1] = 0.f; py[j & 1] = 0.f; pz[j & 1] = 0.f;
-          const int k = k4 + j;
-          if (k < cnt) {                                          // wave-uniform
-            while (base + k >= row_end) {                         // (wave-uniform) the stream enters the next row
-              row_epilogue(row);
-              ++row;
-              row_end = row_end2;
-              row_end2 = rowptr_c[min(row + 2, a.Nsrc)];
-              row_request(row);
-            }
-            // the next edge's rows fly during this edge's math
-            if (j & 1) in0 = load_edge(min(k + 1, cnt - 1)); else in1 = load_edge(min(k + 1, cnt - 1));
-            const EdgeIn& cur = (j & 1) ? in1 : in0;
-            // ---- (S0, S1) of the three parts: 12 taps, one LDS read each, requested during the previous edge
-            hn_f2 Ss = {0.f, 0.f}, Sa = {0.f, 0.f}, Sb = {0.f, 0.f};
-            auto taps4 = [&](int m0, const hn_f4 (&w)[4]) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const hn_f2 g = {rec[2 * (m0 + q)], rec[2 * (m0 + q) + 1]};
-                Ss = __builtin_elementwise_fma(g, hn_f2{w[q].x, w[q].x}, Ss);
-                if (HAS_VEC) Sa = __builtin_elementwise_fma(g, hn_f2{w[q].y, w[q].y}, Sa);
-                Sb = __builtin_elementwise_fma(g, hn_f2{w[q].z, w[q].z}, Sb);
-              }
-            };
-            lds_wait_all(wA, wB, wC);
-            taps4(0, wA);
-            taps4(4, wB);
-            taps4(8, wC);
-            const float rx = rec[28], ry = rec[29], rz = rec[30], invd = rec[31];
-            const unsigned waddr_next = (unsigned)__float_as_int(rec[25]) * (HN_CB * 16) + tile_lane;
-            // the taps are consumed: request the NEXT edge's record into the same scalar registers and its weight rows
-            // into the same vector registers; their latency hides behind the rest of this edge
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" : "+v"(Ss), "+v"(Sa), "+v"(Sb));      // (every tap of this edge has been issued)
-            load_record(min(base + k + 1, a.E - 1));
-            lds_issue4(waddr_next, wA);
-            lds_issue4(waddr_next + 4 * (HN_CB * 16), wB);
-            lds_issue4(waddr_next + 8 * (HN_CB * 16), wC);
-            __builtin_amdgcn_sched_barrier(0);
-            if (fresh) row_scale();                               // (wave-uniform) first edge of a row
-            const float gx1 = cur.gx1, g0 = cur.g0, g1 = cur.g1, g2 = cur.g2;
-            // (the .x sums are rbfh - bias, the .y sums d rbfh / d d: see the record layout)
-            // ---- part s: dx = sum xs * rs
-            const float rs = Ss.x + bs;
-            gs = fmaf(gx1, rs, gs);
-            float pdv = gx1 * xs * Ss.y;
-            // ---- part a: dvec += vec_j * (xa * ra) / sqrt(3H)
-            if (HAS_VEC) {
-              const float ra_ = Sa.x + ba;
-              const float A = fmaf(g0, vj0, fmaf(g1, vj1, g2 * vj2));
-              ga = fmaf(A, ra_, ga);
-              const float w = xas * ra_;
-              gv0 = fmaf(g0, w, gv0); gv1 = fmaf(g1, w, gv1); gv2 = fmaf(g2, w, gv2);
-              pdv = fmaf(A * xa, Sa.y, pdv);
-            }
-            // ---- part b: dvec += rhat * (xb * rb) / sqrt(H)
-            const float rb_ = Sb.x + bb;
-            const float B = fmaf(rx, g0, fmaf(ry, g1, rz * g2));
-            gb = fmaf(B, rb_, gb);
-            pdv = fmaf(B * xb, Sb.y, pdv);
-            // ---- this channel's share of dE/dD, already Cartesian (rhat and 1/d are wave-uniform scalars here):
-            // d = |D|, rhat = D/d:  gD = pd rhat + (pr - (pr.rhat) rhat) / d  with  pr = q (g0,g1,g2), pr.rhat = q B
-            const float qi = xb * rb_ * invd;
-            const float tpar = fmaf(-B, qi, pdv);
-            px[j & 1] = fmaf(tpar, rx, g0 * qi); py[j & 1] = fmaf(tpar, ry, g1 * qi); pz[j & 1] = fmaf(tpar, rz, g2 * qi);
-          }
-          if (j & 1) {
-            ux[j >> 1] = pair_fold(px[0], px[1]); uy[j >> 1] = pair_fold(py[0], py[1]); uz[j >> 1] = pair_fold(pz[0], pz[1]);
-          }
+      // per-channel Cartesian dE/dD of the current pair of edges / folded pairs (32-lane partial sums)
+      float px[2], py[2], pz[2];
+      float ux[2], uy[2], uz[2];
+      auto edge_body = [&](auto J, int k) {
+        constexpr int j = decltype(J)::value;
+        while (base + k >= row_end) {                         // (wave-uniform) the stream enters the next row
+          row_epilogue(row);
+          ++row;
+          row_end = row_end2;
+          row_end2 = rowptr_c[min(row + 2, a.Nsrc)];
+          row_request(row);
         }
-        // ---- channel sums of these (up to) four edges, one 16-byte store per edge (DPP row k holds edge {0,2,1,3}[k])
+        // the next edge's rows fly during this edge's math
+        // (index lanes past the batch hold offset 0: a harmless extra read of row 0; only slot 3 can step past lane 63)
+        const int kn = j == 3 ? min(k + 1, 63) : k + 1;
+        if (j & 1) in0 = load_edge(kn); else in1 = load_edge(kn);
+        const EdgeIn& cur = (j & 1) ? in1 : in0;
+        float (&tl)[5] = (j & 1) ? tl1 : tl0;
+        // ---- (S0, S1) of the three parts: 12 taps, one LDS read each, requested during the previous edge
+        hn_f2 Ss = {0.f, 0.f}, Sa = {0.f, 0.f}, Sb = {0.f, 0.f};
+        auto taps4 = [&](int m0, const hn_f4 (&w)[4]) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const hn_f2 g = {rec[2 * (m0 + q)], rec[2 * (m0 + q) + 1]};
+            Ss = __builtin_elementwise_fma(g, hn_f2{w[q].x, w[q].x}, Ss);
+            if (HAS_VEC) Sa = __builtin_elementwise_fma(g, hn_f2{w[q].y, w[q].y}, Sa);
+            Sb = __builtin_elementwise_fma(g, hn_f2{w[q].z, w[q].z}, Sb);
+          }
+        };
+        lds_wait_all(wA, wB, wC);
+        taps4(0, wA);
+        taps4(4, wB);
+        taps4(8, wC);
+        const unsigned waddr_next = (unsigned)__float_as_int(tl[0]) * (HN_CB * 16) + tile_lane;
+        // the taps are consumed: request the NEXT edge's record (taps into the same scalar registers, tail into the other
+        // set) and its weight rows into the same vector registers; their latency hides behind the rest of this edge
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(Ss), "+v"(Sa), "+v"(Sb));      // (every tap of this edge has been issued)
+        rp += kRec;
+        if (j & 1) load_record(tl0); else load_record(tl1);
+        issue_weights(waddr_next);
+        __builtin_amdgcn_sched_barrier(0);
+        if (fresh) row_scale();                               // (wave-uniform) first edge of a row
+        const float rx = tl[1], ry = tl[2], rz = tl[3], invd = tl[4];
+        const float gx1 = cur.gx1, g0 = cur.g0, g1 = cur.g1, g2 = cur.g2;
+        // (the .x sums are rbfh - bias, the .y sums d rbfh / d d: see the record layout)
+        // ---- part s: dx = sum xs * rs
+        const float rs = Ss.x + bs;
+        gs = fmaf(gx1, rs, gs);
+        float pdv = gx1 * xs * Ss.y;
+        // ---- part a: dvec += vec_j * (xa * ra) / sqrt(3H)
+        if (HAS_VEC) {
+          const float ra_ = Sa.x + ba;
+          const float A = fmaf(g0, vj0, fmaf(g1, vj1, g2 * vj2));
+          ga = fmaf(A, ra_, ga);
+          const float w = xas * ra_;
+          gv0 = fmaf(g0, w, gv0); gv1 = fmaf(g1, w, gv1); gv2 = fmaf(g2, w, gv2);
+          pdv = fmaf(A * xa, Sa.y, pdv);
+        }
+        // ---- part b: dvec += rhat * (xb * rb) / sqrt(H)
+        const float rb_ = Sb.x + bb;
+        const float B = fmaf(rx, g0, fmaf(ry, g1, rz * g2));
+        gb = fmaf(B, rb_, gb);
+        pdv = fmaf(B * xb, Sb.y, pdv);
+        // ---- this channel's share of dE/dD, already Cartesian (rhat and 1/d are wave-uniform scalars here):
+        // d = |D|, rhat = D/d:  gD = pd rhat + (pr - (pr.rhat) rhat) / d  with  pr = q (g0,g1,g2), pr.rhat = q B
+        const float qi = xb * rb_ * invd;
+        const float tpar = fmaf(-B, qi, pdv);
+        px[j & 1] = fmaf(tpar, rx, g0 * qi); py[j & 1] = fmaf(tpar, ry, g1 * qi); pz[j & 1] = fmaf(tpar, rz, g2 * qi);
+      };
+      auto fold = [&](int h) {
+        ux[h] = pair_fold(px[0], px[1]); uy[h] = pair_fold(py[0], py[1]); uz[h] = pair_fold(pz[0], pz[1]);
+      };
+      // ---- channel sums of (up to) four edges, one 16-byte store per edge (DPP row k holds edge {0,2,1,3}[k])
+      auto group_store = [&](int k4) {
         const float sx = quad_total(ux[0], ux[1]), sy = quad_total(uy[0], uy[1]), sz = quad_total(uz[0], uz[1]);
         const int je = (row16 == 0) ? 0 : (row16 == 1 ? 2 : (row16 == 2 ? 1 : 3));
         const int p0 = __builtin_amdgcn_readlane(my_pos, k4), p1 = __builtin_amdgcn_readlane(my_pos, min(k4 + 1, cnt - 1));
         const int p2 = __builtin_amdgcn_readlane(my_pos, min(k4 + 2, cnt - 1)), p3 = __builtin_amdgcn_readlane(my_pos, min(k4 + 3, cnt - 1));
         const int pw = (row16 == 0) ? p0 : (row16 == 1 ? p2 : (row16 == 2 ? p1 : p3));
         if ((lane & 15) == 0 && k4 + je < cnt) gedge[pw] = make_float4(sx, sy, sz, 0.f);
+      };
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+      int k4 = 0;
+      for (; k4 + 4 <= cnt; k4 += 4) {                        // whole groups: no per-edge bounds checks
+        edge_body(I0{}, k4); edge_body(I1{}, k4 + 1); fold(0);
+        edge_body(I2{}, k4 + 2); edge_body(I3{}, k4 + 3); fold(1);
+        group_store(k4);
+      }
+      if (k4 < cnt) {                                         // the stream's last, partial group: absent edges add zeros
+        px[1] = 0.f; py[1] = 0.f; pz[1] = 0.f;
+        edge_body(I0{}, k4);
+        if (k4 + 1 < cnt) edge_body(I1{}, k4 + 1);
+        fold(0);
+        px[0] = 0.f; py[0] = 0.f; pz[0] = 0.f; px[1] = 0.f; py[1] = 0.f; pz[1] = 0.f;
+        if (k4 + 2 < cnt) edge_body(I2{}, k4 + 2);
+        fold(1);
+        group_store(k4);
       }
     }
     // ---- the stream is exhausted: finish the current row and the rows without edges behind it

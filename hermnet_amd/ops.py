@@ -217,11 +217,11 @@ class MessageScatter(torch.autograd.Function):
 
 
 def edge_radial_table(graph, rbf, edge):
-    """[E,32] per-edge radial record (window start, 12 tap pairs, unit vector) in CSC order -- the order the
+    """[E+1,32] per-edge radial record (window start, 12 tap pairs, unit vector) in CSC order -- the order the
     channel-per-lane backward kernel walks --; ONE launch per step: geometry and radial basis are the same for every
     layer (`include/hermnet_hip.h`: hermnet_edge_radial_table)."""
     E = edge.size(0)
-    table = torch.empty(E, 32, dtype=torch.float32, device=edge.device)
+    table = torch.empty(E + 1, 32, dtype=torch.float32, device=edge.device)      # (+1: the stream reads one record ahead)
     gs, rs = graph.as_struct(), rbf.struct()
     _lib.check(_launch("edge_radial_table", lambda: _lib.load().hermnet_edge_radial_table(
         ctypes.byref(gs), ctypes.byref(rs), _lib.ptr(edge), _lib.ptr(table), _stream())), "hermnet_edge_radial_table")

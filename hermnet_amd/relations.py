@@ -54,7 +54,7 @@ class RelationalGraph(object):
     def __init__(self):
         self._cstruct = None
         self._rel_bounds = None
-        self.edge_table = None     # [E,32] per-edge radial record of the current step (set by HVNet.forward)
+        self.edge_table = None     # [E+1,32] per-edge radial records of the current step, CSC order (set by HVNet.forward)
         self.num_src = 0           # separate source-row space (HTNet): rows of xh / vec; 0 = same rows as the targets
         self.res_row = None        # [N] int32 source row feeding the residual of each target row, or None
         self.triadic_pairs = 0     # HTNet: pair relations per centre element (target rows = T_elem * pairs * block)

@@ -194,8 +194,9 @@ int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc* rbf, int h
                                 const float* edge_table, float* gvec_partials, void* stream);
 
 /* Per-edge radial record, computed ONCE per step (geometry and radial basis are shared by every layer):
- * table [E, 32] floats in CSC order -- record q belongs to CSC edge q, i.e. CSR edge csc_pos[q]; `edge` stays in CSR
- * order --, so the backward, which walks the CSC segments, reads one sequential stream:
+ * table [E + 1, 32] floats in CSC order -- record q belongs to CSC edge q, i.e. CSR edge csc_pos[q]; `edge` stays in
+ * CSR order; record E repeats record E-1, the kernel requests one record ahead without a bounds check --, so the
+ * backward, which walks the CSC segments, reads one sequential stream:
  *   [2m], [2m+1]  env(u) g_m  and  (env'(u) g_m + 2 coeff env(u) g_m (u - mu_{lo+m})) / rc   for the 12 taps m of the
  *                 edge's window, g_m = exp(coeff (u - mu_{lo+m})^2): contracted with the rbf_proj rows they give
  *                 rbfh - bias and d rbfh / d d
