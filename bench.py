@@ -431,7 +431,10 @@ def main():
         # what actually limits each message kernel (profiles/README.md): the backward kernels issue
         # VALU work (banded 12-tap contraction) for longer than their HBM time; the forward kernels' gathers are served
         # from L2 / Infinity Cache faster than HBM could deliver the same bytes
-        limiter = {"message_scatter_fwd": "l2/infinity-cache gather", "message_scatter_fwd_l0": "l2/infinity-cache gather",
+        # (forward: with every gather folded into an L2-resident set it gains 7 % -- profiles/r02_kbench_gather_locality.log --
+        # so it is the dependent load -> LDS -> FMA chain at 2 waves per SIMD, not the gather rate, that sets its time)
+        limiter = {"message_scatter_fwd": "issue/latency at 2 waves per SIMD (gathers from L2/Infinity Cache)",
+                   "message_scatter_fwd_l0": "issue/latency (gathers from L2/Infinity Cache)",
                    "message_scatter_bwd": "valu-issue", "message_scatter_bwd_l0": "valu-issue"}
         for k in kernels:
             if k in limiter:
