@@ -7,6 +7,7 @@ are treated as constants (energy/force evaluation; parameter gradients are not p
 the training step runs through the differentiable device-op path, `HVNet.forward` in train() mode).
 """
 import ctypes
+import os as _os
 
 import torch
 
@@ -15,7 +16,6 @@ from .ops import _launch, _split_t, _stream
 
 P = _lib.ptr
 
-import os as _os
 # HERMNET_NODE_GEMM=1: node-level linears on the build's own fp32 MFMA GEMM with ScaledSiLU (forward and backward)
 # fused into the operand load / result store (csrc/node_gemm.hip) instead of library GEMMs + separate elementwise
 # launches (uniform row layout only).  OFF by default: measured on config 2 it enqueues faster (2.06 vs 2.71 ms of host
@@ -151,14 +151,20 @@ class EdgeGradSink(object):
     writes its slice, and `EdgeFanout.backward` reduces all slices in ONE pass (instead of a zero-fill, a
     block sum and an autograd accumulation per layer)."""
 
-    def __init__(self, layers, nblk, E, device):
+    def __init__(self, layers, nblk, E, device, zero=True):
+        """`zero=False`: every edge has a target of a known element, so every slot is written by the kernels and the
+        69 MB (config 2) zero-fill can be skipped."""
         self.shape = (layers, nblk, E, 4)
         self.device = device
+        self.zero = zero
         self.buf = None
 
     def slice(self, li):
-        if self.buf is None:     # edges of unknown-type / inactive targets are never written: zero once
-            self.buf = torch.zeros(self.shape, dtype=torch.float32, device=self.device)
+        if self.buf is None:     # edges to targets of an unknown element are never written: zero once if there are any
+            alloc = torch.zeros if self.zero else torch.empty
+            self.buf = alloc(self.shape, dtype=torch.float32, device=self.device)
+            if not self.zero and _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":
+                self.buf.fill_(float("nan"))         # (tests: a slot the kernels did not write would poison the forces)
         return self.buf[li]
 
 
