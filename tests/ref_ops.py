@@ -209,7 +209,8 @@ def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge):
         x1, vec1 = message_scatter_ref(xh_, v_, x_, e_, w.wt, w.brbf, graph, rbf)
         ins = [xh_, x_, D] + ([v_] if vec is not None else [])
         gr = torch.autograd.grad([x1, vec1], ins, [gx1, gvec1])
-    gedge[0, :, :3] = gr[2]          # all column blocks' contributions in slice 0; the others stay zero
+    gedge.zero_()                    # (the caller may hand over uninitialised memory: the kernels write every slot)
+    gedge[0, :, :3] = gr[2]          # all column blocks' contributions in slice 0, the others zero
     gxh, gv, gx = gr[0], (gr[3] if vec is not None else None), gr[1]
     res = getattr(graph, "res_row", None)
     if res is not None:
