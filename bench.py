@@ -13,7 +13,9 @@ Workloads (`--config`; `auto` = c2 on one GPU, c4 on several):
   c4    BASELINE configs[3]: the FIXED 100,000-atom cell (fcc 10 x 10 x 250, 36 x 36 x 900 A), sharded by atom into N
         slabs with a one-hop halo: STRONG scaling (total work fixed).  On one GPU: the same cell unsharded.
   weak  one cell of N x 10k atoms (fcc 10 x 10 x 25N), ~10k owned atoms per rank: weak scaling (round 1's mode).
-N > 1: one process per GPU (torchrun).  Every rank plans its slab on the device from the coordinates alone
+N > 1: one process per GPU.  `python bench.py --gpus N` on its own starts the N ranks itself (fresh child processes via
+`python -m torch.distributed.run`, before this process makes any GPU call) and relays rank 0's line; inside a torchrun job
+(WORLD_SIZE set, the driver's command line) it is one of the ranks.  Every rank plans its slab on the device from the coordinates alone
 (`sharding.partition_slab`: owners, geometric halo, neighbour search over owned + halo atoms only); per layer one
 RCCL all-to-all moves the halo rows, the energy is one scalar all-reduce.
 
@@ -250,6 +252,75 @@ def gemm_flops_per_step(N, nk, H, T, layers):
     return 2 * layers * (pre + upd)
 
 
+def self_launch(ngpus, argv):
+    """Start the `ngpus` ranks of this benchmark as FRESH child processes (`python -m torch.distributed.run`, one
+    process per GPU, rendezvous on 127.0.0.1 at a free port) and relay their output.  Called before this process has
+    touched the GPU (a process that has initialised HIP must not fork/exec ranks).  Returns the exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HERMNET_BENCH_CHILD="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // ngpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln                      # rank 0's JSON line
+        else:
+            print(ln, file=sys.stderr)     # anything else the ranks wrote to stdout is not the result
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode != 0:
+        print("bench.py: the %d-rank child job exited with code %d" % (ngpus, proc.returncode), file=sys.stderr)
+        return proc.returncode
+    return 0 if line is not None else 1
+
+
+def rank_fence(sharded, backend, dev):
+    """barrier + device synchronisation on both sides (the contract's bracket of the timed region)."""
+    def fence():
+        if dev is not None:
+            torch.cuda.synchronize()
+        if sharded:
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev.index])
+            else:
+                dist.barrier()
+        if dev is not None:
+            torch.cuda.synchronize()
+    return fence
+
+
+def launch_rehearsal(args, world, rank):
+    """`--launch-rehearsal`: the launcher, rendezvous, fences and the max-over-ranks timing around an EMPTY step --
+    no model, no GPU, nothing measured (value null).  What the CPU suite can check of the N > 1 command line."""
+    if world > 1:
+        dist.init_process_group("gloo")
+    fence = rank_fence(world > 1, "gloo", None)
+    fence()
+    t0 = time.perf_counter()
+    fence()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    ranks = torch.ones(1, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks)
+    if rank == 0:
+        print(json.dumps({"metric": "launch rehearsal (no workload)", "value": None, "unit": "atom-steps/s",
+                          "n_gpus": world, "ranks_seen": int(ranks.item()), "steps": 0, "warmup": 0,
+                          "ms_per_step": None, "scaling": "strong", "rehearsal": True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,15 +335,25 @@ def main():
                          "on a single GPU (launch through torch.distributed.run --nproc-per-node 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal with several ranks sharing one GPU (exchange staged through the host)")
+    ap.add_argument("--launch-rehearsal", action="store_true",
+                    help="launcher check without a GPU: every rank joins the process group, runs the fences and the "
+                         "max-over-ranks reduction of the timed region around an empty step, rank 0 prints a line with "
+                         "value null (tests/test_bench_launcher.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    sharded = world > 1 or args.shard_anyway
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                         % (args.gpus, args.gpus))
+        if "WORLD_SIZE" in os.environ or os.environ.get("HERMNET_BENCH_CHILD"):
+            raise SystemExit("bench.py --gpus %d inside a %d-rank job: launch with python -m torch.distributed.run "
+                             "--nproc-per-node %d bench.py --gpus %d" % (args.gpus, world, args.gpus, args.gpus))
+        # plain `python bench.py --gpus N`: this process has made no GPU call yet and never will -- it starts the N
+        # ranks as fresh children, relays rank 0's line and exits with their code
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    sharded = world > 1 or args.shard_anyway
+    if args.launch_rehearsal:
+        return launch_rehearsal(args, world, rank)
     cfg = args.config if args.config != "auto" else ("c4" if world > 1 else "c2")
     ndev = torch.cuda.device_count()
     dev = torch.device("cuda", local_rank % max(ndev, 1))
@@ -347,11 +428,7 @@ def main():
         f = -torch.autograd.grad(e.sum(), d.pos)[0]
         return e, f
 
-    def fence():
-        torch.cuda.synchronize()
-        if sharded:
-            dist.barrier()
-        torch.cuda.synchronize()
+    fence = rank_fence(sharded, args.backend, dev)
 
     def max_over_ranks(v):
         if not sharded:
@@ -520,9 +597,9 @@ def main():
                 out["secondary"]["training"] = {"error": repr(ex)}
         if world == 1 and not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_kw, elems, seed)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if sharded:
-        dist.barrier()
+        fence()
         dist.destroy_process_group()
 
 

@@ -33,7 +33,6 @@ class GraphedStep(object):
         self.model, self.data = model, data
         self.pos = data.pos.detach().clone().requires_grad_(True)      # static input
         data.pos = self.pos
-        self._key = (data.edge_index.data_ptr(), data.edge_index.size(1), data.atomic_number.data_ptr())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -45,15 +44,26 @@ class GraphedStep(object):
         with torch.cuda.graph(self.graph):
             self.energy, self.forces = self._eager()
         torch.cuda.synchronize()
+        # the captured topology: the tensor OBJECTS (kept alive here, so their addresses cannot be handed to a rebuilt
+        # list of the same size) and their versions (in-place edits); taken after the first forward, which fills in a
+        # missing `batch`
+        self._topo = self._topology(data)
 
     def _eager(self):
         e = self.model(self.data)
         f = -torch.autograd.grad(e.sum(), self.pos)[0]
         return e.detach(), f
 
+    @staticmethod
+    def _topology(data):
+        keep = [data.get(k) for k in ("edge_index", "edge_shift", "cell", "atomic_number", "batch")]
+        return [(t, None if t is None else t._version) for t in keep]
+
     def matches(self, data):
-        """True while `data` carries the neighbour list this graph was captured for."""
-        return (data.edge_index.data_ptr(), data.edge_index.size(1), data.atomic_number.data_ptr()) == self._key
+        """True while `data` carries the neighbour list (edge_index, edge_shift, cell, atomic numbers, batch) this graph
+        was captured for: the same tensor objects, not modified in place since."""
+        now = self._topology(data)
+        return all(a is b and va == vb for (a, va), (b, vb) in zip(self._topo, now))
 
     def __call__(self, pos=None):
         if pos is not None:
