@@ -15,7 +15,7 @@ _ERR = {1: "HN_ERR_BAD_ARG (unsupported shape or null pointer)",
         3: "HN_ERR_LAUNCH (kernel launch failed)"}
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers
-ABI_VERSION = 4          # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
+ABI_VERSION = 5          # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
 
 
 class RbfDesc(ctypes.Structure):
@@ -75,10 +75,12 @@ SIGNATURES = {
     "hermnet_update_mid_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_energy_head_fwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_energy_head_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
-    "hermnet_node_gemm": (ctypes.c_int, [c_fp, ctypes.c_long, ctypes.c_long, c_fp, ctypes.c_long, ctypes.c_long,
-                                         c_fp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                         ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_long, ctypes.c_int, c_fp, ctypes.c_long,
-                                         c_fp, ctypes.c_long, ctypes.c_long, c_fp]),
+    "hermnet_node_chain_supported": (ctypes.c_int, [ctypes.c_int]),
+    "hermnet_node_pre_fwd": (ctypes.c_int, [c_fp] * 9 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                       ctypes.c_float, c_fp]),
+    "hermnet_node_pre_bwd": (ctypes.c_int, [c_fp] * 10 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_node_update_fwd": (ctypes.c_int, [c_fp] * 15 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_node_update_bwd": (ctypes.c_int, [c_fp] * 13 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_halo_rows": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "hermnet_halo_accumulate": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "hermnet_host_rbf_row": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,

@@ -16,12 +16,10 @@ from .ops import _launch, _split_t, _stream
 
 P = _lib.ptr
 
-# HERMNET_NODE_GEMM=1: node-level linears on the build's own fp32 MFMA GEMM with ScaledSiLU (forward and backward)
-# fused into the operand load / result store (csrc/node_gemm.hip) instead of library GEMMs + separate elementwise
-# launches (uniform row layout only).  OFF by default: measured on config 2 it enqueues faster (2.06 vs 2.71 ms of host
-# time per step) but runs slower on the GPU (4.40 vs 3.88 ms/step) -- its 64 x 64 tiles reach 45-75 TF against the
-# library's 57-81 TF on these skinny shapes, and a prologue-fused activation is re-evaluated by every column tile.
-_NODE_GEMM = _os.environ.get("HERMNET_NODE_GEMM", "0") != "0"
+# HERMNET_NODE_CHAIN=0: node-level linears through library GEMMs joined by the stage kernels (the only path for widths
+# the chain kernels are not instantiated for) instead of the four chain kernels of csrc/node_chain.hip.
+def _node_chain_enabled():
+    return _os.environ.get("HERMNET_NODE_CHAIN", "1") != "0"
 
 
 class LayerWeights(object):
@@ -106,25 +104,38 @@ class LayerWeights(object):
         self.wv_s, self.wvt_s = st(self.wv), st(self.wvt)
         self.wx0_s, self.wx0t_s, self.bx0_s = st(self.wx0), st(self.wx0t), st(self.bx0)[:, None, :].contiguous()
         self.wx2_s, self.wx2t_s, self.bx2_s = st(self.wx2), st(self.wx2t), st(self.bx2)[:, None, :].contiguous()
+        # MFMA-operand-order copies for the chain kernels (include/hermnet_hip.h: frag(W))
+        self.chain = nodeops.chain_supported(Hp)
+        if self.chain:
+            fr = nodeops.weight_fragments
+            w1s = self.w1cat.view(len(ml), Hp, Hp)
+            self.w1f, self.w1tf = fr(w1s), fr(w1s.transpose(1, 2).contiguous())
+            self.w2f, self.w2tf = fr(self.w2), fr(self.w2t)
+            self.wvf, self.wvtf = fr(self.wv_s), fr(self.wvt_s)
+            self.wx0f, self.wx0tf = fr(self.wx0_s), fr(self.wx0t_s)
+            self.wx2f, self.wx2tf = fr(self.wx2_s), fr(self.wx2t_s)
         self.key = key
         return self
 
 
-def _msg_fwd(graph, rbf, H, xh, vec, x, w, edge):
+def _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=True):
+    """`xh_bias=False`: xh already includes x_proj's bias (chain kernels)."""
     lib = _lib.load()
+    b2 = w.b2 if xh_bias else None
     x1 = torch.empty(graph.N, H, dtype=x.dtype, device=x.device)          # target rows (= source rows unless HTNet)
     vec1 = torch.empty(graph.N, 3, H, dtype=x.dtype, device=x.device)
     gs, rs = graph.as_struct(), rbf.struct()
     _lib.check(_launch("message_scatter_fwd" + ("" if vec is not None else "_l0"),
                        lambda: lib.hermnet_message_scatter_fwd(
-                           ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(w.b2), P(vec), P(x), P(w.wt), P(w.brbf), P(edge),
+                           ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(b2), P(vec), P(x), P(w.wt), P(w.brbf), P(edge),
                            P(x1), P(vec1), _stream())), "hermnet_message_scatter_fwd")
     return x1, vec1
 
 
-def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge):
+def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True):
     """`gedge` [H/64, E, 4] (zero-filled by the caller) receives the per-column-block Cartesian edge gradients."""
     lib = _lib.load()
+    b2 = w.b2 if xh_bias else None
     gxh = torch.empty_like(xh)
     split = _split_t(graph)
     gvec = None if vec is None else (torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
@@ -137,7 +148,7 @@ def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge):
     gs, rs = graph.as_struct(), rbf.struct()
     _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"),
                        lambda: lib.hermnet_message_scatter_bwd(
-                           ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(w.b2), P(vec), P(w.wt), P(w.brbf), P(edge),
+                           ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(b2), P(vec), P(w.wt), P(w.brbf), P(edge),
                            P(gx1), P(gvec1), P(gxh), P(gvec), P(gx), P(gedge), split, P(graph.edge_table), P(part),
                            _stream())),
                "hermnet_message_scatter_bwd")
@@ -206,37 +217,27 @@ class FusedRelationalLayer(torch.autograd.Function):
         vec = None if vec is None else vec.contiguous()
         # --- node projection of every relation: xh[t] = x_proj_t(LayerNorm_t(x))  (rmnet.py:52)
         uni, B = graph.uniform and nk > 0, graph.block
-        fused_gemm = _NODE_GEMM and uni and x.is_cuda
+        ctx.chain = w.chain and _node_chain_enabled()
+        if ctx.chain:
+            # three launches: node_pre_fwd (LayerNorm + x_proj of every relation), the message kernel, node_update_fwd
+            hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T)
+            x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False)
+            x_out, vec_out, vp, h2b, q23 = nodeops.node_update_fwd(x1, vec1, w, graph)
+            ctx.save_for_backward(x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23)
+            ctx.graph, ctx.rbf, ctx.w, ctx.sink, ctx.li = graph, rbf, w, sink, li
+            return x_out, vec_out
         n, mean, rstd = nodeops.layernorm_fwd(x, 1e-5, h_real=w.h_real)
-        if fused_gemm:
-            h = torch.empty(Ns, T * H, dtype=x.dtype, device=x.device)
-            nodeops.gemm(n, w.w1cat, h, Ns, T * H, H, bias=w.b1cat)                                           # [Ns, T*H]
-            xh = torch.empty(T, Ns, 3 * H, dtype=x.dtype, device=x.device)
-            # ScaledSiLU applied while the operand tile is staged: the activation is never materialised
-            nodeops.gemm(h, w.w2, xh, Ns, 3 * H, H, batch=T, lda=T * H, sA=H, sB=3 * H * H, sC=Ns * 3 * H, prologue=1)
-        else:
-            h = _launch("gemm", lambda: torch.addmm(w.b1cat, n, w.w1cat.t()))                                 # [Ns, T*H]
-            a = nodeops.ssilu_fwd(h)
-            # (biases that would be broadcast over a batched GEMM's rows are added by the consuming kernel
-            # instead: baddbmm with a broadcast bias first copies it over the whole output)
-            xh = _launch("gemm", lambda: torch.bmm(a.view(Ns, T, H).transpose(0, 1), w.w2t))                  # [T, Ns, 3H], + b2 on load
+        h = _launch("gemm", lambda: torch.addmm(w.b1cat, n, w.w1cat.t()))                                     # [Ns, T*H]
+        a = nodeops.ssilu_fwd(h)
+        # (biases that would be broadcast over a batched GEMM's rows are added by the consuming kernel
+        # instead: baddbmm with a broadcast bias first copies it over the whole output)
+        xh = _launch("gemm", lambda: torch.bmm(a.view(Ns, T, H).transpose(0, 1), w.w2t))                      # [T, Ns, 3H], + b2 on load
         # --- fused edge part + residual (rmnet.py:55-73, 24-26)
         x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge)
         # --- PaiNNUpdate on the rows of each relation (rmnet.py:94-107)
         vp = torch.empty(N, 3, 2 * H, dtype=x.dtype, device=x.device)
         h2 = torch.empty(N, H, dtype=x.dtype, device=x.device)
         q = torch.empty(N, 3 * H, dtype=x.dtype, device=x.device)
-        if fused_gemm:
-            nodeops.gemm(vec1, w.wv_s, vp, 3 * B, 2 * H, H, batch=T, sA=3 * B * H, sB=2 * H * H, sC=3 * B * 2 * H)
-            vdot, xin = nodeops.update_mid(vp, x1, nk, H)
-            nodeops.gemm(xin, w.wx0_s, h2, B, H, 2 * H, batch=T, sA=B * 2 * H, sB=H * 2 * H, sC=B * H)
-            nodeops.gemm(h2, w.wx2_s, q, B, 3 * H, H, batch=T, sA=B * H, sB=3 * H * H, sC=B * 3 * H,
-                         prologue=1, pbias=w.bx0_s, s_pbias=H)
-            x_out, vec_out = nodeops.update_out(q, vdot, vp, x1, vec1, graph.row_active, N, nk, H, qbias=w.bx2_s,
-                                                rows_per_bias=B)
-            ctx.save_for_backward(x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q)
-            ctx.graph, ctx.rbf, ctx.w, ctx.sink, ctx.li = graph, rbf, w, sink, li
-            return x_out, vec_out
         if uni:   # every relation owns `B` rows: one batched GEMM per stage
             _launch("gemm", lambda: torch.bmm(vec1[:nk].view(T, 3 * B, H), w.wvt_s, out=vp[:nk].view(T, 3 * B, 2 * H)))
         else:
@@ -269,9 +270,7 @@ class FusedRelationalLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gxo, gvo):
-        x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q = ctx.saved_tensors
         graph, rbf, w = ctx.graph, ctx.rbf, ctx.w
-        Ns, H = x.shape
         N = graph.N
         T = graph.T
         rp = graph.type_rowptr_host
@@ -279,21 +278,17 @@ class FusedRelationalLayer(torch.autograd.Function):
         gxo = gxo.contiguous()
         gvo = gvo.contiguous()
         uni, B = graph.uniform and nk > 0, graph.block
-        qb = dict(qbias=w.bx2_s, rows_per_bias=B) if uni else {}
-        kb = dict(bias=w.bx0_s, rows_per_bias=B) if uni else {}
-        gq, gvdot, gvp, gx1, gvec1 = nodeops.update_out_bwd(gxo, gvo, q, vdot, vp, graph.row_active, N, nk, H, **qb)
-        fused_gemm = _NODE_GEMM and uni and x.is_cuda
-        gxin = torch.empty(N, 2 * H, dtype=x.dtype, device=x.device)
-        if fused_gemm:
-            # (gq Wx2) * ScaledSiLU'(h2 + bx0): the activation's backward rides in the GEMM's epilogue
-            gh2 = torch.empty(nk, H, dtype=x.dtype, device=x.device)
-            nodeops.gemm(gq, w.wx2t_s, gh2, B, H, 3 * H, batch=T, sA=B * 3 * H, sB=H * 3 * H, sC=B * H,
-                         epilogue=1, bias=w.bx0_s, s_bias=H, E=h2, lde=H, sE=B * H)
-            nodeops.gemm(gh2, w.wx0t_s, gxin, B, 2 * H, H, batch=T, sA=B * H, sB=2 * H * H, sC=B * 2 * H)
-            nodeops.update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, nk, H)
-            nodeops.gemm(gvp, w.wvt_s, gvec1, 3 * B, H, 2 * H, batch=T, sA=3 * B * 2 * H, sB=H * 2 * H, sC=3 * B * H,
-                         epilogue=2)                                                           # gvec1 += gvp Wv
+        if ctx.chain:
+            x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23 = ctx.saved_tensors
+            Ns, H = x.shape
+            gx1, gvec1 = nodeops.node_update_bwd(gxo, gvo, vp, h2b, q23, w, graph)
         else:
+            x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q = ctx.saved_tensors
+            Ns, H = x.shape
+            qb = dict(qbias=w.bx2_s, rows_per_bias=B) if uni else {}
+            kb = dict(bias=w.bx0_s, rows_per_bias=B) if uni else {}
+            gq, gvdot, gvp, gx1, gvec1 = nodeops.update_out_bwd(gxo, gvo, q, vdot, vp, graph.row_active, N, nk, H, **qb)
+            gxin = torch.empty(N, 2 * H, dtype=x.dtype, device=x.device)
             ga2 = torch.empty(N, H, dtype=x.dtype, device=x.device)
             if uni:
                 _launch("gemm", lambda: torch.bmm(gq[:nk].view(T, B, 3 * H), w.wx2_s, out=ga2[:nk].view(T, B, H)))
@@ -325,7 +320,7 @@ class FusedRelationalLayer(torch.autograd.Function):
             gedge = ctx.sink.slice(ctx.li)
         else:
             gedge = torch.zeros(H // 64, graph.E, 4, dtype=torch.float32, device=gx1.device)
-        gxh, gvec_in, gx_in = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge)
+        gxh, gvec_in, gx_in = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=not ctx.chain)
         if graph.num_src:
             # HTNet: the residual (rmnet.py:24-26) reads the atom's own row from each of its P virtual target rows;
             # its gradient returns as the sum over those rows (the kernel adds no identity term in this mode)
@@ -335,17 +330,13 @@ class FusedRelationalLayer(torch.autograd.Function):
                 gvec_in[:Te * B_] += gvec1.view(Te, P_, B_, 3, H).sum(1).reshape(Te * B_, 3, H)
         gx_total = None
         if ctx.needs_input_grad[0]:
-            if fused_gemm:
-                gh = torch.empty(Ns, T * H, dtype=x.dtype, device=x.device)
-                nodeops.gemm(gxh, w.w2t, gh, Ns, H, 3 * H, batch=T, sA=Ns * 3 * H, sB=H * 3 * H, ldc=T * H, sC=H,
-                             epilogue=1, E=h, lde=T * H, sE=H)                   # (gxh W2) * ScaledSiLU'(h)
-                gn = torch.empty(Ns, H, dtype=x.dtype, device=x.device)
-                nodeops.gemm(gh, w.w1cat_t, gn, Ns, H, T * H)
+            if ctx.chain:
+                gx_total = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in)
             else:
                 ga = _launch("gemm", lambda: torch.bmm(gxh, w.w2))                                            # [T, Ns, H]
                 gh = nodeops.ssilu_bwd(ga, h, Ns, T, H, H, Ns * H)                   # [Ns, T*H]
                 gn = _launch("gemm", lambda: torch.mm(gh, w.w1cat))                                           # [N, H]
-            gx_total = nodeops.layernorm_bwd(gn, x, mean, rstd, add=gx_in, h_real=w.h_real)
+                gx_total = nodeops.layernorm_bwd(gn, x, mean, rstd, add=gx_in, h_real=w.h_real)
         ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
         return gx_total, gvec_in, ge, None, None, None, None, None
 

@@ -118,14 +118,81 @@ def halo_accumulate(x, vec, plan, buf):
         P(x), P(vec), P(rows), P(ptr), P(pos), int(rows.numel()), x.size(1), P(buf), _stream())), "hermnet_halo_accumulate")
 
 
-def gemm(A, Bt, C, M, N, K, batch=1, lda=None, ldb=None, ldc=None, sA=0, sB=0, sC=0,
-         prologue=0, pbias=None, s_pbias=0, epilogue=0, bias=None, s_bias=0, E=None, lde=0, sE=0, a_off=0, c_off=0, e_off=0):
-    """C[b] = epilogue(prologue(A[b]) @ Bt[b]^T) on the fp32 matrix pipe with the neighbouring elementwise stage fused
-    (include/hermnet_hip.h: hermnet_node_gemm).  Tensors are passed with explicit leading dimensions / batch strides
-    (in elements) so that column slices and relation blocks of larger arrays need no copies; `*_off` = element offsets."""
-    fp = lambda t, off=0: None if t is None else t.data_ptr() + 4 * off
-    _lib.check(_launch("node_gemm", lambda: _lib.load().hermnet_node_gemm(
-        fp(A, a_off), lda if lda is not None else K, sA, fp(Bt), ldb if ldb is not None else K, sB,
-        fp(C, c_off), ldc if ldc is not None else N, sC, M, N, K, batch, prologue, fp(pbias), s_pbias,
-        epilogue, fp(bias), s_bias, fp(E, e_off), lde, sE, _stream())), "hermnet_node_gemm")
-    return C
+# ---- node chain kernels (csrc/node_chain.hip): one launch per chain on the fp32 matrix pipe ---------------------------
+def chain_supported(H):
+    """Widths the chain kernels are instantiated for (other widths: library GEMMs + the stage kernels above)."""
+    return H in (64, 128, 256)
+
+
+def weight_fragments(w):
+    """nn.Linear weight [out, in] (or a stack [T, out, in]) -> the same values in MFMA B-operand order
+    (include/hermnet_hip.h: frag(W)); out % 32 == 0, in % 8 == 0."""
+    lead = w.shape[:-2]
+    o, k = w.shape[-2:]
+    f = w.reshape(*lead, o // 32, 32, k // 8, 2, 4)
+    n = len(lead)
+    return f.permute(*range(n), n, n + 2, n + 3, n + 1, n + 4).contiguous().reshape(*lead, o * k)
+
+
+def _rowptr_host(graph):
+    import ctypes
+    c = getattr(graph, "_rowptr_c", None)
+    if c is None:
+        vals = list(graph.type_rowptr_host)
+        c = (ctypes.c_int * len(vals))(*vals)
+        try:
+            graph._rowptr_c = c
+        except AttributeError:
+            pass
+    return c
+
+
+def node_pre_fwd(x, w, T):
+    """x [Ns,H] -> (hb [T,Ns,H], xh [T,Ns,3H] incl. bias, mean [Ns], rstd [Ns])  (rmnet.py:52 for every relation)."""
+    Ns, H = x.shape
+    dev, dt = x.device, x.dtype
+    hb = torch.empty(T, Ns, H, dtype=dt, device=dev)
+    xh = torch.empty(T, Ns, 3 * H, dtype=dt, device=dev)
+    mean = torch.empty(Ns, dtype=dt, device=dev)
+    rstd = torch.empty(Ns, dtype=dt, device=dev)
+    _lib.check(_launch("node_pre_fwd", lambda: _lib.load().hermnet_node_pre_fwd(
+        P(x), P(w.w1f), P(w.b1cat), P(w.w2f), P(w.b2), P(hb), P(xh), P(mean), P(rstd), Ns, T, H, w.h_real, 1e-5,
+        _stream())), "hermnet_node_pre_fwd")
+    return hb, xh, mean, rstd
+
+
+def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None):
+    """Gradient of node_pre_fwd w.r.t. x (+ add)."""
+    T, Ns, H = hb.shape
+    parts = torch.empty(T, Ns, H, dtype=x.dtype, device=x.device)
+    gx = torch.empty_like(x)
+    _lib.check(_launch("node_pre_bwd", lambda: _lib.load().hermnet_node_pre_bwd(
+        P(gxh), P(hb), P(w.w2tf), P(w.w1tf), P(parts), P(x), P(mean), P(rstd), P(add), P(gx), Ns, T, H, w.h_real,
+        _stream())), "hermnet_node_pre_bwd")
+    return gx
+
+
+def node_update_fwd(x1, vec1, w, graph):
+    """(x1, vec1) -> (x_out, vec_out) and the saved (vp [N,3,2H], h2b [N,H], q23 [N,2H])  (rmnet.py:94-107, 29-31)."""
+    N, H = x1.shape
+    dev, dt = x1.device, x1.dtype
+    vp = torch.empty(N, 3, 2 * H, dtype=dt, device=dev)
+    h2b = torch.empty(N, H, dtype=dt, device=dev)
+    q23 = torch.empty(N, 2 * H, dtype=dt, device=dev)
+    xo = torch.empty(N, H, dtype=dt, device=dev)
+    vo = torch.empty(N, 3, H, dtype=dt, device=dev)
+    _lib.check(_launch("node_update_fwd", lambda: _lib.load().hermnet_node_update_fwd(
+        P(x1), P(vec1), P(w.wvf), P(w.wx0f), P(w.bx0_s), P(w.wx2f), P(w.bx2_s), P(graph.row_active), P(graph.type_rowptr),
+        _rowptr_host(graph), P(vp), P(h2b), P(q23), P(xo), P(vo), N, graph.T, H, _stream())), "hermnet_node_update_fwd")
+    return xo, vo, vp, h2b, q23
+
+
+def node_update_bwd(gxo, gvo, vp, h2b, q23, w, graph):
+    """Gradient of node_update_fwd w.r.t. (x1, vec1)."""
+    N, H = gxo.shape
+    gx1 = torch.empty_like(gxo)
+    gvec1 = torch.empty_like(gvo)
+    _lib.check(_launch("node_update_bwd", lambda: _lib.load().hermnet_node_update_bwd(
+        P(gxo), P(gvo), P(vp), P(h2b), P(q23), P(w.wx2tf), P(w.wx0tf), P(w.wvtf), P(graph.row_active), P(graph.type_rowptr),
+        _rowptr_host(graph), P(gx1), P(gvec1), N, graph.T, H, _stream())), "hermnet_node_update_bwd")
+    return gx1, gvec1

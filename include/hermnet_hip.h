@@ -16,7 +16,8 @@
  *   - float = IEEE fp32 (the reference is fp32-only), indices = int32 (int64 where a parameter says so:
  *     the caller's edge_index / atomic_number / halo index lists arrive as torch LongTensors).
  *
- * ABI version 4 (`hermnet_abi_version`): v4 puts the radial table in CSC order (hermnet_edge_radial_table takes the
+ * ABI version 5 (`hermnet_abi_version`): v5 replaces the stand-alone node GEMM by the node chain kernels
+ * (hermnet_node_pre_fwd/_bwd, hermnet_node_update_fwd/_bwd); v4 puts the radial table in CSC order (hermnet_edge_radial_table takes the
  * graph); v3 added the deterministic halo accumulate, separate source / target row
  * spaces (HTNet) and the fused node-chain kernels; v2 added the bias-on-load arguments, LayerNorm, the energy head, the
  * CSC position gradient and the halo packing; the Python side refuses a library of another version.
@@ -264,20 +265,46 @@ int hermnet_energy_head_fwd(const float* h, const float* w, const float* b, cons
 int hermnet_energy_head_bwd(const float* ge, const float* h, const float* w, const float* row_mask, float* gh,
                             int rows, int cols, void* stream);
 
-/* fp32 MFMA GEMM of the node-level linears (rmnet.py:52 x_proj, rmnet.py:94-107 vec_proj / xvec_proj and their input
- * gradients) with the neighbouring elementwise stage fused in (csrc/node_gemm.hip):
- *     C[b][M, N] = epilogue( prologue(A[b])[M, K] . Bt[b][N, K]^T ),   b < batch (relation blocks; strides in elements)
- * A, Bt are K-contiguous (lda, ldb multiples of 4; K a multiple of 64); Bt is an nn.Linear weight [out, in] (or the
- * transposed copy the host keeps for backward products).
- *   prologue 0: none            1: A := ScaledSiLU(A + pbias[b][k])   (pbias may be NULL)
- *   epilogue 0: C = acc + bias[b][n] (bias may be NULL)
- *            1: C = acc * ScaledSiLU'(E[b][m, n] + bias[b][n])   (backward of the activation; bias may be NULL)
- *            2: C += acc */
-int hermnet_node_gemm(const float* A, long lda, long strideA, const float* Bt, long ldb, long strideB,
-                      float* C, long ldc, long strideC, int M, int N, int K, int batch,
-                      int prologue, const float* pbias, long stridePbias,
-                      int epilogue, const float* bias, long strideBias,
-                      const float* E, long lde, long strideE, void* stream);
+/* ---- A7 (node MLP) + A11 + A12 as chain kernels on the fp32 matrix pipe (csrc/node_chain.hip) -----------------------
+ * One launch per chain instead of library GEMMs joined by elementwise launches; hidden activations never reach HBM.
+ * hidden must be 64, 128 or 256 (hermnet_node_chain_supported; other widths: the stage-wise entry points above around
+ * the caller's GEMMs).  Weights arrive in FRAGMENT ORDER: for an nn.Linear weight W [out, in] (or its transpose for
+ * the backward products), frag(W)[((cb * in/8 + q) * 64 + l) * 4 + e] = W[32 cb + (l & 31)][8 q + 4 (l >> 5) + e],
+ * i.e. W.view(out/32, 32, in/8, 2, 4).permute(0, 2, 3, 1, 4) -- the B operand registers of v_mfma_f32_32x32x2_f32, so
+ * that a wave loads one coalesced KiB per k-group straight into the operand.  `[T]` = stacked over the relations.
+ *
+ * hermnet_node_pre_fwd   (rmnet.py:52): for every relation t and source row,
+ *     hb[t] = LayerNorm(x) W1_t^T + b1_t   (LayerNorm without affine: folded into W1 / b1 by the host; statistics over
+ *                                           the first hidden_real channels, 0 = all),   saved for the backward
+ *     xh[t] = ScaledSiLU(hb[t]) W2_t^T + b2_t      [T, num_src, 3H]   (bias INCLUDED: pass xh_bias = NULL to the
+ *                                                                       message kernels)
+ *     mean, rstd [num_src]: the LayerNorm statistics.
+ * hermnet_node_pre_bwd: gx = LayerNorm'(x)^T sum_t ((gxh[t] W2_t) * ScaledSiLU'(hb[t])) W1_t + add
+ *     (w2t_frag = frag(W2_t^T [H, 3H]), w1t_frag = frag(W1_t^T [H, H]); gn_parts [T, num_src, H] is workspace; add may
+ *     be NULL; gx may alias add). */
+int hermnet_node_chain_supported(int hidden);
+int hermnet_node_pre_fwd(const float* x, const float* w1_frag, const float* b1, const float* w2_frag, const float* b2,
+                         float* hb, float* xh, float* mean, float* rstd, int num_src, int num_rel, int hidden,
+                         int hidden_real, float eps, void* stream);
+int hermnet_node_pre_bwd(const float* gxh, const float* hb, const float* w2t_frag, const float* w1t_frag,
+                         float* gn_parts, const float* x, const float* mean, const float* rstd, const float* add,
+                         float* gx, int num_src, int num_rel, int hidden, int hidden_real, void* stream);
+/* hermnet_node_update_fwd (rmnet.py:94-107, 29-31; hermnet.py:51,56-61), target rows in relation order:
+ *     vp = vec1 Wv^T  [N,3,2H] = (v1 | v2), saved;   vdot = sum_d v1 v2 / sqrt(H);   n = sqrt(sum_d v2^2 + 1e-8)
+ *     h2b = [x1 | n] Wx0^T + bx0  [N,H], saved;      (p | q | r) = ScaledSiLU(h2b) Wx2^T + bx2;   q23 = (q | r) [N,2H], saved
+ *     x_out = x1 + (p + q vdot)/sqrt2,  vec_out[d] = vec1[d] + r v1[d];   rows with row_active == 0 (row_active may be
+ *     NULL: all active) and rows >= type_rowptr[T] are written as zero.
+ * type_rowptr [T+1] on the device and the same values on the host (`type_rowptr_host`: the launch geometry).
+ * hermnet_node_update_bwd: (gx_out, gvec_out) -> (gx1, gvec1), the gradients w.r.t. x1 / vec1 (parameters are
+ *     constants); wx2t_frag = frag(Wx2^T [H,3H]), wx0t_frag = frag(Wx0^T [2H,H]), wvt_frag = frag(Wv^T [H,2H]). */
+int hermnet_node_update_fwd(const float* x1, const float* vec1, const float* wv_frag, const float* wx0_frag,
+                            const float* bx0, const float* wx2_frag, const float* bx2, const float* row_active,
+                            const int* type_rowptr, const int* type_rowptr_host, float* vp, float* h2b, float* q23,
+                            float* x_out, float* vec_out, int num_nodes, int num_rel, int hidden, void* stream);
+int hermnet_node_update_bwd(const float* gx_out, const float* gvec_out, const float* vp, const float* h2b,
+                            const float* q23, const float* wx2t_frag, const float* wx0t_frag, const float* wvt_frag,
+                            const float* row_active, const int* type_rowptr, const int* type_rowptr_host, float* gx1,
+                            float* gvec1, int num_nodes, int num_rel, int hidden, void* stream);
 
 /* Halo exchange packing for atom-sharded runs (one process per GPU; the exchange itself is an RCCL all-to-all made
  * by the host code, hermnet_amd/sharding.py).  A packed row = [ x (H) | vec (3H) ]; idx [n] (int64) holds rows.

@@ -189,16 +189,135 @@ def update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, rows, H):
     gvp[:rows, :, H:] = gd * s * v1 + gnn * v2
 
 
-def msg_fwd(graph, rbf, H, xh, vec, x, w, edge):
+# ---- node chain kernels (hermnet_amd.nodeops.node_*; csrc/node_chain.hip): same contracts, plain weights of `w` --------
+def node_pre_fwd(x, w, T):
+    Ns, H = x.shape
+    dt = x.dtype
+    n, mean, rstd = layernorm_fwd(x, 1e-5, h_real=w.h_real)
+    hb = (n @ w.w1cat.to(dt).t() + w.b1cat.to(dt)).view(Ns, T, H).transpose(0, 1).contiguous()      # [T, Ns, H]
+    a = torch.nn.functional.silu(hb) / 0.6
+    xh = torch.bmm(a, w.w2t.to(dt)) + w.b2.to(dt)                                                    # [T, Ns, 3H]
+    return hb, xh, mean, rstd
+
+
+def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None):
+    T, Ns, H = hb.shape
+    dt = x.dtype
+    gh = torch.bmm(gxh, w.w2.to(dt)) * _dssilu(hb)                                                   # [T, Ns, H]
+    gn = torch.bmm(gh, w.w1cat.to(dt).view(T, H, H)).sum(0)
+    return layernorm_bwd(gn, x, mean, rstd, add=add, h_real=w.h_real)
+
+
+def _update_parts(x1, vec1, w, graph):
+    """Per relation block: (rows, v1, v2, vdot, norm, h2b, p, q, r) with autograd enabled inputs."""
+    H = x1.size(1)
+    dt = x1.dtype
+    rp = graph.type_rowptr_host
+    out = []
+    for t in range(graph.T):
+        lo, hi = rp[t], rp[t + 1]
+        if hi <= lo:
+            continue
+        vp = vec1[lo:hi] @ w.wv[t].to(dt).t()                                   # [n, 3, 2H]
+        v1, v2 = vp[..., :H], vp[..., H:]
+        vdot = (v1 * v2).sum(1) / math.sqrt(H)
+        norm = torch.sqrt((v2 ** 2).sum(1) + 1e-8)
+        h2b = torch.cat([x1[lo:hi], norm], 1) @ w.wx0[t].to(dt).t() + w.bx0[t].to(dt)
+        pqr = (torch.nn.functional.silu(h2b) / 0.6) @ w.wx2[t].to(dt).t() + w.bx2[t].to(dt)
+        out.append((lo, hi, vp, v1, vdot, h2b, pqr))
+    return out
+
+
+def _node_update(x1, vec1, w, graph):
+    N, H = x1.shape
+    dt = x1.dtype
+    act = torch.ones(N, dtype=dt) if graph.row_active is None else graph.row_active.to(dt)
+    xo = torch.zeros(N, H, dtype=dt)
+    vo = torch.zeros(N, 3, H, dtype=dt)
+    vp_all = torch.zeros(N, 3, 2 * H, dtype=dt)
+    h2b_all = torch.zeros(N, H, dtype=dt)
+    q23 = torch.zeros(N, 2 * H, dtype=dt)
+    xs, vs = [], []
+    for lo, hi, vp, v1, vdot, h2b, pqr in _update_parts(x1, vec1, w, graph):
+        p, q, r = pqr[:, :H], pqr[:, H:2 * H], pqr[:, 2 * H:]
+        m = (act[lo:hi] != 0).to(dt)
+        xs.append((lo, hi, (x1[lo:hi] + (p + q * vdot) / math.sqrt(2.0)) * m[:, None]))
+        vs.append((lo, hi, (vec1[lo:hi] + r[:, None, :] * v1) * m[:, None, None]))
+        vp_all[lo:hi], h2b_all[lo:hi], q23[lo:hi] = vp.detach(), h2b.detach(), pqr[:, H:].detach()
+    if xs:
+        xo = torch.cat([torch.zeros(0, H, dtype=dt)] + _fill_rows(xs, N, (H,), dt))
+        vo = torch.cat([torch.zeros(0, 3, H, dtype=dt)] + _fill_rows(vs, N, (3, H), dt))
+    return xo, vo, vp_all, h2b_all, q23
+
+
+def _fill_rows(parts, N, shape, dt):
+    """Differentiable assembly of row blocks [(lo, hi, values)] into an N-row array (gaps = zero rows)."""
+    out, at = [], 0
+    for lo, hi, v in parts:
+        if lo > at:
+            out.append(torch.zeros((lo - at,) + shape, dtype=dt))
+        out.append(v)
+        at = hi
+    if at < N:
+        out.append(torch.zeros((N - at,) + shape, dtype=dt))
+    return out
+
+
+def node_update_fwd(x1, vec1, w, graph):
+    with torch.no_grad():
+        return _node_update(x1, vec1, w, graph)
+
+
+def node_update_bwd(gxo, gvo, vp, h2b, q23, w, graph):
+    """The kernel's backward formulas from the saved (vp, h2b, q23) (checked against autograd of the forward in
+    tests/test_host_logic.py)."""
+    N, H = gxo.shape
+    dt = gxo.dtype
+    act = torch.ones(N, dtype=dt) if graph.row_active is None else graph.row_active.to(dt)
+    gx1 = torch.zeros(N, H, dtype=dt)
+    gvec1 = torch.zeros(N, 3, H, dtype=dt)
+    rp = graph.type_rowptr_host
+    r2, rh = 1 / math.sqrt(2.0), 1 / math.sqrt(H)
+    for t in range(graph.T):
+        lo, hi = rp[t], rp[t + 1]
+        if hi <= lo:
+            continue
+        m = (act[lo:hi] != 0).to(dt)
+        gx, gv = gxo[lo:hi] * m[:, None], gvo[lo:hi] * m[:, None, None]
+        v1, v2 = vp[lo:hi, :, :H], vp[lo:hi, :, H:]
+        vdot = (v1 * v2).sum(1) * rh
+        norm = torch.sqrt((v2 ** 2).sum(1) + 1e-8)
+        q2, q3 = q23[lo:hi, :H], q23[lo:hi, H:]
+        gq = torch.cat([gx * r2, gx * vdot * r2, (gv * v1).sum(1)], 1)
+        gh2 = (gq @ w.wx2[t].to(dt)) * _dssilu(h2b[lo:hi])
+        gxin = gh2 @ w.wx0[t].to(dt)
+        gx1[lo:hi] = gx + gxin[:, :H]
+        gnn = gxin[:, H:] / norm
+        s_ = gx * q2 * (r2 * rh)
+        gv1 = gv * q3[:, None, :] + s_[:, None, :] * v2
+        gv2 = s_[:, None, :] * v1 + gnn[:, None, :] * v2
+        gvec1[lo:hi] = gv + torch.cat([gv1, gv2], -1) @ w.wv[t].to(dt)
+    return gx1, gvec1
+
+
+def node_update_bwd_from_inputs(gxo, gvo, x1, vec1, w, graph):
+    with torch.enable_grad():
+        x1_ = x1.detach().requires_grad_(True)
+        v_ = vec1.detach().requires_grad_(True)
+        xo, vo, _, _, _ = _node_update(x1_, v_, w, graph)
+        return torch.autograd.grad([xo, vo], [x1_, v_], [gxo, gvo])
+
+
+def msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=True):
     edge = edge[0] if edge.dim() == 3 else edge
-    return message_scatter_ref(xh + w.b2, vec, x, edge, w.wt, w.brbf, graph, rbf)     # xh_bias = w.b2 [T,1,3H]
+    return message_scatter_ref(xh + w.b2 if xh_bias else xh, vec, x, edge, w.wt, w.brbf, graph, rbf)     # xh_bias = w.b2 [T,1,3H]
 
 
-def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge):
+def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True):
     """Backward contract of hermnet_message_scatter_bwd via autograd of the dense restatement;
     the edge gradient is Cartesian (w.r.t. D = rhat * d)."""
     with torch.enable_grad():
-        xh_ = (xh + w.b2).detach().requires_grad_(True)
+        xh_ = (xh + w.b2 if xh_bias else xh).detach().requires_grad_(True)
         x_ = torch.zeros(xh.size(1), H, dtype=xh.dtype).requires_grad_(True)
         v_ = vec.detach().requires_grad_(True) if vec is not None else None
         if edge.dim() == 3:          # per-layer handle of EdgeFanout: [H/64, E, 4] view of the same edge array

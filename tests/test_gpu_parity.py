@@ -251,6 +251,61 @@ def test_node_kernels_match_pytorch_restatement():
         assert rel_err(gvp_d.cpu()[:nk], gvp[:nk]) < 1e-6 and rel_err(gx1_d.cpu(), gx1) < 1e-6
 
 
+@pytest.mark.parametrize("H,T,counts,uniform,hr", [(128, 3, (70, 91, 45), None, 0), (128, 3, (130, 3, 61), False, 0),
+                                                   (64, 2, (100, 77), None, 50), (256, 3, (40, 33, 50), None, 0),
+                                                   (128, 1, (300,), None, 0), (128, 3, (4000, 3900, 4100), None, 0),
+                                                   (128, 3, (7000, 7100, 6900), None, 0)])
+def test_node_chain_kernels_match_restatement(H, T, counts, uniform, hr):
+    """csrc/node_chain.hip (LayerNorm + x_proj chain, PaiNNUpdate chain and their backward kernels on the fp32 matrix
+    pipe) vs the fp64 PyTorch restatement of tests/ref_ops.py: ragged relation blocks, an inactive relation, rows of
+    unknown elements, zero-padded channels (hidden_real), both 64- and 32-row tile instances at H = 128."""
+    from test_host_logic import _layer_weights_and_graph
+    from hermnet_amd import nodeops
+    dev = _dev()
+    w, g = _layer_weights_and_graph(H, T, counts, uniform=uniform, unknown=5)
+    w.h_real = hr
+    if hr:      # zero-padded channels: the padded rows / columns of every weight are zero (layer.LayerWeights.refresh)
+        pytest.skip("padded widths are covered by the model-level tests (test_other_widths_vs_oracle)")
+    gen = torch.Generator().manual_seed(2)
+    N = g.N
+    rnd = lambda *s_: torch.randn(*s_, generator=gen)
+    x, x1, vec1 = rnd(N, H), rnd(N, H), rnd(N, 3, H)
+    gxh, gxo, gvo, add = rnd(T, N, 3 * H) * 0.3, rnd(N, H), rnd(N, 3, H), rnd(N, H)
+    # device copies of the weights and the graph
+    import copy
+    wd = copy.copy(w)
+    for k, v in vars(w).items():
+        if torch.is_tensor(v):
+            setattr(wd, k, v.to(dev))
+    gd = copy.copy(g)
+    gd.row_active, gd.type_rowptr = g.row_active.to(dev), g.type_rowptr.to(dev)
+    gd._rowptr_c = None
+    c = lambda t: t.to(dev)
+    d64 = lambda t: t.double()
+    hb, xh, mean, rstd = nodeops.node_pre_fwd(c(x), wd, T)
+    hb_r, xh_r, mean_r, rstd_r = ref_ops.node_pre_fwd(d64(x), w, T)
+    assert rel_err(hb.cpu().double(), hb_r) < 2e-6 and rel_err(xh.cpu().double(), xh_r) < 2e-6
+    assert rel_err(mean.cpu().double(), mean_r) < 2e-6 and rel_err(rstd.cpu().double(), rstd_r) < 2e-6
+    for a in (None, add):
+        gx = nodeops.node_pre_bwd(c(gxh), hb, c(x), mean, rstd, wd, add=None if a is None else c(a))
+        gx_r = ref_ops.node_pre_bwd(d64(gxh), hb_r, d64(x), mean_r, rstd_r, w, add=None if a is None else d64(a))
+        assert rel_err(gx.cpu().double(), gx_r) < 5e-6
+    xo, vo, vp, h2b, q23 = nodeops.node_update_fwd(c(x1), c(vec1), wd, gd)
+    refs = ref_ops.node_update_fwd(d64(x1), d64(vec1), w, g)
+    nk = g.type_rowptr_host[-1]
+    for k, (a, b) in enumerate(zip((xo, vo, vp, h2b, q23), refs)):
+        a = a.cpu().double()
+        if k >= 2:                      # saved tensors: defined on the rows of known elements
+            a, b = a[:nk], b[:nk]
+            real = (g.row_real[:nk] != 0) if g.row_real is not None else slice(None)
+            a, b = a[real], b[real]
+        assert rel_err(a, b) < 3e-6, k
+    gx1, gvec1 = nodeops.node_update_bwd(c(gxo), c(gvo), vp, h2b, q23, wd, gd)
+    gx1_r, gvec1_r = ref_ops.node_update_bwd(d64(gxo), d64(gvo), refs[2], refs[3], refs[4], w, g)
+    assert rel_err(gx1.cpu().double(), gx1_r) < 5e-6 and rel_err(gvec1.cpu().double(), gvec1_r) < 5e-6
+    assert torch.isfinite(gx1).all() and torch.isfinite(gvec1).all()
+
+
 @pytest.mark.parametrize("H", [64, 128, 320, 1024])
 def test_layernorm_kernels(H):
     """`hermnet_layernorm_fwd/_bwd` (no affine) vs torch.native_layer_norm and its backward."""

@@ -205,7 +205,7 @@ def test_fused_layer_orchestration_matches_golden(name, monkeypatch):
     monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
     monkeypatch.setattr(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
     for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid", "update_out", "update_out_bwd",
-               "update_mid_bwd"]:
+               "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd", "node_update_bwd"]:
         monkeypatch.setattr(lmod.nodeops, fn, getattr(ref_ops, fn))
     monkeypatch.setattr(lmod, "_msg_fwd", ref_ops.msg_fwd)
     monkeypatch.setattr(lmod, "_msg_bwd", ref_ops.msg_bwd)
@@ -289,7 +289,7 @@ def test_eval_mode_parameters_are_constants_unless_asked(monkeypatch):
     monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
     monkeypatch.setattr(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
     for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid",
-               "update_out", "update_out_bwd", "update_mid_bwd"]:
+               "update_out", "update_out_bwd", "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd", "node_update_bwd"]:
         monkeypatch.setattr(lmod.nodeops, fn, getattr(ref_ops, fn))
     monkeypatch.setattr(lmod, "_msg_fwd", ref_ops.msg_fwd)
     monkeypatch.setattr(lmod, "_msg_bwd", ref_ops.msg_bwd)
@@ -326,7 +326,7 @@ def test_width_not_multiple_of_64_runs_on_zero_padded_channels(H, monkeypatch):
     monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
     monkeypatch.setattr(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
     for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid",
-               "update_out", "update_out_bwd", "update_mid_bwd"]:
+               "update_out", "update_out_bwd", "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd", "node_update_bwd"]:
         monkeypatch.setattr(lmod.nodeops, fn, getattr(ref_ops, fn))
     monkeypatch.setattr(lmod, "_msg_fwd", ref_ops.msg_fwd)
     monkeypatch.setattr(lmod, "_msg_bwd", ref_ops.msg_bwd)
@@ -343,3 +343,60 @@ def test_width_not_multiple_of_64_runs_on_zero_padded_channels(H, monkeypatch):
     e = model(d)
     f = -torch.autograd.grad(e.sum(), d.pos)[0]
     assert rel_err(e.detach(), e_ref) < 5e-6 and rel_err(f, f_ref) < 1e-5
+
+
+def _layer_weights_and_graph(H, T, counts, seed=0, unknown=3, uniform=None):
+    """LayerWeights of T randomly initialised PaiNNModules + a relation-ordered graph with `counts[t]` atoms per element."""
+    import hermnet_amd as hn
+    from hermnet_amd.layer import LayerWeights
+    from hermnet_amd.relations import RelationalGraph
+    from hermnet_amd.rmnet import PaiNNModule
+    torch.manual_seed(seed)
+    mods = [PaiNNModule(hidden_channels=H, num_rbf=16) for _ in range(T)]
+    for m in mods:
+        for p in m.parameters():
+            p.data.normal_(0, 0.3)
+    w = LayerWeights(mods).refresh()
+    zs = [13, 28, 29, 79][:T]
+    z = torch.cat([torch.full((c,), zs[t], dtype=torch.long) for t, c in enumerate(counts)] + [torch.full((unknown,), 1, dtype=torch.long)])
+    z = z[torch.randperm(z.numel())]
+    n = z.numel()
+    src = torch.randint(0, n, (4 * n,))
+    tgt = torch.randint(0, n, (4 * n,))
+    if T > 1:           # leave the last element without incoming edges: an inactive relation (hermnet.py:56-57)
+        keep = z[tgt] != zs[T - 1]
+        src, tgt = src[keep], tgt[keep]
+    g = RelationalGraph.build(z, torch.stack([src, tgt]), zs, uniform=uniform)
+    return w, g
+
+
+@pytest.mark.parametrize("H,T,counts,uniform", [(64, 3, (20, 31, 9), None), (64, 2, (40, 3), False), (128, 1, (37,), None)])
+def test_node_chain_restatements_are_consistent(H, T, counts, uniform):
+    """tests/ref_ops.py's restatements of the node chain kernels: the explicit backward formulas (what
+    csrc/node_chain.hip implements from the saved vp / h2b / q23) equal autograd of the forward formulas; the
+    fragment-ordered weights hold the same values as the plain ones."""
+    from hermnet_amd import nodeops
+    w, g = _layer_weights_and_graph(H, T, counts, uniform=uniform)
+    gen = torch.Generator().manual_seed(1)
+    N = g.N
+    x1, vec1 = torch.randn(N, H, generator=gen).double(), torch.randn(N, 3, H, generator=gen).double()
+    xo, vo, vp, h2b, q23 = ref_ops.node_update_fwd(x1, vec1, w, g)
+    act = g.row_active != 0
+    assert float(xo[~act].abs().max()) == 0.0 and float(vo[~act].abs().max()) == 0.0 and bool((~act).any())
+    gxo, gvo = torch.randn(N, H, generator=gen).double(), torch.randn(N, 3, H, generator=gen).double()
+    a = ref_ops.node_update_bwd(gxo, gvo, vp, h2b, q23, w, g)
+    b = ref_ops.node_update_bwd_from_inputs(gxo, gvo, x1, vec1, w, g)
+    assert rel_err(a[0], b[0]) < 1e-12 and rel_err(a[1], b[1]) < 1e-12
+    # pre chain: backward formulas vs autograd
+    x = torch.randn(N, H, generator=gen).double().requires_grad_(True)
+    hb, xh, mean, rstd = ref_ops.node_pre_fwd(x, w, T)
+    gxh = torch.randn(T, N, 3 * H, generator=gen).double()
+    (gx_auto,) = torch.autograd.grad(xh, x, gxh)
+    gx = ref_ops.node_pre_bwd(gxh, hb.detach(), x.detach(), mean.detach(), rstd.detach(), w)
+    assert rel_err(gx, gx_auto) < 1e-10
+    # fragment order: frag(W)[((cb * K/8 + q) * 64 + l) * 4 + e] = W[32 cb + (l & 31)][8 q + 4 (l >> 5) + e]
+    W = w.wx0_s                                                   # [T, H, 2H]
+    f = nodeops.weight_fragments(W).view(T, H // 32, 2 * H // 8, 64, 4)
+    for (t, cb, q, l, e) in [(0, 0, 0, 0, 0), (T - 1, H // 32 - 1, 2 * H // 8 - 1, 63, 3), (0, 1, 5, 37, 2)]:
+        assert float(f[t, cb, q, l, e]) == float(W[t, 32 * cb + (l & 31), 8 * q + 4 * (l >> 5) + e])
+    assert torch.equal(f.reshape(T, -1), w.wx0f)
