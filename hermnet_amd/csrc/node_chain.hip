@@ -18,12 +18,17 @@
 //     W[32 cb + (l & 31)][8q + 4 (l >> 5) .. +3], i.e. exactly the B operand registers of lane l: one coalesced 1 KiB
 //     global_load_dwordx4 per wave, straight from L2 (a layer's weights are < 1 MB) into the MFMA operand, two k-groups
 //     ahead of use.  Waves of a workgroup split the OUTPUT COLUMNS, so no weight byte is loaded twice per workgroup;
-//   * C: 32 x 32 accumulator blocks; a wave owns the same 32-channel slices of every part of an output (s|a|b, v1|v2,
-//     p|q|r), so products of parts (vec_dot, q * vdot, r * v1) are lane-local.
+//   * C: 32 x 32 accumulator blocks, TRANSPOSED (the weight fragment is the MFMA's row operand, the activation its column
+//     operand): a lane holds ONE tile row and 16 channels as four runs of 4 consecutive channels, so every epilogue
+//     access to a row-major [rows][channels] array is a 16-byte load / store at `row offset + constant` (4 per block
+//     instead of 16 dwords, one address register per array), LDS tiles are written with ds_write_b128, and per-row
+//     quantities (row flags) are per-lane.  A wave owns the same 32-channel slices of every part of an output
+//     (s|a|b, v1|v2, p|q|r), so products of parts (vec_dot, q * vdot, r * v1) are lane-local.
 // Two workgroups per CU (<= 68 KB of LDS, <= 256 VGPRs): one's elementwise / staging phases run beside the other's
 // matrix phases.  fp32 MFMA is exact fp32 (a k-ordered fmaf chain): results equal a library GEMM's to rounding.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/hermnet_hip.h"
 
 namespace {
@@ -56,8 +61,28 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// accumulator elements per epilogue batch (all global loads of a batch are requested before the first is consumed)
-constexpr int G = 4;
+// Diagnostic build (-DHN_STAMPS): wave 0 of every workgroup records the shader clock at phase boundaries into a buffer
+// of its own (tools/chain_stamps.py reads it back); no stamp executes in the product build.
+#ifdef HN_STAMPS
+__device__ unsigned long long hn_stamps[8192 * 16];
+#define STAMP_HWID()                                                                                 \
+  do {                                                                                               \
+    if (threadIdx.x == 0) {                                                                          \
+      unsigned hw, xcc;                                                                              \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                               \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                             \
+      hn_stamps[((blockIdx.x + gridDim.x * blockIdx.y) & 8191) * 16 + 15] = ((unsigned long long)xcc << 32) | hw; \
+    }                                                                                                \
+  } while (0)
+#define STAMP(k)                                                                                     \
+  do {                                                                                               \
+    if (threadIdx.x == 0)                                                                            \
+      hn_stamps[((blockIdx.x + gridDim.x * blockIdx.y) & 8191) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define STAMP(k)
+#define STAMP_HWID()
+#endif
 
 // Geometry of a TR-row tile of width H on a 256-thread workgroup (4 waves).
 template <int H_, int TR_>
@@ -73,38 +98,49 @@ struct Cfg {
   static_assert(CB % WC == 0 && (TR / 32) % WR == 0 && RB >= 1 && F4 >= 1, "unsupported tile");
 };
 
-// ---- B operand: a ring of weight fragments, PF = 2 k-groups ahead ------------------------------------------------
+// ---- B operand: a ring of RS weight fragments per column block, RS - 1 k-groups ahead of use -------------------------
+// One wave per SIMD has nobody to hide a late operand: a k-group is RB * NJ * 4 MFMAs = RB * NJ * 256 cycles, an L2 hit
+// under load 500-800: three groups ahead.
 template <int NJ, int RS>
 struct BRing { f32x4 v[RS][NJ]; };
 
-// first two k-groups of a stream (call it early: before the barrier / epilogue that precedes the product)
+// ring slots of a product with RB x NJ accumulator blocks per wave
+constexpr int ring_size(int rb_nj, bool more) { return 4; }
+
+// first RS - 1 k-groups of a stream (call it early: before the barrier / epilogue that precedes the product)
 template <int NJ, int RS>
 __device__ __forceinline__ void b_preload(BRing<NJ, RS>& r, const f32x4* const (&bp)[NJ]) {
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) { r.v[0][j] = bp[j][0]; r.v[1][j] = bp[j][64]; }
+  for (int g = 0; g < RS - 1; ++g)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) r.v[g][j] = bp[j][g * 64];
 }
 
-// acc[rb][j] += A[rows of block rb][k-groups 0 .. KP/8) . W_j, W_j streamed from bp[j] (this lane's pointer at group 0
+// acc[rb][j] += W_j[k-groups 0 .. KP/8) . A[rows of block rb]^T, W_j streamed from bp[j] (this lane's pointer at group 0
 // of the panel).  `As`: this lane's LDS read pointer, &tile[(first row of the wave + (l & 31)) * LD + 4 (l >> 5)].
-// The ring holds groups 0 and 1 on entry.  MORE: the stream continues behind this panel (next panel of the same
-// product): groups KP/8 and KP/8 + 1 are requested too and sit in slots 0 and 1 on exit (needs KP/8 % RS == 0).
+// The ring holds groups 0 .. RS-2 on entry.  MORE: the stream continues behind this panel (next panel of the same
+// product): its first RS - 1 groups are requested too and sit in slots 0 .. RS-2 on exit (needs KP/8 % RS == 0).
 template <int KP, int LD, int RB, int NJ, int RS, bool MORE>
 __device__ __forceinline__ void mma_panel(f32x16 (&acc)[RB][NJ], const float* As, const f32x4* const (&bp)[NJ],
                                           BRing<NJ, RS>& ring) {
-  constexpr int NQ = KP / 8;
-  static_assert(NQ >= 2 && (!MORE || NQ % RS == 0), "panel / ring mismatch");
-  f32x4 a[2][RB];
+  constexpr int NQ = KP / 8, PF = RS - 1;
+  static_assert(NQ % RS == 0 && RS % 2 == 0, "panel / ring mismatch");
+  f32x4 a[2][RB];                                       // LDS reads one k-group ahead
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(As + rb * 32 * LD);
+  // One k-group: request the weight group PF ahead and the tile group 1 ahead, then RB x NJ x 4 MFMAs.  The groups
+  // run RS at a time in a ROLLED loop (ring slots are then compile-time constants): a fully unrolled chain kernel is
+  // 50-60 KB of code -- more than the instruction cache -- and hipcc's scheduler, handed a whole panel as one region,
+  // spills what the caller keeps in flight around the product.
+  auto group = [&](int q0, int qq, bool load_b, bool load_a) {
+    const int q = q0 + qq;
+    if (load_b) {
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    if (MORE || q + 2 < NQ) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) ring.v[(q + 2) % RS][j] = bp[j][(q + 2) * 64];
+      for (int j = 0; j < NJ; ++j) ring.v[(qq + PF) % RS][j] = bp[j][(q + PF) * 64];
     }
-    if (q + 1 < NQ) {
+    if (load_a) {
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) a[(q + 1) & 1][rb] = *reinterpret_cast<const f32x4*>(As + rb * 32 * LD + 8 * (q + 1));
+      for (int rb = 0; rb < RB; ++rb) a[(qq + 1) & 1][rb] = *reinterpret_cast<const f32x4*>(As + rb * 32 * LD + 8 * (q + 1));
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -112,8 +148,15 @@ __device__ __forceinline__ void mma_panel(f32x16 (&acc)[RB][NJ], const float* As
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][rb][i], ring.v[q % RS][j][i], acc[rb][j], 0, 0, 0);
+          acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring.v[qq % RS][j][i], a[qq & 1][rb][i], acc[rb][j], 0, 0, 0);
+  };
+#pragma unroll 1
+  for (int q0 = 0; q0 < NQ - RS; q0 += RS) {
+#pragma unroll
+    for (int qq = 0; qq < RS; ++qq) group(q0, qq, true, true);
   }
+#pragma unroll
+  for (int qq = 0; qq < RS; ++qq) group(NQ - RS, qq, MORE || qq + PF < RS, qq + 1 < RS);
 }
 
 template <int RB, int NJ>
@@ -135,21 +178,81 @@ __device__ __forceinline__ rsrc_t tile_rsrc(const float* base, int valid_floats)
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, valid_floats > 0 ? valid_floats * 4 : 0, 0x00020000);
 }
 __device__ __forceinline__ float bld(rsrc_t r, int off) {
+#ifdef HN_KO_LOADS     // diagnostic build: no epilogue / staging loads (results wrong, time meaningful)
+  return 1.0f;
+#endif
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off * 4, 0, 0));
 }
 __device__ __forceinline__ void bst(rsrc_t r, int off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off * 4, 0, 0);
 }
+#ifdef HN_KO_STORES    // diagnostic build: a store only when the value is NaN-patterned (never), so the work stays live
+#define HN_STORE_IF(v) if (__builtin_expect((v)[0] == 1.2345e-30f, 0))
+#else
+#define HN_STORE_IF(v)
+#endif
 __device__ __forceinline__ f32x4 bld4(rsrc_t r, int off) {
+#ifdef HN_KO_LOADS
+  return (f32x4){1.f, 0.5f, 0.25f, 2.f};
+#endif
   const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, off * 4, 0, 0);
   return __builtin_bit_cast(f32x4, u);
 }
 __device__ __forceinline__ void bst4(rsrc_t r, int off, f32x4 v) {
+  HN_STORE_IF(v)
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off * 4, 0, 0);
 }
 
-// accumulator element i of a 32 x 32 block: row offset inside the block
-__device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+// Coalesced store of one 32 x 32 accumulator block through a wave-private LDS transpose.  A lane owns a ROW of the
+// block: stored straight from the registers, one instruction would write 64 16-byte pieces into 32 different rows
+// (measured: ~750 cycles per instruction, 5 B/clk/CU -- the epilogues took as long as the products).  Instead the four
+// runs go to this wave's scratch [32][36] (ds_write_b128, lane = row) and come back as 4 x (8 rows x 128 contiguous
+// bytes): the same number of store instructions, each writing whole 128-byte lines.  LDS operations of one wave execute
+// in order, so no barrier or wait is needed between the two halves.  `off_block`: float offset of the block's first
+// row / first channel in the destination, LDG its row stride.
+constexpr int kScrLd = 36, kScrFloats = 32 * kScrLd;
+template <int LDG>
+__device__ __forceinline__ void store_block(float* scr, int lane, const f32x4 (&v)[4], rsrc_t r, int off_block) {
+  const int m = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(scr + m * kScrLd + 8 * g + 4 * h) = v[g];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int rr = it * 8 + (lane >> 3), c = (lane & 7) * 4;
+    bst4(r, off_block + rr * LDG + c, *reinterpret_cast<const f32x4*>(scr + rr * kScrLd + c));
+  }
+}
+
+// The same for loads, in two steps so that the memory round trip hides behind a product: `issue` requests the block as
+// 4 x (8 rows x 128 contiguous bytes) into registers, `finish` (any time later) passes it through the scratch and
+// returns the four runs of this lane's row.
+struct BlockLoad { f32x4 v[4]; };
+template <int LDG>
+__device__ __forceinline__ void issue_block(BlockLoad& b, int lane, rsrc_t r, int off_block) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) b.v[it] = bld4(r, off_block + (it * 8 + (lane >> 3)) * LDG + (lane & 7) * 4);
+}
+__device__ __forceinline__ void finish_block(float* scr, int lane, const BlockLoad& b, f32x4 (&out)[4]) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+    *reinterpret_cast<f32x4*>(scr + (it * 8 + (lane >> 3)) * kScrLd + (lane & 7) * 4) = b.v[it];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    out[g] = *reinterpret_cast<const f32x4*>(scr + (lane & 31) * kScrLd + 8 * g + 4 * (lane >> 5));
+}
+
+// Accumulator block (rb, cb) of D^T = W . A^T: lane l holds tile row  (first row of the wave) + 32 rb + (l & 31)  and the
+// channels  32 cb + 8 g + 4 (l >> 5) + e  in register 4 g + e  (g, e < 4): run g of the block as one float4.
+__device__ __forceinline__ f32x4 run4(const f32x16& acc, int g) {
+  return (f32x4){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+}
+__device__ __forceinline__ void set_run4(f32x16& acc, int g, f32x4 v) {
+  acc[4 * g] = v[0]; acc[4 * g + 1] = v[1]; acc[4 * g + 2] = v[2]; acc[4 * g + 3] = v[3];
+}
+__device__ __forceinline__ f32x4 ssilu4(f32x4 v) { return (f32x4){ssilu(v[0]), ssilu(v[1]), ssilu(v[2]), ssilu(v[3])}; }
+__device__ __forceinline__ f32x4 dssilu4(f32x4 v) { return (f32x4){dssilu(v[0]), dssilu(v[1]), dssilu(v[2]), dssilu(v[3])}; }
+__device__ __forceinline__ f32x4 ld4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void pin4(f32x4& v) { asm volatile("" : "+v"(v)); }
 
 // cooperative copy of a [TR][W] tile (row stride `ld_src` floats in global memory) through registers
 template <int TR, int W>
@@ -196,11 +299,13 @@ template <int H, int TR>
 __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
   using C = Cfg<H, TR>;
   constexpr int LD = C::LD, RB = C::RB, CPW = C::CPW, CB = C::CB;
-  extern __shared__ __align__(16) float tile[];           // [TR][LD]
+  extern __shared__ __align__(16) float tile[];           // [TR][LD], then 4 x [32][36] store scratch
   const int t = blockIdx.y, row0 = blockIdx.x * TR;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave % C::WC, wr = wave / C::WC;
+  float* scr = tile + TR * LD + wave * kScrFloats;
   const int nrows = min(TR, a.Ns - row0);
+  const rsrc_t x_r = tile_rsrc(a.x + (size_t)row0 * H, nrows * H);
   const rsrc_t hb_r = tile_rsrc(a.hb + ((size_t)t * a.Ns + row0) * H, nrows * H);
   const rsrc_t xh_r = tile_rsrc(a.xh + ((size_t)t * a.Ns + row0) * 3 * H, nrows * 3 * H);
 
@@ -215,81 +320,106 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
   for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int j = 0; j < CPW; ++j) bp2[p * CPW + j] = w2 + (size_t)(p * CB + wc * CPW + j) * (H / 8) * 64;
-  BRing<CPW, 3> r1;
+  BRing<CPW, ring_size(RB * CPW, false)> r1;
   b_preload(r1, bp1);
+  STAMP(0);
+  STAMP_HWID();
 
-  // ---- LayerNorm without affine (rmnet.py:52), a wave per row, statistics over the first Hr channels
-  constexpr int EPL = H / 64;
-  const float inv_hr = 1.0f / (float)a.Hr;
-#pragma unroll 4
-  for (int i = 0; i < TR / 4; ++i) {
-    const int lr = wave * (TR / 4) + i, row = row0 + lr;
-    float v[EPL], m[EPL];
+  // ---- LayerNorm without affine (rmnet.py:52): TPR adjacent lanes share a row (its float4s dealt round-robin, so a
+  // load instruction reads 16 TPR contiguous bytes per row); statistics over the first Hr channels, two passes in
+  // registers, the cross-lane sums are two or three DPP steps
+  {
+    constexpr int TPR = 256 / TR, NF = H / 4 / TPR;
+    const int lr = tid / TPR, q = tid % TPR;
+    f32x4 v[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) v[k] = bld4(x_r, lr * H + (k * TPR + q) * 4);
     float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      const int c = lane * EPL + e;
-      m[e] = c < a.Hr ? 1.f : 0.f;
-      v[e] = row < a.Ns ? a.x[(size_t)row * H + c] * m[e] : 0.f;
-      s += v[e];
-    }
-    const float mu = wave_sum(s) * inv_hr;
-    float q = 0.f;
+    for (int k = 0; k < NF; ++k)
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) { v[e] = (v[e] - mu) * m[e]; q = fmaf(v[e], v[e], q); }
-    const float rs = rsqrtf(wave_sum(q) * inv_hr + a.eps);
+      for (int e = 0; e < 4; ++e) {
+        if ((k * TPR + q) * 4 + e >= a.Hr) v[k][e] = 0.f;
+        s += v[k][e];
+      }
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) tile[lr * LD + lane * EPL + e] = v[e] * rs;
-    if (t == 0 && lane == 0 && row < a.Ns) { a.mean[row] = mu; a.rstd[row] = rs; }
+    for (int m = 1; m < TPR; m <<= 1) s += __shfl_xor(s, m, 64);
+    const float mu = s / (float)a.Hr;
+    float qq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NF; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[k][e] = (k * TPR + q) * 4 + e < a.Hr ? v[k][e] - mu : 0.f;
+        qq = fmaf(v[k][e], v[k][e], qq);
+      }
+#pragma unroll
+    for (int m = 1; m < TPR; m <<= 1) qq += __shfl_xor(qq, m, 64);
+    const float rs = rsqrtf(qq / (float)a.Hr + a.eps);
+#pragma unroll
+    for (int k = 0; k < NF; ++k) *reinterpret_cast<f32x4*>(tile + lr * LD + (k * TPR + q) * 4) = v[k] * rs;
+    if (t == 0 && q == 0 && lr < nrows) { a.mean[row0 + lr] = mu; a.rstd[row0 + lr] = rs; }
   }
+  STAMP(1);
   __syncthreads();
+  STAMP(2);
 
   // ---- h = n W1^T
-  const float* As = tile + (wr * RB * 32 + (lane & 31)) * LD + 4 * (lane >> 5);
+  const int mrow = wr * RB * 32 + (lane & 31), ch = 4 * (lane >> 5);
+  const float* As = tile + mrow * LD + ch;
   f32x16 acc1[RB][CPW];
   zero_acc(acc1);
-  mma_panel<H, LD, RB, CPW, 3, false>(acc1, As, bp1, r1);
-  BRing<3 * CPW, 3> r2;
+  mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, false), false>(acc1, As, bp1, r1);
+  STAMP(3);
+  BRing<3 * CPW, ring_size(RB * 3 * CPW, false)> r2;
   b_preload(r2, bp2);
   __syncthreads();                                   // every wave has read n
+  STAMP(4);
   // ---- + b1, save, ScaledSiLU -> the tile becomes the A operand of the second product
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
-      const int col = (wc * CPW + j) * 32 + (lane & 31);
-      const float bias = a.b1[(size_t)t * H + col];
+      f32x4 hv[4];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int lr = (wr * RB + rb) * 32 + acc_row(i, lane);
-        const float hv = acc1[rb][j][i] + bias;
-        bst(hb_r, lr * H + col, hv);
-        tile[lr * LD + col] = ssilu(hv);
+      for (int g = 0; g < 4; ++g) {
+        const int lr = mrow + rb * 32, c0 = (wc * CPW + j) * 32 + 8 * g + ch;
+        hv[g] = run4(acc1[rb][j], g) + ld4g(a.b1 + (size_t)t * H + c0);
+        *reinterpret_cast<f32x4*>(tile + lr * LD + c0) = ssilu4(hv[g]);
       }
+      store_block<H>(scr, lane, hv, hb_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
     }
+  STAMP(5);
   __syncthreads();
+  STAMP(6);
   // ---- xh = a W2^T + b2
   f32x16 acc2[RB][3 * CPW];
   zero_acc(acc2);
-  mma_panel<H, LD, RB, 3 * CPW, 3, false>(acc2, As, bp2, r2);
+  mma_panel<H, LD, RB, 3 * CPW, ring_size(RB * 3 * CPW, false), false>(acc2, As, bp2, r2);
+  STAMP(7);
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int jj = 0; jj < 3 * CPW; ++jj) {
-      const int col = (jj / CPW) * H + (wc * CPW + jj % CPW) * 32 + (lane & 31);
-      const float bias = a.b2[(size_t)t * 3 * H + col];
+      const int cblk = (jj / CPW) * H + (wc * CPW + jj % CPW) * 32;
+      f32x4 v[4];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int lr = (wr * RB + rb) * 32 + acc_row(i, lane);
-        bst(xh_r, lr * 3 * H + col, acc2[rb][jj][i] + bias);
-      }
+      for (int g = 0; g < 4; ++g) v[g] = run4(acc2[rb][jj], g) + ld4g(a.b2 + (size_t)t * 3 * H + cblk + 8 * g + ch);
+      store_block<3 * H>(scr, lane, v, xh_r, (wr * RB + rb) * 32 * 3 * H + cblk);
     }
+  STAMP(8);
 }
 
 // =====================================================================================================================
 // node_pre_bwd: one workgroup = (TR source rows, relation t) -> gn[t] (the sum over t and the LayerNorm backward follow
 // in layernorm_bwd_parts_kernel)
 // =====================================================================================================================
+// LDS floats of node_pre_bwd: two K-chunk buffers, later the gh tile + the store scratch in the same space
+constexpr int pre_bwd_lds_floats(int H, int TR) {
+  const int kc = H < 128 ? H : 128, chunks = 2 * TR * (kc + 4), tail = TR * (H + 4) + 4 * kScrFloats;
+  return chunks > tail ? chunks : tail;
+}
+
 struct PreBwdArgs {
   const float* gxh;    // [T, Ns, 3H]
   const float* hb;     // [T, Ns, H]
@@ -305,12 +435,14 @@ __global__ __launch_bounds__(256, 2) void node_pre_bwd_kernel(PreBwdArgs a) {
   constexpr int LD = C::LD, RB = C::RB, CPW = C::CPW;
   constexpr int KC = H < 128 ? H : 128;            // K chunk of the first product (K = 3H)
   constexpr int NCH = 3 * H / KC, LDC = KC + 4;
-  static_assert(2 * TR * LDC >= TR * LD, "the gh tile must fit the two chunk buffers");
-  extern __shared__ __align__(16) float lds[];            // 2 x [TR][LDC]
+  static_assert(2 * TR * LDC >= TR * LD, "the gh tile must fit the two chunk buffers");   // (+ scratch: pre_bwd_lds_floats)
+  extern __shared__ __align__(16) float lds[];            // 2 x [TR][LDC], then 4 x [32][36] store scratch
   const int t = blockIdx.y, row0 = blockIdx.x * TR;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave % C::WC, wr = wave / C::WC;
+  float* scr = lds + TR * LD + wave * kScrFloats;     // the chunk buffers' upper part: free once the gh tile is written
   const int nrows = min(TR, a.Ns - row0);
+  const int mrow = wr * RB * 32 + (lane & 31), ch = 4 * (lane >> 5);
 
   const f32x4* w2t = reinterpret_cast<const f32x4*>(a.w2tf + (size_t)t * 3 * H * H) + lane;
   const f32x4* w1t = reinterpret_cast<const f32x4*>(a.w1tf + (size_t)t * H * H) + lane;
@@ -321,26 +453,19 @@ __global__ __launch_bounds__(256, 2) void node_pre_bwd_kernel(PreBwdArgs a) {
     bpa[j] = w2t + (size_t)(wc * CPW + j) * (3 * H / 8) * 64;
     bpb[j] = w1t + (size_t)(wc * CPW + j) * (H / 8) * 64;
   }
-  BRing<CPW, 4> ra;
+  BRing<CPW, ring_size(RB * CPW, true)> ra;
   b_preload(ra, bpa);
   const rsrc_t gxh_r = tile_rsrc(a.gxh + ((size_t)t * a.Ns + row0) * 3 * H, nrows * 3 * H);
   const rsrc_t hb_r = tile_rsrc(a.hb + ((size_t)t * a.Ns + row0) * H, nrows * H);
   const rsrc_t gn_r = tile_rsrc(a.gn + ((size_t)t * a.Ns + row0) * H, nrows * H);
   TileRegs<TR, KC> regs;
   tile_load<TR, KC>(regs, gxh_r, 3 * H, 0, tid);
-  // ScaledSiLU'(hb) of this lane's accumulator positions, requested now
-  float dact[RB][CPW][16];
+  // hb of this wave's accumulator blocks, requested now (coalesced), transposed behind the first product
+  BlockLoad lhb[RB][CPW];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int j = 0; j < CPW; ++j) {
-      const int col = (wc * CPW + j) * 32 + (lane & 31);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int lr = (wr * RB + rb) * 32 + acc_row(i, lane);
-        dact[rb][j][i] = bld(hb_r, lr * H + col);
-      }
-    }
+    for (int j = 0; j < CPW; ++j) issue_block<H>(lhb[rb][j], lane, hb_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
 
   // ---- ga = gxh W2   (K = 3H in chunks, double-buffered through registers)
   f32x16 acc[RB][CPW];
@@ -351,14 +476,14 @@ __global__ __launch_bounds__(256, 2) void node_pre_bwd_kernel(PreBwdArgs a) {
     tile_store<TR, KC, LDC>(buf, regs, tid);
     __syncthreads();
     if (kc + 1 < NCH) tile_load<TR, KC>(regs, gxh_r, 3 * H, (kc + 1) * KC, tid);
-    const float* As = buf + (wr * RB * 32 + (lane & 31)) * LDC + 4 * (lane >> 5);
+    const float* As = buf + mrow * LDC + ch;
     const f32x4* bpk[CPW];
 #pragma unroll
     for (int j = 0; j < CPW; ++j) bpk[j] = bpa[j] + (size_t)kc * (KC / 8) * 64;
-    if (kc + 1 < NCH) mma_panel<KC, LDC, RB, CPW, 4, true>(acc, As, bpk, ra);
-    else mma_panel<KC, LDC, RB, CPW, 4, false>(acc, As, bpk, ra);
+    if (kc + 1 < NCH) mma_panel<KC, LDC, RB, CPW, ring_size(RB * CPW, true), true>(acc, As, bpk, ra);
+    else mma_panel<KC, LDC, RB, CPW, ring_size(RB * CPW, true), false>(acc, As, bpk, ra);
   }
-  BRing<CPW, 3> rb_;
+  BRing<CPW, ring_size(RB * CPW, false)> rb_;
   b_preload(rb_, bpb);
   __syncthreads();                                   // the chunk buffers are free
   // ---- gh = ga * ScaledSiLU'(hb) -> tile
@@ -367,29 +492,24 @@ __global__ __launch_bounds__(256, 2) void node_pre_bwd_kernel(PreBwdArgs a) {
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
-      const int col = (wc * CPW + j) * 32 + (lane & 31);
+      f32x4 hbv[4];
+      finish_block(scr, lane, lhb[rb][j], hbv);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int lr = (wr * RB + rb) * 32 + acc_row(i, lane);
-        tile[lr * LD + col] = acc[rb][j][i] * dssilu(dact[rb][j][i]);
-      }
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(tile + (mrow + rb * 32) * LD + (wc * CPW + j) * 32 + 8 * g + ch) =
+            run4(acc[rb][j], g) * dssilu4(hbv[g]);
     }
   __syncthreads();
   // ---- gn_t = gh W1
   f32x16 acc2[RB][CPW];
   zero_acc(acc2);
-  const float* As = tile + (wr * RB * 32 + (lane & 31)) * LD + 4 * (lane >> 5);
-  mma_panel<H, LD, RB, CPW, 3, false>(acc2, As, bpb, rb_);
+  mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, false), false>(acc2, tile + mrow * LD + ch, bpb, rb_);
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
-      const int col = (wc * CPW + j) * 32 + (lane & 31);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int lr = (wr * RB + rb) * 32 + acc_row(i, lane);
-        bst(gn_r, lr * H + col, acc2[rb][j][i]);
-      }
+      const f32x4 v[4] = {run4(acc2[rb][j], 0), run4(acc2[rb][j], 1), run4(acc2[rb][j], 2), run4(acc2[rb][j], 3)};
+      store_block<H>(scr, lane, v, gn_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
     }
 }
 
@@ -474,6 +594,7 @@ struct UpdFwdArgs {
   float* vp;                // [N, 3, 2H]  (v1 | v2), saved
   float* h2b;               // [N, H]      xvec_proj[0] output incl. bias, saved
   float* q23;               // [N, 2H]     (q | r) incl. bias, saved
+  float* nrm;               // [N, H]      sqrt(sum_d v2^2 + 1e-8), saved
   float* x_out;             // [N, H]
   float* vec_out;           // [N, 3, H]
   int N, T;
@@ -483,9 +604,10 @@ template <int H, int TR, int MINW>
 __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a) {
   using C = Cfg<H, TR>;
   constexpr int LD = C::LD, RB = C::RB, CPW = C::CPW, CB = C::CB;
-  extern __shared__ __align__(16) float lds[];            // 2 x [TR][LD]
+  extern __shared__ __align__(16) float lds[];            // 2 x [TR][LD], then 4 x [32][36] store scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave % C::WC, wr = wave / C::WC;
+  float* scr = lds + 2 * TR * LD + wave * kScrFloats;
   const TileInfo ti = find_tile(a.type_rowptr, a.T, a.N, TR, blockIdx.x);
   const int row0 = ti.row0, nrows = ti.nrows, t = ti.t;
   if (t >= a.T) {                                 // rows of unknown elements: zero
@@ -516,8 +638,7 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
 #pragma unroll
     for (int j = 0; j < CPW; ++j) bpq[p * CPW + j] = wx2 + (size_t)(p * CB + wc * CPW + j) * (H / 8) * 64;
 
-  const int lrow = wr * RB * 32 + (lane & 31);
-  // uniform bases of this tile's rows: every per-lane address below is base + a 32-bit offset inside the tile
+  const int mrow = wr * RB * 32 + (lane & 31), ch = 4 * (lane >> 5);
   const rsrc_t x1_r = tile_rsrc(a.x1 + (size_t)row0 * H, nrows * H);
   const rsrc_t vec1_r = tile_rsrc(a.vec1 + (size_t)row0 * 3 * H, nrows * 3 * H);
   const rsrc_t act_r = tile_rsrc(a.row_active ? a.row_active + row0 : a.x1, a.row_active ? nrows : 0);
@@ -527,64 +648,81 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
   const rsrc_t q23_r = tile_rsrc(a.q23 + (size_t)row0 * 2 * H, nrows * 2 * H);
   const rsrc_t xo_r = tile_rsrc(a.x_out + (size_t)row0 * H, nrows * H);
   const rsrc_t vo_r = tile_rsrc(a.vec_out + (size_t)row0 * 3 * H, nrows * 3 * H);
-  float dot[RB][CPW][16], sq[RB][CPW][16];
+  const rsrc_t nrm_r = tile_rsrc(a.nrm + (size_t)row0 * H, nrows * H);
+  f32x4 dot[RB][CPW][4], sq[RB][CPW][4], kv1[RB][CPW][4][3];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int j = 0; j < CPW; ++j)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) dot[rb][j][i] = sq[rb][j][i] = 0.f;
+      for (int g = 0; g < 4; ++g) dot[rb][j][g] = sq[rb][j][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- vp[d] = vec1[d] Wv^T for the three Cartesian components; vec_dot and |v2|^2 accumulate in registers
+  // (every weight ring is requested BEFORE the stores of the epilogue in front of its product: vmcnt retires in order,
+  // so a fragment requested behind a store would make the product's first MFMA wait for the store to drain)
+  STAMP(0);
+  STAMP_HWID();
   TileRegs<TR, H> regs;
   tile_load<TR, H>(regs, vec1_r, 3 * H, 0, tid);
+  BRing<2 * CPW, ring_size(RB * 2 * CPW, false)> rv;
+  BRing<CPW, ring_size(RB * CPW, true)> rx;
+  b_preload(rv, bpv);
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     float* buf = lds + (d & 1) * TR * LD;
     tile_store<TR, H, LD>(buf, regs, tid);
-    BRing<2 * CPW, 3> rv;
-    b_preload(rv, bpv);
     __syncthreads();
+    STAMP(1 + 3 * d);
     if (d < 2) tile_load<TR, H>(regs, vec1_r, 3 * H, (d + 1) * H, tid);
     else tile_load<TR, H>(regs, x1_r, H, 0, tid);
     f32x16 accv[RB][2 * CPW];
     zero_acc(accv);
-    mma_panel<H, LD, RB, 2 * CPW, 3, false>(accv, buf + lrow * LD + 4 * (lane >> 5), bpv, rv);
+    mma_panel<H, LD, RB, 2 * CPW, ring_size(RB * 2 * CPW, false), false>(accv, buf + mrow * LD + ch, bpv, rv);
+    STAMP(2 + 3 * d);
+    if (d < 2) b_preload(rv, bpv);
+    else b_preload(rx, bpx);
+    fence_sched();
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int j = 0; j < CPW; ++j) {
-        const int col = (wc * CPW + j) * 32 + (lane & 31);
+        f32x4 v1[4], v2[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if ((i & 7) == 0) fence_sched();
-          const int lr = (wr * RB + rb) * 32 + acc_row(i, lane);
-          const float v1 = accv[rb][j][i], v2 = accv[rb][CPW + j][i];
-          dot[rb][j][i] = fmaf(v1, v2, dot[rb][j][i]);
-          sq[rb][j][i] = fmaf(v2, v2, sq[rb][j][i]);
-          pin(dot[rb][j][i]);
-          pin(sq[rb][j][i]);
-          bst(vp_r, (lr * 3 + d) * 2 * H + col, v1);
-          bst(vp_r, (lr * 3 + d) * 2 * H + H + col, v2);
+        for (int g = 0; g < 4; ++g) {
+          v1[g] = run4(accv[rb][j], g);
+          v2[g] = run4(accv[rb][CPW + j], g);
+          kv1[rb][j][g][d] = v1[g];                  // stays in registers for dvec = r v1
+          dot[rb][j][g] += v1[g] * v2[g];
+          sq[rb][j][g] += v2[g] * v2[g];
+          pin4(dot[rb][j][g]);
+          pin4(sq[rb][j][g]);
         }
+        const int ob = ((wr * RB + rb) * 32 * 3 + d) * 2 * H + (wc * CPW + j) * 32;
+        store_block<6 * H>(scr, lane, v1, vp_r, ob);
+        store_block<6 * H>(scr, lane, v2, vp_r, ob + H);
       }
+    STAMP(3 + 3 * d);
   }
   // ---- xin = [x1 | sqrt(|v2|^2 + 1e-8)]: x1 -> buffer 1 (free since the product of d = 1), the norm -> buffer 0
   float* bufx = lds + TR * LD;
   float* bufn = lds;
   tile_store<TR, H, LD>(bufx, regs, tid);
-  BRing<CPW, 4> rx;
-  b_preload(rx, bpx);
   __syncthreads();                                   // every wave has finished the product of d = 2 (buffer 0)
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
-      const int col = (wc * CPW + j) * 32 + (lane & 31);
+      f32x4 nv[4];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) bufn[((wr * RB + rb) * 32 + acc_row(i, lane)) * LD + col] = sqrtf(sq[rb][j][i] + 1e-8f);
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 s2 = sq[rb][j][g] + 1e-8f;
+        nv[g] = (f32x4){sqrtf(s2[0]), sqrtf(s2[1]), sqrtf(s2[2]), sqrtf(s2[3])};
+        *reinterpret_cast<f32x4*>(bufn + (mrow + rb * 32) * LD + (wc * CPW + j) * 32 + 8 * g + ch) = nv[g];
+      }
+      store_block<H>(scr, lane, nv, nrm_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
     }
   __syncthreads();
+  STAMP(10);
   // ---- h2 = xin Wx0^T + bx0 (K = 2H: two panels)
   f32x16 acch[RB][CPW];
   zero_acc(acch);
@@ -592,71 +730,79 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
     const f32x4* bpx1[CPW];
 #pragma unroll
     for (int j = 0; j < CPW; ++j) bpx1[j] = bpx[j] + (size_t)(H / 8) * 64;
-    mma_panel<H, LD, RB, CPW, 4, true>(acch, bufx + lrow * LD + 4 * (lane >> 5), bpx, rx);
-    mma_panel<H, LD, RB, CPW, 4, false>(acch, bufn + lrow * LD + 4 * (lane >> 5), bpx1, rx);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true>(acch, bufx + mrow * LD + ch, bpx, rx);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), false>(acch, bufn + mrow * LD + ch, bpx1, rx);
   }
-  BRing<3 * CPW, 3> rq;
+  STAMP(11);
+  BRing<3 * CPW, ring_size(RB * 3 * CPW, false)> rq;
   b_preload(rq, bpq);
-  __syncthreads();                                   // both buffers are free
+  __syncthreads();                                   // both buffers are free (x1 is re-read from memory below)
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
-      const int col = (wc * CPW + j) * 32 + (lane & 31);
-      const float bias = a.bx0[(size_t)t * H + col];
+      f32x4 hv[4];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int lr = (wr * RB + rb) * 32 + acc_row(i, lane);
-        const float hv = acch[rb][j][i] + bias;
-        bst(h2b_r, lr * H + col, hv);
-        lds[lr * LD + col] = ssilu(hv);
+      for (int g = 0; g < 4; ++g) {
+        const int lr = mrow + rb * 32, c0 = (wc * CPW + j) * 32 + 8 * g + ch;
+        hv[g] = run4(acch[rb][j], g) + ld4g(a.bx0 + (size_t)t * H + c0);
+        *reinterpret_cast<f32x4*>(lds + lr * LD + c0) = ssilu4(hv[g]);
       }
+      store_block<H>(scr, lane, hv, h2b_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
     }
   __syncthreads();
-  // ---- (p | q | r) = a2 Wx2^T + bx2, then the update and the residual
+  // ---- (p | q | r) = a2 Wx2^T + bx2, then the update and the residual.  Of the epilogue's inputs, v1 is still in
+  // registers, x1 still in buffer 1; vec1 is requested BEFORE the product (coalesced) and transposed behind it.
+  BlockLoad lvv[RB][CPW][3];
+  float pon[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    pon[rb] = bld(act_r, mrow + rb * 32);
+#pragma unroll
+    for (int j = 0; j < CPW; ++j)
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        issue_block<3 * H>(lvv[rb][j][d], lane, vec1_r, ((wr * RB + rb) * 32 * 3 + d) * H + (wc * CPW + j) * 32);
+  }
+  fence_sched();
+  STAMP(12);
   f32x16 accq[RB][3 * CPW];
   zero_acc(accq);
-  mma_panel<H, LD, RB, 3 * CPW, 3, false>(accq, lds + lrow * LD + 4 * (lane >> 5), bpq, rq);
+  mma_panel<H, LD, RB, 3 * CPW, ring_size(RB * 3 * CPW, false), false>(accq, lds + mrow * LD + ch, bpq, rq);
+  STAMP(13);
+  fence_sched();
   const float inv_sqrt_h = rsqrtf((float)H);
-  // Batches of G accumulator elements: all loads of a batch are requested, then consumed (one L2 round trip per batch
-  // instead of one per element); the scheduling barriers keep hipcc from pulling later batches' loads in front.
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
+  for (int rb = 0; rb < RB; ++rb) {
+    const float on = (all_on | (pon[rb] != 0.f)) ? 1.f : 0.f;
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
-      const int col = (wc * CPW + j) * 32 + (lane & 31);
-      const float bp_ = a.bx2[(size_t)t * 3 * H + col], bq_ = a.bx2[(size_t)t * 3 * H + H + col],
-                  br_ = a.bx2[(size_t)t * 3 * H + 2 * H + col];
+      f32x4 q[4], r[4], xo[4];
 #pragma unroll
-      for (int g = 0; g < 16 / G; ++g) {
-        fence_sched();
-        float v1[G][3], vv[G][3], onf[G];
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = (wc * CPW + j) * 32 + 8 * g + ch;
+        const float* bb = a.bx2 + (size_t)t * 3 * H + c0;
+        const f32x4 p = run4(accq[rb][j], g) + ld4g(bb);
+        q[g] = run4(accq[rb][CPW + j], g) + ld4g(bb + H);
+        r[g] = run4(accq[rb][2 * CPW + j], g) + ld4g(bb + 2 * H);
+        const f32x4 x1v = *reinterpret_cast<const f32x4*>(bufx + (mrow + rb * 32) * LD + c0);
+        xo[g] = (x1v + (p + q[g] * dot[rb][j][g] * inv_sqrt_h) * kInvSqrt2) * on;
+      }
+      const int rblk = (wr * RB + rb) * 32, cblk = (wc * CPW + j) * 32;
+      store_block<2 * H>(scr, lane, q, q23_r, rblk * 2 * H + cblk);
+      store_block<2 * H>(scr, lane, r, q23_r, rblk * 2 * H + H + cblk);
+      store_block<H>(scr, lane, xo, xo_r, rblk * H + cblk);
 #pragma unroll
-        for (int e = 0; e < G; ++e) {
-          const int lr = (wr * RB + rb) * 32 + acc_row(G * g + e, lane);
-          onf[e] = bld(act_r, lr);
+      for (int d = 0; d < 3; ++d) {
+        f32x4 vo[4];
+        finish_block(scr, lane, lvv[rb][j][d], vo);          // vec1[d] of this lane's row
 #pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            v1[e][d] = bld(vp_r, (lr * 3 + d) * 2 * H + col);
-            vv[e][d] = bld(vec1_r, (lr * 3 + d) * H + col);
-          }
-        }
-        fence_sched();
-#pragma unroll
-        for (int e = 0; e < G; ++e) {
-          const int i = G * g + e;
-          const int lr = (wr * RB + rb) * 32 + acc_row(i, lane);
-          const bool on = all_on | (onf[e] != 0.f);
-          const float p = accq[rb][j][i] + bp_, q = accq[rb][CPW + j][i] + bq_, r = accq[rb][2 * CPW + j][i] + br_;
-          bst(q23_r, lr * 2 * H + col, q);
-          bst(q23_r, lr * 2 * H + H + col, r);
-          const float xv = bufx[lr * LD + col];          // x1: the tile is still in buffer 1
-          bst(xo_r, lr * H + col, on ? xv + (p + q * dot[rb][j][i] * inv_sqrt_h) * kInvSqrt2 : 0.f);
-#pragma unroll
-          for (int d = 0; d < 3; ++d) bst(vo_r, (lr * 3 + d) * H + col, on ? fmaf(r, v1[e][d], vv[e][d]) : 0.f);
-        }
+        for (int g = 0; g < 4; ++g) vo[g] = (vo[g] + r[g] * kv1[rb][j][g][d]) * on;
+        store_block<3 * H>(scr, lane, vo, vo_r, (rblk * 3 + d) * H + cblk);
       }
     }
+  }
+  STAMP(14);
 }
 
 // =====================================================================================================================
@@ -668,6 +814,7 @@ struct UpdBwdArgs {
   const float* vp;          // [N, 3, 2H]
   const float* h2b;         // [N, H]
   const float* q23;         // [N, 2H]
+  const float* nrm;         // [N, H]
   const float* wx2tf;       // [T] fragments of xvec_proj[2].weight^T [H, 3H]
   const float* wx0tf;       // [T] fragments of xvec_proj[0].weight^T [2H, H]
   const float* wvtf;        // [T] fragments of vec_proj.weight^T [H, 2H]
@@ -682,11 +829,12 @@ template <int H, int TR, int MINW>
 __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a) {
   using C = Cfg<H, TR>;
   constexpr int LD = C::LD, RB = C::RB, CPW = C::CPW, CB = C::CB, F4 = C::F4, V = H / 4;
-  extern __shared__ __align__(16) float lds[];            // 2 x [TR][LD]
+  extern __shared__ __align__(16) float lds[];            // 2 x [TR][LD], then 4 x [32][36] store scratch
   float* buf0 = lds;
   float* buf1 = lds + TR * LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave % C::WC, wr = wave / C::WC;
+  float* scr = lds + 2 * TR * LD + wave * kScrFloats;
   const TileInfo ti = find_tile(a.type_rowptr, a.T, a.N, TR, blockIdx.x);
   const int row0 = ti.row0, nrows = ti.nrows, t = ti.t;
   if (t >= a.T) {
@@ -714,15 +862,16 @@ __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a
   for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int j = 0; j < CPW; ++j) bpx[p * CPW + j] = wx0t + (size_t)(p * CB + wc * CPW + j) * (H / 8) * 64;
-  BRing<CPW, 4> ra;
+  BRing<CPW, ring_size(RB * CPW, true)> ra;
   b_preload(ra, bpa);
-  const int lrow = wr * RB * 32 + (lane & 31);
+  const int mrow = wr * RB * 32 + (lane & 31), ch = 4 * (lane >> 5);
   const float inv_sqrt_h = rsqrtf((float)H);
   const rsrc_t gxo_r = tile_rsrc(a.gxo + (size_t)row0 * H, nrows * H);
   const rsrc_t gvo_r = tile_rsrc(a.gvo + (size_t)row0 * 3 * H, nrows * 3 * H);
   const rsrc_t vp_r = tile_rsrc(a.vp + (size_t)row0 * 6 * H, nrows * 6 * H);
   const rsrc_t h2b_r = tile_rsrc(a.h2b + (size_t)row0 * H, nrows * H);
   const rsrc_t q23_r = tile_rsrc(a.q23 + (size_t)row0 * 2 * H, nrows * 2 * H);
+  const rsrc_t nrm_r = tile_rsrc(a.nrm + (size_t)row0 * H, nrows * H);
   const rsrc_t act_r = tile_rsrc(a.row_active ? a.row_active + row0 : a.gxo, a.row_active ? nrows : 0);
   const bool all_on = a.row_active == nullptr;
   const rsrc_t gx1_r = tile_rsrc(a.gx1 + (size_t)row0 * H, nrows * H);
@@ -734,27 +883,33 @@ __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a
   for (int it = 0; it < F4; ++it) {
     if ((it & 1) == 0) fence_sched();     // two positions (20 float4 loads) in flight, not all F4
     const int idx = tid + it * 256, lr = idx / V, c = (idx % V) * 4;
-    f32x4 g1 = {0.f, 0.f, 0.f, 0.f}, g2 = g1, gq3 = g1;
-    {
-      // (rows past the tile's end load zeros; inactive rows are multiplied by zero: their saved values are finite)
-      const float on = (all_on | (bld(act_r, lr) != 0.f)) ? 1.f : 0.f;
-      const f32x4 gx = bld4(gxo_r, lr * H + c) * on;
-      f32x4 vd = {0.f, 0.f, 0.f, 0.f};
+    // (rows past the tile's end load zeros; inactive rows are multiplied by zero: their saved values are finite)
+    const float on = (all_on | (bld(act_r, lr) != 0.f)) ? 1.f : 0.f;
+    const f32x4 gx = bld4(gxo_r, lr * H + c) * on;
+    f32x4 vd = {0.f, 0.f, 0.f, 0.f}, gq3 = vd;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const f32x4 v1 = bld4(vp_r, (lr * 3 + d) * 2 * H + c);
-        const f32x4 v2 = bld4(vp_r, (lr * 3 + d) * 2 * H + H + c);
-        const f32x4 gv = bld4(gvo_r, (lr * 3 + d) * H + c) * on;
-        vd += v1 * v2;
-        gq3 += gv * v1;
-      }
-      g1 = gx * kInvSqrt2;
-      g2 = gx * vd * (inv_sqrt_h * kInvSqrt2);
+    for (int d = 0; d < 3; ++d) {
+      const f32x4 v1 = bld4(vp_r, (lr * 3 + d) * 2 * H + c);
+      const f32x4 v2 = bld4(vp_r, (lr * 3 + d) * 2 * H + H + c);
+      const f32x4 gv = bld4(gvo_r, (lr * 3 + d) * H + c) * on;
+      vd += v1 * v2;
+      gq3 += gv * v1;
     }
-    *reinterpret_cast<f32x4*>(buf0 + lr * LD + c) = g1;
-    *reinterpret_cast<f32x4*>(buf1 + lr * LD + c) = g2;
+    *reinterpret_cast<f32x4*>(buf0 + lr * LD + c) = gx * kInvSqrt2;
+    *reinterpret_cast<f32x4*>(buf1 + lr * LD + c) = gx * vd * (inv_sqrt_h * kInvSqrt2);
     g3.v[it] = gq3;
   }
+  // h2b and gx of this wave's accumulator blocks: requested now (coalesced), transposed behind the first product
+  BlockLoad lh2[RB][CPW], lgx[RB][CPW], lq2[RB][CPW];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+      const int ob = (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32;
+      issue_block<H>(lh2[rb][j], lane, h2b_r, ob);
+      issue_block<H>(lgx[rb][j], lane, gxo_r, ob);
+      issue_block<2 * H>(lq2[rb][j], lane, q23_r, (wr * RB + rb) * 32 * 2 * H + (wc * CPW + j) * 32);
+    }
   __syncthreads();
   // ---- ga2 = gq Wx2  (K = 3H: three panels)
   f32x16 acc[RB][CPW];
@@ -764,135 +919,143 @@ __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a
     const f32x4* bp2[CPW];
 #pragma unroll
     for (int j = 0; j < CPW; ++j) { bp1[j] = bpa[j] + (size_t)(H / 8) * 64; bp2[j] = bpa[j] + (size_t)(2 * H / 8) * 64; }
-    mma_panel<H, LD, RB, CPW, 4, true>(acc, buf0 + lrow * LD + 4 * (lane >> 5), bpa, ra);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true>(acc, buf0 + mrow * LD + ch, bpa, ra);
     __syncthreads();                                 // buffer 0 is free
     tile_store<TR, H, LD>(buf0, g3, tid);
-    mma_panel<H, LD, RB, CPW, 4, true>(acc, buf1 + lrow * LD + 4 * (lane >> 5), bp1, ra);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true>(acc, buf1 + mrow * LD + ch, bp1, ra);
     __syncthreads();                                 // third part in place, buffer 1 free
-    mma_panel<H, LD, RB, CPW, 4, false>(acc, buf0 + lrow * LD + 4 * (lane >> 5), bp2, ra);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), false>(acc, buf0 + mrow * LD + ch, bp2, ra);
   }
-  BRing<2 * CPW, 3> rx;
+  BRing<2 * CPW, ring_size(RB * 2 * CPW, false)> rx;
   b_preload(rx, bpx);
   fence_sched();
   // ---- gh2 = ga2 * ScaledSiLU'(h2b) -> buffer 1
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-    for (int j = 0; j < CPW; ++j) {
-      const int col = (wc * CPW + j) * 32 + (lane & 31);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int lr = (wr * RB + rb) * 32 + acc_row(i, lane);
-        const float hv = bld(h2b_r, lr * H + col);
-        buf1[lr * LD + col] = acc[rb][j][i] * dssilu(hv);
-      }
-    }
-  __syncthreads();
-  // ---- gxin = gh2 Wx0   (gx1 part | g|v2| part); the gx1 part accumulates onto the identity term gx
   f32x16 accx[RB][2 * CPW];
-  float gxv[RB][CPW][16];
+  f32x4 s_[RB][CPW][4];            // s = gvdot / sqrt(H) = gx q / sqrt(2H) per accumulator position
+  float onr[RB];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
+  for (int rb = 0; rb < RB; ++rb) {
+    onr[rb] = (all_on | (bld(act_r, mrow + rb * 32) != 0.f)) ? 1.f : 0.f;
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
-      const int col = (wc * CPW + j) * 32 + (lane & 31);
+      f32x4 ph2[4], gxv[4], q2[4];
+      finish_block(scr, lane, lh2[rb][j], ph2);
+      finish_block(scr, lane, lgx[rb][j], gxv);
+      finish_block(scr, lane, lq2[rb][j], q2);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int lr = (wr * RB + rb) * 32 + acc_row(i, lane);
-        const float on = (all_on | (bld(act_r, lr) != 0.f)) ? 1.f : 0.f;
-        gxv[rb][j][i] = bld(gxo_r, lr * H + col) * on;
-        accx[rb][j][i] = gxv[rb][j][i];
-        accx[rb][CPW + j][i] = 0.f;
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<f32x4*>(buf1 + (mrow + rb * 32) * LD + (wc * CPW + j) * 32 + 8 * g + ch) =
+            run4(acc[rb][j], g) * dssilu4(ph2[g]);
+        gxv[g] *= onr[rb];
+        s_[rb][j][g] = gxv[g] * q2[g] * (kInvSqrt2 * inv_sqrt_h);
+        pin4(s_[rb][j][g]);
+        // gxin = gh2 Wx0 (gx1 part | g|v2| part): the gx1 part accumulates onto the identity term gx
+        set_run4(accx[rb][j], g, gxv[g]);
+        set_run4(accx[rb][CPW + j], g, (f32x4){0.f, 0.f, 0.f, 0.f});
       }
     }
-  mma_panel<H, LD, RB, 2 * CPW, 3, false>(accx, buf1 + lrow * LD + 4 * (lane >> 5), bpx, rx);
+  }
   fence_sched();
-  // per accumulator position: s = gvdot / sqrt(H) = gx q / sqrt(2H), gnn = g|v2| / |v2|   (batches of G, loads first)
-  float s_[RB][CPW][16], gnn[RB][CPW][16];
+  // Everything the next epilogues read from memory is requested one product ahead of its use (coalesced), and
+  // transposed into this lane's row behind that product.
+  BlockLoad lnr[RB][CPW], lgv[RB][CPW], lq3[RB][CPW], lw1[RB][CPW], lw2[RB][CPW];
+// inputs of the staging of component d: gv, (q3), v1, v2
+#define HN_REQUEST(d)                                                                                         \
+  _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) _Pragma("unroll") for (int j = 0; j < CPW; ++j) {          \
+    const int rblk = (wr * RB + rb) * 32, cblk = (wc * CPW + j) * 32;                                          \
+    issue_block<3 * H>(lgv[rb][j], lane, gvo_r, (rblk * 3 + (d)) * H + cblk);                                  \
+    if ((d) == 0) issue_block<2 * H>(lq3[rb][j], lane, q23_r, rblk * 2 * H + H + cblk);                        \
+    issue_block<6 * H>(lw1[rb][j], lane, vp_r, (rblk * 3 + (d)) * 2 * H + cblk);                               \
+    issue_block<6 * H>(lw2[rb][j], lane, vp_r, (rblk * 3 + (d)) * 2 * H + H + cblk);                           \
+  }
+  f32x4 pgv[RB][CPW][4], pq3[RB][CPW][4], pw1[RB][CPW][4], pw2[RB][CPW][4];
+#define HN_ARRIVE(d)                                                                                          \
+  _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) _Pragma("unroll") for (int j = 0; j < CPW; ++j) {          \
+    finish_block(scr, lane, lgv[rb][j], pgv[rb][j]);                                                           \
+    if ((d) == 0) finish_block(scr, lane, lq3[rb][j], pq3[rb][j]);                                             \
+    finish_block(scr, lane, lw1[rb][j], pw1[rb][j]);                                                           \
+    finish_block(scr, lane, lw2[rb][j], pw2[rb][j]);                                                           \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) pgv[rb][j][g] *= onr[rb];                                    \
+  }
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
-      const int col = (wc * CPW + j) * 32 + (lane & 31);
+      const int rblk = (wr * RB + rb) * 32, cblk = (wc * CPW + j) * 32;
+      issue_block<H>(lnr[rb][j], lane, nrm_r, rblk * H + cblk);
+    }
+  HN_REQUEST(0)
+  fence_sched();
+  __syncthreads();
+  mma_panel<H, LD, RB, 2 * CPW, ring_size(RB * 2 * CPW, false), false>(accx, buf1 + mrow * LD + ch, bpx, rx);
+  // (weight rings are requested BEFORE the stores of the epilogue in front of their product: vmcnt retires in order)
+  BRing<CPW, ring_size(RB * CPW, true)> rg;
+  b_preload(rg, bpg);
+  fence_sched();
+  f32x4 pnrm[RB][CPW][4];
 #pragma unroll
-      for (int g = 0; g < 16 / G; ++g) {
-        fence_sched();
-        float v2[G][3], qv[G];
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int e = 0; e < G; ++e) {
-          const int lr = (wr * RB + rb) * 32 + acc_row(G * g + e, lane);
-          qv[e] = bld(q23_r, lr * 2 * H + col);
+    for (int j = 0; j < CPW; ++j) {
+      finish_block(scr, lane, lnr[rb][j], pnrm[rb][j]);
 #pragma unroll
-          for (int d = 0; d < 3; ++d) v2[e][d] = bld(vp_r, (lr * 3 + d) * 2 * H + H + col);
-        }
-        fence_sched();
-#pragma unroll
-        for (int e = 0; e < G; ++e) {
-          const int i = G * g + e;
-          const int lr = (wr * RB + rb) * 32 + acc_row(i, lane);
-          bst(gx1_r, lr * H + col, accx[rb][j][i]);
-          const float sq = fmaf(v2[e][0], v2[e][0], fmaf(v2[e][1], v2[e][1], v2[e][2] * v2[e][2]));
-          s_[rb][j][i] = gxv[rb][j][i] * qv[e] * (kInvSqrt2 * inv_sqrt_h);
-          gnn[rb][j][i] = accx[rb][CPW + j][i] * rsqrtf(sq + 1e-8f);
-          pin(s_[rb][j][i]);
-          pin(gnn[rb][j][i]);
-        }
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 nv = pnrm[rb][j][g];       // (rows past the tile's end load 0: their products are zero anyway)
+        pnrm[rb][j][g] = (f32x4){__builtin_amdgcn_rcpf(fmaxf(nv[0], 1e-4f)), __builtin_amdgcn_rcpf(fmaxf(nv[1], 1e-4f)),
+                                 __builtin_amdgcn_rcpf(fmaxf(nv[2], 1e-4f)), __builtin_amdgcn_rcpf(fmaxf(nv[3], 1e-4f))};
       }
+    }
+  HN_ARRIVE(0)
+  // per accumulator position: gnn = g|v2| / |v2|
+  f32x4 gnn[RB][CPW][4];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+      f32x4 v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v[g] = run4(accx[rb][j], g);
+        gnn[rb][j][g] = run4(accx[rb][CPW + j], g) * pnrm[rb][j][g];
+        pin4(gnn[rb][j][g]);
+      }
+      store_block<H>(scr, lane, v, gx1_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
     }
   // ---- gvec1[d] = gv[d] + (gv1[d] | gv2[d]) Wv,  gv1 = gv q3 + s v2,  gv2 = s v1 + gnn v2  (the accumulator starts at gv[d])
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    BRing<CPW, 4> rg;
-    b_preload(rg, bpg);
     f32x16 accg[RB][CPW];
     __syncthreads();                                 // the previous product has read both buffers
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int j = 0; j < CPW; ++j) {
-        const int col = (wc * CPW + j) * 32 + (lane & 31);
+      for (int j = 0; j < CPW; ++j)
 #pragma unroll
-        for (int g = 0; g < 16 / G; ++g) {
-          fence_sched();
-          float gv[G], q3[G], v1[G], v2[G], onf[G];
-#pragma unroll
-          for (int e = 0; e < G; ++e) {
-            const int lr = (wr * RB + rb) * 32 + acc_row(G * g + e, lane);
-            onf[e] = bld(act_r, lr);
-            gv[e] = bld(gvo_r, (lr * 3 + d) * H + col);
-            q3[e] = bld(q23_r, lr * 2 * H + H + col);
-            v1[e] = bld(vp_r, (lr * 3 + d) * 2 * H + col);
-            v2[e] = bld(vp_r, (lr * 3 + d) * 2 * H + H + col);
-          }
-          fence_sched();
-#pragma unroll
-          for (int e = 0; e < G; ++e) {
-            const int i = G * g + e;
-            const int lr = (wr * RB + rb) * 32 + acc_row(i, lane);
-            const float gvm = (all_on | (onf[e] != 0.f)) ? gv[e] : 0.f;
-            accg[rb][j][i] = gvm;
-            buf0[lr * LD + col] = fmaf(gvm, q3[e], s_[rb][j][i] * v2[e]);
-            buf1[lr * LD + col] = fmaf(s_[rb][j][i], v1[e], gnn[rb][j][i] * v2[e]);
-          }
+        for (int g = 0; g < 4; ++g) {
+          const int lr = mrow + rb * 32, c0 = (wc * CPW + j) * 32 + 8 * g + ch;
+          const f32x4 gv = pgv[rb][j][g], v1 = pw1[rb][j][g], v2 = pw2[rb][j][g];
+          set_run4(accg[rb][j], g, gv);
+          *reinterpret_cast<f32x4*>(buf0 + lr * LD + c0) = gv * pq3[rb][j][g] + s_[rb][j][g] * v2;
+          *reinterpret_cast<f32x4*>(buf1 + lr * LD + c0) = s_[rb][j][g] * v1 + gnn[rb][j][g] * v2;
         }
-      }
+    fence_sched();
+    if (d < 2) { HN_REQUEST(d + 1) }                 // in flight during the product below
+    fence_sched();
     __syncthreads();
     const f32x4* bpg1[CPW];
 #pragma unroll
     for (int j = 0; j < CPW; ++j) bpg1[j] = bpg[j] + (size_t)(H / 8) * 64;
-    mma_panel<H, LD, RB, CPW, 4, true>(accg, buf0 + lrow * LD + 4 * (lane >> 5), bpg, rg);
-    mma_panel<H, LD, RB, CPW, 4, false>(accg, buf1 + lrow * LD + 4 * (lane >> 5), bpg1, rg);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true>(accg, buf0 + mrow * LD + ch, bpg, rg);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), false>(accg, buf1 + mrow * LD + ch, bpg1, rg);
+    if (d < 2) b_preload(rg, bpg);
     fence_sched();
+    if (d < 2) { HN_ARRIVE(d + 1) }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int j = 0; j < CPW; ++j) {
-        const int col = (wc * CPW + j) * 32 + (lane & 31);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int lr = (wr * RB + rb) * 32 + acc_row(i, lane);
-          bst(gvec1_r, (lr * 3 + d) * H + col, accg[rb][j][i]);
-        }
+        const f32x4 v[4] = {run4(accg[rb][j], 0), run4(accg[rb][j], 1), run4(accg[rb][j], 2), run4(accg[rb][j], 3)};
+        store_block<3 * H>(scr, lane, v, gvec1_r, ((wr * RB + rb) * 32 * 3 + d) * H + (wc * CPW + j) * 32);
       }
   }
 }
@@ -923,29 +1086,41 @@ int launch_chain(void (*kernel)(Args), dim3 grid, size_t lds_bytes, void* stream
 // LDS floats of a kernel family for tile (H, TR): NB buffers of [TR][H + 4]
 #define HN_CHAIN_DISPATCH(KERNEL, GRID, NB, ARGS)                                                          \
   switch (hidden) {                                                                                        \
-    case 64: return launch_chain(KERNEL<64, 64>, GRID(64), (size_t)NB * 64 * 68 * 4, stream, ARGS);        \
-    case 128: return launch_chain(KERNEL<128, 64>, GRID(64), (size_t)NB * 64 * 132 * 4, stream, ARGS);     \
-    case 256: return launch_chain(KERNEL<256, 32>, GRID(32), (size_t)NB * 32 * 260 * 4, stream, ARGS);     \
+    case 64: return launch_chain(KERNEL<64, 64>, GRID(64), (size_t)(NB * 64 * 68 + 4 * kScrFloats) * 4, stream, ARGS);        \
+    case 128: return launch_chain(KERNEL<128, 64>, GRID(64), (size_t)(NB * 64 * 132 + 4 * kScrFloats) * 4, stream, ARGS);     \
+    case 256: return launch_chain(KERNEL<256, 32>, GRID(32), (size_t)(NB * 32 * 260 + 4 * kScrFloats) * 4, stream, ARGS);     \
     default: return HN_ERR_BAD_ARG;                                                                        \
   }
 
-// Update kernels: tile (H, TR) and register budget.  H = 128 has two instances: 64-row tiles keep ~300 values per lane
-// live (one wave per SIMD, 512 registers) and load every weight fragment once per 64 rows -- the choice while the grid
-// has at most one tile per CU anyway; 32-row tiles fit 256 registers, so two or three workgroups share a CU and one's
-// elementwise phases run beside another's matrix phases -- the choice for large grids.
+// Update kernels: tile (H, TR) and register budget.  H = 128 has two instances: 32-row tiles fit 256 registers, so two
+// workgroups share a CU and one's elementwise phases run beside the other's matrix phases (the default: measured
+// 64 / 77 us against 75 / 99 us per launch at 10,000 rows); 64-row tiles keep ~400 values per lane live (one wave per SIMD,
+// 512 registers) and load every weight fragment once per 64 rows (HERMNET_UPDATE_TILE64_MAX = largest grid, in 64-row
+// tiles, that takes them).
+inline int tile64_max() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("HERMNET_UPDATE_TILE64_MAX"); v = e ? atoi(e) : 0; }
+  return v;
+}
 #define HN_TILES(TR) tiles_of(type_rowptr_host, num_rel, num_nodes, TR)
 #define HN_UPDATE_DISPATCH(KERNEL, ARGS)                                                                              \
   switch (hidden) {                                                                                                   \
-    case 64: return launch_chain(KERNEL<64, 64, 2>, dim3((unsigned)HN_TILES(64)), (size_t)2 * 64 * 68 * 4, stream, ARGS); \
+    case 64: return launch_chain(KERNEL<64, 64, 2>, dim3((unsigned)HN_TILES(64)), (size_t)(2 * 64 * 68 + 4 * kScrFloats) * 4, stream, ARGS); \
     case 128:                                                                                                         \
-      if (HN_TILES(64) <= 320)                                                                                        \
-        return launch_chain(KERNEL<128, 64, 1>, dim3((unsigned)HN_TILES(64)), (size_t)2 * 64 * 132 * 4, stream, ARGS); \
-      return launch_chain(KERNEL<128, 32, 2>, dim3((unsigned)HN_TILES(32)), (size_t)2 * 32 * 132 * 4, stream, ARGS);  \
-    case 256: return launch_chain(KERNEL<256, 32, 1>, dim3((unsigned)HN_TILES(32)), (size_t)2 * 32 * 260 * 4, stream, ARGS); \
+      if (HN_TILES(64) <= tile64_max())                                                                               \
+        return launch_chain(KERNEL<128, 64, 1>, dim3((unsigned)HN_TILES(64)), (size_t)(2 * 64 * 132 + 4 * kScrFloats) * 4, stream, ARGS); \
+      return launch_chain(KERNEL<128, 32, 2>, dim3((unsigned)HN_TILES(32)), (size_t)(2 * 32 * 132 + 4 * kScrFloats) * 4, stream, ARGS);  \
+    case 256: return launch_chain(KERNEL<256, 32, 1>, dim3((unsigned)HN_TILES(32)), (size_t)(2 * 32 * 260 + 4 * kScrFloats) * 4, stream, ARGS); \
     default: return HN_ERR_BAD_ARG;                                                                                   \
   }
 
 }  // namespace
+
+#ifdef HN_STAMPS
+extern "C" int hermnet_debug_stamps(unsigned long long* out_host, int count) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(hn_stamps), (size_t)count * sizeof(unsigned long long)) == hipSuccess ? 0 : 3;
+}
+#endif
 
 extern "C" int hermnet_node_chain_supported(int hidden) { return hidden == 64 || hidden == 128 || hidden == 256; }
 
@@ -973,9 +1148,9 @@ extern "C" int hermnet_node_pre_bwd(const float* gxh, const float* hb, const flo
   // chunk buffers: 2 x [TR][min(H,128) + 4]
   int rc;
   switch (hidden) {
-    case 64: rc = launch_chain(node_pre_bwd_kernel<64, 64>, HN_GRID(64), (size_t)2 * 64 * 68 * 4, stream, a); break;
-    case 128: rc = launch_chain(node_pre_bwd_kernel<128, 64>, HN_GRID(64), (size_t)2 * 64 * 132 * 4, stream, a); break;
-    default: rc = launch_chain(node_pre_bwd_kernel<256, 32>, HN_GRID(32), (size_t)2 * 32 * 132 * 4, stream, a); break;
+    case 64: rc = launch_chain(node_pre_bwd_kernel<64, 64>, HN_GRID(64), (size_t)pre_bwd_lds_floats(64, 64) * 4, stream, a); break;
+    case 128: rc = launch_chain(node_pre_bwd_kernel<128, 64>, HN_GRID(64), (size_t)pre_bwd_lds_floats(128, 64) * 4, stream, a); break;
+    default: rc = launch_chain(node_pre_bwd_kernel<256, 32>, HN_GRID(32), (size_t)pre_bwd_lds_floats(256, 32) * 4, stream, a); break;
   }
 #undef HN_GRID
   if (rc != HN_OK) return rc;
@@ -988,31 +1163,31 @@ extern "C" int hermnet_node_pre_bwd(const float* gxh, const float* hb, const flo
 extern "C" int hermnet_node_update_fwd(const float* x1, const float* vec1, const float* wv_frag, const float* wx0_frag,
                                        const float* bx0, const float* wx2_frag, const float* bx2,
                                        const float* row_active, const int* type_rowptr, const int* type_rowptr_host,
-                                       float* vp, float* h2b, float* q23, float* x_out, float* vec_out, int num_nodes,
-                                       int num_rel, int hidden, void* stream) {
+                                       float* vp, float* h2b, float* q23, float* nrm, float* x_out, float* vec_out,
+                                       int num_nodes, int num_rel, int hidden, void* stream) {
   if (num_nodes < 0 || num_rel <= 0 || !type_rowptr_host) return HN_ERR_BAD_ARG;
   if (!hermnet_node_chain_supported(hidden)) return HN_ERR_BAD_ARG;
   if (num_nodes == 0) return HN_OK;
-  if (!x1 || !vec1 || !wv_frag || !wx0_frag || !bx0 || !wx2_frag || !bx2 || !type_rowptr || !vp || !h2b || !q23 ||
+  if (!x1 || !vec1 || !wv_frag || !wx0_frag || !bx0 || !wx2_frag || !bx2 || !type_rowptr || !vp || !h2b || !q23 || !nrm ||
       !x_out || !vec_out || type_rowptr_host[num_rel] > num_nodes)
     return HN_ERR_BAD_ARG;
-  UpdFwdArgs a = {x1, vec1, wv_frag, wx0_frag, bx0, wx2_frag, bx2, row_active, type_rowptr, vp, h2b, q23, x_out, vec_out,
-                  num_nodes, num_rel};
+  UpdFwdArgs a = {x1, vec1, wv_frag, wx0_frag, bx0, wx2_frag, bx2, row_active, type_rowptr, vp, h2b, q23, nrm, x_out,
+                  vec_out, num_nodes, num_rel};
   HN_UPDATE_DISPATCH(node_update_fwd_kernel, a);
 }
 
 extern "C" int hermnet_node_update_bwd(const float* gx_out, const float* gvec_out, const float* vp, const float* h2b,
-                                       const float* q23, const float* wx2t_frag, const float* wx0t_frag,
+                                       const float* q23, const float* nrm, const float* wx2t_frag, const float* wx0t_frag,
                                        const float* wvt_frag, const float* row_active, const int* type_rowptr,
                                        const int* type_rowptr_host, float* gx1, float* gvec1, int num_nodes, int num_rel,
                                        int hidden, void* stream) {
   if (num_nodes < 0 || num_rel <= 0 || !type_rowptr_host) return HN_ERR_BAD_ARG;
   if (!hermnet_node_chain_supported(hidden)) return HN_ERR_BAD_ARG;
   if (num_nodes == 0) return HN_OK;
-  if (!gx_out || !gvec_out || !vp || !h2b || !q23 || !wx2t_frag || !wx0t_frag || !wvt_frag || !type_rowptr || !gx1 ||
+  if (!gx_out || !gvec_out || !vp || !h2b || !q23 || !nrm || !wx2t_frag || !wx0t_frag || !wvt_frag || !type_rowptr || !gx1 ||
       !gvec1 || type_rowptr_host[num_rel] > num_nodes)
     return HN_ERR_BAD_ARG;
-  UpdBwdArgs a = {gx_out, gvec_out, vp, h2b, q23, wx2t_frag, wx0t_frag, wvt_frag, row_active, type_rowptr, gx1, gvec1,
+  UpdBwdArgs a = {gx_out, gvec_out, vp, h2b, q23, nrm, wx2t_frag, wx0t_frag, wvt_frag, row_active, type_rowptr, gx1, gvec1,
                   num_nodes, num_rel};
   HN_UPDATE_DISPATCH(node_update_bwd_kernel, a);
 }

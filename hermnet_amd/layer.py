@@ -222,8 +222,8 @@ class FusedRelationalLayer(torch.autograd.Function):
             # three launches: node_pre_fwd (LayerNorm + x_proj of every relation), the message kernel, node_update_fwd
             hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T)
             x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False)
-            x_out, vec_out, vp, h2b, q23 = nodeops.node_update_fwd(x1, vec1, w, graph)
-            ctx.save_for_backward(x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23)
+            x_out, vec_out, vp, h2b, q23, nrm = nodeops.node_update_fwd(x1, vec1, w, graph)
+            ctx.save_for_backward(x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23, nrm)
             ctx.graph, ctx.rbf, ctx.w, ctx.sink, ctx.li = graph, rbf, w, sink, li
             return x_out, vec_out
         n, mean, rstd = nodeops.layernorm_fwd(x, 1e-5, h_real=w.h_real)
@@ -279,9 +279,9 @@ class FusedRelationalLayer(torch.autograd.Function):
         gvo = gvo.contiguous()
         uni, B = graph.uniform and nk > 0, graph.block
         if ctx.chain:
-            x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23 = ctx.saved_tensors
+            x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23, nrm = ctx.saved_tensors
             Ns, H = x.shape
-            gx1, gvec1 = nodeops.node_update_bwd(gxo, gvo, vp, h2b, q23, w, graph)
+            gx1, gvec1 = nodeops.node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph)
         else:
             x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q = ctx.saved_tensors
             Ns, H = x.shape

@@ -173,26 +173,28 @@ def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None):
 
 
 def node_update_fwd(x1, vec1, w, graph):
-    """(x1, vec1) -> (x_out, vec_out) and the saved (vp [N,3,2H], h2b [N,H], q23 [N,2H])  (rmnet.py:94-107, 29-31)."""
+    """(x1, vec1) -> (x_out, vec_out) and the saved (vp [N,3,2H], h2b [N,H], q23 [N,2H], nrm [N,H])
+    (rmnet.py:94-107, 29-31)."""
     N, H = x1.shape
     dev, dt = x1.device, x1.dtype
     vp = torch.empty(N, 3, 2 * H, dtype=dt, device=dev)
     h2b = torch.empty(N, H, dtype=dt, device=dev)
     q23 = torch.empty(N, 2 * H, dtype=dt, device=dev)
+    nrm = torch.empty(N, H, dtype=dt, device=dev)
     xo = torch.empty(N, H, dtype=dt, device=dev)
     vo = torch.empty(N, 3, H, dtype=dt, device=dev)
     _lib.check(_launch("node_update_fwd", lambda: _lib.load().hermnet_node_update_fwd(
         P(x1), P(vec1), P(w.wvf), P(w.wx0f), P(w.bx0_s), P(w.wx2f), P(w.bx2_s), P(graph.row_active), P(graph.type_rowptr),
-        _rowptr_host(graph), P(vp), P(h2b), P(q23), P(xo), P(vo), N, graph.T, H, _stream())), "hermnet_node_update_fwd")
-    return xo, vo, vp, h2b, q23
+        _rowptr_host(graph), P(vp), P(h2b), P(q23), P(nrm), P(xo), P(vo), N, graph.T, H, _stream())), "hermnet_node_update_fwd")
+    return xo, vo, vp, h2b, q23, nrm
 
 
-def node_update_bwd(gxo, gvo, vp, h2b, q23, w, graph):
+def node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph):
     """Gradient of node_update_fwd w.r.t. (x1, vec1)."""
     N, H = gxo.shape
     gx1 = torch.empty_like(gxo)
     gvec1 = torch.empty_like(gvo)
     _lib.check(_launch("node_update_bwd", lambda: _lib.load().hermnet_node_update_bwd(
-        P(gxo), P(gvo), P(vp), P(h2b), P(q23), P(w.wx2tf), P(w.wx0tf), P(w.wvtf), P(graph.row_active), P(graph.type_rowptr),
+        P(gxo), P(gvo), P(vp), P(h2b), P(q23), P(nrm), P(w.wx2tf), P(w.wx0tf), P(w.wvtf), P(graph.row_active), P(graph.type_rowptr),
         _rowptr_host(graph), P(gx1), P(gvec1), N, graph.T, H, _stream())), "hermnet_node_update_bwd")
     return gx1, gvec1

@@ -290,7 +290,8 @@ int hermnet_node_pre_bwd(const float* gxh, const float* hb, const float* w2t_fra
                          float* gn_parts, const float* x, const float* mean, const float* rstd, const float* add,
                          float* gx, int num_src, int num_rel, int hidden, int hidden_real, void* stream);
 /* hermnet_node_update_fwd (rmnet.py:94-107, 29-31; hermnet.py:51,56-61), target rows in relation order:
- *     vp = vec1 Wv^T  [N,3,2H] = (v1 | v2), saved;   vdot = sum_d v1 v2 / sqrt(H);   n = sqrt(sum_d v2^2 + 1e-8)
+ *     vp = vec1 Wv^T  [N,3,2H] = (v1 | v2), saved;   vdot = sum_d v1 v2 / sqrt(H);   n = sqrt(sum_d v2^2 + 1e-8) -> nrm
+ *                                                                                    [N,H], saved
  *     h2b = [x1 | n] Wx0^T + bx0  [N,H], saved;      (p | q | r) = ScaledSiLU(h2b) Wx2^T + bx2;   q23 = (q | r) [N,2H], saved
  *     x_out = x1 + (p + q vdot)/sqrt2,  vec_out[d] = vec1[d] + r v1[d];   rows with row_active == 0 (row_active may be
  *     NULL: all active) and rows >= type_rowptr[T] are written as zero.
@@ -300,9 +301,11 @@ int hermnet_node_pre_bwd(const float* gxh, const float* hb, const float* w2t_fra
 int hermnet_node_update_fwd(const float* x1, const float* vec1, const float* wv_frag, const float* wx0_frag,
                             const float* bx0, const float* wx2_frag, const float* bx2, const float* row_active,
                             const int* type_rowptr, const int* type_rowptr_host, float* vp, float* h2b, float* q23,
-                            float* x_out, float* vec_out, int num_nodes, int num_rel, int hidden, void* stream);
+                            float* nrm, float* x_out, float* vec_out, int num_nodes, int num_rel, int hidden,
+                            void* stream);
 int hermnet_node_update_bwd(const float* gx_out, const float* gvec_out, const float* vp, const float* h2b,
-                            const float* q23, const float* wx2t_frag, const float* wx0t_frag, const float* wvt_frag,
+                            const float* q23, const float* nrm, const float* wx2t_frag, const float* wx0t_frag,
+                            const float* wvt_frag,
                             const float* row_active, const int* type_rowptr, const int* type_rowptr_host, float* gx1,
                             float* gvec1, int num_nodes, int num_rel, int hidden, void* stream);
 

@@ -237,6 +237,7 @@ def _node_update(x1, vec1, w, graph):
     vp_all = torch.zeros(N, 3, 2 * H, dtype=dt)
     h2b_all = torch.zeros(N, H, dtype=dt)
     q23 = torch.zeros(N, 2 * H, dtype=dt)
+    nrm = torch.zeros(N, H, dtype=dt)
     xs, vs = [], []
     for lo, hi, vp, v1, vdot, h2b, pqr in _update_parts(x1, vec1, w, graph):
         p, q, r = pqr[:, :H], pqr[:, H:2 * H], pqr[:, 2 * H:]
@@ -244,10 +245,11 @@ def _node_update(x1, vec1, w, graph):
         xs.append((lo, hi, (x1[lo:hi] + (p + q * vdot) / math.sqrt(2.0)) * m[:, None]))
         vs.append((lo, hi, (vec1[lo:hi] + r[:, None, :] * v1) * m[:, None, None]))
         vp_all[lo:hi], h2b_all[lo:hi], q23[lo:hi] = vp.detach(), h2b.detach(), pqr[:, H:].detach()
+        nrm[lo:hi] = torch.sqrt((vp[..., H:].detach() ** 2).sum(1) + 1e-8)
     if xs:
         xo = torch.cat([torch.zeros(0, H, dtype=dt)] + _fill_rows(xs, N, (H,), dt))
         vo = torch.cat([torch.zeros(0, 3, H, dtype=dt)] + _fill_rows(vs, N, (3, H), dt))
-    return xo, vo, vp_all, h2b_all, q23
+    return xo, vo, vp_all, h2b_all, q23, nrm
 
 
 def _fill_rows(parts, N, shape, dt):
@@ -268,7 +270,7 @@ def node_update_fwd(x1, vec1, w, graph):
         return _node_update(x1, vec1, w, graph)
 
 
-def node_update_bwd(gxo, gvo, vp, h2b, q23, w, graph):
+def node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph):
     """The kernel's backward formulas from the saved (vp, h2b, q23) (checked against autograd of the forward in
     tests/test_host_logic.py)."""
     N, H = gxo.shape
@@ -286,7 +288,7 @@ def node_update_bwd(gxo, gvo, vp, h2b, q23, w, graph):
         gx, gv = gxo[lo:hi] * m[:, None], gvo[lo:hi] * m[:, None, None]
         v1, v2 = vp[lo:hi, :, :H], vp[lo:hi, :, H:]
         vdot = (v1 * v2).sum(1) * rh
-        norm = torch.sqrt((v2 ** 2).sum(1) + 1e-8)
+        norm = nrm[lo:hi]
         q2, q3 = q23[lo:hi, :H], q23[lo:hi, H:]
         gq = torch.cat([gx * r2, gx * vdot * r2, (gv * v1).sum(1)], 1)
         gh2 = (gq @ w.wx2[t].to(dt)) * _dssilu(h2b[lo:hi])
@@ -304,7 +306,7 @@ def node_update_bwd_from_inputs(gxo, gvo, x1, vec1, w, graph):
     with torch.enable_grad():
         x1_ = x1.detach().requires_grad_(True)
         v_ = vec1.detach().requires_grad_(True)
-        xo, vo, _, _, _ = _node_update(x1_, v_, w, graph)
+        xo, vo = _node_update(x1_, v_, w, graph)[:2]
         return torch.autograd.grad([xo, vo], [x1_, v_], [gxo, gvo])
 
 

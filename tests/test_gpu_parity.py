@@ -290,18 +290,18 @@ def test_node_chain_kernels_match_restatement(H, T, counts, uniform, hr):
         gx = nodeops.node_pre_bwd(c(gxh), hb, c(x), mean, rstd, wd, add=None if a is None else c(a))
         gx_r = ref_ops.node_pre_bwd(d64(gxh), hb_r, d64(x), mean_r, rstd_r, w, add=None if a is None else d64(a))
         assert rel_err(gx.cpu().double(), gx_r) < 5e-6
-    xo, vo, vp, h2b, q23 = nodeops.node_update_fwd(c(x1), c(vec1), wd, gd)
+    xo, vo, vp, h2b, q23, nrm = nodeops.node_update_fwd(c(x1), c(vec1), wd, gd)
     refs = ref_ops.node_update_fwd(d64(x1), d64(vec1), w, g)
     nk = g.type_rowptr_host[-1]
-    for k, (a, b) in enumerate(zip((xo, vo, vp, h2b, q23), refs)):
+    for k, (a, b) in enumerate(zip((xo, vo, vp, h2b, q23, nrm), refs)):
         a = a.cpu().double()
         if k >= 2:                      # saved tensors: defined on the rows of known elements
             a, b = a[:nk], b[:nk]
             real = (g.row_real[:nk] != 0) if g.row_real is not None else slice(None)
             a, b = a[real], b[real]
         assert rel_err(a, b) < 3e-6, k
-    gx1, gvec1 = nodeops.node_update_bwd(c(gxo), c(gvo), vp, h2b, q23, wd, gd)
-    gx1_r, gvec1_r = ref_ops.node_update_bwd(d64(gxo), d64(gvo), refs[2], refs[3], refs[4], w, g)
+    gx1, gvec1 = nodeops.node_update_bwd(c(gxo), c(gvo), vp, h2b, q23, nrm, wd, gd)
+    gx1_r, gvec1_r = ref_ops.node_update_bwd(d64(gxo), d64(gvo), refs[2], refs[3], refs[4], refs[5], w, g)
     assert rel_err(gx1.cpu().double(), gx1_r) < 5e-6 and rel_err(gvec1.cpu().double(), gvec1_r) < 5e-6
     assert torch.isfinite(gx1).all() and torch.isfinite(gvec1).all()
 

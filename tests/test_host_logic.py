@@ -380,11 +380,11 @@ def test_node_chain_restatements_are_consistent(H, T, counts, uniform):
     gen = torch.Generator().manual_seed(1)
     N = g.N
     x1, vec1 = torch.randn(N, H, generator=gen).double(), torch.randn(N, 3, H, generator=gen).double()
-    xo, vo, vp, h2b, q23 = ref_ops.node_update_fwd(x1, vec1, w, g)
+    xo, vo, vp, h2b, q23, nrm = ref_ops.node_update_fwd(x1, vec1, w, g)
     act = g.row_active != 0
     assert float(xo[~act].abs().max()) == 0.0 and float(vo[~act].abs().max()) == 0.0 and bool((~act).any())
     gxo, gvo = torch.randn(N, H, generator=gen).double(), torch.randn(N, 3, H, generator=gen).double()
-    a = ref_ops.node_update_bwd(gxo, gvo, vp, h2b, q23, w, g)
+    a = ref_ops.node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, g)
     b = ref_ops.node_update_bwd_from_inputs(gxo, gvo, x1, vec1, w, g)
     assert rel_err(a[0], b[0]) < 1e-12 and rel_err(a[1], b[1]) < 1e-12
     # pre chain: backward formulas vs autograd

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Times the four node chain kernels (csrc/node_chain.hip) on the row counts of BASELINE configs[1] (10,000 atoms, 3
+relations, H = 128) or any other size:   python tools/chain_bench.py [atoms] [H] [T] [reps]
+Prints microseconds per launch (HIP events around `reps` back-to-back launches) and the fp32 MFMA utilisation."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from hermnet_amd import nodeops  # noqa: E402
+from hermnet_amd.layer import LayerWeights  # noqa: E402
+from hermnet_amd.relations import RelationalGraph  # noqa: E402
+from hermnet_amd.rmnet import PaiNNModule  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    H = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+    T = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    reps = int(sys.argv[4]) if len(sys.argv) > 4 else 50
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    mods = [PaiNNModule(hidden_channels=H, num_rbf=16).to(dev) for _ in range(T)]
+    w = LayerWeights(mods).refresh()
+    zs = [13, 28, 29, 79, 47, 46][:T]
+    z = torch.tensor(zs, device=dev)[torch.randint(0, T, (n,), device=dev)]
+    src = torch.randint(0, n, (4 * n,), device=dev)
+    tgt = torch.randint(0, n, (4 * n,), device=dev)
+    g = RelationalGraph.build(z, torch.stack([src, tgt]), zs)
+    N = g.N
+    x, x1, vec1 = torch.randn(N, H, device=dev), torch.randn(N, H, device=dev), torch.randn(N, 3, H, device=dev)
+    gxh, gxo, gvo = torch.randn(T, N, 3 * H, device=dev), torch.randn(N, H, device=dev), torch.randn(N, 3, H, device=dev)
+    hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T)
+    xo, vo, vp, h2b, q23, nrm = nodeops.node_update_fwd(x1, vec1, w, g)
+    cases = {
+        "node_pre_fwd": (lambda: nodeops.node_pre_fwd(x, w, T), 2 * N * T * 4 * H * H),
+        "node_pre_bwd": (lambda: nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w), 2 * N * T * 4 * H * H),
+        "node_update_fwd": (lambda: nodeops.node_update_fwd(x1, vec1, w, g), 2 * N * 11 * H * H),
+        "node_update_bwd": (lambda: nodeops.node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, g), 2 * N * 11 * H * H),
+    }
+    print("rows %d (atoms %d), H %d, T %d" % (N, n, H, T))
+    for name, (fn, flop) in cases.items():
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) / reps * 1e3
+        print("%-16s %8.1f us   %6.1f TFLOP/s  (%.2f of 155)" % (name, us, flop / us / 1e6, flop / us / 1e6 / 155))
+
+
+if __name__ == "__main__":
+    main()
