@@ -110,11 +110,17 @@ class RadialBasis(nn.Module):
             raise ValueError(f"Unknown radial basis function '{rbf_name}'.")
         self._desc = None
 
+    # largest Gaussian basis whose rbf_proj column block fits the backward kernel's LDS tile ((R + 23) tap rows x 64
+    # channels x 16 B <= 160 KiB, csrc/message_bwd_cl.hip; the forward tile would take R <= 190)
+    FUSED_MAX_RBF = 137
+
     @property
     def fused(self):
-        """True when the basis is the one the fused gfx950 kernel evaluates in registers (Gaussian, the
-        reference default, hermnet.py:87)."""
-        return self.rbf_name == "gaussian"
+        """True when the basis is the one the fused gfx950 kernel evaluates in registers: Gaussian (the reference
+        default, hermnet.py:87) with at most FUSED_MAX_RBF functions.  Larger Gaussian bases (the reference accepts any
+        `num_rbf`, hermnet.py:86) take the same route as the Bessel / Bernstein bases: basis materialised from the
+        kernel's distances, rbf_proj as a library GEMM, gather / index_add device ops."""
+        return self.rbf_name == "gaussian" and self.num_radial <= self.FUSED_MAX_RBF
 
     def forward(self, d):
         """`rmnet.py:168-172` as differentiable device ops: envelope(d/rc)[:,None] * rbf(d/rc) -> [E,R].

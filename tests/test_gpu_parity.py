@@ -812,6 +812,54 @@ def test_other_widths_vs_oracle(H, R, layers):
     _oracle_vs_hip(data, ["Al", "Ni", "Cu"], dict(rc=5.0, num_layers=layers, hidden_channels=H, num_rbf=R), 40 + H)
 
 
+@pytest.mark.parametrize("R", [137, 138, 192, 256])
+def test_large_gaussian_basis_vs_oracle(R):
+    """The reference accepts any `num_rbf` (hermnet.py:86, rmnet.py:155-158).  Up to RadialBasis.FUSED_MAX_RBF = 137 the
+    rbf_proj column block fits the fused kernels' LDS tile; beyond it the Gaussian basis takes the materialised route
+    (forward AND forces), which used to raise HN_ERR_LDS at the first force call."""
+    from hermnet_amd.rmnet import RadialBasis
+    data = synth.fcc_alloy(reps=(2, 2, 3))
+    kw = dict(rc=5.0, num_layers=2, hidden_channels=128, num_rbf=R)
+    assert hn.HVNet(["Al"], **kw).radial_basis.fused == (R <= RadialBasis.FUSED_MAX_RBF)
+    _oracle_vs_hip(data, ["Al", "Ni", "Cu"], kw, 300 + R)
+
+
+@pytest.mark.parametrize("env", [{}, {"HERMNET_BWD_CL": "0"}, {"HERMNET_NODE_CHAIN": "0"}])
+@pytest.mark.parametrize("case", ["alloy108", "alloy108_h64", "alloy108_unknown_type", "mol16", "skewed", "width100"])
+def test_edge_gradient_sink_is_fully_written(case, env, monkeypatch):
+    """HVNet.forward hands the backward kernels an UNINITIALISED edge-gradient buffer when every edge has a target of a
+    known element (hermnet.py: EdgeGradSink(zero=False)): every [layer, H/64, E] slot must then be written by whichever
+    backward form runs.  HERMNET_DEBUG_POISON=1 fills the buffer with NaN first: a skipped slot would poison the forces.
+    Covers the channel-per-lane and the 16-lanes-per-edge backward, a padded width, rows without edges, and an
+    unknown-element case (which must take the zero-filled buffer)."""
+    monkeypatch.setenv("HERMNET_DEBUG_POISON", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    dev = _dev()
+    if case in ("skewed", "width100"):
+        if case == "skewed":
+            data = synth.fcc_alloy(reps=(2, 2, 3))
+            z = data.atomic_number.clone()
+            z[3:] = 13                                  # 3 atoms of two elements, the rest Al: tight layout, tiny blocks
+            data.atomic_number = z
+            kw = dict(rc=5.0, num_layers=2, hidden_channels=128, num_rbf=32)
+        else:
+            data = synth.molecule_batch(num_graphs=5, seed=3)
+            kw = dict(rc=5.0, num_layers=2, hidden_channels=100, num_rbf=32)
+        elems = ["Al", "Ni", "Cu"] if case == "skewed" else ["H", "C", "O"]
+        e, f = _oracle_vs_hip(data, elems, kw, 5)
+        assert torch.isfinite(f).all()
+        return
+    g = Golden(case)
+    model = g.model().to(dev)
+    d = g.data().to(dev)
+    d.pos.requires_grad_(True)
+    e = model(d)
+    f = -torch.autograd.grad(e.sum(), d.pos)[0]
+    assert torch.isfinite(f).all()
+    assert rel_err(e.detach().cpu(), g.energy) < TOL and rel_err(f.cpu(), g.forces) < TOL
+
+
 def test_width_not_multiple_of_64_molecule_batch_and_htnet():
     """any `hidden_channels` runs fused -- also for batches (intensive read-out) and HTNet."""
     data = synth.molecule_batch(num_graphs=6, seed=2)
