@@ -291,9 +291,17 @@ struct PreFwdArgs {
   float* xh;           // [T, Ns, 3H]  incl. bias
   float* mean;         // [Ns]
   float* rstd;         // [Ns]
+  const int* src_ranges;   // [T][4] or null: relation t only ever gathers source rows [r0, r1) and [r2, r3)
   int Ns, T, Hr;
   float eps;
 };
+
+// HTNet: relation (c; p, q) gathers source rows of elements p and q only -- tiles outside both row ranges are skipped
+__device__ __forceinline__ bool tile_wanted(const int* __restrict__ ranges, int t, int row0, int TR) {
+  if (ranges == nullptr) return true;
+  const int r0 = ranges[4 * t], r1 = ranges[4 * t + 1], r2 = ranges[4 * t + 2], r3 = ranges[4 * t + 3];
+  return (row0 < r1 && row0 + TR > r0) || (row0 < r3 && row0 + TR > r2);
+}
 
 template <int H, int TR>
 __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
@@ -305,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
   const int wc = wave % C::WC, wr = wave / C::WC;
   float* scr = tile + TR * LD + wave * kScrFloats;
   const int nrows = min(TR, a.Ns - row0);
+  if (!tile_wanted(a.src_ranges, t, row0, TR)) return;     // xh[t] / hb[t] of these rows are never read
   const rsrc_t x_r = tile_rsrc(a.x + (size_t)row0 * H, nrows * H);
   const rsrc_t hb_r = tile_rsrc(a.hb + ((size_t)t * a.Ns + row0) * H, nrows * H);
   const rsrc_t xh_r = tile_rsrc(a.xh + ((size_t)t * a.Ns + row0) * 3 * H, nrows * 3 * H);
@@ -358,7 +367,8 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
     const float rs = rsqrtf(qq / (float)a.Hr + a.eps);
 #pragma unroll
     for (int k = 0; k < NF; ++k) *reinterpret_cast<f32x4*>(tile + lr * LD + (k * TPR + q) * 4) = v[k] * rs;
-    if (t == 0 && q == 0 && lr < nrows) { a.mean[row0 + lr] = mu; a.rstd[row0 + lr] = rs; }
+    // (every relation that wants the tile writes the same statistics: with source ranges relation 0 may skip it)
+    if ((t == 0 || a.src_ranges != nullptr) && q == 0 && lr < nrows) { a.mean[row0 + lr] = mu; a.rstd[row0 + lr] = rs; }
   }
   STAMP(1);
   __syncthreads();
@@ -426,6 +436,7 @@ struct PreBwdArgs {
   const float* w2tf;   // [T] fragments of W2_t^T [H, 3H]
   const float* w1tf;   // [T] fragments of W1_t^T [H, H]
   float* gn;           // [T, Ns, H]
+  const int* src_ranges;   // as in PreFwdArgs; skipped tiles contribute zero rows to gn[t]
   int Ns, T;
 };
 
@@ -443,6 +454,11 @@ __global__ __launch_bounds__(256, 2) void node_pre_bwd_kernel(PreBwdArgs a) {
   float* scr = lds + TR * LD + wave * kScrFloats;     // the chunk buffers' upper part: free once the gh tile is written
   const int nrows = min(TR, a.Ns - row0);
   const int mrow = wr * RB * 32 + (lane & 31), ch = 4 * (lane >> 5);
+  if (!tile_wanted(a.src_ranges, t, row0, TR)) {
+    float* g0 = a.gn + ((size_t)t * a.Ns + row0) * H;
+    for (int i = tid; i < nrows * (H / 4); i += 256) reinterpret_cast<f32x4*>(g0)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    return;
+  }
 
   const f32x4* w2t = reinterpret_cast<const f32x4*>(a.w2tf + (size_t)t * 3 * H * H) + lane;
   const f32x4* w1t = reinterpret_cast<const f32x4*>(a.w1tf + (size_t)t * H * H) + lane;
@@ -1125,26 +1141,27 @@ extern "C" int hermnet_debug_stamps(unsigned long long* out_host, int count) {
 extern "C" int hermnet_node_chain_supported(int hidden) { return hidden == 64 || hidden == 128 || hidden == 256; }
 
 extern "C" int hermnet_node_pre_fwd(const float* x, const float* w1_frag, const float* b1, const float* w2_frag,
-                                    const float* b2, float* hb, float* xh, float* mean, float* rstd, int num_src,
-                                    int num_rel, int hidden, int hidden_real, float eps, void* stream) {
+                                    const float* b2, float* hb, float* xh, float* mean, float* rstd,
+                                    const int* src_ranges, int num_src, int num_rel, int hidden, int hidden_real,
+                                    float eps, void* stream) {
   if (num_src < 0 || num_rel <= 0 || hidden_real > hidden) return HN_ERR_BAD_ARG;
   if (!hermnet_node_chain_supported(hidden)) return HN_ERR_BAD_ARG;
   if (num_src == 0) return HN_OK;
   if (!x || !w1_frag || !b1 || !w2_frag || !b2 || !hb || !xh || !mean || !rstd) return HN_ERR_BAD_ARG;
-  PreFwdArgs a = {x, w1_frag, b1, w2_frag, b2, hb, xh, mean, rstd, num_src, num_rel, hidden_real > 0 ? hidden_real : hidden, eps};
+  PreFwdArgs a = {x, w1_frag, b1, w2_frag, b2, hb, xh, mean, rstd, src_ranges, num_src, num_rel, hidden_real > 0 ? hidden_real : hidden, eps};
 #define HN_GRID(TR) dim3((unsigned)((num_src + TR - 1) / TR), (unsigned)num_rel)
   HN_CHAIN_DISPATCH(node_pre_fwd_kernel, HN_GRID, 1, a);
 }
 
 extern "C" int hermnet_node_pre_bwd(const float* gxh, const float* hb, const float* w2t_frag, const float* w1t_frag,
                                     float* gn_parts, const float* x, const float* mean, const float* rstd,
-                                    const float* add, float* gx, int num_src, int num_rel, int hidden, int hidden_real,
-                                    void* stream) {
+                                    const float* add, float* gx, const int* src_ranges, int num_src, int num_rel,
+                                    int hidden, int hidden_real, void* stream) {
   if (num_src < 0 || num_rel <= 0 || hidden_real > hidden) return HN_ERR_BAD_ARG;
   if (!hermnet_node_chain_supported(hidden)) return HN_ERR_BAD_ARG;
   if (num_src == 0) return HN_OK;
   if (!gxh || !hb || !w2t_frag || !w1t_frag || !gn_parts || !x || !mean || !rstd || !gx) return HN_ERR_BAD_ARG;
-  PreBwdArgs a = {gxh, hb, w2t_frag, w1t_frag, gn_parts, num_src, num_rel};
+  PreBwdArgs a = {gxh, hb, w2t_frag, w1t_frag, gn_parts, src_ranges, num_src, num_rel};
   // chunk buffers: 2 x [TR][min(H,128) + 4]
   int rc;
   switch (hidden) {

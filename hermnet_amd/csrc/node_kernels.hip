@@ -390,6 +390,44 @@ __global__ __launch_bounds__(256) void halo_accumulate_kernel(float* __restrict_
   st4(row, acc);
 }
 
+// ---- HTNet: combine a centre atom's P pair relations (DESIGN.md "HTNet") ----------------------------------------------
+// Target rows are [Te][P][B] blocks of B rows; the layer's result for the atom in row c*B + i is the MEAN over its P
+// virtual rows.  One packed pass over (x | vec): a float4 of [rows, 4H] per thread.
+//   FWD: out[c*B + i] = (1/P) sum_k in[(c*P + k)*B + i]   for rows < Te*B, zero rows behind (elements outside `elems`)
+//   BWD: gin[(c*P + k)*B + i] = gout[c*B + i] / P
+//   ACC: out[c*B + i] += (sx | sv) * sum_k in[(c*P + k)*B + i]   (the residual's gradient: the kernel-side identity
+//        term of hermnet_message_scatter_bwd is absent with virtual target rows, the host adds it summed over P)
+template <int MODE>   // 0 FWD, 1 BWD, 2 ACC
+__global__ __launch_bounds__(256) void pair_mean_kernel(const float* __restrict__ xin, const float* __restrict__ vin,
+                                                        float* __restrict__ xout, float* __restrict__ vout, int Te, int P,
+                                                        int B, int rows_out, int H, float sx, float sv) {
+  const int q4 = H;                                     // float4 per packed row of 4H floats
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long rows = MODE == 0 ? rows_out : (MODE == 1 ? (long)Te * P * B : (long)Te * B);
+  if (i >= rows * q4) return;
+  const long r = i / q4;
+  const int c = (int)(i % q4) * 4;                     // in [0, 4H)
+  const float sc = c < H ? sx : sv;
+  auto at = [&](const float* x, const float* v, long row) {
+    return c < H ? ld4(x + row * H + c) : ld4(v + row * 3 * H + (c - H));
+  };
+  float* dst = c < H ? xout + r * H + c : vout + r * 3 * H + (c - H);
+  if (MODE != 1) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < (long)Te * B) {
+      const long ce = r / B, ii = r % B;
+      for (int k = 0; k < P; ++k) acc = add4(acc, at(xin, vin, (ce * P + k) * B + ii));
+      acc = make_float4(acc.x * sc, acc.y * sc, acc.z * sc, acc.w * sc);
+    }
+    if (MODE == 2) acc = add4(acc, ld4(dst));
+    st4(dst, acc);
+  } else {
+    const long ce = r / ((long)P * B), ii = r % B;
+    const float4 g = at(xin, vin, ce * B + ii);
+    st4(dst, make_float4(g.x * sc, g.y * sc, g.z * sc, g.w * sc));
+  }
+}
+
 inline dim3 grid_for(long n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 #define HN_LAUNCH_END return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH
 
@@ -504,6 +542,25 @@ extern "C" int hermnet_energy_head_bwd(const float* ge, const float* h, const fl
   const long n4 = (long)rows * (cols / 4);
   hipLaunchKernelGGL(energy_head_bwd_kernel, grid_for(n4, 256), dim3(256), 0, (hipStream_t)stream, ge, h, w, row_mask, gh, n4,
                      cols);
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_pair_mean(int mode, const float* x_in, const float* vec_in, float* x_out, float* vec_out,
+                                 int num_elem, int pairs, int block, int rows_out, int hidden, float scale_x,
+                                 float scale_vec, void* stream) {
+  if (num_elem < 0 || pairs <= 0 || block < 0 || hidden <= 0 || (hidden & 3) || rows_out < (long)num_elem * block ||
+      mode < 0 || mode > 2)
+    return HN_ERR_BAD_ARG;
+  const long rows = mode == 0 ? (long)rows_out : (mode == 1 ? (long)num_elem * pairs * block : (long)num_elem * block);
+  if (rows == 0) return HN_OK;
+  if (!x_in || !vec_in || !x_out || !vec_out) return HN_ERR_BAD_ARG;
+  const dim3 grid = grid_for(rows * hidden, 256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(pair_mean_kernel<0>, grid, dim3(256), 0, s, x_in, vec_in, x_out, vec_out, num_elem, pairs, block, rows_out, hidden, scale_x, scale_vec); break;
+    case 1: hipLaunchKernelGGL(pair_mean_kernel<1>, grid, dim3(256), 0, s, x_in, vec_in, x_out, vec_out, num_elem, pairs, block, rows_out, hidden, scale_x, scale_vec); break;
+    default: hipLaunchKernelGGL(pair_mean_kernel<2>, grid, dim3(256), 0, s, x_in, vec_in, x_out, vec_out, num_elem, pairs, block, rows_out, hidden, scale_x, scale_vec); break;
+  }
   HN_LAUNCH_END;
 }
 

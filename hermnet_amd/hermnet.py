@@ -254,15 +254,38 @@ class HeteroTriadicConv(HeteroVertexConv):
         data = super().forward(data)                   # (x, vec) in target rows [T * P * B, ...]
         g = data._hn_graph
         P_, B_, Te = g.triadic_pairs, g.block, g.T // g.triadic_pairs
-        H = data.x.size(1)
-        x = data.x.view(Te, P_, B_, H).mean(1).reshape(Te * B_, H)
-        vec = data.vec.view(Te, P_, B_, 3, H).mean(1).reshape(Te * B_, 3, H)
-        pad = g.num_src - Te * B_                      # atoms of elements outside `elems`: zero rows (hermnet.py:51)
-        if pad > 0:
-            x = torch.cat([x, x.new_zeros(pad, H)], 0)
-            vec = torch.cat([vec, vec.new_zeros(pad, 3, H)], 0)
-        data.x, data.vec = x, vec
+        data.x, data.vec = PairMean.apply(data.x, data.vec, Te, P_, B_, g.num_src)
         return data
+
+
+class PairMean(torch.autograd.Function):
+    """(x, vec) of the [Te][P][B] virtual target rows -> their mean over P in source rows [num_src, ...]; atoms of
+    elements outside `elems` (rows behind Te*B) get zero rows (hermnet.py:51).  One launch each way on the GPU."""
+
+    @staticmethod
+    def forward(ctx, x, vec, Te, P_, B_, rows_out):
+        ctx.dims = (Te, P_, B_, rows_out)
+        if x.is_cuda:
+            from . import nodeops
+            return nodeops.pair_mean(x.contiguous(), vec.contiguous(), Te, P_, B_, rows_out)
+        H = x.size(1)
+        xo = x.new_zeros(rows_out, H)
+        vo = vec.new_zeros(rows_out, 3, H)
+        xo[:Te * B_] = x.view(Te, P_, B_, H).mean(1).reshape(Te * B_, H)
+        vo[:Te * B_] = vec.view(Te, P_, B_, 3, H).mean(1).reshape(Te * B_, 3, H)
+        return xo, vo
+
+    @staticmethod
+    def backward(ctx, gx, gvec):
+        Te, P_, B_, rows_out = ctx.dims
+        if gx.is_cuda:
+            from . import nodeops
+            gxi, gvi = nodeops.pair_mean(gx.contiguous(), gvec.contiguous(), Te, P_, B_, rows_out, backward=True)
+            return gxi, gvi, None, None, None, None
+        H = gx.size(1)
+        gxi = (gx[:Te * B_].view(Te, 1, B_, H) / P_).expand(Te, P_, B_, H).reshape(Te * P_ * B_, H)
+        gvi = (gvec[:Te * B_].view(Te, 1, B_, 3, H) / P_).expand(Te, P_, B_, 3, H).reshape(Te * P_ * B_, 3, H)
+        return gxi, gvi, None, None, None, None
 
 
 class HTNet(HVNet):

@@ -220,7 +220,7 @@ class FusedRelationalLayer(torch.autograd.Function):
         ctx.chain = w.chain and _node_chain_enabled()
         if ctx.chain:
             # three launches: node_pre_fwd (LayerNorm + x_proj of every relation), the message kernel, node_update_fwd
-            hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T)
+            hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges)
             x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False)
             x_out, vec_out, vp, h2b, q23, nrm = nodeops.node_update_fwd(x1, vec1, w, graph)
             ctx.save_for_backward(x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23, nrm)
@@ -325,13 +325,16 @@ class FusedRelationalLayer(torch.autograd.Function):
             # HTNet: the residual (rmnet.py:24-26) reads the atom's own row from each of its P virtual target rows;
             # its gradient returns as the sum over those rows (the kernel adds no identity term in this mode)
             P_, B_, Te = graph.triadic_pairs, graph.block, graph.T // graph.triadic_pairs
-            gx_in[:Te * B_] += gx1.view(Te, P_, B_, H).sum(1).reshape(Te * B_, H) * (0.5 ** 0.5)
-            if gvec_in is not None:
-                gvec_in[:Te * B_] += gvec1.view(Te, P_, B_, 3, H).sum(1).reshape(Te * B_, 3, H)
+            if gx_in.is_cuda and gvec_in is not None:
+                nodeops.pair_sum_accumulate(gx1, gvec1, gx_in, gvec_in, Te, P_, B_, 0.5 ** 0.5, 1.0)
+            else:
+                gx_in[:Te * B_] += gx1.view(Te, P_, B_, H).sum(1).reshape(Te * B_, H) * (0.5 ** 0.5)
+                if gvec_in is not None:
+                    gvec_in[:Te * B_] += gvec1.view(Te, P_, B_, 3, H).sum(1).reshape(Te * B_, 3, H)
         gx_total = None
         if ctx.needs_input_grad[0]:
             if ctx.chain:
-                gx_total = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in)
+                gx_total = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, src_ranges=graph.src_ranges)
             else:
                 ga = _launch("gemm", lambda: torch.bmm(gxh, w.w2))                                            # [T, Ns, H]
                 gh = nodeops.ssilu_bwd(ga, h, Ns, T, H, H, Ns * H)                   # [Ns, T*H]

@@ -99,6 +99,28 @@ def energy_head_bwd(ge, h, w, mask=None):
     return gh
 
 
+def pair_mean(x, vec, Te, P_, B, rows_out, backward=False):
+    """HTNet: mean over a centre atom's P virtual target rows (backward=False: [Te*P*B, ...] -> [rows_out, ...], zero
+    rows behind Te*B) or its gradient (backward=True: [rows_out, ...] -> [Te*P*B, ...])."""
+    H = x.size(1)
+    rows = Te * P_ * B if backward else rows_out
+    xo = torch.empty(rows, H, dtype=x.dtype, device=x.device)
+    vo = torch.empty(rows, 3, H, dtype=x.dtype, device=x.device)
+    _lib.check(_launch("pair_mean", lambda: _lib.load().hermnet_pair_mean(
+        1 if backward else 0, P(x), P(vec), P(xo), P(vo), Te, P_, B, rows_out, H, 1.0 / P_, 1.0 / P_, _stream())),
+        "hermnet_pair_mean")
+    return xo, vo
+
+
+def pair_sum_accumulate(x, vec, x_acc, vec_acc, Te, P_, B, scale_x, scale_vec):
+    """x_acc[c*B + i] += scale_x * sum_k x[(c*P + k)*B + i] (and vec likewise): the residual's gradient of HTNet's virtual
+    target rows, one launch."""
+    H = x.size(1)
+    _lib.check(_launch("pair_sum", lambda: _lib.load().hermnet_pair_mean(
+        2, P(x), P(vec), P(x_acc), P(vec_acc), Te, P_, B, x_acc.size(0), H, scale_x, scale_vec, _stream())),
+        "hermnet_pair_mean")
+
+
 def halo_rows(mode, x, vec, idx, buf=None):
     """Packed halo rows [n, 4H] = [x | vec] of the rows `idx` (int64): mode 0 pack, 1 pack-and-clear, 2 unpack,
     3 accumulate (see include/hermnet_hip.h).  Returns `buf` (allocated for the packing modes)."""
@@ -147,27 +169,29 @@ def _rowptr_host(graph):
     return c
 
 
-def node_pre_fwd(x, w, T):
-    """x [Ns,H] -> (hb [T,Ns,H], xh [T,Ns,3H] incl. bias, mean [Ns], rstd [Ns])  (rmnet.py:52 for every relation)."""
+def node_pre_fwd(x, w, T, src_ranges=None):
+    """x [Ns,H] -> (hb [T,Ns,H], xh [T,Ns,3H] incl. bias, mean [Ns], rstd [Ns])  (rmnet.py:52 for every relation).
+    `src_ranges` [T,4] int32 (HTNet): the two source-row ranges a relation gathers from; other rows are skipped."""
     Ns, H = x.shape
     dev, dt = x.device, x.dtype
     hb = torch.empty(T, Ns, H, dtype=dt, device=dev)
     xh = torch.empty(T, Ns, 3 * H, dtype=dt, device=dev)
-    mean = torch.empty(Ns, dtype=dt, device=dev)
-    rstd = torch.empty(Ns, dtype=dt, device=dev)
+    alloc = torch.empty if src_ranges is None else torch.zeros      # rows no relation wants keep (0, 0): finite
+    mean = alloc(Ns, dtype=dt, device=dev)
+    rstd = alloc(Ns, dtype=dt, device=dev)
     _lib.check(_launch("node_pre_fwd", lambda: _lib.load().hermnet_node_pre_fwd(
-        P(x), P(w.w1f), P(w.b1cat), P(w.w2f), P(w.b2), P(hb), P(xh), P(mean), P(rstd), Ns, T, H, w.h_real, 1e-5,
-        _stream())), "hermnet_node_pre_fwd")
+        P(x), P(w.w1f), P(w.b1cat), P(w.w2f), P(w.b2), P(hb), P(xh), P(mean), P(rstd), P(src_ranges), Ns, T, H, w.h_real,
+        1e-5, _stream())), "hermnet_node_pre_fwd")
     return hb, xh, mean, rstd
 
 
-def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None):
+def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None, src_ranges=None):
     """Gradient of node_pre_fwd w.r.t. x (+ add)."""
     T, Ns, H = hb.shape
     parts = torch.empty(T, Ns, H, dtype=x.dtype, device=x.device)
     gx = torch.empty_like(x)
     _lib.check(_launch("node_pre_bwd", lambda: _lib.load().hermnet_node_pre_bwd(
-        P(gxh), P(hb), P(w.w2tf), P(w.w1tf), P(parts), P(x), P(mean), P(rstd), P(add), P(gx), Ns, T, H, w.h_real,
+        P(gxh), P(hb), P(w.w2tf), P(w.w1tf), P(parts), P(x), P(mean), P(rstd), P(add), P(gx), P(src_ranges), Ns, T, H, w.h_real,
         _stream())), "hermnet_node_pre_bwd")
     return gx
 

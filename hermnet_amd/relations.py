@@ -49,7 +49,7 @@ class RelationalGraph(object):
                  "type_rowptr", "type_rowptr_host", "csr_rowptr", "csr_src", "csr_perm", "csc_rowptr", "csc_tgt",
                  "csc_pos", "out_rowptr", "out_edges", "src_id", "tgt_id", "shift", "row_active", "row_real",
                  "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device", "_cstruct", "_rel_bounds",
-                 "edge_table", "num_src", "res_row", "triadic_pairs", "src_real", "_rowptr_c")
+                 "edge_table", "num_src", "res_row", "triadic_pairs", "src_real", "_rowptr_c", "src_ranges")
 
     def __init__(self):
         self._cstruct = None
@@ -60,6 +60,7 @@ class RelationalGraph(object):
         self.res_row = None        # [N] int32 source row feeding the residual of each target row, or None
         self.triadic_pairs = 0     # HTNet: pair relations per centre element (target rows = T_elem * pairs * block)
         self.src_real = None       # HTNet: [num_src] 1 for source rows that hold an atom
+        self.src_ranges = None     # HTNet: [T,4] int32, the two source-row ranges a relation gathers from (nodeops.node_pre_fwd)
 
     def rel_edge_bounds(self):
         """CSR edge ranges of the relations: edges of relation t are [b[t], b[t+1]) (rows are relation-ordered and
@@ -362,6 +363,10 @@ class RelationalGraph(object):
         rel_edges = csr_rowptr[tn[1:]] - csr_rowptr[tn[:-1]] if TR > 0 else torch.zeros(0, dtype=torch.long, device=dev)
         g.row_active = (rel_edges > 0)[r_rel].float() * row_real if Nt > 0 else row_real
         g.res_row = (r_el * B + r_loc).to(i32)
+        # relation (c; p, q) gathers sources of elements p and q only: the x_proj chain skips the other rows
+        g.src_ranges = _cached_i32(tuple(v for _c in range(T) for (p_, q_) in pairs
+                                         for v in (p_ * B, p_ * B + cnt_host[p_], (q_ * B if q_ != p_ else 0),
+                                                   (q_ * B + cnt_host[q_] if q_ != p_ else 0))), dev).view(TR, 4)
         g.batch32 = None if batch is None else batch.to(i32).contiguous()
         g.batch_rows = None
         if batch is not None and g.num_graphs > 1:

@@ -279,16 +279,21 @@ int hermnet_energy_head_bwd(const float* ge, const float* h, const float* w, con
  *     xh[t] = ScaledSiLU(hb[t]) W2_t^T + b2_t      [T, num_src, 3H]   (bias INCLUDED: pass xh_bias = NULL to the
  *                                                                       message kernels)
  *     mean, rstd [num_src]: the LayerNorm statistics.
+ *     src_ranges (device, [T][4] int32, or NULL = every row): relation t only ever gathers source rows [r0, r1) and
+ *     [r2, r3) (HTNet: relation (c; p, q) gathers atoms of elements p and q); 64-row tiles outside both ranges are
+ *     skipped -- their rows of hb / xh are left unwritten, their statistics must be pre-set by the caller (zeros), and
+ *     the backward contributes zero for them.
  * hermnet_node_pre_bwd: gx = LayerNorm'(x)^T sum_t ((gxh[t] W2_t) * ScaledSiLU'(hb[t])) W1_t + add
  *     (w2t_frag = frag(W2_t^T [H, 3H]), w1t_frag = frag(W1_t^T [H, H]); gn_parts [T, num_src, H] is workspace; add may
  *     be NULL; gx may alias add). */
 int hermnet_node_chain_supported(int hidden);
 int hermnet_node_pre_fwd(const float* x, const float* w1_frag, const float* b1, const float* w2_frag, const float* b2,
-                         float* hb, float* xh, float* mean, float* rstd, int num_src, int num_rel, int hidden,
-                         int hidden_real, float eps, void* stream);
+                         float* hb, float* xh, float* mean, float* rstd, const int* src_ranges, int num_src,
+                         int num_rel, int hidden, int hidden_real, float eps, void* stream);
 int hermnet_node_pre_bwd(const float* gxh, const float* hb, const float* w2t_frag, const float* w1t_frag,
                          float* gn_parts, const float* x, const float* mean, const float* rstd, const float* add,
-                         float* gx, int num_src, int num_rel, int hidden, int hidden_real, void* stream);
+                         float* gx, const int* src_ranges, int num_src, int num_rel, int hidden, int hidden_real,
+                         void* stream);
 /* hermnet_node_update_fwd (rmnet.py:94-107, 29-31; hermnet.py:51,56-61), target rows in relation order:
  *     vp = vec1 Wv^T  [N,3,2H] = (v1 | v2), saved;   vdot = sum_d v1 v2 / sqrt(H);   n = sqrt(sum_d v2^2 + 1e-8) -> nrm
  *                                                                                    [N,H], saved
@@ -308,6 +313,18 @@ int hermnet_node_update_bwd(const float* gx_out, const float* gvec_out, const fl
                             const float* wvt_frag,
                             const float* row_active, const int* type_rowptr, const int* type_rowptr_host, float* gx1,
                             float* gvec1, int num_nodes, int num_rel, int hidden, void* stream);
+
+/* HTNet (hermnet.py:155-157 is a stub; DESIGN.md "HTNet"): a centre atom's P pair relations are averaged.  Target rows
+ * are [num_elem][pairs][block] blocks of `block` rows ("virtual" rows, one per atom and pair relation):
+ *   mode 0:  x_out [rows_out,H], vec_out [rows_out,3,H]: row c*block + i = scale * sum_k in[(c*pairs + k)*block + i]
+ *            (scale_x for x, scale_vec for vec; the mean: 1/pairs), rows >= num_elem*block are written as zero (atoms
+ *            of elements outside `elems`, hermnet.py:51)
+ *   mode 1:  x_out / vec_out [num_elem*pairs*block, ...] = the gradient w.r.t. the virtual rows: scale * in[c*block + i]
+ *            (x_in / vec_in then hold the [rows_out, ...] gradient)
+ *   mode 2:  as mode 0 for the rows < num_elem*block, ACCUMULATED into x_out / vec_out (the residual's gradient summed
+ *            over a centre's virtual rows: scale_x = 1/sqrt(2), scale_vec = 1, rmnet.py:24-26). */
+int hermnet_pair_mean(int mode, const float* x_in, const float* vec_in, float* x_out, float* vec_out, int num_elem,
+                      int pairs, int block, int rows_out, int hidden, float scale_x, float scale_vec, void* stream);
 
 /* Halo exchange packing for atom-sharded runs (one process per GPU; the exchange itself is an RCCL all-to-all made
  * by the host code, hermnet_amd/sharding.py).  A packed row = [ x (H) | vec (3H) ]; idx [n] (int64) holds rows.

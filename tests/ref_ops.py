@@ -190,7 +190,7 @@ def update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, rows, H):
 
 
 # ---- node chain kernels (hermnet_amd.nodeops.node_*; csrc/node_chain.hip): same contracts, plain weights of `w` --------
-def node_pre_fwd(x, w, T):
+def node_pre_fwd(x, w, T, src_ranges=None):
     Ns, H = x.shape
     dt = x.dtype
     n, mean, rstd = layernorm_fwd(x, 1e-5, h_real=w.h_real)
@@ -200,7 +200,7 @@ def node_pre_fwd(x, w, T):
     return hb, xh, mean, rstd
 
 
-def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None):
+def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None, src_ranges=None):
     T, Ns, H = hb.shape
     dt = x.dtype
     gh = torch.bmm(gxh, w.w2.to(dt)) * _dssilu(hb)                                                   # [T, Ns, H]
