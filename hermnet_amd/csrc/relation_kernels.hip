@@ -308,6 +308,87 @@ __global__ __launch_bounds__(kBlock) void csc_tgt2_kernel(const int* __restrict_
   if (k < n) csc_tgt[k] = rt_csr[csc_pos[k]];
 }
 
+// ---- fused edge orders (round 3): both histograms in one pass over the edge list, ONE scan over the concatenated
+// counters [ row(target) : N + 1 | relation(target) * N + row(source) : (T + 1) N + 1 ], the CSC scatter inside the CSR
+// gather, csc_tgt inside the CSC rank sort: 10 launches instead of 21 for the same (bit-identical) orders.
+__global__ __launch_bounds__(kBlock) void edge_keys_hist_kernel(const long* __restrict__ edge_index, int E,
+                                                               const int* __restrict__ row_of_node,
+                                                               const int* __restrict__ row_start, int T, int N,
+                                                               int* __restrict__ key1, int* __restrict__ key2,
+                                                               int* __restrict__ hist) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int rs = row_of_node[edge_index[e]], rt = row_of_node[edge_index[(size_t)E + e]];
+  const int k2 = relation_of_row(rt, row_start, T) * N + rs;        // == T*N + rs for unknown-element targets
+  key1[e] = rt;
+  key2[e] = k2;
+  atomicAdd(&hist[rt], 1);
+  atomicAdd(&hist[N + 1 + k2], 1);
+}
+
+// scan_apply for the concatenated counters: the running offsets go to `all` (cursor copy for the scatters) and, in
+// their final form, straight to csr_rowptr [N + 1] and csc_rowptr [T N + 1] (second part: minus the E edges in front)
+__global__ __launch_bounds__(kBlock) void scan_apply_orders_kernel(const int* __restrict__ in, int n, const int* __restrict__ sums,
+                                                                  int* __restrict__ all, int N, int T, int E,
+                                                                  int* __restrict__ csr_rowptr, int* __restrict__ csc_rowptr) {
+  __shared__ int lds[4];
+  const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  int x[4], v = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { x[q] = (base + q < n) ? in[base + q] : 0; v += x[q]; }
+  int total;
+  int run = block_exclusive_scan(v, lds, total) + sums[blockIdx.x];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = base + q;
+    if (i < n) {
+      all[i] = run;
+      if (i <= N) csr_rowptr[i] = run;
+      else if (i - (N + 1) <= T * N) csc_rowptr[i - (N + 1)] = run - E;
+    }
+    run += x[q];
+  }
+}
+
+// CSR-ordered per-edge arrays, and the scatter of the CSR positions into their CSC groups
+__global__ __launch_bounds__(kBlock) void csr_gather_scatter_kernel(
+    const long* __restrict__ edge_index, const float* __restrict__ shift, int E, int N,
+    const int* __restrict__ row_of_node, const int* __restrict__ csr_perm, const int* __restrict__ key2,
+    int* __restrict__ csr_src, int* __restrict__ src_id, int* __restrict__ tgt_id, float* __restrict__ shift_csr,
+    int* __restrict__ rt_csr, int* __restrict__ cursor2 /* counters of the second part */, int* __restrict__ slots2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= E) return;
+  const int e = csr_perm[k];
+  const int s = (int)edge_index[e], t = (int)edge_index[(size_t)E + e];
+  csr_src[k] = row_of_node[s];
+  src_id[k] = s;
+  tgt_id[k] = t;
+  rt_csr[k] = row_of_node[t];
+  if (shift != nullptr) {
+    shift_csr[3 * k + 0] = shift[3 * e + 0];
+    shift_csr[3 * k + 1] = shift[3 * e + 1];
+    shift_csr[3 * k + 2] = shift[3 * e + 2];
+  }
+  slots2[atomicAdd(&cursor2[key2[e]], 1) - E] = k;
+}
+
+// rank sort of the CSC groups (group g = [rp[g] - E, rp[g+1] - E) of the concatenated scan) + csc_tgt
+__global__ __launch_bounds__(kBlock) void csc_rank_sort_kernel(const int* __restrict__ rp2, int E, int ngroups,
+                                                              const int* __restrict__ slots, const int* __restrict__ rt_csr,
+                                                              int* __restrict__ csc_pos, int* __restrict__ csc_tgt) {
+  const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (g >= ngroups) return;
+  const int lane = threadIdx.x & 63;
+  const int beg = rp2[g] - E, end = rp2[g + 1] - E;
+  for (int a = beg + lane; a < end; a += 64) {
+    const int v = slots[a];
+    int rank = 0;
+    for (int b = beg; b < end; ++b) rank += slots[b] < v ? 1 : 0;
+    csc_pos[beg + rank] = v;
+    csc_tgt[beg + rank] = rt_csr[v];
+  }
+}
+
 int bits_for(unsigned max_key_exclusive) {
   int b = 1;
   while (b < 32 && (1u << b) < max_key_exclusive) ++b;
@@ -347,13 +428,14 @@ extern "C" size_t hermnet_build_relations_workspace(int num_atoms, int num_rows,
   const size_t n = (size_t)(num_edges > num_atoms ? num_edges : num_atoms) + 1;
   const size_t nk = (size_t)(num_rel + 1) * (size_t)num_rows + 2;
   // 5 index buffers of n + cursor and full CSC row pointer of (T+1)*N + sort/scan storage
-  return align256(work_temp_bytes((int)n, (int)nk)) + 5 * align256(n * sizeof(unsigned)) + 2 * align256(nk * sizeof(int)) + 256;
+  const size_t nall = nk + (size_t)num_rows + 4;     // concatenated counters of both edge orders
+  return align256(work_temp_bytes((int)n, (int)nall)) + 5 * align256(n * sizeof(unsigned)) + 2 * align256(nall * sizeof(int)) + 256;
 }
 
 extern "C" int hermnet_build_relations(const long* atomic_number, const long* edge_index, const float* shift,
                                        int num_atoms, int num_edges, const int* z_list, int num_rel,
                                        const int* row_start, int num_rows,
-                                       const unsigned char* rel_active, const hn_relations_out* out,
+                                       const unsigned char* rel_active, const hn_relations_out* out, int rows_ready,
                                        void* workspace, size_t workspace_bytes, void* stream) {
   const int NA = num_atoms, E = num_edges, T = num_rel, N = num_rows;
   if (NA < 0 || E < 0 || T <= 0 || N < NA || !out || !z_list || !row_start) return HN_ERR_BAD_ARG;
@@ -362,7 +444,7 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t n = (size_t)(E > NA ? E : NA) + 1;
   char* w = reinterpret_cast<char*>(workspace);
-  const size_t tb = align256(work_temp_bytes((int)n, (int)((size_t)(T + 1) * N + 2)));
+  const size_t tb = align256(work_temp_bytes((int)n, (int)((size_t)(T + 1) * N + 2 + (size_t)N + 4)));
   void* temp = w; w += tb;
   unsigned* keyA = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
   unsigned* keyB = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
@@ -371,7 +453,9 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
   unsigned* rt_sorted = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
   size_t tbytes = tb;
 
-  // ---- rows
+  // ---- rows (rows_ready: node_order / row_of_node / z_rows / row_real of `out` were filled by an earlier call with
+  // the same atomic numbers and row layout -- they depend on nothing else)
+  if (!rows_ready) {
   hipLaunchKernelGGL(zero_i32_kernel, grid_for(N), dim3(kBlock), 0, s, out->z_rows, (long)N);
   hipLaunchKernelGGL(zero_i32_kernel, grid_for(N), dim3(kBlock), 0, s, reinterpret_cast<int*>(out->row_real), (long)N);
   if (NA > 0) {
@@ -381,37 +465,58 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
     hipLaunchKernelGGL(assign_rows_kernel, grid_for(NA), dim3(kBlock), 0, s, keyB, out->node_order, NA, row_start,
                        T, atomic_number, out->row_of_node, out->z_rows, out->row_real);
   }
-  // ---- edge orders by counting sort (see group_by_key)
-  int* ikeyA = reinterpret_cast<int*>(keyA);
-  int* ikey2 = reinterpret_cast<int*>(keyB);
-  int* ikey3 = reinterpret_cast<int*>(key3);
+  }
+  // ---- edge orders by counting sort (histogram -> scan -> scatter -> per-group rank sort; see the kernels above)
+  int* key1 = reinterpret_cast<int*>(keyA);
+  int* key2 = reinterpret_cast<int*>(keyB);
+  int* slots = valA;
   int* rt_csr = reinterpret_cast<int*>(rt_sorted);
-  GroupWork gw;
-  gw.slots = valA;
-  gw.cursor = reinterpret_cast<int*>(w); w += align256(sizeof(int) * ((size_t)(T + 1) * N + 2));
-  int* csc_rowptr_full = reinterpret_cast<int*>(w); w += align256(sizeof(int) * ((size_t)(T + 1) * N + 2));
-  gw.scan_temp = temp;
-  gw.scan_bytes = tb;
-  int rcg;
-  // CSR: edges grouped by row(target), ascending edge id
+  const size_t nall = (size_t)(N + 1) + (size_t)(T + 1) * N + 1;            // concatenated counters
+  int* hist = reinterpret_cast<int*>(w); w += align256(sizeof(int) * (nall + 2));
+  int* rp_all = reinterpret_cast<int*>(w); w += align256(sizeof(int) * (nall + 2));
+  int* cursor = hist;                                                       // the counters become the scatter cursors
+  const bool want_out = out->out_rowptr != nullptr && out->out_edges != nullptr;
+  hipLaunchKernelGGL(zero_i32_kernel, grid_for((long)nall), dim3(kBlock), 0, s, hist, (long)nall);
   if (E > 0)
-    hipLaunchKernelGGL(edge_target_row_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, E, out->row_of_node, ikeyA);
-  if ((rcg = group_by_key(ikeyA, E, N, out->csr_rowptr, out->csr_perm, gw, s)) != HN_OK) return rcg;
-  if (E > 0)
-    hipLaunchKernelGGL(csr_gather2_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, shift, E, N, T, out->row_of_node,
-                       row_start, out->csr_perm, out->csr_src, out->src_id, out->tgt_id, out->shift_csr, rt_csr, ikey2,
-                       ikey3);
-  // CSC: CSR positions grouped by (relation(target), row(source)); edges to unknown-element targets fall
-  // into the extra key range [T*N, (T+1)*N) and are simply not covered by csc_rowptr[0 .. T*N]
-  if ((rcg = group_by_key(ikey2, E, (T + 1) * N, csc_rowptr_full, out->csc_pos, gw, s)) != HN_OK) return rcg;
-  hipLaunchKernelGGL(copy_i32_kernel, grid_for((long)T * N + 1), dim3(kBlock), 0, s, csc_rowptr_full, T * N + 1,
-                     out->csc_rowptr);
-  if (E > 0)
-    hipLaunchKernelGGL(csc_tgt2_kernel, grid_for(E), dim3(kBlock), 0, s, rt_csr, out->csc_pos, E, out->csc_tgt);
-  // out adjacency: CSR positions grouped by row(source) -- optional: hermnet_edge_geometry_bwd_csc reads the
-  // same information from the CSC order
-  if (out->out_rowptr != nullptr && out->out_edges != nullptr)
+    hipLaunchKernelGGL(edge_keys_hist_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, E, out->row_of_node, row_start, T,
+                       N, key1, key2, hist);
+  {
+    const int n = (int)nall, nb = (n + kScanTile - 1) / kScanTile;
+    int* sums = reinterpret_cast<int*>(temp);
+    if (tb < scan_temp_bytes(n)) return HN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(kBlock), 0, s, hist, n, sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, s, sums, nb);
+    hipLaunchKernelGGL(scan_apply_orders_kernel, dim3(nb), dim3(kBlock), 0, s, hist, n, sums, rp_all, N, T, E, out->csr_rowptr,
+                       out->csc_rowptr);
+  }
+  if (E > 0) {
+    // (the scan wrote its offsets to rp_all; the scatters advance a copy: hist is reused for it)
+    hipLaunchKernelGGL(copy_i32_kernel, grid_for((long)nall), dim3(kBlock), 0, s, rp_all, (int)nall, cursor);
+    // CSR: edges grouped by row(target), ascending edge id inside a row
+    hipLaunchKernelGGL(scatter_kernel, grid_for(E), dim3(kBlock), 0, s, key1, E, cursor, slots);
+    hipLaunchKernelGGL(group_rank_sort_kernel, dim3((unsigned)((N + 3) / 4)), dim3(kBlock), 0, s, rp_all, N, slots, out->csr_perm);
+    // CSC: CSR positions grouped by (relation(target), row(source)); edges to unknown-element targets fall into the extra
+    // key range [T*N, (T+1)*N) and are simply not covered by csc_rowptr[0 .. T*N]
+    hipLaunchKernelGGL(csr_gather_scatter_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, shift, E, N, out->row_of_node,
+                       out->csr_perm, key2, out->csr_src, out->src_id, out->tgt_id, out->shift_csr, rt_csr, cursor + N + 1,
+                       slots);
+    const int ng2 = (T + 1) * N;
+    hipLaunchKernelGGL(csc_rank_sort_kernel, dim3((unsigned)((ng2 + 3) / 4)), dim3(kBlock), 0, s, rp_all + N + 1, E, ng2, slots,
+                       rt_csr, out->csc_pos, out->csc_tgt);
+  }
+  // out adjacency: CSR positions grouped by row(source) -- optional: hermnet_edge_geometry_bwd_csc reads the same
+  // information from the CSC order
+  if (want_out) {
+    GroupWork gw;
+    gw.slots = slots;
+    gw.cursor = hist;
+    gw.scan_temp = temp;
+    gw.scan_bytes = tb;
+    int* ikey3 = reinterpret_cast<int*>(key3);
+    if (E > 0) hipLaunchKernelGGL(copy_i32_kernel, grid_for(E), dim3(kBlock), 0, s, out->csr_src, E, ikey3);
+    int rcg;
     if ((rcg = group_by_key(ikey3, E, N, out->out_rowptr, out->out_edges, gw, s)) != HN_OK) return rcg;
+  }
   hipLaunchKernelGGL(row_active_kernel, grid_for(N), dim3(kBlock), 0, s, out->csc_rowptr, row_start, N, T,
                      rel_active, out->row_real, out->row_active);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;

@@ -127,17 +127,22 @@ class RelationalGraph(object):
             _lib.check(lib.hermnet_relation_counts(P(z), NA, P(zl), T, P(counts), _stream()), "hermnet_relation_counts")
             nb = batch.long().max().reshape(1) + 1 if (batch is not None and NA > 0) else torch.ones(1, dtype=torch.long, device=dev)
             host = torch.cat([counts.long(), nb]).cpu().tolist()
-            hit = (zl, host[:T + 1], int(host[-1]), z)
+            hit = (zl, host[:T + 1], int(host[-1]), z, {})
             _COUNT_CACHE.insert(0, (atomic_number, atomic_number._version, batch,
                                     None if batch is None else batch._version, tuple(z_list), hit))
             del _COUNT_CACHE[8:]
-        zl, cnt_host, g.num_graphs, z = hit
+        zl, cnt_host, g.num_graphs, z = hit[:4]
+        rows_cache = hit[4]                   # {(uniform layout key): row arrays}: they depend on the atoms only
         g.uniform, g.block, starts, N = RelationalGraph._layout(cnt_host, T, uniform)
         g.N, g.type_rowptr_host = N, starts[:T + 1]
         g.type_rowptr = _cached_i32(tuple(starts[:T + 1]), dev)
         e32 = lambda n: torch.empty(n, dtype=i32, device=dev)
-        g.node_order, g.row_of_node, z_rows = e32(NA), e32(NA), e32(N)
-        g.row_real = torch.empty(N, dtype=torch.float32, device=dev)
+        rows = rows_cache.get((g.uniform, N))
+        rows_ready = rows is not None
+        if rows is None:
+            rows = dict(node_order=e32(NA), row_of_node=e32(NA), z_rows=e32(N),
+                        row_real=torch.empty(N, dtype=torch.float32, device=dev))
+        g.row_real = rows["row_real"]
         g.row_active = torch.empty(N, dtype=torch.float32, device=dev)
         g.csr_rowptr, g.csr_src, g.csr_perm, g.src_id, g.tgt_id = e32(N + 1), e32(E), e32(E), e32(E), e32(E)
         g.csc_rowptr, g.csc_tgt, g.csc_pos = e32(T * N + 1), e32(E), e32(E)
@@ -148,16 +153,23 @@ class RelationalGraph(object):
         act = None if rel_active is None else _cached_u8(tuple(bool(a) for a in rel_active), dev)
         wbytes = lib.hermnet_build_relations_workspace(NA, N, E, T)
         work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-        out = _lib.RelationsOut(P(g.node_order), P(g.row_of_node), P(z_rows), P(g.row_real), P(g.row_active),
+        out = _lib.RelationsOut(P(rows["node_order"]), P(rows["row_of_node"]), P(rows["z_rows"]), P(g.row_real), P(g.row_active),
                                 P(g.csr_rowptr), P(g.csr_src), P(g.csr_perm), P(g.src_id), P(g.tgt_id), P(g.shift),
                                 P(g.csc_rowptr), P(g.csc_tgt), P(g.csc_pos), P(g.out_rowptr), P(g.out_edges))
         _lib.check(lib.hermnet_build_relations(P(z), P(ei), P(shift), NA, E, P(zl), T, P(g.type_rowptr), N, P(act),
-                                               ctypes.byref(out), P(work), wbytes, _stream()),
+                                               ctypes.byref(out), 1 if rows_ready else 0, P(work), wbytes, _stream()),
                    "hermnet_build_relations")
-        g.z_rows = z_rows.long()
-        g.row_of_node = g.row_of_node.long()      # used as a gather index by the host code
-        g.node_order = g.node_order.long()
-        g.batch32 = None if batch is None else batch.to(i32).contiguous()
+        if not rows_ready:
+            # int64 copies for the host code's gathers (embedding, index_select), made once per atom set
+            rows["z_rows64"] = rows["z_rows"].long()
+            rows["row_of_node64"] = rows["row_of_node"].long()
+            rows["node_order64"] = rows["node_order"].long()
+            rows["batch32"] = None if batch is None else batch.to(i32).contiguous()
+            if len(rows_cache) > 4:
+                rows_cache.clear()
+            rows_cache[(g.uniform, N)] = rows
+        g.z_rows, g.row_of_node, g.node_order = rows["z_rows64"], rows["row_of_node64"], rows["node_order64"]
+        g.batch32 = rows["batch32"]
         g.batch_rows = None
         if batch is not None and g.num_graphs > 1:
             g.graph_perm = torch.argsort(batch.long(), stable=True)

@@ -131,11 +131,15 @@ int hermnet_relation_counts(const long* atomic_number, int num_atoms, const int*
                             int* counts, void* stream);
 size_t hermnet_build_relations_workspace(int num_atoms, int num_rows, int num_edges, int num_rel);
 /* edge_index [2,E] int64 (row 0 = source, row 1 = target, hermnet.py:135); shift [E,3] or NULL;
- * rel_active [T] bytes or NULL (NULL: a relation is active iff it receives at least one edge). */
+ * rel_active [T] bytes or NULL (NULL: a relation is active iff it receives at least one edge).
+ * rows_ready != 0: `out->node_order / row_of_node / z_rows / row_real` already hold the row layout of these atomic
+ * numbers (they depend on atomic_number, z_list and row_start only, not on the edges: a caller that evaluates the same
+ * atoms again -- every MD step -- passes the arrays of its previous call); only the edge orders are built. */
 int hermnet_build_relations(const long* atomic_number, const long* edge_index, const float* shift,
                             int num_atoms, int num_edges, const int* z_list, int num_rel,
                             const int* row_start, int num_rows, const unsigned char* rel_active,
-                            const hn_relations_out* out, void* workspace, size_t workspace_bytes, void* stream);
+                            const hn_relations_out* out, int rows_ready, void* workspace, size_t workspace_bytes,
+                            void* stream);
 
 /* ---- A2: HVNet.with_edge (hermnet.py:133-152) -------------------------------------------
  * edge[e] = (rx, ry, rz, d) for CSR edge e, D = pos[src] - pos[tgt] (+ shift @ cell[batch[src]]),
