@@ -8,8 +8,13 @@
 // (strict), no (i, i, 0), self images allowed, output sorted by (i, j, Sx, Sy, Sz); float64
 // arithmetic on the float32 coordinates.
 //
-// Pipeline: wrap + bin (fractional bins >= rc wide) -> sort atoms by bin -> count pairs per atom
-// -> exclusive scan -> fill -> one radix sort of 64-bit (i, j, S) keys.  Integer/streaming work.
+// Pipeline: wrap + bin (fractional bins >= rc wide) -> sort atoms by bin -> ONE pass over the candidates that counts
+// an atom's pairs and stashes their 64-bit (i, j, S) keys in a per-atom slot of kStash entries -> exclusive scan ->
+// (host reads E) -> per-atom rank sort of the stashed keys, decoded straight into edge_index / edge_shift.
+// Round 3: the keys of an atom are written by its own wave, so the list is already grouped by i and only needs
+// ordering INSIDE an atom (tens of entries): the global radix sort of E 64-bit keys (0.16 ms at 431k pairs) and the
+// second pass over the candidates (0.07 ms) are gone.  An atom with more than kStash pairs makes the caller take the
+// two-pass form (count, then fill).  Integer/streaming work.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
@@ -20,6 +25,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kMaxImg = 8;                 // |S| per axis after un-wrapping must stay below this
 constexpr int kCode = 2 * kMaxImg + 1;     // 17 values per axis
+constexpr int kStash = 160;                // keys kept per atom by the counting pass (fcc at rc = 5 A: 43)
 inline dim3 grid_for(long n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 struct NbrGeom {
@@ -85,9 +91,10 @@ __global__ __launch_bounds__(kBlock) void nbr_binstart_kernel(const unsigned* __
   start[r] = lo;
 }
 
-// Visit every candidate (j, image) of atom i; FILL = false counts, FILL = true writes 64-bit keys
+// Visit every candidate (j, image) of atom i.  MODE 0 counts and stashes the keys at keys[i * kStash ...] (flags: bit 0
+// |S| overflow, bit 1 an atom with more than kStash pairs), MODE 1 writes the keys at keys[offset[i] ...] (two-pass form).
 // key = ((i * N + j) * 17^3 + code(S)),  S = image - wrap_j + wrap_i (shift for the caller's coordinates).
-template <bool FILL>
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restrict__ fw, const int* __restrict__ wrap,
                                                           const int* __restrict__ sorted_ids,
                                                           const int* __restrict__ bin_start, int N, NbrGeom g,
@@ -108,7 +115,8 @@ __global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restr
     if (g.periodic) bk = (int)(fi[k] * g.nbins[k]); else bk = (int)((fi[k] - g.lo[k]) * g.inv[4 * k]);
     bi[k] = bk < 0 ? 0 : (bk >= g.nbins[k] ? g.nbins[k] - 1 : bk);
   }
-  long out = FILL ? offset[i] : 0;
+  constexpr bool FILL = MODE == 1;
+  long out = FILL ? offset[i] : (long)i * kStash;
   int n = 0;
   for (int ox = -g.reach[0]; ox <= g.reach[0]; ++ox)
     for (int oy = -g.reach[1]; oy <= g.reach[1]; ++oy)
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restr
             hit = (d2 < g.rc2) && !(j == i && img[0] == 0 && img[1] == 0 && img[2] == 0);
           }
           const unsigned long long m = __ballot(hit);
-          if (FILL && hit) {
+          if (hit) {
             const int S[3] = {img[0] - wrap[3 * j] + wrap[3 * i], img[1] - wrap[3 * j + 1] + wrap[3 * i + 1],
                               img[2] - wrap[3 * j + 2] + wrap[3 * i + 2]};
             if (S[0] < -kMaxImg || S[0] > kMaxImg || S[1] < -kMaxImg || S[1] > kMaxImg || S[2] < -kMaxImg ||
@@ -154,15 +162,19 @@ __global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restr
             // position inside the atom's key range: hits of earlier lanes first (the keys are sorted afterwards,
             // so only "each slot written once" matters)
             const int slot = __popcll(m & ((1ull << lane) - 1ull));
-            keys[out + slot] = ((unsigned long long)i * (unsigned long long)N + (unsigned long long)j) *
-                                   (unsigned long long)(kCode * kCode * kCode) + code;
+            if (FILL || n + slot < kStash)
+              keys[out + slot] = ((unsigned long long)i * (unsigned long long)N + (unsigned long long)j) *
+                                     (unsigned long long)(kCode * kCode * kCode) + code;
           }
           const int nh = __popcll(m);
           out += nh;
           n += nh;
         }
       }
-  if (!FILL && lane == 0) count[i] = n;
+  if (!FILL && lane == 0) {
+    count[i] = n;
+    if (n > kStash) atomicOr(overflow, 2);
+  }
 }
 
 // sorted keys -> edge_index [2,E] int64 ([i; j]) and shifts [E,3] float32 (sign * S)
@@ -185,6 +197,37 @@ __global__ __launch_bounds__(kBlock) void nbr_decode_kernel(const unsigned long 
   }
 }
 
+// One wave per atom: rank sort of its keys (unique, so rank = number of smaller keys) and decode into the caller's
+// arrays at offset[i] + rank.  `stride` = kStash (stashed keys at src[i * kStash]) or 0 (keys at src[offset[i]]).
+__global__ __launch_bounds__(kBlock) void nbr_sort_decode_kernel(const unsigned long long* __restrict__ src, int stride,
+                                                                const int* __restrict__ count, const long* __restrict__ offset,
+                                                                int N, long E, float sign, int swap_rows,
+                                                                long* __restrict__ edge_index, float* __restrict__ shift) {
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const int lane = threadIdx.x & 63;
+  const int n = count[i];
+  const long base = offset[i];
+  const unsigned long long* keys = src + (stride ? (long)i * stride : base);
+  const unsigned long long c3 = (unsigned long long)(kCode * kCode * kCode);
+  for (int a = lane; a < n; a += 64) {
+    const unsigned long long key = keys[a];
+    int rank = 0;
+    for (int b = 0; b < n; ++b) rank += keys[b] < key ? 1 : 0;
+    const long e = base + rank;
+    const unsigned long long pair = key / c3;
+    const int code = (int)(key - pair * c3);
+    const long j = (long)(pair - (unsigned long long)i * N);
+    edge_index[e] = swap_rows ? j : (long)i;
+    edge_index[E + e] = swap_rows ? (long)i : j;
+    if (shift != nullptr) {
+      shift[3 * e + 0] = sign * (float)(code / (kCode * kCode) - kMaxImg);
+      shift[3 * e + 1] = sign * (float)((code / kCode) % kCode - kMaxImg);
+      shift[3 * e + 2] = sign * (float)(code % kCode - kMaxImg);
+    }
+  }
+}
+
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 int key_bits(int N) {
@@ -196,7 +239,7 @@ int key_bits(int N) {
 
 struct NbrWork {
   double* fw; int* wrap; unsigned* bin; unsigned* bin_sorted; int* ids; int* ids_sorted; int* bin_start;
-  int* count; long* offset; int* overflow; void* temp; size_t temp_bytes;
+  int* count; long* offset; int* overflow; unsigned long long* stash; void* temp; size_t temp_bytes;
 };
 
 size_t temp_bytes_for(int N) {
@@ -261,13 +304,14 @@ void carve(void* workspace, int N, long nbins, NbrWork& w) {
   w.count = (int*)take(sizeof(int) * (size_t)(N + 1));
   w.offset = (long*)take(sizeof(long) * (size_t)(N + 1));
   w.overflow = (int*)take(256);
+  w.stash = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)N * kStash);
   w.temp = p;
 }
 
 size_t fixed_bytes(int N, long nbins) {
   return align256(sizeof(double) * 3 * (size_t)N) + align256(sizeof(int) * 3 * (size_t)N) + 4 * align256(sizeof(int) * (size_t)N) +
          align256(sizeof(int) * (size_t)(nbins + 1)) + align256(sizeof(int) * (size_t)(N + 1)) +
-         align256(sizeof(long) * (size_t)(N + 1)) + 256;
+         align256(sizeof(long) * (size_t)(N + 1)) + 256 + align256(sizeof(unsigned long long) * (size_t)N * kStash);
 }
 
 }  // namespace
@@ -278,14 +322,6 @@ extern "C" size_t hermnet_neighbor_workspace(int num_atoms) {
   return fixed_bytes(num_atoms, nbins) + align256(temp_bytes_for(num_atoms > 0 ? num_atoms : 1)) + 512;
 }
 
-extern "C" size_t hermnet_neighbor_sort_workspace(long num_edges) {
-  size_t c = 0;
-  if (num_edges > 0)
-    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, c, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                            (int)num_edges, 0, 64, (hipStream_t)0);
-  return align256(c) + 256;
-}
-
 extern "C" int hermnet_neighbor_count(const float* pos, int num_atoms, const double* cell_host,
                                       const double* lo_host, const double* hi_host, double rc,
                                       void* workspace, size_t workspace_bytes, long* total_device, void* stream) {
@@ -293,7 +329,7 @@ extern "C" int hermnet_neighbor_count(const float* pos, int num_atoms, const dou
   if (N < 0 || rc <= 0.0 || !workspace || !total_device) return HN_ERR_BAD_ARG;
   if (!cell_host && (!lo_host || !hi_host)) return HN_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (N == 0) return hipMemsetAsync(total_device, 0, sizeof(long), s) == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+  if (N == 0) return hipMemsetAsync(total_device, 0, 2 * sizeof(long), s) == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
   if (!pos) return HN_ERR_BAD_ARG;
   NbrGeom g;
   long nbins = 0;
@@ -322,28 +358,29 @@ extern "C" int hermnet_neighbor_count(const float* pos, int num_atoms, const dou
     return HN_ERR_LAUNCH;
   hipLaunchKernelGGL(nbr_binstart_kernel, grid_for(nbins + 1), dim3(kBlock), 0, s, w.bin_sorted, N, (int)nbins, w.bin_start);
   if (hipMemsetAsync(w.count + N, 0, sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
-  hipLaunchKernelGGL(nbr_pairs_kernel<false>, grid_for((long)N * 64), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N,
-                     g, (const long*)nullptr, w.count, (unsigned long long*)nullptr, w.overflow);
+  if (hipMemsetAsync(w.overflow, 0, 2 * sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
+  hipLaunchKernelGGL(nbr_pairs_kernel<0>, grid_for((long)N * 64), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N,
+                     g, (const long*)nullptr, w.count, w.stash, w.overflow);
   tb = w.temp_bytes;
   if (hipcub::DeviceScan::ExclusiveSum(w.temp, tb, w.count, w.offset, N + 1, s) != hipSuccess) return HN_ERR_LAUNCH;
   if (hipMemcpyAsync(total_device, w.offset + N, sizeof(long), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return HN_ERR_LAUNCH;
+  // total_device[1] = flags of the pass (low 32 bits; the high half of the long is the zeroed word behind it)
+  if (hipMemcpyAsync(total_device + 1, w.overflow, sizeof(long), hipMemcpyDeviceToDevice, s) != hipSuccess)
     return HN_ERR_LAUNCH;
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
 
 extern "C" int hermnet_neighbor_fill(const float* pos, int num_atoms, const double* cell_host,
                                      const double* lo_host, const double* hi_host, double rc,
-                                     void* workspace, size_t workspace_bytes, void* sort_workspace,
-                                     size_t sort_workspace_bytes, long num_edges, float shift_sign,
-                                     int source_first, unsigned long long* keys_a, unsigned long long* keys_b,
-                                     long* edge_index, float* edge_shift, int* overflow_device, void* stream) {
+                                     void* workspace, size_t workspace_bytes, long num_edges, float shift_sign,
+                                     int source_first, int stash_ok, unsigned long long* keys,
+                                     long* edge_index, float* edge_shift, void* stream) {
   const int N = num_atoms;
-  if (N <= 0 || num_edges < 0 || !workspace || !edge_index || !overflow_device) return HN_ERR_BAD_ARG;
+  if (N <= 0 || num_edges < 0 || !workspace || !edge_index) return HN_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(overflow_device, 0, sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
   if (num_edges == 0) return HN_OK;
-  if (!keys_a || !keys_b || !sort_workspace || (double)N * N * 4913.0 >= 1.8e19) return HN_ERR_BAD_ARG;
-  if (num_edges > 0x7fffffffl) return HN_ERR_BAD_ARG;
+  if ((double)N * N * 4913.0 >= 1.8e19 || num_edges > 0x7fffffffl || (!stash_ok && !keys)) return HN_ERR_BAD_ARG;
   NbrGeom g;
   long nbins = 0;
   int rc_ = make_geom(cell_host, lo_host, hi_host, rc, g, nbins);
@@ -360,12 +397,11 @@ extern "C" int hermnet_neighbor_fill(const float* pos, int num_atoms, const doub
   NbrWork w;
   carve(workspace, N, 8l * N + 64, w);
   w.temp_bytes = workspace_bytes - (size_t)((char*)w.temp - (char*)workspace);
-  hipLaunchKernelGGL(nbr_pairs_kernel<true>, grid_for((long)N * 64), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N, g,
-                     w.offset, (int*)nullptr, keys_a, overflow_device);
-  size_t tb = sort_workspace_bytes;
-  if (hipcub::DeviceRadixSort::SortKeys(sort_workspace, tb, keys_a, keys_b, (int)num_edges, 0, key_bits(N), s) != hipSuccess)
-    return HN_ERR_LAUNCH;
-  hipLaunchKernelGGL(nbr_decode_kernel, grid_for(num_edges), dim3(kBlock), 0, s, keys_b, num_edges, N, shift_sign,
+  if (!stash_ok)    // an atom had more pairs than its stash slot: second pass over the candidates into `keys`
+    hipLaunchKernelGGL(nbr_pairs_kernel<1>, grid_for((long)N * 64), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N,
+                       g, w.offset, (int*)nullptr, keys, w.overflow);
+  hipLaunchKernelGGL(nbr_sort_decode_kernel, grid_for((long)N * 64), dim3(kBlock), 0, s,
+                     stash_ok ? w.stash : keys, stash_ok ? kStash : 0, w.count, w.offset, N, num_edges, shift_sign,
                      source_first, edge_index, edge_shift);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }

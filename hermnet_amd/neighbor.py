@@ -157,24 +157,21 @@ def _neighbor_search_device(pos, rc, cell, reference_compat):
         lo_h, hi_h = dbl3(0, 0, 0), dbl3(1, 1, 1)
     ws_bytes = lib.hermnet_neighbor_workspace(N)
     work = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    total = torch.zeros(1, dtype=torch.long, device=dev)
+    total = torch.zeros(2, dtype=torch.long, device=dev)
     args = (P(p32), N, cell_h, lo_h, hi_h, float(rc), P(work), ws_bytes)
     _lib.check(lib.hermnet_neighbor_count(*args, P(total), stream), "hermnet_neighbor_count")
-    E = int(total.item())                                    # the one host read of the search
+    E, flags = total.tolist()                                # the one host read of the search
+    if flags & 1:                                            # an image shift beyond +-8 cells: the host path handles it
+        return None
     edge_index = torch.empty(2, E, dtype=torch.long, device=dev)
     periodic = cell is not None
     shift = torch.empty(E, 3, dtype=torch.float32, device=dev) if periodic else None
     if E > 0:
-        sw_bytes = lib.hermnet_neighbor_sort_workspace(E)
-        sort_work = torch.empty(sw_bytes, dtype=torch.uint8, device=dev)
-        keys = torch.empty(2, E, dtype=torch.long, device=dev)
-        overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        stash_ok = 0 if (flags & 2) else 1
+        keys = None if stash_ok else torch.empty(E, dtype=torch.long, device=dev)
         sign = 1.0 if reference_compat else -1.0
-        _lib.check(lib.hermnet_neighbor_fill(*args, P(sort_work), sw_bytes, E, sign, 0 if periodic else 1,
-                                             P(keys[0]), P(keys[1]), P(edge_index), P(shift), P(overflow), stream),
-                   "hermnet_neighbor_fill")
-        if int(overflow.item()) != 0:
-            return None
+        _lib.check(lib.hermnet_neighbor_fill(*args, E, sign, 0 if periodic else 1, stash_ok, P(keys), P(edge_index),
+                                             P(shift), stream), "hermnet_neighbor_fill")
     return (edge_index, shift) if periodic else edge_index
 
 

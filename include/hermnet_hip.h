@@ -84,24 +84,25 @@ typedef struct hn_graph {
 /* ---- A16 / K18-K19: neighbor_search (data.py:14-24; ase primitive_neighbor_list / torch_cluster
  * radius_graph on the host in the reference).  Device-side cell list, float64 arithmetic on the
  * float32 coordinates; pair (i, j, S) iff |pos_j - pos_i + S cell| < rc (strict), no (i,i,0),
- * output sorted by (i, j, Sx, Sy, Sz).  Two calls around one host read of the pair count:
- *   hermnet_neighbor_count  -> total_device[0] = E      (keeps its state in `workspace`)
- *   hermnet_neighbor_fill   -> edge_index [2,E] int64, edge_shift [E,3] = shift_sign * S
+ * output sorted by (i, j, Sx, Sy, Sz).  Two calls around one host read:
+ *   hermnet_neighbor_count  -> total_device[0] = E, total_device[1] = flags (bit 0: an |S| component exceeded 8 --
+ *                              coordinates many cells away from the cell: wrap them or use the host path; bit 1: an
+ *                              atom has more pairs than the per-atom key stash holds); keeps its state in `workspace`
+ *   hermnet_neighbor_fill   -> edge_index [2,E] int64, edge_shift [E,3] = shift_sign * S.  stash_ok = 1 (flag bit 1
+ *                              clear): the keys stashed by the counting pass are rank-sorted per atom and decoded --
+ *                              no second pass over the candidates, no global sort; stash_ok = 0: two-pass form through
+ *                              `keys` [E] (may be NULL when stash_ok = 1).
  * cell_host: 9 doubles (rows = lattice vectors) on the HOST, or NULL for an open system, in which
  * case lo_host/hi_host give the bounding box of the coordinates.  source_first = 1 writes rows
- * [j; i] (radius_graph convention: source, target), 0 writes [i; j] (the reference's periodic path).
- * overflow_device[0] != 0 afterwards means an |S| component exceeded 8 (coordinates many cells away
- * from the cell): the caller must wrap the coordinates or use the host path. */
+ * [j; i] (radius_graph convention: source, target), 0 writes [i; j] (the reference's periodic path). */
 size_t hermnet_neighbor_workspace(int num_atoms);
-size_t hermnet_neighbor_sort_workspace(long num_edges);
 int hermnet_neighbor_count(const float* pos, int num_atoms, const double* cell_host, const double* lo_host,
                            const double* hi_host, double rc, void* workspace, size_t workspace_bytes,
-                           long* total_device, void* stream);
+                           long* total_device /* [2] */, void* stream);
 int hermnet_neighbor_fill(const float* pos, int num_atoms, const double* cell_host, const double* lo_host,
                           const double* hi_host, double rc, void* workspace, size_t workspace_bytes,
-                          void* sort_workspace, size_t sort_workspace_bytes, long num_edges, float shift_sign,
-                          int source_first, unsigned long long* keys_a, unsigned long long* keys_b,
-                          long* edge_index, float* edge_shift, int* overflow_device, void* stream);
+                          long num_edges, float shift_sign, int source_first, int stash_ok,
+                          unsigned long long* keys, long* edge_index, float* edge_shift, void* stream);
 
 /* ---- A13: in_subgraph (utils.py:11-24) replaced by a one-off device-side build of the relation-ordered
  * graph per neighbour list (three stable radix sorts + binary-searched row pointers, no host sync).

@@ -692,7 +692,7 @@ def test_config4_100k_atoms_properties():
     assert torch.equal(e, e2) and torch.equal(f, f2)
 
 
-@pytest.mark.parametrize("case", ["cubic", "triclinic", "small_cell", "unwrapped", "open", "alloy10k", "molecule"])
+@pytest.mark.parametrize("case", ["cubic", "triclinic", "small_cell", "unwrapped", "open", "alloy10k", "molecule", "dense_stash_overflow"])
 def test_device_neighbor_search_bit_exact_vs_host(case):
     """csrc/neighbor_kernels.hip vs the host cell list (itself checked against brute force on CPU):
     identical (i, j, S) lists, identical order -- 'neighbour indices bit-exact' (north_star)."""
@@ -711,6 +711,8 @@ def test_device_neighbor_search_bit_exact_vs_host(case):
         pos = rs.uniform(0, 1, size=(40, 3)) @ cell + rs.randint(-2, 3, size=(40, 3)) @ cell
     elif case == "open":
         pos = rs.uniform(-4, 4, size=(80, 3)); rc = 3.0
+    elif case == "dense_stash_overflow":      # > 160 pairs per atom: the two-pass form behind the per-atom key stash
+        d = synth.fcc_alloy(reps=(3, 3, 3)); pos = d.pos.numpy().astype(np.float64); cell = d.cell[0].numpy().astype(np.float64); rc = 8.0
     elif case == "alloy10k":
         d = synth.fcc_alloy(); pos = d.pos.numpy().astype(np.float64); cell = d.cell[0].numpy().astype(np.float64); rc = 5.0
     else:
