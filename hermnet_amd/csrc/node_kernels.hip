@@ -390,6 +390,75 @@ __global__ __launch_bounds__(256) void halo_accumulate_kernel(float* __restrict_
   st4(row, acc);
 }
 
+// ---- fused read-out (hermnet.py:113-117,129): e[n] = w2 . ScaledSiLU(W0 x[n] + b0) + b2, without a library GEMM --------
+// 0.16 GFLOP at 10k atoms: not worth a matrix-core kernel, but worth two launches and an [N, H/2] round trip less.
+// A 256-thread workgroup owns 32 rows: the weight matrix (K x M floats, <= 64 KB) and the rows' operand tile sit in
+// LDS; a wave works on 8 rows at once, lane = output column (M/64 columns per lane), so a weight value read from LDS
+// (conflict-free) is used for 8 rows and the operand values are LDS broadcasts.
+//   FWD: operand x [N, H], weights W0^T [H, C], result h [N, C] (saved) and e [N];  K = H, M = C
+//   BWD: operand gh [N, C] = ge mask w2 ScaledSiLU'(h) built on the fly, weights W0 [C, H], result gx [N, H];  K = C, M = H
+template <bool FWD, int MPL>      // MPL = output columns per lane (M = 64 MPL)
+__global__ __launch_bounds__(256) void energy_head_fused_kernel(const float* __restrict__ opnd, const float* __restrict__ wkm,
+                                                                const float* __restrict__ b0, const float* __restrict__ w2,
+                                                                const float* __restrict__ b2, const float* __restrict__ ge,
+                                                                const float* __restrict__ mask, float* __restrict__ out_mat,
+                                                                float* __restrict__ e, int rows, int K) {
+  constexpr int M = 64 * MPL;
+  extern __shared__ __align__(16) float lds[];
+  float* wl = lds;                        // [K][M]
+  float* xt = lds + (size_t)K * M;        // [32][K + 1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * 32;
+  for (int i = tid; i < K * M / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(wkm)[i];
+  for (int i = tid; i < 32 * K; i += 256) {
+    const int r = i / K, k = i % K, row = row0 + r;
+    float v = 0.f;
+    if (row < rows) {
+      if (FWD) v = opnd[(size_t)row * K + k];
+      else v = ge[row] * (mask ? mask[row] : 1.0f) * w2[k] * dssilu(opnd[(size_t)row * K + k]);
+    }
+    xt[r * (K + 1) + k] = v;
+  }
+  __syncthreads();
+  float acc[8][MPL];
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int m = 0; m < MPL; ++m) acc[r][m] = 0.f;
+  const float* xr = xt + wave * 8 * (K + 1);
+  for (int k = 0; k < K; ++k) {
+    float w[MPL];
+#pragma unroll
+    for (int m = 0; m < MPL; ++m) w[m] = wl[k * M + m * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float xv = xr[r * (K + 1) + k];
+#pragma unroll
+      for (int m = 0; m < MPL; ++m) acc[r][m] = fmaf(xv, w[m], acc[r][m]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int row = row0 + wave * 8 + r;
+    if (row >= rows) continue;                       // (wave-uniform)
+    if (FWD) {
+      float s = 0.f;
+#pragma unroll
+      for (int m = 0; m < MPL; ++m) {
+        const int c = m * 64 + lane;
+        const float hv = acc[r][m] + b0[c];
+        out_mat[(size_t)row * M + c] = hv;
+        s += hv * sigmoidf_(hv) * w2[c];
+      }
+      s = wave_sum(s);
+      if (lane == 0) e[row] = (s * kSiluScale + (b2 ? b2[0] : 0.f)) * (mask ? mask[row] : 1.0f);
+    } else {
+#pragma unroll
+      for (int m = 0; m < MPL; ++m) out_mat[(size_t)row * M + m * 64 + lane] = acc[r][m];
+    }
+  }
+}
+
 // ---- HTNet: combine a centre atom's P pair relations (DESIGN.md "HTNet") ----------------------------------------------
 // Target rows are [Te][P][B] blocks of B rows; the layer's result for the atom in row c*B + i is the MEAN over its P
 // virtual rows.  One packed pass over (x | vec): a float4 of [rows, 4H] per thread.
@@ -543,6 +612,63 @@ extern "C" int hermnet_energy_head_bwd(const float* ge, const float* h, const fl
   hipLaunchKernelGGL(energy_head_bwd_kernel, grid_for(n4, 256), dim3(256), 0, (hipStream_t)stream, ge, h, w, row_mask, gh, n4,
                      cols);
   HN_LAUNCH_END;
+}
+
+// Fused read-out.  forward: x [rows, hidden] -> h [rows, cols] (pre-activation, saved for the backward) and e [rows];
+// w0t = out_energy[0].weight^T [hidden, cols].  backward: ge [rows] -> gx [rows, hidden]; w0 = out_energy[0].weight
+// [cols, hidden].  cols in {64, 128, 256} and hidden in {64, 128, 256} with hidden * cols * 4 <= 64 KiB; else HN_ERR_BAD_ARG
+// (the caller then takes the library-GEMM form: hermnet_energy_head_fwd / _bwd).
+extern "C" int hermnet_energy_head_fused_fwd(const float* x, const float* w0t, const float* b0, const float* w2,
+                                             const float* b2, const float* row_mask, float* h, float* e, int rows,
+                                             int hidden, int cols, void* stream) {
+  if (rows < 0 || (cols != 64 && cols != 128 && cols != 256) || hidden <= 0 || (hidden & 3) ||
+      (size_t)hidden * cols * 4 > 65536)
+    return HN_ERR_BAD_ARG;
+  if (rows == 0) return HN_OK;
+  if (!x || !w0t || !b0 || !w2 || !h || !e) return HN_ERR_BAD_ARG;
+  const size_t lds = ((size_t)hidden * cols + 32 * (hidden + 1)) * sizeof(float);
+  const dim3 grid((unsigned)((rows + 31) / 32));
+  hipStream_t s = (hipStream_t)stream;
+  auto go = [&](auto kern) -> int {
+    static bool done = false;
+    if (!done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 98304) != hipSuccess)
+        return HN_ERR_LDS;
+      done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, w0t, b0, w2, b2, (const float*)nullptr, row_mask, h, e, rows, hidden);
+    HN_LAUNCH_END;
+  };
+  if (cols == 64) return go(energy_head_fused_kernel<true, 1>);
+  if (cols == 128) return go(energy_head_fused_kernel<true, 2>);
+  return go(energy_head_fused_kernel<true, 4>);
+}
+
+extern "C" int hermnet_energy_head_fused_bwd(const float* ge, const float* h, const float* w0, const float* w2,
+                                             const float* row_mask, float* gx, int rows, int hidden, int cols,
+                                             void* stream) {
+  if (rows < 0 || (hidden != 64 && hidden != 128 && hidden != 256) || cols <= 0 || (cols & 3) ||
+      (size_t)hidden * cols * 4 > 65536)
+    return HN_ERR_BAD_ARG;
+  if (rows == 0) return HN_OK;
+  if (!ge || !h || !w0 || !w2 || !gx) return HN_ERR_BAD_ARG;
+  const size_t lds = ((size_t)hidden * cols + 32 * (cols + 1)) * sizeof(float);
+  const dim3 grid((unsigned)((rows + 31) / 32));
+  hipStream_t s = (hipStream_t)stream;
+  auto go = [&](auto kern) -> int {
+    static bool done = false;
+    if (!done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 98304) != hipSuccess)
+        return HN_ERR_LDS;
+      done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, h, w0, (const float*)nullptr, w2, (const float*)nullptr, ge, row_mask,
+                       gx, (float*)nullptr, rows, cols);
+    HN_LAUNCH_END;
+  };
+  if (hidden == 64) return go(energy_head_fused_kernel<false, 1>);
+  if (hidden == 128) return go(energy_head_fused_kernel<false, 2>);
+  return go(energy_head_fused_kernel<false, 4>);
 }
 
 extern "C" int hermnet_pair_mean(int mode, const float* x_in, const float* vec_in, float* x_out, float* vec_out,

@@ -352,14 +352,38 @@ class EnergyHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w0, b0, w2, b2, mask=None):
         """`mask` [N] (optional) multiplies the per-row energies: padding rows of the relation order -> 0."""
-        h = _launch("gemm", lambda: torch.addmm(b0, x, w0.t()))                       # [N, H/2]
         w2v = w2.reshape(-1).contiguous()
-        ctx.save_for_backward(h, w0, w2v)
         ctx.mask = mask
+        ctx.fused = x.is_cuda and nodeops.head_fused_supported(x.size(1), w0.size(0))
+        if ctx.fused:      # one launch each way, no library GEMM (csrc/node_kernels.hip: energy_head_fused_kernel)
+            w0c = w0.contiguous()
+            h, e = nodeops.energy_head_fused_fwd(x, _transposed_once(w0c), b0, w2v, b2, mask)
+            ctx.save_for_backward(h, w0c, w2v)
+            return e
+        h = _launch("gemm", lambda: torch.addmm(b0, x, w0.t()))                       # [N, H/2]
+        ctx.save_for_backward(h, w0, w2v)
         return nodeops.energy_head_fwd(h, w2v, b2, mask)      # [N]
 
     @staticmethod
     def backward(ctx, ge):
         h, w0, w2v = ctx.saved_tensors
+        if ctx.fused:
+            return nodeops.energy_head_fused_bwd(ge.contiguous(), h, w0, w2v, ctx.mask), None, None, None, None, None
         gh = nodeops.energy_head_bwd(ge.contiguous(), h, w2v, ctx.mask)
         return _launch("gemm", lambda: torch.mm(gh, w0)), None, None, None, None, None
+
+
+_T_CACHE = []
+
+
+def _transposed_once(w):
+    """w^T (contiguous), rebuilt only when the parameter changes (storage address, version, shape; the cache holds the
+    source tensor, so its address cannot be reused while the entry lives)."""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    for ent in _T_CACHE:
+        if ent[0] == key:
+            return ent[2]
+    wt = w.t().contiguous()
+    _T_CACHE.insert(0, (key, w, wt))
+    del _T_CACHE[4:]
+    return wt

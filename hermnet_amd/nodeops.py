@@ -99,6 +99,30 @@ def energy_head_bwd(ge, h, w, mask=None):
     return gh
 
 
+def head_fused_supported(H, C):
+    return C in (64, 128, 256) and H in (64, 128, 256) and H * C * 4 <= 65536
+
+
+def energy_head_fused_fwd(x, w0t, b0, w2, b2, mask=None):
+    """x [rows,H] -> (h [rows,C] pre-activation, e [rows]) in one launch (no library GEMM); w0t = out_energy[0].weight^T."""
+    rows, H = x.shape
+    C = w0t.size(1)
+    h = torch.empty(rows, C, dtype=x.dtype, device=x.device)
+    e = torch.empty(rows, dtype=x.dtype, device=x.device)
+    _lib.check(_launch("energy_head_fused_fwd", lambda: _lib.load().hermnet_energy_head_fused_fwd(
+        P(x), P(w0t), P(b0), P(w2), P(b2), P(mask), P(h), P(e), rows, H, C, _stream())), "hermnet_energy_head_fused_fwd")
+    return h, e
+
+
+def energy_head_fused_bwd(ge, h, w0, w2, mask=None):
+    rows, C = h.shape
+    H = w0.size(1)
+    gx = torch.empty(rows, H, dtype=h.dtype, device=h.device)
+    _lib.check(_launch("energy_head_fused_bwd", lambda: _lib.load().hermnet_energy_head_fused_bwd(
+        P(ge), P(h), P(w0), P(w2), P(mask), P(gx), rows, H, C, _stream())), "hermnet_energy_head_fused_bwd")
+    return gx
+
+
 def pair_mean(x, vec, Te, P_, B, rows_out, backward=False):
     """HTNet: mean over a centre atom's P virtual target rows (backward=False: [Te*P*B, ...] -> [rows_out, ...], zero
     rows behind Te*B) or its gradient (backward=True: [rows_out, ...] -> [Te*P*B, ...])."""

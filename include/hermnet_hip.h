@@ -270,6 +270,17 @@ int hermnet_energy_head_fwd(const float* h, const float* w, const float* b, cons
 int hermnet_energy_head_bwd(const float* ge, const float* h, const float* w, const float* row_mask, float* gh,
                             int rows, int cols, void* stream);
 
+/* The whole read-out in one launch each way (no library GEMM): forward  h = x W0^T + b0 [rows, cols] (saved),
+ * e = (w2 . ScaledSiLU(h) + b2) row_mask;  backward  gx = (ge row_mask w2 ScaledSiLU'(h)) W0  [rows, hidden].
+ * w0t = out_energy[0].weight^T [hidden, cols], w0 = out_energy[0].weight [cols, hidden].  Supported: the output width
+ * of each product (cols forward, hidden backward) in {64, 128, 256} and hidden * cols * 4 <= 64 KiB (the weight matrix
+ * is staged in LDS); otherwise HN_ERR_BAD_ARG and the caller uses hermnet_energy_head_fwd / _bwd around its own GEMM. */
+int hermnet_energy_head_fused_fwd(const float* x, const float* w0t, const float* b0, const float* w2, const float* b2,
+                                  const float* row_mask, float* h, float* e, int rows, int hidden, int cols,
+                                  void* stream);
+int hermnet_energy_head_fused_bwd(const float* ge, const float* h, const float* w0, const float* w2,
+                                  const float* row_mask, float* gx, int rows, int hidden, int cols, void* stream);
+
 /* ---- A7 (node MLP) + A11 + A12 as chain kernels on the fp32 matrix pipe (csrc/node_chain.hip) -----------------------
  * One launch per chain instead of library GEMMs joined by elementwise launches; hidden activations never reach HBM.
  * hidden must be 64, 128 or 256 (hermnet_node_chain_supported; other widths: the stage-wise entry points above around

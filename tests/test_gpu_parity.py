@@ -337,6 +337,20 @@ def test_energy_head_kernels():
             assert rel_err(e.cpu(), ref_ops.energy_head_fwd(h, w, b, mask)) < 2e-6
             gh = nodeops.energy_head_bwd(ge.to(dev), h.to(dev), w.to(dev), md)
             assert rel_err(gh.cpu(), ref_ops.energy_head_bwd(ge, h, w, mask)) < 2e-6
+    # the whole read-out in one launch each way (no library GEMM): hermnet.py:113-117,129
+    for rows, H, C in [(257, 128, 64), (31, 64, 64), (1000, 64, 128), (100, 256, 64)]:
+        assert nodeops.head_fused_supported(H, C)
+        x, w0, b0 = torch.randn(rows, H, generator=gen), torch.randn(C, H, generator=gen) * 0.2, torch.randn(C, generator=gen)
+        w2, b2, ge = torch.randn(C, generator=gen), torch.randn(1, generator=gen), torch.randn(rows, generator=gen)
+        for mask in (None, (torch.arange(rows) % 7 != 0).float()):
+            md = None if mask is None else mask.to(dev)
+            h_r = x.double() @ w0.double().t() + b0.double()
+            e_r = ref_ops.energy_head_fwd(h_r, w2.double(), b2.double(), None if mask is None else mask.double())
+            h, e = nodeops.energy_head_fused_fwd(x.to(dev), w0.t().contiguous().to(dev), b0.to(dev), w2.to(dev), b2.to(dev), md)
+            assert rel_err(h.cpu().double(), h_r) < 2e-6 and rel_err(e.cpu().double(), e_r) < 3e-6
+            gx = nodeops.energy_head_fused_bwd(ge.to(dev), h, w0.to(dev), w2.to(dev), md)
+            gx_r = ref_ops.energy_head_bwd(ge.double(), h_r, w2.double(), None if mask is None else mask.double()) @ w0.double()
+            assert rel_err(gx.cpu().double(), gx_r) < 3e-6
 
 
 def test_halo_rows_kernels():
