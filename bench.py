@@ -387,18 +387,14 @@ def main():
     from hermnet_amd import synth, ops, _lib
     from hermnet_amd.utils import enable_tuned_gemms, freeze_gemm_tuning
     _lib.load()   # fail loudly if the HIP library is missing
-    # GEMM solution choice: the recorded table covers the single-GPU shapes; a sharded rank has its own row counts,
-    # so TunableOp times the candidates of those shapes during the (untimed) warm-up steps and is frozen before
-    # the timed region.  Set PYTORCH_TUNABLEOP_ENABLED yourself to take over.
+    # No library GEMM is left on the energy/force path (csrc/node_chain.hip, the fused read-out), so there is nothing for
+    # TunableOp to choose: round 2's recorded table / online tuning during the warm-up -- and with it the risk of ranks
+    # timing candidates differently in a multi-GPU run -- are off unless asked for (HERMNET_BENCH_TUNED_GEMMS=1: only the
+    # training secondary and widths outside {64, 128, 256} still call library GEMMs).
     tuned = online_tuning = False
-    if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is None:
-        want_online = args.warmup > 0 and os.environ.get("HERMNET_BENCH_ONLINE_TUNING", "1") != "0"
-        online_tuning = (sharded or cfg != "c2") and want_online
+    if os.environ.get("HERMNET_BENCH_TUNED_GEMMS", "0") != "0" and os.environ.get("PYTORCH_TUNABLEOP_ENABLED") is None:
+        online_tuning = args.warmup > 0
         tuned = enable_tuned_gemms(online=online_tuning)
-        if not tuned and not online_tuning and want_online:
-            # the recorded table was rejected (other library versions): time the candidates in the warm-up instead
-            online_tuning = True
-            enable_tuned_gemms(online=True)
 
     elems = ["Al", "Ni", "Cu"]
     model_kw = dict(rc=5.0, num_layers=5, hidden_channels=128, num_rbf=128)
