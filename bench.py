@@ -586,6 +586,17 @@ def main():
             except Exception as ex:
                 out["secondary"]["single_gpu_same_cell"] = {"error": repr(ex)}
         if world == 1 and not sharded and not args.no_secondary:
+            try:      # kernel launches of ONE step, counted by the profiler (every device kernel, torch's included)
+                from torch.profiler import ProfilerActivity, profile
+                with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                    step()
+                    torch.cuda.synchronize()
+                names = [ev.name for ev in prof.events() if ev.device_type is not None and str(ev.device_type).endswith("CUDA")]
+                out["secondary"]["launches_per_step"] = len(names)
+                out["secondary"]["launches_per_step_own_kernels"] = sum(
+                    1 for n_ in names if "anonymous namespace" in n_ or n_.startswith("void (anonymous"))
+            except Exception as ex:
+                out["secondary"]["launches_per_step"] = {"error": repr(ex)}
             # the same step captured once and replayed as ONE hipGraph launch (valid while the neighbour list is
             # unchanged, hermnet_amd/graph.py): what the GPU needs when the host is out of the loop
             try:
