@@ -238,11 +238,12 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     dv = x.new_zeros(N, 3, H)
     if parts:
         m = parts[0] if len(parts) == 1 else torch.cat(parts, 0)                   # [Ek, 3H]
-        s_, a_, b_ = m[:, :H], m[:, H:2 * H], m[:, 2 * H:]
-        mv = b_[:, None, :] * edge[:Ek, :3, None]                                  # rmnet.py:64-66
+        # (unbind of the [Ek,3,H] view: its backward is ONE stack, where three column slices each zero-fill a full
+        # [Ek,3H] gradient; the constant factors ride on the [Ek,H] parts, not on the 3x larger vector message)
+        s_, a_, b_ = m.view(-1, 3, H).unbind(1)
+        mv = (b_ * (1 / math.sqrt(H)))[:, None, :] * edge[:Ek, :3, None]           # rmnet.py:64-66
         if vec is not None:
-            mv = mv + vec.index_select(0, src[:Ek]) * (a_ * (1 / math.sqrt(3.0)))[:, None, :]
-        mv = mv * (1 / math.sqrt(H))
+            mv = torch.addcmul(mv, vec.index_select(0, src[:Ek]), (a_ * (1 / math.sqrt(3.0 * H)))[:, None, :])
         dx = dx.index_add(0, tgt_row[:Ek], s_)                                     # aggregate, rmnet.py:69-73
         dv = dv.index_add(0, tgt_row[:Ek], mv)
     known = (rel_row < T).to(x.dtype)
@@ -276,12 +277,12 @@ def _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed):
     wx2, bx2 = st(u.xvec_proj[2].weight for u in ul), st(u.xvec_proj[2].bias for u in ul)           # [T,3H,H], [T,3H]
     xt, vt = x1[:nk].view(T, B, H), vec1[:nk].view(T, B, 3, H)
     vp = torch.bmm(vt.reshape(T, B * 3, H), wv.transpose(1, 2)).view(T, B, 3, 2 * H)
-    v1, v2 = vp[..., :H], vp[..., H:]
+    v1, v2 = vp.view(T, B, 3, 2, H).unbind(3)
     vdot = (v1 * v2).sum(dim=2) * ul[0].inv_sqrt_h
     xin = torch.cat([xt, torch.sqrt((v2 ** 2).sum(dim=2) + 1e-8)], dim=-1)                           # [T,B,2H]
     h2 = torch.baddbmm(bx0[:, None, :], xin, wx0.transpose(1, 2))
     q = torch.baddbmm(bx2[:, None, :], F.silu(h2) * ul[0].xvec_proj[1].scale_factor, wx2.transpose(1, 2))
-    q1, q2, q3 = q[..., :H], q[..., H:2 * H], q[..., 2 * H:]
+    q1, q2, q3 = q.view(T, B, 3, H).unbind(2)
     xo = xt + (q1 + q2 * vdot) * ul[0].inv_sqrt_2
     vo = vt + q3.unsqueeze(2) * v1
     x_out, v_out = xo.reshape(nk, H), vo.reshape(nk, 3, H)
