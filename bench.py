@@ -16,7 +16,7 @@ Workloads (`--config`; `auto` = c2 on one GPU, c4 on several):
 N > 1: one process per GPU.  `python bench.py --gpus N` on its own starts the N ranks itself (fresh child processes via
 `python -m torch.distributed.run`, before this process makes any GPU call) and relays rank 0's line; inside a torchrun job
 (WORLD_SIZE set, the driver's command line) it is one of the ranks.  Every rank plans its slab on the device from the coordinates alone
-(`sharding.partition_slab`: owners, geometric halo, neighbour search over owned + halo atoms only); per layer one
+(`sharding.SlabStepper`: owners, geometric halo of rc + skin kept while valid, neighbour search over owned + halo atoms only); per layer one
 RCCL all-to-all moves the halo rows, the energy is one scalar all-reduce.
 
 Prints ONE JSON line on rank 0.
@@ -410,15 +410,20 @@ def main():
         # every rank holds the global coordinates (what a calculator is handed per MD step) and plans ITS slab on the
         # device: owners, geometric halo, neighbour search over owned + halo atoms only (outside the timed region,
         # like the neighbour list of the single-GPU headline; timed separately below)
-        from hermnet_amd.sharding import partition_slab
+        from hermnet_amd.sharding import SlabStepper, plan_slab
         pos_np, cell_np, z_np = synth.fcc_alloy_atoms(reps=reps, seed=0)
         gpos = torch.from_numpy(pos_np.astype(np.float32)).to(dev)
         gcell = torch.from_numpy(cell_np.astype(np.float32)).to(dev)
         gz = torch.from_numpy(z_np).to(dev)
         group = dist.group.WORLD
 
+        # the slab plan (owners, halo = rc + skin, exchange lists) is kept while no atom has moved further than skin/2;
+        # per step only the displacement check and the slab-local neighbour search run (sharding.SlabStepper)
+        SKIN = 1.0
+        stepper = SlabStepper(gz, gcell, model_kw["rc"], rank, world, skin=SKIN, group=group)
+
         def plan_shard():
-            return partition_slab(gpos, gz, gcell, model_kw["rc"], rank, world, group=group)
+            return stepper(gpos)
 
         data, plan = plan_shard()
         halo = int(plan.halo_global.numel())
@@ -503,6 +508,14 @@ def main():
             md_step()
         fence()
         md = max_over_ranks(time.perf_counter() - t1) / nmd
+        replan_ms = None
+        if sharded:       # what a re-plan costs when the skin is used up (every ~10-50 MD steps)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                plan_slab(gpos, gz, gcell, model_kw["rc"], rank, world, group=group, skin=SKIN)
+            fence()
+            replan_ms = max_over_ranks(time.perf_counter() - t1) / 3 * 1e3
 
     if rank == 0:
         ksum = timer.summary()            # name -> (launches, mean ms), HIP events on the launch stream
@@ -565,9 +578,14 @@ def main():
         }
         if md is not None:
             out["secondary"] = {"atom_steps_per_s_incl_planning": N_global / md, "ms_per_step_incl_planning": md * 1e3,
-                                "note": ("slab plan + slab-local device neighbour search + relation build + energy + "
-                                         "forces per step, max over ranks") if sharded else
+                                "note": ("displacement check + slab-local device neighbour search (edges into owned "
+                                         "atoms only) + relation build + energy + forces per step, max over ranks") if sharded else
                                         "device cell-list neighbour search + relation build + energy + forces per step"}
+            out["secondary"]["incl_planning_over_step"] = md / (dt / args.steps)
+            if sharded:
+                out["secondary"].update({"skin_A": SKIN, "replan_ms": replan_ms, "replans_in_run": stepper.replans,
+                                         "planning_note": "plan reused under the Verlet skin (static coordinates here); a "
+                                                          "re-plan costs replan_ms more on the step that needs it"})
         if sharded and not args.no_secondary and cfg != "weak":
             # the strong-scaling baseline inside the same run: the same cell, unsharded, on rank 0's GPU
             try:

@@ -15,7 +15,7 @@ _ERR = {1: "HN_ERR_BAD_ARG (unsupported shape or null pointer)",
         3: "HN_ERR_LAUNCH (kernel launch failed)"}
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers
-ABI_VERSION = 5          # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
+ABI_VERSION = 6          # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
 
 
 class RbfDesc(ctypes.Structure):
@@ -51,10 +51,10 @@ SIGNATURES = {
     "hermnet_edge_radial_table": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), c_fp, c_fp, c_fp]),
     "hermnet_neighbor_workspace": (ctypes.c_size_t, [ctypes.c_int]),
     "hermnet_neighbor_count": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_double, c_fp,
-                                              ctypes.c_size_t, c_fp, c_fp]),
+                                              ctypes.c_size_t, c_fp, c_fp, c_fp]),
     "hermnet_neighbor_fill": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_double, c_fp, ctypes.c_size_t,
                                              ctypes.c_long, ctypes.c_float, ctypes.c_int, ctypes.c_int,
-                                             c_fp, c_fp, c_fp, c_fp]),
+                                             c_fp, c_fp, c_fp, c_fp, c_fp]),
     "hermnet_relation_counts": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp]),
     "hermnet_build_relations_workspace": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "hermnet_build_relations": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_int,

@@ -5,7 +5,7 @@
 #include "../../include/hermnet_hip.h"
 #include "hermnet_math.h"
 
-#define HN_ABI_VERSION 5
+#define HN_ABI_VERSION 6
 #define HN_STR2(x) #x
 #define HN_STR(x) HN_STR2(x)
 

@@ -100,12 +100,20 @@ __global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restr
                                                           const int* __restrict__ bin_start, int N, NbrGeom g,
                                                           const long* __restrict__ offset, int* __restrict__ count,
                                                           unsigned long long* __restrict__ keys,
-                                                          int* __restrict__ overflow) {
+                                                          int* __restrict__ overflow,
+                                                          const unsigned char* __restrict__ target_ok, int target_is_j) {
   // one WAVE per atom: the lanes share the candidates of a bin (one atom per thread left the chip at 40 workgroups
   // for 10k atoms, each thread walking ~200 candidates serially: 0.2 ms per pass)
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= N) return;
   const int lane = threadIdx.x & 63;
+  // `target_ok` (atom-sharded lists, sharding.py): only pairs whose TARGET atom is flagged are listed -- the target is j
+  // in the periodic convention ([i; j]), i in the open-system one ([j; i])
+  if (target_ok != nullptr && !target_is_j && !target_ok[i]) {
+    if (MODE == 0 && lane == 0) count[i] = 0;
+    return;
+  }
+  const bool mask_j = target_ok != nullptr && target_is_j;
   const double fi[3] = {fw[3 * i], fw[3 * i + 1], fw[3 * i + 2]};
   double pi[3];
   if (g.periodic) cart_of(g, fi, pi); else { pi[0] = fi[0]; pi[1] = fi[1]; pi[2] = fi[2]; }
@@ -149,6 +157,7 @@ __global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restr
             const double dx = pj[0] - pi[0], dy = pj[1] - pi[1], dz = pj[2] - pi[2];
             const double d2 = dx * dx + dy * dy + dz * dz;
             hit = (d2 < g.rc2) && !(j == i && img[0] == 0 && img[1] == 0 && img[2] == 0);
+            if (mask_j) hit = hit && target_ok[j] != 0;
           }
           const unsigned long long m = __ballot(hit);
           if (hit) {
@@ -324,7 +333,8 @@ extern "C" size_t hermnet_neighbor_workspace(int num_atoms) {
 
 extern "C" int hermnet_neighbor_count(const float* pos, int num_atoms, const double* cell_host,
                                       const double* lo_host, const double* hi_host, double rc,
-                                      void* workspace, size_t workspace_bytes, long* total_device, void* stream) {
+                                      void* workspace, size_t workspace_bytes, const unsigned char* target_ok,
+                                      long* total_device, void* stream) {
   const int N = num_atoms;
   if (N < 0 || rc <= 0.0 || !workspace || !total_device) return HN_ERR_BAD_ARG;
   if (!cell_host && (!lo_host || !hi_host)) return HN_ERR_BAD_ARG;
@@ -360,7 +370,7 @@ extern "C" int hermnet_neighbor_count(const float* pos, int num_atoms, const dou
   if (hipMemsetAsync(w.count + N, 0, sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
   if (hipMemsetAsync(w.overflow, 0, 2 * sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
   hipLaunchKernelGGL(nbr_pairs_kernel<0>, grid_for((long)N * 64), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N,
-                     g, (const long*)nullptr, w.count, w.stash, w.overflow);
+                     g, (const long*)nullptr, w.count, w.stash, w.overflow, target_ok, g.periodic);
   tb = w.temp_bytes;
   if (hipcub::DeviceScan::ExclusiveSum(w.temp, tb, w.count, w.offset, N + 1, s) != hipSuccess) return HN_ERR_LAUNCH;
   if (hipMemcpyAsync(total_device, w.offset + N, sizeof(long), hipMemcpyDeviceToDevice, s) != hipSuccess)
@@ -375,7 +385,8 @@ extern "C" int hermnet_neighbor_fill(const float* pos, int num_atoms, const doub
                                      const double* lo_host, const double* hi_host, double rc,
                                      void* workspace, size_t workspace_bytes, long num_edges, float shift_sign,
                                      int source_first, int stash_ok, unsigned long long* keys,
-                                     long* edge_index, float* edge_shift, void* stream) {
+                                     const unsigned char* target_ok, long* edge_index, float* edge_shift,
+                                     void* stream) {
   const int N = num_atoms;
   if (N <= 0 || num_edges < 0 || !workspace || !edge_index) return HN_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -399,7 +410,7 @@ extern "C" int hermnet_neighbor_fill(const float* pos, int num_atoms, const doub
   w.temp_bytes = workspace_bytes - (size_t)((char*)w.temp - (char*)workspace);
   if (!stash_ok)    // an atom had more pairs than its stash slot: second pass over the candidates into `keys`
     hipLaunchKernelGGL(nbr_pairs_kernel<1>, grid_for((long)N * 64), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N,
-                       g, w.offset, (int*)nullptr, keys, w.overflow);
+                       g, w.offset, (int*)nullptr, keys, w.overflow, target_ok, g.periodic);
   hipLaunchKernelGGL(nbr_sort_decode_kernel, grid_for((long)N * 64), dim3(kBlock), 0, s,
                      stash_ok ? w.stash : keys, stash_ok ? kStash : 0, w.count, w.offset, N, num_edges, shift_sign,
                      source_first, edge_index, edge_shift);

@@ -99,7 +99,7 @@ class HVNet(nn.Module):
 
     def _build_graph(self, data, zl, shard):
         """Relation-ordered graph of this neighbour list (the replacement of `in_subgraph`, utils.py:11-24)."""
-        rel_active = None if shard is None else [z in shard.z_with_in_edges for z in zl]
+        rel_active = None if shard is None else shard.rel_active(zl)
         return RelationalGraph.build(data.atomic_number, data.edge_index, zl,
                                      edge_shift=data.get("edge_shift") if data.get("cell") is not None else None,
                                      batch=data.batch, rel_active=rel_active)
@@ -147,7 +147,7 @@ class HVNet(nn.Module):
             if shard.owned_mask.device != pos.device:
                 shard.to(pos.device)
             pos = HaloExchange.apply(pos, shard.atom_plan)                  # halo coordinates from their owners
-            row_plan = shard.atom_plan.remap(graph.row_of_node)
+            row_plan = shard.row_plan(graph.row_of_node)
         if train:
             edge = self._edge_geometry_autograd(pos, data.get("cell"), graph)
         else:

@@ -135,8 +135,23 @@ def neighbor_list(pos, rc, cell=None, pbc=(True, True, True), chunk=200000):
     return i[key], j[key], s[key]
 
 
-def _neighbor_search_device(pos, rc, cell, reference_compat):
-    """Device cell list (`csrc/neighbor_kernels.hip`); same result as the host path, tensors stay on the GPU."""
+_CELL_HOST = []        # [(cell tensor, version, 9 doubles)]: the cell of an MD run is the same tensor step after step
+
+
+def _cell_on_host(cell):
+    """The 3x3 cell as host doubles; read back once per tensor object and version (the read is a host sync)."""
+    for ent in _CELL_HOST:
+        if ent[0] is cell and ent[1] == cell._version:
+            return ent[2]
+    vals = cell.detach().double().cpu().reshape(-1, 3, 3)[0].contiguous().reshape(-1).tolist()
+    _CELL_HOST.insert(0, (cell, cell._version, vals))
+    del _CELL_HOST[4:]
+    return vals
+
+
+def _neighbor_search_device(pos, rc, cell, reference_compat, target_mask=None):
+    """Device cell list (`csrc/neighbor_kernels.hip`); same result as the host path, tensors stay on the GPU.
+    `target_mask` [N] bool/uint8: list only the pairs whose target atom (row 1) is flagged (atom shards)."""
     import ctypes
     from . import _lib
     lib = _lib.load()
@@ -148,18 +163,23 @@ def _neighbor_search_device(pos, rc, cell, reference_compat):
     dbl3 = ctypes.c_double * 3
     cell_h = lo_h = hi_h = None
     if cell is not None:
-        c = cell.detach().double().cpu().reshape(-1, 3, 3)[0].contiguous().numpy()
-        cell_h = (ctypes.c_double * 9)(*c.reshape(-1).tolist())
+        cell_h = (ctypes.c_double * 9)(*_cell_on_host(cell))
     elif N > 0:
         mm = torch.stack([p32.min(0).values, p32.max(0).values]).double().cpu().tolist()
         lo_h, hi_h = dbl3(*mm[0]), dbl3(*mm[1])
     else:
         lo_h, hi_h = dbl3(0, 0, 0), dbl3(1, 1, 1)
+    mask = None
+    if target_mask is not None:
+        mask = target_mask if target_mask.dtype == torch.uint8 else target_mask.to(torch.uint8)
+        mask = mask.contiguous()
+        if mask.numel() != N or mask.device != dev:
+            raise ValueError("target_mask must be [N] on the device of pos")
     ws_bytes = lib.hermnet_neighbor_workspace(N)
     work = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     total = torch.zeros(2, dtype=torch.long, device=dev)
     args = (P(p32), N, cell_h, lo_h, hi_h, float(rc), P(work), ws_bytes)
-    _lib.check(lib.hermnet_neighbor_count(*args, P(total), stream), "hermnet_neighbor_count")
+    _lib.check(lib.hermnet_neighbor_count(*args, P(mask), P(total), stream), "hermnet_neighbor_count")
     E, flags = total.tolist()                                # the one host read of the search
     if flags & 1:                                            # an image shift beyond +-8 cells: the host path handles it
         return None
@@ -170,8 +190,8 @@ def _neighbor_search_device(pos, rc, cell, reference_compat):
         stash_ok = 0 if (flags & 2) else 1
         keys = None if stash_ok else torch.empty(E, dtype=torch.long, device=dev)
         sign = 1.0 if reference_compat else -1.0
-        _lib.check(lib.hermnet_neighbor_fill(*args, E, sign, 0 if periodic else 1, stash_ok, P(keys), P(edge_index),
-                                             P(shift), stream), "hermnet_neighbor_fill")
+        _lib.check(lib.hermnet_neighbor_fill(*args, E, sign, 0 if periodic else 1, stash_ok, P(keys), P(mask),
+                                             P(edge_index), P(shift), stream), "hermnet_neighbor_fill")
     return (edge_index, shift) if periodic else edge_index
 
 
@@ -189,7 +209,7 @@ def _cap_neighbors(edge_index, cap):
     return edge_index[:, (pos - start) < cap]
 
 
-def neighbor_search(pos, rc, cell=None, reference_compat=False):
+def neighbor_search(pos, rc, cell=None, reference_compat=False, target_mask=None):
     """Drop-in for `HermNet/data.py:14-24`.
 
     pos: float Tensor [N,3]; cell: Tensor [3,3] or [1,3,3] or None.
@@ -201,21 +221,31 @@ def neighbor_search(pos, rc, cell=None, reference_compat=False):
     minimum-image ones: periodic `edge_shift = +S` (`data.py:19-24`, see the module docstring) and, for open
     systems, `radius_graph`'s default cap of 32 neighbours per atom (`data.py:16`; torch_cluster keeps an
     implementation-defined subset -- its GPU kernel the 32 lowest source indices, which is what is kept here).
+
+    `target_mask` [N] bool (no reference counterpart; `sharding.py`): keep only the edges whose target atom
+    (`edge_index[1]`) is flagged, same order -- the list of an atom shard, without building the rest.
     """
     if cell is None and reference_compat:
-        return _cap_neighbors(neighbor_search(pos, rc, None, False), 32)
+        return _cap_neighbors(neighbor_search(pos, rc, None, False, target_mask), 32)
     if pos.is_cuda:
-        out = _neighbor_search_device(pos, rc, cell, reference_compat)
+        out = _neighbor_search_device(pos, rc, cell, reference_compat, target_mask)
         if out is not None:
             return out
     dev = pos.device
     p = pos.detach().cpu().numpy()
+    keep = None if target_mask is None else target_mask.detach().cpu().numpy().astype(bool)
     if cell is None:
         i, j, _ = neighbor_list(p, rc, None)
+        if keep is not None:
+            sel = keep[i]
+            i, j = i[sel], j[sel]
         # radius_graph convention: row 0 = source (neighbour), row 1 = target (centre)
         return torch.from_numpy(np.vstack([j, i])).long().to(dev)
     c = cell.detach().cpu().numpy().reshape(-1, 3, 3)[0]
     i, j, s = neighbor_list(p, rc, c)
+    if keep is not None:
+        sel = keep[j]
+        i, j, s = i[sel], j[sel], s[sel]
     edge_index = torch.from_numpy(np.vstack([i, j])).long()
     sign = 1.0 if reference_compat else -1.0
     edge_shift = torch.from_numpy(sign * s.astype(np.float32)).float()

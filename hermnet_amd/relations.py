@@ -150,7 +150,10 @@ class RelationalGraph(object):
         g.out_rowptr = g.out_edges = None
         shift = None if edge_shift is None else edge_shift.float().contiguous()
         g.shift = None if shift is None else torch.empty(E, 3, dtype=torch.float32, device=dev)
-        act = None if rel_active is None else _cached_u8(tuple(bool(a) for a in rel_active), dev)
+        if torch.is_tensor(rel_active):       # device flags (slab plans, sharding.py): no host read
+            act = rel_active.to(device=dev, dtype=torch.uint8).contiguous()
+        else:
+            act = None if rel_active is None else _cached_u8(tuple(bool(a) for a in rel_active), dev)
         wbytes = lib.hermnet_build_relations_workspace(NA, N, E, T)
         work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
         out = _lib.RelationsOut(P(rows["node_order"]), P(rows["row_of_node"]), P(rows["z_rows"]), P(g.row_real), P(g.row_active),
@@ -248,6 +251,8 @@ class RelationalGraph(object):
             tn = torch.arange(T + 1, device=dev) * N
             act = torch.cat([(csc_rowptr[tn[1:]] - csc_rowptr[tn[:-1]]) > 0,
                              torch.zeros(1, dtype=torch.bool, device=dev)])
+        elif torch.is_tensor(rel_active):
+            act = torch.cat([rel_active.to(dev).bool(), torch.zeros(1, dtype=torch.bool, device=dev)])
         else:
             act = torch.tensor([bool(a) for a in rel_active] + [False], dtype=torch.bool, device=dev)
         g.row_active = act[rel_row].float() * g.row_real

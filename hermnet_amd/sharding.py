@@ -190,11 +190,28 @@ class ShardPlan(object):
         self.atom_plan = atom_plan            # ExchangePlan in local atom order
         self.owned_mask = owned_mask          # BoolTensor [N_loc]
         self.group = group
-        self.z_with_in_edges = None           # atomic numbers that receive >= 1 edge GLOBALLY (hermnet.py:56-57)
+        self.z_with_in_edges = None           # atomic numbers that receive >= 1 edge GLOBALLY (hermnet.py:56-57): a set
+        self.has_in_edges = None              # ... or the same as a device array [128] of 0/1 (slab plans)
+        self._row_plan = None                 # (row_of_node tensor, atom_plan in that row order)
 
     @property
     def n_owned(self):
         return int(self.owned_global.numel())
+
+    def rel_active(self, zl):
+        """Which of the model's relations (target elements `zl`) run: a list of bool (host plans) or a uint8 device
+        array (slab plans; consumed by the relation build without a host read)."""
+        if self.has_in_edges is not None:
+            idx = torch.tensor([min(int(z), 127) for z in zl], dtype=torch.long, device=self.has_in_edges.device)
+            return self.has_in_edges.index_select(0, idx).to(torch.uint8)
+        return [z in self.z_with_in_edges for z in zl]
+
+    def row_plan(self, row_of_node):
+        """The atom exchange lists in the relation-row order of `row_of_node` (cached per tensor: the row layout of an
+        atom set does not change along a trajectory, relations.py)."""
+        if self._row_plan is None or self._row_plan[0] is not row_of_node:
+            self._row_plan = (row_of_node, self.atom_plan.remap(row_of_node))
+        return self._row_plan[1]
 
     def to(self, device):
         self.owned_global = self.owned_global.to(device)
@@ -354,79 +371,141 @@ def _within_cutoff_of_slab(coord, lo, hi, reach, periodic):
     return inside | (dist <= reach)
 
 
-def partition_slab(pos, atomic_number, cell, rc, rank, world, axis=None, group=None, reference_compat=False):
-    """Slab decomposition of ONE structure from its coordinates alone (no global edge list).
+def plan_slab(pos, atomic_number, cell, rc, rank, world, axis=None, group=None, skin=0.0):
+    """The part of a slab decomposition that depends on WHERE the atoms are only to within `skin`/2: owners
+    (equal-count slabs), the geometric halo (everything within rc + skin of the slab along the slab axis), the
+    exchange lists.  pos [N,3] float32, atomic_number [N], cell [3,3] / [1,3,3] / None -- the same on every rank, on
+    the device the step will run on (host tensors work too: CPU rehearsal).
 
-    pos [N,3] float32, atomic_number [N], cell [3,3] / [1,3,3] / None -- the same on every rank, on the device the
-    step will run on (host tensors work too: CPU rehearsal).  Returns (local_data, plan) with the contract of
-    `partition`: local atoms = owned + halo in ascending global id, edges = cutoff pairs whose TARGET is owned,
-    found by a neighbour search over the local atoms only.  The halo is geometric (everything within rc of the
-    slab along the slab axis), so sender and receiver derive identical exchange lists independently; it is a
-    superset of the atoms that really send an edge across (by the few with no partner inside the slab).
-    One host read (2 x world counts + the local edge count of the search)."""
-    from .neighbor import neighbor_search
+    Local atoms = owned atoms in ascending global id, then halo atoms in ascending global id (halo rows therefore
+    close every relation's row block: the node kernels can treat "rows that wait for the exchange" as T windows).
+    The halo is geometric, so sender and receiver derive identical exchange lists independently; it is a superset of
+    the atoms that really send an edge across.  While no atom has moved further than skin/2 from `plan.pos_ref`,
+    every source within rc of an owned atom is still a local atom: the plan stays valid and only the neighbour
+    list is rebuilt (`slab_data`).  All peers' send lists come from ONE [world, N] mask; one host read (the
+    2 x world counts)."""
     dev = pos.device
     n = pos.size(0)
     owner, coord, (lo, hi), axis, margin = slab_owner_device(pos, cell, world, axis)
     periodic = cell is not None
-    reach = float(rc) * margin * (1.0 + 1e-9) + 1e-12
+    reach = (float(rc) + float(skin)) * margin * (1.0 + 1e-9) + 1e-12
     mine = owner == rank
-    need = _within_cutoff_of_slab(coord, lo[rank], hi[rank], reach, periodic)      # owned atoms are inside
-    local_mask = mine | need
-    local_ids = torch.nonzero(local_mask).reshape(-1)                               # ascending global id
-    is_owned = mine[local_ids]
+    # near[p, a]: atom a lies within reach of slab p (atoms of slab p itself included)
+    near = _within_cutoff_of_slab(coord[None, :], lo[:, None], hi[:, None], reach, periodic)
+    halo_mask = near[rank] & ~mine
+    send_mask = near & mine[None, :]
+    send_mask[rank] = False
+    # receive: my halo grouped by owner (ascending id inside a group); send: for every peer, the atoms I own
+    # that lie within reach of ITS slab -- the same set and order the peer derives for its receive list
+    owned = torch.nonzero(mine).reshape(-1)
+    halo = torch.nonzero(halo_mask).reshape(-1)                                     # ascending global id
+    local_ids = torch.cat([owned, halo])
+    n_owned = owned.numel()
     g2l = torch.full((n,), -1, dtype=torch.long, device=dev)
     g2l[local_ids] = torch.arange(local_ids.numel(), device=dev)
-
-    # receive: my halo grouped by owner (ascending id inside a group); send: for every peer, the atoms I own
-    # that lie within rc of ITS slab -- the same set and order the peer derives for its receive list
-    halo = local_ids[~is_owned]
     halo_owner = owner[halo]
-    key = torch.argsort(halo_owner, stable=True)
-    recv_idx = g2l[halo[key]]
-    send_lists, cnt = [], [torch.bincount(halo_owner, minlength=world)]
-    for p in range(world):
-        if p == rank:
-            send_lists.append(torch.zeros(0, dtype=torch.long, device=dev))
-            continue
-        m = mine & _within_cutoff_of_slab(coord, lo[p], hi[p], reach, periodic)
-        send_lists.append(g2l[torch.nonzero(m).reshape(-1)])
-    cnt.append(torch.stack([torch.tensor(s_.numel(), device=dev) for s_ in send_lists]))
-    counts = torch.stack(cnt).cpu().tolist()                                        # the one host read of the plan
-    recv_counts, send_counts = counts[0], counts[1]
-    send_idx = torch.cat(send_lists) if send_lists else torch.zeros(0, dtype=torch.long, device=dev)
-
-    # cutoff graph of the local atoms in the GLOBAL cell; keep the edges into owned atoms
-    pos_l = pos.detach()[local_ids]
-    cell_t = None if cell is None else cell.detach().reshape(-1, 3, 3)[0]
-    if periodic:
-        ei, sh = neighbor_search(pos_l, rc, cell_t, reference_compat=reference_compat)
-    else:
-        ei, sh = neighbor_search(pos_l, rc, None, reference_compat=reference_compat), None
-    keep = is_owned[ei[1]]
-    ei = ei[:, keep]
-    pos_l = torch.where(is_owned[:, None], pos_l, torch.zeros_like(pos_l))          # halo rows: filled by the exchange
-    z = atomic_number[local_ids]
-    kw = dict(pos=pos_l, atomic_number=z, edge_index=ei, batch=torch.zeros(local_ids.numel(), dtype=torch.long, device=dev))
-    if periodic:
-        kw["cell"] = cell.detach().reshape(1, 3, 3)
-        kw["edge_shift"] = sh[keep]
-    local = Data(**kw)
-    plan = ShardPlan(rank, world, local_ids[is_owned], halo, ExchangePlan(send_idx, send_counts, recv_idx, recv_counts, group),
+    recv_idx = g2l[halo[torch.argsort(halo_owner, stable=True)]]
+    pairs = torch.nonzero(send_mask)                                                # (peer, atom), peer-major
+    send_idx = g2l[pairs[:, 1]]
+    counts = torch.stack([torch.bincount(halo_owner, minlength=world),
+                          torch.bincount(pairs[:, 0], minlength=world)]).cpu().tolist()   # the host read of the plan
+    is_owned = torch.zeros(local_ids.numel(), dtype=torch.bool, device=dev)
+    is_owned[:n_owned] = True
+    plan = ShardPlan(rank, world, owned, halo, ExchangePlan(send_idx, counts[1], recv_idx, counts[0], group),
                      is_owned, 1, group)
-    plan.owned_local = torch.nonzero(is_owned).reshape(-1)
+    plan.owned_local = torch.arange(n_owned, device=dev)
     plan.local_global = local_ids
-    # hermnet.py:56-57: a relation is skipped when NO atom of its element receives an edge anywhere in the structure
+    plan.rc, plan.skin = float(rc), float(skin)
+    plan.pos_ref = pos.detach().clone()
+    plan.z_local = atomic_number[local_ids]
+    plan.batch_local = torch.zeros(local_ids.numel(), dtype=torch.long, device=dev)
+    plan.target_mask = is_owned.to(torch.uint8)
+    plan.cell = None if cell is None else cell.detach().reshape(1, 3, 3)
+    return plan
+
+
+def slab_data(plan, pos, reference_compat=False):
+    """This rank's `Data` for the current coordinates under a plan that is still valid (`plan_moved` says whether it
+    is): the cutoff pairs among the local atoms whose TARGET is owned, listed directly by the neighbour search
+    (`target_mask`; nothing of the other pairs is built or filtered afterwards).  Halo coordinates are placeholders
+    (zeros): HVNet.forward fills them through the exchange so that force contributions flow back to the owners.
+    One host read (the edge count of the search)."""
+    from .neighbor import neighbor_search
+    dev = pos.device
+    pos_l = pos.detach().index_select(0, plan.local_global)
+    cell = plan.cell
+    if cell is not None:
+        ei, sh = neighbor_search(pos_l, plan.rc, cell, reference_compat=reference_compat, target_mask=plan.target_mask)
+    else:
+        ei, sh = neighbor_search(pos_l, plan.rc, None, reference_compat=reference_compat, target_mask=plan.target_mask), None
+    z = plan.z_local
+    kw = dict(pos=pos_l * plan.owned_mask[:, None].to(pos_l.dtype), atomic_number=z, edge_index=ei, batch=plan.batch_local)
+    if cell is not None:
+        kw["cell"] = cell
+        kw["edge_shift"] = sh
+    local = Data(**kw)
+    # hermnet.py:56-57: a relation is skipped when NO atom of its element receives an edge anywhere in the structure;
+    # kept on the device (the relation build takes the flags as a device array: no host read per step)
     has_in = torch.zeros(128, dtype=torch.int32, device=dev)
     if ei.size(1) > 0:
         has_in[z[ei[1]].clamp(max=127)] = 1
-    if world > 1 and dist.is_available() and dist.is_initialized():
-        if _host_staged(group, has_in):
+    if plan.world > 1 and dist.is_available() and dist.is_initialized():
+        if _host_staged(plan.group, has_in):
             h = has_in.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
-            has_in = h
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=plan.group)
+            has_in = h.to(dev)
         else:
-            dist.all_reduce(has_in, op=dist.ReduceOp.MAX, group=group)
-    plan.z_with_in_edges = set(int(v) for v in torch.nonzero(has_in).reshape(-1).cpu().tolist())
+            dist.all_reduce(has_in, op=dist.ReduceOp.MAX, group=plan.group)
+    plan.has_in_edges = has_in
     local._hn_shard = plan
-    return local, plan
+    return local
+
+
+def plan_moved(plan, pos):
+    """0-d bool tensor: some atom is further than skin/2 from where the plan saw it (same answer on every rank: all
+    ranks hold the same coordinates)."""
+    d2 = ((pos.detach() - plan.pos_ref) ** 2).sum(dim=1)
+    return d2.max() > (0.5 * plan.skin) ** 2 if d2.numel() > 0 else torch.zeros((), dtype=torch.bool, device=pos.device)
+
+
+def partition_slab(pos, atomic_number, cell, rc, rank, world, axis=None, group=None, reference_compat=False, skin=0.0):
+    """Slab decomposition of ONE structure from its coordinates alone (no global edge list): `plan_slab` +
+    `slab_data`.  Returns (local_data, plan) with the contract of `partition`, except for the order of the local
+    atoms (owned first, then halo; see `plan_slab`)."""
+    plan = plan_slab(pos, atomic_number, cell, rc, rank, world, axis=axis, group=group, skin=skin)
+    return slab_data(plan, pos, reference_compat), plan
+
+
+class SlabStepper(object):
+    """Per-step planning of an atom-sharded MD run: the plan is kept while it is valid under a Verlet skin.
+
+        stepper = SlabStepper(atomic_number, cell, rc, rank, world, skin=1.0)
+        local, plan = stepper(pos)          # every step; `pos` = the global coordinates, the same on every rank
+
+    Per step: the displacement check (three elementwise launches), the slab-local neighbour search for the current
+    coordinates and the has-in-edges reduction; the slab plan itself (owners, halo, exchange lists, their host read)
+    only when an atom has moved further than skin/2 since it was made.  The check's flag is read together with the
+    search's edge count -- the search runs optimistically on the old plan and is repeated after a re-plan."""
+
+    def __init__(self, atomic_number, cell, rc, rank, world, skin=1.0, axis=None, group=None, reference_compat=False):
+        self.z, self.cell, self.rc, self.skin = atomic_number, cell, float(rc), float(skin)
+        self.rank, self.world, self.axis, self.group = rank, world, axis, group
+        self.reference_compat = reference_compat
+        self.plan = None
+        self.replans = 0
+
+    def _replan(self, pos):
+        self.plan = plan_slab(pos, self.z, self.cell, self.rc, self.rank, self.world, axis=self.axis, group=self.group,
+                              skin=self.skin)
+        self.replans += 1
+
+    def __call__(self, pos):
+        if self.plan is None or self.plan.pos_ref.shape != pos.shape:
+            self._replan(pos)
+            return slab_data(self.plan, pos, self.reference_compat), self.plan
+        moved = plan_moved(self.plan, pos)
+        local = slab_data(self.plan, pos, self.reference_compat)      # (its host read has waited for `moved` too)
+        if bool(moved):
+            self._replan(pos)
+            local = slab_data(self.plan, pos, self.reference_compat)
+        return local, self.plan

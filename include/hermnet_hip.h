@@ -16,7 +16,8 @@
  *   - float = IEEE fp32 (the reference is fp32-only), indices = int32 (int64 where a parameter says so:
  *     the caller's edge_index / atomic_number / halo index lists arrive as torch LongTensors).
  *
- * ABI version 5 (`hermnet_abi_version`): v5 replaces the stand-alone node GEMM by the node chain kernels
+ * ABI version 6 (`hermnet_abi_version`): v6 adds the target mask of the neighbour search (lists of an atom shard) and the
+ * row windows of the node pre kernels (halo exchange overlap); v5 replaces the stand-alone node GEMM by the node chain kernels
  * (hermnet_node_pre_fwd/_bwd, hermnet_node_update_fwd/_bwd); v4 puts the radial table in CSC order (hermnet_edge_radial_table takes the
  * graph); v3 added the deterministic halo accumulate, separate source / target row
  * spaces (HTNet) and the fused node-chain kernels; v2 added the bias-on-load arguments, LayerNorm, the energy head, the
@@ -94,15 +95,19 @@ typedef struct hn_graph {
  *                              `keys` [E] (may be NULL when stash_ok = 1).
  * cell_host: 9 doubles (rows = lattice vectors) on the HOST, or NULL for an open system, in which
  * case lo_host/hi_host give the bounding box of the coordinates.  source_first = 1 writes rows
- * [j; i] (radius_graph convention: source, target), 0 writes [i; j] (the reference's periodic path). */
+ * [j; i] (radius_graph convention: source, target), 0 writes [i; j] (the reference's periodic path).
+ * target_ok (ABI v6; NULL = every atom): [num_atoms] bytes, only pairs whose TARGET atom (row 1 of edge_index) is
+ * flagged are counted and listed -- the list of an atom shard (owned + halo atoms in, edges into owned atoms out);
+ * pass the same pointer to both calls. */
 size_t hermnet_neighbor_workspace(int num_atoms);
 int hermnet_neighbor_count(const float* pos, int num_atoms, const double* cell_host, const double* lo_host,
                            const double* hi_host, double rc, void* workspace, size_t workspace_bytes,
-                           long* total_device /* [2] */, void* stream);
+                           const unsigned char* target_ok, long* total_device /* [2] */, void* stream);
 int hermnet_neighbor_fill(const float* pos, int num_atoms, const double* cell_host, const double* lo_host,
                           const double* hi_host, double rc, void* workspace, size_t workspace_bytes,
                           long num_edges, float shift_sign, int source_first, int stash_ok,
-                          unsigned long long* keys, long* edge_index, float* edge_shift, void* stream);
+                          unsigned long long* keys, const unsigned char* target_ok, long* edge_index,
+                          float* edge_shift, void* stream);
 
 /* ---- A13: in_subgraph (utils.py:11-24) replaced by a one-off device-side build of the relation-ordered
  * graph per neighbour list (three stable radix sorts + binary-searched row pointers, no host sync).

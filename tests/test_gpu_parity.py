@@ -740,6 +740,15 @@ def test_device_neighbor_search_bit_exact_vs_host(case):
             assert devr.is_cuda and torch.equal(devr.cpu(), host)
         else:
             assert devr[0].is_cuda and torch.equal(devr[0].cpu(), host[0]) and torch.equal(devr[1].cpu(), host[1])
+    # lists of an atom shard: only the edges into flagged targets, straight from the search (both the stash and the
+    # two-pass form)
+    mask = torch.from_numpy(rs.rand(p.size(0)) < 0.5)
+    host = neighbor_search(p, rc, c, target_mask=mask)
+    devr = neighbor_search(p.to(dev), rc, None if c is None else c.to(dev), target_mask=mask.to(dev))
+    if cell is None:
+        assert torch.equal(devr.cpu(), host) and bool(mask[host[1]].all())
+    else:
+        assert torch.equal(devr[0].cpu(), host[0]) and torch.equal(devr[1].cpu(), host[1]) and bool(mask[host[0][1]].all())
 
 
 def _oracle_vs_hip(data, elems, kw, seed, tol=TOL, e_floor=0.1):

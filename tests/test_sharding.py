@@ -230,7 +230,10 @@ def test_partition_slab_is_consistent_and_covers_the_global_graph(case, world):
         seen |= keys
         assert bool(plan.owned_mask[loc.edge_index[1]].all())                    # targets are owned
         assert float(loc.pos[~plan.owned_mask].abs().sum()) == 0.0               # halo coordinates arrive by exchange
-        assert torch.equal(plan.local_global, torch.sort(plan.local_global).values)
+        # local order: owned atoms by ascending id, then halo atoms by ascending id
+        assert torch.equal(plan.local_global, torch.cat([plan.owned_global, plan.halo_global]))
+        assert torch.equal(plan.halo_global, torch.sort(plan.halo_global).values)
+        assert bool(plan.owned_mask[:plan.n_owned].all()) and not bool(plan.owned_mask[plan.n_owned:].any())
         for p in range(world):
             ap, q = plan.atom_plan, parts[p][1].atom_plan
             send_idx = ap.send_idx[sum(ap.send_counts[:p]):sum(ap.send_counts[:p + 1])]
@@ -240,6 +243,59 @@ def test_partition_slab_is_consistent_and_covers_the_global_graph(case, world):
             assert not bool(parts[p][1].owned_mask[recv_idx].any())
             assert torch.equal(plan.local_global[send_idx], parts[p][1].local_global[recv_idx])
     assert seen == all_edges
+
+
+def test_neighbor_search_target_mask_is_the_filtered_list():
+    """`target_mask` keeps exactly the edges whose target is flagged, in the same order (host path; the device path is
+    checked against it in tests/test_gpu_parity.py)."""
+    from hermnet_amd import synth
+    from hermnet_amd.neighbor import neighbor_search
+    d = synth.fcc_alloy(reps=(3, 3, 6))
+    mask = torch.from_numpy(np.random.RandomState(0).rand(d.pos.size(0)) < 0.4)
+    ei, sh = neighbor_search(d.pos, 5.0, d.cell)
+    ei_m, sh_m = neighbor_search(d.pos, 5.0, d.cell, target_mask=mask)
+    keep = mask[ei[1]]
+    assert torch.equal(ei_m, ei[:, keep]) and torch.equal(sh_m, sh[keep]) and 0 < ei_m.size(1) < ei.size(1)
+    pos_open = d.pos[:200]
+    eo = neighbor_search(pos_open, 5.0)
+    eo_m = neighbor_search(pos_open, 5.0, target_mask=mask[:200])
+    assert torch.equal(eo_m, eo[:, mask[:200][eo[1]]])
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_slab_stepper_reuses_the_plan_under_the_skin(world):
+    """A plan made with halo = rc + skin stays exact while no atom has moved further than skin/2: along a random walk
+    the per-rank lists (rebuilt every step on the OLD plan) still cover the global cutoff graph of the CURRENT
+    coordinates exactly once; a large move triggers one re-plan on every rank."""
+    from hermnet_amd import synth
+    from hermnet_amd.neighbor import neighbor_search
+    from hermnet_amd.sharding import SlabStepper
+    d = synth.fcc_alloy(reps=(3, 3, 24))
+    skin = 0.8
+    steppers = [SlabStepper(d.atomic_number, d.cell, 5.0, r, world, skin=skin) for r in range(world)]
+    rs = np.random.RandomState(5)
+    pos = d.pos.clone()
+    step_len = 0.06        # per step and axis (seeded walk: the largest displacement after 7 steps stays below skin/2)
+    walk = torch.zeros_like(pos)
+    for it in range(9):
+        if it > 0:
+            walk = walk + torch.from_numpy(rs.uniform(-step_len, step_len, size=pos.shape)).float()
+        if it == 8:
+            walk[17] += torch.tensor([0.0, 0.0, 1.5])        # one atom jumps: every rank must re-plan
+        cur = pos + walk
+        ei, sh = neighbor_search(cur, 5.0, d.cell)
+        want = set(map(tuple, torch.cat([ei, sh.long().T]).T.tolist()))
+        seen = set()
+        for r in range(world):
+            loc, plan = steppers[r](cur)
+            keys = _edge_keys(plan, loc)
+            assert len(keys) == loc.edge_index.size(1) and not (keys & seen)
+            assert bool(plan.owned_mask[loc.edge_index[1]].all())
+            seen |= keys
+        assert seen == want, it
+        moved_far = float((walk ** 2).sum(1).max()) > (skin / 2) ** 2
+        assert [s_.replans for s_ in steppers] == [2 if moved_far else 1] * world, (it, moved_far)
+    assert moved_far        # the last step did cross the threshold
 
 
 def _slab_worker(rank, world, port, out):
@@ -264,7 +320,7 @@ def _slab_worker(rank, world, port, out):
         e = model(local)
         f_local = -torch.autograd.grad(e.sum(), local.pos)[0]
         out[rank] = (e.detach().numpy(), plan.owned_global.numpy(), f_local[plan.owned_local].numpy(),
-                     int(plan.halo_global.numel()), sorted(plan.z_with_in_edges))
+                     int(plan.halo_global.numel()), torch.nonzero(plan.has_in_edges).reshape(-1).tolist())
     finally:
         dist.destroy_process_group()
 
