@@ -78,8 +78,9 @@ SIGNATURES = {
     "hermnet_energy_head_fused_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_node_chain_supported": (ctypes.c_int, [ctypes.c_int]),
     "hermnet_node_pre_fwd": (ctypes.c_int, [c_fp] * 10 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                                        ctypes.c_float, c_fp]),
-    "hermnet_node_pre_bwd": (ctypes.c_int, [c_fp] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
+                                                        ctypes.c_float, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_node_pre_bwd": (ctypes.c_int, [c_fp] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp,
+                                                        ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_node_update_fwd": (ctypes.c_int, [c_fp] * 16 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_node_update_bwd": (ctypes.c_int, [c_fp] * 14 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_pair_mean": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -294,7 +294,23 @@ struct PreFwdArgs {
   const int* src_ranges;   // [T][4] or null: relation t only ever gathers source rows [r0, r1) and [r2, r3)
   int Ns, T, Hr;
   float eps;
+  const int* windows;      // [nwin][2] row windows or null (see tile_selected)
+  int nwin, wmode;
 };
+
+// Row windows (atom shards, sharding.py: the halo rows close every relation's row block): a launch with wmode 1 runs
+// only the tiles that touch a window, wmode 2 only the others -- the rows that do not wait for the halo exchange are
+// projected while it is in flight, the rest after it (backward: the halo tiles first, so that their gradients travel
+// while the others are computed).  The two launches partition the tiles; wmode 0 runs all of them.
+__device__ __forceinline__ bool tile_selected(const int* __restrict__ win, int nwin, int wmode, int row0, int TR) {
+  if (wmode == 0) return true;
+  bool inside = false;
+  for (int k = 0; k < nwin; ++k) {
+    const int lo = win[2 * k], hi = win[2 * k + 1];
+    inside |= hi > lo && row0 < hi && row0 + TR > lo;
+  }
+  return inside == (wmode == 1);
+}
 
 // HTNet: relation (c; p, q) gathers source rows of elements p and q only -- tiles outside both row ranges are skipped
 __device__ __forceinline__ bool tile_wanted(const int* __restrict__ ranges, int t, int row0, int TR) {
@@ -313,6 +329,7 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
   const int wc = wave % C::WC, wr = wave / C::WC;
   float* scr = tile + TR * LD + wave * kScrFloats;
   const int nrows = min(TR, a.Ns - row0);
+  if (!tile_selected(a.windows, a.nwin, a.wmode, row0, TR)) return;
   if (!tile_wanted(a.src_ranges, t, row0, TR)) return;     // xh[t] / hb[t] of these rows are never read
   const rsrc_t x_r = tile_rsrc(a.x + (size_t)row0 * H, nrows * H);
   const rsrc_t hb_r = tile_rsrc(a.hb + ((size_t)t * a.Ns + row0) * H, nrows * H);
@@ -438,6 +455,8 @@ struct PreBwdArgs {
   float* gn;           // [T, Ns, H]
   const int* src_ranges;   // as in PreFwdArgs; skipped tiles contribute zero rows to gn[t]
   int Ns, T;
+  const int* windows;      // as in PreFwdArgs
+  int nwin, wmode;
 };
 
 template <int H, int TR>
@@ -454,6 +473,7 @@ __global__ __launch_bounds__(256, 2) void node_pre_bwd_kernel(PreBwdArgs a) {
   float* scr = lds + TR * LD + wave * kScrFloats;     // the chunk buffers' upper part: free once the gh tile is written
   const int nrows = min(TR, a.Ns - row0);
   const int mrow = wr * RB * 32 + (lane & 31), ch = 4 * (lane >> 5);
+  if (!tile_selected(a.windows, a.nwin, a.wmode, row0, TR)) return;
   if (!tile_wanted(a.src_ranges, t, row0, TR)) {
     float* g0 = a.gn + ((size_t)t * a.Ns + row0) * H;
     for (int i = tid; i < nrows * (H / 4); i += 256) reinterpret_cast<f32x4*>(g0)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -533,9 +553,12 @@ __global__ __launch_bounds__(256, 2) void node_pre_bwd_kernel(PreBwdArgs a) {
 __global__ __launch_bounds__(256) void layernorm_bwd_parts_kernel(const float* __restrict__ g, int nparts, long part_stride,
                                                                   const float* __restrict__ x, const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, const float* __restrict__ add,
-                                                                  float* __restrict__ gx, int rows, int H, int Hr) {
+                                                                  float* __restrict__ gx, int rows, int H, int Hr,
+                                                                  const int* __restrict__ windows, int nwin, int wmode,
+                                                                  int TR) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
+  if (!tile_selected(windows, nwin, wmode, r / TR * TR, TR)) return;     // the rows of the pre kernel's tiles
   const int lane = threadIdx.x & 63;
   const float mu = mean[r], rs = rstd[r];
   constexpr int KMAX = 4;                        // H <= 1024
@@ -1143,12 +1166,14 @@ extern "C" int hermnet_node_chain_supported(int hidden) { return hidden == 64 ||
 extern "C" int hermnet_node_pre_fwd(const float* x, const float* w1_frag, const float* b1, const float* w2_frag,
                                     const float* b2, float* hb, float* xh, float* mean, float* rstd,
                                     const int* src_ranges, int num_src, int num_rel, int hidden, int hidden_real,
-                                    float eps, void* stream) {
+                                    float eps, const int* row_windows, int num_windows, int window_mode, void* stream) {
   if (num_src < 0 || num_rel <= 0 || hidden_real > hidden) return HN_ERR_BAD_ARG;
+  if (window_mode < 0 || window_mode > 2 || (window_mode && (!row_windows || num_windows < 0))) return HN_ERR_BAD_ARG;
   if (!hermnet_node_chain_supported(hidden)) return HN_ERR_BAD_ARG;
   if (num_src == 0) return HN_OK;
   if (!x || !w1_frag || !b1 || !w2_frag || !b2 || !hb || !xh || !mean || !rstd) return HN_ERR_BAD_ARG;
-  PreFwdArgs a = {x, w1_frag, b1, w2_frag, b2, hb, xh, mean, rstd, src_ranges, num_src, num_rel, hidden_real > 0 ? hidden_real : hidden, eps};
+  PreFwdArgs a = {x, w1_frag, b1, w2_frag, b2, hb, xh, mean, rstd, src_ranges, num_src, num_rel, hidden_real > 0 ? hidden_real : hidden, eps,
+                  row_windows, num_windows, window_mode};
 #define HN_GRID(TR) dim3((unsigned)((num_src + TR - 1) / TR), (unsigned)num_rel)
   HN_CHAIN_DISPATCH(node_pre_fwd_kernel, HN_GRID, 1, a);
 }
@@ -1156,12 +1181,14 @@ extern "C" int hermnet_node_pre_fwd(const float* x, const float* w1_frag, const 
 extern "C" int hermnet_node_pre_bwd(const float* gxh, const float* hb, const float* w2t_frag, const float* w1t_frag,
                                     float* gn_parts, const float* x, const float* mean, const float* rstd,
                                     const float* add, float* gx, const int* src_ranges, int num_src, int num_rel,
-                                    int hidden, int hidden_real, void* stream) {
+                                    int hidden, int hidden_real, const int* row_windows, int num_windows,
+                                    int window_mode, void* stream) {
   if (num_src < 0 || num_rel <= 0 || hidden_real > hidden) return HN_ERR_BAD_ARG;
+  if (window_mode < 0 || window_mode > 2 || (window_mode && (!row_windows || num_windows < 0))) return HN_ERR_BAD_ARG;
   if (!hermnet_node_chain_supported(hidden)) return HN_ERR_BAD_ARG;
   if (num_src == 0) return HN_OK;
   if (!gxh || !hb || !w2t_frag || !w1t_frag || !gn_parts || !x || !mean || !rstd || !gx) return HN_ERR_BAD_ARG;
-  PreBwdArgs a = {gxh, hb, w2t_frag, w1t_frag, gn_parts, src_ranges, num_src, num_rel};
+  PreBwdArgs a = {gxh, hb, w2t_frag, w1t_frag, gn_parts, src_ranges, num_src, num_rel, row_windows, num_windows, window_mode};
   // chunk buffers: 2 x [TR][min(H,128) + 4]
   int rc;
   switch (hidden) {
@@ -1173,7 +1200,7 @@ extern "C" int hermnet_node_pre_bwd(const float* gxh, const float* hb, const flo
   if (rc != HN_OK) return rc;
   hipLaunchKernelGGL(layernorm_bwd_parts_kernel, dim3((unsigned)((num_src + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      gn_parts, num_rel, (long)num_src * hidden, x, mean, rstd, add, gx, num_src, hidden,
-                     hidden_real > 0 ? hidden_real : hidden);
+                     hidden_real > 0 ? hidden_real : hidden, row_windows, num_windows, window_mode, hidden == 256 ? 32 : 64);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
 

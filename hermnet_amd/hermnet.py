@@ -10,7 +10,7 @@ from .elements import atomic_numbers
 from .ops import EdgeGeometry, TrueEdgeGradient, edge_radial_table
 from .relations import RelationalGraph
 from .sharding import HaloExchange, HaloExchangeFeatures, SumAcrossRanks
-from .layer import EdgeFanout, EdgeGradSink, EnergyHead, FusedRelationalLayer, LayerWeights
+from .layer import EdgeFanout, EdgeGradSink, EnergyHead, FusedRelationalLayer, LayerWeights, _node_chain_enabled
 from .rmnet import PaiNNModule, RadialBasis, ScaledSiLU, relational_layer
 
 
@@ -28,6 +28,20 @@ class HeteroVertexConv(nn.Module):
         g = data.get("_hn_graph")
         if g is None:
             raise RuntimeError("HeteroVertexConv.forward needs a Data prepared by HVNet.forward")
+        # atom shards: the halo rows of (x, vec) are still with their owners (HVNet.forward leaves the exchange to the
+        # layer that consumes them).  The fused chain path overlaps it with its node projection; every other path runs
+        # it first.
+        halo, data._hn_halo = data.get("_hn_halo"), None
+        w = None
+        if (halo is not None and data.get("_hn_edge_embed") is None
+                and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0"):
+            if self._weights is None:
+                self._weights = LayerWeights(self.mods.values())
+            w = self._weights.refresh()
+        if halo is not None and not (w is not None and w.chain and _node_chain_enabled()
+                                     and os.environ.get("HERMNET_HALO_OVERLAP", "1") != "0"):
+            data.x, data.vec = HaloExchangeFeatures.apply(data.x, data.vec, halo.plan)
+            halo = None
         if data.get("_hn_edge_embed") is not None:
             # optional radial bases (Bessel / Bernstein): materialised basis, device ops + autograd
             data.x, data.vec = relational_layer(self.mods.values(), data.x, data.vec, data._hn_edge, g, None,
@@ -41,8 +55,9 @@ class HeteroVertexConv(nn.Module):
             self._weights = LayerWeights(self.mods.values())
         handles, li = data.get("_hn_edge_handles"), data.get("_hn_layer", 0)
         edge = data._hn_edge if handles is None else handles[li]
-        data.x, data.vec = FusedRelationalLayer.apply(data.x, data.vec, edge, g, data._hn_rbf, self._weights.refresh(),
-                                                      data.get("_hn_edge_sink"), li)
+        data.x, data.vec = FusedRelationalLayer.apply(data.x, data.vec, edge, g, data._hn_rbf,
+                                                      w if w is not None else self._weights.refresh(),
+                                                      data.get("_hn_edge_sink"), li, halo)
         return data
 
 
@@ -171,7 +186,7 @@ class HVNet(nn.Module):
         # rmnet.py:168-172 for the optional bases only: [E,R] basis from the kernel's distances
         data._hn_edge_embed = None if fused else self.radial_basis(edge[:, 3])
         data.x, data.vec = x, vec
-        data._hn_edge_handles = data._hn_edge_sink = None
+        data._hn_edge_handles = data._hn_edge_sink = data._hn_halo = None
         if fused and edge.requires_grad and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0":
             # one reduction of the edge gradients per step instead of one per layer (layer.EdgeFanout)
             # (atoms of an unknown element own the rows past type_rowptr[T]; only edges INTO them go unwritten)
@@ -182,8 +197,9 @@ class HVNet(nn.Module):
             data._hn_layer = li
             data = conv(data)
             if row_plan is not None and li + 1 < len(self.hermconvs):
-                # one exchange per layer: (x | vec) rows of halo atoms, 4H floats each
-                data.x, data.vec = HaloExchangeFeatures.apply(data.x, data.vec, row_plan)
+                # one exchange per layer: (x | vec) rows of halo atoms, 4H floats each -- due before the next layer reads
+                # them, run BY that layer (overlapped with its node projection where it can, HeteroVertexConv.forward)
+                data._hn_halo = shard.halo_overlap(graph)
         x = data.x
         if Hp != H:
             x = x[:, :H]                                                    # the read-out sees the real channels

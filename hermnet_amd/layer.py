@@ -204,10 +204,13 @@ class FusedRelationalLayer(torch.autograd.Function):
     """(x, vec, edge) -> (x_out, vec_out) for one layer, relation (row) order."""
 
     @staticmethod
-    def forward(ctx, x, vec, edge, graph, rbf, w, sink=None, li=0):
+    def forward(ctx, x, vec, edge, graph, rbf, w, sink=None, li=0, halo=None):
         """`edge`: [E,4], or this layer's handle from `EdgeFanout` ([H/64,E,4] stride-0 view; same memory).
         x / vec live in SOURCE rows, the outputs in TARGET rows; the two coincide for HVNet and differ for HTNet
-        (`graph.num_src`: one target row per atom and pair relation, relations.build_triadic)."""
+        (`graph.num_src`: one target row per atom and pair relation, relations.build_triadic).
+        `halo` (atom shards, chain path only; `sharding.HaloOverlap`): the exchange of the halo rows of (x, vec) is
+        still due -- it runs here, around the node projection: pack, start the all-to-all, project the row tiles
+        that hold no halo row, wait, unpack IN PLACE, project the rest.  The backward mirrors it."""
         Ns, H = x.shape
         N = graph.N
         T = graph.T
@@ -220,12 +223,26 @@ class FusedRelationalLayer(torch.autograd.Function):
         ctx.chain = w.chain and _node_chain_enabled()
         if ctx.chain:
             # three launches: node_pre_fwd (LayerNorm + x_proj of every relation), the message kernel, node_update_fwd
-            hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges)
+            if halo is None:
+                hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges)
+            else:
+                from .sharding import _all_to_all_rows_start
+                plan = halo.plan
+                send = nodeops.halo_rows(0, x, vec, plan.send_idx)
+                recv, work = _all_to_all_rows_start(send, plan.send_counts, plan.recv_counts, plan.group)
+                pre = nodeops.node_pre_fwd(x, w, T, windows=halo.windows, mode=2)
+                if work is not None:
+                    work.wait()
+                nodeops.halo_rows(2, x, vec, plan.recv_idx, recv)
+                hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T, windows=halo.windows, mode=1, out=pre)
+            ctx.halo = halo
             x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False)
             x_out, vec_out, vp, h2b, q23, nrm = nodeops.node_update_fwd(x1, vec1, w, graph)
             ctx.save_for_backward(x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23, nrm)
             ctx.graph, ctx.rbf, ctx.w, ctx.sink, ctx.li = graph, rbf, w, sink, li
             return x_out, vec_out
+        if halo is not None:
+            raise RuntimeError("the in-layer halo exchange belongs to the chain path (HeteroVertexConv.forward decides)")
         n, mean, rstd = nodeops.layernorm_fwd(x, 1e-5, h_real=w.h_real)
         h = _launch("gemm", lambda: torch.addmm(w.b1cat, n, w.w1cat.t()))                                     # [Ns, T*H]
         a = nodeops.ssilu_fwd(h)
@@ -333,7 +350,20 @@ class FusedRelationalLayer(torch.autograd.Function):
                     gvec_in[:Te * B_] += gvec1.view(Te, P_, B_, 3, H).sum(1).reshape(Te * B_, 3, H)
         gx_total = None
         if ctx.needs_input_grad[0]:
-            if ctx.chain:
+            if ctx.chain and ctx.halo is not None:
+                # the gradients of the halo rows first: they travel to their owners while the other tiles are computed
+                from .sharding import _all_to_all_rows_start
+                halo = ctx.halo
+                plan = halo.plan
+                out = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, windows=halo.windows, mode=1)
+                gx_total = out[0]
+                gsend = nodeops.halo_rows(1, gx_total, gvec_in, plan.recv_idx)          # pack and clear: none stays here
+                back, work = _all_to_all_rows_start(gsend, plan.recv_counts, plan.send_counts, plan.group)
+                nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, windows=halo.windows, mode=2, out=out)
+                if work is not None:
+                    work.wait()
+                nodeops.halo_accumulate(gx_total, gvec_in, plan, back)                  # gradients of my atoms used elsewhere
+            elif ctx.chain:
                 gx_total = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, src_ranges=graph.src_ranges)
             else:
                 ga = _launch("gemm", lambda: torch.bmm(gxh, w.w2))                                            # [T, Ns, H]
@@ -341,7 +371,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                 gn = _launch("gemm", lambda: torch.mm(gh, w.w1cat))                                           # [N, H]
                 gx_total = nodeops.layernorm_bwd(gn, x, mean, rstd, add=gx_in, h_real=w.h_real)
         ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
-        return gx_total, gvec_in, ge, None, None, None, None, None
+        return gx_total, gvec_in, ge, None, None, None, None, None, None
 
 
 class EnergyHead(torch.autograd.Function):

@@ -193,31 +193,42 @@ def _rowptr_host(graph):
     return c
 
 
-def node_pre_fwd(x, w, T, src_ranges=None):
+def node_pre_fwd(x, w, T, src_ranges=None, windows=None, mode=0, out=None):
     """x [Ns,H] -> (hb [T,Ns,H], xh [T,Ns,3H] incl. bias, mean [Ns], rstd [Ns])  (rmnet.py:52 for every relation).
-    `src_ranges` [T,4] int32 (HTNet): the two source-row ranges a relation gathers from; other rows are skipped."""
+    `src_ranges` [T,4] int32 (HTNet): the two source-row ranges a relation gathers from; other rows are skipped.
+    `windows` [W,2] int32 + `mode` (atom shards): 1 = only the row tiles that touch a window, 2 = only the others;
+    the second of the two calls passes the first one's result as `out`."""
     Ns, H = x.shape
     dev, dt = x.device, x.dtype
-    hb = torch.empty(T, Ns, H, dtype=dt, device=dev)
-    xh = torch.empty(T, Ns, 3 * H, dtype=dt, device=dev)
-    alloc = torch.empty if src_ranges is None else torch.zeros      # rows no relation wants keep (0, 0): finite
-    mean = alloc(Ns, dtype=dt, device=dev)
-    rstd = alloc(Ns, dtype=dt, device=dev)
+    if out is None:
+        hb = torch.empty(T, Ns, H, dtype=dt, device=dev)
+        xh = torch.empty(T, Ns, 3 * H, dtype=dt, device=dev)
+        alloc = torch.empty if src_ranges is None else torch.zeros      # rows no relation wants keep (0, 0): finite
+        mean = alloc(Ns, dtype=dt, device=dev)
+        rstd = alloc(Ns, dtype=dt, device=dev)
+    else:
+        hb, xh, mean, rstd = out
+    nwin = 0 if windows is None else int(windows.size(0))
     _lib.check(_launch("node_pre_fwd", lambda: _lib.load().hermnet_node_pre_fwd(
         P(x), P(w.w1f), P(w.b1cat), P(w.w2f), P(w.b2), P(hb), P(xh), P(mean), P(rstd), P(src_ranges), Ns, T, H, w.h_real,
-        1e-5, _stream())), "hermnet_node_pre_fwd")
+        1e-5, P(windows), nwin, mode if windows is not None else 0, _stream())), "hermnet_node_pre_fwd")
     return hb, xh, mean, rstd
 
 
-def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None, src_ranges=None):
-    """Gradient of node_pre_fwd w.r.t. x (+ add)."""
+def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None, src_ranges=None, windows=None, mode=0, out=None):
+    """Gradient of node_pre_fwd w.r.t. x (+ add).  `windows` / `mode` / `out` as in node_pre_fwd (`out` = (gx, parts) of
+    the first call)."""
     T, Ns, H = hb.shape
-    parts = torch.empty(T, Ns, H, dtype=x.dtype, device=x.device)
-    gx = torch.empty_like(x)
+    if out is None:
+        parts = torch.empty(T, Ns, H, dtype=x.dtype, device=x.device)
+        gx = torch.empty_like(x)
+    else:
+        gx, parts = out
+    nwin = 0 if windows is None else int(windows.size(0))
     _lib.check(_launch("node_pre_bwd", lambda: _lib.load().hermnet_node_pre_bwd(
         P(gxh), P(hb), P(w.w2tf), P(w.w1tf), P(parts), P(x), P(mean), P(rstd), P(add), P(gx), P(src_ranges), Ns, T, H, w.h_real,
-        _stream())), "hermnet_node_pre_bwd")
-    return gx
+        P(windows), nwin, mode if windows is not None else 0, _stream())), "hermnet_node_pre_bwd")
+    return gx if out is None and windows is None else (gx, parts)
 
 
 def node_update_fwd(x1, vec1, w, graph):

@@ -81,6 +81,41 @@ def _all_to_all_rows(buf, in_counts, out_counts, group):
     return out
 
 
+def _all_to_all_rows_start(buf, in_counts, out_counts, group):
+    """(out, work): the same exchange, started asynchronously where the backend allows it.  RCCL ("nccl") runs the
+    collective on its own stream behind everything already enqueued on the current one; kernels launched next overlap
+    with it, and `work.wait()` makes the current STREAM (not the host) wait for the result.  The gloo rehearsal
+    (ranks sharing one GPU, CPU tests) completes it here: work = None."""
+    if not buf.is_cuda or _host_staged(group, buf):
+        return _all_to_all_rows(buf, in_counts, out_counts, group), None
+    out = buf.new_empty((sum(out_counts),) + tuple(buf.shape[1:]))
+    work = dist.all_to_all_single(out, buf.contiguous(), output_split_sizes=out_counts, input_split_sizes=in_counts,
+                                  group=group, async_op=True)
+    return out, work
+
+
+class HaloOverlap(object):
+    """An exchange of (x, vec) halo rows that is still DUE when a layer starts: the fused layer
+    (`layer.FusedRelationalLayer`) runs it itself, with the node projection of the rows that do not wait for it in
+    between (compute while the halo is in flight), and mirrors that in its backward.
+    plan: ExchangePlan in relation-row order; windows: [W,2] int32 row ranges that contain every halo row."""
+
+    def __init__(self, plan, windows):
+        self.plan, self.windows = plan, windows
+
+    @staticmethod
+    def row_windows(halo_rows, type_rowptr, num_rows):
+        """One [lo, hi) row window per relation block (+ the unknown-element block) around the given rows; device
+        ops only, empty blocks give (0, 0)."""
+        T1 = int(type_rowptr.numel())                       # T + 1 block starts -> T + 1 blocks incl. unknown elements
+        dev = halo_rows.device
+        blk = torch.bucketize(halo_rows, type_rowptr.long()[1:], right=True)
+        lo = torch.full((T1,), int(num_rows), dtype=torch.long, device=dev).scatter_reduce(0, blk, halo_rows, "amin")
+        hi = torch.full((T1,), -1, dtype=torch.long, device=dev).scatter_reduce(0, blk, halo_rows, "amax") + 1
+        lo = torch.minimum(lo, hi)                          # empty block: (0, 0)
+        return torch.stack([lo, hi], dim=1).to(torch.int32).contiguous()
+
+
 class HaloExchange(torch.autograd.Function):
     """out = x with its halo entries replaced by the owners' current values (differentiable).  Used for the
     coordinates (once per step); index_select / index_copy_ / index_fill_ only: advanced-index assignment
@@ -210,8 +245,16 @@ class ShardPlan(object):
         """The atom exchange lists in the relation-row order of `row_of_node` (cached per tensor: the row layout of an
         atom set does not change along a trajectory, relations.py)."""
         if self._row_plan is None or self._row_plan[0] is not row_of_node:
-            self._row_plan = (row_of_node, self.atom_plan.remap(row_of_node))
+            self._row_plan = (row_of_node, self.atom_plan.remap(row_of_node), None)
         return self._row_plan[1]
+
+    def halo_overlap(self, graph):
+        """`HaloOverlap` of this plan for the row layout of `graph` (cached with the row plan)."""
+        plan = self.row_plan(graph.row_of_node)
+        if self._row_plan[2] is None:
+            win = HaloOverlap.row_windows(plan.recv_idx, graph.type_rowptr, graph.N)
+            self._row_plan = self._row_plan[:2] + (HaloOverlap(plan, win),)
+        return self._row_plan[2]
 
     def to(self, device):
         self.owned_global = self.owned_global.to(device)

@@ -306,15 +306,20 @@ int hermnet_energy_head_fused_bwd(const float* ge, const float* h, const float* 
  *     the backward contributes zero for them.
  * hermnet_node_pre_bwd: gx = LayerNorm'(x)^T sum_t ((gxh[t] W2_t) * ScaledSiLU'(hb[t])) W1_t + add
  *     (w2t_frag = frag(W2_t^T [H, 3H]), w1t_frag = frag(W1_t^T [H, H]); gn_parts [T, num_src, H] is workspace; add may
- *     be NULL; gx may alias add). */
+ *     be NULL; gx may alias add).
+ * row_windows (device, [num_windows][2] int32 row ranges) + window_mode (ABI v6; atom shards, no reference counterpart):
+ *     0 = every row tile (row_windows may be NULL); 1 = only the tiles (64 rows; 32 at hidden 256) that touch a window;
+ *     2 = only the others.  Two calls with modes 2 and 1 on the same buffers compute what one call with mode 0 does:
+ *     the host puts the halo exchange between them (forward: 2, wait + unpack, 1; backward: 1, send, 2). */
 int hermnet_node_chain_supported(int hidden);
 int hermnet_node_pre_fwd(const float* x, const float* w1_frag, const float* b1, const float* w2_frag, const float* b2,
                          float* hb, float* xh, float* mean, float* rstd, const int* src_ranges, int num_src,
-                         int num_rel, int hidden, int hidden_real, float eps, void* stream);
+                         int num_rel, int hidden, int hidden_real, float eps, const int* row_windows, int num_windows,
+                         int window_mode, void* stream);
 int hermnet_node_pre_bwd(const float* gxh, const float* hb, const float* w2t_frag, const float* w1t_frag,
                          float* gn_parts, const float* x, const float* mean, const float* rstd, const float* add,
                          float* gx, const int* src_ranges, int num_src, int num_rel, int hidden, int hidden_real,
-                         void* stream);
+                         const int* row_windows, int num_windows, int window_mode, void* stream);
 /* hermnet_node_update_fwd (rmnet.py:94-107, 29-31; hermnet.py:51,56-61), target rows in relation order:
  *     vp = vec1 Wv^T  [N,3,2H] = (v1 | v2), saved;   vdot = sum_d v1 v2 / sqrt(H);   n = sqrt(sum_d v2^2 + 1e-8) -> nrm
  *                                                                                    [N,H], saved

@@ -190,22 +190,73 @@ def update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, rows, H):
 
 
 # ---- node chain kernels (hermnet_amd.nodeops.node_*; csrc/node_chain.hip): same contracts, plain weights of `w` --------
-def node_pre_fwd(x, w, T, src_ranges=None):
+def _tile_rows(Ns, H, windows, mode, device):
+    """Rows of the tiles a windowed launch of the pre kernels runs (csrc/node_chain.hip: tile_selected)."""
+    TR = 32 if H == 256 else 64
+    row0 = torch.arange(Ns, device=device) // TR * TR
+    inside = torch.zeros(Ns, dtype=torch.bool, device=device)
+    for lo, hi in windows.tolist():
+        if hi > lo:
+            inside |= (row0 < hi) & (row0 + TR > lo)
+    return inside if mode == 1 else ~inside
+
+
+def node_pre_fwd(x, w, T, src_ranges=None, windows=None, mode=0, out=None):
     Ns, H = x.shape
     dt = x.dtype
     n, mean, rstd = layernorm_fwd(x, 1e-5, h_real=w.h_real)
     hb = (n @ w.w1cat.to(dt).t() + w.b1cat.to(dt)).view(Ns, T, H).transpose(0, 1).contiguous()      # [T, Ns, H]
     a = torch.nn.functional.silu(hb) / 0.6
     xh = torch.bmm(a, w.w2t.to(dt)) + w.b2.to(dt)                                                    # [T, Ns, 3H]
-    return hb, xh, mean, rstd
+    if windows is None or mode == 0:
+        return hb, xh, mean, rstd
+    # a windowed launch writes the rows of its tiles only (the rest: poison until the other launch fills it)
+    rows = _tile_rows(Ns, H, windows, mode, x.device)
+    if out is None:
+        out = tuple(torch.full_like(t_, float("nan")) for t_ in (hb, xh, mean, rstd))
+    out[0][:, rows], out[1][:, rows], out[2][rows], out[3][rows] = hb[:, rows], xh[:, rows], mean[rows], rstd[rows]
+    return out
 
 
-def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None, src_ranges=None):
+def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None, src_ranges=None, windows=None, mode=0, out=None):
     T, Ns, H = hb.shape
     dt = x.dtype
     gh = torch.bmm(gxh, w.w2.to(dt)) * _dssilu(hb)                                                   # [T, Ns, H]
     gn = torch.bmm(gh, w.w1cat.to(dt).view(T, H, H)).sum(0)
-    return layernorm_bwd(gn, x, mean, rstd, add=add, h_real=w.h_real)
+    gx = layernorm_bwd(gn, x, mean, rstd, add=add, h_real=w.h_real)
+    if windows is None or mode == 0:
+        return gx
+    rows = _tile_rows(Ns, H, windows, mode, x.device)
+    if out is None:
+        out = (torch.full_like(gx, float("nan")), None)
+    out[0][rows] = gx[rows]
+    return out
+
+
+def halo_rows(mode, x, vec, idx, buf=None):
+    """csrc/node_kernels.hip: hermnet_halo_rows -- 0 pack, 1 pack-and-clear, 2 unpack (in place)."""
+    H = x.size(1)
+    if mode in (0, 1):
+        buf = torch.cat([x.index_select(0, idx), vec.index_select(0, idx).reshape(-1, 3 * H)], dim=1)
+        if mode == 1:
+            x.index_fill_(0, idx, 0)
+            vec.index_fill_(0, idx, 0)
+        return buf
+    assert mode == 2
+    x.index_copy_(0, idx, buf[:, :H])
+    vec.index_copy_(0, idx, buf[:, H:].reshape(-1, 3, H))
+    return buf
+
+
+def halo_accumulate(x, vec, plan, buf):
+    """hermnet_halo_accumulate: returned gradients summed per owned row in send-list order."""
+    H = x.size(1)
+    if buf.size(0) == 0:
+        return
+    rows, ptr, pos = plan.accumulate_lists()
+    seg = torch.segment_reduce(buf.index_select(0, pos), "sum", lengths=ptr[1:] - ptr[:-1])
+    x.index_add_(0, rows, seg[:, :H])
+    vec.index_add_(0, rows, seg[:, H:].reshape(-1, 3, H))
 
 
 def _update_parts(x1, vec1, w, graph):

@@ -290,6 +290,22 @@ def test_node_chain_kernels_match_restatement(H, T, counts, uniform, hr):
         gx = nodeops.node_pre_bwd(c(gxh), hb, c(x), mean, rstd, wd, add=None if a is None else c(a))
         gx_r = ref_ops.node_pre_bwd(d64(gxh), hb_r, d64(x), mean_r, rstd_r, w, add=None if a is None else d64(a))
         assert rel_err(gx.cpu().double(), gx_r) < 5e-6
+    # row windows (atom shards: the halo exchange sits between two launches that partition the row tiles): the tiles
+    # outside the windows, then the tiles that touch one, give bit for bit what one launch gives -- poisoned buffers
+    # in between, windows that are empty, ragged and straddling a tile border
+    win = torch.tensor([[0, 0], [N // 3 - 5, N // 3 + 9], [N - 3, N]], dtype=torch.int32, device=dev)
+    sel = ref_ops._tile_rows(N, H, win.cpu(), 1, torch.device("cpu"))
+    assert bool(sel.any()) and (N <= 128 or not bool(sel.all()))
+    part = nodeops.node_pre_fwd(c(x), wd, T, windows=win, mode=2, out=tuple(torch.full_like(t_, float("nan")) for t_ in (hb, xh, mean, rstd)))
+    assert bool(torch.isnan(part[1][:, sel.to(dev)]).all()) and bool(torch.equal(part[1][:, ~sel.to(dev)], xh[:, ~sel.to(dev)]))
+    full = nodeops.node_pre_fwd(c(x), wd, T, windows=win, mode=1, out=part)
+    for a, b in zip(full, (hb, xh, mean, rstd)):
+        assert torch.equal(a, b)
+    poison = (torch.full_like(gx, float("nan")), torch.full((T, N, H), float("nan"), device=dev))
+    first = nodeops.node_pre_bwd(c(gxh), hb, c(x), mean, rstd, wd, add=c(add), windows=win, mode=1, out=poison)
+    assert bool(torch.equal(first[0][sel.to(dev)], gx[sel.to(dev)])) and bool(torch.isnan(first[0][~sel.to(dev)]).all())
+    both = nodeops.node_pre_bwd(c(gxh), hb, c(x), mean, rstd, wd, add=c(add), windows=win, mode=2, out=first)
+    assert torch.equal(both[0], gx)
     xo, vo, vp, h2b, q23, nrm = nodeops.node_update_fwd(c(x1), c(vec1), wd, gd)
     refs = ref_ops.node_update_fwd(d64(x1), d64(vec1), w, g)
     nk = g.type_rowptr_host[-1]

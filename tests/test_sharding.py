@@ -25,7 +25,8 @@ def _patch_cpu_ops(monkeypatch=None):
     put(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
     put(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
     for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid", "update_out", "update_out_bwd",
-               "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd", "node_update_bwd"]:
+               "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd", "node_update_bwd", "halo_rows",
+               "halo_accumulate"]:
         put(lmod.nodeops, fn, getattr(ref_ops, fn))
     put(lmod, "_msg_fwd", ref_ops.msg_fwd)
     put(lmod, "_msg_bwd", ref_ops.msg_bwd)
@@ -317,10 +318,20 @@ def _slab_worker(rank, world, port, out):
             p.requires_grad_(False)
         local, plan = partition_slab(d.pos, d.atomic_number, d.cell, SLAB_KW["rc"], rank, world)
         local.pos.requires_grad_(True)
+        # the exchange of the feature rows runs INSIDE the consuming layer (pack / unpack calls of layer.py), split
+        # around its windowed node projection
+        import hermnet_amd.layer as lmod
+        calls = {"n": 0}
+        inner = lmod.nodeops.halo_rows
+
+        def counted(*a, **k):
+            calls["n"] += 1
+            return inner(*a, **k)
+        lmod.nodeops.halo_rows = counted
         e = model(local)
         f_local = -torch.autograd.grad(e.sum(), local.pos)[0]
         out[rank] = (e.detach().numpy(), plan.owned_global.numpy(), f_local[plan.owned_local].numpy(),
-                     int(plan.halo_global.numel()), torch.nonzero(plan.has_in_edges).reshape(-1).tolist())
+                     int(plan.halo_global.numel()), torch.nonzero(plan.has_in_edges).reshape(-1).tolist(), calls["n"])
     finally:
         dist.destroy_process_group()
 
@@ -350,9 +361,10 @@ def test_slab_partition_world8_gloo_matches_single_process(monkeypatch):
     forces = np.zeros_like(f_ref.numpy())
     seen = np.zeros(forces.shape[0], dtype=int)
     for r in range(world):
-        e, owned, f, nhalo, zin = out[r]
+        e, owned, f, nhalo, zin, packs = out[r]
         assert rel_err(torch.from_numpy(e), e_ref.detach()) < 5e-6
         assert nhalo > 0 and zin == [13, 28, 29]
+        assert packs == 3 * (SLAB_KW["num_layers"] - 1)      # in-layer exchange: pack + unpack forward, pack-and-clear backward
         forces[owned] = f
         seen[owned] += 1
     assert (seen == 1).all()
