@@ -39,7 +39,7 @@ class HeteroVertexConv(nn.Module):
                 self._weights = LayerWeights(self.mods.values())
             w = self._weights.refresh()
         if halo is not None and not (w is not None and w.chain and _node_chain_enabled()
-                                     and os.environ.get("HERMNET_HALO_OVERLAP", "1") != "0"):
+                                     and os.environ.get("HERMNET_HALO_OVERLAP", "0") != "0"):
             data.x, data.vec = HaloExchangeFeatures.apply(data.x, data.vec, halo.plan)
             halo = None
         if data.get("_hn_edge_embed") is not None:

@@ -227,7 +227,8 @@ class ShardPlan(object):
         self.group = group
         self.z_with_in_edges = None           # atomic numbers that receive >= 1 edge GLOBALLY (hermnet.py:56-57): a set
         self.has_in_edges = None              # ... or the same as a device array [128] of 0/1 (slab plans)
-        self._row_plan = None                 # (row_of_node tensor, atom_plan in that row order)
+        self._row_plan = None                 # (row_of_node tensor, atom_plan in that row order, HaloOverlap)
+        self._zl_index = None                 # ((element list, device), its index tensor) for `rel_active`
 
     @property
     def n_owned(self):
@@ -237,8 +238,10 @@ class ShardPlan(object):
         """Which of the model's relations (target elements `zl`) run: a list of bool (host plans) or a uint8 device
         array (slab plans; consumed by the relation build without a host read)."""
         if self.has_in_edges is not None:
-            idx = torch.tensor([min(int(z), 127) for z in zl], dtype=torch.long, device=self.has_in_edges.device)
-            return self.has_in_edges.index_select(0, idx).to(torch.uint8)
+            key = (tuple(zl), self.has_in_edges.device)
+            if self._zl_index is None or self._zl_index[0] != key:      # (a host-to-device copy waits for the stream: once)
+                self._zl_index = (key, torch.tensor([min(int(z), 127) for z in zl], dtype=torch.long, device=key[1]))
+            return self.has_in_edges.index_select(0, self._zl_index[1]).to(torch.uint8)
         return [z in self.z_with_in_edges for z in zl]
 
     def row_plan(self, row_of_node):

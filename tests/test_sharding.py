@@ -299,11 +299,12 @@ def test_slab_stepper_reuses_the_plan_under_the_skin(world):
     assert moved_far        # the last step did cross the threshold
 
 
-def _slab_worker(rank, world, port, out):
+def _slab_worker(rank, world, port, out, overlap):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["HERMNET_HALO_OVERLAP"] = overlap
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -339,16 +340,18 @@ def _slab_worker(rank, world, port, out):
 SLAB_KW = dict(rc=5.0, num_layers=3, hidden_channels=64, num_rbf=32)
 
 
-def test_slab_partition_world8_gloo_matches_single_process(monkeypatch):
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_slab_partition_world8_gloo_matches_single_process(monkeypatch, overlap):
     """BASELINE configs[3]'s plan at world size 8 on CPU (gloo): an fcc 3x3x24 cell in 8 slabs of 10.8 A, every
     rank plans from the coordinates alone and searches only its slab; energy and forces must equal the
-    single-process evaluation of the whole cell (same host pipeline, kernels restated in PyTorch)."""
+    single-process evaluation of the whole cell (same host pipeline, kernels restated in PyTorch).  Both forms of the
+    feature exchange: between the layers, and inside the consuming layer around its windowed node projection."""
     import hermnet_amd as hn
     from hermnet_amd import synth
     world = 8
     port = 33500 + os.getpid() % 2000
     out = mp.Manager().dict()
-    mp.spawn(_slab_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_slab_worker, args=(world, port, out, overlap), nprocs=world, join=True)
     _patch_cpu_ops(monkeypatch)
     d = synth.fcc_alloy(reps=(3, 3, 24))
     model = hn.HVNet(["Al", "Ni", "Cu"], **SLAB_KW).eval()
@@ -364,18 +367,21 @@ def test_slab_partition_world8_gloo_matches_single_process(monkeypatch):
         e, owned, f, nhalo, zin, packs = out[r]
         assert rel_err(torch.from_numpy(e), e_ref.detach()) < 5e-6
         assert nhalo > 0 and zin == [13, 28, 29]
-        assert packs == 3 * (SLAB_KW["num_layers"] - 1)      # in-layer exchange: pack + unpack forward, pack-and-clear backward
+        # HERMNET_HALO_OVERLAP=1: the exchange runs inside the consuming layer (pack + unpack forward, pack-and-clear
+        # backward), split around the windowed node projection
+        assert packs == (3 * (SLAB_KW["num_layers"] - 1) if overlap == "1" else 0)
         forces[owned] = f
         seen[owned] += 1
     assert (seen == 1).all()
     assert rel_err(torch.from_numpy(forces), f_ref) < 2e-5
 
 
-def _gpu_slab_worker(rank, world, reps, port, out):
+def _gpu_slab_worker(rank, world, reps, port, out, overlap):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["HERMNET_HALO_OVERLAP"] = overlap
     dist.init_process_group("gloo", rank=rank, world_size=world)     # ranks share the GPU: exchange staged through the host
     try:
         import hermnet_amd as hn
@@ -416,14 +422,15 @@ def _gpu_slab_worker(rank, world, reps, port, out):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,reps", [(2, (10, 10, 250)), (3, (10, 10, 25))])
-def test_sharded_100k_cell_matches_single_gpu(world, reps):
+@pytest.mark.parametrize("world,reps,overlap", [(2, (10, 10, 250), "0"), (3, (10, 10, 25), "0"), (3, (10, 10, 25), "1")])
+def test_sharded_100k_cell_matches_single_gpu(world, reps, overlap):
     """BASELINE configs[3] at full size (fcc 10x10x250 = 100,000 atoms) through the sharded HIP path with slab-local
     planning, ranks sharing the one GPU of the box; energy and forces must equal the unsharded evaluation of the
-    same cell on one GPU.  (world 3 on the 10k cell: uneven slabs.)"""
+    same cell on one GPU.  (world 3 on the 10k cell: uneven slabs; overlap = "1": the feature exchange inside the
+    consuming layer, between the two windowed launches of its node projection.)"""
     port = 37500 + (os.getpid() + world) % 2000
     out = mp.Manager().dict()
-    mp.spawn(_gpu_slab_worker, args=(world, reps, port, out), nprocs=world, join=True)
+    mp.spawn(_gpu_slab_worker, args=(world, reps, port, out, overlap), nprocs=world, join=True)
     n = 4 * reps[0] * reps[1] * reps[2]
     e_ref, f_ref = torch.from_numpy(out[0]["e_ref"]), torch.from_numpy(out[0]["f_ref"])
     forces = np.zeros((n, 3), dtype=np.float32)
