@@ -60,59 +60,10 @@ __global__ __launch_bounds__(kBlock) void assign_rows_kernel(
   row_real[row] = 1.0f;
 }
 
-__global__ __launch_bounds__(kBlock) void edge_keys_kernel(const long* __restrict__ edge_index, int E,
-                                                          const int* __restrict__ row_of_node,
-                                                          unsigned* __restrict__ key, int* __restrict__ val) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < E) { key[e] = (unsigned)row_of_node[edge_index[(size_t)E + e]]; val[e] = e; }   // row(target)
-}
-
 __device__ __forceinline__ int relation_of_row(int row, const int* __restrict__ row_start, int T) {
   int t = 0;
   while (t < T && row >= row_start[t + 1]) ++t;   // row_start[T] = first unknown row
   return t;
-}
-
-// CSR-ordered per-edge arrays + the CSC sort key
-__global__ __launch_bounds__(kBlock) void csr_gather_kernel(
-    const long* __restrict__ edge_index, const float* __restrict__ shift, int E, int N, int T,
-    const int* __restrict__ row_of_node, const int* __restrict__ row_start,
-    const unsigned* __restrict__ rt_sorted, const int* __restrict__ csr_perm, int* __restrict__ csr_src,
-    int* __restrict__ src_id, int* __restrict__ tgt_id, float* __restrict__ shift_csr,
-    unsigned* __restrict__ key2, unsigned* __restrict__ key3, int* __restrict__ pos) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= E) return;
-  const int e = csr_perm[k];
-  const int s = (int)edge_index[e], t = (int)edge_index[(size_t)E + e];
-  const int rs = row_of_node[s];
-  csr_src[k] = rs;
-  src_id[k] = s;
-  tgt_id[k] = t;
-  if (shift != nullptr) {
-    shift_csr[3 * k + 0] = shift[3 * e + 0];
-    shift_csr[3 * k + 1] = shift[3 * e + 1];
-    shift_csr[3 * k + 2] = shift[3 * e + 2];
-  }
-  key2[k] = (unsigned)relation_of_row((int)rt_sorted[k], row_start, T) * (unsigned)N + (unsigned)rs;
-  key3[k] = (unsigned)rs;
-  pos[k] = k;
-}
-
-// rowptr[r] = number of sorted keys < r  (r = 0..nrows)
-__global__ __launch_bounds__(kBlock) void rowptr_kernel(const unsigned* __restrict__ sorted, int n, int nrows,
-                                                       int* __restrict__ rowptr) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r > nrows) return;
-  int lo = 0, hi = n;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted[mid] < (unsigned)r) lo = mid + 1; else hi = mid; }
-  rowptr[r] = lo;
-}
-
-__global__ __launch_bounds__(kBlock) void csc_tgt_kernel(const unsigned* __restrict__ rt_sorted,
-                                                        const int* __restrict__ csc_pos, int E,
-                                                        int* __restrict__ csc_tgt) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < E) csc_tgt[k] = (int)rt_sorted[csc_pos[k]];
 }
 
 // row_active = real row of a relation that receives >= 1 edge (hermnet.py:56-57), or the caller's override
@@ -252,6 +203,11 @@ __global__ __launch_bounds__(kBlock) void copy_i32_kernel(const int* __restrict_
   if (i < n) dst[i] = src[i];
 }
 
+__global__ __launch_bounds__(kBlock) void iota_scaled_kernel(int* __restrict__ dst, int n, int scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = i * scale;
+}
+
 struct GroupWork {
   int* cursor;      // [max keys + 1]
   int* slots;       // [n]
@@ -269,43 +225,6 @@ int group_by_key(const int* key, int n, int nkeys, int* rowptr, int* out, const 
   hipLaunchKernelGGL(scatter_kernel, grid_for(n), dim3(kBlock), 0, s, key, n, w.cursor, w.slots);
   hipLaunchKernelGGL(group_rank_sort_kernel, dim3((unsigned)((nkeys + 3) / 4)), dim3(kBlock), 0, s, rowptr, nkeys, w.slots, out);
   return HN_OK;
-}
-
-__global__ __launch_bounds__(kBlock) void edge_target_row_kernel(const long* __restrict__ edge_index, int E,
-                                                                const int* __restrict__ row_of_node,
-                                                                int* __restrict__ key) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < E) key[e] = row_of_node[edge_index[(size_t)E + e]];
-}
-
-// CSR-ordered per-edge arrays + the CSC / out-adjacency keys
-__global__ __launch_bounds__(kBlock) void csr_gather2_kernel(
-    const long* __restrict__ edge_index, const float* __restrict__ shift, int E, int N, int T,
-    const int* __restrict__ row_of_node, const int* __restrict__ row_start, const int* __restrict__ csr_perm,
-    int* __restrict__ csr_src, int* __restrict__ src_id, int* __restrict__ tgt_id, float* __restrict__ shift_csr,
-    int* __restrict__ rt_csr, int* __restrict__ key2, int* __restrict__ key3) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= E) return;
-  const int e = csr_perm[k];
-  const int s = (int)edge_index[e], t = (int)edge_index[(size_t)E + e];
-  const int rs = row_of_node[s], rt = row_of_node[t];
-  csr_src[k] = rs;
-  src_id[k] = s;
-  tgt_id[k] = t;
-  rt_csr[k] = rt;
-  if (shift != nullptr) {
-    shift_csr[3 * k + 0] = shift[3 * e + 0];
-    shift_csr[3 * k + 1] = shift[3 * e + 1];
-    shift_csr[3 * k + 2] = shift[3 * e + 2];
-  }
-  key2[k] = relation_of_row(rt, row_start, T) * N + rs;    // == T*N + rs for unknown-element targets
-  key3[k] = rs;
-}
-
-__global__ __launch_bounds__(kBlock) void csc_tgt2_kernel(const int* __restrict__ rt_csr, const int* __restrict__ csc_pos,
-                                                         int n, int* __restrict__ csc_tgt) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) csc_tgt[k] = rt_csr[csc_pos[k]];
 }
 
 // ---- fused edge orders (round 3): both histograms in one pass over the edge list, ONE scan over the concatenated
@@ -326,10 +245,11 @@ __global__ __launch_bounds__(kBlock) void edge_keys_hist_kernel(const long* __re
   atomicAdd(&hist[N + 1 + k2], 1);
 }
 
-// scan_apply for the concatenated counters: the running offsets go to `all` (cursor copy for the scatters) and, in
-// their final form, straight to csr_rowptr [N + 1] and csc_rowptr [T N + 1] (second part: minus the E edges in front)
+// scan_apply for the concatenated counters [ n1 + 1 | n2 + ... ]: the running offsets go to `all` (cursor copy for the
+// scatters) and, in their final form, straight to csr_rowptr [n1 + 1] and csc_rowptr [n2 + 1] (second part: minus the E
+// edges in front).  HVNet: n1 = N, n2 = T N; HTNet: n1 = target rows, n2 = relations x source rows.
 __global__ __launch_bounds__(kBlock) void scan_apply_orders_kernel(const int* __restrict__ in, int n, const int* __restrict__ sums,
-                                                                  int* __restrict__ all, int N, int T, int E,
+                                                                  int* __restrict__ all, int n1, long n2, int E,
                                                                   int* __restrict__ csr_rowptr, int* __restrict__ csc_rowptr) {
   __shared__ int lds[4];
   const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
@@ -343,8 +263,8 @@ __global__ __launch_bounds__(kBlock) void scan_apply_orders_kernel(const int* __
     const int i = base + q;
     if (i < n) {
       all[i] = run;
-      if (i <= N) csr_rowptr[i] = run;
-      else if (i - (N + 1) <= T * N) csc_rowptr[i - (N + 1)] = run - E;
+      if (i <= n1) csr_rowptr[i] = run;
+      else if (i - (n1 + 1) <= n2) csc_rowptr[i - (n1 + 1)] = run - E;
     }
     run += x[q];
   }
@@ -389,6 +309,75 @@ __global__ __launch_bounds__(kBlock) void csc_rank_sort_kernel(const int* __rest
   }
 }
 
+// ---- HTNet (round 3): the triadic relation orders with the same counting sort.  Relation (c; {p, q}) = centre element c,
+// unordered pair of neighbour elements; P = T (T + 1) / 2 pairs, enumerated p-major (k(p, q) = p T - p (p - 1) / 2 + q - p).
+// A directed edge j -> i is listed once for every pair that contains element(j): expanded edge x = e T + m stands for the
+// pair {element(j), m}.  SOURCE rows: the atoms in (element, id) order, blocks of B rows (Ns rows); TARGET rows: block
+// (c P + k) B + (position of i inside its element), one block per relation.  All atoms must be of listed elements.
+struct TriMap { int T, P, B, Ns; };
+
+__device__ __forceinline__ void tri_keys(const TriMap& m, int rs, int rt, int mm, int& vt, int& k2) {
+  const int a = rs / m.B, c = rt / m.B, loc = rt - c * m.B;
+  const int p = a < mm ? a : mm, q = a < mm ? mm : a;
+  const int rel = c * m.P + p * m.T - p * (p - 1) / 2 + (q - p);
+  vt = rel * m.B + loc;
+  k2 = rel * m.Ns + rs;
+}
+
+__global__ __launch_bounds__(kBlock) void tri_keys_hist_kernel(const long* __restrict__ edge_index, int E0, TriMap m,
+                                                              const int* __restrict__ row_of_node, int Nt,
+                                                              int* __restrict__ key1, int* __restrict__ hist) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= E0 * m.T) return;
+  const int e = x / m.T;
+  int vt, k2;
+  tri_keys(m, row_of_node[edge_index[e]], row_of_node[edge_index[(size_t)E0 + e]], x - e * m.T, vt, k2);
+  key1[x] = vt;
+  atomicAdd(&hist[vt], 1);
+  atomicAdd(&hist[Nt + 1 + k2], 1);
+}
+
+// CSR-ordered per-edge arrays of the expanded list (csr_perm = ORIGINAL edge id), and the scatter into the CSC groups
+__global__ __launch_bounds__(kBlock) void tri_gather_scatter_kernel(
+    const long* __restrict__ edge_index, const float* __restrict__ shift, int E0, int E, TriMap m,
+    const int* __restrict__ row_of_node, const int* __restrict__ perm_x, int* __restrict__ csr_perm,
+    int* __restrict__ csr_src, int* __restrict__ src_id, int* __restrict__ tgt_id, float* __restrict__ shift_csr,
+    int* __restrict__ rt_csr, int* __restrict__ cursor2, int* __restrict__ slots2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= E) return;
+  const int x = perm_x[k];
+  const int e = x / m.T;
+  const int s = (int)edge_index[e], t = (int)edge_index[(size_t)E0 + e];
+  const int rs = row_of_node[s];
+  int vt, k2;
+  tri_keys(m, rs, row_of_node[t], x - e * m.T, vt, k2);
+  csr_perm[k] = e;
+  csr_src[k] = rs;
+  src_id[k] = s;
+  tgt_id[k] = t;
+  rt_csr[k] = vt;
+  if (shift != nullptr) {
+    shift_csr[3 * k + 0] = shift[3 * e + 0];
+    shift_csr[3 * k + 1] = shift[3 * e + 1];
+    shift_csr[3 * k + 2] = shift[3 * e + 2];
+  }
+  slots2[atomicAdd(&cursor2[k2], 1) - E] = k;
+}
+
+// target rows: real = the atom exists; active = its relation has at least one edge (hermnet.py:56-57); res_row = the
+// atom's own source row (residual, rmnet.py:24-26)
+__global__ __launch_bounds__(kBlock) void tri_rows_kernel(TriMap m, int Nt, const int* __restrict__ elem_counts,
+                                                         const int* __restrict__ csr_rowptr, float* __restrict__ row_real,
+                                                         float* __restrict__ row_active, int* __restrict__ res_row) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= Nt) return;
+  const int rel = r / m.B, loc = r - rel * m.B, el = rel / m.P;
+  const float real = loc < elem_counts[el] ? 1.0f : 0.0f;
+  row_real[r] = real;
+  row_active[r] = (csr_rowptr[(rel + 1) * m.B] - csr_rowptr[rel * m.B]) > 0 ? real : 0.0f;
+  res_row[r] = el * m.B + loc;
+}
+
 int bits_for(unsigned max_key_exclusive) {
   int b = 1;
   while (b < 32 && (1u << b) < max_key_exclusive) ++b;
@@ -408,6 +397,22 @@ size_t work_temp_bytes(int n, int nkeys) {
 }
 
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// atoms sorted by (relation, id) into rows: node_order, row_of_node, z_rows, row_real of `out`
+int build_rows(const long* atomic_number, int NA, const int* z_list, int T, const int* row_start, int N,
+               const hn_relations_out* out, unsigned* keyA, unsigned* keyB, int* valA, void* temp, size_t tbytes,
+               hipStream_t s) {
+  hipLaunchKernelGGL(zero_i32_kernel, grid_for(N), dim3(kBlock), 0, s, out->z_rows, (long)N);
+  hipLaunchKernelGGL(zero_i32_kernel, grid_for(N), dim3(kBlock), 0, s, reinterpret_cast<int*>(out->row_real), (long)N);
+  if (NA > 0) {
+    hipLaunchKernelGGL(atom_keys_kernel, grid_for(NA), dim3(kBlock), 0, s, atomic_number, NA, z_list, T, keyA, valA);
+    if (hipcub::DeviceRadixSort::SortPairs(temp, tbytes, keyA, keyB, valA, out->node_order, NA, 0, bits_for(T + 1), s)
+        != hipSuccess) return HN_ERR_LAUNCH;
+    hipLaunchKernelGGL(assign_rows_kernel, grid_for(NA), dim3(kBlock), 0, s, keyB, out->node_order, NA, row_start,
+                       T, atomic_number, out->row_of_node, out->z_rows, out->row_real);
+  }
+  return HN_OK;
+}
 
 }  // namespace
 
@@ -456,15 +461,8 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
   // ---- rows (rows_ready: node_order / row_of_node / z_rows / row_real of `out` were filled by an earlier call with
   // the same atomic numbers and row layout -- they depend on nothing else)
   if (!rows_ready) {
-  hipLaunchKernelGGL(zero_i32_kernel, grid_for(N), dim3(kBlock), 0, s, out->z_rows, (long)N);
-  hipLaunchKernelGGL(zero_i32_kernel, grid_for(N), dim3(kBlock), 0, s, reinterpret_cast<int*>(out->row_real), (long)N);
-  if (NA > 0) {
-    hipLaunchKernelGGL(atom_keys_kernel, grid_for(NA), dim3(kBlock), 0, s, atomic_number, NA, z_list, T, keyA, valA);
-    if (hipcub::DeviceRadixSort::SortPairs(temp, tbytes, keyA, keyB, valA, out->node_order, NA, 0, bits_for(T + 1), s)
-        != hipSuccess) return HN_ERR_LAUNCH;
-    hipLaunchKernelGGL(assign_rows_kernel, grid_for(NA), dim3(kBlock), 0, s, keyB, out->node_order, NA, row_start,
-                       T, atomic_number, out->row_of_node, out->z_rows, out->row_real);
-  }
+    const int rcr = build_rows(atomic_number, NA, z_list, T, row_start, N, out, keyA, keyB, valA, temp, tbytes, s);
+    if (rcr != HN_OK) return rcr;
   }
   // ---- edge orders by counting sort (histogram -> scan -> scatter -> per-group rank sort; see the kernels above)
   int* key1 = reinterpret_cast<int*>(keyA);
@@ -486,7 +484,7 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
     if (tb < scan_temp_bytes(n)) return HN_ERR_BAD_ARG;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(kBlock), 0, s, hist, n, sums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, s, sums, nb);
-    hipLaunchKernelGGL(scan_apply_orders_kernel, dim3(nb), dim3(kBlock), 0, s, hist, n, sums, rp_all, N, T, E, out->csr_rowptr,
+    hipLaunchKernelGGL(scan_apply_orders_kernel, dim3(nb), dim3(kBlock), 0, s, hist, n, sums, rp_all, N, (long)T * N, E, out->csr_rowptr,
                        out->csc_rowptr);
   }
   if (E > 0) {
@@ -519,5 +517,78 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
   }
   hipLaunchKernelGGL(row_active_kernel, grid_for(N), dim3(kBlock), 0, s, out->csc_rowptr, row_start, N, T,
                      rel_active, out->row_real, out->row_active);
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}
+
+extern "C" size_t hermnet_build_triadic_workspace(int num_atoms, int num_edges, int num_elem, int block) {
+  const size_t T = (size_t)num_elem, P = T * (T + 1) / 2, TR = T * P;
+  const size_t Ns = T * (size_t)block, Nt = TR * (size_t)block, E = T * (size_t)num_edges;
+  const size_t n = (E > (size_t)num_atoms ? E : (size_t)num_atoms) + 1;
+  const size_t nall = (Nt + 1) + TR * Ns + 1;
+  return align256(work_temp_bytes((int)n, (int)(nall + 4))) + 4 * align256(n * sizeof(unsigned)) + 2 * align256((nall + 2) * sizeof(int)) +
+         align256((T + 1) * sizeof(int)) + 256;
+}
+
+extern "C" int hermnet_build_triadic(const long* atomic_number, const long* edge_index, const float* shift,
+                                     int num_atoms, int num_edges, const int* z_list, int num_elem, int block,
+                                     const int* elem_counts, const hn_relations_out* out, float* tgt_row_real,
+                                     int* res_row, int rows_ready, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  const int NA = num_atoms, E0 = num_edges, T = num_elem, B = block;
+  if (NA < 0 || E0 < 0 || T <= 0 || B < 0 || !out || !z_list || !elem_counts || !tgt_row_real || !res_row) return HN_ERR_BAD_ARG;
+  const long P = (long)T * (T + 1) / 2, TR = T * P, Ns = (long)T * B, Nt = TR * B, E = (long)T * E0;
+  if (TR * Ns + Nt + 8 >= 0x7FFFFFFFl || E >= 0x7FFFFFFFl || Ns < NA) return HN_ERR_BAD_ARG;      // keys and counters are int32
+  if (!workspace || workspace_bytes < hermnet_build_triadic_workspace(NA, E0, T, B)) return HN_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t n = (size_t)(E > NA ? E : NA) + 1;
+  const size_t nall = (size_t)(Nt + 1) + (size_t)(TR * Ns) + 1;
+  char* w = reinterpret_cast<char*>(workspace);
+  const size_t tb = align256(work_temp_bytes((int)n, (int)(nall + 4)));
+  void* temp = w; w += tb;
+  unsigned* keyA = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
+  unsigned* keyB = reinterpret_cast<unsigned*>(w); w += align256(n * sizeof(unsigned));
+  int* valA = reinterpret_cast<int*>(w); w += align256(n * sizeof(unsigned));
+  int* rt_csr = reinterpret_cast<int*>(w); w += align256(n * sizeof(unsigned));
+  int* hist = reinterpret_cast<int*>(w); w += align256(sizeof(int) * (nall + 2));
+  int* rp_all = reinterpret_cast<int*>(w); w += align256(sizeof(int) * (nall + 2));
+  int* row_start = reinterpret_cast<int*>(w); w += align256(sizeof(int) * (T + 1));
+  const TriMap m = {T, (int)P, B, (int)Ns};
+  if (!rows_ready) {      // source rows: the HVNet layout with every element padded to `block` rows
+    // (row_start[t] = t B, written by a kernel: the stream may be capturing)
+    hipLaunchKernelGGL(zero_i32_kernel, grid_for(T + 1), dim3(kBlock), 0, s, row_start, (long)T + 1);
+    hipLaunchKernelGGL(iota_scaled_kernel, grid_for(T + 1), dim3(kBlock), 0, s, row_start, T + 1, B);
+    const int rcr = build_rows(atomic_number, NA, z_list, T, row_start, (int)Ns, out, keyA, keyB, valA, temp, tb, s);
+    if (rcr != HN_OK) return rcr;
+  }
+  int* key1 = reinterpret_cast<int*>(keyA);
+  int* perm_x = reinterpret_cast<int*>(keyB);
+  int* slots = valA;
+  int* cursor = hist;
+  hipLaunchKernelGGL(zero_i32_kernel, grid_for((long)nall), dim3(kBlock), 0, s, hist, (long)nall);
+  if (E > 0)
+    hipLaunchKernelGGL(tri_keys_hist_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, E0, m, out->row_of_node, (int)Nt, key1, hist);
+  {
+    const int nn = (int)nall, nb = (nn + kScanTile - 1) / kScanTile;
+    int* sums = reinterpret_cast<int*>(temp);
+    if (tb < scan_temp_bytes(nn)) return HN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(kBlock), 0, s, hist, nn, sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, s, sums, nb);
+    hipLaunchKernelGGL(scan_apply_orders_kernel, dim3(nb), dim3(kBlock), 0, s, hist, nn, sums, rp_all, (int)Nt, TR * Ns, (int)E,
+                       out->csr_rowptr, out->csc_rowptr);
+  }
+  if (E > 0) {
+    hipLaunchKernelGGL(copy_i32_kernel, grid_for((long)nall), dim3(kBlock), 0, s, rp_all, (int)nall, cursor);
+    hipLaunchKernelGGL(scatter_kernel, grid_for(E), dim3(kBlock), 0, s, key1, (int)E, cursor, slots);
+    hipLaunchKernelGGL(group_rank_sort_kernel, dim3((unsigned)((Nt + 3) / 4)), dim3(kBlock), 0, s, rp_all, (int)Nt, slots, perm_x);
+    hipLaunchKernelGGL(tri_gather_scatter_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, shift, E0, (int)E, m,
+                       out->row_of_node, perm_x, out->csr_perm, out->csr_src, out->src_id, out->tgt_id, out->shift_csr, rt_csr,
+                       cursor + Nt + 1, slots);
+    const int ng2 = (int)(TR * Ns);
+    hipLaunchKernelGGL(csc_rank_sort_kernel, dim3((unsigned)((ng2 + 3) / 4)), dim3(kBlock), 0, s, rp_all + Nt + 1, (int)E, ng2, slots,
+                       rt_csr, out->csc_pos, out->csc_tgt);
+  }
+  if (Nt > 0)
+    hipLaunchKernelGGL(tri_rows_kernel, grid_for(Nt), dim3(kBlock), 0, s, m, (int)Nt, elem_counts, out->csr_rowptr, tgt_row_real,
+                       out->row_active, res_row);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }

@@ -99,6 +99,35 @@ class RelationalGraph(object):
         return uniform, block, starts, starts[T] + cnt_host[T]
 
     @staticmethod
+    def _atom_counts(atomic_number, batch, z_list):
+        """(z_list on the device, atoms per relation + unknown [T+1] on the host, number of graphs, atomic numbers as
+        int64, {row-layout cache}) of these atoms: a host sync, skipped while the same tensors are passed again (atom
+        types and batch assignment do not change along an MD trajectory).  Keyed on the identity of the caller's
+        tensor OBJECTS, which the cache keeps alive: an address alone could be reused by a different tensor of the
+        same size."""
+        from . import _lib
+        lib = _lib.load()
+        dev = atomic_number.device
+        NA, T = int(atomic_number.numel()), len(z_list)
+        i32, P = torch.int32, _lib.ptr
+        for ent in _COUNT_CACHE:
+            if (ent[0] is atomic_number and ent[1] == atomic_number._version and ent[2] is batch
+                    and ent[3] == (None if batch is None else batch._version) and ent[4] == tuple(z_list)):
+                return ent[5]
+        from .ops import _stream
+        z = atomic_number.long().contiguous()
+        zl = torch.tensor(list(z_list), dtype=i32, device=dev)
+        counts = torch.empty(T + 1, dtype=i32, device=dev)
+        _lib.check(lib.hermnet_relation_counts(P(z), NA, P(zl), T, P(counts), _stream()), "hermnet_relation_counts")
+        nb = batch.long().max().reshape(1) + 1 if (batch is not None and NA > 0) else torch.ones(1, dtype=torch.long, device=dev)
+        host = torch.cat([counts.long(), nb]).cpu().tolist()
+        hit = (zl, host[:T + 1], int(host[-1]), z, {})
+        _COUNT_CACHE.insert(0, (atomic_number, atomic_number._version, batch,
+                                None if batch is None else batch._version, tuple(z_list), hit))
+        del _COUNT_CACHE[8:]
+        return hit
+
+    @staticmethod
     def _build_native(atomic_number, edge_index, z_list, edge_shift, batch, rel_active, uniform):
         import ctypes
         from . import _lib
@@ -110,27 +139,7 @@ class RelationalGraph(object):
         g.num_atoms, g.E, g.T, g.device = NA, E, T, dev
         ei = edge_index.long().contiguous()
         i32, P = torch.int32, _lib.ptr
-        # element counts and graph count: a host sync, skipped while the same tensors are passed again
-        # (atom types and batch assignment do not change along an MD trajectory).  Keyed on the identity of the
-        # caller's tensor OBJECTS, which the cache keeps alive: an address alone could be reused by a different
-        # tensor of the same size.
-        hit = None
-        for ent in _COUNT_CACHE:
-            if (ent[0] is atomic_number and ent[1] == atomic_number._version and ent[2] is batch
-                    and ent[3] == (None if batch is None else batch._version) and ent[4] == tuple(z_list)):
-                hit = ent[5]
-                break
-        if hit is None:
-            z = atomic_number.long().contiguous()
-            zl = torch.tensor(list(z_list), dtype=i32, device=dev)
-            counts = torch.empty(T + 1, dtype=i32, device=dev)
-            _lib.check(lib.hermnet_relation_counts(P(z), NA, P(zl), T, P(counts), _stream()), "hermnet_relation_counts")
-            nb = batch.long().max().reshape(1) + 1 if (batch is not None and NA > 0) else torch.ones(1, dtype=torch.long, device=dev)
-            host = torch.cat([counts.long(), nb]).cpu().tolist()
-            hit = (zl, host[:T + 1], int(host[-1]), z, {})
-            _COUNT_CACHE.insert(0, (atomic_number, atomic_number._version, batch,
-                                    None if batch is None else batch._version, tuple(z_list), hit))
-            del _COUNT_CACHE[8:]
+        hit = RelationalGraph._atom_counts(atomic_number, batch, z_list)
         zl, cnt_host, g.num_graphs, z = hit[:4]
         rows_cache = hit[4]                   # {(uniform layout key): row arrays}: they depend on the atoms only
         g.uniform, g.block, starts, N = RelationalGraph._layout(cnt_host, T, uniform)
@@ -286,6 +295,79 @@ class RelationalGraph(object):
         return g
 
     @staticmethod
+    def _build_triadic_native(atomic_number, edge_index, z_list, edge_shift, batch):
+        """`build_triadic` through `hermnet_build_triadic` (csrc/relation_kernels.hip); None when an atom is of an
+        element outside `z_list` (the torch build handles those)."""
+        import ctypes
+        from . import _lib
+        from .ops import _stream
+        lib = _lib.load()
+        dev = atomic_number.device
+        NA, E0, T = int(atomic_number.numel()), int(edge_index.size(1)), len(z_list)
+        zl, cnt_host, num_graphs, z, rows_cache = RelationalGraph._atom_counts(atomic_number, batch, z_list)
+        if cnt_host[T] != 0:
+            return None
+        Pn = T * (T + 1) // 2
+        TR, B = T * Pn, max(cnt_host[:T])
+        Ns, Nt, E = T * B, TR * B, T * E0
+        if TR * Ns + Nt + 8 >= 2 ** 31 or E >= 2 ** 31:
+            return None
+        g = RelationalGraph()
+        g.num_atoms, g.T, g.device, g.uniform, g.block, g.num_graphs = NA, TR, dev, True, B, num_graphs
+        g.N, g.num_src, g.triadic_pairs, g.E = Nt, Ns, Pn, E
+        g.type_rowptr_host = [r * B for r in range(TR + 1)]
+        g.type_rowptr = _cached_i32(tuple(g.type_rowptr_host), dev)
+        i32, P = torch.int32, _lib.ptr
+        e32 = lambda n: torch.empty(n, dtype=i32, device=dev)
+        rows = rows_cache.get(("triadic", B))
+        rows_ready = rows is not None
+        if rows is None:
+            rows = dict(node_order=e32(NA), row_of_node=e32(NA), z_rows=e32(Ns),
+                        src_real=torch.empty(Ns, dtype=torch.float32, device=dev))
+        g.src_real = g.row_real = rows["src_real"]                 # the energy read-out masks SOURCE rows
+        g.row_active = torch.empty(Nt, dtype=torch.float32, device=dev)
+        tgt_real = torch.empty(Nt, dtype=torch.float32, device=dev)
+        g.res_row = e32(Nt)
+        g.csr_rowptr, g.csr_src, g.csr_perm, g.src_id, g.tgt_id = e32(Nt + 1), e32(E), e32(E), e32(E), e32(E)
+        g.csc_rowptr, g.csc_tgt, g.csc_pos = e32(TR * Ns + 1), e32(E), e32(E)
+        g.out_rowptr = g.out_edges = None
+        ei = edge_index.long().contiguous()
+        shift = None if edge_shift is None else edge_shift.float().contiguous()
+        g.shift = None if shift is None else torch.empty(E, 3, dtype=torch.float32, device=dev)
+        counts_d = _cached_i32(tuple(cnt_host[:T]), dev)
+        wbytes = lib.hermnet_build_triadic_workspace(NA, E0, T, B)
+        work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        out = _lib.RelationsOut(P(rows["node_order"]), P(rows["row_of_node"]), P(rows["z_rows"]), P(rows["src_real"]),
+                                P(g.row_active), P(g.csr_rowptr), P(g.csr_src), P(g.csr_perm), P(g.src_id), P(g.tgt_id),
+                                P(g.shift), P(g.csc_rowptr), P(g.csc_tgt), P(g.csc_pos), None, None)
+        _lib.check(lib.hermnet_build_triadic(P(z), P(ei), P(shift), NA, E0, P(zl), T, B, P(counts_d), ctypes.byref(out),
+                                             P(tgt_real), P(g.res_row), 1 if rows_ready else 0, P(work), wbytes, _stream()),
+                   "hermnet_build_triadic")
+        if not rows_ready:
+            rows["z_rows64"] = rows["z_rows"].long()
+            rows["row_of_node64"] = rows["row_of_node"].long()
+            rows["node_order64"] = rows["node_order"].long()
+            rows["batch32"] = None if batch is None else batch.to(i32).contiguous()
+            if len(rows_cache) > 4:
+                rows_cache.clear()
+            rows_cache[("triadic", B)] = rows
+        g.z_rows, g.row_of_node, g.node_order = rows["z_rows64"], rows["row_of_node64"], rows["node_order64"]
+        g.batch32 = rows["batch32"]
+        g.batch_rows = None
+        pairs = [(p, q) for p in range(T) for q in range(p, T)]
+        g.src_ranges = _cached_i32(tuple(v for _c in range(T) for (p_, q_) in pairs
+                                         for v in (p_ * B, p_ * B + cnt_host[p_], (q_ * B if q_ != p_ else 0),
+                                                   (q_ * B + cnt_host[q_] if q_ != p_ else 0))), dev).view(TR, 4)
+        if batch is not None and g.num_graphs > 1:
+            g.graph_perm = torch.argsort(batch.long(), stable=True)
+            g.graph_lengths = torch.zeros(g.num_graphs, dtype=torch.long, device=dev).index_add_(
+                0, batch.long(), torch.ones_like(batch.long()))
+        else:
+            g.graph_perm = None
+            g.graph_lengths = None
+        return g
+
+    @staticmethod
     def build_triadic(atomic_number, edge_index, z_list, edge_shift=None, batch=None):
         """HTNet's relation-ordered graph (DESIGN.md "HTNet"): relation rho = (centre element c, unordered pair
         {p, q} of neighbour elements), T * T(T+1)/2 of them.
@@ -297,8 +379,14 @@ class RelationalGraph(object):
         once for every pair that contains element(j), i.e. T times: CSR by target row, CSC by (relation, SOURCE row),
         which is exactly the layout the message kernels consume with `num_src` / `res_row` set.
 
-        Built with device-side torch ops (three stable sorts per neighbour list; HTNet is a secondary path -- the
-        HVNet build has its own kernels)."""
+        GPU tensors whose atoms are all of listed elements take the device-side build (`hermnet_build_triadic`, the
+        HVNet build's counting sort over the expanded list); everything else the torch-op build below, which defines
+        the result (tests/test_htnet.py compares the two)."""
+        if (atomic_number.is_cuda and os.environ.get("HERMNET_NATIVE_RELATIONS", "1") != "0" and len(z_list) > 0
+                and atomic_number.numel() > 0):
+            g = RelationalGraph._build_triadic_native(atomic_number, edge_index, z_list, edge_shift, batch)
+            if g is not None:
+                return g
         g = RelationalGraph()
         dev = atomic_number.device
         NA, E0, T = int(atomic_number.numel()), int(edge_index.size(1)), len(z_list)

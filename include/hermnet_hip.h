@@ -147,6 +147,22 @@ int hermnet_build_relations(const long* atomic_number, const long* edge_index, c
                             const hn_relations_out* out, int rows_ready, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* HTNet (README.md:27 "Heterogeneous Triadic Networks"; build-defined): the relation orders of the
+ * triadic graph with the same counting sort (ABI v6).  Relation (c; {p, q}) = centre element c and an unordered pair of
+ * neighbour elements, T * P of them (P = T (T + 1) / 2, pairs enumerated p-major); a directed edge j -> i is listed
+ * once per pair that contains element(j): E = T * num_edges entries.  SOURCE rows = the atoms in (element, id) order,
+ * every element padded to `block` rows (Ns = T * block); TARGET rows = one block per relation (Nt = T * P * block).
+ * Every atom must be of a listed element (the host falls back to its torch build otherwise).
+ * out: node_order, row_of_node [NA], z_rows, row_real [Ns] (source rows; skipped when rows_ready), row_active [Nt],
+ * csr_rowptr [Nt+1], csr_src / csr_perm (ORIGINAL edge id) / src_id / tgt_id [E], shift_csr [E,3], csc_rowptr
+ * [T P Ns + 1] (groups = relation * Ns + source row), csc_tgt, csc_pos [E]; out_rowptr / out_edges unused.
+ * elem_counts [T] device ints (atoms per element); tgt_row_real [Nt]; res_row [Nt] = the atom's own source row. */
+size_t hermnet_build_triadic_workspace(int num_atoms, int num_edges, int num_elem, int block);
+int hermnet_build_triadic(const long* atomic_number, const long* edge_index, const float* shift, int num_atoms,
+                          int num_edges, const int* z_list, int num_elem, int block, const int* elem_counts,
+                          const hn_relations_out* out, float* tgt_row_real, int* res_row, int rows_ready,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- A2: HVNet.with_edge (hermnet.py:133-152) -------------------------------------------
  * edge[e] = (rx, ry, rz, d) for CSR edge e, D = pos[src] - pos[tgt] (+ shift @ cell[batch[src]]),
  * d = |D| with d ~ 0 (atol 1e-6) replaced by 1e-6, r = D / d.

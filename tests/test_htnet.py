@@ -153,6 +153,42 @@ def test_hip_path_matches_oracle(name, elems, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["alloy108", "mol16", "c1_si64", "alloy10k", "molecules64"])
+def test_native_triadic_build_is_the_torch_build(case, monkeypatch):
+    """`hermnet_build_triadic` (counting sort over the expanded edge list) vs the torch-op build that defines the
+    result: every array of the graph bit for bit, twice (the second call reuses the cached row layout)."""
+    from hermnet_amd.relations import RelationalGraph
+    from hermnet_amd.elements import atomic_numbers
+    dev = _dev()
+    if case == "alloy10k":
+        d, elems = synth.fcc_alloy(), ["Al", "Ni", "Cu"]
+    elif case == "molecules64":
+        d, elems = synth.molecule_batch(num_graphs=64), ["H", "C", "O"]
+    else:
+        d = Golden(case).data()
+        elems = {"alloy108": ["Al", "Ni", "Cu"], "mol16": ["H", "C", "O"], "c1_si64": ["Si"]}[case]
+    zl = [atomic_numbers[e] for e in elems]
+    d = d.to(dev)
+    args = (d.atomic_number, d.edge_index, zl, d.get("edge_shift"), d.batch)
+    monkeypatch.setenv("HERMNET_NATIVE_RELATIONS", "0")
+    ref = RelationalGraph.build_triadic(*args)
+    monkeypatch.setenv("HERMNET_NATIVE_RELATIONS", "1")
+    for _ in range(2):
+        g = RelationalGraph.build_triadic(*args)
+        assert (g.N, g.E, g.T, g.num_src, g.block, g.triadic_pairs, g.num_graphs) == \
+               (ref.N, ref.E, ref.T, ref.num_src, ref.block, ref.triadic_pairs, ref.num_graphs)
+        assert g.type_rowptr_host == ref.type_rowptr_host
+        for k in ["type_rowptr", "node_order", "row_of_node", "z_rows", "src_real", "row_real", "row_active", "res_row",
+                  "csr_rowptr", "csr_src", "csr_perm", "src_id", "tgt_id", "shift", "csc_rowptr", "csc_tgt", "csc_pos",
+                  "src_ranges", "batch32"]:
+            a, b = getattr(g, k), getattr(ref, k)
+            assert (a is None) == (b is None), k
+            if a is not None:
+                assert a.shape == b.shape and torch.equal(a.long() if not a.is_floating_point() else a,
+                                                          b.long() if not b.is_floating_point() else b), k
+
+
+@pytest.mark.gpu
 def test_single_element_htnet_is_hvnet_gpu():
     g = Golden("c1_si64")
     hv = g.model()
