@@ -62,7 +62,7 @@ SIGNATURES = {
                                                ctypes.c_size_t, c_fp]),
     "hermnet_build_triadic_workspace": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "hermnet_build_triadic": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int,
-                                             c_fp, ctypes.POINTER(RelationsOut), c_fp, c_fp, ctypes.c_int, c_fp,
+                                             c_fp, c_fp, ctypes.POINTER(RelationsOut), c_fp, c_fp, ctypes.c_int, c_fp,
                                              ctypes.c_size_t, c_fp]),
     "hermnet_ssilu_fwd": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_long, ctypes.c_int, c_fp]),
     "hermnet_ssilu_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -367,14 +367,17 @@ __global__ __launch_bounds__(kBlock) void tri_gather_scatter_kernel(
 // target rows: real = the atom exists; active = its relation has at least one edge (hermnet.py:56-57); res_row = the
 // atom's own source row (residual, rmnet.py:24-26)
 __global__ __launch_bounds__(kBlock) void tri_rows_kernel(TriMap m, int Nt, const int* __restrict__ elem_counts,
-                                                         const int* __restrict__ csr_rowptr, float* __restrict__ row_real,
-                                                         float* __restrict__ row_active, int* __restrict__ res_row) {
+                                                         const int* __restrict__ csr_rowptr,
+                                                         const unsigned char* __restrict__ rel_active,
+                                                         float* __restrict__ row_real, float* __restrict__ row_active,
+                                                         int* __restrict__ res_row) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= Nt) return;
   const int rel = r / m.B, loc = r - rel * m.B, el = rel / m.P;
   const float real = loc < elem_counts[el] ? 1.0f : 0.0f;
   row_real[r] = real;
-  row_active[r] = (csr_rowptr[(rel + 1) * m.B] - csr_rowptr[rel * m.B]) > 0 ? real : 0.0f;
+  const bool act = rel_active ? rel_active[rel] != 0 : (csr_rowptr[(rel + 1) * m.B] - csr_rowptr[rel * m.B]) > 0;
+  row_active[r] = act ? real : 0.0f;
   res_row[r] = el * m.B + loc;
 }
 
@@ -531,9 +534,9 @@ extern "C" size_t hermnet_build_triadic_workspace(int num_atoms, int num_edges, 
 
 extern "C" int hermnet_build_triadic(const long* atomic_number, const long* edge_index, const float* shift,
                                      int num_atoms, int num_edges, const int* z_list, int num_elem, int block,
-                                     const int* elem_counts, const hn_relations_out* out, float* tgt_row_real,
-                                     int* res_row, int rows_ready, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+                                     const int* elem_counts, const unsigned char* rel_active,
+                                     const hn_relations_out* out, float* tgt_row_real, int* res_row, int rows_ready,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
   const int NA = num_atoms, E0 = num_edges, T = num_elem, B = block;
   if (NA < 0 || E0 < 0 || T <= 0 || B < 0 || !out || !z_list || !elem_counts || !tgt_row_real || !res_row) return HN_ERR_BAD_ARG;
   const long P = (long)T * (T + 1) / 2, TR = T * P, Ns = (long)T * B, Nt = TR * B, E = (long)T * E0;
@@ -588,7 +591,7 @@ extern "C" int hermnet_build_triadic(const long* atomic_number, const long* edge
                        rt_csr, out->csc_pos, out->csc_tgt);
   }
   if (Nt > 0)
-    hipLaunchKernelGGL(tri_rows_kernel, grid_for(Nt), dim3(kBlock), 0, s, m, (int)Nt, elem_counts, out->csr_rowptr, tgt_row_real,
-                       out->row_active, res_row);
+    hipLaunchKernelGGL(tri_rows_kernel, grid_for(Nt), dim3(kBlock), 0, s, m, (int)Nt, elem_counts, out->csr_rowptr, rel_active,
+                       tgt_row_real, out->row_active, res_row);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }

@@ -9,7 +9,7 @@ from torch import nn
 from .elements import atomic_numbers
 from .ops import EdgeGeometry, TrueEdgeGradient, edge_radial_table
 from .relations import RelationalGraph
-from .sharding import HaloExchange, HaloExchangeFeatures, SumAcrossRanks
+from .sharding import HaloExchange, HaloExchangeFeatures, HaloGradReturn, SumAcrossRanks
 from .layer import EdgeFanout, EdgeGradSink, EnergyHead, FusedRelationalLayer, LayerWeights, _node_chain_enabled
 from .rmnet import PaiNNModule, RadialBasis, ScaledSiLU, relational_layer
 
@@ -38,7 +38,7 @@ class HeteroVertexConv(nn.Module):
             if self._weights is None:
                 self._weights = LayerWeights(self.mods.values())
             w = self._weights.refresh()
-        if halo is not None and not (w is not None and w.chain and _node_chain_enabled()
+        if halo is not None and not (w is not None and w.chain and _node_chain_enabled() and g.num_src == 0
                                      and os.environ.get("HERMNET_HALO_OVERLAP", "0") != "0"):
             data.x, data.vec = HaloExchangeFeatures.apply(data.x, data.vec, halo.plan)
             halo = None
@@ -161,7 +161,10 @@ class HVNet(nn.Module):
                                           "DistributedDataParallel over whole graphs (example/dist_train.py:63)")
             if shard.owned_mask.device != pos.device:
                 shard.to(pos.device)
-            pos = HaloExchange.apply(pos, shard.atom_plan)                  # halo coordinates from their owners
+            if shard.halo_pos_local:       # coordinates are there; their gradients still go home
+                pos = HaloGradReturn.apply(pos, shard.atom_plan)
+            else:
+                pos = HaloExchange.apply(pos, shard.atom_plan)              # halo coordinates from their owners
             row_plan = shard.row_plan(graph.row_of_node)
         if train:
             edge = self._edge_geometry_autograd(pos, data.get("cell"), graph)
@@ -323,11 +326,10 @@ class HTNet(HVNet):
                 mods={k: PaiNNModule(hidden_channels=hidden_channels, num_rbf=num_rbf) for k in keys}))
 
     def _build_graph(self, data, zl, shard):
-        if shard is not None:
-            raise NotImplementedError("atom-sharded evaluation is implemented for HVNet")
         return RelationalGraph.build_triadic(data.atomic_number, data.edge_index, zl,
                                              edge_shift=data.get("edge_shift") if data.get("cell") is not None else None,
-                                             batch=data.batch)
+                                             batch=data.batch,
+                                             rel_active=None if shard is None else shard.rel_active_triadic(zl))
 
     def forward(self, data):
         if (self.training or self.eval_param_grads) and torch.is_grad_enabled():

@@ -295,7 +295,7 @@ class RelationalGraph(object):
         return g
 
     @staticmethod
-    def _build_triadic_native(atomic_number, edge_index, z_list, edge_shift, batch):
+    def _build_triadic_native(atomic_number, edge_index, z_list, edge_shift, batch, rel_active=None):
         """`build_triadic` through `hermnet_build_triadic` (csrc/relation_kernels.hip); None when an atom is of an
         element outside `z_list` (the torch build handles those)."""
         import ctypes
@@ -340,7 +340,11 @@ class RelationalGraph(object):
         out = _lib.RelationsOut(P(rows["node_order"]), P(rows["row_of_node"]), P(rows["z_rows"]), P(rows["src_real"]),
                                 P(g.row_active), P(g.csr_rowptr), P(g.csr_src), P(g.csr_perm), P(g.src_id), P(g.tgt_id),
                                 P(g.shift), P(g.csc_rowptr), P(g.csc_tgt), P(g.csc_pos), None, None)
-        _lib.check(lib.hermnet_build_triadic(P(z), P(ei), P(shift), NA, E0, P(zl), T, B, P(counts_d), ctypes.byref(out),
+        if torch.is_tensor(rel_active):
+            act = rel_active.to(device=dev, dtype=torch.uint8).contiguous()
+        else:
+            act = None if rel_active is None else _cached_u8(tuple(bool(a) for a in rel_active), dev)
+        _lib.check(lib.hermnet_build_triadic(P(z), P(ei), P(shift), NA, E0, P(zl), T, B, P(counts_d), P(act), ctypes.byref(out),
                                              P(tgt_real), P(g.res_row), 1 if rows_ready else 0, P(work), wbytes, _stream()),
                    "hermnet_build_triadic")
         if not rows_ready:
@@ -368,7 +372,7 @@ class RelationalGraph(object):
         return g
 
     @staticmethod
-    def build_triadic(atomic_number, edge_index, z_list, edge_shift=None, batch=None):
+    def build_triadic(atomic_number, edge_index, z_list, edge_shift=None, batch=None, rel_active=None):
         """HTNet's relation-ordered graph (DESIGN.md "HTNet"): relation rho = (centre element c, unordered pair
         {p, q} of neighbour elements), T * T(T+1)/2 of them.
 
@@ -379,12 +383,14 @@ class RelationalGraph(object):
         once for every pair that contains element(j), i.e. T times: CSR by target row, CSC by (relation, SOURCE row),
         which is exactly the layout the message kernels consume with `num_src` / `res_row` set.
 
+        `rel_active` [T P] (list or device tensor): overrides "a relation runs iff it receives an edge here" (atom shards).
+
         GPU tensors whose atoms are all of listed elements take the device-side build (`hermnet_build_triadic`, the
         HVNet build's counting sort over the expanded list); everything else the torch-op build below, which defines
         the result (tests/test_htnet.py compares the two)."""
         if (atomic_number.is_cuda and os.environ.get("HERMNET_NATIVE_RELATIONS", "1") != "0" and len(z_list) > 0
                 and atomic_number.numel() > 0):
-            g = RelationalGraph._build_triadic_native(atomic_number, edge_index, z_list, edge_shift, batch)
+            g = RelationalGraph._build_triadic_native(atomic_number, edge_index, z_list, edge_shift, batch, rel_active)
             if g is not None:
                 return g
         g = RelationalGraph()
@@ -466,7 +472,14 @@ class RelationalGraph(object):
         row_real = (r_loc < cnt_d[r_el.clamp(max=max(T - 1, 0))]).float() if Nt > 0 else torch.zeros(0, device=dev)
         tn = torch.arange(TR + 1, device=dev) * B
         rel_edges = csr_rowptr[tn[1:]] - csr_rowptr[tn[:-1]] if TR > 0 else torch.zeros(0, dtype=torch.long, device=dev)
-        g.row_active = (rel_edges > 0)[r_rel].float() * row_real if Nt > 0 else row_real
+        # (`rel_active` [T P]: the caller knows better, e.g. a shard whose relation has edges on other ranks only)
+        if rel_active is None:
+            act = rel_edges > 0
+        elif torch.is_tensor(rel_active):
+            act = rel_active.to(dev).bool()
+        else:
+            act = torch.tensor([bool(a) for a in rel_active], dtype=torch.bool, device=dev)
+        g.row_active = act[r_rel].float() * row_real if Nt > 0 else row_real
         g.res_row = (r_el * B + r_loc).to(i32)
         # relation (c; p, q) gathers sources of elements p and q only: the x_proj chain skips the other rows
         g.src_ranges = _cached_i32(tuple(v for _c in range(T) for (p_, q_) in pairs

@@ -143,6 +143,21 @@ class HaloExchange(torch.autograd.Function):
         return gx, None
 
 
+class HaloGradReturn(torch.autograd.Function):
+    """Identity on coordinates whose halo rows are ALREADY the owners' values (slab plans: every rank is handed all
+    coordinates, `slab_data`); the backward sends the gradients of the halo rows to their owners and accumulates them
+    there -- the return half of `HaloExchange`, without the forward collective."""
+
+    @staticmethod
+    def forward(ctx, x, plan):
+        ctx.plan = plan
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return HaloExchange.backward(ctx, g)
+
+
 def _writable(g):
     """A gradient this backward may update in place: the engine hands over the producer's fresh tensor when the
     forward output had a single consumer (the next layer); anything that looks shared is copied first."""
@@ -227,8 +242,11 @@ class ShardPlan(object):
         self.group = group
         self.z_with_in_edges = None           # atomic numbers that receive >= 1 edge GLOBALLY (hermnet.py:56-57): a set
         self.has_in_edges = None              # ... or the same as a device array [128] of 0/1 (slab plans)
+        self.zz_with_in_edges = None          # (target Z, source Z) pairs joined by >= 1 edge globally: a set ...
+        self.has_in_pairs = None              # ... or a device array [128 * 128] of 0/1 (slab plans)
         self._row_plan = None                 # (row_of_node tensor, atom_plan in that row order, HaloOverlap)
         self._zl_index = None                 # ((element list, device), its index tensor) for `rel_active`
+        self.halo_pos_local = False           # True: Data.pos already holds the halo atoms' coordinates (slab plans)
 
     @property
     def n_owned(self):
@@ -243,6 +261,23 @@ class ShardPlan(object):
                 self._zl_index = (key, torch.tensor([min(int(z), 127) for z in zl], dtype=torch.long, device=key[1]))
             return self.has_in_edges.index_select(0, self._zl_index[1]).to(torch.uint8)
         return [z in self.z_with_in_edges for z in zl]
+
+    def rel_active_triadic(self, zl):
+        """HTNet's relations (c; {p, q}), c-major and pairs p-major (relations.build_triadic): one runs iff an atom of
+        element c receives an edge from an atom of element p or q anywhere in the structure."""
+        T = len(zl)
+        trip = [(c, p, q) for c in range(T) for p in range(T) for q in range(p, T)]
+        if self.has_in_pairs is not None:
+            dev = self.has_in_pairs.device
+            key = ("triadic", tuple(zl), dev)
+            if self._zl_index is None or self._zl_index[0] != key:
+                cl = lambda k: min(int(zl[k]), 127)
+                self._zl_index = (key, torch.tensor([[cl(c) * 128 + cl(p) for c, p, q in trip],
+                                                     [cl(c) * 128 + cl(q) for c, p, q in trip]], dtype=torch.long, device=dev))
+            idx = self._zl_index[1]
+            return (self.has_in_pairs.index_select(0, idx[0]) | self.has_in_pairs.index_select(0, idx[1])).to(torch.uint8)
+        zz = self.zz_with_in_edges
+        return [((zl[c], zl[p]) in zz) or ((zl[c], zl[q]) in zz) for c, p, q in trip]
 
     def row_plan(self, row_of_node):
         """The atom exchange lists in the relation-row order of `row_of_node` (cached per tensor: the row layout of an
@@ -362,7 +397,9 @@ def partition(data, rank, world, axis=None, group=None):
                      owned_mask, num_graphs, group)
     plan.owned_local = torch.from_numpy(np.nonzero(is_owned)[0])
     plan.local_global = torch.from_numpy(local_ids.copy())
-    plan.z_with_in_edges = set(int(v) for v in np.unique(data.atomic_number.cpu().numpy()[tgt]))
+    z_np = data.atomic_number.cpu().numpy()
+    plan.z_with_in_edges = set(int(v) for v in np.unique(z_np[tgt]))
+    plan.zz_with_in_edges = set((int(a), int(b)) for a, b in np.unique(np.stack([z_np[tgt], z_np[src]], 1), axis=0))
     local._hn_shard = plan
     return local, plan
 
@@ -467,15 +504,17 @@ def plan_slab(pos, atomic_number, cell, rc, rank, world, axis=None, group=None, 
     plan.batch_local = torch.zeros(local_ids.numel(), dtype=torch.long, device=dev)
     plan.target_mask = is_owned.to(torch.uint8)
     plan.cell = None if cell is None else cell.detach().reshape(1, 3, 3)
+    plan.halo_pos_local = True            # `slab_data` fills the halo coordinates itself
     return plan
 
 
 def slab_data(plan, pos, reference_compat=False):
     """This rank's `Data` for the current coordinates under a plan that is still valid (`plan_moved` says whether it
     is): the cutoff pairs among the local atoms whose TARGET is owned, listed directly by the neighbour search
-    (`target_mask`; nothing of the other pairs is built or filtered afterwards).  Halo coordinates are placeholders
-    (zeros): HVNet.forward fills them through the exchange so that force contributions flow back to the owners.
-    One host read (the edge count of the search)."""
+    (`target_mask`; nothing of the other pairs is built or filtered afterwards).  Halo rows of `pos` hold the atoms'
+    coordinates (every rank has them all): no coordinate exchange in the forward pass, HVNet.forward only routes the
+    halo rows' force contributions back to the owners (`HaloGradReturn`).  One host read (the edge count of the
+    search)."""
     from .neighbor import neighbor_search
     dev = pos.device
     pos_l = pos.detach().index_select(0, plan.local_global)
@@ -485,16 +524,17 @@ def slab_data(plan, pos, reference_compat=False):
     else:
         ei, sh = neighbor_search(pos_l, plan.rc, None, reference_compat=reference_compat, target_mask=plan.target_mask), None
     z = plan.z_local
-    kw = dict(pos=pos_l * plan.owned_mask[:, None].to(pos_l.dtype), atomic_number=z, edge_index=ei, batch=plan.batch_local)
+    kw = dict(pos=pos_l, atomic_number=z, edge_index=ei, batch=plan.batch_local)
     if cell is not None:
         kw["cell"] = cell
         kw["edge_shift"] = sh
     local = Data(**kw)
     # hermnet.py:56-57: a relation is skipped when NO atom of its element receives an edge anywhere in the structure;
     # kept on the device (the relation build takes the flags as a device array: no host read per step)
-    has_in = torch.zeros(128, dtype=torch.int32, device=dev)
+    # (flags per (target element, source element): HTNet's relations are skipped pair-wise; HVNet reads the row maxima)
+    has_in = torch.zeros(128 * 128, dtype=torch.int32, device=dev)
     if ei.size(1) > 0:
-        has_in[z[ei[1]].clamp(max=127)] = 1
+        has_in[z[ei[1]].clamp(max=127) * 128 + z[ei[0]].clamp(max=127)] = 1
     if plan.world > 1 and dist.is_available() and dist.is_initialized():
         if _host_staged(plan.group, has_in):
             h = has_in.cpu()
@@ -502,7 +542,8 @@ def slab_data(plan, pos, reference_compat=False):
             has_in = h.to(dev)
         else:
             dist.all_reduce(has_in, op=dist.ReduceOp.MAX, group=plan.group)
-    plan.has_in_edges = has_in
+    plan.has_in_pairs = has_in
+    plan.has_in_edges = has_in.view(128, 128).amax(dim=1)
     local._hn_shard = plan
     return local
 

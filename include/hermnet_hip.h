@@ -156,11 +156,14 @@ int hermnet_build_relations(const long* atomic_number, const long* edge_index, c
  * out: node_order, row_of_node [NA], z_rows, row_real [Ns] (source rows; skipped when rows_ready), row_active [Nt],
  * csr_rowptr [Nt+1], csr_src / csr_perm (ORIGINAL edge id) / src_id / tgt_id [E], shift_csr [E,3], csc_rowptr
  * [T P Ns + 1] (groups = relation * Ns + source row), csc_tgt, csc_pos [E]; out_rowptr / out_edges unused.
- * elem_counts [T] device ints (atoms per element); tgt_row_real [Nt]; res_row [Nt] = the atom's own source row. */
+ * elem_counts [T] device ints (atoms per element); tgt_row_real [Nt]; res_row [Nt] = the atom's own source row;
+ * rel_active [T P] bytes or NULL (NULL: a relation is active iff it receives at least one edge HERE; an atom shard
+ * passes the flags of the whole structure). */
 size_t hermnet_build_triadic_workspace(int num_atoms, int num_edges, int num_elem, int block);
 int hermnet_build_triadic(const long* atomic_number, const long* edge_index, const float* shift, int num_atoms,
                           int num_edges, const int* z_list, int num_elem, int block, const int* elem_counts,
-                          const hn_relations_out* out, float* tgt_row_real, int* res_row, int rows_ready,
+                          const unsigned char* rel_active, const hn_relations_out* out, float* tgt_row_real,
+                          int* res_row, int rows_ready,
                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- A2: HVNet.with_edge (hermnet.py:133-152) -------------------------------------------

@@ -230,7 +230,7 @@ def test_partition_slab_is_consistent_and_covers_the_global_graph(case, world):
         assert len(keys) == loc.edge_index.size(1) and not (keys & seen)
         seen |= keys
         assert bool(plan.owned_mask[loc.edge_index[1]].all())                    # targets are owned
-        assert float(loc.pos[~plan.owned_mask].abs().sum()) == 0.0               # halo coordinates arrive by exchange
+        assert torch.equal(loc.pos, d.pos[plan.local_global])                    # halo coordinates included: no exchange
         # local order: owned atoms by ascending id, then halo atoms by ascending id
         assert torch.equal(plan.local_global, torch.cat([plan.owned_global, plan.halo_global]))
         assert torch.equal(plan.halo_global, torch.sort(plan.halo_global).values)
@@ -376,7 +376,62 @@ def test_slab_partition_world8_gloo_matches_single_process(monkeypatch, overlap)
     assert rel_err(torch.from_numpy(forces), f_ref) < 2e-5
 
 
-def _gpu_slab_worker(rank, world, reps, port, out, overlap):
+def _htnet_worker(rank, world, port, out, planner):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _patch_cpu_ops()
+        import hermnet_amd as hn
+        from hermnet_amd import synth
+        from hermnet_amd.sharding import partition, partition_slab
+        d = synth.fcc_alloy(reps=(3, 3, 12))
+        model = hn.HTNet(["Al", "Ni", "Cu"], **SLAB_KW).eval()
+        model.load_state_dict(synth.synth_state_dict(model.state_dict(), 3))
+        for p in model.parameters():
+            p.requires_grad_(False)
+        if planner == "slab":
+            local, plan = partition_slab(d.pos, d.atomic_number, d.cell, SLAB_KW["rc"], rank, world)
+        else:
+            local, plan = partition(d, rank, world)
+        local.pos.requires_grad_(True)
+        e = model(local)
+        f_local = -torch.autograd.grad(e.sum(), local.pos)[0]
+        out[rank] = (e.detach().numpy(), plan.owned_global.numpy(), f_local[plan.owned_local].numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("planner,world", [("slab", 3), ("edges", 2)])
+def test_htnet_sharded_matches_single_process(monkeypatch, planner, world):
+    """HTNet (18 triadic relations) through the same atom sharding: exchange in source rows, relations switched on by
+    the (centre element, neighbour element) flags of the WHOLE structure; equals the single-process evaluation."""
+    import hermnet_amd as hn
+    from hermnet_amd import synth
+    port = 35500 + (os.getpid() + world) % 2000
+    out = mp.Manager().dict()
+    mp.spawn(_htnet_worker, args=(world, port, out, planner), nprocs=world, join=True)
+    _patch_cpu_ops(monkeypatch)
+    d = synth.fcc_alloy(reps=(3, 3, 12))
+    model = hn.HTNet(["Al", "Ni", "Cu"], **SLAB_KW).eval()
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), 3))
+    for p in model.parameters():
+        p.requires_grad_(False)
+    d.pos.requires_grad_(True)
+    e_ref = model(d)
+    f_ref = -torch.autograd.grad(e_ref.sum(), d.pos)[0]
+    forces = np.zeros_like(f_ref.numpy())
+    for r in range(world):
+        e, owned, f = out[r]
+        assert rel_err(torch.from_numpy(e), e_ref.detach()) < 5e-6
+        forces[owned] = f
+    assert rel_err(torch.from_numpy(forces), f_ref) < 2e-5
+
+
+def _gpu_slab_worker(rank, world, reps, port, out, overlap, kind="hvnet"):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -389,7 +444,7 @@ def _gpu_slab_worker(rank, world, reps, port, out, overlap):
         from hermnet_amd.sharding import partition_slab
         dev = torch.device("cuda:0")
         kw = dict(rc=5.0, num_layers=5, hidden_channels=128, num_rbf=128)
-        model = hn.HVNet(["Al", "Ni", "Cu"], **kw).eval()
+        model = (hn.HTNet if kind == "htnet" else hn.HVNet)(["Al", "Ni", "Cu"], **kw).eval()
         model.load_state_dict(synth.synth_state_dict(model.state_dict(), 10))
         model = model.to(dev)
         for p in model.parameters():
@@ -422,15 +477,17 @@ def _gpu_slab_worker(rank, world, reps, port, out, overlap):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,reps,overlap", [(2, (10, 10, 250), "0"), (3, (10, 10, 25), "0"), (3, (10, 10, 25), "1")])
-def test_sharded_100k_cell_matches_single_gpu(world, reps, overlap):
+@pytest.mark.parametrize("world,reps,overlap,kind", [(2, (10, 10, 250), "0", "hvnet"), (3, (10, 10, 25), "0", "hvnet"),
+                                                     (3, (10, 10, 25), "1", "hvnet"), (2, (6, 6, 12), "0", "htnet")])
+def test_sharded_100k_cell_matches_single_gpu(world, reps, overlap, kind):
     """BASELINE configs[3] at full size (fcc 10x10x250 = 100,000 atoms) through the sharded HIP path with slab-local
     planning, ranks sharing the one GPU of the box; energy and forces must equal the unsharded evaluation of the
     same cell on one GPU.  (world 3 on the 10k cell: uneven slabs; overlap = "1": the feature exchange inside the
-    consuming layer, between the two windowed launches of its node projection.)"""
+    consuming layer, between the two windowed launches of its node projection; kind = "htnet": the triadic model through
+    the same sharding.)"""
     port = 37500 + (os.getpid() + world) % 2000
     out = mp.Manager().dict()
-    mp.spawn(_gpu_slab_worker, args=(world, reps, port, out, overlap), nprocs=world, join=True)
+    mp.spawn(_gpu_slab_worker, args=(world, reps, port, out, overlap, kind), nprocs=world, join=True)
     n = 4 * reps[0] * reps[1] * reps[2]
     e_ref, f_ref = torch.from_numpy(out[0]["e_ref"]), torch.from_numpy(out[0]["f_ref"])
     forces = np.zeros((n, 3), dtype=np.float32)

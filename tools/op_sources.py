@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which host lines launch the small torch kernels of one energy+forces step (aten::copy_, aten::to, aten::sum, sort, cat ...):
-    python tools/op_sources.py      (configs[1], one profiled step after warm-up)"""
+    python tools/op_sources.py [htnet]     (configs[1] / configs[2], one profiled step after warm-up)"""
 import os
 import sys
 
@@ -12,7 +12,8 @@ import hermnet_amd as hn  # noqa: E402
 from hermnet_amd import synth  # noqa: E402
 
 dev = torch.device("cuda")
-model = hn.HVNet(["Al", "Ni", "Cu"], rc=5.0, num_layers=5, hidden_channels=128, num_rbf=128).eval()
+Model = hn.HTNet if (len(sys.argv) > 1 and sys.argv[1] == "htnet") else hn.HVNet
+model = Model(["Al", "Ni", "Cu"], rc=5.0, num_layers=5, hidden_channels=128, num_rbf=128).eval()
 model.load_state_dict(synth.synth_state_dict(model.state_dict(), 10))
 model = model.to(dev)
 for p in model.parameters():
