@@ -213,27 +213,93 @@ class PaiNNModule(nn.Module):
         self.inv_sqrt_2 = 1 / math.sqrt(2.0)
 
 
+class _RowKey(object):
+    """One edge -> row assignment `idx` [K] (values < n_rows) in both forms the pair below needs: the index vector for
+    the gather, and (perm, lengths) -- the edges sorted by row and the run lengths of all n_rows rows -- for a sum
+    without atomics.  perm = None: the edges already come sorted by row."""
+
+    def __init__(self, idx, perm, lengths, n_rows):
+        self.idx, self.perm, self.lengths, self.n_rows = idx, perm, lengths, int(n_rows)
+
+
+class GatherRows(torch.autograd.Function):
+    """y = x[key.idx].  Gather and row-sum are each other's adjoint, so the pair is closed under differentiation to any
+    order (create_graph=True): no zero-filled index_add_ with float atomics anywhere in the training step."""
+
+    @staticmethod
+    def forward(ctx, x, key):
+        ctx.key = key
+        return x.index_select(0, key.idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        return SumRows.apply(g, ctx.key), None
+
+
+class SumRows(torch.autograd.Function):
+    """y[r] = sum of x[k] over the edges k with key.idx[k] == r, in a fixed order (segmented sum over the sorted
+    edges: deterministic, unlike index_add_)."""
+
+    @staticmethod
+    def forward(ctx, x, key):
+        ctx.key = key
+        xs = x if key.perm is None else x.index_select(0, key.perm)
+        if xs.size(0) == 0:
+            return x.new_zeros((key.n_rows,) + tuple(x.shape[1:]))
+        return torch.segment_reduce(xs.contiguous(), "sum", lengths=key.lengths, unsafe=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        return GatherRows.apply(g, ctx.key), None
+
+
+def _row_keys(graph, T, N, bounds):
+    """(key of the targets of the first Ek CSR edges, [key of relation t's sources], key of all sources) for
+    `message_scatter_generic`, from the graph's CSR / CSC orders; built once per graph."""
+    keys = getattr(graph, "_row_keys", None)
+    if keys is not None:
+        return keys
+    dev = graph.csr_rowptr.device
+    rowptr = graph.csr_rowptr.long()
+    Ek = bounds[T]
+    nk = int(graph.type_rowptr_host[-1])
+    lengths = rowptr[1:] - rowptr[:-1]
+    lengths = torch.cat([lengths[:nk], lengths.new_zeros(N - nk)])           # edges into unknown-element rows: not summed
+    tgt_row = torch.repeat_interleave(torch.arange(N, device=dev), lengths)
+    k_tgt = _RowKey(tgt_row, None, lengths, N)
+    src = graph.csr_src.long()
+    crp, cpos = graph.csc_rowptr.long(), graph.csc_pos.long()               # groups (relation, source row) over CSR positions
+    k_src = []
+    for t in range(T):
+        e0, e1 = bounds[t], bounds[t + 1]
+        seg = crp[t * N:(t + 1) * N + 1]
+        k_src.append(_RowKey(src[e0:e1], cpos[e0:e1] - e0, seg[1:] - seg[:-1], N))
+    # all relations at once: sorted by (source row) = the T groups of a row merged; built by one stable sort
+    order = torch.argsort(src[:Ek], stable=True)
+    k_all = _RowKey(src[:Ek], order, torch.bincount(src[:Ek], minlength=N), N)
+    graph._row_keys = (k_tgt, k_src, k_all)
+    return graph._row_keys
+
+
 def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     """Same contract as the fused kernel (rmnet.py:24-26,55-73) for a MATERIALISED basis `edge_embed`
-    [E,R] (CSR order): library GEMM per relation + gather/index_add device ops, differentiable to any order by
+    [E,R] (CSR order): library GEMM per relation + gather / segmented-sum device ops, differentiable to any order by
     PyTorch autograd.  Path of train() mode (parameter gradients, create_graph=True) and of the optional
     radial bases."""
     T, N, H3 = xh.shape
     H = H3 // 3
-    rowptr = graph.csr_rowptr.long()
-    tgt_row = torch.repeat_interleave(torch.arange(N, device=x.device), rowptr[1:] - rowptr[:-1])
-    src = graph.csr_src.long()
     rel_row = torch.bucketize(torch.arange(N, device=x.device), graph.type_rowptr.long()[1:], right=True)
     # rows are relation-ordered and CSR is row-ordered: the edges of relation t are ONE contiguous CSR range
     # (no per-relation masks or gathers of the edge arrays)
     bounds = graph.rel_edge_bounds()
     Ek = bounds[T]                                             # edges whose target has a known element
+    k_tgt, k_src, k_all = _row_keys(graph, T, N, bounds)
     parts = []
     for t in range(T):
         e0, e1 = bounds[t], bounds[t + 1]
         if e1 > e0:
             rb = F.linear(edge_embed[e0:e1], w_rbf[t], b_rbf[t])                   # rbf_proj, rmnet.py:55
-            parts.append(xh[t].index_select(0, src[e0:e1]) * rb)                   # x_j * rbfh, rmnet.py:58,61-62
+            parts.append(GatherRows.apply(xh[t], k_src[t]) * rb)                   # x_j * rbfh, rmnet.py:58,61-62
     dx = x.new_zeros(N, H)
     dv = x.new_zeros(N, 3, H)
     if parts:
@@ -243,9 +309,9 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
         s_, a_, b_ = m.view(-1, 3, H).unbind(1)
         mv = (b_ * (1 / math.sqrt(H)))[:, None, :] * edge[:Ek, :3, None]           # rmnet.py:64-66
         if vec is not None:
-            mv = torch.addcmul(mv, vec.index_select(0, src[:Ek]), (a_ * (1 / math.sqrt(3.0 * H)))[:, None, :])
-        dx = dx.index_add(0, tgt_row[:Ek], s_)                                     # aggregate, rmnet.py:69-73
-        dv = dv.index_add(0, tgt_row[:Ek], mv)
+            mv = torch.addcmul(mv, GatherRows.apply(vec, k_all), (a_ * (1 / math.sqrt(3.0 * H)))[:, None, :])
+        dx = SumRows.apply(s_, k_tgt)                                              # aggregate, rmnet.py:69-73
+        dv = SumRows.apply(mv, k_tgt)
     known = (rel_row < T).to(x.dtype)
     x1 = (x + dx) * (1 / math.sqrt(2.0)) * known[:, None]
     vec1 = ((vec if vec is not None else 0) + dv) * known[:, None, None]
