@@ -294,22 +294,27 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     bounds = graph.rel_edge_bounds()
     Ek = bounds[T]                                             # edges whose target has a known element
     k_tgt, k_src, k_all = _row_keys(graph, T, N, bounds)
+    # the constant factors of the vector message (1/sqrt(3H) on the `a` part, 1/sqrt(H) on `b`, rmnet.py:64-66) ride on
+    # the [3H, R] projection weights, not on per-edge tensors
+    sc = x.new_ones(3 * H)
+    sc[H:2 * H] = 1 / math.sqrt(3.0 * H)
+    sc[2 * H:] = 1 / math.sqrt(H)
     parts = []
     for t in range(T):
         e0, e1 = bounds[t], bounds[t + 1]
         if e1 > e0:
-            rb = F.linear(edge_embed[e0:e1], w_rbf[t], b_rbf[t])                   # rbf_proj, rmnet.py:55
+            rb = F.linear(edge_embed[e0:e1], w_rbf[t] * sc[:, None], b_rbf[t] * sc)   # rbf_proj, rmnet.py:55
             parts.append(GatherRows.apply(xh[t], k_src[t]) * rb)                   # x_j * rbfh, rmnet.py:58,61-62
     dx = x.new_zeros(N, H)
     dv = x.new_zeros(N, 3, H)
     if parts:
         m = parts[0] if len(parts) == 1 else torch.cat(parts, 0)                   # [Ek, 3H]
         # (unbind of the [Ek,3,H] view: its backward is ONE stack, where three column slices each zero-fill a full
-        # [Ek,3H] gradient; the constant factors ride on the [Ek,H] parts, not on the 3x larger vector message)
+        # [Ek,3H] gradient)
         s_, a_, b_ = m.view(-1, 3, H).unbind(1)
-        mv = (b_ * (1 / math.sqrt(H)))[:, None, :] * edge[:Ek, :3, None]           # rmnet.py:64-66
+        mv = b_[:, None, :] * edge[:Ek, :3, None]                                  # rmnet.py:64-66
         if vec is not None:
-            mv = torch.addcmul(mv, GatherRows.apply(vec, k_all), (a_ * (1 / math.sqrt(3.0 * H)))[:, None, :])
+            mv = torch.addcmul(mv, GatherRows.apply(vec, k_all), a_[:, None, :])
         dx = SumRows.apply(s_, k_tgt)                                              # aggregate, rmnet.py:69-73
         dv = SumRows.apply(mv, k_tgt)
     known = (rel_row < T).to(x.dtype)

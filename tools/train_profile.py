@@ -22,8 +22,13 @@ def step():
     loss = 0.2 * F.mse_loss(e, y) + 0.8 * F.mse_loss(f, ftgt)
     loss.backward()
     return loss
+import time
 for _ in range(2): step()
 torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter(); step(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+print("training step (forward + create_graph force pass + backward, no optimiser): median %.1f ms, min %.1f ms" % (sorted(ts)[2] * 1e3, min(ts) * 1e3))
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
 rows = [(ev.device_time_total, ev.count, ev.key) for ev in prof.key_averages() if ev.device_time_total > 0 and ev.key.startswith("aten::")]
