@@ -1,0 +1,217 @@
+// gfx950 kernels of the TRAINING path (train() mode: example/dist_train.py:86-99 differentiates the forces w.r.t. the
+// parameters, so every op needs a second derivative).  The per-edge message algebra of PaiNNMessage
+// (/root/reference/HermNet/rmnet.py:58-66) is multilinear in its inputs, so its backward and the backward of its backward
+// are again per-edge products and channel sums: three streaming kernels replace ~35 elementwise / reduction launches per
+// layer of the autograd graph, each reading and writing every [E, 3H] operand once.
+//
+//   X [E,3H] = x_proj(LayerNorm(x))[source]  (parts Xs | Xa | Xb),  R [E,3H] = rbf_proj(rbf(d)) (Rs | Ra | Rb; the constant
+//   factors 1/sqrt(3H), 1/sqrt(H) ride on the projection weights),  V [E,3,H] = vec[source] (NULL in layer 0),  U [E,3] = rhat
+//
+//   forward     S = Xs Rs                                   [E,H]     -> dx after the row sum
+//               M_d = (Xb Rb) U_d + V_d (Xa Ra)             [E,3,H]   -> dvec after the row sum
+//   backward    (GS, GM) -> gX, gR, gV, gU                  (first-order cotangents)
+//   backward^2  (cX, cR, cV, cU) -> dGS, dGM, dX, dR, dV, dU (cotangents of the backward's outputs; any of c* may be NULL)
+//
+// Mapping: LPE lanes per edge (power of two >= H/4, at most 64), a lane owns channel quads q = l, l + LPE, ...; sums
+// over the channels are shuffles inside the lane group: deterministic, no atomics.  HBM-streaming work.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hermnet_hip.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ f4 ld4z(const float* p, size_t off) { return p ? *reinterpret_cast<const f4*>(p + off) : (f4){0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+__device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
+
+template <int LPE>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < LPE; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+struct EdgeMsgArgs {
+  const float *X, *R, *V, *U;          // inputs of the forward
+  const float *GS, *GM;                // cotangents of (S, M)
+  const float *cX, *cR, *cV, *cU;      // cotangents of the backward's outputs (each may be null = zero)
+  float *o0, *o1, *o2, *o3, *o4, *o5;  // outputs, see the kernels
+  long E;
+  int H;
+};
+
+template <int LPE, bool HAS_V>
+__global__ __launch_bounds__(256) void edge_msg_fwd_kernel(EdgeMsgArgs a) {
+  // o0 = S [E,H], o1 = M [E,3,H]
+  constexpr int EPB = 256 / LPE;
+  const int l = threadIdx.x % LPE;
+  const long e = (long)blockIdx.x * EPB + threadIdx.x / LPE;
+  if (e >= a.E) return;
+  const int H = a.H, Q = H >> 2;
+  const float u0 = a.U[3 * e], u1 = a.U[3 * e + 1], u2 = a.U[3 * e + 2];
+  const float* X = a.X + (size_t)e * 3 * H;
+  const float* R = a.R + (size_t)e * 3 * H;
+  for (int q = l; q < Q; q += LPE) {
+    const int c = 4 * q;
+    const f4 xs = ld4(X + c), xa = ld4(X + H + c), xb = ld4(X + 2 * H + c);
+    const f4 rs = ld4(R + c), ra = ld4(R + H + c), rb = ld4(R + 2 * H + c);
+    st4(a.o0 + (size_t)e * H + c, xs * rs);
+    const f4 B = xb * rb;
+    f4 m0 = B * u0, m1 = B * u1, m2 = B * u2;
+    if (HAS_V) {
+      const f4 A = xa * ra;
+      const float* V = a.V + (size_t)e * 3 * H + c;
+      m0 += ld4(V) * A; m1 += ld4(V + H) * A; m2 += ld4(V + 2 * H) * A;
+    }
+    float* M = a.o1 + (size_t)e * 3 * H + c;
+    st4(M, m0); st4(M + H, m1); st4(M + 2 * H, m2);
+  }
+}
+
+template <int LPE, bool HAS_V>
+__global__ __launch_bounds__(256) void edge_msg_bwd_kernel(EdgeMsgArgs a) {
+  // o0 = gX [E,3H], o1 = gR [E,3H], o2 = gV [E,3,H] (HAS_V), o3 = gU [E,3]
+  constexpr int EPB = 256 / LPE;
+  const int l = threadIdx.x % LPE;
+  const long e = (long)blockIdx.x * EPB + threadIdx.x / LPE;
+  const bool live = e < a.E;              // (dead lane groups still take part in the shuffles)
+  const int H = a.H, Q = H >> 2;
+  const long ee = live ? e : 0;
+  const float u0 = a.U[3 * ee], u1 = a.U[3 * ee + 1], u2 = a.U[3 * ee + 2];
+  const size_t b3 = (size_t)ee * 3 * H;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (live)
+    for (int q = l; q < Q; q += LPE) {
+      const int c = 4 * q;
+      const f4 xs = ld4(a.X + b3 + c), xa = ld4(a.X + b3 + H + c), xb = ld4(a.X + b3 + 2 * H + c);
+      const f4 rs = ld4(a.R + b3 + c), ra = ld4(a.R + b3 + H + c), rb = ld4(a.R + b3 + 2 * H + c);
+      const f4 gs = ld4(a.GS + (size_t)ee * H + c);
+      const f4 g0 = ld4(a.GM + b3 + c), g1 = ld4(a.GM + b3 + H + c), g2 = ld4(a.GM + b3 + 2 * H + c);
+      const f4 gB = g0 * u0 + g1 * u1 + g2 * u2;
+      f4 gXa = (f4){0.f, 0.f, 0.f, 0.f}, gRa = gXa;
+      if (HAS_V) {
+        const f4 v0 = ld4(a.V + b3 + c), v1 = ld4(a.V + b3 + H + c), v2 = ld4(a.V + b3 + 2 * H + c);
+        const f4 gA = g0 * v0 + g1 * v1 + g2 * v2, A = xa * ra;
+        gXa = gA * ra; gRa = gA * xa;
+        st4(a.o2 + b3 + c, g0 * A); st4(a.o2 + b3 + H + c, g1 * A); st4(a.o2 + b3 + 2 * H + c, g2 * A);
+      }
+      st4(a.o0 + b3 + c, gs * rs); st4(a.o0 + b3 + H + c, gXa); st4(a.o0 + b3 + 2 * H + c, gB * rb);
+      st4(a.o1 + b3 + c, gs * xs); st4(a.o1 + b3 + H + c, gRa); st4(a.o1 + b3 + 2 * H + c, gB * xb);
+      const f4 B = xb * rb;
+      s0 += hsum(g0 * B); s1 += hsum(g1 * B); s2 += hsum(g2 * B);
+    }
+  s0 = group_sum<LPE>(s0); s1 = group_sum<LPE>(s1); s2 = group_sum<LPE>(s2);
+  if (live && l == 0) { a.o3[3 * e] = s0; a.o3[3 * e + 1] = s1; a.o3[3 * e + 2] = s2; }
+}
+
+template <int LPE, bool HAS_V>
+__global__ __launch_bounds__(256) void edge_msg_bwd2_kernel(EdgeMsgArgs a) {
+  // o0 = dGS [E,H], o1 = dGM [E,3,H], o2 = dX [E,3H], o3 = dR [E,3H], o4 = dV [E,3,H] (HAS_V), o5 = dU [E,3]
+  constexpr int EPB = 256 / LPE;
+  const int l = threadIdx.x % LPE;
+  const long e = (long)blockIdx.x * EPB + threadIdx.x / LPE;
+  const bool live = e < a.E;
+  const int H = a.H, Q = H >> 2;
+  const long ee = live ? e : 0;
+  const float u0 = a.U[3 * ee], u1 = a.U[3 * ee + 1], u2 = a.U[3 * ee + 2];
+  const float k0 = a.cU ? a.cU[3 * ee] : 0.f, k1 = a.cU ? a.cU[3 * ee + 1] : 0.f, k2 = a.cU ? a.cU[3 * ee + 2] : 0.f;
+  const size_t b3 = (size_t)ee * 3 * H;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (live)
+    for (int q = l; q < Q; q += LPE) {
+      const int c = 4 * q;
+      const f4 xs = ld4(a.X + b3 + c), xa = ld4(a.X + b3 + H + c), xb = ld4(a.X + b3 + 2 * H + c);
+      const f4 rs = ld4(a.R + b3 + c), ra = ld4(a.R + b3 + H + c), rb = ld4(a.R + b3 + 2 * H + c);
+      const f4 gs = ld4(a.GS + (size_t)ee * H + c);
+      const f4 g0 = ld4(a.GM + b3 + c), g1 = ld4(a.GM + b3 + H + c), g2 = ld4(a.GM + b3 + 2 * H + c);
+      const f4 cXs = ld4z(a.cX, b3 + c), cXa = ld4z(a.cX, b3 + H + c), cXb = ld4z(a.cX, b3 + 2 * H + c);
+      const f4 cRs = ld4z(a.cR, b3 + c), cRa = ld4z(a.cR, b3 + H + c), cRb = ld4z(a.cR, b3 + 2 * H + c);
+      st4(a.o0 + (size_t)ee * H + c, cXs * rs + cRs * xs);
+      const f4 tB = cXb * rb + cRb * xb, B = xb * rb;
+      const f4 gB = g0 * u0 + g1 * u1 + g2 * u2, sU = g0 * k0 + g1 * k1 + g2 * k2;
+      f4 d0 = tB * u0 + B * k0, d1 = tB * u1 + B * k1, d2 = tB * u2 + B * k2;
+      f4 dXa = (f4){0.f, 0.f, 0.f, 0.f}, dRa = dXa;
+      if (HAS_V) {
+        const f4 v0 = ld4(a.V + b3 + c), v1 = ld4(a.V + b3 + H + c), v2 = ld4(a.V + b3 + 2 * H + c);
+        const f4 w0 = ld4z(a.cV, b3 + c), w1 = ld4z(a.cV, b3 + H + c), w2 = ld4z(a.cV, b3 + 2 * H + c);
+        const f4 tA = cXa * ra + cRa * xa, A = xa * ra;
+        const f4 gA = g0 * v0 + g1 * v1 + g2 * v2, sV = g0 * w0 + g1 * w1 + g2 * w2;
+        d0 += tA * v0 + w0 * A; d1 += tA * v1 + w1 * A; d2 += tA * v2 + w2 * A;
+        dXa = cRa * gA + ra * sV; dRa = cXa * gA + xa * sV;
+        st4(a.o4 + b3 + c, tA * g0); st4(a.o4 + b3 + H + c, tA * g1); st4(a.o4 + b3 + 2 * H + c, tA * g2);
+      }
+      st4(a.o1 + b3 + c, d0); st4(a.o1 + b3 + H + c, d1); st4(a.o1 + b3 + 2 * H + c, d2);
+      st4(a.o2 + b3 + c, cRs * gs); st4(a.o2 + b3 + H + c, dXa); st4(a.o2 + b3 + 2 * H + c, cRb * gB + rb * sU);
+      st4(a.o3 + b3 + c, cXs * gs); st4(a.o3 + b3 + H + c, dRa); st4(a.o3 + b3 + 2 * H + c, cXb * gB + xb * sU);
+      s0 += hsum(tB * g0); s1 += hsum(tB * g1); s2 += hsum(tB * g2);
+    }
+  s0 = group_sum<LPE>(s0); s1 = group_sum<LPE>(s1); s2 = group_sum<LPE>(s2);
+  if (live && l == 0) { a.o5[3 * e] = s0; a.o5[3 * e + 1] = s1; a.o5[3 * e + 2] = s2; }
+}
+
+
+
+
+#define HN_EDGE_LAUNCH(KERNEL)                                                                                    \
+  do {                                                                                                            \
+    const int Q = a.H >> 2;                                                                                       \
+    int lpe = 1;                                                                                                  \
+    while (lpe < Q && lpe < 64) lpe <<= 1;                                                                        \
+    const unsigned blocks = (unsigned)((a.E + (256 / lpe) - 1) / (256 / lpe));                                    \
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);                                                        \
+    switch (lpe) {                                                                                                \
+      case 1: if (has_v) hipLaunchKernelGGL((KERNEL<1, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<1, false>), dim3(blocks), dim3(256), 0, s, a); break;      \
+      case 2: if (has_v) hipLaunchKernelGGL((KERNEL<2, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<2, false>), dim3(blocks), dim3(256), 0, s, a); break;      \
+      case 4: if (has_v) hipLaunchKernelGGL((KERNEL<4, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<4, false>), dim3(blocks), dim3(256), 0, s, a); break;      \
+      case 8: if (has_v) hipLaunchKernelGGL((KERNEL<8, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<8, false>), dim3(blocks), dim3(256), 0, s, a); break;      \
+      case 16: if (has_v) hipLaunchKernelGGL((KERNEL<16, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<16, false>), dim3(blocks), dim3(256), 0, s, a); break;  \
+      case 32: if (has_v) hipLaunchKernelGGL((KERNEL<32, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<32, false>), dim3(blocks), dim3(256), 0, s, a); break;  \
+      default: if (has_v) hipLaunchKernelGGL((KERNEL<64, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<64, false>), dim3(blocks), dim3(256), 0, s, a); break; \
+    }                                                                                                             \
+    return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;                                               \
+  } while (0)
+
+bool bad_shape(long E, int H) { return E < 0 || H <= 0 || (H & 3) != 0 || (double)E * 3.0 * H >= 9.0e18; }
+
+}  // namespace
+
+extern "C" int hermnet_edge_message_fwd(const float* X, const float* R, const float* V, const float* U, long num_edges,
+                                        int hidden, float* S, float* M, void* stream) {
+  if (bad_shape(num_edges, hidden)) return HN_ERR_BAD_ARG;
+  if (num_edges == 0) return HN_OK;
+  if (!X || !R || !U || !S || !M) return HN_ERR_BAD_ARG;
+  EdgeMsgArgs a = {};
+  a.X = X; a.R = R; a.V = V; a.U = U; a.o0 = S; a.o1 = M; a.E = num_edges; a.H = hidden;
+  const bool has_v = V != nullptr;
+  HN_EDGE_LAUNCH(edge_msg_fwd_kernel);
+}
+
+extern "C" int hermnet_edge_message_bwd(const float* GS, const float* GM, const float* X, const float* R, const float* V,
+                                        const float* U, long num_edges, int hidden, float* gX, float* gR, float* gV,
+                                        float* gU, void* stream) {
+  if (bad_shape(num_edges, hidden)) return HN_ERR_BAD_ARG;
+  if (num_edges == 0) return HN_OK;
+  if (!GS || !GM || !X || !R || !U || !gX || !gR || !gU || (V && !gV)) return HN_ERR_BAD_ARG;
+  EdgeMsgArgs a = {};
+  a.X = X; a.R = R; a.V = V; a.U = U; a.GS = GS; a.GM = GM;
+  a.o0 = gX; a.o1 = gR; a.o2 = gV; a.o3 = gU; a.E = num_edges; a.H = hidden;
+  const bool has_v = V != nullptr;
+  HN_EDGE_LAUNCH(edge_msg_bwd_kernel);
+}
+
+extern "C" int hermnet_edge_message_bwd2(const float* cX, const float* cR, const float* cV, const float* cU,
+                                         const float* GS, const float* GM, const float* X, const float* R,
+                                         const float* V, const float* U, long num_edges, int hidden, float* dGS,
+                                         float* dGM, float* dX, float* dR, float* dV, float* dU, void* stream) {
+  if (bad_shape(num_edges, hidden)) return HN_ERR_BAD_ARG;
+  if (num_edges == 0) return HN_OK;
+  if (!GS || !GM || !X || !R || !U || !dGS || !dGM || !dX || !dR || !dU || (V && !dV)) return HN_ERR_BAD_ARG;
+  EdgeMsgArgs a = {};
+  a.X = X; a.R = R; a.V = V; a.U = U; a.GS = GS; a.GM = GM; a.cX = cX; a.cR = cR; a.cV = V ? cV : nullptr; a.cU = cU;
+  a.o0 = dGS; a.o1 = dGM; a.o2 = dX; a.o3 = dR; a.o4 = dV; a.o5 = dU; a.E = num_edges; a.H = hidden;
+  const bool has_v = V != nullptr;
+  HN_EDGE_LAUNCH(edge_msg_bwd2_kernel);
+}

@@ -6,6 +6,7 @@ What stays in PyTorch here is node-level dense algebra (LayerNorm + the two MLPs
 `rmnet.py:52` and `rmnet.py:94-107`): plain library GEMMs with elementwise epilogues.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -253,9 +254,99 @@ class SumRows(torch.autograd.Function):
         return GatherRows.apply(g, ctx.key), None
 
 
+def _edge_message_torch(X, R, V, U):
+    """The per-edge message algebra of rmnet.py:58-66 in differentiable torch ops (host tensors, widths that are not a
+    multiple of 4): S = Xs Rs, M_d = (Xb Rb) U_d + V_d (Xa Ra)."""
+    H = X.size(1) // 3
+    # (unbind of the [E,3,H] view: its backward is ONE stack, where three column slices each zero-fill a full gradient)
+    xs, xa, xb = X.view(-1, 3, H).unbind(1)
+    rs, ra, rb = R.view(-1, 3, H).unbind(1)
+    M = (xb * rb)[:, None, :] * U[:, :, None]
+    if V is not None:
+        M = torch.addcmul(M, V, (xa * ra)[:, None, :])
+    return xs * rs, M
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+class EdgeMessage(torch.autograd.Function):
+    """(X [E,3H], R [E,3H], V [E,3,H] | None, U [E,3]) -> (S [E,H], M [E,3,H]) on the GPU: `hermnet_edge_message_fwd`.
+    The map is multilinear, so its backward (`EdgeMessageGrad`) and the backward of that are per-edge products and
+    channel sums again -- three streaming kernels (csrc/train_kernels.hip) for what the autograd graph of the torch
+    expression spreads over ~35 elementwise / reduction launches per layer and order."""
+
+    @staticmethod
+    def forward(ctx, X, R, V, U):
+        from . import _lib
+        from .ops import _stream
+        X, R, V, U = _c(X), _c(R), _c(V), _c(U)
+        E, H = X.size(0), X.size(1) // 3
+        S = torch.empty(E, H, dtype=X.dtype, device=X.device)
+        M = torch.empty(E, 3, H, dtype=X.dtype, device=X.device)
+        P = _lib.ptr
+        _lib.check(_lib.load().hermnet_edge_message_fwd(P(X), P(R), P(V), P(U), E, H, P(S), P(M), _stream()),
+                   "hermnet_edge_message_fwd")
+        ctx.save_for_backward(X, R, V, U)
+        return S, M
+
+    @staticmethod
+    def backward(ctx, GS, GM):
+        X, R, V, U = ctx.saved_tensors
+        gX, gR, gV, gU = EdgeMessageGrad.apply(GS, GM, X, R, V, U)
+        return gX, gR, gV, gU
+
+
+class EdgeMessageGrad(torch.autograd.Function):
+    """First-order cotangents of `EdgeMessage` (`hermnet_edge_message_bwd`); differentiable once more
+    (`hermnet_edge_message_bwd2`), which is what `autograd.grad(E, pos, create_graph=True)` + `loss.backward()` need."""
+
+    @staticmethod
+    def forward(ctx, GS, GM, X, R, V, U):
+        from . import _lib
+        from .ops import _stream
+        E, H = X.size(0), X.size(1) // 3
+        GS = torch.zeros(E, H, dtype=X.dtype, device=X.device) if GS is None else _c(GS)
+        GM = torch.zeros(E, 3, H, dtype=X.dtype, device=X.device) if GM is None else _c(GM)
+        gX, gR = torch.empty_like(X), torch.empty_like(R)
+        gV = None if V is None else torch.empty_like(V)
+        gU = torch.empty_like(U)
+        P = _lib.ptr
+        _lib.check(_lib.load().hermnet_edge_message_bwd(P(GS), P(GM), P(X), P(R), P(V), P(U), E, H, P(gX), P(gR), P(gV),
+                                                        P(gU), _stream()), "hermnet_edge_message_bwd")
+        ctx.save_for_backward(GS, GM, X, R, V, U)
+        return gX, gR, gV, gU
+
+    @staticmethod
+    def backward(ctx, cX, cR, cV, cU):
+        from . import _lib
+        from .ops import _stream
+        GS, GM, X, R, V, U = ctx.saved_tensors
+        E, H = X.size(0), X.size(1) // 3
+        cX, cR, cV, cU = _c(cX), _c(cR), _c(cV), _c(cU)
+        dGS, dGM = torch.empty_like(GS), torch.empty_like(GM)
+        dX, dR = torch.empty_like(X), torch.empty_like(R)
+        dV = None if V is None else torch.empty_like(V)
+        dU = torch.empty_like(U)
+        P = _lib.ptr
+        _lib.check(_lib.load().hermnet_edge_message_bwd2(P(cX), P(cR), P(cV), P(cU), P(GS), P(GM), P(X), P(R), P(V), P(U),
+                                                         E, H, P(dGS), P(dGM), P(dX), P(dR), P(dV), P(dU), _stream()),
+                   "hermnet_edge_message_bwd2")
+        return dGS, dGM, dX, dR, dV, dU
+
+
+def edge_message(X, R, V, U):
+    """S, M of the per-edge message algebra: the kernels on the GPU (fp32, width a multiple of 4), torch ops otherwise."""
+    if (X.is_cuda and X.dtype == torch.float32 and (X.size(1) // 3) % 4 == 0 and X.size(0) > 0
+            and os.environ.get("HERMNET_TRAIN_KERNELS", "1") != "0"):
+        return EdgeMessage.apply(X, R, V, U)
+    return _edge_message_torch(X, R, V, U)
+
+
 def _row_keys(graph, T, N, bounds):
-    """(key of the targets of the first Ek CSR edges, [key of relation t's sources], key of all sources) for
-    `message_scatter_generic`, from the graph's CSR / CSC orders; built once per graph."""
+    """(key of the targets of the first Ek CSR edges, key of their sources, key of their (relation, source) rows of
+    xh.view(T N, 3H)) for `message_scatter_generic`, from the graph's CSR / CSC orders; built once per graph."""
     keys = getattr(graph, "_row_keys", None)
     if keys is not None:
         return keys
@@ -269,15 +360,14 @@ def _row_keys(graph, T, N, bounds):
     k_tgt = _RowKey(tgt_row, None, lengths, N)
     src = graph.csr_src.long()
     crp, cpos = graph.csc_rowptr.long(), graph.csc_pos.long()               # groups (relation, source row) over CSR positions
-    k_src = []
-    for t in range(T):
-        e0, e1 = bounds[t], bounds[t + 1]
-        seg = crp[t * N:(t + 1) * N + 1]
-        k_src.append(_RowKey(src[e0:e1], cpos[e0:e1] - e0, seg[1:] - seg[:-1], N))
     # all relations at once: sorted by (source row) = the T groups of a row merged; built by one stable sort
     order = torch.argsort(src[:Ek], stable=True)
     k_all = _RowKey(src[:Ek], order, torch.bincount(src[:Ek], minlength=N), N)
-    graph._row_keys = (k_tgt, k_src, k_all)
+    # rows of xh.view(T * N, 3H): (relation of the edge's target, source row) -- the CSC groups themselves
+    rel_of_edge = torch.repeat_interleave(torch.arange(T, device=dev),
+                                          torch.tensor([bounds[t + 1] - bounds[t] for t in range(T)], device=dev))
+    k_xh = _RowKey(rel_of_edge * N + src[:Ek], cpos[:Ek], crp[1:T * N + 1] - crp[:T * N], T * N)
+    graph._row_keys = (k_tgt, k_all, k_xh)
     return graph._row_keys
 
 
@@ -293,7 +383,7 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     # (no per-relation masks or gathers of the edge arrays)
     bounds = graph.rel_edge_bounds()
     Ek = bounds[T]                                             # edges whose target has a known element
-    k_tgt, k_src, k_all = _row_keys(graph, T, N, bounds)
+    k_tgt, k_all, k_xh = _row_keys(graph, T, N, bounds)
     # the constant factors of the vector message (1/sqrt(3H) on the `a` part, 1/sqrt(H) on `b`, rmnet.py:64-66) ride on
     # the [3H, R] projection weights, not on per-edge tensors
     sc = x.new_ones(3 * H)
@@ -303,20 +393,17 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     for t in range(T):
         e0, e1 = bounds[t], bounds[t + 1]
         if e1 > e0:
-            rb = F.linear(edge_embed[e0:e1], w_rbf[t] * sc[:, None], b_rbf[t] * sc)   # rbf_proj, rmnet.py:55
-            parts.append(GatherRows.apply(xh[t], k_src[t]) * rb)                   # x_j * rbfh, rmnet.py:58,61-62
+            parts.append(F.linear(edge_embed[e0:e1], w_rbf[t] * sc[:, None], b_rbf[t] * sc))   # rbf_proj, rmnet.py:55
     dx = x.new_zeros(N, H)
     dv = x.new_zeros(N, 3, H)
     if parts:
-        m = parts[0] if len(parts) == 1 else torch.cat(parts, 0)                   # [Ek, 3H]
-        # (unbind of the [Ek,3,H] view: its backward is ONE stack, where three column slices each zero-fill a full
-        # [Ek,3H] gradient)
-        s_, a_, b_ = m.view(-1, 3, H).unbind(1)
-        mv = b_[:, None, :] * edge[:Ek, :3, None]                                  # rmnet.py:64-66
-        if vec is not None:
-            mv = torch.addcmul(mv, GatherRows.apply(vec, k_all), a_[:, None, :])
-        dx = SumRows.apply(s_, k_tgt)                                              # aggregate, rmnet.py:69-73
-        dv = SumRows.apply(mv, k_tgt)
+        R = parts[0] if len(parts) == 1 else torch.cat(parts, 0)                   # [Ek, 3H]
+        X = GatherRows.apply(xh.reshape(T * N, 3 * H), k_xh)                       # x_j of every edge, rmnet.py:58
+        V = None if vec is None else GatherRows.apply(vec, k_all)
+        # x_j * rbfh and the vector message (rmnet.py:61-66), then the aggregation (rmnet.py:69-73)
+        S, M = edge_message(X, R, V, edge[:Ek, :3])
+        dx = SumRows.apply(S, k_tgt)
+        dv = SumRows.apply(M, k_tgt)
     known = (rel_row < T).to(x.dtype)
     x1 = (x + dx) * (1 / math.sqrt(2.0)) * known[:, None]
     vec1 = ((vec if vec is not None else 0) + dv) * known[:, None, None]

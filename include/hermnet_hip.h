@@ -371,6 +371,26 @@ int hermnet_node_update_bwd(const float* gx_out, const float* gvec_out, const fl
 int hermnet_pair_mean(int mode, const float* x_in, const float* vec_in, float* x_out, float* vec_out, int num_elem,
                       int pairs, int block, int rows_out, int hidden, float scale_x, float scale_vec, void* stream);
 
+/* ---- the training step's per-edge message algebra (rmnet.py:58-66 inside example/dist_train.py:86-99, where the
+ * forces are differentiated w.r.t. the parameters: every op needs a second derivative).  ABI v6; csrc/train_kernels.hip.
+ *   X [E,3H] = x_proj(LayerNorm(x)) of the edge's source (Xs | Xa | Xb),  R [E,3H] = rbf_proj(rbf(d)) (Rs | Ra | Rb, the
+ *   constant factors 1/sqrt(3H), 1/sqrt(H) already on the a / b parts),  V [E,3,H] = vec of the source or NULL (layer 0),
+ *   U [E,3] = rhat.   hidden must be a multiple of 4.
+ *   fwd :  S = Xs Rs [E,H];  M_d = (Xb Rb) U_d + V_d (Xa Ra) [E,3,H]        (their row sums are dx, dvec)
+ *   bwd :  cotangents (GS, GM) -> gX, gR [E,3H], gV [E,3,H] (NULL with V), gU [E,3]
+ *   bwd2:  cotangents (cX, cR, cV, cU; each may be NULL = zero) of bwd's outputs -> dGS [E,H], dGM [E,3,H], dX, dR
+ *          [E,3H], dV [E,3,H] (NULL with V), dU [E,3]   -- the backward of the backward; the map is multilinear, so all
+ *          three are per-edge products and channel sums (deterministic, no atomics). */
+int hermnet_edge_message_fwd(const float* X, const float* R, const float* V, const float* U, long num_edges, int hidden,
+                             float* S, float* M, void* stream);
+int hermnet_edge_message_bwd(const float* GS, const float* GM, const float* X, const float* R, const float* V,
+                             const float* U, long num_edges, int hidden, float* gX, float* gR, float* gV, float* gU,
+                             void* stream);
+int hermnet_edge_message_bwd2(const float* cX, const float* cR, const float* cV, const float* cU, const float* GS,
+                              const float* GM, const float* X, const float* R, const float* V, const float* U,
+                              long num_edges, int hidden, float* dGS, float* dGM, float* dX, float* dR, float* dV,
+                              float* dU, void* stream);
+
 /* Halo exchange packing for atom-sharded runs (one process per GPU; the exchange itself is an RCCL all-to-all made
  * by the host code, hermnet_amd/sharding.py).  A packed row = [ x (H) | vec (3H) ]; idx [n] (int64) holds rows.
  *   mode 0  buf[k] = rows[idx[k]]                         pack what the neighbours need

@@ -322,6 +322,43 @@ def test_node_chain_kernels_match_restatement(H, T, counts, uniform, hr):
     assert torch.isfinite(gx1).all() and torch.isfinite(gvec1).all()
 
 
+@pytest.mark.parametrize("E,H,has_v", [(1000, 128, True), (777, 128, False), (301, 100, True), (50, 512, True), (5, 4, True),
+                                       (130, 36, False)])
+def test_edge_message_kernels_match_autograd_to_second_order(E, H, has_v):
+    """csrc/train_kernels.hip (the training step's per-edge message algebra: forward, backward, backward of the backward)
+    vs PyTorch autograd on the torch expression of the same map in float64: outputs, first-order gradients taken with
+    create_graph=True, and the gradients of a functional of those w.r.t. every input AND the first cotangents."""
+    from hermnet_amd import rmnet
+    dev = _dev()
+    gen = torch.Generator().manual_seed(E + H)
+    rnd = lambda *s_: torch.randn(*s_, generator=gen)
+    base = dict(X=rnd(E, 3 * H), R=rnd(E, 3 * H), V=rnd(E, 3, H) if has_v else None, U=rnd(E, 3),
+                ws=rnd(E, H), wm=rnd(E, 3, H))
+    wg = dict(X=rnd(E, 3 * H), R=rnd(E, 3 * H), V=rnd(E, 3, H), U=rnd(E, 3))
+
+    def run(fn, device, dtype):
+        t = {k: (None if v is None else v.to(device=device, dtype=dtype).requires_grad_(True)) for k, v in base.items()}
+        S, M = fn(t["X"], t["R"], t["V"], t["U"])
+        L1 = (S * t["ws"]).sum() + (M * t["wm"]).sum()
+        names = [k for k in ("X", "R", "V", "U") if t[k] is not None]
+        first = torch.autograd.grad(L1, [t[k] for k in names], create_graph=True)
+        L2 = sum((g * wg[k].to(device=device, dtype=dtype)).sum() for k, g in zip(names, first))
+        leaves = names + ["ws", "wm"]
+        second = torch.autograd.grad(L2, [t[k] for k in leaves], allow_unused=True)
+        out = {"S": S, "M": M}
+        out.update({"g" + k: g for k, g in zip(names, first)})
+        out.update({"d" + k: g for k, g in zip(leaves, second)})
+        return {k: (None if v is None else v.detach().double().cpu()) for k, v in out.items()}
+
+    got = run(rmnet.EdgeMessage.apply, dev, torch.float32)
+    ref = run(rmnet._edge_message_torch, torch.device("cpu"), torch.float64)
+    assert set(got) == set(ref)
+    for k in ref:
+        assert (got[k] is None) == (ref[k] is None), k
+        if ref[k] is not None:
+            assert rel_err(got[k], ref[k]) < 1e-5, (k, rel_err(got[k], ref[k]))
+
+
 @pytest.mark.parametrize("H", [64, 128, 320, 1024])
 def test_layernorm_kernels(H):
     """`hermnet_layernorm_fwd/_bwd` (no affine) vs torch.native_layer_norm and its backward."""
