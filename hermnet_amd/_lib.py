@@ -64,6 +64,7 @@ SIGNATURES = {
     "hermnet_build_triadic": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int,
                                              c_fp, c_fp, ctypes.POINTER(RelationsOut), c_fp, c_fp, ctypes.c_int, c_fp,
                                              ctypes.c_size_t, c_fp]),
+    "hermnet_segment_sum": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_long, ctypes.c_int, c_fp, c_fp]),
     "hermnet_edge_message_fwd": (ctypes.c_int, [c_fp] * 4 + [ctypes.c_long, ctypes.c_int, c_fp, c_fp, c_fp]),
     "hermnet_edge_message_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_long, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "hermnet_edge_message_bwd2": (ctypes.c_int, [c_fp] * 10 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 7),

@@ -215,3 +215,57 @@ extern "C" int hermnet_edge_message_bwd2(const float* cX, const float* cR, const
   const bool has_v = V != nullptr;
   HN_EDGE_LAUNCH(edge_msg_bwd2_kernel);
 }
+
+// ---- segmented row sum with an optional gather: out[r] = sum_{q in [rowptr[r], rowptr[r+1])} x[perm ? perm[q] : q]
+// (the adjoint of a row gather; rows of `width` floats, width a multiple of 4).  LPR lanes per output row, a lane owns
+// column quads c = l, l + LPR, ...; the members of a row are added in list order: deterministic, no atomics, one pass
+// over x (torch: index_select into a sorted copy, then segment_reduce).
+namespace {
+
+template <int LPR>
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ x, const long* __restrict__ perm,
+                                                         const long* __restrict__ rowptr, float* __restrict__ out,
+                                                         long n_rows, int width) {
+  constexpr int RPB = 256 / LPR;
+  const int l = threadIdx.x % LPR;
+  const long r = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+  if (r >= n_rows) return;
+  const long q0 = rowptr[r], q1 = rowptr[r + 1];
+  const int Q = width >> 2;
+  for (int c = l; c < Q; c += LPR) {
+    f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
+    long q = q0;
+    for (; q + 1 < q1; q += 2) {            // two rows in flight
+      const long i0 = perm ? perm[q] : q, i1 = perm ? perm[q + 1] : q + 1;
+      const f4 v0 = ld4(x + (size_t)i0 * width + 4 * c), v1 = ld4(x + (size_t)i1 * width + 4 * c);
+      acc += v0;
+      acc += v1;
+    }
+    if (q < q1) acc += ld4(x + (size_t)(perm ? perm[q] : q) * width + 4 * c);
+    st4(out + (size_t)r * width + 4 * c, acc);
+  }
+}
+
+}  // namespace
+
+extern "C" int hermnet_segment_sum(const float* x, const long* perm, const long* rowptr, long num_rows, int width,
+                                   float* out, void* stream) {
+  if (num_rows < 0 || width <= 0 || (width & 3) != 0) return HN_ERR_BAD_ARG;
+  if (num_rows == 0) return HN_OK;
+  if (!x || !rowptr || !out) return HN_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int Q = width >> 2;
+  int lpr = 1;
+  while (lpr < Q && lpr < 64) lpr <<= 1;
+  const unsigned blocks = (unsigned)((num_rows + (256 / lpr) - 1) / (256 / lpr));
+  switch (lpr) {
+    case 1: hipLaunchKernelGGL(segment_sum_kernel<1>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+    case 2: hipLaunchKernelGGL(segment_sum_kernel<2>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+    case 4: hipLaunchKernelGGL(segment_sum_kernel<4>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+    case 8: hipLaunchKernelGGL(segment_sum_kernel<8>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+    case 16: hipLaunchKernelGGL(segment_sum_kernel<16>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+    case 32: hipLaunchKernelGGL(segment_sum_kernel<32>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+    default: hipLaunchKernelGGL(segment_sum_kernel<64>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+  }
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}

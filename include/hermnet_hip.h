@@ -391,6 +391,12 @@ int hermnet_edge_message_bwd2(const float* cX, const float* cR, const float* cV,
                               long num_edges, int hidden, float* dGS, float* dGM, float* dX, float* dR, float* dV,
                               float* dU, void* stream);
 
+/* Segmented row sum with an optional gather (the adjoint of a row gather; training path, ABI v6):
+ * out[r] = sum over q in [rowptr[r], rowptr[r+1]) of x[perm ? perm[q] : q], rows of `width` floats (a multiple of 4),
+ * members added in list order (deterministic).  perm [rowptr[num_rows]] int64 or NULL; rowptr [num_rows + 1] int64. */
+int hermnet_segment_sum(const float* x, const long* perm, const long* rowptr, long num_rows, int width, float* out,
+                        void* stream);
+
 /* Halo exchange packing for atom-sharded runs (one process per GPU; the exchange itself is an RCCL all-to-all made
  * by the host code, hermnet_amd/sharding.py).  A packed row = [ x (H) | vec (3H) ]; idx [n] (int64) holds rows.
  *   mode 0  buf[k] = rows[idx[k]]                         pack what the neighbours need

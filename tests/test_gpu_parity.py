@@ -359,6 +359,36 @@ def test_edge_message_kernels_match_autograd_to_second_order(E, H, has_v):
             assert rel_err(got[k], ref[k]) < 1e-5, (k, rel_err(got[k], ref[k]))
 
 
+@pytest.mark.parametrize("K,n_rows,shape", [(5000, 700, (128,)), (5000, 700, (3, 128)), (333, 50, (100,)), (40, 64, (4,)),
+                                            (2000, 10, (3, 512))])
+def test_segment_sum_kernel_and_its_adjoint_pair(K, n_rows, shape):
+    """`hermnet_segment_sum` behind `rmnet.SumRows` (rows gathered inside the sum, list order) vs index_add in float64,
+    sorted and permuted assignments, empty rows; and `GatherRows` / `SumRows` differentiate into each other."""
+    from hermnet_amd import rmnet
+    dev = _dev()
+    gen = torch.Generator().manual_seed(K)
+    idx = torch.randint(0, n_rows, (K,), generator=gen)
+    idx[idx == 3] = 4                                   # an empty row
+    x = torch.randn(K, *shape, generator=gen)
+    want = torch.zeros(n_rows, *shape, dtype=torch.float64).index_add_(0, idx, x.double())
+    for sorted_input in (False, True):
+        if sorted_input:
+            order = torch.argsort(idx, stable=True)
+            idx_, x_, perm = idx[order], x[order], None
+        else:
+            idx_, x_, perm = idx, x, torch.argsort(idx, stable=True).to(dev)
+        key = rmnet._RowKey(idx_.to(dev), perm, torch.bincount(idx_, minlength=n_rows).to(dev), n_rows)
+        xd = x_.to(dev).requires_grad_(True)
+        out = rmnet.SumRows.apply(xd, key)
+        assert rel_err(out.detach().cpu().double(), want) < 1e-6
+        w = torch.randn(n_rows, *shape, generator=gen).to(dev)
+        g, = torch.autograd.grad((out * w).sum(), xd, create_graph=True)
+        assert torch.equal(g, w.index_select(0, idx_.to(dev)))                       # the adjoint: a gather
+        w2 = torch.randn(K, *shape, generator=gen).to(dev)
+        back, = torch.autograd.grad((rmnet.GatherRows.apply(w.clone().requires_grad_(True), key) * w2).sum(), xd, allow_unused=True)
+        assert back is None
+
+
 @pytest.mark.parametrize("H", [64, 128, 320, 1024])
 def test_layernorm_kernels(H):
     """`hermnet_layernorm_fwd/_bwd` (no affine) vs torch.native_layer_norm and its backward."""

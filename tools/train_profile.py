@@ -34,3 +34,13 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
 rows = [(ev.device_time_total, ev.count, ev.key) for ev in prof.key_averages() if ev.device_time_total > 0 and ev.key.startswith("aten::")]
 for t, c, k in sorted(rows, reverse=True)[:30]:
     print("%9.1f us  x%4d  %s" % (t, c, k))
+import collections
+kern = collections.defaultdict(lambda: [0, 0.0])
+for ev in prof.events():
+    if str(ev.device_type).endswith("CUDA"):
+        kern[ev.name[:90]][0] += 1
+        kern[ev.name[:90]][1] += ev.device_time_total if ev.device_time_total else (ev.time_range.end - ev.time_range.start)
+tot = sum(v[1] for v in kern.values())
+print("device kernels: %.1f ms in %d launches" % (tot / 1e3, sum(v[0] for v in kern.values())))
+for name, (n, t) in sorted(kern.items(), key=lambda kv: -kv[1][1])[:25]:
+    print("%9.1f us  x%4d  %s" % (t, n, name))
