@@ -42,5 +42,5 @@ for ev in prof.events():
         kern[ev.name[:90]][1] += ev.device_time_total if ev.device_time_total else (ev.time_range.end - ev.time_range.start)
 tot = sum(v[1] for v in kern.values())
 print("device kernels: %.1f ms in %d launches" % (tot / 1e3, sum(v[0] for v in kern.values())))
-for name, (n, t) in sorted(kern.items(), key=lambda kv: -kv[1][1])[:25]:
+for name, (n, t) in sorted(kern.items(), key=lambda kv: -kv[1][1])[:60]:
     print("%9.1f us  x%4d  %s" % (t, n, name))
