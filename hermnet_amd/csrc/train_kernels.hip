@@ -41,7 +41,13 @@ struct EdgeMsgArgs {
   float *o0, *o1, *o2, *o3, *o4, *o5;  // outputs, see the kernels
   long E;
   int H;
+  // row indices (each may be null = the edge's own row e): X / cX rows of edge e live at row xi[e] of their arrays,
+  // V / cV at vi[e], GS / GM at ti[e] -- the gathers x_j = xh[(relation, source)], vec_j = vec[source] and the
+  // cotangent gathers g[target] happen inside the kernels instead of materialising [E, .] copies
+  const long *xi, *vi, *ti;
 };
+
+__device__ __forceinline__ size_t row_of(const long* idx, long e) { return (size_t)(idx ? idx[e] : e); }
 
 template <int LPE, bool HAS_V>
 __global__ __launch_bounds__(256) void edge_msg_fwd_kernel(EdgeMsgArgs a) {
@@ -52,8 +58,9 @@ __global__ __launch_bounds__(256) void edge_msg_fwd_kernel(EdgeMsgArgs a) {
   if (e >= a.E) return;
   const int H = a.H, Q = H >> 2;
   const float u0 = a.U[3 * e], u1 = a.U[3 * e + 1], u2 = a.U[3 * e + 2];
-  const float* X = a.X + (size_t)e * 3 * H;
+  const float* X = a.X + row_of(a.xi, e) * 3 * H;
   const float* R = a.R + (size_t)e * 3 * H;
+  const size_t bv = row_of(a.vi, e) * 3 * H;
   for (int q = l; q < Q; q += LPE) {
     const int c = 4 * q;
     const f4 xs = ld4(X + c), xa = ld4(X + H + c), xb = ld4(X + 2 * H + c);
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256) void edge_msg_fwd_kernel(EdgeMsgArgs a) {
     f4 m0 = B * u0, m1 = B * u1, m2 = B * u2;
     if (HAS_V) {
       const f4 A = xa * ra;
-      const float* V = a.V + (size_t)e * 3 * H + c;
+      const float* V = a.V + bv + c;
       m0 += ld4(V) * A; m1 += ld4(V + H) * A; m2 += ld4(V + 2 * H) * A;
     }
     float* M = a.o1 + (size_t)e * 3 * H + c;
@@ -81,19 +88,20 @@ __global__ __launch_bounds__(256) void edge_msg_bwd_kernel(EdgeMsgArgs a) {
   const int H = a.H, Q = H >> 2;
   const long ee = live ? e : 0;
   const float u0 = a.U[3 * ee], u1 = a.U[3 * ee + 1], u2 = a.U[3 * ee + 2];
-  const size_t b3 = (size_t)ee * 3 * H;
+  const size_t b3 = (size_t)ee * 3 * H;                      // the edge's own row: R and every per-edge output
+  const size_t bx = row_of(a.xi, ee) * 3 * H, bw = row_of(a.vi, ee) * 3 * H, bt = row_of(a.ti, ee);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if (live)
     for (int q = l; q < Q; q += LPE) {
       const int c = 4 * q;
-      const f4 xs = ld4(a.X + b3 + c), xa = ld4(a.X + b3 + H + c), xb = ld4(a.X + b3 + 2 * H + c);
+      const f4 xs = ld4(a.X + bx + c), xa = ld4(a.X + bx + H + c), xb = ld4(a.X + bx + 2 * H + c);
       const f4 rs = ld4(a.R + b3 + c), ra = ld4(a.R + b3 + H + c), rb = ld4(a.R + b3 + 2 * H + c);
-      const f4 gs = ld4(a.GS + (size_t)ee * H + c);
-      const f4 g0 = ld4(a.GM + b3 + c), g1 = ld4(a.GM + b3 + H + c), g2 = ld4(a.GM + b3 + 2 * H + c);
+      const f4 gs = ld4(a.GS + bt * H + c);
+      const f4 g0 = ld4(a.GM + bt * 3 * H + c), g1 = ld4(a.GM + bt * 3 * H + H + c), g2 = ld4(a.GM + bt * 3 * H + 2 * H + c);
       const f4 gB = g0 * u0 + g1 * u1 + g2 * u2;
       f4 gXa = (f4){0.f, 0.f, 0.f, 0.f}, gRa = gXa;
       if (HAS_V) {
-        const f4 v0 = ld4(a.V + b3 + c), v1 = ld4(a.V + b3 + H + c), v2 = ld4(a.V + b3 + 2 * H + c);
+        const f4 v0 = ld4(a.V + bw + c), v1 = ld4(a.V + bw + H + c), v2 = ld4(a.V + bw + 2 * H + c);
         const f4 gA = g0 * v0 + g1 * v1 + g2 * v2, A = xa * ra;
         gXa = gA * ra; gRa = gA * xa;
         st4(a.o2 + b3 + c, g0 * A); st4(a.o2 + b3 + H + c, g1 * A); st4(a.o2 + b3 + 2 * H + c, g2 * A);
@@ -118,16 +126,17 @@ __global__ __launch_bounds__(256) void edge_msg_bwd2_kernel(EdgeMsgArgs a) {
   const long ee = live ? e : 0;
   const float u0 = a.U[3 * ee], u1 = a.U[3 * ee + 1], u2 = a.U[3 * ee + 2];
   const float k0 = a.cU ? a.cU[3 * ee] : 0.f, k1 = a.cU ? a.cU[3 * ee + 1] : 0.f, k2 = a.cU ? a.cU[3 * ee + 2] : 0.f;
-  const size_t b3 = (size_t)ee * 3 * H;
+  const size_t b3 = (size_t)ee * 3 * H;                      // the edge's own row: R and every per-edge output
+  const size_t bx = row_of(a.xi, ee) * 3 * H, bw = row_of(a.vi, ee) * 3 * H, bt = row_of(a.ti, ee);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if (live)
     for (int q = l; q < Q; q += LPE) {
       const int c = 4 * q;
-      const f4 xs = ld4(a.X + b3 + c), xa = ld4(a.X + b3 + H + c), xb = ld4(a.X + b3 + 2 * H + c);
+      const f4 xs = ld4(a.X + bx + c), xa = ld4(a.X + bx + H + c), xb = ld4(a.X + bx + 2 * H + c);
       const f4 rs = ld4(a.R + b3 + c), ra = ld4(a.R + b3 + H + c), rb = ld4(a.R + b3 + 2 * H + c);
-      const f4 gs = ld4(a.GS + (size_t)ee * H + c);
-      const f4 g0 = ld4(a.GM + b3 + c), g1 = ld4(a.GM + b3 + H + c), g2 = ld4(a.GM + b3 + 2 * H + c);
-      const f4 cXs = ld4z(a.cX, b3 + c), cXa = ld4z(a.cX, b3 + H + c), cXb = ld4z(a.cX, b3 + 2 * H + c);
+      const f4 gs = ld4(a.GS + bt * H + c);
+      const f4 g0 = ld4(a.GM + bt * 3 * H + c), g1 = ld4(a.GM + bt * 3 * H + H + c), g2 = ld4(a.GM + bt * 3 * H + 2 * H + c);
+      const f4 cXs = ld4z(a.cX, bx + c), cXa = ld4z(a.cX, bx + H + c), cXb = ld4z(a.cX, bx + 2 * H + c);
       const f4 cRs = ld4z(a.cR, b3 + c), cRa = ld4z(a.cR, b3 + H + c), cRb = ld4z(a.cR, b3 + 2 * H + c);
       st4(a.o0 + (size_t)ee * H + c, cXs * rs + cRs * xs);
       const f4 tB = cXb * rb + cRb * xb, B = xb * rb;
@@ -135,8 +144,8 @@ __global__ __launch_bounds__(256) void edge_msg_bwd2_kernel(EdgeMsgArgs a) {
       f4 d0 = tB * u0 + B * k0, d1 = tB * u1 + B * k1, d2 = tB * u2 + B * k2;
       f4 dXa = (f4){0.f, 0.f, 0.f, 0.f}, dRa = dXa;
       if (HAS_V) {
-        const f4 v0 = ld4(a.V + b3 + c), v1 = ld4(a.V + b3 + H + c), v2 = ld4(a.V + b3 + 2 * H + c);
-        const f4 w0 = ld4z(a.cV, b3 + c), w1 = ld4z(a.cV, b3 + H + c), w2 = ld4z(a.cV, b3 + 2 * H + c);
+        const f4 v0 = ld4(a.V + bw + c), v1 = ld4(a.V + bw + H + c), v2 = ld4(a.V + bw + 2 * H + c);
+        const f4 w0 = ld4z(a.cV, bw + c), w1 = ld4z(a.cV, bw + H + c), w2 = ld4z(a.cV, bw + 2 * H + c);
         const f4 tA = cXa * ra + cRa * xa, A = xa * ra;
         const f4 gA = g0 * v0 + g1 * v1 + g2 * v2, sV = g0 * w0 + g1 * w1 + g2 * w2;
         d0 += tA * v0 + w0 * A; d1 += tA * v1 + w1 * A; d2 += tA * v2 + w2 * A;
@@ -179,18 +188,20 @@ bool bad_shape(long E, int H) { return E < 0 || H <= 0 || (H & 3) != 0 || (doubl
 }  // namespace
 
 extern "C" int hermnet_edge_message_fwd(const float* X, const float* R, const float* V, const float* U, long num_edges,
-                                        int hidden, float* S, float* M, void* stream) {
+                                        int hidden, const long* x_rows, const long* v_rows, float* S, float* M,
+                                        void* stream) {
   if (bad_shape(num_edges, hidden)) return HN_ERR_BAD_ARG;
   if (num_edges == 0) return HN_OK;
   if (!X || !R || !U || !S || !M) return HN_ERR_BAD_ARG;
   EdgeMsgArgs a = {};
-  a.X = X; a.R = R; a.V = V; a.U = U; a.o0 = S; a.o1 = M; a.E = num_edges; a.H = hidden;
+  a.X = X; a.R = R; a.V = V; a.U = U; a.o0 = S; a.o1 = M; a.E = num_edges; a.H = hidden; a.xi = x_rows; a.vi = v_rows;
   const bool has_v = V != nullptr;
   HN_EDGE_LAUNCH(edge_msg_fwd_kernel);
 }
 
 extern "C" int hermnet_edge_message_bwd(const float* GS, const float* GM, const float* X, const float* R, const float* V,
-                                        const float* U, long num_edges, int hidden, float* gX, float* gR, float* gV,
+                                        const float* U, long num_edges, int hidden, const long* x_rows,
+                                        const long* v_rows, const long* t_rows, float* gX, float* gR, float* gV,
                                         float* gU, void* stream) {
   if (bad_shape(num_edges, hidden)) return HN_ERR_BAD_ARG;
   if (num_edges == 0) return HN_OK;
@@ -198,13 +209,15 @@ extern "C" int hermnet_edge_message_bwd(const float* GS, const float* GM, const 
   EdgeMsgArgs a = {};
   a.X = X; a.R = R; a.V = V; a.U = U; a.GS = GS; a.GM = GM;
   a.o0 = gX; a.o1 = gR; a.o2 = gV; a.o3 = gU; a.E = num_edges; a.H = hidden;
+  a.xi = x_rows; a.vi = v_rows; a.ti = t_rows;
   const bool has_v = V != nullptr;
   HN_EDGE_LAUNCH(edge_msg_bwd_kernel);
 }
 
 extern "C" int hermnet_edge_message_bwd2(const float* cX, const float* cR, const float* cV, const float* cU,
                                          const float* GS, const float* GM, const float* X, const float* R,
-                                         const float* V, const float* U, long num_edges, int hidden, float* dGS,
+                                         const float* V, const float* U, long num_edges, int hidden,
+                                         const long* x_rows, const long* v_rows, const long* t_rows, float* dGS,
                                          float* dGM, float* dX, float* dR, float* dV, float* dU, void* stream) {
   if (bad_shape(num_edges, hidden)) return HN_ERR_BAD_ARG;
   if (num_edges == 0) return HN_OK;
@@ -212,6 +225,7 @@ extern "C" int hermnet_edge_message_bwd2(const float* cX, const float* cR, const
   EdgeMsgArgs a = {};
   a.X = X; a.R = R; a.V = V; a.U = U; a.GS = GS; a.GM = GM; a.cX = cX; a.cR = cR; a.cV = V ? cV : nullptr; a.cU = cU;
   a.o0 = dGS; a.o1 = dGM; a.o2 = dX; a.o3 = dR; a.o4 = dV; a.o5 = dU; a.E = num_edges; a.H = hidden;
+  a.xi = x_rows; a.vi = v_rows; a.ti = t_rows;
   const bool has_v = V != nullptr;
   HN_EDGE_LAUNCH(edge_msg_bwd2_kernel);
 }

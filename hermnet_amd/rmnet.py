@@ -252,13 +252,7 @@ class SumRows(torch.autograd.Function):
         if (x.is_cuda and x.dtype == torch.float32 and width % 4 == 0
                 and os.environ.get("HERMNET_TRAIN_KERNELS", "1") != "0"):
             # one pass: the rows are gathered inside the sum (csrc/train_kernels.hip: hermnet_segment_sum)
-            from .ops import _stream
-            x = x.contiguous()
-            out = torch.empty((key.n_rows,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-            P = _lib.ptr
-            _lib.check(_lib.load().hermnet_segment_sum(P(x), P(key.perm), P(key.rowptr), key.n_rows, width, P(out), _stream()),
-                       "hermnet_segment_sum")
-            return out
+            return _segsum(x, key)
         xs = x if key.perm is None else x.index_select(0, key.perm)
         return torch.segment_reduce(xs.contiguous(), "sum", lengths=key.lengths, unsafe=True)
 
@@ -329,7 +323,7 @@ class EdgeMessage(torch.autograd.Function):
         S = torch.empty(E, H, dtype=X.dtype, device=X.device)
         M = torch.empty(E, 3, H, dtype=X.dtype, device=X.device)
         P = _lib.ptr
-        _lib.check(_lib.load().hermnet_edge_message_fwd(P(X), P(R), P(V), P(U), E, H, P(S), P(M), _stream()),
+        _lib.check(_lib.load().hermnet_edge_message_fwd(P(X), P(R), P(V), P(U), E, H, None, None, P(S), P(M), _stream()),
                    "hermnet_edge_message_fwd")
         ctx.save_for_backward(X, R, V, U)
         return S, M
@@ -356,8 +350,8 @@ class EdgeMessageGrad(torch.autograd.Function):
         gV = None if V is None else torch.empty_like(V)
         gU = torch.empty_like(U)
         P = _lib.ptr
-        _lib.check(_lib.load().hermnet_edge_message_bwd(P(GS), P(GM), P(X), P(R), P(V), P(U), E, H, P(gX), P(gR), P(gV),
-                                                        P(gU), _stream()), "hermnet_edge_message_bwd")
+        _lib.check(_lib.load().hermnet_edge_message_bwd(P(GS), P(GM), P(X), P(R), P(V), P(U), E, H, None, None, None,
+                                                        P(gX), P(gR), P(gV), P(gU), _stream()), "hermnet_edge_message_bwd")
         ctx.save_for_backward(GS, GM, X, R, V, U)
         return gX, gR, gV, gU
 
@@ -374,15 +368,97 @@ class EdgeMessageGrad(torch.autograd.Function):
         dU = torch.empty_like(U)
         P = _lib.ptr
         _lib.check(_lib.load().hermnet_edge_message_bwd2(P(cX), P(cR), P(cV), P(cU), P(GS), P(GM), P(X), P(R), P(V), P(U),
-                                                         E, H, P(dGS), P(dGM), P(dX), P(dR), P(dV), P(dU), _stream()),
-                   "hermnet_edge_message_bwd2")
+                                                         E, H, None, None, None, P(dGS), P(dGM), P(dX), P(dR), P(dV), P(dU),
+                                                         _stream()), "hermnet_edge_message_bwd2")
         return dGS, dGM, dX, dR, dV, dU
+
+
+def _segsum(x, key):
+    """out[r] = sum of x[k] over the edges k of row r (`hermnet_segment_sum`: rows gathered inside the sum, list order)."""
+    from .ops import _stream
+    x = x.contiguous()
+    out = torch.empty((key.n_rows,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    P = _lib.ptr
+    _lib.check(_lib.load().hermnet_segment_sum(P(x), P(key.perm), P(key.rowptr), key.n_rows, x[0].numel(), P(out), _stream()),
+               "hermnet_segment_sum")
+    return out
+
+
+class MessageAlgebra(torch.autograd.Function):
+    """(xh [T N,3H], vec [N,3,H] | None, R [E,3H], U [E,3]) -> (dx [N,H], dvec [N,3,H]): gather of x_j / vec_j, the
+    per-edge algebra and the aggregation of rmnet.py:58-73 with NODE-level inputs and outputs.  The kernels of
+    `EdgeMessage` read their gathered operands through row indices (x_j = xh[(relation, source)], vec_j = vec[source],
+    cotangents = g[target]) and the row sums follow inside the function, so no [E, 3H] copy of a gathered operand and
+    no per-edge gradient ever enters the autograd graph: what two graph nodes share and the engine has to add up is
+    node-sized.  Twice differentiable through `MessageAlgebraGrad`.  keys = (targets, sources, (relation, source))."""
+
+    @staticmethod
+    def forward(ctx, xh, vec, R, U, keys):
+        from .ops import _stream
+        k_tgt, k_all, k_xh = keys
+        xh, vec, R, U = _c(xh), _c(vec), _c(R), _c(U)
+        E, H = R.size(0), R.size(1) // 3
+        S = torch.empty(E, H, dtype=R.dtype, device=R.device)
+        M = torch.empty(E, 3, H, dtype=R.dtype, device=R.device)
+        P = _lib.ptr
+        _lib.check(_lib.load().hermnet_edge_message_fwd(P(xh), P(R), P(vec), P(U), E, H, P(k_xh.idx), P(k_all.idx), P(S), P(M),
+                                                        _stream()), "hermnet_edge_message_fwd")
+        ctx.save_for_backward(xh, vec, R, U)
+        ctx.keys = keys
+        return _segsum(S, k_tgt), _segsum(M, k_tgt)
+
+    @staticmethod
+    def backward(ctx, g_dx, g_dv):
+        xh, vec, R, U = ctx.saved_tensors
+        g_xh, g_vec, gR, gU = MessageAlgebraGrad.apply(g_dx, g_dv, xh, vec, R, U, ctx.keys)
+        return g_xh, g_vec, gR, gU, None
+
+
+class MessageAlgebraGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g_dx, g_dv, xh, vec, R, U, keys):
+        from .ops import _stream
+        k_tgt, k_all, k_xh = keys
+        E, H = R.size(0), R.size(1) // 3
+        g_dx = torch.zeros(k_tgt.n_rows, H, dtype=R.dtype, device=R.device) if g_dx is None else _c(g_dx)
+        g_dv = torch.zeros(k_tgt.n_rows, 3, H, dtype=R.dtype, device=R.device) if g_dv is None else _c(g_dv)
+        gX, gR = torch.empty_like(R), torch.empty_like(R)
+        gV = None if vec is None else torch.empty(E, 3, H, dtype=R.dtype, device=R.device)
+        gU = torch.empty_like(U)
+        P = _lib.ptr
+        _lib.check(_lib.load().hermnet_edge_message_bwd(P(g_dx), P(g_dv), P(xh), P(R), P(vec), P(U), E, H, P(k_xh.idx),
+                                                        P(k_all.idx), P(k_tgt.idx), P(gX), P(gR), P(gV), P(gU), _stream()),
+                   "hermnet_edge_message_bwd")
+        ctx.save_for_backward(g_dx, g_dv, xh, vec, R, U)
+        ctx.keys = keys
+        return _segsum(gX, k_xh), (None if vec is None else _segsum(gV, k_all)), gR, gU
+
+    @staticmethod
+    def backward(ctx, c_xh, c_vec, cR, cU):
+        from .ops import _stream
+        g_dx, g_dv, xh, vec, R, U = ctx.saved_tensors
+        k_tgt, k_all, k_xh = ctx.keys
+        E, H = R.size(0), R.size(1) // 3
+        c_xh, c_vec, cR, cU = _c(c_xh), _c(c_vec), _c(cR), _c(cU)
+        new = lambda *shape: torch.empty(*shape, dtype=R.dtype, device=R.device)
+        dGS, dGM, dX, dR, dU = new(E, H), new(E, 3, H), new(E, 3 * H), new(E, 3 * H), new(E, 3)
+        dV = None if vec is None else new(E, 3, H)
+        P = _lib.ptr
+        _lib.check(_lib.load().hermnet_edge_message_bwd2(P(c_xh), P(cR), P(c_vec), P(cU), P(g_dx), P(g_dv), P(xh), P(R), P(vec),
+                                                         P(U), E, H, P(k_xh.idx), P(k_all.idx), P(k_tgt.idx), P(dGS), P(dGM),
+                                                         P(dX), P(dR), P(dV), P(dU), _stream()), "hermnet_edge_message_bwd2")
+        return (_segsum(dGS, k_tgt), _segsum(dGM, k_tgt), _segsum(dX, k_xh), (None if vec is None else _segsum(dV, k_all)),
+                dR, dU, None)
+
+
+def _train_kernels(t):
+    return (t.is_cuda and t.dtype == torch.float32 and (t.size(-1) // 3) % 4 == 0 and t.size(0) > 0
+            and os.environ.get("HERMNET_TRAIN_KERNELS", "1") != "0")
 
 
 def edge_message(X, R, V, U):
     """S, M of the per-edge message algebra: the kernels on the GPU (fp32, width a multiple of 4), torch ops otherwise."""
-    if (X.is_cuda and X.dtype == torch.float32 and (X.size(1) // 3) % 4 == 0 and X.size(0) > 0
-            and os.environ.get("HERMNET_TRAIN_KERNELS", "1") != "0"):
+    if _train_kernels(X):
         return EdgeMessage.apply(X, R, V, U)
     return _edge_message_torch(X, R, V, U)
 
@@ -443,12 +519,16 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     dv = x.new_zeros(N, 3, H)
     if parts:
         R = parts[0] if len(parts) == 1 else torch.cat(parts, 0)                   # [Ek, 3H]
-        X = GatherRows.apply(xh.reshape(T * N, 3 * H), k_xh)                       # x_j of every edge, rmnet.py:58
-        V = None if vec is None else GatherRows.apply(vec, k_all)
-        # x_j * rbfh and the vector message (rmnet.py:61-66), then the aggregation (rmnet.py:69-73)
-        S, M = edge_message(X, R, V, edge[:Ek, :3])
-        dx = SumRows.apply(S, k_tgt)
-        dv = SumRows.apply(M, k_tgt)
+        if _train_kernels(R):
+            # gather x_j / vec_j (rmnet.py:58), x_j * rbfh and the vector message (:61-66), aggregation (:69-73): one
+            # twice-differentiable function with node-level inputs and outputs (csrc/train_kernels.hip)
+            dx, dv = MessageAlgebra.apply(xh.reshape(T * N, 3 * H), vec, R, edge[:Ek, :3], (k_tgt, k_all, k_xh))
+        else:
+            X = GatherRows.apply(xh.reshape(T * N, 3 * H), k_xh)                   # x_j of every edge, rmnet.py:58
+            V = None if vec is None else GatherRows.apply(vec, k_all)
+            S, M = edge_message(X, R, V, edge[:Ek, :3])
+            dx = SumRows.apply(S, k_tgt)
+            dv = SumRows.apply(M, k_tgt)
     known = (rel_row < T).to(x.dtype)
     x1 = (x + dx) * (1 / math.sqrt(2.0)) * known[:, None]
     vec1 = ((vec if vec is not None else 0) + dv) * known[:, None, None]

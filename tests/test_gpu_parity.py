@@ -359,6 +359,58 @@ def test_edge_message_kernels_match_autograd_to_second_order(E, H, has_v):
             assert rel_err(got[k], ref[k]) < 1e-5, (k, rel_err(got[k], ref[k]))
 
 
+@pytest.mark.parametrize("E,N,T,H,has_v", [(4000, 300, 3, 128, True), (900, 77, 2, 64, False), (500, 40, 1, 100, True)])
+def test_message_algebra_node_level_matches_autograd_to_second_order(E, N, T, H, has_v):
+    """`rmnet.MessageAlgebra` (gathers through row indices inside the edge kernels, row sums inside the function:
+    node-level inputs and outputs) vs gather -> torch expression -> index_add in float64 autograd, to second order."""
+    from hermnet_amd import rmnet
+    dev = _dev()
+    gen = torch.Generator().manual_seed(E + N)
+    rnd = lambda *s_: torch.randn(*s_, generator=gen)
+    tgt = torch.sort(torch.randint(0, N, (E,), generator=gen)).values
+    tgt[tgt == 5] = 6                                                    # a row without edges
+    src = torch.randint(0, N, (E,), generator=gen)
+    rel = torch.sort(torch.randint(0, T, (E,), generator=gen)).values
+    xrow = rel * N + src
+
+    def keys(device):
+        mk = lambda idx, perm, n: rmnet._RowKey(idx.to(device), None if perm is None else perm.to(device),
+                                                torch.bincount(idx, minlength=n).to(device), n)
+        return (mk(tgt, None, N), mk(src, torch.argsort(src, stable=True), N), mk(xrow, torch.argsort(xrow, stable=True), T * N))
+
+    base = dict(xh=rnd(T * N, 3 * H), vec=rnd(N, 3, H) if has_v else None, R=rnd(E, 3 * H), U=rnd(E, 3),
+                wx=rnd(N, H), wv=rnd(N, 3, H))
+    wg = dict(xh=rnd(T * N, 3 * H), vec=rnd(N, 3, H), R=rnd(E, 3 * H), U=rnd(E, 3))
+
+    def run(kernels, device, dtype):
+        t = {k: (None if v is None else v.to(device=device, dtype=dtype).requires_grad_(True)) for k, v in base.items()}
+        if kernels:
+            dx, dv = rmnet.MessageAlgebra.apply(t["xh"], t["vec"], t["R"], t["U"], keys(device))
+        else:
+            X = t["xh"][xrow.to(device)]
+            V = None if t["vec"] is None else t["vec"][src.to(device)]
+            S, M = rmnet._edge_message_torch(X, t["R"], V, t["U"])
+            dx = torch.zeros(N, H, dtype=dtype, device=device).index_add(0, tgt.to(device), S)
+            dv = torch.zeros(N, 3, H, dtype=dtype, device=device).index_add(0, tgt.to(device), M)
+        L1 = (dx * t["wx"]).sum() + (dv * t["wv"]).sum()
+        names = [k for k in ("xh", "vec", "R", "U") if t[k] is not None]
+        first = torch.autograd.grad(L1, [t[k] for k in names], create_graph=True)
+        L2 = sum((g * wg[k].to(device=device, dtype=dtype)).sum() for k, g in zip(names, first))
+        leaves = names + ["wx", "wv"]
+        second = torch.autograd.grad(L2, [t[k] for k in leaves], allow_unused=True)
+        out = {"dx": dx, "dv": dv}
+        out.update({"g_" + k: g for k, g in zip(names, first)})
+        out.update({"dd_" + k: g for k, g in zip(leaves, second)})
+        return {k: (None if v is None else v.detach().double().cpu()) for k, v in out.items()}
+
+    got, ref = run(True, dev, torch.float32), run(False, torch.device("cpu"), torch.float64)
+    assert set(got) == set(ref)
+    for k in ref:
+        assert (got[k] is None) == (ref[k] is None), k
+        if ref[k] is not None:
+            assert rel_err(got[k], ref[k]) < 1e-5, (k, rel_err(got[k], ref[k]))
+
+
 @pytest.mark.parametrize("K,n_rows,shape", [(5000, 700, (128,)), (5000, 700, (3, 128)), (333, 50, (100,)), (40, 64, (4,)),
                                             (2000, 10, (3, 512))])
 def test_segment_sum_kernel_and_its_adjoint_pair(K, n_rows, shape):
