@@ -65,9 +65,9 @@ SIGNATURES = {
                                              c_fp, c_fp, ctypes.POINTER(RelationsOut), c_fp, c_fp, ctypes.c_int, c_fp,
                                              ctypes.c_size_t, c_fp]),
     "hermnet_segment_sum": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_long, ctypes.c_int, c_fp, c_fp]),
-    "hermnet_edge_message_fwd": (ctypes.c_int, [c_fp] * 4 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 5),
-    "hermnet_edge_message_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 8),
-    "hermnet_edge_message_bwd2": (ctypes.c_int, [c_fp] * 10 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 10),
+    "hermnet_edge_message_fwd": (ctypes.c_int, [c_fp] * 4 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 6),
+    "hermnet_edge_message_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 9),
+    "hermnet_edge_message_bwd2": (ctypes.c_int, [c_fp] * 10 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 11),
     "hermnet_ssilu_fwd": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_long, ctypes.c_int, c_fp]),
     "hermnet_ssilu_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_long, ctypes.c_long, c_fp]),

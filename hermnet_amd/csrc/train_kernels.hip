@@ -44,7 +44,9 @@ struct EdgeMsgArgs {
   // row indices (each may be null = the edge's own row e): X / cX rows of edge e live at row xi[e] of their arrays,
   // V / cV at vi[e], GS / GM at ti[e] -- the gathers x_j = xh[(relation, source)], vec_j = vec[source] and the
   // cotangent gathers g[target] happen inside the kernels instead of materialising [E, .] copies
-  const long *xi, *vi, *ti;
+  // ri: R (and cR) of edge e is row ri[e]; gR / dR are written to that row as well (R may be stored in another edge order,
+  // e.g. sorted by distance bucket: rmnet.BucketedBasis)
+  const long *xi, *vi, *ti, *ri;
 };
 
 __device__ __forceinline__ size_t row_of(const long* idx, long e) { return (size_t)(idx ? idx[e] : e); }
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void edge_msg_fwd_kernel(EdgeMsgArgs a) {
   const int H = a.H, Q = H >> 2;
   const float u0 = a.U[3 * e], u1 = a.U[3 * e + 1], u2 = a.U[3 * e + 2];
   const float* X = a.X + row_of(a.xi, e) * 3 * H;
-  const float* R = a.R + (size_t)e * 3 * H;
+  const float* R = a.R + row_of(a.ri, e) * 3 * H;
   const size_t bv = row_of(a.vi, e) * 3 * H;
   for (int q = l; q < Q; q += LPE) {
     const int c = 4 * q;
@@ -90,12 +92,13 @@ __global__ __launch_bounds__(256) void edge_msg_bwd_kernel(EdgeMsgArgs a) {
   const float u0 = a.U[3 * ee], u1 = a.U[3 * ee + 1], u2 = a.U[3 * ee + 2];
   const size_t b3 = (size_t)ee * 3 * H;                      // the edge's own row: R and every per-edge output
   const size_t bx = row_of(a.xi, ee) * 3 * H, bw = row_of(a.vi, ee) * 3 * H, bt = row_of(a.ti, ee);
+  const size_t br = row_of(a.ri, ee) * 3 * H;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if (live)
     for (int q = l; q < Q; q += LPE) {
       const int c = 4 * q;
       const f4 xs = ld4(a.X + bx + c), xa = ld4(a.X + bx + H + c), xb = ld4(a.X + bx + 2 * H + c);
-      const f4 rs = ld4(a.R + b3 + c), ra = ld4(a.R + b3 + H + c), rb = ld4(a.R + b3 + 2 * H + c);
+      const f4 rs = ld4(a.R + br + c), ra = ld4(a.R + br + H + c), rb = ld4(a.R + br + 2 * H + c);
       const f4 gs = ld4(a.GS + bt * H + c);
       const f4 g0 = ld4(a.GM + bt * 3 * H + c), g1 = ld4(a.GM + bt * 3 * H + H + c), g2 = ld4(a.GM + bt * 3 * H + 2 * H + c);
       const f4 gB = g0 * u0 + g1 * u1 + g2 * u2;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256) void edge_msg_bwd_kernel(EdgeMsgArgs a) {
         st4(a.o2 + b3 + c, g0 * A); st4(a.o2 + b3 + H + c, g1 * A); st4(a.o2 + b3 + 2 * H + c, g2 * A);
       }
       st4(a.o0 + b3 + c, gs * rs); st4(a.o0 + b3 + H + c, gXa); st4(a.o0 + b3 + 2 * H + c, gB * rb);
-      st4(a.o1 + b3 + c, gs * xs); st4(a.o1 + b3 + H + c, gRa); st4(a.o1 + b3 + 2 * H + c, gB * xb);
+      st4(a.o1 + br + c, gs * xs); st4(a.o1 + br + H + c, gRa); st4(a.o1 + br + 2 * H + c, gB * xb);
       const f4 B = xb * rb;
       s0 += hsum(g0 * B); s1 += hsum(g1 * B); s2 += hsum(g2 * B);
     }
@@ -128,16 +131,17 @@ __global__ __launch_bounds__(256) void edge_msg_bwd2_kernel(EdgeMsgArgs a) {
   const float k0 = a.cU ? a.cU[3 * ee] : 0.f, k1 = a.cU ? a.cU[3 * ee + 1] : 0.f, k2 = a.cU ? a.cU[3 * ee + 2] : 0.f;
   const size_t b3 = (size_t)ee * 3 * H;                      // the edge's own row: R and every per-edge output
   const size_t bx = row_of(a.xi, ee) * 3 * H, bw = row_of(a.vi, ee) * 3 * H, bt = row_of(a.ti, ee);
+  const size_t br = row_of(a.ri, ee) * 3 * H;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if (live)
     for (int q = l; q < Q; q += LPE) {
       const int c = 4 * q;
       const f4 xs = ld4(a.X + bx + c), xa = ld4(a.X + bx + H + c), xb = ld4(a.X + bx + 2 * H + c);
-      const f4 rs = ld4(a.R + b3 + c), ra = ld4(a.R + b3 + H + c), rb = ld4(a.R + b3 + 2 * H + c);
+      const f4 rs = ld4(a.R + br + c), ra = ld4(a.R + br + H + c), rb = ld4(a.R + br + 2 * H + c);
       const f4 gs = ld4(a.GS + bt * H + c);
       const f4 g0 = ld4(a.GM + bt * 3 * H + c), g1 = ld4(a.GM + bt * 3 * H + H + c), g2 = ld4(a.GM + bt * 3 * H + 2 * H + c);
       const f4 cXs = ld4z(a.cX, bx + c), cXa = ld4z(a.cX, bx + H + c), cXb = ld4z(a.cX, bx + 2 * H + c);
-      const f4 cRs = ld4z(a.cR, b3 + c), cRa = ld4z(a.cR, b3 + H + c), cRb = ld4z(a.cR, b3 + 2 * H + c);
+      const f4 cRs = ld4z(a.cR, br + c), cRa = ld4z(a.cR, br + H + c), cRb = ld4z(a.cR, br + 2 * H + c);
       st4(a.o0 + (size_t)ee * H + c, cXs * rs + cRs * xs);
       const f4 tB = cXb * rb + cRb * xb, B = xb * rb;
       const f4 gB = g0 * u0 + g1 * u1 + g2 * u2, sU = g0 * k0 + g1 * k1 + g2 * k2;
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256) void edge_msg_bwd2_kernel(EdgeMsgArgs a) {
       }
       st4(a.o1 + b3 + c, d0); st4(a.o1 + b3 + H + c, d1); st4(a.o1 + b3 + 2 * H + c, d2);
       st4(a.o2 + b3 + c, cRs * gs); st4(a.o2 + b3 + H + c, dXa); st4(a.o2 + b3 + 2 * H + c, cRb * gB + rb * sU);
-      st4(a.o3 + b3 + c, cXs * gs); st4(a.o3 + b3 + H + c, dRa); st4(a.o3 + b3 + 2 * H + c, cXb * gB + xb * sU);
+      st4(a.o3 + br + c, cXs * gs); st4(a.o3 + br + H + c, dRa); st4(a.o3 + br + 2 * H + c, cXb * gB + xb * sU);
       s0 += hsum(tB * g0); s1 += hsum(tB * g1); s2 += hsum(tB * g2);
     }
   s0 = group_sum<LPE>(s0); s1 = group_sum<LPE>(s1); s2 = group_sum<LPE>(s2);
@@ -188,28 +192,28 @@ bool bad_shape(long E, int H) { return E < 0 || H <= 0 || (H & 3) != 0 || (doubl
 }  // namespace
 
 extern "C" int hermnet_edge_message_fwd(const float* X, const float* R, const float* V, const float* U, long num_edges,
-                                        int hidden, const long* x_rows, const long* v_rows, float* S, float* M,
-                                        void* stream) {
+                                        int hidden, const long* x_rows, const long* v_rows, const long* r_rows, float* S,
+                                        float* M, void* stream) {
   if (bad_shape(num_edges, hidden)) return HN_ERR_BAD_ARG;
   if (num_edges == 0) return HN_OK;
   if (!X || !R || !U || !S || !M) return HN_ERR_BAD_ARG;
   EdgeMsgArgs a = {};
-  a.X = X; a.R = R; a.V = V; a.U = U; a.o0 = S; a.o1 = M; a.E = num_edges; a.H = hidden; a.xi = x_rows; a.vi = v_rows;
+  a.X = X; a.R = R; a.V = V; a.U = U; a.o0 = S; a.o1 = M; a.E = num_edges; a.H = hidden; a.xi = x_rows; a.vi = v_rows; a.ri = r_rows;
   const bool has_v = V != nullptr;
   HN_EDGE_LAUNCH(edge_msg_fwd_kernel);
 }
 
 extern "C" int hermnet_edge_message_bwd(const float* GS, const float* GM, const float* X, const float* R, const float* V,
                                         const float* U, long num_edges, int hidden, const long* x_rows,
-                                        const long* v_rows, const long* t_rows, float* gX, float* gR, float* gV,
-                                        float* gU, void* stream) {
+                                        const long* v_rows, const long* t_rows, const long* r_rows, float* gX,
+                                        float* gR, float* gV, float* gU, void* stream) {
   if (bad_shape(num_edges, hidden)) return HN_ERR_BAD_ARG;
   if (num_edges == 0) return HN_OK;
   if (!GS || !GM || !X || !R || !U || !gX || !gR || !gU || (V && !gV)) return HN_ERR_BAD_ARG;
   EdgeMsgArgs a = {};
   a.X = X; a.R = R; a.V = V; a.U = U; a.GS = GS; a.GM = GM;
   a.o0 = gX; a.o1 = gR; a.o2 = gV; a.o3 = gU; a.E = num_edges; a.H = hidden;
-  a.xi = x_rows; a.vi = v_rows; a.ti = t_rows;
+  a.xi = x_rows; a.vi = v_rows; a.ti = t_rows; a.ri = r_rows;
   const bool has_v = V != nullptr;
   HN_EDGE_LAUNCH(edge_msg_bwd_kernel);
 }
@@ -217,15 +221,16 @@ extern "C" int hermnet_edge_message_bwd(const float* GS, const float* GM, const 
 extern "C" int hermnet_edge_message_bwd2(const float* cX, const float* cR, const float* cV, const float* cU,
                                          const float* GS, const float* GM, const float* X, const float* R,
                                          const float* V, const float* U, long num_edges, int hidden,
-                                         const long* x_rows, const long* v_rows, const long* t_rows, float* dGS,
-                                         float* dGM, float* dX, float* dR, float* dV, float* dU, void* stream) {
+                                         const long* x_rows, const long* v_rows, const long* t_rows,
+                                         const long* r_rows, float* dGS, float* dGM, float* dX, float* dR, float* dV,
+                                         float* dU, void* stream) {
   if (bad_shape(num_edges, hidden)) return HN_ERR_BAD_ARG;
   if (num_edges == 0) return HN_OK;
   if (!GS || !GM || !X || !R || !U || !dGS || !dGM || !dX || !dR || !dU || (V && !dV)) return HN_ERR_BAD_ARG;
   EdgeMsgArgs a = {};
   a.X = X; a.R = R; a.V = V; a.U = U; a.GS = GS; a.GM = GM; a.cX = cX; a.cR = cR; a.cV = V ? cV : nullptr; a.cU = cU;
   a.o0 = dGS; a.o1 = dGM; a.o2 = dX; a.o3 = dR; a.o4 = dV; a.o5 = dU; a.E = num_edges; a.H = hidden;
-  a.xi = x_rows; a.vi = v_rows; a.ti = t_rows;
+  a.xi = x_rows; a.vi = v_rows; a.ti = t_rows; a.ri = r_rows;
   const bool has_v = V != nullptr;
   HN_EDGE_LAUNCH(edge_msg_bwd2_kernel);
 }

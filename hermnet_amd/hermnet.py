@@ -187,7 +187,14 @@ class HVNet(nn.Module):
             # forces wanted: the backward message kernels read the radial quantities of an edge from this table
             graph.edge_table = edge_radial_table(graph, rbf, edge.detach())
         # rmnet.py:168-172 for the optional bases only: [E,R] basis from the kernel's distances
-        data._hn_edge_embed = None if fused else self.radial_basis(edge[:, 3])
+        if fused:
+            data._hn_edge_embed = None
+        elif (train and pos.is_cuda and self.radial_basis.rbf_name == "gaussian" and H % 4 == 0 and graph.T > 0
+              and os.environ.get("HERMNET_TRAIN_KERNELS", "1") != "0" and os.environ.get("HERMNET_TRAIN_BUCKETS", "1") != "0"):
+            # train(): the basis sorted by (relation, distance bucket) and cut to the bucket's 32 centres (rmnet.BucketedBasis)
+            data._hn_edge_embed = self.radial_basis.bucketed(edge[:, 3], graph.rel_edge_bounds(), graph.T)
+        else:
+            data._hn_edge_embed = self.radial_basis(edge[:, 3])
         data.x, data.vec = x, vec
         data._hn_edge_handles = data._hn_edge_sink = data._hn_halo = None
         if fused and edge.requires_grad and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0":

@@ -145,6 +145,51 @@ class RadialBasis(nn.Module):
             rbf = self.rbf.prefactor * (ed ** self.rbf.exp1) * ((1 - ed) ** self.rbf.exp2)
         return env[:, None] * rbf
 
+    def bucketed(self, d, bounds, T):
+        """`BucketedBasis` of the edges [0, bounds[T]) (CSR order: relation t owns [bounds[t], bounds[t+1])) with
+        distances d.  Window of bucket b: centres b*20 - 5 .. b*20 + 26; an edge with floor(u/delta) - 5 = lo goes to
+        bucket (lo + 5) // 20, so the twelve centres lo .. lo + 11 around u lie inside.  One host read (group sizes)."""
+        Ek, dev = bounds[T], d.device
+        W, C = BucketedBasis.WIDTH, BucketedBasis.CHUNK
+        S = W - 12
+        off = self.rbf.offset
+        R = off.numel()
+        delta = float(off[1] - off[0]) if R > 1 else 1.0
+        nb = (R + 4) // S + 1
+        u = d[:Ek] * self.inv_cutoff
+        lo = torch.floor(u.detach() / delta).clamp(min=0, max=R + S).long() - 5
+        bucket = ((lo + 5) // S).clamp(max=nb - 1)
+        rel = torch.repeat_interleave(torch.arange(T, device=dev),
+                                      torch.tensor([bounds[t + 1] - bounds[t] for t in range(T)], device=dev))
+        key = rel * nb + bucket
+        cnt = torch.bincount(key, minlength=T * nb)
+        cnt_h = cnt.tolist()                                                                 # the host read
+        chunks = [(c + C - 1) // C for c in cnt_h]
+        nc = sum(chunks)
+        start_pad = torch.tensor([0] + chunks[:-1], device=dev).cumsum(0) * C                # first padded row of a group
+        start = torch.cumsum(cnt, 0) - cnt
+        order = torch.argsort(key, stable=True)
+        ks = key[order]
+        slot = torch.empty(Ek, dtype=torch.long, device=dev)
+        slot[order] = start_pad[ks] + torch.arange(Ek, device=dev) - start[ks]
+        src = torch.full((nc * C,), Ek, dtype=torch.long, device=dev)                        # padding rows -> the dummy entry
+        src[slot] = torch.arange(Ek, device=dev)
+        group = torch.repeat_interleave(torch.arange(T * nb, device=dev), torch.tensor(chunks, device=dev))
+        up = torch.cat([u, u.new_zeros(1)]).index_select(0, src)                              # [nc * C], differentiable
+        if isinstance(self.envelope, PolynomialEnvelope):
+            p = self.envelope.p
+            a, b, c = -(p + 1) * (p + 2) / 2, p * (p + 2), -p * (p + 1) / 2
+            env = 1 + a * up ** p + b * up ** (p + 1) + c * up ** (p + 2)
+        else:   # (evaluated at 0 beyond the cutoff: exp(+large) there would turn the masked branch's zero gradient into NaN)
+            us = torch.where(up < 1, up, torch.zeros_like(up))
+            env = torch.exp(-(us ** 2) / ((1 - us) * (1 + us)))
+        env = torch.where((up < 1) & (src < Ek), env, torch.zeros_like(up))
+        k = ((group % nb) * S - 5)[:, None] + torch.arange(W, device=dev)[None, :]           # [nc, 32] centre indices
+        mu = off[k.clamp(0, R - 1)]
+        colok = ((k >= 0) & (k < R)).to(up.dtype)
+        phi = torch.exp(self.rbf.coeff * (up.view(nc, C, 1) - mu[:, None, :]) ** 2) * (env.view(nc, C, 1) * colok[:, None, :])
+        return BucketedBasis(phi, group, slot, nb, R)
+
     def descriptor(self):
         if self.rbf_name != "gaussian":
             raise NotImplementedError("the fused kernel evaluates the Gaussian basis only; use RadialBasis.forward")
@@ -261,6 +306,35 @@ class SumRows(torch.autograd.Function):
         return GatherRows.apply(g, ctx.key), None
 
 
+class BucketedBasis(object):
+    """The Gaussian basis of the first Ek edges, SORTED by (relation of the target, distance bucket) and cut to the 32
+    centres of the edge's bucket: phi [nc, C, 32] (chunks of C rows; every (relation, bucket) group is padded to whole
+    chunks with zero rows), group [nc] = relation * nb + bucket of each chunk, slot [Ek] = row of every edge in that
+    order.  rbf_proj then is ONE batched [C,32] x [32,3H] product per layer instead of three dense [E_t,R] x [R,3H]
+    GEMMs: a quarter of the FLOPs (a Gaussian is < 2e-8 of its peak six widths away, and a 32-centre window holds
+    every centre within six widths of any distance of its bucket), still on the matrix pipe, still plain torch ops --
+    differentiable to any order."""
+
+    WIDTH, CHUNK = 32, 1024
+
+    def __init__(self, phi, group, slot, nb, num_radial):
+        self.phi, self.group, self.slot, self.nb, self.num_radial = phi, group, slot, int(nb), int(num_radial)
+
+    def project(self, w_rbf, b_rbf, scale):
+        """rbf_proj of every relation (rmnet.py:55) on the bucketed basis -> R [nc * C, 3H] in the sorted edge order;
+        `scale` [3H] multiplies the output channels."""
+        T, S = len(w_rbf), BucketedBasis.WIDTH - 12
+        wt = torch.stack([(w_rbf[t] * scale[:, None]).t() for t in range(T)])               # [T, R, 3H]
+        need = (self.nb - 1) * S + BucketedBasis.WIDTH                                       # rows the windows reach
+        wt = F.pad(wt, (0, 0, 5, max(need - 5 - wt.size(1), 0)))                             # centre k sits at row k + 5
+        win = wt.unfold(1, BucketedBasis.WIDTH, S)[:, :self.nb]                              # [T, nb, 3H, 32]
+        win = win.permute(0, 1, 3, 2).reshape(T * self.nb, BucketedBasis.WIDTH, -1)
+        bias = torch.stack([b_rbf[t] * scale for t in range(T)])                             # [T, 3H]
+        wc = win.index_select(0, self.group)
+        bc = bias.index_select(0, self.group // self.nb)
+        return torch.baddbmm(bc[:, None, :], self.phi, wc).reshape(-1, wc.size(2))
+
+
 class TallLinear(torch.autograd.Function):
     """y = a @ w.T + b for a TALL `a` [K, R] (K = the edges of a relation, ~1e5) and a small w [O, R].  The forward and
     the input gradient are ordinary GEMMs; the WEIGHT gradient g.T @ a reduces over K into an [O, R] result -- three
@@ -323,7 +397,7 @@ class EdgeMessage(torch.autograd.Function):
         S = torch.empty(E, H, dtype=X.dtype, device=X.device)
         M = torch.empty(E, 3, H, dtype=X.dtype, device=X.device)
         P = _lib.ptr
-        _lib.check(_lib.load().hermnet_edge_message_fwd(P(X), P(R), P(V), P(U), E, H, None, None, P(S), P(M), _stream()),
+        _lib.check(_lib.load().hermnet_edge_message_fwd(P(X), P(R), P(V), P(U), E, H, None, None, None, P(S), P(M), _stream()),
                    "hermnet_edge_message_fwd")
         ctx.save_for_backward(X, R, V, U)
         return S, M
@@ -350,7 +424,7 @@ class EdgeMessageGrad(torch.autograd.Function):
         gV = None if V is None else torch.empty_like(V)
         gU = torch.empty_like(U)
         P = _lib.ptr
-        _lib.check(_lib.load().hermnet_edge_message_bwd(P(GS), P(GM), P(X), P(R), P(V), P(U), E, H, None, None, None,
+        _lib.check(_lib.load().hermnet_edge_message_bwd(P(GS), P(GM), P(X), P(R), P(V), P(U), E, H, None, None, None, None,
                                                         P(gX), P(gR), P(gV), P(gU), _stream()), "hermnet_edge_message_bwd")
         ctx.save_for_backward(GS, GM, X, R, V, U)
         return gX, gR, gV, gU
@@ -368,7 +442,7 @@ class EdgeMessageGrad(torch.autograd.Function):
         dU = torch.empty_like(U)
         P = _lib.ptr
         _lib.check(_lib.load().hermnet_edge_message_bwd2(P(cX), P(cR), P(cV), P(cU), P(GS), P(GM), P(X), P(R), P(V), P(U),
-                                                         E, H, None, None, None, P(dGS), P(dGM), P(dX), P(dR), P(dV), P(dU),
+                                                         E, H, None, None, None, None, P(dGS), P(dGM), P(dX), P(dR), P(dV), P(dU),
                                                          _stream()), "hermnet_edge_message_bwd2")
         return dGS, dGM, dX, dR, dV, dU
 
@@ -390,19 +464,20 @@ class MessageAlgebra(torch.autograd.Function):
     `EdgeMessage` read their gathered operands through row indices (x_j = xh[(relation, source)], vec_j = vec[source],
     cotangents = g[target]) and the row sums follow inside the function, so no [E, 3H] copy of a gathered operand and
     no per-edge gradient ever enters the autograd graph: what two graph nodes share and the engine has to add up is
-    node-sized.  Twice differentiable through `MessageAlgebraGrad`.  keys = (targets, sources, (relation, source))."""
+    node-sized.  Twice differentiable through `MessageAlgebraGrad`.  keys = (targets, sources, (relation, source), rows
+    of R or None)."""
 
     @staticmethod
     def forward(ctx, xh, vec, R, U, keys):
         from .ops import _stream
-        k_tgt, k_all, k_xh = keys
+        k_tgt, k_all, k_xh, r_rows = keys
         xh, vec, R, U = _c(xh), _c(vec), _c(R), _c(U)
-        E, H = R.size(0), R.size(1) // 3
+        E, H = U.size(0), R.size(1) // 3
         S = torch.empty(E, H, dtype=R.dtype, device=R.device)
         M = torch.empty(E, 3, H, dtype=R.dtype, device=R.device)
         P = _lib.ptr
-        _lib.check(_lib.load().hermnet_edge_message_fwd(P(xh), P(R), P(vec), P(U), E, H, P(k_xh.idx), P(k_all.idx), P(S), P(M),
-                                                        _stream()), "hermnet_edge_message_fwd")
+        _lib.check(_lib.load().hermnet_edge_message_fwd(P(xh), P(R), P(vec), P(U), E, H, P(k_xh.idx), P(k_all.idx), P(r_rows),
+                                                        P(S), P(M), _stream()), "hermnet_edge_message_fwd")
         ctx.save_for_backward(xh, vec, R, U)
         ctx.keys = keys
         return _segsum(S, k_tgt), _segsum(M, k_tgt)
@@ -418,17 +493,19 @@ class MessageAlgebraGrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g_dx, g_dv, xh, vec, R, U, keys):
         from .ops import _stream
-        k_tgt, k_all, k_xh = keys
-        E, H = R.size(0), R.size(1) // 3
+        k_tgt, k_all, k_xh, r_rows = keys
+        E, H = U.size(0), R.size(1) // 3
         g_dx = torch.zeros(k_tgt.n_rows, H, dtype=R.dtype, device=R.device) if g_dx is None else _c(g_dx)
         g_dv = torch.zeros(k_tgt.n_rows, 3, H, dtype=R.dtype, device=R.device) if g_dv is None else _c(g_dv)
-        gX, gR = torch.empty_like(R), torch.empty_like(R)
+        gX = torch.empty(E, 3 * H, dtype=R.dtype, device=R.device)
+        # (R kept in another edge order with padding rows: rows no edge points to get no gradient)
+        gR = torch.empty_like(R) if r_rows is None else torch.zeros_like(R)
         gV = None if vec is None else torch.empty(E, 3, H, dtype=R.dtype, device=R.device)
         gU = torch.empty_like(U)
         P = _lib.ptr
         _lib.check(_lib.load().hermnet_edge_message_bwd(P(g_dx), P(g_dv), P(xh), P(R), P(vec), P(U), E, H, P(k_xh.idx),
-                                                        P(k_all.idx), P(k_tgt.idx), P(gX), P(gR), P(gV), P(gU), _stream()),
-                   "hermnet_edge_message_bwd")
+                                                        P(k_all.idx), P(k_tgt.idx), P(r_rows), P(gX), P(gR), P(gV), P(gU),
+                                                        _stream()), "hermnet_edge_message_bwd")
         ctx.save_for_backward(g_dx, g_dv, xh, vec, R, U)
         ctx.keys = keys
         return _segsum(gX, k_xh), (None if vec is None else _segsum(gV, k_all)), gR, gU
@@ -437,16 +514,18 @@ class MessageAlgebraGrad(torch.autograd.Function):
     def backward(ctx, c_xh, c_vec, cR, cU):
         from .ops import _stream
         g_dx, g_dv, xh, vec, R, U = ctx.saved_tensors
-        k_tgt, k_all, k_xh = ctx.keys
-        E, H = R.size(0), R.size(1) // 3
+        k_tgt, k_all, k_xh, r_rows = ctx.keys
+        E, H = U.size(0), R.size(1) // 3
         c_xh, c_vec, cR, cU = _c(c_xh), _c(c_vec), _c(cR), _c(cU)
         new = lambda *shape: torch.empty(*shape, dtype=R.dtype, device=R.device)
-        dGS, dGM, dX, dR, dU = new(E, H), new(E, 3, H), new(E, 3 * H), new(E, 3 * H), new(E, 3)
+        dGS, dGM, dX, dU = new(E, H), new(E, 3, H), new(E, 3 * H), new(E, 3)
+        dR = torch.empty_like(R) if r_rows is None else torch.zeros_like(R)
         dV = None if vec is None else new(E, 3, H)
         P = _lib.ptr
         _lib.check(_lib.load().hermnet_edge_message_bwd2(P(c_xh), P(cR), P(c_vec), P(cU), P(g_dx), P(g_dv), P(xh), P(R), P(vec),
-                                                         P(U), E, H, P(k_xh.idx), P(k_all.idx), P(k_tgt.idx), P(dGS), P(dGM),
-                                                         P(dX), P(dR), P(dV), P(dU), _stream()), "hermnet_edge_message_bwd2")
+                                                         P(U), E, H, P(k_xh.idx), P(k_all.idx), P(k_tgt.idx), P(r_rows), P(dGS),
+                                                         P(dGM), P(dX), P(dR), P(dV), P(dU), _stream()),
+                   "hermnet_edge_message_bwd2")
         return (_segsum(dGS, k_tgt), _segsum(dGM, k_tgt), _segsum(dX, k_xh), (None if vec is None else _segsum(dV, k_all)),
                 dR, dU, None)
 
@@ -508,21 +587,26 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     sc = x.new_ones(3 * H)
     sc[H:2 * H] = 1 / math.sqrt(3.0 * H)
     sc[2 * H:] = 1 / math.sqrt(H)
-    # (split, not slices: the backward of a split is ONE cat, a slice's zero-fills the whole [E,R] gradient)
-    emb = edge_embed.split([bounds[t + 1] - bounds[t] for t in range(T)] + [edge_embed.size(0) - Ek])
-    parts = []
-    for t in range(T):
-        e0, e1 = bounds[t], bounds[t + 1]
-        if e1 > e0:
-            parts.append(TallLinear.apply(emb[t], w_rbf[t] * sc[:, None], b_rbf[t] * sc))   # rbf_proj, rmnet.py:55
     dx = x.new_zeros(N, H)
     dv = x.new_zeros(N, 3, H)
+    parts = []
+    if isinstance(edge_embed, BucketedBasis):
+        if Ek > 0:     # rbf_proj (rmnet.py:55) as one batched product on the bucketed basis; R stays in its sorted order
+            R = edge_embed.project(w_rbf, b_rbf, sc)
+            dx, dv = MessageAlgebra.apply(xh.reshape(T * N, 3 * H), vec, R, edge[:Ek, :3], (k_tgt, k_all, k_xh, edge_embed.slot))
+    else:
+        # (split, not slices: the backward of a split is ONE cat, a slice's zero-fills the whole [E,R] gradient)
+        emb = edge_embed.split([bounds[t + 1] - bounds[t] for t in range(T)] + [edge_embed.size(0) - Ek])
+        for t in range(T):
+            e0, e1 = bounds[t], bounds[t + 1]
+            if e1 > e0:
+                parts.append(TallLinear.apply(emb[t], w_rbf[t] * sc[:, None], b_rbf[t] * sc))   # rbf_proj, rmnet.py:55
     if parts:
         R = parts[0] if len(parts) == 1 else torch.cat(parts, 0)                   # [Ek, 3H]
         if _train_kernels(R):
             # gather x_j / vec_j (rmnet.py:58), x_j * rbfh and the vector message (:61-66), aggregation (:69-73): one
             # twice-differentiable function with node-level inputs and outputs (csrc/train_kernels.hip)
-            dx, dv = MessageAlgebra.apply(xh.reshape(T * N, 3 * H), vec, R, edge[:Ek, :3], (k_tgt, k_all, k_xh))
+            dx, dv = MessageAlgebra.apply(xh.reshape(T * N, 3 * H), vec, R, edge[:Ek, :3], (k_tgt, k_all, k_xh, None))
         else:
             X = GatherRows.apply(xh.reshape(T * N, 3 * H), k_xh)                   # x_j of every edge, rmnet.py:58
             V = None if vec is None else GatherRows.apply(vec, k_all)

@@ -383,17 +383,21 @@ int hermnet_pair_mean(int mode, const float* x_in, const float* vec_in, float* x
  *          three are per-edge products and channel sums (deterministic, no atomics).
  *   x_rows / v_rows / t_rows [E] int64 (each may be NULL = row e): X and cX are read at row x_rows[e] of their arrays
  *   (x_j = xh[(relation, source)] without a gathered copy), V and cV at v_rows[e] (vec[source]), GS and GM at t_rows[e]
- *   (the cotangents of dx, dvec of the edge's target); every OUTPUT is per edge -- the caller sums gX / gV / dGS / ...
- *   into rows with hermnet_segment_sum. */
+ *   (the cotangents of dx, dvec of the edge's target); R and cR at r_rows[e], where gR / dR are written as well (R kept
+ *   in another edge order; rows no edge points to are left untouched); every other OUTPUT is per edge -- the caller
+ *   sums gX / gV / dGS / ... into rows with hermnet_segment_sum. */
 int hermnet_edge_message_fwd(const float* X, const float* R, const float* V, const float* U, long num_edges, int hidden,
-                             const long* x_rows, const long* v_rows, float* S, float* M, void* stream);
+                             const long* x_rows, const long* v_rows, const long* r_rows, float* S, float* M,
+                             void* stream);
 int hermnet_edge_message_bwd(const float* GS, const float* GM, const float* X, const float* R, const float* V,
                              const float* U, long num_edges, int hidden, const long* x_rows, const long* v_rows,
-                             const long* t_rows, float* gX, float* gR, float* gV, float* gU, void* stream);
+                             const long* t_rows, const long* r_rows, float* gX, float* gR, float* gV, float* gU,
+                             void* stream);
 int hermnet_edge_message_bwd2(const float* cX, const float* cR, const float* cV, const float* cU, const float* GS,
                               const float* GM, const float* X, const float* R, const float* V, const float* U,
                               long num_edges, int hidden, const long* x_rows, const long* v_rows, const long* t_rows,
-                              float* dGS, float* dGM, float* dX, float* dR, float* dV, float* dU, void* stream);
+                              const long* r_rows, float* dGS, float* dGM, float* dX, float* dR, float* dV, float* dU,
+                              void* stream);
 
 /* Segmented row sum with an optional gather (the adjoint of a row gather; training path, ABI v6):
  * out[r] = sum over q in [rowptr[r], rowptr[r+1]) of x[perm ? perm[q] : q], rows of `width` floats (a multiple of 4),
