@@ -280,7 +280,16 @@ class HeteroTriadicConv(HeteroVertexConv):
         data = super().forward(data)                   # (x, vec) in target rows [T * P * B, ...]
         g = data._hn_graph
         P_, B_, Te = g.triadic_pairs, g.block, g.T // g.triadic_pairs
-        data.x, data.vec = PairMean.apply(data.x, data.vec, Te, P_, B_, g.num_src)
+        if data.get("_hn_edge_embed") is not None:     # train(): plain torch ops, differentiable to any order
+            H = data.x.size(1)
+            xo = data.x.view(Te, P_, B_, H).mean(1).reshape(Te * B_, H)
+            vo = data.vec.view(Te, P_, B_, 3, H).mean(1).reshape(Te * B_, 3, H)
+            if g.num_src > Te * B_:                    # atoms of elements outside `elems`: zero rows (hermnet.py:51)
+                xo = torch.cat([xo, xo.new_zeros(g.num_src - Te * B_, H)], 0)
+                vo = torch.cat([vo, vo.new_zeros(g.num_src - Te * B_, 3, H)], 0)
+            data.x, data.vec = xo, vo
+        else:
+            data.x, data.vec = PairMean.apply(data.x, data.vec, Te, P_, B_, g.num_src)
         return data
 
 
@@ -319,7 +328,7 @@ class HTNet(HVNet):
     raises NotImplementedError (`hermnet.py:155-157`); this is the BUILD-DEFINED model specified in DESIGN.md
     ("HTNet"), with HVNet's constructor and `forward(data)`: one PaiNNModule per (centre element, unordered pair of
     neighbour elements), `hermconvs.{l}.mods.{c}_{p}-{q}.*` in the state_dict.  With a single element it IS HVNet.
-    Energy / force evaluation (eval()) only; parity is checked against `oracle.htnet_energy` ("parity unpinned")."""
+    Parity is checked against `oracle.htnet_energy` ("parity unpinned")."""
 
     def __init__(self, elems: Union[str, List[str]], rc: float = 5., intensive: bool = False, num_layers: int = 5,
                  hidden_channels: int = 512, num_rbf: int = 128, rbf={"name": "gaussian"},
@@ -339,8 +348,8 @@ class HTNet(HVNet):
                                              rel_active=None if shard is None else shard.rel_active_triadic(zl))
 
     def forward(self, data):
-        if (self.training or self.eval_param_grads) and torch.is_grad_enabled():
-            raise NotImplementedError("HTNet: energy / force evaluation (eval()) only")
+        """eval(): the fused kernels (Gaussian basis).  train(): the differentiable path of HVNet on the triadic graph --
+        every parameter of the 18 (T * P) PaiNNModules per layer gets its gradient, forces included in the loss."""
         if not self.radial_basis.fused:
             raise NotImplementedError("HTNet runs on the fused kernels: Gaussian radial basis")
         return super().forward(data)

@@ -542,9 +542,11 @@ def edge_message(X, R, V, U):
     return _edge_message_torch(X, R, V, U)
 
 
-def _row_keys(graph, T, N, bounds):
-    """(key of the targets of the first Ek CSR edges, key of their sources, key of their (relation, source) rows of
-    xh.view(T N, 3H)) for `message_scatter_generic`, from the graph's CSR / CSC orders; built once per graph."""
+def _row_keys(graph, T, Nt, Ns, bounds):
+    """(key of the targets of the first Ek CSR edges [Nt target rows], key of their sources [Ns source rows], key of
+    their (relation, source) rows of xh.view(T Ns, 3H), key of the residual rows or None) for `message_scatter_generic`,
+    from the graph's CSR / CSC orders; built once per graph.  Nt = Ns for HVNet; HTNet has one target row per atom and
+    pair relation and reads the residual from the atom's own source row (`graph.res_row`)."""
     keys = getattr(graph, "_row_keys", None)
     if keys is not None:
         return keys
@@ -553,19 +555,23 @@ def _row_keys(graph, T, N, bounds):
     Ek = bounds[T]
     nk = int(graph.type_rowptr_host[-1])
     lengths = rowptr[1:] - rowptr[:-1]
-    lengths = torch.cat([lengths[:nk], lengths.new_zeros(N - nk)])           # edges into unknown-element rows: not summed
-    tgt_row = torch.repeat_interleave(torch.arange(N, device=dev), lengths)
-    k_tgt = _RowKey(tgt_row, None, lengths, N)
+    lengths = torch.cat([lengths[:nk], lengths.new_zeros(Nt - nk)])          # edges into unknown-element rows: not summed
+    tgt_row = torch.repeat_interleave(torch.arange(Nt, device=dev), lengths)
+    k_tgt = _RowKey(tgt_row, None, lengths, Nt)
     src = graph.csr_src.long()
     crp, cpos = graph.csc_rowptr.long(), graph.csc_pos.long()               # groups (relation, source row) over CSR positions
     # all relations at once: sorted by (source row) = the T groups of a row merged; built by one stable sort
     order = torch.argsort(src[:Ek], stable=True)
-    k_all = _RowKey(src[:Ek], order, torch.bincount(src[:Ek], minlength=N), N)
-    # rows of xh.view(T * N, 3H): (relation of the edge's target, source row) -- the CSC groups themselves
+    k_all = _RowKey(src[:Ek], order, torch.bincount(src[:Ek], minlength=Ns), Ns)
+    # rows of xh.view(T * Ns, 3H): (relation of the edge's target, source row) -- the CSC groups themselves
     rel_of_edge = torch.repeat_interleave(torch.arange(T, device=dev),
                                           torch.tensor([bounds[t + 1] - bounds[t] for t in range(T)], device=dev))
-    k_xh = _RowKey(rel_of_edge * N + src[:Ek], cpos[:Ek], crp[1:T * N + 1] - crp[:T * N], T * N)
-    graph._row_keys = (k_tgt, k_all, k_xh)
+    k_xh = _RowKey(rel_of_edge * Ns + src[:Ek], cpos[:Ek], crp[1:T * Ns + 1] - crp[:T * Ns], T * Ns)
+    k_res = None
+    if graph.res_row is not None:
+        res = graph.res_row.long()
+        k_res = _RowKey(res, torch.argsort(res, stable=True), torch.bincount(res, minlength=Ns), Ns)
+    graph._row_keys = (k_tgt, k_all, k_xh, k_res)
     return graph._row_keys
 
 
@@ -574,14 +580,15 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     [E,R] (CSR order): library GEMM per relation + gather / segmented-sum device ops, differentiable to any order by
     PyTorch autograd.  Path of train() mode (parameter gradients, create_graph=True) and of the optional
     radial bases."""
-    T, N, H3 = xh.shape
+    T, Ns, H3 = xh.shape                                       # Ns source rows (rows of x / vec / xh[t])
     H = H3 // 3
+    N = graph.N                                                # target rows (= Ns for HVNet; HTNet: one per atom and pair)
     rel_row = torch.bucketize(torch.arange(N, device=x.device), graph.type_rowptr.long()[1:], right=True)
     # rows are relation-ordered and CSR is row-ordered: the edges of relation t are ONE contiguous CSR range
     # (no per-relation masks or gathers of the edge arrays)
     bounds = graph.rel_edge_bounds()
     Ek = bounds[T]                                             # edges whose target has a known element
-    k_tgt, k_all, k_xh = _row_keys(graph, T, N, bounds)
+    k_tgt, k_all, k_xh, k_res = _row_keys(graph, T, N, Ns, bounds)
     # the constant factors of the vector message (1/sqrt(3H) on the `a` part, 1/sqrt(H) on `b`, rmnet.py:64-66) ride on
     # the [3H, R] projection weights, not on per-edge tensors
     sc = x.new_ones(3 * H)
@@ -593,7 +600,7 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     if isinstance(edge_embed, BucketedBasis):
         if Ek > 0:     # rbf_proj (rmnet.py:55) as one batched product on the bucketed basis; R stays in its sorted order
             R = edge_embed.project(w_rbf, b_rbf, sc)
-            dx, dv = MessageAlgebra.apply(xh.reshape(T * N, 3 * H), vec, R, edge[:Ek, :3], (k_tgt, k_all, k_xh, edge_embed.slot))
+            dx, dv = MessageAlgebra.apply(xh.reshape(T * Ns, 3 * H), vec, R, edge[:Ek, :3], (k_tgt, k_all, k_xh, edge_embed.slot))
     else:
         # (split, not slices: the backward of a split is ONE cat, a slice's zero-fills the whole [E,R] gradient)
         emb = edge_embed.split([bounds[t + 1] - bounds[t] for t in range(T)] + [edge_embed.size(0) - Ek])
@@ -606,16 +613,19 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
         if _train_kernels(R):
             # gather x_j / vec_j (rmnet.py:58), x_j * rbfh and the vector message (:61-66), aggregation (:69-73): one
             # twice-differentiable function with node-level inputs and outputs (csrc/train_kernels.hip)
-            dx, dv = MessageAlgebra.apply(xh.reshape(T * N, 3 * H), vec, R, edge[:Ek, :3], (k_tgt, k_all, k_xh, None))
+            dx, dv = MessageAlgebra.apply(xh.reshape(T * Ns, 3 * H), vec, R, edge[:Ek, :3], (k_tgt, k_all, k_xh, None))
         else:
-            X = GatherRows.apply(xh.reshape(T * N, 3 * H), k_xh)                   # x_j of every edge, rmnet.py:58
+            X = GatherRows.apply(xh.reshape(T * Ns, 3 * H), k_xh)                  # x_j of every edge, rmnet.py:58
             V = None if vec is None else GatherRows.apply(vec, k_all)
             S, M = edge_message(X, R, V, edge[:Ek, :3])
             dx = SumRows.apply(S, k_tgt)
             dv = SumRows.apply(M, k_tgt)
     known = (rel_row < T).to(x.dtype)
-    x1 = (x + dx) * (1 / math.sqrt(2.0)) * known[:, None]
-    vec1 = ((vec if vec is not None else 0) + dv) * known[:, None, None]
+    # the residual (rmnet.py:24-26) reads the target atom's own row: the same row for HVNet, `res_row` for HTNet
+    xr = x if k_res is None else GatherRows.apply(x, k_res)
+    vr = 0 if vec is None else (vec if k_res is None else GatherRows.apply(vec, k_res))
+    x1 = (xr + dx) * (1 / math.sqrt(2.0)) * known[:, None]
+    vec1 = (vr + dv) * known[:, None, None]
     return x1, vec1
 
 
@@ -623,7 +633,7 @@ def _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed):
     """`relational_layer` for the uniform row layout with every per-relation Linear run as ONE batched GEMM over
     the [T, block, .] view of the rows (stacked parameters; gradients flow back through the stacking).  Same
     arithmetic as the per-relation loop, a third of the kernel launches: the differentiable path is launch-bound."""
-    T, N, H = len(mlist), x.size(0), x.size(1)
+    T, N, H = len(mlist), graph.N, x.size(1)           # N target rows (x / vec hold graph.num_src source rows for HTNet)
     B, nk = graph.block, graph.type_rowptr_host[-1]
     ml = [m.message_layer for m in mlist]
     ul = [m.update_layer for m in mlist]

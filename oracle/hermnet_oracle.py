@@ -318,6 +318,24 @@ def energy_and_forces(sd, elems, data, **kw):
     return e.detach(), f
 
 
+def htnet_training_loss_and_grads(sd, elems, data, y, forces, gamma=0.8, **kw):
+    """`training_loss_and_grads` for the build-defined HTNet (same loss, `example/dist_train.py:86-99`): the checker of
+    HTNet's train() mode.  Parity unpinned, like everything about HTNet: the reference's class is a stub."""
+    buffers = ("radial_basis.rbf.offset",)
+    p = {k: (v.detach().clone().requires_grad_(True) if (k not in buffers and v.is_floating_point()) else v)
+         for k, v in sd.items()}
+    pos = data.pos.detach().clone().requires_grad_(True)
+    e = htnet_energy(p, elems, pos, data.atomic_number, data.edge_index, data.batch,
+                     data.get("edge_shift"), data.get("cell"), **kw)
+    e_loss = F.mse_loss(e, y)
+    f = -torch.autograd.grad(e.sum(), pos, create_graph=True)[0]
+    f_loss = F.mse_loss(f, forces)
+    loss = (1 - gamma) * e_loss + gamma * f_loss
+    keys = [k for k, v in p.items() if v.requires_grad]
+    grads = torch.autograd.grad(loss, [p[k] for k in keys], allow_unused=True)
+    return loss.detach(), e_loss.detach(), f_loss.detach(), dict(zip(keys, grads))
+
+
 def training_loss_and_grads(sd, elems, data, y, forces, gamma=0.8, **kw):
     """One optimisation step's loss and parameter gradients, `example/dist_train.py:86-99`:
     e_loss = MSE(E, y), F = -d(sum E)/d pos with create_graph=True, f_loss = MSE(F, forces),

@@ -152,6 +152,49 @@ def test_hip_path_matches_oracle(name, elems, kw):
     assert rel_err(e.cpu(), e_ref) < 1e-5 and rel_err(f.cpu(), f_ref) < 1e-5
 
 
+def _htnet_training_check(name, elems, kw, device, monkeypatch=None):
+    """One training step of `example/dist_train.py:86-99` (energy + force loss, create_graph=True, backward to every
+    parameter) on HTNet in train() mode vs autograd through the oracle."""
+    from test_training import training_step, assert_grads_close
+    g = Golden(name)
+    model, sd = _model(elems, kw)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    model = model.to(device).train()
+    d = g.data()
+    gen = torch.Generator().manual_seed(11)
+    e0, _ = orc.htnet_energy_and_forces(sd, elems, d, **kw)
+    y = e0 + 0.5 * torch.randn(e0.numel(), generator=gen)
+    ftgt = 0.5 * torch.randn(d.pos.shape, generator=gen)
+    lo, leo, lfo, og = orc.htnet_training_loss_and_grads(sd, elems, d, y, ftgt, 0.8, **kw)
+    l, le, lf = training_step(model, g.data().to(device), y.to(device), ftgt.to(device), 0.8)
+    scale = max(1.0, float(e0.abs().max())) * max(1.0, float(lo))
+    assert abs(float(l) - float(lo)) < 2e-5 * scale and abs(float(lf) - float(lfo)) < 2e-5 * max(1.0, float(lfo))
+    # relations without an edge are skipped (hermnet.py:56-57): their modules get no gradient on either side
+    want = {k: v for k, v in og.items() if v is not None}
+    got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None and k in want}
+    extra = [k for k, p in model.named_parameters() if p.grad is not None and k not in want and float(p.grad.abs().max()) > 0]
+    assert not extra, extra
+    assert_grads_close(got, want)
+
+
+@pytest.mark.parametrize("name,elems", [("alloy108", ["Al", "Ni", "Cu"]), ("mol16", ["H", "C", "O"])])
+def test_train_mode_parameter_gradients_match_oracle_cpu(name, elems, monkeypatch):
+    """HTNet.train(): the differentiable path on the triadic graph (two row spaces, residual through `res_row`, mean over
+    a centre's pair relations), host tensors; every parameter gradient against the oracle's autograd."""
+    import hermnet_amd.hermnet as hmod
+    monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
+    _htnet_training_check(name, elems, KW, torch.device("cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,elems,kw", [("alloy108", ["Al", "Ni", "Cu"], KW),
+                                           ("mol16", ["H", "C", "O"], dict(rc=5.0, num_layers=3, hidden_channels=128, num_rbf=128))])
+def test_train_mode_parameter_gradients_match_oracle_gpu(name, elems, kw):
+    """The same step on the GPU: training kernels (csrc/train_kernels.hip), bucketed basis, native triadic build."""
+    _htnet_training_check(name, elems, kw, _dev())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["alloy108", "mol16", "c1_si64", "alloy10k", "molecules64"])
 def test_native_triadic_build_is_the_torch_build(case, monkeypatch):
