@@ -29,7 +29,7 @@ ts = []
 for _ in range(5):
     t0 = time.perf_counter(); step(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 print("training step (forward + create_graph force pass + backward, no optimiser): median %.1f ms, min %.1f ms" % (sorted(ts)[2] * 1e3, min(ts) * 1e3))
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step(); torch.cuda.synchronize()
 rows = [(ev.device_time_total, ev.count, ev.key) for ev in prof.key_averages() if ev.device_time_total > 0 and ev.key.startswith("aten::")]
 for t, c, k in sorted(rows, reverse=True)[:30]:
@@ -44,3 +44,12 @@ tot = sum(v[1] for v in kern.values())
 print("device kernels: %.1f ms in %d launches" % (tot / 1e3, sum(v[0] for v in kern.values())))
 for name, (n, t) in sorted(kern.items(), key=lambda kv: -kv[1][1])[:60]:
     print("%9.1f us  x%4d  %s" % (t, n, name))
+byshape = collections.defaultdict(lambda: [0, 0.0])
+for ev in prof.events():
+    if ev.device_time_total > 0 and ev.name.startswith("aten::") and not any((c.name or "").startswith("aten::") and c.device_time_total > 0 for c in (ev.cpu_children or [])):
+        k = (ev.name, str([tuple(s_) for s_ in (ev.input_shapes or []) if s_][:2]))
+        byshape[k][0] += 1
+        byshape[k][1] += ev.device_time_total
+print("leaf aten ops by input shapes:")
+for (name, shp), (n, t) in sorted(byshape.items(), key=lambda kv: -kv[1][1])[:45]:
+    print("%9.1f us  x%4d  %-28s %s" % (t, n, name, shp))
