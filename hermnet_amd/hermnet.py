@@ -191,7 +191,7 @@ class HVNet(nn.Module):
             data._hn_edge_embed = None
         elif (train and pos.is_cuda and self.radial_basis.rbf_name == "gaussian" and H % 4 == 0 and graph.T > 0
               and os.environ.get("HERMNET_TRAIN_KERNELS", "1") != "0" and os.environ.get("HERMNET_TRAIN_BUCKETS", "1") != "0"):
-            # train(): the basis sorted by (relation, distance bucket) and cut to the bucket's 32 centres (rmnet.BucketedBasis)
+            # train(): the basis sorted by (relation, distance bucket) and cut to the bucket's 32 centres (trainops.BucketedBasis)
             data._hn_edge_embed = self.radial_basis.bucketed(edge[:, 3], graph.rel_edge_bounds(), graph.T)
         else:
             data._hn_edge_embed = self.radial_basis(edge[:, 3])

@@ -55,7 +55,7 @@ class RelationalGraph(object):
         self._cstruct = None
         self._rel_bounds = None
         self._rowptr_c = None      # type_rowptr_host as a ctypes int array (nodeops._rowptr_host)
-        self._row_keys = None      # gather / segmented-sum keys of the differentiable path (rmnet._row_keys)
+        self._row_keys = None      # gather / segmented-sum keys of the differentiable path (trainops._row_keys)
         self.edge_table = None     # [E+1,32] per-edge radial records of the current step, CSC order (set by HVNet.forward)
         self.num_src = 0           # separate source-row space (HTNet): rows of xh / vec; 0 = same rows as the targets
         self.res_row = None        # [N] int32 source row feeding the residual of each target row, or None

@@ -328,7 +328,7 @@ def test_edge_message_kernels_match_autograd_to_second_order(E, H, has_v):
     """csrc/train_kernels.hip (the training step's per-edge message algebra: forward, backward, backward of the backward)
     vs PyTorch autograd on the torch expression of the same map in float64: outputs, first-order gradients taken with
     create_graph=True, and the gradients of a functional of those w.r.t. every input AND the first cotangents."""
-    from hermnet_amd import rmnet
+    from hermnet_amd import rmnet, trainops
     dev = _dev()
     gen = torch.Generator().manual_seed(E + H)
     rnd = lambda *s_: torch.randn(*s_, generator=gen)
@@ -350,8 +350,8 @@ def test_edge_message_kernels_match_autograd_to_second_order(E, H, has_v):
         out.update({"d" + k: g for k, g in zip(leaves, second)})
         return {k: (None if v is None else v.detach().double().cpu()) for k, v in out.items()}
 
-    got = run(rmnet.EdgeMessage.apply, dev, torch.float32)
-    ref = run(rmnet._edge_message_torch, torch.device("cpu"), torch.float64)
+    got = run(trainops.EdgeMessage.apply, dev, torch.float32)
+    ref = run(trainops._edge_message_torch, torch.device("cpu"), torch.float64)
     assert set(got) == set(ref)
     for k in ref:
         assert (got[k] is None) == (ref[k] is None), k
@@ -361,11 +361,11 @@ def test_edge_message_kernels_match_autograd_to_second_order(E, H, has_v):
 
 @pytest.mark.parametrize("E,H,R,T,env", [(6000, 128, 128, 3, "polynomial"), (900, 64, 50, 2, "polynomial"), (700, 32, 20, 1, "exponential")])
 def test_bucketed_basis_projection_matches_dense_to_second_order(E, H, R, T, env):
-    """`rmnet.BucketedBasis` (edges sorted by (relation, distance bucket), 32-centre windows, one batched product) vs the
+    """`trainops.BucketedBasis` (edges sorted by (relation, distance bucket), 32-centre windows, one batched product) vs the
     dense Gaussian basis + nn.Linear per relation in float64: values in the edges' own order, first-order gradients
     w.r.t. distances, weights and biases with create_graph=True, and the gradients of a functional of those.
     Distances run past the cutoff and to both ends of the centre range."""
-    from hermnet_amd import rmnet
+    from hermnet_amd import rmnet, trainops
     dev = _dev()
     gen = torch.Generator().manual_seed(E + R)
     rc = 5.0
@@ -413,9 +413,9 @@ def test_bucketed_basis_projection_matches_dense_to_second_order(E, H, R, T, env
 
 @pytest.mark.parametrize("E,N,T,H,has_v", [(4000, 300, 3, 128, True), (900, 77, 2, 64, False), (500, 40, 1, 100, True)])
 def test_message_algebra_node_level_matches_autograd_to_second_order(E, N, T, H, has_v):
-    """`rmnet.MessageAlgebra` (gathers through row indices inside the edge kernels, row sums inside the function:
+    """`trainops.MessageAlgebra` (gathers through row indices inside the edge kernels, row sums inside the function:
     node-level inputs and outputs) vs gather -> torch expression -> index_add in float64 autograd, to second order."""
-    from hermnet_amd import rmnet
+    from hermnet_amd import rmnet, trainops
     dev = _dev()
     gen = torch.Generator().manual_seed(E + N)
     rnd = lambda *s_: torch.randn(*s_, generator=gen)
@@ -426,7 +426,7 @@ def test_message_algebra_node_level_matches_autograd_to_second_order(E, N, T, H,
     xrow = rel * N + src
 
     def keys(device):
-        mk = lambda idx, perm, n: rmnet._RowKey(idx.to(device), None if perm is None else perm.to(device),
+        mk = lambda idx, perm, n: trainops._RowKey(idx.to(device), None if perm is None else perm.to(device),
                                                 torch.bincount(idx, minlength=n).to(device), n)
         return (mk(tgt, None, N), mk(src, torch.argsort(src, stable=True), N), mk(xrow, torch.argsort(xrow, stable=True), T * N),
                 None)
@@ -438,11 +438,11 @@ def test_message_algebra_node_level_matches_autograd_to_second_order(E, N, T, H,
     def run(kernels, device, dtype):
         t = {k: (None if v is None else v.to(device=device, dtype=dtype).requires_grad_(True)) for k, v in base.items()}
         if kernels:
-            dx, dv = rmnet.MessageAlgebra.apply(t["xh"], t["vec"], t["R"], t["U"], keys(device))
+            dx, dv = trainops.MessageAlgebra.apply(t["xh"], t["vec"], t["R"], t["U"], keys(device))
         else:
             X = t["xh"][xrow.to(device)]
             V = None if t["vec"] is None else t["vec"][src.to(device)]
-            S, M = rmnet._edge_message_torch(X, t["R"], V, t["U"])
+            S, M = trainops._edge_message_torch(X, t["R"], V, t["U"])
             dx = torch.zeros(N, H, dtype=dtype, device=device).index_add(0, tgt.to(device), S)
             dv = torch.zeros(N, 3, H, dtype=dtype, device=device).index_add(0, tgt.to(device), M)
         L1 = (dx * t["wx"]).sum() + (dv * t["wv"]).sum()
@@ -467,9 +467,9 @@ def test_message_algebra_node_level_matches_autograd_to_second_order(E, N, T, H,
 @pytest.mark.parametrize("K,n_rows,shape", [(5000, 700, (128,)), (5000, 700, (3, 128)), (333, 50, (100,)), (40, 64, (4,)),
                                             (2000, 10, (3, 512))])
 def test_segment_sum_kernel_and_its_adjoint_pair(K, n_rows, shape):
-    """`hermnet_segment_sum` behind `rmnet.SumRows` (rows gathered inside the sum, list order) vs index_add in float64,
+    """`hermnet_segment_sum` behind `trainops.SumRows` (rows gathered inside the sum, list order) vs index_add in float64,
     sorted and permuted assignments, empty rows; and `GatherRows` / `SumRows` differentiate into each other."""
-    from hermnet_amd import rmnet
+    from hermnet_amd import rmnet, trainops
     dev = _dev()
     gen = torch.Generator().manual_seed(K)
     idx = torch.randint(0, n_rows, (K,), generator=gen)
@@ -482,15 +482,15 @@ def test_segment_sum_kernel_and_its_adjoint_pair(K, n_rows, shape):
             idx_, x_, perm = idx[order], x[order], None
         else:
             idx_, x_, perm = idx, x, torch.argsort(idx, stable=True).to(dev)
-        key = rmnet._RowKey(idx_.to(dev), perm, torch.bincount(idx_, minlength=n_rows).to(dev), n_rows)
+        key = trainops._RowKey(idx_.to(dev), perm, torch.bincount(idx_, minlength=n_rows).to(dev), n_rows)
         xd = x_.to(dev).requires_grad_(True)
-        out = rmnet.SumRows.apply(xd, key)
+        out = trainops.SumRows.apply(xd, key)
         assert rel_err(out.detach().cpu().double(), want) < 1e-6
         w = torch.randn(n_rows, *shape, generator=gen).to(dev)
         g, = torch.autograd.grad((out * w).sum(), xd, create_graph=True)
         assert torch.equal(g, w.index_select(0, idx_.to(dev)))                       # the adjoint: a gather
         w2 = torch.randn(K, *shape, generator=gen).to(dev)
-        back, = torch.autograd.grad((rmnet.GatherRows.apply(w.clone().requires_grad_(True), key) * w2).sum(), xd, allow_unused=True)
+        back, = torch.autograd.grad((trainops.GatherRows.apply(w.clone().requires_grad_(True), key) * w2).sum(), xd, allow_unused=True)
         assert back is None
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Weight-gradient product of the training path's rbf_proj (g^T a: [3H, K] x [K, R], K ~ 1e5 edges of a relation):
-library GEMM vs batched K-chunks + sum (rmnet.TallLinear), chunk sizes.  python tools/tall_gemm_bench.py"""
+library GEMM vs batched K-chunks + sum (trainops.TallLinear), chunk sizes.  python tools/tall_gemm_bench.py"""
 import time
 import torch
 dev = torch.device("cuda")
