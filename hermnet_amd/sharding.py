@@ -580,6 +580,7 @@ class SlabStepper(object):
         self.reference_compat = reference_compat
         self.plan = None
         self.replans = 0
+        self._cell_key = None
 
     def _replan(self, pos):
         self.plan = plan_slab(pos, self.z, self.cell, self.rc, self.rank, self.world, axis=self.axis, group=self.group,
@@ -587,6 +588,13 @@ class SlabStepper(object):
         self.replans += 1
 
     def __call__(self, pos):
+        # (a cell that was replaced or edited in place -- NPT -- moves the slab bounds: plan again)
+        cell_key = None if self.cell is None else (self.cell, self.cell._version)
+        if self.plan is not None and (cell_key is None) != (self._cell_key is None):
+            self.plan = None
+        if self.plan is not None and cell_key is not None and (cell_key[0] is not self._cell_key[0] or cell_key[1] != self._cell_key[1]):
+            self.plan = None
+        self._cell_key = cell_key
         if self.plan is None or self.plan.pos_ref.shape != pos.shape:
             self._replan(pos)
             return slab_data(self.plan, pos, self.reference_compat), self.plan
