@@ -274,9 +274,13 @@ def _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed):
     g, b = st(m.x_layernorm.weight for m in ml), st(m.x_layernorm.bias for m in ml)                 # [T,H]
     w1, b1 = st(m.x_proj[0].weight for m in ml), st(m.x_proj[0].bias for m in ml)                   # [T,H,H], [T,H]
     w2, b2 = st(m.x_proj[2].weight for m in ml), st(m.x_proj[2].bias for m in ml)                   # [T,3H,H], [T,3H]
-    xn = n.unsqueeze(0) * g[:, None, :] + b[:, None, :]                                              # [T,N,H]
-    h = torch.baddbmm(b1[:, None, :], xn, w1.transpose(1, 2))
-    xh = torch.baddbmm(b2[:, None, :], F.silu(h) * ml[0].x_proj[1].scale_factor, w2.transpose(1, 2))   # [T,N,3H]
+    # the LayerNorm affine of relation t folds into its first Linear (W1 diag(g), b1 + W1 b: [H,H]-sized ops instead of
+    # [T,N,H]-sized ones in every order of differentiation), and the T first Linears become ONE [N,H] x [H,T H] product
+    w1f = (w1 * g[:, None, :]).reshape(T * H, H)
+    b1f = (b1 + torch.bmm(w1, b[:, :, None]).squeeze(2)).reshape(T * H)
+    h = torch.addmm(b1f, n, w1f.t()).view(-1, T, H).transpose(0, 1)                                   # [T,N,H]
+    # (ScaledSiLU's constant factor rides on the following weight, not on the [T,N,H] activations)
+    xh = torch.baddbmm(b2[:, None, :], F.silu(h), (w2 * ml[0].x_proj[1].scale_factor).transpose(1, 2))  # [T,N,3H]
     x1, vec1 = message_scatter_generic(xh, vec, x, edge, edge_embed, [m.rbf_proj.weight for m in ml],
                                        [m.rbf_proj.bias for m in ml], graph)
     # --- PaiNNUpdate on the rows of each relation (rmnet.py:94-107), blocks of B rows
@@ -289,7 +293,7 @@ def _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed):
     vdot = (v1 * v2).sum(dim=2) * ul[0].inv_sqrt_h
     xin = torch.cat([xt, torch.sqrt((v2 ** 2).sum(dim=2) + 1e-8)], dim=-1)                           # [T,B,2H]
     h2 = torch.baddbmm(bx0[:, None, :], xin, wx0.transpose(1, 2))
-    q = torch.baddbmm(bx2[:, None, :], F.silu(h2) * ul[0].xvec_proj[1].scale_factor, wx2.transpose(1, 2))
+    q = torch.baddbmm(bx2[:, None, :], F.silu(h2), (wx2 * ul[0].xvec_proj[1].scale_factor).transpose(1, 2))
     q1, q2, q3 = q.view(T, B, 3, H).unbind(2)
     xo = xt + (q1 + q2 * vdot) * ul[0].inv_sqrt_2
     vo = vt + q3.unsqueeze(2) * v1
