@@ -176,6 +176,12 @@ class RadialBasis(nn.Module):
         src = torch.full((nc * C,), Ek, dtype=torch.long, device=dev)                        # padding rows -> the dummy entry
         src[slot] = torch.arange(Ek, device=dev)
         group = torch.repeat_interleave(torch.arange(T * nb, device=dev), torch.tensor(chunks, device=dev))
+        # the padding rows (no edge points to them): the edge kernels' R gradients zero these instead of the whole buffer
+        import numpy as np
+        first = np.concatenate([[0], np.cumsum(chunks[:-1])]) * C
+        pad = np.concatenate([np.arange(first[i] + cnt_h[i], first[i] + chunks[i] * C) for i in range(len(chunks))] +
+                             [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+        pad = torch.from_numpy(pad).to(dev)
         up = torch.cat([u, u.new_zeros(1)]).index_select(0, src)                              # [nc * C], differentiable
         if isinstance(self.envelope, PolynomialEnvelope):
             p = self.envelope.p
@@ -189,7 +195,7 @@ class RadialBasis(nn.Module):
         mu = off[k.clamp(0, R - 1)]
         colok = ((k >= 0) & (k < R)).to(up.dtype)
         phi = torch.exp(self.rbf.coeff * (up.view(nc, C, 1) - mu[:, None, :]) ** 2) * (env.view(nc, C, 1) * colok[:, None, :])
-        return BucketedBasis(phi, group, slot, nb, R)
+        return BucketedBasis(phi, group, slot, nb, R, pad)
 
     def descriptor(self):
         if self.rbf_name != "gaussian":

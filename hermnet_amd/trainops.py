@@ -75,8 +75,9 @@ class BucketedBasis(object):
 
     WIDTH, CHUNK = 32, 1024
 
-    def __init__(self, phi, group, slot, nb, num_radial):
+    def __init__(self, phi, group, slot, nb, num_radial, pad=None):
         self.phi, self.group, self.slot, self.nb, self.num_radial = phi, group, slot, int(nb), int(num_radial)
+        self.pad = pad        # [n_pad] rows of the sorted order that hold no edge
 
     def project(self, w_rbf, b_rbf, scale):
         """rbf_proj of every relation (rmnet.py:55) on the bucketed basis -> R [nc * C, 3H] in the sorted edge order;
@@ -216,6 +217,20 @@ def _segsum(x, key):
     return out
 
 
+def _rows_buffer(R, r_rows, keys):
+    """Buffer for a gradient of R that the edge kernels write row by row (at r_rows): rows no edge points to must read
+    zero -- all of them zeroed, or only the listed padding rows (keys[4])."""
+    if r_rows is None:
+        return torch.empty_like(R)
+    pad = keys[4] if len(keys) > 4 else None
+    if pad is None:
+        return torch.zeros_like(R)
+    out = torch.empty_like(R)
+    if pad.numel() > 0:
+        out.index_fill_(0, pad, 0.0)
+    return out
+
+
 class MessageAlgebra(torch.autograd.Function):
     """(xh [T N,3H], vec [N,3,H] | None, R [E,3H], U [E,3]) -> (dx [N,H], dvec [N,3,H]): gather of x_j / vec_j, the
     per-edge algebra and the aggregation of rmnet.py:58-73 with NODE-level inputs and outputs.  The kernels of
@@ -223,12 +238,12 @@ class MessageAlgebra(torch.autograd.Function):
     cotangents = g[target]) and the row sums follow inside the function, so no [E, 3H] copy of a gathered operand and
     no per-edge gradient ever enters the autograd graph: what two graph nodes share and the engine has to add up is
     node-sized.  Twice differentiable through `MessageAlgebraGrad`.  keys = (targets, sources, (relation, source), rows
-    of R or None)."""
+    of R or None, padding rows of R or None)."""
 
     @staticmethod
     def forward(ctx, xh, vec, R, U, keys):
         from .ops import _stream
-        k_tgt, k_all, k_xh, r_rows = keys
+        k_tgt, k_all, k_xh, r_rows = keys[:4]
         xh, vec, R, U = _c(xh), _c(vec), _c(R), _c(U)
         E, H = U.size(0), R.size(1) // 3
         S = torch.empty(E, H, dtype=R.dtype, device=R.device)
@@ -251,13 +266,13 @@ class MessageAlgebraGrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g_dx, g_dv, xh, vec, R, U, keys):
         from .ops import _stream
-        k_tgt, k_all, k_xh, r_rows = keys
+        k_tgt, k_all, k_xh, r_rows = keys[:4]
         E, H = U.size(0), R.size(1) // 3
         g_dx = torch.zeros(k_tgt.n_rows, H, dtype=R.dtype, device=R.device) if g_dx is None else _c(g_dx)
         g_dv = torch.zeros(k_tgt.n_rows, 3, H, dtype=R.dtype, device=R.device) if g_dv is None else _c(g_dv)
         gX = torch.empty(E, 3 * H, dtype=R.dtype, device=R.device)
         # (R kept in another edge order with padding rows: rows no edge points to get no gradient)
-        gR = torch.empty_like(R) if r_rows is None else torch.zeros_like(R)
+        gR = _rows_buffer(R, r_rows, keys)
         gV = None if vec is None else torch.empty(E, 3, H, dtype=R.dtype, device=R.device)
         gU = torch.empty_like(U)
         P = _lib.ptr
@@ -272,12 +287,12 @@ class MessageAlgebraGrad(torch.autograd.Function):
     def backward(ctx, c_xh, c_vec, cR, cU):
         from .ops import _stream
         g_dx, g_dv, xh, vec, R, U = ctx.saved_tensors
-        k_tgt, k_all, k_xh, r_rows = ctx.keys
+        k_tgt, k_all, k_xh, r_rows = ctx.keys[:4]
         E, H = U.size(0), R.size(1) // 3
         c_xh, c_vec, cR, cU = _c(c_xh), _c(c_vec), _c(cR), _c(cU)
         new = lambda *shape: torch.empty(*shape, dtype=R.dtype, device=R.device)
         dGS, dGM, dX, dU = new(E, H), new(E, 3, H), new(E, 3 * H), new(E, 3)
-        dR = torch.empty_like(R) if r_rows is None else torch.zeros_like(R)
+        dR = _rows_buffer(R, r_rows, ctx.keys)
         dV = None if vec is None else new(E, 3, H)
         P = _lib.ptr
         _lib.check(_lib.load().hermnet_edge_message_bwd2(P(c_xh), P(cR), P(c_vec), P(cU), P(g_dx), P(g_dv), P(xh), P(R), P(vec),
@@ -358,7 +373,8 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     if isinstance(edge_embed, BucketedBasis):
         if Ek > 0:     # rbf_proj (rmnet.py:55) as one batched product on the bucketed basis; R stays in its sorted order
             R = edge_embed.project(w_rbf, b_rbf, sc)
-            dx, dv = MessageAlgebra.apply(xh.reshape(T * Ns, 3 * H), vec, R, edge[:Ek, :3], (k_tgt, k_all, k_xh, edge_embed.slot))
+            dx, dv = MessageAlgebra.apply(xh.reshape(T * Ns, 3 * H), vec, R, edge[:Ek, :3],
+                                          (k_tgt, k_all, k_xh, edge_embed.slot, edge_embed.pad))
     else:
         # (split, not slices: the backward of a split is ONE cat, a slice's zero-fills the whole [E,R] gradient)
         emb = edge_embed.split([bounds[t + 1] - bounds[t] for t in range(T)] + [edge_embed.size(0) - Ek])
@@ -371,7 +387,7 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
         if _train_kernels(R):
             # gather x_j / vec_j (rmnet.py:58), x_j * rbfh and the vector message (:61-66), aggregation (:69-73): one
             # twice-differentiable function with node-level inputs and outputs (csrc/train_kernels.hip)
-            dx, dv = MessageAlgebra.apply(xh.reshape(T * Ns, 3 * H), vec, R, edge[:Ek, :3], (k_tgt, k_all, k_xh, None))
+            dx, dv = MessageAlgebra.apply(xh.reshape(T * Ns, 3 * H), vec, R, edge[:Ek, :3], (k_tgt, k_all, k_xh, None, None))
         else:
             X = GatherRows.apply(xh.reshape(T * Ns, 3 * H), k_xh)                  # x_j of every edge, rmnet.py:58
             V = None if vec is None else GatherRows.apply(vec, k_all)
