@@ -297,6 +297,11 @@ def test_slab_stepper_reuses_the_plan_under_the_skin(world):
         moved_far = float((walk ** 2).sum(1).max()) > (skin / 2) ** 2
         assert [s_.replans for s_ in steppers] == [2 if moved_far else 1] * world, (it, moved_far)
     assert moved_far        # the last step did cross the threshold
+    # a cell that is edited in place (NPT) or replaced invalidates the slab bounds: plan again, same coordinates
+    before = [s_.replans for s_ in steppers]
+    d.cell.mul_(1.0)
+    loc, plan = steppers[0](cur)
+    assert steppers[0].replans == before[0] + 1 and steppers[1].replans == before[1]
 
 
 def _slab_worker(rank, world, port, out, overlap):
