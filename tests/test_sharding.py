@@ -481,6 +481,78 @@ def _gpu_slab_worker(rank, world, reps, port, out, overlap, kind="hvnet"):
         dist.destroy_process_group()
 
 
+def _gpu_stepper_worker(rank, world, port, out):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # ranks share the GPU: exchange staged through the host
+    try:
+        import hermnet_amd as hn
+        from hermnet_amd import synth
+        from hermnet_amd.neighbor import neighbor_search
+        from hermnet_amd.sharding import SlabStepper
+        dev = torch.device("cuda:0")
+        kw = dict(rc=5.0, num_layers=3, hidden_channels=128, num_rbf=128)
+        model = hn.HVNet(["Al", "Ni", "Cu"], **kw).eval()
+        model.load_state_dict(synth.synth_state_dict(model.state_dict(), 10))
+        model = model.to(dev)
+        for p in model.parameters():
+            p.requires_grad_(False)
+        pos, cell, z = synth.fcc_alloy_atoms(reps=(6, 6, 20))
+        pos_t = torch.from_numpy(pos.astype(np.float32)).to(dev)
+        cell_t = torch.from_numpy(cell.astype(np.float32)).to(dev)
+        z_t = torch.from_numpy(z).to(dev)
+        stepper = SlabStepper(z_t, cell_t, 5.0, rank, world, skin=0.8)
+        gen = torch.Generator().manual_seed(3)            # the same walk on every rank
+        walk = torch.zeros_like(pos_t)
+        res = []
+        for it in range(6):
+            if it > 0:
+                walk = walk + (0.12 * (torch.rand(pos_t.shape, generator=gen) - 0.5)).to(dev)
+            if it == 4:
+                walk[11] += torch.tensor([0.0, 0.0, 1.3], device=dev)      # past skin/2: every rank plans again
+            cur = pos_t + walk
+            local, plan = stepper(cur)
+            local.pos.requires_grad_(True)
+            e = model(local)
+            f = -torch.autograd.grad(e.sum(), local.pos)[0]
+            step = dict(e=e.detach().cpu().numpy(), owned=plan.owned_global.cpu().numpy(), f=f[plan.owned_local].cpu().numpy(),
+                        replans=stepper.replans)
+            if rank == 0:     # the same coordinates on one GPU, unsharded, list rebuilt
+                ei, sh = neighbor_search(cur, 5.0, cell_t)
+                d = hn.Data(pos=cur.clone().requires_grad_(True), atomic_number=z_t, edge_index=ei, edge_shift=sh,
+                            cell=cell_t.reshape(1, 3, 3), batch=torch.zeros(cur.size(0), dtype=torch.long, device=dev))
+                eg = model(d)
+                step["e_ref"] = eg.detach().cpu().numpy()
+                step["f_ref"] = (-torch.autograd.grad(eg.sum(), d.pos)[0]).cpu().numpy()
+            res.append(step)
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_slab_stepper_along_a_trajectory_matches_single_gpu():
+    """Six steps of a random walk on 2 ranks sharing the GPU: the slab plan is made once, reused while every atom stays
+    within skin/2 (only the target-masked neighbour search runs per step), and made again after one atom jumps; at every
+    step energy and forces equal the unsharded evaluation of the same coordinates."""
+    world = 2
+    port = 38500 + os.getpid() % 2000
+    out = mp.Manager().dict()
+    mp.spawn(_gpu_stepper_worker, args=(world, port, out), nprocs=world, join=True)
+    n = out[0][0]["f_ref"].shape[0]
+    for it in range(6):
+        e_ref, f_ref = torch.from_numpy(out[0][it]["e_ref"]), torch.from_numpy(out[0][it]["f_ref"])
+        forces = np.zeros((n, 3), dtype=np.float32)
+        for r in range(world):
+            st = out[r][it]
+            assert rel_err(torch.from_numpy(st["e"]), e_ref) < 1e-5, (it, r)
+            assert st["replans"] == (1 if it < 4 else 2), (it, r, st["replans"])
+            forces[st["owned"]] = st["f"]
+        assert rel_err(torch.from_numpy(forces), f_ref) < 1e-5, it
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,reps,overlap,kind", [(2, (10, 10, 250), "0", "hvnet"), (3, (10, 10, 25), "0", "hvnet"),
                                                      (3, (10, 10, 25), "1", "hvnet"), (2, (6, 6, 12), "0", "htnet")])
