@@ -2,8 +2,6 @@ import sys, time, torch
 sys.path.insert(0, '.')
 import hermnet_amd as hn
 from hermnet_amd import synth
-from hermnet_amd.utils import enable_tuned_gemms, freeze_gemm_tuning
-enable_tuned_gemms(online=True)
 dev = torch.device('cuda:0')
 kw = dict(rc=5.0, num_layers=5, hidden_channels=128, num_rbf=128)
 model = hn.HVNet(["Al", "Ni", "Cu"], **kw).eval()
