@@ -106,11 +106,16 @@ def cpu_baseline(model_kw, elems, seed):
     n, dt, reps = best
     # the same sample through the oracle's vectorised mode (one mask per relation instead of the reference's
     # O(N*E) in_subgraph loop): the GPU/CPU ratio is not meant to be inflated by that loop
-    t0 = time.time()
-    orc.energy_and_forces(sd, elems, synth.fcc_alloy(reps=reps), mode="vectorised", **kw)
-    dt_vec = time.time() - t0
+    # (same protocol as the faithful mode: one warm-up step at this size, then the median of the timed ones)
+    tv = []
+    for _ in range(4):
+        t0 = time.time()
+        orc.energy_and_forces(sd, elems, sample, mode="vectorised", **kw)
+        tv.append(time.time() - t0)
+    tv = sorted(tv[1:])
+    dt_vec = tv[len(tv) // 2]
     return {"value": n / dt, "unit": "atom-steps/s", "cores": cores, "kind": "port",
-            "vectorised_value": n / dt_vec,
+            "vectorised_value": n / dt_vec, "vectorised_timed_steps_s": [round(t_, 2) for t_ in tv],
             "timed_steps_s": [round(t_, 2) for t_ in times], "warmup_step_s": round(dt_probe, 2),
             "sample": "oracle mode=faithful (reference op sequence incl. in_subgraph loop), energy+forces steps on a "
                       "%d-atom slice (fcc %dx%dx%d) of the same alloy/model: one warm-up step at this size, median of "
@@ -118,19 +123,33 @@ def cpu_baseline(model_kw, elems, seed):
 
 
 def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=10):
-    """Device copy bandwidth of this box (read + written bytes per second of a 1 GiB buffer copy), GB/s."""
+    """Device copy bandwidth of this box, GB/s (read + written bytes per second of a 1 GiB buffer copy): the library's
+    float4 stream kernel (`hermnet_stream_copy`: 16-byte loads and stores, the method behind MI355X_MICROARCH.md's
+    6.29 TB/s; best of a few grid sizes) and, beside it, what `Tensor.copy_` gets.  -> (stream kernel, copy_)."""
+    from hermnet_amd import _lib
+    lib = _lib.load()
     a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
     b = torch.empty_like(a)
-    for _ in range(3):
-        b.copy_(a)
-    torch.cuda.synchronize()
-    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s0.record()
-    for _ in range(reps):
-        b.copy_(a)
-    s1.record()
-    torch.cuda.synchronize()
-    return 2.0 * nbytes * reps / (s0.elapsed_time(s1) * 1e-3) / 1e9
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        for _ in range(reps):
+            fn()
+        s1.record()
+        torch.cuda.synchronize()
+        return 2.0 * nbytes * reps / (s0.elapsed_time(s1) * 1e-3) / 1e9
+
+    best = 0.0
+    for wgs in (256 * 4, 256 * 8, 256 * 16, 256 * 32):
+        best = max(best, timed(lambda: _lib.check(lib.hermnet_stream_copy(a.data_ptr(), b.data_ptr(), a.numel(), wgs, stream),
+                                                   "hermnet_stream_copy")))
+    assert torch.equal(a[:4096], b[:4096]) and torch.equal(a[-4096:], b[-4096:])
+    return best, timed(lambda: b.copy_(a))
 
 
 def other_configs_secondary(hn, synth, dev, model_kw, steps=5, skip_c4=False):
@@ -296,12 +315,21 @@ def chain_kernel_bounds(gsum, N, nk, H, T):
     return out
 
 
-def self_launch(ngpus, argv):
+def self_launch(ngpus, argv, timeout=None):
     """Start the `ngpus` ranks of this benchmark as FRESH child processes (`python -m torch.distributed.run`, one
     process per GPU, rendezvous on 127.0.0.1 at a free port) and relay their output.  Called before this process has
     touched the GPU (a process that has initialised HIP must not fork/exec ranks).  Returns the exit code."""
     import socket
     import subprocess
+    tools = [v for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_TOOL_LIBRARIES", "HSA_TOOLS_LIB",
+                       "HERMNET_PROFILER_HINT")
+             for v in [os.environ.get(k, "")] if "rocprof" in v.lower()]
+    if tools:
+        # under rocprofv3 this process would be an idle relay and the ranks unprofiled children: refuse
+        print("bench.py: --gpus %d would start the ranks as child processes, which the profiler attached to THIS process "
+              "(%s) does not see.  Profile one rank instead: rocprofv3 ... -- python3 -m torch.distributed.run "
+              "--nproc-per-node 1 bench.py --shard-anyway (tools/profile_shard1.sh)." % (ngpus, tools[0]), file=sys.stderr)
+        return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -311,18 +339,48 @@ def self_launch(ngpus, argv):
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // ngpus)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    import signal
+    import threading
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)
+    timed_out = []
+
+    def expire():          # a hung rank (rendezvous, RCCL) must not block forever: end the whole child job
+        timed_out.append(True)
+        victims = []
+        try:      # the elastic agent starts every rank in a session of its own: collect the whole tree first
+            import psutil
+            victims = [c.pid for c in psutil.Process(proc.pid).children(recursive=True)]
+        except Exception:
+            pass
+        for pid in victims + [proc.pid]:           # exactly the processes this launcher started, by pid
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except OSError:
+                pass
+
+    watchdog = threading.Timer(timeout, expire) if timeout and timeout > 0 else None
+    if watchdog is not None:
+        watchdog.daemon = True
+        watchdog.start()
     line = None
-    for ln in proc.stdout.splitlines():
+    for ln in proc.stdout:                 # relayed line by line, as the ranks write
+        ln = ln.rstrip("\n")
         if ln.startswith("{") and '"metric"' in ln:
             line = ln                      # rank 0's JSON line
         else:
-            print(ln, file=sys.stderr)     # anything else the ranks wrote to stdout is not the result
+            print(ln, file=sys.stderr, flush=True)     # anything else the ranks wrote to stdout is not the result
+    rc = proc.wait()
+    if watchdog is not None:
+        watchdog.cancel()
     if line is not None:
         print(line, flush=True)
-    if proc.returncode != 0:
-        print("bench.py: the %d-rank child job exited with code %d" % (ngpus, proc.returncode), file=sys.stderr)
-        return proc.returncode
+    if timed_out:
+        print("bench.py: the %d-rank child job did not finish within --launch-timeout %.0f s and was killed"
+              % (ngpus, timeout), file=sys.stderr)
+        return 124
+    if rc != 0:
+        print("bench.py: the %d-rank child job exited with code %d" % (ngpus, rc), file=sys.stderr)
+        return rc
     return 0 if line is not None else 1
 
 
@@ -348,6 +406,8 @@ def launch_rehearsal(args, world, rank):
         dist.init_process_group("gloo")
     fence = rank_fence(world > 1, "gloo", None)
     fence()
+    if os.environ.get("HERMNET_REHEARSAL_HANG"):      # tests: a rank that never comes back (launcher watchdog)
+        time.sleep(float(os.environ["HERMNET_REHEARSAL_HANG"]))
     t0 = time.perf_counter()
     fence()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
@@ -383,6 +443,9 @@ def main():
                     help="launcher check without a GPU: every rank joins the process group, runs the fences and the "
                          "max-over-ranks reduction of the timed region around an empty step, rank 0 prints a line with "
                          "value null (tests/test_bench_launcher.py)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="plain `--gpus N` only: seconds after which the child job is killed (a hung rank must not block "
+                         "forever); 0 = none")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -394,7 +457,7 @@ def main():
                              "--nproc-per-node %d bench.py --gpus %d" % (args.gpus, world, args.gpus, args.gpus))
         # plain `python bench.py --gpus N`: this process has made no GPU call yet and never will -- it starts the N
         # ranks as fresh children, relays rank 0's line and exits with their code
-        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], timeout=args.launch_timeout))
     sharded = world > 1 or args.shard_anyway
     if args.launch_rehearsal:
         return launch_rehearsal(args, world, rank)
@@ -566,9 +629,22 @@ def main():
         limiter = {"message_scatter_fwd": "issue/latency at 2 waves per SIMD (gathers from L2/Infinity Cache)",
                    "message_scatter_fwd_l0": "issue/latency (gathers from L2/Infinity Cache)",
                    "message_scatter_bwd": "valu-issue", "message_scatter_bwd_l0": "valu-issue"}
+        traffic_all = json.load(open(tpath)) if os.path.exists(tpath) else {}
         for k in kernels:
             if k in limiter:
                 kernels[k]["limiter"] = limiter[k]
+                tb = traffic_all.get(k)
+                if tb:      # HBM-side bytes per launch from the PMC passes (profiles/traffic.json, tools/profile_round.sh)
+                    kernels[k]["traffic_GB"] = tb / 1e9
+                    kernels[k]["hbm_frac_measured"] = tb / 1e9 / (kernels[k]["avg_ms"] / 1e3) / HBM_PEAK_GBS
+                    kernels[k]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the builder's box " \
+                                                   "(profiles/traffic.json), not measured in this run"
+                if k.startswith("message_scatter_fwd"):
+                    kernels[k]["ceiling"] = ("gather rows are served by L2 / Infinity Cache, not HBM: the algorithmic fraction "
+                                             "(`hbm_frac`) can exceed 1; the guide's random-row gather ceiling from the Infinity "
+                                             "Cache is 8.6 TB/s (MI355X_MICROARCH.md, 'Indexed rows'), `hbm_frac_measured` is "
+                                             "the HBM-side share")
+                    kernels[k]["frac_of_cache_gather_ceiling"] = kernels[k]["GBps"] / 8600.0
         gsum = gtimer.summary()
         gemm_ms = sum(cnt * ms for _, (cnt, ms) in gsum.items()) / 3.0          # per step
         nk = N if not sharded else N
@@ -604,6 +680,7 @@ def main():
             "mfma": mfma,
             "kernels": kernels,
             "energy": float(e.detach()[0]),
+            "library": _lib.build_info(),
         }
         if md is not None:
             out["secondary"] = {"atom_steps_per_s_incl_planning": N_global / md, "ms_per_step_incl_planning": md * 1e3,
@@ -651,7 +728,10 @@ def main():
             except Exception as ex:
                 out["secondary"]["graph_replay"] = {"error": repr(ex)}
             try:   # the box's own copy bandwidth next to the 8 TB/s the roofline is priced against
-                out["roofline"]["measured_copy_GBps"] = measured_copy_bandwidth(dev)
+                cp_k, cp_t = measured_copy_bandwidth(dev)
+                out["roofline"]["measured_copy_GBps"] = cp_k
+                out["roofline"]["measured_copy_GBps_torch_copy"] = cp_t
+                out["roofline"]["frac_of_measured_copy"] = out["roofline"]["achieved"] / cp_k
             except Exception as ex:
                 out["roofline"]["measured_copy_GBps"] = None
             # secondary figures: the other single-GPU configurations of BASELINE.json at full size, same model

@@ -15,7 +15,7 @@ _ERR = {1: "HN_ERR_BAD_ARG (unsupported shape or null pointer)",
         3: "HN_ERR_LAUNCH (kernel launch failed)"}
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers
-ABI_VERSION = 6          # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
+ABI_VERSION = 7          # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
 
 
 class RbfDesc(ctypes.Structure):
@@ -95,11 +95,32 @@ SIGNATURES = {
                                          ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_fp]),
     "hermnet_halo_rows": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "hermnet_halo_accumulate": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
+    "hermnet_stream_copy": (ctypes.c_int, [c_fp, c_fp, ctypes.c_size_t, ctypes.c_int, c_fp]),
     "hermnet_host_rbf_row": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                             ctypes.c_int, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp]),
 }
 
 _lib = None
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the library's sources, as `csrc/Makefile` stamps it into
+    `hermnet_build_info()` (`src=...`): *.hip, *.cpp, *.h of csrc/ in sorted order, then include/hermnet_hip.h."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(os.path.basename(f) for pat in ("*.hip", "*.cpp", "*.h") for f in glob.glob(os.path.join(csrc, pat)))
+    paths = [os.path.join(csrc, f) for f in files] + [os.path.join(_HERE, "..", "include", "hermnet_hip.h")]
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build_info():
+    """`hermnet_build_info()` of the loaded library (ABI, target, source hash, build date) as a str."""
+    return load().hermnet_build_info().decode()
 
 
 def load():
@@ -119,6 +140,17 @@ def load():
     if lib.hermnet_abi_version() != ABI_VERSION:
         raise RuntimeError("hermnet_amd: %s has ABI version %d, the Python side expects %d -- rebuild it "
                            "(`make -C hermnet_amd/csrc`)" % (LIB_PATH, lib.hermnet_abi_version(), ABI_VERSION))
+    # the library must have been built from the sources next to it: a stale prebuilt binary would otherwise be what
+    # the tests and the benchmark measure (HERMNET_LIB_PATH = an explicitly chosen diagnostic build: not checked)
+    if not os.environ.get("HERMNET_LIB_PATH") and os.environ.get("HERMNET_ALLOW_STALE_LIB", "0") == "0":
+        info = lib.hermnet_build_info().decode()
+        try:
+            want = source_hash()
+        except OSError:
+            want = None                       # sources not shipped: nothing to compare with
+        if want is not None and ("src=" + want) not in info:
+            raise RuntimeError("hermnet_amd: %s was not built from the sources in hermnet_amd/csrc (library: %s; sources "
+                               "hash to %s) -- rebuild it (`make -C hermnet_amd/csrc`)" % (LIB_PATH, info, want))
     _lib = lib
     return lib
 

@@ -5,14 +5,17 @@
 #include "../../include/hermnet_hip.h"
 #include "hermnet_math.h"
 
-#define HN_ABI_VERSION 6
+#define HN_ABI_VERSION 7
+#ifndef HN_SRC_HASH
+#define HN_SRC_HASH "unknown"
+#endif
 #define HN_STR2(x) #x
 #define HN_STR(x) HN_STR2(x)
 
 extern "C" int hermnet_abi_version(void) { return HN_ABI_VERSION; }
 
 extern "C" const char* hermnet_build_info(void) {
-  return "hermnet_hip abi=" HN_STR(HN_ABI_VERSION) " target=gfx950 taps=12 colblock=64 built " __DATE__ " " __TIME__;
+  return "hermnet_hip abi=" HN_STR(HN_ABI_VERSION) " target=gfx950 taps=12 colblock=64 src=" HN_SRC_HASH " built " __DATE__ " " __TIME__;
 }
 
 extern "C" int hermnet_host_rbf_row(const float* offset, int R, float inv_rc, float coeff,

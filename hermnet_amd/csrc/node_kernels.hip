@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void energy_head_bwd_kernel(const float* __res
 // MODE 0: buf[k] = rows[idx[k]]            (pack)
 // MODE 1: buf[k] = rows[idx[k]]; rows[idx[k]] = 0   (pack the gradients of overwritten halo rows, then clear them)
 // MODE 2: rows[idx[k]] = buf[k]            (unpack; idx unique)
-// MODE 3: rows[idx[k]] += buf[k]           (accumulate at the owner; idx may repeat across destination ranks)
+// (accumulating returned gradients at their owner is halo_accumulate_kernel below: ordered sums, no float atomics)
 template <int MODE>
 __global__ __launch_bounds__(256) void halo_rows_kernel(float* __restrict__ x, float* __restrict__ vec,
                                                         const long* __restrict__ idx, int n, int H,
@@ -360,11 +360,8 @@ __global__ __launch_bounds__(256) void halo_rows_kernel(float* __restrict__ x, f
   } else if (MODE == 1) {
     st4(b, ld4(row));
     st4(row, make_float4(0.f, 0.f, 0.f, 0.f));
-  } else if (MODE == 2) {
-    st4(row, ld4(b));
   } else {
-    const float4 v = ld4(b);
-    atomicAdd(row + 0, v.x); atomicAdd(row + 1, v.y); atomicAdd(row + 2, v.z); atomicAdd(row + 3, v.w);
+    st4(row, ld4(b));
   }
 }
 
@@ -692,7 +689,7 @@ extern "C" int hermnet_pair_mean(int mode, const float* x_in, const float* vec_i
 
 extern "C" int hermnet_halo_rows(int mode, float* x, float* vec, const long* idx, int n, int hidden, float* buf,
                                  void* stream) {
-  if (n < 0 || hidden <= 0 || (hidden & 3) || mode < 0 || mode > 3) return HN_ERR_BAD_ARG;
+  if (n < 0 || hidden <= 0 || (hidden & 3) || mode < 0 || mode > 2) return HN_ERR_BAD_ARG;
   if (n == 0) return HN_OK;
   if (!x || !vec || !idx || !buf) return HN_ERR_BAD_ARG;
   const dim3 grid = grid_for((long)n * hidden, 256);
@@ -701,7 +698,7 @@ extern "C" int hermnet_halo_rows(int mode, float* x, float* vec, const long* idx
     case 0: hipLaunchKernelGGL(halo_rows_kernel<0>, grid, dim3(256), 0, s, x, vec, idx, n, hidden, buf); break;
     case 1: hipLaunchKernelGGL(halo_rows_kernel<1>, grid, dim3(256), 0, s, x, vec, idx, n, hidden, buf); break;
     case 2: hipLaunchKernelGGL(halo_rows_kernel<2>, grid, dim3(256), 0, s, x, vec, idx, n, hidden, buf); break;
-    default: hipLaunchKernelGGL(halo_rows_kernel<3>, grid, dim3(256), 0, s, x, vec, idx, n, hidden, buf); break;
+    default: return HN_ERR_BAD_ARG;
   }
   HN_LAUNCH_END;
 }

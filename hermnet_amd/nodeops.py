@@ -146,8 +146,8 @@ def pair_sum_accumulate(x, vec, x_acc, vec_acc, Te, P_, B, scale_x, scale_vec):
 
 
 def halo_rows(mode, x, vec, idx, buf=None):
-    """Packed halo rows [n, 4H] = [x | vec] of the rows `idx` (int64): mode 0 pack, 1 pack-and-clear, 2 unpack,
-    3 accumulate (see include/hermnet_hip.h).  Returns `buf` (allocated for the packing modes)."""
+    """Packed halo rows [n, 4H] = [x | vec] of the rows `idx` (int64): mode 0 pack, 1 pack-and-clear, 2 unpack
+    (see include/hermnet_hip.h).  Returns `buf` (allocated for the packing modes)."""
     n, H = int(idx.numel()), x.size(1)
     if buf is None:
         buf = torch.empty(n, 4 * H, dtype=x.dtype, device=x.device)
@@ -158,7 +158,7 @@ def halo_rows(mode, x, vec, idx, buf=None):
 
 def halo_accumulate(x, vec, plan, buf):
     """rows[plan.acc_rows[u]] += sum of the packed rows `buf[plan.acc_pos[q]]` of segment u, in list order
-    (deterministic replacement of halo_rows mode 3)."""
+    (ordered sums: no float atomics anywhere on the path)."""
     rows, ptr, pos = plan.accumulate_lists()
     _lib.check(_launch("halo_accumulate", lambda: _lib.load().hermnet_halo_accumulate(
         P(x), P(vec), P(rows), P(ptr), P(pos), int(rows.numel()), x.size(1), P(buf), _stream())), "hermnet_halo_accumulate")

@@ -67,27 +67,53 @@ def build_graph(cell, elements, pos, rc, device=None, reference_compat=False):
     return data
 
 
+def _evaluate(model, data, device, pbc, want_virial, trn_mean=0.0):
+    """One energy + force evaluation -> (energy [graphs] tensor, forces [N,3] tensor, W [3,3] tensor in energy units
+    or None).  W = -dE/d(strain) = sum_i pos_i (x) F_i - cell^T dE/dcell, symmetrised (`utils.virial_calc` with unit
+    factor 1); the cell gradient comes from the edge geometry kernel's backward."""
+    device = torch.device(device)
+    data = data.to(device)
+    data.pos.requires_grad = True
+    periodic = bool(pbc) and data.get('cell') is not None
+    if want_virial and periodic:
+        data.cell.requires_grad = True
+    model.eval()
+    energy = model(data) + trn_mean
+    forces = -torch.autograd.grad(energy.sum(), data.pos, retain_graph=want_virial and periodic)[0]
+    w = None
+    if want_virial:
+        w = virial_calc(cell=data.get('cell'), pos=data.pos.detach(), forces=forces, energy=energy, units='lj',
+                        pbc=periodic).detach()
+    return energy.detach(), forces.detach(), w
+
+
 def model_calc(model, data, device, pbc, ensemble='NVT', trn_mean=0.0, units='metal'):
     """`calculator.py:59-98` / `lmp_calc.py:36-85`: (energy float, forces [N,3] float32, virial [6]).
 
     virial (NPT only) is the symmetrised pressure*volume tensor of `virial_calc` in the order
-    [xx, yy, zz, xy, xz, yz] (LAMMPS `fix client/md`); zeros for NVT like the reference."""
-    device = torch.device(device)
-    data = data.to(device)
-    data.pos.requires_grad = True
+    [xx, yy, zz, xy, xz, yz] -- what LAMMPS `fix client/md` expects (`lmp_calc.py:58-67,232-235`); zeros for NVT like
+    the reference.  This is the LAMMPS packing; ASE's `stress` is made from the same tensor in
+    `NNCalculator.calculate` (`stress_from_virial`)."""
+    from ..utils import _NKTV2P
+    if units not in _NKTV2P:
+        raise ValueError('Illegal units command')
     npt = ensemble.lower() == 'npt'
-    if npt and pbc and data.get('cell') is not None:
-        data.cell.requires_grad = True
-    model.eval()
-    energy = model(data) + trn_mean
-    forces = -torch.autograd.grad(energy.sum(), data.pos, retain_graph=npt and pbc)[0]
+    energy, forces, w = _evaluate(model, data, device, pbc, npt, trn_mean)
     if npt:
-        v = virial_calc(cell=data.get('cell'), pos=data.pos.detach(), forces=forces, energy=energy, units=units,
-                        pbc=bool(pbc) and data.get('cell') is not None).detach().cpu().numpy()
+        v = (w * _NKTV2P[units]).cpu().numpy()
         virial = np.array([v[0, 0], v[1, 1], v[2, 2], v[0, 1], v[0, 2], v[1, 2]])
     else:
         virial = np.zeros(6, dtype=np.float32)
-    return energy.detach().cpu().item(), forces.detach().cpu().numpy().reshape(-1, 3), virial
+    return energy.cpu().item(), forces.cpu().numpy().reshape(-1, 3), virial
+
+
+def stress_from_virial(w, volume):
+    """ASE's contract for `results['stress']`: sigma = (1/V) dE/d(strain) = -W / V in eV/A^3 (W in eV), Voigt order
+    [xx, yy, zz, yz, xz, xy] (`ase.calculators.calculator`: cell filters and NPT dynamics consume it in that form).
+    The reference hands ASE the LAMMPS virial instead (`calculator.py:85-97`: pressure*volume units, LAMMPS order,
+    opposite sign, `[0,1]` where `[0,0]` is meant) -- SURVEY 8(b) lists it under "reproduce the intent"."""
+    s = -np.asarray(w, dtype=np.float64) / float(volume)
+    return np.array([s[0, 0], s[1, 1], s[2, 2], s[1, 2], s[0, 2], s[0, 1]])
 
 
 class NNCalculator(_Base):
@@ -115,11 +141,19 @@ class NNCalculator(_Base):
         dev = self.device_ if torch.device(self.device_).type == 'cuda' else None
         data = build_graph(cell=cell, elements=elems, pos=atoms.positions, rc=self.model.rc, device=dev,
                            reference_compat=self.reference_compat)
-        energy, forces, virial = self.model_calc(data=data, device=self.device_, pbc=pbc, ensemble=self.ensemble)
+        # stress whenever ASE asks for it (or the ensemble is NPT) on a periodic cell; an open system has none
+        want = pbc and cell is not None and (self.ensemble.lower() == 'npt' or 'stress' in tuple(properties))
+        energy, forces, w = _evaluate(self.model, data, self.device_, pbc, want, self.trn_mean)
+        energy = energy.cpu().item()
         self.results['energy'] = energy
         self.results['free_energy'] = energy
-        self.results['forces'] = forces
-        self.results['stress'] = virial
+        self.results['forces'] = forces.cpu().numpy().reshape(-1, 3)
+        if want:
+            volume = abs(float(np.linalg.det(np.asarray(cell, dtype=np.float64).reshape(3, 3))))
+            self.results['stress'] = stress_from_virial(w.cpu().numpy(), volume)
+        else:
+            self.results['stress'] = np.zeros(6)
 
     def model_calc(self, data, device, pbc, ensemble='NVT'):
+        """`calculator.py:59-98`: (energy, forces [N,3], LAMMPS-packed virial [6]) -- see the module-level function."""
         return model_calc(self.model, data, device, pbc, ensemble, self.trn_mean)

@@ -16,7 +16,9 @@
  *   - float = IEEE fp32 (the reference is fp32-only), indices = int32 (int64 where a parameter says so:
  *     the caller's edge_index / atomic_number / halo index lists arrive as torch LongTensors).
  *
- * ABI version 6 (`hermnet_abi_version`): v6 adds the target mask of the neighbour search (lists of an atom shard) and the
+ * ABI version 7 (`hermnet_abi_version`): v7 adds the row windows of the message kernels (interior / boundary launches
+ * around the halo exchange), node chain kernels for every width that is a multiple of 64 up to 512, hermnet_stream_copy, and drops
+ * the float-atomic mode 3 of hermnet_halo_rows; v6 added the target mask of the neighbour search (lists of an atom shard) and the
  * row windows of the node pre kernels (halo exchange overlap); v5 replaces the stand-alone node GEMM by the node chain kernels
  * (hermnet_node_pre_fwd/_bwd, hermnet_node_update_fwd/_bwd); v4 puts the radial table in CSC order (hermnet_edge_radial_table takes the
  * graph); v3 added the deterministic halo accumulate, separate source / target row
@@ -410,14 +412,19 @@ int hermnet_segment_sum(const float* x, const long* perm, const long* rowptr, lo
  *   mode 0  buf[k] = rows[idx[k]]                         pack what the neighbours need
  *   mode 1  buf[k] = rows[idx[k]]; rows[idx[k]] = 0       pack the gradients of my halo rows and clear them
  *   mode 2  rows[idx[k]] = buf[k]                         unpack received halo rows (idx unique)
- *   mode 3  rows[idx[k]] += buf[k]                        accumulate returned gradients (idx may repeat: atomics) */
+ * Any other mode: HN_ERR_BAD_ARG (the float-atomic accumulate of ABI <= 6 is gone: hermnet_halo_accumulate). */
 int hermnet_halo_rows(int mode, float* x, float* vec, const long* idx, int n, int hidden, float* buf, void* stream);
 
-/* Deterministic form of mode 3 (what the sharded backward uses): the returned packed rows are summed per owner row in
+/* Accumulating returned gradients at their owner: the returned packed rows are summed per owner row in
  * a FIXED order, rows[seg_rows[u]] += sum_{q in [seg_ptr[u], seg_ptr[u+1])} buf[seg_pos[q]]  (seg_rows unique, int64
  * lists prepared once per exchange plan by hermnet_amd/sharding.py) -- no atomics, bit-reproducible. */
 int hermnet_halo_accumulate(float* x, float* vec, const long* seg_rows, const long* seg_ptr, const long* seg_pos,
                             int num_rows, int hidden, const float* buf, void* stream);
+
+/* float4 stream copy dst[i] = src[i] (16-byte aligned pointers, num_floats % 4 == 0): not part of the path -- the yardstick
+ * for SURVEY.md 8(d)'s "measured copy bandwidth on the box" (bench.py: roofline.measured_copy_GBps; the method of
+ * MI355X_MICROARCH.md's 6.29 TB/s figure).  `workgroups` <= 0: 8 per CU. */
+int hermnet_stream_copy(const float* src, float* dst, size_t num_floats, int workgroups, void* stream);
 
 /* Host-side (CPU) evaluation of the per-edge radial contraction exactly as the device code
  * computes it (banded 12-tap Gaussian window): rb[c] = b[c] + env(u) * sum_k W[c,k] g_k(u) and

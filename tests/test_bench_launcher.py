@@ -43,3 +43,15 @@ def test_failing_rank_gives_nonzero_exit_and_no_line():
 def test_mismatched_world_is_refused_inside_a_job():
     p = _run("--gpus", "4", "--launch-rehearsal", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "inside a 2-rank job" in p.stderr
+
+
+def test_self_launch_is_refused_under_a_profiler():
+    # a profiler attached to the relay process would see an idle parent and miss the ranks
+    p = _run("--gpus", "2", "--launch-rehearsal", env={"HERMNET_PROFILER_HINT": "/opt/rocm/lib/librocprofiler-sdk-tool.so"})   # (the real variables would load the tool)
+    assert p.returncode == 2 and "Profile one rank instead" in p.stderr and not p.stdout.strip()
+
+
+def test_hung_child_job_is_killed_at_the_launch_timeout():
+    # HERMNET_REHEARSAL_HANG makes every rank of the rehearsal sleep: the launcher must end the job and say so
+    p = _run("--gpus", "2", "--launch-rehearsal", "--launch-timeout", "8", env={"HERMNET_REHEARSAL_HANG": "600"})
+    assert p.returncode == 124 and "launch-timeout" in p.stderr
