@@ -522,7 +522,12 @@ def slab_data(plan, pos, reference_compat=False):
     if cell is not None:
         ei, sh = neighbor_search(pos_l, plan.rc, cell, reference_compat=reference_compat, target_mask=plan.target_mask)
     else:
-        ei, sh = neighbor_search(pos_l, plan.rc, None, reference_compat=reference_compat, target_mask=plan.target_mask), None
+        ei, sh = neighbor_search(pos_l, plan.rc, None, target_mask=plan.target_mask), None
+        if reference_compat:
+            # `radius_graph`'s cap (data.py:16) keeps a target's 32 lowest source INDICES -- indices of the whole
+            # structure.  The local order is owned-then-halo, so the cap is applied on global ids here (the capped list
+            # of a shard is then exactly the unsharded capped list restricted to the owned targets).
+            ei = _cap_by_global_source(ei, plan.local_global, int(plan.pos_ref.size(0)), 32)
     z = plan.z_local
     kw = dict(pos=pos_l, atomic_number=z, edge_index=ei, batch=plan.batch_local)
     if cell is not None:
@@ -548,6 +553,25 @@ def slab_data(plan, pos, reference_compat=False):
     return local
 
 
+def _cap_by_global_source(edge_index, local_global, n_global, cap):
+    """Keep at most `cap` in-edges per target: those whose sources have the lowest GLOBAL ids; the surviving edges stay
+    in their (target, local source) order."""
+    E = edge_index.size(1)
+    if E == 0:
+        return edge_index
+    dev = edge_index.device
+    key = edge_index[1] * int(n_global) + local_global.index_select(0, edge_index[0])
+    order = torch.argsort(key, stable=True)
+    tgt = edge_index[1].index_select(0, order)
+    pos = torch.arange(E, device=dev)
+    first = torch.ones(E, dtype=torch.bool, device=dev)
+    first[1:] = tgt[1:] != tgt[:-1]
+    start = torch.cummax(torch.where(first, pos, torch.zeros_like(pos)), 0).values
+    keep = torch.zeros(E, dtype=torch.bool, device=dev)
+    keep[order] = (pos - start) < cap
+    return edge_index[:, keep]
+
+
 def plan_moved(plan, pos):
     """0-d bool tensor: some atom is further than skin/2 from where the plan saw it (same answer on every rank: all
     ranks hold the same coordinates)."""
@@ -571,8 +595,9 @@ class SlabStepper(object):
 
     Per step: the displacement check (three elementwise launches), the slab-local neighbour search for the current
     coordinates and the has-in-edges reduction; the slab plan itself (owners, halo, exchange lists, their host read)
-    only when an atom has moved further than skin/2 since it was made.  The check's flag is read together with the
-    search's edge count -- the search runs optimistically on the old plan and is repeated after a re-plan."""
+    only when an atom has moved further than skin/2 since it was made (the check's flag is read back first, so a
+    re-plan step searches once).  The cell and the atomic numbers are watched by tensor identity and version: replace
+    them or edit them in place, never through `.data` (writes through `.data` or a numpy view do not bump the version)."""
 
     def __init__(self, atomic_number, cell, rc, rank, world, skin=1.0, axis=None, group=None, reference_compat=False):
         self.z, self.cell, self.rc, self.skin = atomic_number, cell, float(rc), float(skin)
@@ -581,6 +606,7 @@ class SlabStepper(object):
         self.plan = None
         self.replans = 0
         self._cell_key = None
+        self._z_key = (None, None)
 
     def _replan(self, pos):
         self.plan = plan_slab(pos, self.z, self.cell, self.rc, self.rank, self.world, axis=self.axis, group=self.group,
@@ -590,6 +616,10 @@ class SlabStepper(object):
     def __call__(self, pos):
         # (a cell that was replaced or edited in place -- NPT -- moves the slab bounds: plan again)
         cell_key = None if self.cell is None else (self.cell, self.cell._version)
+        z_key = (self.z, self.z._version)          # an in-place species swap changes plan.z_local
+        if self.plan is not None and (z_key[0] is not self._z_key[0] or z_key[1] != self._z_key[1]):
+            self.plan = None
+        self._z_key = z_key
         if self.plan is not None and (cell_key is None) != (self._cell_key is None):
             self.plan = None
         if self.plan is not None and cell_key is not None and (cell_key[0] is not self._cell_key[0] or cell_key[1] != self._cell_key[1]):
@@ -598,9 +628,8 @@ class SlabStepper(object):
         if self.plan is None or self.plan.pos_ref.shape != pos.shape:
             self._replan(pos)
             return slab_data(self.plan, pos, self.reference_compat), self.plan
-        moved = plan_moved(self.plan, pos)
-        local = slab_data(self.plan, pos, self.reference_compat)      # (its host read has waited for `moved` too)
-        if bool(moved):
+        # one 0-d read-back decides (the search's own host read follows anyway): on a re-plan step the search and the
+        # relation-flag reduction then run ONCE, on the new plan
+        if bool(plan_moved(self.plan, pos)):
             self._replan(pos)
-            local = slab_data(self.plan, pos, self.reference_compat)
-        return local, self.plan
+        return slab_data(self.plan, pos, self.reference_compat), self.plan

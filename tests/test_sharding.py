@@ -263,6 +263,31 @@ def test_neighbor_search_target_mask_is_the_filtered_list():
     assert torch.equal(eo_m, eo[:, mask[:200][eo[1]]])
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_shards_of_an_open_cluster_keep_the_reference_pipelines_capped_list(world):
+    """`reference_compat` on an open system caps every target at its 32 lowest source indices (`data.py:16`,
+    `radius_graph`'s default) -- indices of the WHOLE structure.  A shard lists owned atoms first and halo atoms behind
+    them, so the cap has to be taken on global ids: the shards' lists, mapped back, are exactly the unsharded capped
+    list (a dense cluster: most atoms have far more than 32 neighbours within rc)."""
+    from hermnet_amd.neighbor import neighbor_search
+    from hermnet_amd.sharding import partition_slab
+    rs = np.random.RandomState(3)
+    pos = torch.from_numpy(rs.uniform(0.0, 9.0, size=(400, 3)).astype(np.float32))
+    z = torch.from_numpy(rs.choice([1, 6, 8], size=400))
+    full = neighbor_search(pos, 5.0, None, reference_compat=True)
+    uncapped = neighbor_search(pos, 5.0, None)
+    assert uncapped.size(1) > full.size(1) and int(torch.bincount(full[1]).max()) == 32
+    got = []
+    for rank in range(world):
+        local, plan = partition_slab(pos, z, None, 5.0, rank, world, reference_compat=True)
+        lg = plan.local_global
+        assert bool(plan.owned_mask[local.edge_index[1]].all())
+        got.append(torch.stack([lg[local.edge_index[0]], lg[local.edge_index[1]]]))
+    got = torch.cat(got, 1)
+    key = lambda e: sorted(zip(e[1].tolist(), e[0].tolist()))
+    assert key(got) == key(full)
+
+
 @pytest.mark.parametrize("world", [2, 5])
 def test_slab_stepper_reuses_the_plan_under_the_skin(world):
     """A plan made with halo = rc + skin stays exact while no atom has moved further than skin/2: along a random walk
