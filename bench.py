@@ -198,6 +198,67 @@ def other_configs_secondary(hn, synth, dev, model_kw, steps=5, skip_c4=False):
     return res
 
 
+def count_launches(fn):
+    """Kernel launches of one call of `fn`, counted by the profiler (every device kernel, torch's included) ->
+    (all, this library's own)."""
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    names = [ev.name for ev in prof.events() if ev.device_type is not None and str(ev.device_type).endswith("CUDA")]
+    own = sum(1 for n_ in names if "anonymous namespace" in n_ or n_.startswith("void (anonymous"))
+    return len(names), own
+
+
+def reference_default_width_secondary(hn, synth, dev, data, model_kw, steps=10):
+    """The headline cell at the REFERENCE'S DEFAULT width, hidden_channels = 512 (hermnet.py:86; the width its examples
+    train at): the node chains run on csrc/node_chain_wide.hip, the message kernels on 8 column blocks."""
+    kw = dict(model_kw, hidden_channels=512)
+    model = hn.HVNet(["Al", "Ni", "Cu"], **kw).eval()
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), 10))
+    model = model.to(dev)
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    d = hn.Data(**{k: v for k, v in data if not k.startswith("_hn")})
+    d.pos = d.pos.detach()
+
+    def one():
+        d.pos.requires_grad_(True)
+        en = model(d)
+        return en, -torch.autograd.grad(en.sum(), d.pos)[0]
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    from hermnet_amd import ops
+    gt = ops.KernelTimer(prefix=("gemm", "node_", "message_"))
+    ops.set_kernel_timer(gt)
+    one()
+    torch.cuda.synchronize()
+    ops.set_kernel_timer(None)
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        en, f = one()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    dt = ts[len(ts) // 2]
+    n_all, n_own = count_launches(one)
+    N, H, T, L = d.pos.size(0), 512, 3, kw["num_layers"]
+    gs = gt.summary()
+    node_ms = sum(c * ms for k, (c, ms) in gs.items() if k.startswith("node_") or k == "gemm")
+    gflop = gemm_flops_per_step(N, N, H, T, L) / 1e9
+    return {"workload": "configs[1] cell (%d atoms, %d edges), HVNet hidden=512 num_rbf=%d layers=%d" %
+                        (N, d.edge_index.size(1), kw["num_rbf"], L),
+            "ms_per_step": dt * 1e3, "ms_per_step_min": ts[0] * 1e3, "atom_steps_per_s": N / dt,
+            "launches_per_step": n_all, "launches_per_step_own_kernels": n_own,
+            "node_chain_ms_per_step": node_ms, "node_gflop_per_step": gflop,
+            "node_mfma_util": (gflop / node_ms / FP32_MFMA_PEAK_TF) if node_ms > 0 else None,
+            "kernels_ms": {k: {"launches": c, "avg_ms": ms} for k, (c, ms) in gs.items()},
+            "energy": float(en.detach()[0])}
+
+
 def graph_replay_secondary(hn, synth, dev, model, data, model_kw, steps=20):
     """ms per step of whole-step hipGraph replay: the headline workload and the 1024-molecule batch (launch-bound
     when enqueued eagerly)."""
@@ -296,8 +357,8 @@ def chain_kernel_bounds(gsum, N, nk, H, T):
     peak for this grid.  `frac` = that bound / measured time per launch; `clock` 2.4 GHz as the peak assumes (the
     in-kernel clock stamps see ~2.0 GHz under this load: `frac_at_2GHz`)."""
     cus, flop_per_clk_cu = 256, 256.0
-    tr_pre = 32 if H == 256 else 64
-    tr_upd = 64 if H == 64 else 32
+    from hermnet_amd import nodeops
+    tr_pre, tr_upd = nodeops.chain_tile_rows(H), nodeops.chain_tile_rows(H, update=True)
     grids = {"node_pre_fwd": ((N + tr_pre - 1) // tr_pre * T, 8.0 * tr_pre * H * H),
              "node_pre_bwd": ((N + tr_pre - 1) // tr_pre * T, 8.0 * tr_pre * H * H),
              "node_update_fwd": ((nk + tr_upd - 1) // tr_upd, 22.0 * tr_upd * H * H),
@@ -711,16 +772,15 @@ def main():
                 out["secondary"]["single_gpu_same_cell"] = {"error": repr(ex)}
         if world == 1 and not sharded and not args.no_secondary:
             try:      # kernel launches of ONE step, counted by the profiler (every device kernel, torch's included)
-                from torch.profiler import ProfilerActivity, profile
-                with profile(activities=[ProfilerActivity.CUDA]) as prof:
-                    step()
-                    torch.cuda.synchronize()
-                names = [ev.name for ev in prof.events() if ev.device_type is not None and str(ev.device_type).endswith("CUDA")]
-                out["secondary"]["launches_per_step"] = len(names)
-                out["secondary"]["launches_per_step_own_kernels"] = sum(
-                    1 for n_ in names if "anonymous namespace" in n_ or n_.startswith("void (anonymous"))
+                out["secondary"]["launches_per_step"], out["secondary"]["launches_per_step_own_kernels"] = count_launches(step)
             except Exception as ex:
                 out["secondary"]["launches_per_step"] = {"error": repr(ex)}
+            if cfg == "c2":
+                try:
+                    out["secondary"]["reference_default_width_h512"] = reference_default_width_secondary(
+                        hn, synth, dev, data, model_kw)
+                except Exception as ex:
+                    out["secondary"]["reference_default_width_h512"] = {"error": repr(ex)}
             # the same step captured once and replayed as ONE hipGraph launch (valid while the neighbour list is
             # unchanged, hermnet_amd/graph.py): what the GPU needs when the host is out of the loop
             try:

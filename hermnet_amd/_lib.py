@@ -85,6 +85,7 @@ SIGNATURES = {
     "hermnet_energy_head_fused_fwd": (ctypes.c_int, [c_fp] * 8 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_energy_head_fused_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_node_chain_supported": (ctypes.c_int, [ctypes.c_int]),
+    "hermnet_node_chain_tile_rows": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "hermnet_node_pre_fwd": (ctypes.c_int, [c_fp] * 10 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                         ctypes.c_float, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_node_pre_bwd": (ctypes.c_int, [c_fp] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp,

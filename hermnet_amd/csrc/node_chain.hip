@@ -26,298 +26,12 @@
 //     (s|a|b, v1|v2, p|q|r), so products of parts (vec_dot, q * vdot, r * v1) are lane-local.
 // Two workgroups per CU (<= 68 KB of LDS, <= 256 VGPRs): one's elementwise / staging phases run beside the other's
 // matrix phases.  fp32 MFMA is exact fp32 (a k-ordered fmaf chain): results equal a library GEMM's to rounding.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdlib.h>
-#include "../../include/hermnet_hip.h"
+#include "node_chain_common.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr float kInvSqrt2 = 0.70710678118654752f;
-constexpr float kSiluScale = 1.0f / 0.6f;
-
-// (v_rcp_f32: 1 ulp; an IEEE division costs ten instructions per element in the epilogues)
-__device__ __forceinline__ float sigmoid_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float ssilu(float x) { return x * sigmoid_(x) * kSiluScale; }
-__device__ __forceinline__ float dssilu(float x) {
-  const float s = sigmoid_(x);
-  return s * (1.0f + x * (1.0f - s)) * kSiluScale;
-}
-// An empty volatile asm that "reads and writes" x: the value must exist HERE (pure arithmetic is otherwise free to sink
-// below barriers to its first use, which keeps every accumulator it reads alive until then and spills).
-__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
-// Nothing moves across this point: the "memory" clobber orders the compiler's loads and stores (IR and selection DAG),
-// the scheduling barrier the machine scheduler.
-__device__ __forceinline__ void fence_sched() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
-
-// Diagnostic build (-DHN_STAMPS): wave 0 of every workgroup records the shader clock at phase boundaries into a buffer
-// of its own (tools/chain_stamps.py reads it back); no stamp executes in the product build.
-#ifdef HN_STAMPS
-__device__ unsigned long long hn_stamps[8192 * 16];
-#define STAMP_HWID()                                                                                 \
-  do {                                                                                               \
-    if (threadIdx.x == 0) {                                                                          \
-      unsigned hw, xcc;                                                                              \
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                               \
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                             \
-      hn_stamps[((blockIdx.x + gridDim.x * blockIdx.y) & 8191) * 16 + 15] = ((unsigned long long)xcc << 32) | hw; \
-    }                                                                                                \
-  } while (0)
-#define STAMP(k)                                                                                     \
-  do {                                                                                               \
-    if (threadIdx.x == 0)                                                                            \
-      hn_stamps[((blockIdx.x + gridDim.x * blockIdx.y) & 8191) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define STAMP(k)
-#define STAMP_HWID()
-#endif
-
-// Geometry of a TR-row tile of width H on a 256-thread workgroup (4 waves).
-template <int H_, int TR_>
-struct Cfg {
-  static constexpr int H = H_, TR = TR_;
-  static constexpr int CB = H / 32;                 // 32-channel blocks
-  static constexpr int WC = CB < 4 ? CB : 4;        // waves along the channels
-  static constexpr int WR = 4 / WC;                 // waves along the rows
-  static constexpr int CPW = CB / WC;               // channel blocks per wave
-  static constexpr int RB = TR / 32 / WR;           // 32-row blocks per wave
-  static constexpr int LD = H + 4;                  // LDS row stride of a [TR][H] tile
-  static constexpr int F4 = TR * H / 4 / 256;       // float4 per thread of a cooperative [TR][H] tile copy
-  static_assert(CB % WC == 0 && (TR / 32) % WR == 0 && RB >= 1 && F4 >= 1, "unsupported tile");
-};
-
-// ---- B operand: a ring of RS weight fragments per column block, RS - 1 k-groups ahead of use -------------------------
-// One wave per SIMD has nobody to hide a late operand: a k-group is RB * NJ * 4 MFMAs = RB * NJ * 256 cycles, an L2 hit
-// under load 500-800: three groups ahead.
-template <int NJ, int RS>
-struct BRing { f32x4 v[RS][NJ]; };
-
-// ring slots of a product with RB x NJ accumulator blocks per wave
-constexpr int ring_size(int rb_nj, bool more) { return 4; }
-
-// first RS - 1 k-groups of a stream (call it early: before the barrier / epilogue that precedes the product)
-template <int NJ, int RS>
-__device__ __forceinline__ void b_preload(BRing<NJ, RS>& r, const f32x4* const (&bp)[NJ]) {
-#pragma unroll
-  for (int g = 0; g < RS - 1; ++g)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) r.v[g][j] = bp[j][g * 64];
-}
-
-// acc[rb][j] += W_j[k-groups 0 .. KP/8) . A[rows of block rb]^T, W_j streamed from bp[j] (this lane's pointer at group 0
-// of the panel).  `As`: this lane's LDS read pointer, &tile[(first row of the wave + (l & 31)) * LD + 4 (l >> 5)].
-// The ring holds groups 0 .. RS-2 on entry.  MORE: the stream continues behind this panel (next panel of the same
-// product): its first RS - 1 groups are requested too and sit in slots 0 .. RS-2 on exit (needs KP/8 % RS == 0).
-template <int KP, int LD, int RB, int NJ, int RS, bool MORE>
-__device__ __forceinline__ void mma_panel(f32x16 (&acc)[RB][NJ], const float* As, const f32x4* const (&bp)[NJ],
-                                          BRing<NJ, RS>& ring) {
-  constexpr int NQ = KP / 8, PF = RS - 1;
-  static_assert(NQ % RS == 0 && RS % 2 == 0, "panel / ring mismatch");
-  f32x4 a[2][RB];                                       // LDS reads one k-group ahead
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(As + rb * 32 * LD);
-  // One k-group: request the weight group PF ahead and the tile group 1 ahead, then RB x NJ x 4 MFMAs.  The groups
-  // run RS at a time in a ROLLED loop (ring slots are then compile-time constants): a fully unrolled chain kernel is
-  // 50-60 KB of code -- more than the instruction cache -- and hipcc's scheduler, handed a whole panel as one region,
-  // spills what the caller keeps in flight around the product.
-  auto group = [&](int q0, int qq, bool load_b, bool load_a) {
-    const int q = q0 + qq;
-    if (load_b) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) ring.v[(qq + PF) % RS][j] = bp[j][(q + PF) * 64];
-    }
-    if (load_a) {
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) a[(qq + 1) & 1][rb] = *reinterpret_cast<const f32x4*>(As + rb * 32 * LD + 8 * (q + 1));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring.v[qq % RS][j][i], a[qq & 1][rb][i], acc[rb][j], 0, 0, 0);
-  };
-#pragma unroll 1
-  for (int q0 = 0; q0 < NQ - RS; q0 += RS) {
-#pragma unroll
-    for (int qq = 0; qq < RS; ++qq) group(q0, qq, true, true);
-  }
-#pragma unroll
-  for (int qq = 0; qq < RS; ++qq) group(NQ - RS, qq, MORE || qq + PF < RS, qq + 1 < RS);
-}
-
-template <int RB, int NJ>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[RB][NJ]) {
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[rb][j][i] = 0.f;
-}
-
-// Per-tile buffer descriptors: every per-lane global access of a tile is `uniform base + 32-bit offset` through a raw
-// buffer instruction whose range check replaces the row guards (rows past the tile's last valid row load 0 and drop
-// their stores) -- no exec-mask branches and no 64-bit address arithmetic in the epilogues.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ rsrc_t tile_rsrc(const float* base, int valid_floats) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, valid_floats > 0 ? valid_floats * 4 : 0, 0x00020000);
-}
-__device__ __forceinline__ float bld(rsrc_t r, int off) {
-#ifdef HN_KO_LOADS     // diagnostic build: no epilogue / staging loads (results wrong, time meaningful)
-  return 1.0f;
-#endif
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off * 4, 0, 0));
-}
-__device__ __forceinline__ void bst(rsrc_t r, int off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off * 4, 0, 0);
-}
-#ifdef HN_KO_STORES    // diagnostic build: a store only when the value is NaN-patterned (never), so the work stays live
-#define HN_STORE_IF(v) if (__builtin_expect((v)[0] == 1.2345e-30f, 0))
-#else
-#define HN_STORE_IF(v)
-#endif
-__device__ __forceinline__ f32x4 bld4(rsrc_t r, int off) {
-#ifdef HN_KO_LOADS
-  return (f32x4){1.f, 0.5f, 0.25f, 2.f};
-#endif
-  const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, off * 4, 0, 0);
-  return __builtin_bit_cast(f32x4, u);
-}
-__device__ __forceinline__ void bst4(rsrc_t r, int off, f32x4 v) {
-  HN_STORE_IF(v)
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off * 4, 0, 0);
-}
-
-// Coalesced store of one 32 x 32 accumulator block through a wave-private LDS transpose.  A lane owns a ROW of the
-// block: stored straight from the registers, one instruction would write 64 16-byte pieces into 32 different rows
-// (measured: ~750 cycles per instruction, 5 B/clk/CU -- the epilogues took as long as the products).  Instead the four
-// runs go to this wave's scratch [32][36] (ds_write_b128, lane = row) and come back as 4 x (8 rows x 128 contiguous
-// bytes): the same number of store instructions, each writing whole 128-byte lines.  LDS operations of one wave execute
-// in order, so no barrier or wait is needed between the two halves.  `off_block`: float offset of the block's first
-// row / first channel in the destination, LDG its row stride.
-constexpr int kScrLd = 36, kScrFloats = 32 * kScrLd;
-template <int LDG>
-__device__ __forceinline__ void store_block(float* scr, int lane, const f32x4 (&v)[4], rsrc_t r, int off_block) {
-  const int m = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(scr + m * kScrLd + 8 * g + 4 * h) = v[g];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int rr = it * 8 + (lane >> 3), c = (lane & 7) * 4;
-    bst4(r, off_block + rr * LDG + c, *reinterpret_cast<const f32x4*>(scr + rr * kScrLd + c));
-  }
-}
-
-// The same for loads, in two steps so that the memory round trip hides behind a product: `issue` requests the block as
-// 4 x (8 rows x 128 contiguous bytes) into registers, `finish` (any time later) passes it through the scratch and
-// returns the four runs of this lane's row.
-struct BlockLoad { f32x4 v[4]; };
-template <int LDG>
-__device__ __forceinline__ void issue_block(BlockLoad& b, int lane, rsrc_t r, int off_block) {
-#pragma unroll
-  for (int it = 0; it < 4; ++it) b.v[it] = bld4(r, off_block + (it * 8 + (lane >> 3)) * LDG + (lane & 7) * 4);
-}
-__device__ __forceinline__ void finish_block(float* scr, int lane, const BlockLoad& b, f32x4 (&out)[4]) {
-#pragma unroll
-  for (int it = 0; it < 4; ++it)
-    *reinterpret_cast<f32x4*>(scr + (it * 8 + (lane >> 3)) * kScrLd + (lane & 7) * 4) = b.v[it];
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-    out[g] = *reinterpret_cast<const f32x4*>(scr + (lane & 31) * kScrLd + 8 * g + 4 * (lane >> 5));
-}
-
-// Accumulator block (rb, cb) of D^T = W . A^T: lane l holds tile row  (first row of the wave) + 32 rb + (l & 31)  and the
-// channels  32 cb + 8 g + 4 (l >> 5) + e  in register 4 g + e  (g, e < 4): run g of the block as one float4.
-__device__ __forceinline__ f32x4 run4(const f32x16& acc, int g) {
-  return (f32x4){acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-}
-__device__ __forceinline__ void set_run4(f32x16& acc, int g, f32x4 v) {
-  acc[4 * g] = v[0]; acc[4 * g + 1] = v[1]; acc[4 * g + 2] = v[2]; acc[4 * g + 3] = v[3];
-}
-__device__ __forceinline__ f32x4 ssilu4(f32x4 v) { return (f32x4){ssilu(v[0]), ssilu(v[1]), ssilu(v[2]), ssilu(v[3])}; }
-__device__ __forceinline__ f32x4 dssilu4(f32x4 v) { return (f32x4){dssilu(v[0]), dssilu(v[1]), dssilu(v[2]), dssilu(v[3])}; }
-__device__ __forceinline__ f32x4 ld4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void pin4(f32x4& v) { asm volatile("" : "+v"(v)); }
-
-// cooperative copy of a [TR][W] tile (row stride `ld_src` floats in global memory) through registers
-template <int TR, int W>
-struct TileRegs { f32x4 v[TR * W / 4 / 256]; };
-
-// `src`: descriptor of the tile's rows (valid range = nrows * ld_src floats), `off0`: float offset of the first column
-template <int TR, int W>
-__device__ __forceinline__ void tile_load(TileRegs<TR, W>& r, rsrc_t src, int ld_src, int off0, int tid) {
-  constexpr int V = W / 4, F4 = TR * W / 4 / 256;
-#pragma unroll
-  for (int it = 0; it < F4; ++it) {
-    const int idx = tid + it * 256, row = idx / V, c4 = idx % V;
-    r.v[it] = bld4(src, row * ld_src + off0 + c4 * 4);
-  }
-}
-template <int TR, int W, int LD>
-__device__ __forceinline__ void tile_store(float* tile, const TileRegs<TR, W>& r, int tid) {
-  constexpr int V = W / 4, F4 = TR * W / 4 / 256;
-#pragma unroll
-  for (int it = 0; it < F4; ++it) {
-    const int idx = tid + it * 256, row = idx / V, c4 = idx % V;
-    *reinterpret_cast<f32x4*>(tile + row * LD + c4 * 4) = r.v[it];
-  }
-}
-
 // =====================================================================================================================
 // node_pre_fwd: one workgroup = (TR source rows, relation t)
 // =====================================================================================================================
-struct PreFwdArgs {
-  const float* x;      // [Ns, H]
-  const float* w1f;    // [T] fragments of W1_t [H, H]   (LayerNorm affine folded in)
-  const float* b1;     // [T, H]
-  const float* w2f;    // [T] fragments of W2_t [3H, H]
-  const float* b2;     // [T, 3H]
-  float* hb;           // [T, Ns, H]   pre-activation incl. bias (saved for the backward)
-  float* xh;           // [T, Ns, 3H]  incl. bias
-  float* mean;         // [Ns]
-  float* rstd;         // [Ns]
-  const int* src_ranges;   // [T][4] or null: relation t only ever gathers source rows [r0, r1) and [r2, r3)
-  int Ns, T, Hr;
-  float eps;
-  const int* windows;      // [nwin][2] row windows or null (see tile_selected)
-  int nwin, wmode;
-};
-
-// Row windows (atom shards, sharding.py: the halo rows close every relation's row block): a launch with wmode 1 runs
-// only the tiles that touch a window, wmode 2 only the others -- the rows that do not wait for the halo exchange are
-// projected while it is in flight, the rest after it (backward: the halo tiles first, so that their gradients travel
-// while the others are computed).  The two launches partition the tiles; wmode 0 runs all of them.
-__device__ __forceinline__ bool tile_selected(const int* __restrict__ win, int nwin, int wmode, int row0, int TR) {
-  if (wmode == 0) return true;
-  bool inside = false;
-  for (int k = 0; k < nwin; ++k) {
-    const int lo = win[2 * k], hi = win[2 * k + 1];
-    inside |= hi > lo && row0 < hi && row0 + TR > lo;
-  }
-  return inside == (wmode == 1);
-}
-
-// HTNet: relation (c; p, q) gathers source rows of elements p and q only -- tiles outside both row ranges are skipped
-__device__ __forceinline__ bool tile_wanted(const int* __restrict__ ranges, int t, int row0, int TR) {
-  if (ranges == nullptr) return true;
-  const int r0 = ranges[4 * t], r1 = ranges[4 * t + 1], r2 = ranges[4 * t + 2], r3 = ranges[4 * t + 3];
-  return (row0 < r1 && row0 + TR > r0) || (row0 < r3 && row0 + TR > r2);
-}
 
 template <int H, int TR>
 __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
@@ -447,17 +161,6 @@ constexpr int pre_bwd_lds_floats(int H, int TR) {
   return chunks > tail ? chunks : tail;
 }
 
-struct PreBwdArgs {
-  const float* gxh;    // [T, Ns, 3H]
-  const float* hb;     // [T, Ns, H]
-  const float* w2tf;   // [T] fragments of W2_t^T [H, 3H]
-  const float* w1tf;   // [T] fragments of W1_t^T [H, H]
-  float* gn;           // [T, Ns, H]
-  const int* src_ranges;   // as in PreFwdArgs; skipped tiles contribute zero rows to gn[t]
-  int Ns, T;
-  const int* windows;      // as in PreFwdArgs
-  int nwin, wmode;
-};
 
 template <int H, int TR>
 __global__ __launch_bounds__(256, 2) void node_pre_bwd_kernel(PreBwdArgs a) {
@@ -549,95 +252,10 @@ __global__ __launch_bounds__(256, 2) void node_pre_bwd_kernel(PreBwdArgs a) {
     }
 }
 
-// gx = LayerNorm'(x)^T (sum_p g[p]) + add : the backward of the LayerNorm in front of the T relations' projections
-__global__ __launch_bounds__(256) void layernorm_bwd_parts_kernel(const float* __restrict__ g, int nparts, long part_stride,
-                                                                  const float* __restrict__ x, const float* __restrict__ mean,
-                                                                  const float* __restrict__ rstd, const float* __restrict__ add,
-                                                                  float* __restrict__ gx, int rows, int H, int Hr,
-                                                                  const int* __restrict__ windows, int nwin, int wmode,
-                                                                  int TR) {
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
-  if (!tile_selected(windows, nwin, wmode, r / TR * TR, TR)) return;     // the rows of the pre kernel's tiles
-  const int lane = threadIdx.x & 63;
-  const float mu = mean[r], rs = rstd[r];
-  constexpr int KMAX = 4;                        // H <= 1024
-  f32x4 gv[KMAX], nh[KMAX];
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    const int c = (k * 64 + lane) * 4;
-    gv[k] = nh[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (c < H) {
-      f32x4 gg = *reinterpret_cast<const f32x4*>(g + (size_t)r * H + c);
-      for (int p = 1; p < nparts; ++p) gg += *reinterpret_cast<const f32x4*>(g + p * part_stride + (size_t)r * H + c);
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)r * H + c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float m = c + e < Hr ? 1.f : 0.f;
-        gv[k][e] = gg[e] * m;
-        nh[k][e] = (xv[e] - mu) * rs * m;
-        s1 += gv[k][e];
-        s2 = fmaf(gv[k][e], nh[k][e], s2);
-      }
-    }
-  }
-  const float m1 = wave_sum(s1) / (float)Hr, m2 = wave_sum(s2) / (float)Hr;
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    const int c = (k * 64 + lane) * 4;
-    if (c < H) {
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = c + e < Hr ? rs * (gv[k][e] - m1 - nh[k][e] * m2) : 0.f;
-      if (add != nullptr) o += *reinterpret_cast<const f32x4*>(add + (size_t)r * H + c);
-      *reinterpret_cast<f32x4*>(gx + (size_t)r * H + c) = o;
-    }
-  }
-}
-
-// =====================================================================================================================
-// Tiles of the TARGET rows: relation blocks [type_rowptr[t], type_rowptr[t+1]) cut into TR-row tiles, then the rows of
-// unknown elements [type_rowptr[T], N) (zero rows, hermnet.py:51).
-// =====================================================================================================================
-struct TileInfo { int t, row0, nrows; };
-
-__device__ __forceinline__ TileInfo find_tile(const int* __restrict__ type_rowptr, int T, int N, int TR, int tile) {
-  int first = 0;
-  for (int t = 0; t < T; ++t) {
-    const int lo = type_rowptr[t], hi = type_rowptr[t + 1];
-    const int nt = (hi - lo + TR - 1) / TR;
-    if (tile < first + nt) {
-      const int row0 = lo + (tile - first) * TR;
-      return {t, row0, min(TR, hi - row0)};
-    }
-    first += nt;
-  }
-  const int row0 = type_rowptr[T] + (tile - first) * TR;
-  return {T, row0, min(TR, N - row0)};
-}
 
 // =====================================================================================================================
 // node_update_fwd (rmnet.py:94-107 + the residual of rmnet.py:29-31 + the zero rows of hermnet.py:51,56-57)
 // =====================================================================================================================
-struct UpdFwdArgs {
-  const float* x1;          // [N, H]
-  const float* vec1;        // [N, 3, H]
-  const float* wvf;         // [T] fragments of vec_proj.weight [2H, H]
-  const float* wx0f;        // [T] fragments of xvec_proj[0].weight [H, 2H]
-  const float* bx0;         // [T, H]
-  const float* wx2f;        // [T] fragments of xvec_proj[2].weight [3H, H]
-  const float* bx2;         // [T, 3H]
-  const float* row_active;  // [N] or null
-  const int* type_rowptr;   // [T+1]
-  float* vp;                // [N, 3, 2H]  (v1 | v2), saved
-  float* h2b;               // [N, H]      xvec_proj[0] output incl. bias, saved
-  float* q23;               // [N, 2H]     (q | r) incl. bias, saved
-  float* nrm;               // [N, H]      sqrt(sum_d v2^2 + 1e-8), saved
-  float* x_out;             // [N, H]
-  float* vec_out;           // [N, 3, H]
-  int N, T;
-};
 
 template <int H, int TR, int MINW>
 __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a) {
@@ -847,22 +465,6 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
 // =====================================================================================================================
 // node_update_bwd: (gx_out, gvec_out) -> (gx1, gvec1), parameters are constants
 // =====================================================================================================================
-struct UpdBwdArgs {
-  const float* gxo;         // [N, H]
-  const float* gvo;         // [N, 3, H]
-  const float* vp;          // [N, 3, 2H]
-  const float* h2b;         // [N, H]
-  const float* q23;         // [N, 2H]
-  const float* nrm;         // [N, H]
-  const float* wx2tf;       // [T] fragments of xvec_proj[2].weight^T [H, 3H]
-  const float* wx0tf;       // [T] fragments of xvec_proj[0].weight^T [2H, H]
-  const float* wvtf;        // [T] fragments of vec_proj.weight^T [H, 2H]
-  const float* row_active;  // [N] or null
-  const int* type_rowptr;
-  float* gx1;               // [N, H]
-  float* gvec1;             // [N, 3, H]
-  int N, T;
-};
 
 template <int H, int TR, int MINW>
 __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a) {
@@ -1099,29 +701,6 @@ __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a
   }
 }
 
-int tiles_of(const int* rp_host, int T, int N, int TR) {
-  int n = 0;
-  for (int t = 0; t < T; ++t) n += (rp_host[t + 1] - rp_host[t] + TR - 1) / TR;
-  return n + (N - rp_host[T] + TR - 1) / TR;
-}
-
-// Launch with `lds_bytes` of dynamic LDS (> 64 KB needs the opt-in, once per kernel).
-template <typename Args>
-int launch_chain(void (*kernel)(Args), dim3 grid, size_t lds_bytes, void* stream, const Args& args) {
-  static void (*done[8])(Args);
-  static int ndone = 0;
-  bool seen = false;
-  for (int i = 0; i < ndone; ++i) seen |= done[i] == kernel;
-  if (!seen) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds_bytes) != hipSuccess)
-      return HN_ERR_LDS;
-    if (ndone < 8) done[ndone++] = kernel;
-  }
-  hipLaunchKernelGGL(kernel, grid, dim3(256), lds_bytes, (hipStream_t)stream, args);
-  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
-}
-
 // LDS floats of a kernel family for tile (H, TR): NB buffers of [TR][H + 4]
 #define HN_CHAIN_DISPATCH(KERNEL, GRID, NB, ARGS)                                                          \
   switch (hidden) {                                                                                        \
@@ -1161,7 +740,30 @@ extern "C" int hermnet_debug_stamps(unsigned long long* out_host, int count) {
 }
 #endif
 
-extern "C" int hermnet_node_chain_supported(int hidden) { return hidden == 64 || hidden == 128 || hidden == 256; }
+// node_chain_wide.hip: the same four chains for every multiple of 64 from 128 to 512
+int hn_wide_pre_fwd(int hidden, const PreFwdArgs& a, void* stream);
+int hn_wide_pre_bwd(int hidden, const PreBwdArgs& a, void* stream);
+int hn_wide_update_fwd(int hidden, const UpdFwdArgs& a, int tiles, void* stream);
+int hn_wide_update_bwd(int hidden, const UpdBwdArgs& a, int tiles, void* stream);
+
+// Widths 64 / 128 / 256 have tuned instances in this file; every other multiple of 64 up to 512 -- the reference's default
+// hidden_channels = 512 among them (hermnet.py:86) -- takes the panelled kernels.  HERMNET_NODE_CHAIN_WIDE=1 sends 128 and
+// 256 there too (tests, comparisons).
+static bool use_wide(int hidden) {
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("HERMNET_NODE_CHAIN_WIDE"); force = e ? atoi(e) : 0; }
+  if (hidden == 64) return false;
+  return force != 0 || !(hidden == 128 || hidden == 256);
+}
+// rows per tile of the pre kernels (the row windows of the halo overlap are cut at these boundaries)
+static int pre_tile_rows(int hidden) { return use_wide(hidden) ? 32 : (hidden == 256 ? 32 : 64); }
+
+extern "C" int hermnet_node_chain_supported(int hidden) { return hidden >= 64 && hidden <= 512 && hidden % 64 == 0; }
+extern "C" int hermnet_node_chain_tile_rows(int hidden, int update) {
+  if (!hermnet_node_chain_supported(hidden)) return 0;
+  if (update) return use_wide(hidden) ? 32 : (hidden == 64 ? 64 : 32);
+  return pre_tile_rows(hidden);
+}
 
 extern "C" int hermnet_node_pre_fwd(const float* x, const float* w1_frag, const float* b1, const float* w2_frag,
                                     const float* b2, float* hb, float* xh, float* mean, float* rstd,
@@ -1174,6 +776,7 @@ extern "C" int hermnet_node_pre_fwd(const float* x, const float* w1_frag, const 
   if (!x || !w1_frag || !b1 || !w2_frag || !b2 || !hb || !xh || !mean || !rstd) return HN_ERR_BAD_ARG;
   PreFwdArgs a = {x, w1_frag, b1, w2_frag, b2, hb, xh, mean, rstd, src_ranges, num_src, num_rel, hidden_real > 0 ? hidden_real : hidden, eps,
                   row_windows, num_windows, window_mode};
+  if (use_wide(hidden)) return hn_wide_pre_fwd(hidden, a, stream);
 #define HN_GRID(TR) dim3((unsigned)((num_src + TR - 1) / TR), (unsigned)num_rel)
   HN_CHAIN_DISPATCH(node_pre_fwd_kernel, HN_GRID, 1, a);
 }
@@ -1191,7 +794,8 @@ extern "C" int hermnet_node_pre_bwd(const float* gxh, const float* hb, const flo
   PreBwdArgs a = {gxh, hb, w2t_frag, w1t_frag, gn_parts, src_ranges, num_src, num_rel, row_windows, num_windows, window_mode};
   // chunk buffers: 2 x [TR][min(H,128) + 4]
   int rc;
-  switch (hidden) {
+  if (use_wide(hidden)) rc = hn_wide_pre_bwd(hidden, a, stream);
+  else switch (hidden) {
     case 64: rc = launch_chain(node_pre_bwd_kernel<64, 64>, HN_GRID(64), (size_t)pre_bwd_lds_floats(64, 64) * 4, stream, a); break;
     case 128: rc = launch_chain(node_pre_bwd_kernel<128, 64>, HN_GRID(64), (size_t)pre_bwd_lds_floats(128, 64) * 4, stream, a); break;
     default: rc = launch_chain(node_pre_bwd_kernel<256, 32>, HN_GRID(32), (size_t)pre_bwd_lds_floats(256, 32) * 4, stream, a); break;
@@ -1200,7 +804,7 @@ extern "C" int hermnet_node_pre_bwd(const float* gxh, const float* hb, const flo
   if (rc != HN_OK) return rc;
   hipLaunchKernelGGL(layernorm_bwd_parts_kernel, dim3((unsigned)((num_src + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      gn_parts, num_rel, (long)num_src * hidden, x, mean, rstd, add, gx, num_src, hidden,
-                     hidden_real > 0 ? hidden_real : hidden, row_windows, num_windows, window_mode, hidden == 256 ? 32 : 64);
+                     hidden_real > 0 ? hidden_real : hidden, row_windows, num_windows, window_mode, pre_tile_rows(hidden));
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
 
@@ -1217,6 +821,7 @@ extern "C" int hermnet_node_update_fwd(const float* x1, const float* vec1, const
     return HN_ERR_BAD_ARG;
   UpdFwdArgs a = {x1, vec1, wv_frag, wx0_frag, bx0, wx2_frag, bx2, row_active, type_rowptr, vp, h2b, q23, nrm, x_out,
                   vec_out, num_nodes, num_rel};
+  if (use_wide(hidden)) return hn_wide_update_fwd(hidden, a, HN_TILES(32), stream);
   HN_UPDATE_DISPATCH(node_update_fwd_kernel, a);
 }
 
@@ -1233,5 +838,6 @@ extern "C" int hermnet_node_update_bwd(const float* gx_out, const float* gvec_ou
     return HN_ERR_BAD_ARG;
   UpdBwdArgs a = {gx_out, gvec_out, vp, h2b, q23, nrm, wx2t_frag, wx0t_frag, wvt_frag, row_active, type_rowptr, gx1, gvec1,
                   num_nodes, num_rel};
+  if (use_wide(hidden)) return hn_wide_update_bwd(hidden, a, HN_TILES(32), stream);
   HN_UPDATE_DISPATCH(node_update_bwd_kernel, a);
 }

@@ -166,8 +166,15 @@ def halo_accumulate(x, vec, plan, buf):
 
 # ---- node chain kernels (csrc/node_chain.hip): one launch per chain on the fp32 matrix pipe ---------------------------
 def chain_supported(H):
-    """Widths the chain kernels are instantiated for (other widths: library GEMMs + the stage kernels above)."""
-    return H in (64, 128, 256)
+    """Widths the chain kernels are instantiated for: every multiple of 64 up to 512 (csrc/node_chain.hip for 64 / 128 /
+    256, csrc/node_chain_wide.hip for the rest).  Anything else -- i.e. padded widths beyond 512 -- takes library GEMMs +
+    the stage kernels above."""
+    return bool(_lib.load().hermnet_node_chain_supported(int(H)))
+
+
+def chain_tile_rows(H, update=False):
+    """Rows per tile of the pre (or update) chain kernels at width H: the granularity of the row windows."""
+    return int(_lib.load().hermnet_node_chain_tile_rows(int(H), 1 if update else 0))
 
 
 def weight_fragments(w):

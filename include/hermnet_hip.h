@@ -329,10 +329,13 @@ int hermnet_energy_head_fused_bwd(const float* ge, const float* h, const float* 
  *     (w2t_frag = frag(W2_t^T [H, 3H]), w1t_frag = frag(W1_t^T [H, H]); gn_parts [T, num_src, H] is workspace; add may
  *     be NULL; gx may alias add).
  * row_windows (device, [num_windows][2] int32 row ranges) + window_mode (ABI v6; atom shards, no reference counterpart):
- *     0 = every row tile (row_windows may be NULL); 1 = only the tiles (64 rows; 32 at hidden 256) that touch a window;
+ *     0 = every row tile (row_windows may be NULL); 1 = only the tiles (hermnet_node_chain_tile_rows) that touch a window;
  *     2 = only the others.  Two calls with modes 2 and 1 on the same buffers compute what one call with mode 0 does:
  *     the host puts the halo exchange between them (forward: 2, wait + unpack, 1; backward: 1, send, 2). */
-int hermnet_node_chain_supported(int hidden);
+int hermnet_node_chain_supported(int hidden);   /* hidden % 64 == 0, 64 <= hidden <= 512 (the reference's default is 512) */
+/* Rows per tile of the pre kernels (update = 0) or the update kernels (update != 0) at this width: 64 / 32; 0 when the
+ * width is not supported.  The tiles of window modes 1 / 2 are cut at multiples of it. */
+int hermnet_node_chain_tile_rows(int hidden, int update);
 int hermnet_node_pre_fwd(const float* x, const float* w1_frag, const float* b1, const float* w2_frag, const float* b2,
                          float* hb, float* xh, float* mean, float* rstd, const int* src_ranges, int num_src,
                          int num_rel, int hidden, int hidden_real, float eps, const int* row_windows, int num_windows,

@@ -192,7 +192,8 @@ def update_mid_bwd(gvdot, gxin, vp, xin, gvp, gx1, rows, H):
 # ---- node chain kernels (hermnet_amd.nodeops.node_*; csrc/node_chain.hip): same contracts, plain weights of `w` --------
 def _tile_rows(Ns, H, windows, mode, device):
     """Rows of the tiles a windowed launch of the pre kernels runs (csrc/node_chain.hip: tile_selected)."""
-    TR = 32 if H == 256 else 64
+    from hermnet_amd import nodeops
+    TR = nodeops.chain_tile_rows(H)
     row0 = torch.arange(Ns, device=device) // TR * TR
     inside = torch.zeros(Ns, dtype=torch.bool, device=device)
     for lo, hi in windows.tolist():

@@ -254,7 +254,12 @@ def test_node_kernels_match_pytorch_restatement():
 @pytest.mark.parametrize("H,T,counts,uniform,hr", [(128, 3, (70, 91, 45), None, 0), (128, 3, (130, 3, 61), False, 0),
                                                    (64, 2, (100, 77), None, 50), (256, 3, (40, 33, 50), None, 0),
                                                    (128, 1, (300,), None, 0), (128, 3, (4000, 3900, 4100), None, 0),
-                                                   (128, 3, (7000, 7100, 6900), None, 0)])
+                                                   (128, 3, (7000, 7100, 6900), None, 0),
+                                                   # every other multiple of 64 up to the reference's default width
+                                                   # (csrc/node_chain_wide.hip; odd multiples leave a round half empty)
+                                                   (192, 3, (40, 33, 50), None, 0), (320, 2, (70, 29), None, 0),
+                                                   (384, 3, (33, 64, 31), False, 0), (448, 2, (50, 41), None, 0),
+                                                   (512, 3, (40, 33, 50), None, 0), (512, 1, (700,), None, 0)])
 def test_node_chain_kernels_match_restatement(H, T, counts, uniform, hr):
     """csrc/node_chain.hip (LayerNorm + x_proj chain, PaiNNUpdate chain and their backward kernels on the fp32 matrix
     pipe) vs the fp64 PyTorch restatement of tests/ref_ops.py: ragged relation blocks, an inactive relation, rows of
@@ -778,7 +783,8 @@ def test_calculator_plugin_energy_forces_virial(name):
     e = orc.hvnet_energy(sd, g.elems, p, dd.atomic_number, dd.edge_index, dd.batch, dd.get("edge_shift"), c,
                          **g.oracle_kwargs()) + 0.25
     f = -torch.autograd.grad(e.sum(), p, retain_graph=cell is not None)[0]
-    v = virial_calc(c, p.detach(), f, e, "metal", pbc=cell is not None).detach()
+    w_ev = virial_calc(c, p.detach(), f, e, "lj", pbc=cell is not None).detach()      # W in eV (unit factor 1)
+    v = w_ev * 1.6021765e6                                                               # "metal": utils.py:139-140
     vv = torch.tensor([v[0, 0], v[1, 1], v[2, 2], v[0, 1], v[0, 2], v[1, 2]])
     assert abs(calc.results["energy"] - float(e)) < 1e-5 * abs(float(e))
     assert rel_err(torch.from_numpy(calc.results["forces"]), f) < TOL
@@ -793,8 +799,7 @@ def test_calculator_plugin_energy_forces_virial(name):
     if cell is None:
         assert not st.any()
     else:
-        w = virial_calc(c, p.detach(), f, e, "lj", pbc=True).detach().double().numpy()
-        sig = -w / abs(np.linalg.det(cell.astype("float64")))
+        sig = -w_ev.double().numpy() / abs(np.linalg.det(cell.astype("float64")))
         want = np.array([sig[0, 0], sig[1, 1], sig[2, 2], sig[1, 2], sig[0, 2], sig[0, 1]])
         assert np.abs(st - want).max() < 5e-5 * np.abs(want).max()
 
@@ -1069,6 +1074,7 @@ def test_edge_cases_empty_and_degenerate_graphs():
      "HERMNET_BWD_VARIANT": "16201", "HERMNET_BWD_VARIANT_L0": "16201"},
     {"HERMNET_FWD_VARIANT": "8410", "HERMNET_FWD_VARIANT_L0": "8420",                    # full prefetch / no prefetch
      "HERMNET_BWD_VARIANT": "8400", "HERMNET_BWD_VARIANT_L0": "8410", "HERMNET_BWD_ROWS": "24", "HERMNET_FWD_ROWS": "17"},
+    {"HERMNET_NODE_CHAIN_WIDE": "1"},            # widths 128 / 256 on the panelled chain kernels (node_chain_wide.hip)
 ])
 def test_alternative_kernel_variants(env):
     """The non-default template instances of the message kernels (selected by environment, once per process) must
@@ -1092,7 +1098,8 @@ def test_skewed_composition_uses_tight_layout_and_matches_oracle():
     _oracle_vs_hip(data, ["Al", "Ni", "Cu"], dict(rc=5.0, num_layers=3, hidden_channels=128, num_rbf=64), 77)
 
 
-@pytest.mark.parametrize("H,R,layers", [(512, 128, 2), (64, 20, 3), (192, 50, 2), (96, 16, 2), (100, 32, 3), (50, 20, 2)])
+@pytest.mark.parametrize("H,R,layers", [(512, 128, 2), (64, 20, 3), (192, 50, 2), (96, 16, 2), (100, 32, 3), (50, 20, 2),
+                                        (320, 40, 2), (384, 64, 2), (448, 30, 2), (300, 24, 2), (500, 32, 2)])
 def test_other_widths_vs_oracle(H, R, layers):
     """hidden_channels = 512 is the reference default (hermnet.py:86): 8 column blocks; odd num_rbf; and widths that
     are NOT a multiple of 64 (the reference accepts any, hermnet.py:84-88): 96, 100 and 50 run on the same kernels with

@@ -1,6 +1,6 @@
 """Run by tests/test_gpu_parity.py::test_alternative_kernel_variants in a child process: the kernel variant /
 split mode is read from the environment once per process (csrc/message_kernels.hip), so every non-default
-variant needs a process of its own.  Checks energies + forces of three golden cases at 1e-5."""
+variant needs a process of its own.  Checks energies + forces of four golden cases (H = 128 and 256) at 1e-5."""
 import os
 import sys
 
@@ -15,7 +15,7 @@ from helpers import Golden, rel_err  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
-    for name in ["c1_si64", "alloy108", "mol16"]:
+    for name in ["c1_si64", "alloy108", "mol16", "alloy32_h256"]:
         g = Golden(name)
         model = g.model().to(dev)
         d = g.data().to(dev)
