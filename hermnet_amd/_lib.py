@@ -44,10 +44,11 @@ SIGNATURES = {
     "hermnet_edge_geometry_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp]),
     "hermnet_edge_geometry_bwd_csc": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "hermnet_message_scatter_fwd": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), ctypes.c_int,
-                                                   c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+                                                   c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp]),
     "hermnet_message_scatter_bwd": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), ctypes.c_int,
                                                    c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
-                                                   c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),
+                                                   c_fp, c_fp, c_fp, c_fp, ctypes.c_int, c_fp, c_fp,
+                                                   c_fp, c_fp, ctypes.c_int, c_fp]),
     "hermnet_edge_radial_table": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), c_fp, c_fp, c_fp]),
     "hermnet_neighbor_workspace": (ctypes.c_size_t, [ctypes.c_int]),
     "hermnet_neighbor_count": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_double, c_fp,

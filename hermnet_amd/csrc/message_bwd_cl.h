@@ -29,7 +29,12 @@ struct HnBwdClArgs {
   float4* gedge;             // [H/64, E]
   int rows_per_block;
   int xcd_remap;             // 1 = XCD-contiguous workgroup order (message_kernels.hip: xcd_contiguous)
+  // atom shards: this launch covers the SOURCE rows of `num_ranges` disjoint ascending ranges [lo, hi) only (the rows
+  // whose gradients travel to other ranks first, the rest while they travel); 0 ranges = every row
+  const int* src_ranges;     // [num_ranges][2] device
+  int num_ranges;
 };
 
 size_t hn_bwd_cl_lds_bytes(int R);
-int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, hipStream_t s);
+// `ranges_host`: the same [num_ranges][2] values on the host (grid size)
+int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, const int* ranges_host, hipStream_t s);

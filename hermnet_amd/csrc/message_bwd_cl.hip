@@ -188,8 +188,24 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
   }
   const int t = __builtin_amdgcn_readfirstlane(bz);
   const int cb = __builtin_amdgcn_readfirstlane(by);
-  const int r0 = __builtin_amdgcn_readfirstlane(bx) * a.rows_per_block;
-  const int r1 = min(r0 + a.rows_per_block, a.Nsrc);
+  int r0, r1;
+  if (a.num_ranges > 0) {      // chunk bx of the concatenated ranges (chunks do not straddle a range)
+    int c = __builtin_amdgcn_readfirstlane(bx);
+    r0 = r1 = 0;
+    bool found = false;
+    for (int k = 0; k < a.num_ranges && !found; ++k) {
+      const int lo = a.src_ranges[2 * k], hi = a.src_ranges[2 * k + 1];
+      const int nb = hi > lo ? (hi - lo + a.rows_per_block - 1) / a.rows_per_block : 0;
+      if (c < nb) { r0 = lo + c * a.rows_per_block; r1 = min(r0 + a.rows_per_block, hi); found = true; }
+      c -= nb;
+    }
+    if (!found) return;        // (the grid is sized from the host's copy of the ranges: no surplus chunks expected)
+    r0 = __builtin_amdgcn_readfirstlane(r0);
+    r1 = __builtin_amdgcn_readfirstlane(r1);
+  } else {
+    r0 = __builtin_amdgcn_readfirstlane(bx) * a.rows_per_block;
+    r1 = min(r0 + a.rows_per_block, a.Nsrc);
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
@@ -460,9 +476,20 @@ __global__ __launch_bounds__(256) void message_bwd_finish_kernel(const float4* _
                                                                  const float4* __restrict__ gx1,
                                                                  const int* __restrict__ type_rowptr, int identity,
                                                                  int H, float4* __restrict__ gvec, float4* __restrict__ gx,
-                                                                 long n4_x) {
+                                                                 long n4_x, const int* __restrict__ ranges, int num_ranges) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int identity_rows = identity ? type_rowptr[T] : 0;      // rows below are targets of a known type
+  if (num_ranges > 0) {        // only the rows of this launch's ranges (the others belong to the other launch)
+    bool vin = false, xin = false;
+    const long rv = i / (3 * H / 4), rx = i / (H / 4);
+    for (int k = 0; k < num_ranges; ++k) {
+      const int lo = ranges[2 * k], hi = ranges[2 * k + 1];
+      vin |= rv >= lo && rv < hi;
+      xin |= rx >= lo && rx < hi;
+    }
+    if (!vin) n4_vec = 0;
+    if (!xin) n4_x = 0;
+  }
   if (part && i < n4_vec) {
     float4 acc = part[i];
     for (int t = 1; t < T; ++t) {
@@ -503,7 +530,7 @@ size_t hn_bwd_cl_lds_bytes(int R) {
   return (size_t)(R + 2 * HN_PAD + 1) * HN_CB * sizeof(float4);
 }
 
-int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, hipStream_t s) {
+int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, const int* ranges_host, hipStream_t s) {
   const size_t lds = hn_bwd_cl_lds_bytes(a.R);
   if (lds > 160 * 1024) return HN_ERR_LDS;
   typedef void (*kern_t)(HnBwdClArgs);
@@ -519,18 +546,37 @@ int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, hipStream_t
   // workgroup per CU (the 154 KB tile allows one resident workgroup): ~256 rows = 16 rows per wave
   const int ncb = a.H / HN_CB;
   int rpb = rows_override;
+  long rows = a.Nsrc;
+  if (a.num_ranges > 0) {
+    if (!ranges_host || !a.src_ranges || a.num_ranges > 16) return HN_ERR_BAD_ARG;
+    rows = 0;
+    for (int k = 0; k < a.num_ranges; ++k) {
+      const int lo = ranges_host[2 * k], hi = ranges_host[2 * k + 1];
+      if (lo < 0 || hi > a.Nsrc || (k > 0 && lo < ranges_host[2 * k - 1])) return HN_ERR_BAD_ARG;
+      if (hi > lo) rows += hi - lo;
+    }
+    if (rows == 0) return HN_OK;
+  }
   if (rpb <= 0) {
-    const long work = (long)a.Nsrc * ncb * a.T;
+    const long work = rows * ncb * a.T;
     const int cus = num_cus();
     long rounds = (work + (long)cus * 128) / ((long)cus * 256);
     if (rounds < 1) rounds = 1;
     long wgs_per_tc = cus * rounds / ((long)ncb * a.T);     // chunks per (t, cb), rounded DOWN: a grid one workgroup
     if (wgs_per_tc < 1) wgs_per_tc = 1;                      // over a whole round would double the kernel's time
-    rpb = (int)((a.Nsrc + wgs_per_tc - 1) / wgs_per_tc);
+    rpb = (int)((rows + wgs_per_tc - 1) / wgs_per_tc);
     if (rpb < 16) rpb = 16;
   }
   a.rows_per_block = rpb;
-  dim3 grid((unsigned)((a.Nsrc + rpb - 1) / rpb), (unsigned)ncb, (unsigned)a.T);
+  long chunks = (a.Nsrc + rpb - 1) / rpb;
+  if (a.num_ranges > 0) {
+    chunks = 0;
+    for (int k = 0; k < a.num_ranges; ++k) {
+      const int lo = ranges_host[2 * k], hi = ranges_host[2 * k + 1];
+      if (hi > lo) chunks += (hi - lo + rpb - 1) / rpb;
+    }
+  }
+  dim3 grid((unsigned)chunks, (unsigned)ncb, (unsigned)a.T);
   hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, a);
   // partial sums over the relations + identity terms -> gvec, gx
   const long n4v = has_vec ? (long)a.Nsrc * 3 * a.H / 4 : 0, n4x = (long)a.Nsrc * a.H / 4;
@@ -539,7 +585,7 @@ int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, hipStream_t
                      has_vec ? reinterpret_cast<const float4*>(a.gvec) : nullptr, a.T, n4v,
                      reinterpret_cast<const float4*>(a.gvec1), reinterpret_cast<const float4*>(a.gx1),
                      a.type_rowptr, a.identity, a.H, reinterpret_cast<float4*>(a.gvec_out),
-                     reinterpret_cast<float4*>(a.gx), n4x);
+                     reinterpret_cast<float4*>(a.gx), n4x, a.src_ranges, a.num_ranges);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
 

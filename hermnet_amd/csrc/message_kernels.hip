@@ -79,6 +79,8 @@ struct MsgArgs {
   int rows_per_block;
   int xcd_remap;       // 1 = XCD-contiguous block order (see xcd_contiguous)
   int split_t;         // bwd: 1 = one relation per workgroup (blockIdx.z), gvec is [T,N,3,H] partial sums
+  const int* row_ranges;   // fwd: [T][2] target rows [lo, hi) of every relation this launch covers, or null = whole blocks
+  int zero_unknown;        // fwd: 1 = this launch also zeroes the rows of unknown-element atoms
 };
 
 // ---- VW-wide per-lane vectors ------------------------------------------------------------------
@@ -338,8 +340,11 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nb, int on) {
 // surplus block (0, 1, ...) past the last work block.
 __device__ __forceinline__ int decode_block(const MsgArgs& a, int bx, int& t, int& r0, int& r1) {
   for (t = 0; t < a.T; ++t) {
-    const int lo = a.type_rowptr[t], hi = a.type_rowptr[t + 1];
-    const int nb = (hi - lo + a.rows_per_block - 1) / a.rows_per_block;
+    // (atom shards: the targets that read no halo row run while the halo exchange is in flight, the others after
+    // it -- two launches over complementary [lo, hi) ranges of every relation's row block)
+    const int lo = a.row_ranges ? a.row_ranges[2 * t] : a.type_rowptr[t];
+    const int hi = a.row_ranges ? a.row_ranges[2 * t + 1] : a.type_rowptr[t + 1];
+    const int nb = hi > lo ? (hi - lo + a.rows_per_block - 1) / a.rows_per_block : 0;
     if (bx < nb) {
       r0 = lo + bx * a.rows_per_block;
       r1 = min(r0 + a.rows_per_block, hi);
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
   const int surplus = decode_block(a, xcd_contiguous(blockIdx.x, gridDim.x, a.xcd_remap), t, r0, r1);
   if (surplus >= 0) {
     // the first surplus block zeroes the rows of unknown-type atoms (they are never targets)
-    if (surplus == 0) {
+    if (surplus == 0 && a.zero_unknown) {
       const int c = cb * HN_CB + (threadIdx.x & 63);
       for (int r = a.type_rowptr[a.T] + (int)(threadIdx.x >> 6); r < a.N; r += NW) {
         a.x1[(size_t)r * a.H + c] = 0.f;
@@ -929,7 +934,8 @@ kern_t pick_bwd(int variant, int& nw) {
 extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc* rbf, int hidden,
                                            const float* xh, const float* xh_bias, const float* vec, const float* x,
                                            const float* wt, const float* brbf, const float* edge,
-                                           float* x1, float* vec1, void* stream) {
+                                           float* x1, float* vec1, const int* target_ranges, int zero_unknown_rows,
+                                           void* stream) {
   MsgArgs a = {};
   int rc = fill_args(g, rbf, hidden, a);
   if (rc) return rc;
@@ -938,6 +944,7 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   a.xh = xh; a.xh_bias = xh_bias; a.vec = vec; a.x = x; a.wt = wt; a.brbf = brbf;
   a.edge = reinterpret_cast<const float4*>(edge);
   a.x1 = x1; a.vec1 = vec1;
+  a.row_ranges = target_ranges; a.zero_unknown = (target_ranges == nullptr) || zero_unknown_rows;
   static const int rpb_fwd = env_int("HERMNET_FWD_ROWS", 0);
   // defaults from tools/kbench.py on MI355X (config 2): see DESIGN.md "Kernel variants"
   static const int variant_vec = env_int("HERMNET_FWD_VARIANT", 8420);
@@ -963,7 +970,9 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
                                            const float* wt, const float* brbf, const float* edge,
                                            const float* gx1, const float* gvec1,
                                            float* gxh, float* gvec, float* gx, float* gedge,
-                                           int split_t, const float* edge_table, float* gvec_partials, void* stream) {
+                                           int split_t, const float* edge_table, float* gvec_partials,
+                                           const int* source_ranges, const int* source_ranges_host, int num_ranges,
+                                           void* stream) {
   MsgArgs a = {};
   int rc = fill_args(g, rbf, hidden, a);
   if (rc) return rc;
@@ -979,6 +988,7 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
                      src_rows * 3 * hidden < 0x7fffffffull &&                   // 32-bit row offsets (elements)
                      (!vec || a.T == 1 || gvec_partials);
   if (virtual_targets && !cl_ok) return HN_ERR_BAD_ARG;
+  if (num_ranges < 0 || (num_ranges > 0 && !(cl_ok && (use_cl || virtual_targets)))) return HN_ERR_BAD_ARG;   // ranges: that form only
   if (cl_ok && (use_cl || virtual_targets)) {
     HnBwdClArgs b = {};
     b.N = a.N; b.Nsrc = g->num_src > 0 ? g->num_src : a.N; b.E = a.E; b.T = a.T;
@@ -992,7 +1002,8 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
     static const int rpb_cl = env_int("HERMNET_BWD_CL_ROWS", 0);
     static const int xcd_cl = env_int("HERMNET_XCD_REMAP", 1);
     b.xcd_remap = xcd_cl;
-    return hn_bwd_cl_launch(b, vec != nullptr, rpb_cl, reinterpret_cast<hipStream_t>(stream));
+    b.src_ranges = source_ranges; b.num_ranges = num_ranges;
+    return hn_bwd_cl_launch(b, vec != nullptr, rpb_cl, source_ranges_host, reinterpret_cast<hipStream_t>(stream));
   }
   a.xh = xh; a.xh_bias = xh_bias; a.vec = vec; a.wt = wt; a.brbf = brbf;
   a.edge = reinterpret_cast<const float4*>(edge);

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
   using C = Cfg<H, TR>;
   constexpr int LD = C::LD, RB = C::RB, CPW = C::CPW, CB = C::CB;
   extern __shared__ __align__(16) float tile[];           // [TR][LD], then 4 x [32][36] store scratch
+  stagger_start();
   const int t = blockIdx.y, row0 = blockIdx.x * TR;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave % C::WC, wr = wave / C::WC;
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void node_pre_bwd_kernel(PreBwdArgs a) {
   constexpr int NCH = 3 * H / KC, LDC = KC + 4;
   static_assert(2 * TR * LDC >= TR * LD, "the gh tile must fit the two chunk buffers");   // (+ scratch: pre_bwd_lds_floats)
   extern __shared__ __align__(16) float lds[];            // 2 x [TR][LDC], then 4 x [32][36] store scratch
+  stagger_start();
   const int t = blockIdx.y, row0 = blockIdx.x * TR;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave % C::WC, wr = wave / C::WC;
@@ -262,6 +264,7 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
   using C = Cfg<H, TR>;
   constexpr int LD = C::LD, RB = C::RB, CPW = C::CPW, CB = C::CB;
   extern __shared__ __align__(16) float lds[];            // 2 x [TR][LD], then 4 x [32][36] store scratch
+  stagger_start();
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wave % C::WC, wr = wave / C::WC;
   float* scr = lds + 2 * TR * LD + wave * kScrFloats;
@@ -471,6 +474,7 @@ __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a
   using C = Cfg<H, TR>;
   constexpr int LD = C::LD, RB = C::RB, CPW = C::CPW, CB = C::CB, F4 = C::F4, V = H / 4;
   extern __shared__ __align__(16) float lds[];            // 2 x [TR][LD], then 4 x [32][36] store scratch
+  stagger_start();
   float* buf0 = lds;
   float* buf1 = lds + TR * LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -152,7 +152,21 @@ template <int NJ, int RS>
 struct BRing { f32x4 v[RS][NJ]; };
 
 // ring slots of a product with RB x NJ accumulator blocks per wave
-constexpr int ring_size(int rb_nj, bool more) { return 4; }
+#ifndef HN_RS_SMALL
+#define HN_RS_SMALL 4
+#endif
+constexpr int ring_size(int rb_nj, bool more) { return rb_nj == 1 ? HN_RS_SMALL : 4; }
+
+// Experiment knob (-DHN_STAGGER=n): the workgroup that lands in an ODD wave slot of its SIMD (the second of two
+// co-resident ones) starts n x 8128 cycles late, so that the two do not walk through their matrix phases in lockstep.
+__device__ __forceinline__ void stagger_start() {
+#ifdef HN_STAGGER
+  unsigned hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  if (hw & 1)
+    for (int i = 0; i < HN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+}
 
 // first RS - 1 k-groups of a stream (call it early: before the barrier / epilogue that precedes the product)
 template <int NJ, int RS>

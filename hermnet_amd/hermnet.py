@@ -38,8 +38,13 @@ class HeteroVertexConv(nn.Module):
             if self._weights is None:
                 self._weights = LayerWeights(self.mods.values())
             w = self._weights.refresh()
+        # (default ON: HERMNET_HALO_OVERLAP=0 runs the blocking exchange in front of the layer instead; the overlapped
+        # form needs the chain kernels, HVNet's single row space and the channel-per-lane backward, which takes row ranges)
         if halo is not None and not (w is not None and w.chain and _node_chain_enabled() and g.num_src == 0
-                                     and os.environ.get("HERMNET_HALO_OVERLAP", "0") != "0"):
+                                     and halo.fwd_early is not None and g.N * 3 * data.x.size(1) * 4 < 2 ** 32
+                                     and os.environ.get("HERMNET_BWD_CL", "1") != "0"
+                                     and os.environ.get("HERMNET_BWD_SPLIT_T", "0") == "0"
+                                     and os.environ.get("HERMNET_HALO_OVERLAP", "1") != "0"):
             data.x, data.vec = HaloExchangeFeatures.apply(data.x, data.vec, halo.plan)
             halo = None
         if data.get("_hn_edge_embed") is not None:
@@ -59,6 +64,12 @@ class HeteroVertexConv(nn.Module):
                                                       w if w is not None else self._weights.refresh(),
                                                       data.get("_hn_edge_sink"), li, halo)
         return data
+
+
+def nodeops_tile_rows(Hp):
+    """Rows per tile of the node pre kernels at padded width Hp (64 when the width has no chain kernels: unused then)."""
+    from . import nodeops
+    return nodeops.chain_tile_rows(Hp) or 64
 
 
 class HVNet(nn.Module):
@@ -209,7 +220,7 @@ class HVNet(nn.Module):
             if row_plan is not None and li + 1 < len(self.hermconvs):
                 # one exchange per layer: (x | vec) rows of halo atoms, 4H floats each -- due before the next layer reads
                 # them, run BY that layer (overlapped with its node projection where it can, HeteroVertexConv.forward)
-                data._hn_halo = shard.halo_overlap(graph)
+                data._hn_halo = shard.halo_overlap(graph, nodeops_tile_rows(Hp))
         x = data.x
         if Hp != H:
             x = x[:, :H]                                                    # the read-out sees the real channels

@@ -118,40 +118,57 @@ class LayerWeights(object):
         return self
 
 
-def _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=True):
-    """`xh_bias=False`: xh already includes x_proj's bias (chain kernels)."""
+def _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=True, ranges=None, zero_unknown=True, out=None):
+    """`xh_bias=False`: xh already includes x_proj's bias (chain kernels).  `ranges` [T,2] int32 (device): only these
+    target rows of every relation (atom shards: two launches over complementary ranges around the halo exchange;
+    the second passes the first one's result as `out`)."""
     lib = _lib.load()
     b2 = w.b2 if xh_bias else None
-    x1 = torch.empty(graph.N, H, dtype=x.dtype, device=x.device)          # target rows (= source rows unless HTNet)
-    vec1 = torch.empty(graph.N, 3, H, dtype=x.dtype, device=x.device)
+    if out is None:
+        x1 = torch.empty(graph.N, H, dtype=x.dtype, device=x.device)          # target rows (= source rows unless HTNet)
+        vec1 = torch.empty(graph.N, 3, H, dtype=x.dtype, device=x.device)
+    else:
+        x1, vec1 = out
     gs, rs = graph.as_struct(), rbf.struct()
     _lib.check(_launch("message_scatter_fwd" + ("" if vec is not None else "_l0"),
                        lambda: lib.hermnet_message_scatter_fwd(
                            ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(b2), P(vec), P(x), P(w.wt), P(w.brbf), P(edge),
-                           P(x1), P(vec1), _stream())), "hermnet_message_scatter_fwd")
+                           P(x1), P(vec1), P(ranges), 1 if zero_unknown else 0, _stream())), "hermnet_message_scatter_fwd")
     return x1, vec1
 
 
-def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True):
-    """`gedge` [H/64, E, 4] (zero-filled by the caller) receives the per-column-block Cartesian edge gradients."""
+def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True, ranges=None, out=None):
+    """`gedge` [H/64, E, 4] (zero-filled by the caller) receives the per-column-block Cartesian edge gradients.
+    `ranges` = (device [k,2] int32, host list of (lo, hi)): only these SOURCE rows (atom shards: the halo rows first,
+    the others while their gradients travel; the second call passes the first one's buffers as `out`)."""
     lib = _lib.load()
     b2 = w.b2 if xh_bias else None
-    gxh = torch.empty_like(xh)
     split = _split_t(graph)
-    gvec = None if vec is None else (torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
-                                     if split else torch.empty_like(vec))
-    gx = torch.empty(xh.size(1), H, dtype=gx1.dtype, device=gx1.device)   # source rows
-    # workspace of the channel-per-lane form: per-relation partial sums of gvec
-    part = None
-    if graph.edge_table is not None and vec is not None and graph.T > 1 and not split:
-        part = torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
+    if out is None:
+        gxh = torch.empty_like(xh)
+        gvec = None if vec is None else (torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
+                                         if split else torch.empty_like(vec))
+        gx = torch.empty(xh.size(1), H, dtype=gx1.dtype, device=gx1.device)   # source rows
+        # workspace of the channel-per-lane form: per-relation partial sums of gvec
+        part = None
+        if graph.edge_table is not None and vec is not None and graph.T > 1 and not split:
+            part = torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
+    else:
+        gxh, gvec, gx, part = out
+    rd, rh, nr = None, None, 0
+    if ranges is not None:
+        rd, host = ranges
+        nr = len(host)
+        rh = (ctypes.c_int * (2 * nr))(*[v for lo_hi in host for v in lo_hi])
     gs, rs = graph.as_struct(), rbf.struct()
     _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"),
                        lambda: lib.hermnet_message_scatter_bwd(
                            ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(b2), P(vec), P(w.wt), P(w.brbf), P(edge),
                            P(gx1), P(gvec1), P(gxh), P(gvec), P(gx), P(gedge), split, P(graph.edge_table), P(part),
-                           _stream())),
+                           P(rd), rh, nr, _stream())),
                "hermnet_message_scatter_bwd")
+    if ranges is not None:
+        return gxh, gvec, gx, part
     if split and gvec is not None:
         gvec = gvec.sum(0)
     return gxh, gvec, gx
@@ -225,18 +242,29 @@ class FusedRelationalLayer(torch.autograd.Function):
             # three launches: node_pre_fwd (LayerNorm + x_proj of every relation), the message kernel, node_update_fwd
             if halo is None:
                 hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges)
+                x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False)
             else:
+                # The exchange runs behind the node projection AND the message kernel of every target that reads no
+                # halo row ("run interior edges while the halo is in flight"):
+                #   pack -> start the all-to-all -> project every row (halo rows from stale inputs: redone below) ->
+                #   messages into the early targets -> the STREAM waits -> unpack IN PLACE -> project the tiles that hold
+                #   a halo row -> messages into the remaining targets.
                 from .sharding import _all_to_all_rows_start
                 plan = halo.plan
                 send = nodeops.halo_rows(0, x, vec, plan.send_idx)
                 recv, work = _all_to_all_rows_start(send, plan.send_counts, plan.recv_counts, plan.group)
-                pre = nodeops.node_pre_fwd(x, w, T, windows=halo.windows, mode=2)
+                if _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":
+                    # (tests: nothing that runs before the unpack may depend on a halo row)
+                    nodeops.halo_rows(2, x, vec, plan.recv_idx, torch.full_like(recv, float("nan")))
+                pre = nodeops.node_pre_fwd(x, w, T)
+                out = _msg_fwd(graph, rbf, H, pre[1], vec, x, w, edge, xh_bias=False, ranges=halo.fwd_early, zero_unknown=True)
                 if work is not None:
                     work.wait()
                 nodeops.halo_rows(2, x, vec, plan.recv_idx, recv)
                 hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T, windows=halo.windows, mode=1, out=pre)
+                x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False, ranges=halo.fwd_late,
+                                    zero_unknown=False, out=out)
             ctx.halo = halo
-            x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False)
             x_out, vec_out, vp, h2b, q23, nrm = nodeops.node_update_fwd(x1, vec1, w, graph)
             ctx.save_for_backward(x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23, nrm)
             ctx.graph, ctx.rbf, ctx.w, ctx.sink, ctx.li = graph, rbf, w, sink, li
@@ -337,6 +365,32 @@ class FusedRelationalLayer(torch.autograd.Function):
             gedge = ctx.sink.slice(ctx.li)
         else:
             gedge = torch.zeros(H // 64, graph.E, 4, dtype=torch.float32, device=gx1.device)
+        halo = ctx.halo if ctx.chain else None
+        if halo is not None:
+            # the gradients of the halo rows first: they travel to their owners while the other rows are computed
+            from .sharding import _all_to_all_rows_start
+            plan = halo.plan
+            bufs = None
+            if halo.bwd_first[1]:
+                bufs = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=False, ranges=halo.bwd_first)
+                gxh, gvec_in, gx_in, _ = bufs
+                out = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, windows=halo.windows, mode=1)
+                gsend = nodeops.halo_rows(1, out[0], gvec_in, plan.recv_idx)           # pack and clear: none stays here
+            else:                                                                   # (a rank without halo atoms)
+                out = None
+                gsend = x.new_empty(0, 4 * H)
+            back, work = _all_to_all_rows_start(gsend, plan.recv_counts, plan.send_counts, plan.group)
+            if halo.bwd_rest[1]:
+                bufs = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=False, ranges=halo.bwd_rest,
+                                out=bufs)
+            gxh, gvec_in, gx_in, _ = bufs
+            res = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, windows=halo.windows, mode=2, out=out)
+            gx_total = res[0]
+            if work is not None:
+                work.wait()
+            nodeops.halo_accumulate(gx_total, gvec_in, plan, back)                  # gradients of my atoms used elsewhere
+            ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
+            return gx_total, gvec_in, ge, None, None, None, None, None, None
         gxh, gvec_in, gx_in = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=not ctx.chain)
         if graph.num_src:
             # HTNet: the residual (rmnet.py:24-26) reads the atom's own row from each of its P virtual target rows;
@@ -350,20 +404,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                     gvec_in[:Te * B_] += gvec1.view(Te, P_, B_, 3, H).sum(1).reshape(Te * B_, 3, H)
         gx_total = None
         if ctx.needs_input_grad[0]:
-            if ctx.chain and ctx.halo is not None:
-                # the gradients of the halo rows first: they travel to their owners while the other tiles are computed
-                from .sharding import _all_to_all_rows_start
-                halo = ctx.halo
-                plan = halo.plan
-                out = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, windows=halo.windows, mode=1)
-                gx_total = out[0]
-                gsend = nodeops.halo_rows(1, gx_total, gvec_in, plan.recv_idx)          # pack and clear: none stays here
-                back, work = _all_to_all_rows_start(gsend, plan.recv_counts, plan.send_counts, plan.group)
-                nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, windows=halo.windows, mode=2, out=out)
-                if work is not None:
-                    work.wait()
-                nodeops.halo_accumulate(gx_total, gvec_in, plan, back)                  # gradients of my atoms used elsewhere
-            elif ctx.chain:
+            if ctx.chain:
                 gx_total = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, src_ranges=graph.src_ranges)
             else:
                 ga = _launch("gemm", lambda: torch.bmm(gxh, w.w2))                                            # [T, Ns, H]

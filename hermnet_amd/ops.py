@@ -184,7 +184,7 @@ class MessageScatter(torch.autograd.Function):
         gs, rs = graph.as_struct(), rbf.struct()
         _lib.check(_launch("message_scatter_fwd" + ("" if vec_c is not None else "_l0"), lambda: lib.hermnet_message_scatter_fwd(
             ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), None, _lib.ptr(vec_c), _lib.ptr(x),
-            _lib.ptr(wt), _lib.ptr(brbf), _lib.ptr(edge), _lib.ptr(x1), _lib.ptr(vec1), _stream())),
+            _lib.ptr(wt), _lib.ptr(brbf), _lib.ptr(edge), _lib.ptr(x1), _lib.ptr(vec1), None, 1, _stream())),
             "hermnet_message_scatter_fwd")
         ctx.save_for_backward(xh, vec_c, edge, wt, brbf)
         ctx.graph, ctx.rbf, ctx.H = graph, rbf, H
@@ -210,7 +210,7 @@ class MessageScatter(torch.autograd.Function):
         _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"), lambda: lib.hermnet_message_scatter_bwd(
             ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), None, _lib.ptr(vec), _lib.ptr(wt), _lib.ptr(brbf),
             _lib.ptr(edge), _lib.ptr(gx1), _lib.ptr(gvec1), _lib.ptr(gxh), _lib.ptr(gvec), _lib.ptr(gx),
-            _lib.ptr(gedge), split, _lib.ptr(graph.edge_table), _lib.ptr(part), _stream())), "hermnet_message_scatter_bwd")
+            _lib.ptr(gedge), split, _lib.ptr(graph.edge_table), _lib.ptr(part), None, None, 0, _stream())), "hermnet_message_scatter_bwd")
         if split and gvec is not None:
             gvec = gvec.sum(0)
         return gxh, gvec, gx, gedge.sum(0), None, None, None, None

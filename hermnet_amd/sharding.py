@@ -96,12 +96,19 @@ def _all_to_all_rows_start(buf, in_counts, out_counts, group):
 
 class HaloOverlap(object):
     """An exchange of (x, vec) halo rows that is still DUE when a layer starts: the fused layer
-    (`layer.FusedRelationalLayer`) runs it itself, with the node projection of the rows that do not wait for it in
-    between (compute while the halo is in flight), and mirrors that in its backward.
-    plan: ExchangePlan in relation-row order; windows: [W,2] int32 row ranges that contain every halo row."""
+    (`layer.FusedRelationalLayer`) runs it itself, with everything that does not wait for it in between (SURVEY 8(e):
+    "run interior edges while the halo is in flight"), and mirrors that in its backward.
 
-    def __init__(self, plan, windows):
+    plan       ExchangePlan in relation-row order
+    windows    [W,2] int32 (device): row ranges that contain every halo row (one per element block)
+    fwd_early  [T,2] int32 (device): per relation the TARGET rows that read no halo row -- their messages run while the
+               exchange is in flight; fwd_late: the rest of the relation's row block (incl. the halo rows themselves)
+    bwd_first  (device [k,2] int32, host [(lo, hi)]): the SOURCE rows whose gradients travel -- the halo windows widened to
+               the node kernels' row tiles --, computed and sent first; bwd_rest: every other row, computed meanwhile."""
+
+    def __init__(self, plan, windows, fwd_early=None, fwd_late=None, bwd_first=None, bwd_rest=None):
         self.plan, self.windows = plan, windows
+        self.fwd_early, self.fwd_late, self.bwd_first, self.bwd_rest = fwd_early, fwd_late, bwd_first, bwd_rest
 
     @staticmethod
     def row_windows(halo_rows, type_rowptr, num_rows):
@@ -114,6 +121,43 @@ class HaloOverlap(object):
         hi = torch.full((T1,), -1, dtype=torch.long, device=dev).scatter_reduce(0, blk, halo_rows, "amax") + 1
         lo = torch.minimum(lo, hi)                          # empty block: (0, 0)
         return torch.stack([lo, hi], dim=1).to(torch.int32).contiguous()
+
+    @staticmethod
+    def target_ranges(late_rows, type_rowptr):
+        """(early, late) [T,2] int32: relation block t = [start_t, end_t) is cut at its first late row b_t into the early
+        range [start_t, b_t) and the late range [b_t, end_t).  `late_rows`: rows that read a halo row or are one."""
+        T = int(type_rowptr.numel()) - 1
+        rp = type_rowptr.long()
+        dev = rp.device
+        blk = torch.bucketize(late_rows, rp[1:], right=True)               # block of every late row (T = unknown elements)
+        first = torch.cat([rp[1:], rp[-1:]]).clone()                        # default: the block's end (no late row)
+        first = first.scatter_reduce(0, blk, late_rows, "amin")[:T]
+        first = torch.maximum(first, rp[:T])
+        early = torch.stack([rp[:T], first], dim=1).to(torch.int32).contiguous()
+        late = torch.stack([first, rp[1:T + 1]], dim=1).to(torch.int32).contiguous()
+        return early, late
+
+    @staticmethod
+    def source_ranges(windows_host, tile_rows, num_rows, device):
+        """(first, rest): the windows widened to multiples of `tile_rows` and merged, and their complement in
+        [0, num_rows); each as (device [k,2] int32, host [(lo, hi)])."""
+        wide = sorted((lo // tile_rows * tile_rows, min(-(-hi // tile_rows) * tile_rows, num_rows))
+                      for lo, hi in windows_host if hi > lo)
+        first = []
+        for lo, hi in wide:
+            if first and lo <= first[-1][1]:
+                first[-1] = (first[-1][0], max(first[-1][1], hi))
+            else:
+                first.append((lo, hi))
+        rest, at = [], 0
+        for lo, hi in first:
+            if lo > at:
+                rest.append((at, lo))
+            at = hi
+        if at < num_rows:
+            rest.append((at, num_rows))
+        dv = lambda r: torch.tensor(r, dtype=torch.int32, device=device).reshape(-1, 2) if r else None
+        return (dv(first), first), (dv(rest), rest)
 
 
 class HaloExchange(torch.autograd.Function):
@@ -233,7 +277,7 @@ class ShardPlan(object):
     def __init__(self, rank, world, owned_global, halo_global, atom_plan, owned_mask, num_graphs, group=None):
         self.rank, self.world = rank, world
         self.num_graphs = int(num_graphs)     # of the GLOBAL batch (a rank may own no atom of some graph)
-        self.owned_global = owned_global      # LongTensor: global ids of owned atoms, ascending (= local order)
+        self.owned_global = owned_global      # LongTensor: global ids of owned atoms in local order
         self.halo_global = halo_global        # LongTensor: global ids of halo atoms, ascending
         self.owned_local = None               # LongTensor: local ids of the owned atoms (set by `partition`)
         self.local_global = None              # LongTensor: global id of every local atom
@@ -247,6 +291,8 @@ class ShardPlan(object):
         self._row_plan = None                 # (row_of_node tensor, atom_plan in that row order, HaloOverlap)
         self._zl_index = None                 # ((element list, device), its index tensor) for `rel_active`
         self.halo_pos_local = False           # True: Data.pos already holds the halo atoms' coordinates (slab plans)
+        self.late_local = None                # BoolTensor [N_loc]: local atoms that may READ a halo atom's row (or are halo
+                                              # atoms); the others' messages run while the halo exchange is in flight
 
     @property
     def n_owned(self):
@@ -286,12 +332,23 @@ class ShardPlan(object):
             self._row_plan = (row_of_node, self.atom_plan.remap(row_of_node), None)
         return self._row_plan[1]
 
-    def halo_overlap(self, graph):
-        """`HaloOverlap` of this plan for the row layout of `graph` (cached with the row plan)."""
+    def halo_overlap(self, graph, tile_rows=64):
+        """`HaloOverlap` of this plan for the row layout of `graph` (cached with the row plan; one host read of the
+        T + 1 halo windows when it is made).  `tile_rows`: rows per tile of the node pre kernels at the model's width."""
         plan = self.row_plan(graph.row_of_node)
-        if self._row_plan[2] is None:
+        if self._row_plan[2] is None or self._row_plan[2].tile_rows != tile_rows:
             win = HaloOverlap.row_windows(plan.recv_idx, graph.type_rowptr, graph.N)
-            self._row_plan = self._row_plan[:2] + (HaloOverlap(plan, win),)
+            ov = HaloOverlap(plan, win)
+            ov.tile_rows = tile_rows
+            if graph.num_src == 0:
+                late = self.late_local
+                if late is None:                  # no classification: every owned atom may read a halo row
+                    late = torch.ones(graph.row_of_node.numel(), dtype=torch.bool, device=graph.row_of_node.device)
+                late_rows = graph.row_of_node.index_select(0, torch.nonzero(late).reshape(-1))
+                ov.fwd_early, ov.fwd_late = HaloOverlap.target_ranges(late_rows, graph.type_rowptr)
+                ov.bwd_first, ov.bwd_rest = HaloOverlap.source_ranges(win.cpu().tolist(), tile_rows, graph.N,
+                                                                      graph.row_of_node.device)
+            self._row_plan = self._row_plan[:2] + (ov,)
         return self._row_plan[2]
 
     def to(self, device):
@@ -300,6 +357,8 @@ class ShardPlan(object):
         self.owned_mask = self.owned_mask.to(device)
         self.owned_local = self.owned_local.to(device)
         self.local_global = self.local_global.to(device)
+        if self.late_local is not None:
+            self.late_local = self.late_local.to(device)
         p = self.atom_plan
         self.atom_plan = ExchangePlan(p.send_idx.to(device), p.send_counts, p.recv_idx.to(device), p.recv_counts,
                                       p.group)
@@ -397,6 +456,9 @@ def partition(data, rank, world, axis=None, group=None):
                      owned_mask, num_graphs, group)
     plan.owned_local = torch.from_numpy(np.nonzero(is_owned)[0])
     plan.local_global = torch.from_numpy(local_ids.copy())
+    late = ~is_owned                                   # halo atoms, and the owned atoms that have a halo source
+    late[ltgt[~is_owned[lsrc]]] = True
+    plan.late_local = torch.from_numpy(late.copy())
     z_np = data.atomic_number.cpu().numpy()
     plan.z_with_in_edges = set(int(v) for v in np.unique(z_np[tgt]))
     plan.zz_with_in_edges = set((int(a), int(b)) for a, b in np.unique(np.stack([z_np[tgt], z_np[src]], 1), axis=0))
@@ -460,8 +522,9 @@ def plan_slab(pos, atomic_number, cell, rc, rank, world, axis=None, group=None, 
     exchange lists.  pos [N,3] float32, atomic_number [N], cell [3,3] / [1,3,3] / None -- the same on every rank, on
     the device the step will run on (host tensors work too: CPU rehearsal).
 
-    Local atoms = owned atoms in ascending global id, then halo atoms in ascending global id (halo rows therefore
-    close every relation's row block: the node kernels can treat "rows that wait for the exchange" as T windows).
+    Local atoms = owned interior atoms, owned atoms within rc + skin of a slab face, halo atoms -- each group in
+    ascending global id (so every relation's row block reads [interior | boundary | halo]: "rows that wait for the
+    exchange" are T windows for the node kernels and a row range per relation for the message kernels).
     The halo is geometric, so sender and receiver derive identical exchange lists independently; it is a superset of
     the atoms that really send an edge across.  While no atom has moved further than skin/2 from `plan.pos_ref`,
     every source within rc of an owned atom is still a local atom: the plan stays valid and only the neighbour
@@ -480,7 +543,14 @@ def plan_slab(pos, atomic_number, cell, rc, rank, world, axis=None, group=None, 
     send_mask[rank] = False
     # receive: my halo grouped by owner (ascending id inside a group); send: for every peer, the atoms I own
     # that lie within reach of ITS slab -- the same set and order the peer derives for its receive list
-    owned = torch.nonzero(mine).reshape(-1)
+    # owned atoms that can have a source outside the slab: within `reach` of one of its faces (a source within rc of an
+    # atom further inside lies strictly between the faces, i.e. is owned -- also after moves of up to skin/2 each).
+    # They follow the interior atoms in the local order, so every relation's row block reads
+    # [interior | boundary | halo]: the messages into the interior rows run while the halo exchange is in flight.
+    near_face = mine & ((coord - lo[rank] <= reach) | (hi[rank] - coord <= reach))
+    interior = torch.nonzero(mine & ~near_face).reshape(-1)
+    boundary = torch.nonzero(near_face).reshape(-1)
+    owned = torch.cat([interior, boundary])                                         # each part in ascending global id
     halo = torch.nonzero(halo_mask).reshape(-1)                                     # ascending global id
     local_ids = torch.cat([owned, halo])
     n_owned = owned.numel()
@@ -505,6 +575,8 @@ def plan_slab(pos, atomic_number, cell, rc, rank, world, axis=None, group=None, 
     plan.target_mask = is_owned.to(torch.uint8)
     plan.cell = None if cell is None else cell.detach().reshape(1, 3, 3)
     plan.halo_pos_local = True            # `slab_data` fills the halo coordinates itself
+    plan.late_local = torch.ones(local_ids.numel(), dtype=torch.bool, device=dev)
+    plan.late_local[:interior.numel()] = False
     return plan
 
 

@@ -204,11 +204,17 @@ int hermnet_edge_geometry_bwd_csc(const float* gD, const int* csr_rowptr, const 
  * wt   [T,R,3H]  rbf_proj.weight of relation t, transposed;  brbf [T,3H] its bias
  * edge [E,4]     from hermnet_edge_geometry_fwd (CSR order)
  * out: x1 [N,H], vec1 [N,3,H]; rows >= type_rowptr[T] are written as zero.
- * H must be a multiple of 64. */
+ * H must be a multiple of 64.
+ * target_ranges (ABI v7; device, [T][2] int32, or NULL = every row; no reference counterpart -- atom shards, SURVEY 8(e)
+ *   "run interior edges while the halo is in flight"): this launch computes only the target rows [lo_t, hi_t) of every
+ *   relation t; rows outside are left untouched.  Two launches over complementary ranges give bit for bit what one
+ *   launch gives: the host runs the targets whose sources are all owned rows while the halo exchange is in flight and
+ *   the others behind it.  zero_unknown_rows != 0: this launch also writes the zero rows >= type_rowptr[T] (always
+ *   done when target_ranges is NULL). */
 int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc* rbf, int hidden,
                                 const float* xh, const float* xh_bias, const float* vec, const float* x,
                                 const float* wt, const float* brbf, const float* edge,
-                                float* x1, float* vec1, void* stream);
+                                float* x1, float* vec1, const int* target_ranges, int zero_unknown_rows, void* stream);
 
 /* Backward of hermnet_message_scatter_fwd for the force path (first order).
  * in : gx1 [N,H], gvec1 [N,3,H] (gradients w.r.t. x1, vec1) + the forward inputs
@@ -217,13 +223,19 @@ int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc* rbf, int h
  *      vector D in CSR order (caller sums over the leading axis; buffer must be zero-filled).
  * split_t = 0: one workgroup walks all relations, gvec is [N,3,H];
  * split_t = 1: one relation per workgroup (3-D grid, better balance), gvec is [T,N,3,H] partial
- *              sums (slice 0 carries the residual's identity term), the caller sums over T. */
+ *              sums (slice 0 carries the residual's identity term), the caller sums over T.
+ * source_ranges (ABI v7; device [num_ranges][2] int32 + the same values in source_ranges_host; num_ranges = 0: every
+ *   row): this launch writes gxh / gvec / gx only for the SOURCE rows of the given disjoint ascending ranges (gedge: the
+ *   edges leaving those rows).  Two launches over complementary ranges give bit for bit what one gives: the host runs
+ *   the halo rows first, sends their gradients home and runs the rest while they travel.  Channel-per-lane form only
+ *   (edge_table given): HN_ERR_BAD_ARG otherwise. */
 int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc* rbf, int hidden,
                                 const float* xh, const float* xh_bias, const float* vec,
                                 const float* wt, const float* brbf, const float* edge,
                                 const float* gx1, const float* gvec1,
                                 float* gxh, float* gvec, float* gx, float* gedge, int split_t,
-                                const float* edge_table, float* gvec_partials, void* stream);
+                                const float* edge_table, float* gvec_partials,
+                                const int* source_ranges, const int* source_ranges_host, int num_ranges, void* stream);
 
 /* Per-edge radial record, computed ONCE per step (geometry and radial basis are shared by every layer):
  * table [E + 1, 32] floats in CSC order -- record q belongs to CSC edge q, i.e. CSR edge csc_pos[q]; `edge` stays in

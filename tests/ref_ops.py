@@ -362,14 +362,34 @@ def node_update_bwd_from_inputs(gxo, gvo, x1, vec1, w, graph):
         return torch.autograd.grad([xo, vo], [x1_, v_], [gxo, gvo])
 
 
-def msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=True):
+def _rows_of_ranges(ranges, n):
+    sel = torch.zeros(n, dtype=torch.bool)
+    for lo, hi in ranges:
+        if hi > lo:
+            sel[lo:hi] = True
+    return sel
+
+
+def msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=True, ranges=None, zero_unknown=True, out=None):
+    """`ranges` [T,2]: like the kernel, only these target rows are written (the rest keeps what `out` holds: poison
+    when this call allocates it)."""
     edge = edge[0] if edge.dim() == 3 else edge
-    return message_scatter_ref(xh + w.b2 if xh_bias else xh, vec, x, edge, w.wt, w.brbf, graph, rbf)     # xh_bias = w.b2 [T,1,3H]
+    x1, vec1 = message_scatter_ref(xh + w.b2 if xh_bias else xh, vec, x, edge, w.wt, w.brbf, graph, rbf)  # xh_bias = w.b2 [T,1,3H]
+    if ranges is None:
+        return x1, vec1
+    sel = _rows_of_ranges(ranges.tolist(), x1.size(0))
+    if zero_unknown:
+        sel[int(graph.type_rowptr[-1]):] = True
+    if out is None:
+        out = (torch.full_like(x1, float("nan")), torch.full_like(vec1, float("nan")))
+    out[0][sel], out[1][sel] = x1[sel], vec1[sel]
+    return out
 
 
-def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True):
+def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True, ranges=None, out=None):
     """Backward contract of hermnet_message_scatter_bwd via autograd of the dense restatement;
-    the edge gradient is Cartesian (w.r.t. D = rhat * d)."""
+    the edge gradient is Cartesian (w.r.t. D = rhat * d).  `ranges` = (tensor, [(lo, hi)]): only these SOURCE rows (and
+    the edges leaving them) are written, the call returns its buffers (gxh, gvec, gx, None) for the complementary call."""
     with torch.enable_grad():
         xh_ = (xh + w.b2 if xh_bias else xh).detach().requires_grad_(True)
         x_ = torch.zeros(xh.size(1), H, dtype=xh.dtype).requires_grad_(True)
@@ -382,8 +402,6 @@ def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True):
         x1, vec1 = message_scatter_ref(xh_, v_, x_, e_, w.wt, w.brbf, graph, rbf)
         ins = [xh_, x_, D] + ([v_] if vec is not None else [])
         gr = torch.autograd.grad([x1, vec1], ins, [gx1, gvec1])
-    gedge.zero_()                    # (the caller may hand over uninitialised memory: the kernels write every slot)
-    gedge[0, :, :3] = gr[2]          # all column blocks' contributions in slice 0, the others zero
     gxh, gv, gx = gr[0], (gr[3] if vec is not None else None), gr[1]
     res = getattr(graph, "res_row", None)
     if res is not None:
@@ -393,7 +411,22 @@ def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True):
         gx = gx - torch.zeros_like(gx).index_add_(0, res.long(), gx1 * rk[:, None] * (1 / math.sqrt(2.0)))
         if gv is not None:
             gv = gv - torch.zeros_like(gv).index_add_(0, res.long(), gvec1 * rk[:, None, None])
-    return gxh, gv, gx
+    if ranges is None:
+        gedge.zero_()                    # (the caller may hand over uninitialised memory: the kernels write every slot)
+        gedge[0, :, :3] = gr[2]          # all column blocks' contributions in slice 0, the others zero
+        return gxh, gv, gx
+    sel = _rows_of_ranges(ranges[1], xh.size(1))
+    if out is None:
+        nan = lambda t_: None if t_ is None else torch.full_like(t_, float("nan"))
+        out = (nan(gxh), nan(gv), nan(gx), None)
+    out[0][:, sel] = gxh[:, sel]
+    if gv is not None:
+        out[1][sel] = gv[sel]
+    out[2][sel] = gx[sel]
+    esel = sel[graph.csr_src.long()]                # the edges leaving the selected source rows
+    gedge[:, esel] = 0
+    gedge[0, esel, :3] = gr[2][esel]
+    return out
 
 
 class RefEdgeGeometry(torch.autograd.Function):

@@ -110,6 +110,71 @@ def test_message_scatter_op(name, has_vec, bwd_form):
         assert rel_err(a.double(), b) < 2 * TOL, nm
 
 
+@pytest.mark.parametrize("name,has_vec", [("alloy108", True), ("alloy108_unknown_type", True), ("alloy108_h64", False),
+                                          ("alloy32_h256", True), ("mol16", True)])
+def test_message_kernels_over_complementary_row_ranges_are_bit_identical(name, has_vec):
+    """Atom shards run the message kernels in two launches around the halo exchange ("run interior edges
+    while the halo is in flight"): forward over complementary TARGET row ranges of every relation, backward over
+    complementary SOURCE row ranges.  Poisoned buffers in between; together they must give bit for bit what one launch
+    gives -- ragged, empty and whole-block ranges."""
+    from hermnet_amd import layer as L
+    from hermnet_amd.ops import edge_radial_table
+    from test_host_logic import _layer_weights_and_graph
+    dev = _dev()
+    g = Golden(name)
+    d, graph = _graph(g, dev)
+    model = g.model().to(dev)
+    rbf = model.radial_basis.descriptor()
+    H, R, T, N = model.hidden_channels, rbf.num_rbf, graph.T, graph.N
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    rnd = lambda *s_: torch.randn(*s_, generator=gen).to(dev)
+    xh, x = rnd(T, N, 3 * H), rnd(N, H)
+    vec = rnd(N, 3, H) if has_vec else None
+
+    class W:          # what layer._msg_fwd / _msg_bwd read of LayerWeights
+        wt = (rnd(T, R, 3 * H) / math.sqrt(R)).contiguous()
+        brbf = (0.1 * rnd(T, 3 * H)).contiguous()
+        b2 = None
+    edge = EdgeGeometry.apply(d.pos, d.get("cell"), graph).detach()
+    graph.edge_table = edge_radial_table(graph, rbf, edge)
+    rp = list(graph.type_rowptr_host)
+    x1, vec1 = L._msg_fwd(graph, rbf, H, xh, vec, x, W, edge, xh_bias=False)
+    cuts = [[rp[t], rp[t] + (rp[t + 1] - rp[t]) * k // 3, rp[t + 1]] for t, k in zip(range(T), [1, 0, 3, 2])]
+    early = torch.tensor([[c[0], c[1]] for c in cuts], dtype=torch.int32, device=dev)
+    late = torch.tensor([[c[1], c[2]] for c in cuts], dtype=torch.int32, device=dev)
+    nan = lambda t_: torch.full_like(t_, float("nan"))
+    part = L._msg_fwd(graph, rbf, H, xh, vec, x, W, edge, xh_bias=False, ranges=early, zero_unknown=True, out=(nan(x1), nan(vec1)))
+    esel = torch.zeros(N, dtype=torch.bool, device=dev)
+    for c in cuts:
+        esel[c[0]:c[1]] = True
+    esel[rp[-1]:] = True
+    assert torch.equal(part[0][esel], x1[esel]) and bool(torch.isnan(part[0][~esel]).all())
+    both = L._msg_fwd(graph, rbf, H, xh, vec, x, W, edge, xh_bias=False, ranges=late, zero_unknown=False, out=part)
+    assert torch.equal(both[0], x1) and torch.equal(both[1], vec1)
+
+    gx1, gv1 = rnd(N, H), rnd(N, 3, H)
+    zeros = lambda: torch.zeros(H // 64, graph.E, 4, device=dev)
+    ge = zeros()
+    gxh, gvec, gx = L._msg_bwd(graph, rbf, H, xh, vec, W, edge, gx1, gv1, ge, xh_bias=False)
+    a, b, c_ = N // 5, N // 5 + 37, N - 3
+    for first, rest in [([(a, b), (c_, N)], [(0, a), (b, c_)]), ([(0, N)], []), ([(0, 1)], [(1, N)])]:
+        ge2 = nan(ge)
+        dv = lambda r: torch.tensor(r, dtype=torch.int32, device=dev).reshape(-1, 2)
+        bufs = L._msg_bwd(graph, rbf, H, xh, vec, W, edge, gx1, gv1, ge2, xh_bias=False, ranges=(dv(first), first),
+                          out=(nan(gxh), None if gvec is None else nan(gvec), nan(gx),
+                               None if (vec is None or T == 1) else torch.full((T,) + tuple(vec.shape), float("nan"), device=dev)))
+        fsel = torch.zeros(N, dtype=torch.bool, device=dev)
+        for lo, hi in first:
+            fsel[lo:hi] = True
+        assert torch.equal(bufs[0][:, fsel], gxh[:, fsel]) and torch.equal(bufs[2][fsel], gx[fsel])
+        assert bool(torch.isnan(bufs[2][~fsel]).all())
+        if rest:
+            bufs = L._msg_bwd(graph, rbf, H, xh, vec, W, edge, gx1, gv1, ge2, xh_bias=False, ranges=(dv(rest), rest), out=bufs)
+        assert torch.equal(bufs[0], gxh) and torch.equal(bufs[2], gx) and torch.equal(ge2, ge)
+        if gvec is not None:
+            assert torch.equal(bufs[1], gvec)
+
+
 @pytest.mark.parametrize("name", SMALL_CASES + NONGAUSS_CASES)
 def test_hvnet_matches_reference_golden(name):
     """Energy + forces of the HIP path vs the reference's own outputs (golden fixtures)."""
@@ -707,12 +772,12 @@ def test_bias_on_load_equals_bias_in_operand():
     def run(xh_in, bias, v, tab=None):
         x1, vec1 = torch.empty_like(x), torch.empty(N, 3, H, device=dev)
         assert lib.hermnet_message_scatter_fwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh_in), P(bias), P(v), P(x), P(wt),
-                                               P(brbf), P(edge), P(x1), P(vec1), _stream()) == 0
+                                               P(brbf), P(edge), P(x1), P(vec1), None, 1, _stream()) == 0
         gxh, gvec, gx = torch.empty_like(xh), torch.empty_like(vec), torch.empty_like(x)
         gedge = torch.zeros(H // 64, graph.E, 4, device=dev)
         assert lib.hermnet_message_scatter_bwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh_in), P(bias), P(v), P(wt), P(brbf),
                                                P(edge), P(gx1), P(gv1), P(gxh), P(gvec if v is not None else None), P(gx),
-                                               P(gedge), 0, P(tab), P(part if tab is not None else None), _stream()) == 0
+                                               P(gedge), 0, P(tab), P(part if tab is not None else None), None, None, 0, _stream()) == 0
         return [x1, vec1, gxh, gx, gedge.sum(0)] + ([gvec] if v is not None else [])
 
     for v in (vec, None):

@@ -224,15 +224,24 @@ def test_partition_slab_is_consistent_and_covers_the_global_graph(case, world):
     all_edges = set(map(tuple, glob.T.tolist()))
     seen = set()
     for r, (loc, plan) in enumerate(parts):
-        assert torch.equal(plan.owned_global, exact[r][1].owned_global)           # same slabs as the host planner
+        assert torch.equal(torch.sort(plan.owned_global).values, exact[r][1].owned_global)    # same slabs as the host planner
         assert set(exact[r][1].halo_global.tolist()) <= set(plan.halo_global.tolist())
         keys = _edge_keys(plan, loc)
         assert len(keys) == loc.edge_index.size(1) and not (keys & seen)
         seen |= keys
         assert bool(plan.owned_mask[loc.edge_index[1]].all())                    # targets are owned
         assert torch.equal(loc.pos, d.pos[plan.local_global])                    # halo coordinates included: no exchange
-        # local order: owned atoms by ascending id, then halo atoms by ascending id
+        # local order: owned interior atoms, owned atoms near a slab face, halo atoms -- each by ascending id; every owned
+        # atom that really has a halo source is in the second group (the message kernels run the first group's rows
+        # while the halo exchange is in flight)
         assert torch.equal(plan.local_global, torch.cat([plan.owned_global, plan.halo_global]))
+        late = plan.late_local
+        n_int = int((~late).sum())
+        assert not bool(late[:n_int].any()) and bool(late[n_int:].all()) and n_int <= plan.n_owned
+        for part in (plan.owned_global[:n_int], plan.owned_global[n_int:]):
+            assert torch.equal(part, torch.sort(part).values)
+        reads_halo = loc.edge_index[1][~plan.owned_mask[loc.edge_index[0]]]
+        assert bool(late[reads_halo].all())
         assert torch.equal(plan.halo_global, torch.sort(plan.halo_global).values)
         assert bool(plan.owned_mask[:plan.n_owned].all()) and not bool(plan.owned_mask[plan.n_owned:].any())
         for p in range(world):
@@ -335,6 +344,7 @@ def _slab_worker(rank, world, port, out, overlap):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["HERMNET_HALO_OVERLAP"] = overlap
+    os.environ["HERMNET_DEBUG_POISON"] = "1"      # halo rows are NaN until the exchange has delivered them
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -397,9 +407,9 @@ def test_slab_partition_world8_gloo_matches_single_process(monkeypatch, overlap)
         e, owned, f, nhalo, zin, packs = out[r]
         assert rel_err(torch.from_numpy(e), e_ref.detach()) < 5e-6
         assert nhalo > 0 and zin == [13, 28, 29]
-        # HERMNET_HALO_OVERLAP=1: the exchange runs inside the consuming layer (pack + unpack forward, pack-and-clear
-        # backward), split around the windowed node projection
-        assert packs == (3 * (SLAB_KW["num_layers"] - 1) if overlap == "1" else 0)
+        # HERMNET_HALO_OVERLAP=1 (the default): the exchange runs inside the consuming layer (pack + poison + unpack
+        # forward, pack-and-clear backward) behind the node projection and the messages into the interior rows
+        assert packs == (4 * (SLAB_KW["num_layers"] - 1) if overlap == "1" else 0)
         forces[owned] = f
         seen[owned] += 1
     assert (seen == 1).all()
@@ -495,6 +505,20 @@ def _gpu_slab_worker(rank, world, reps, port, out, overlap, kind="hvnet"):
         e2 = model(local)
         f2 = -torch.autograd.grad(e2.sum(), local.pos)[0]
         res["repro"] = bool(torch.equal(e, e2) and torch.equal(f_local, f2))
+        if overlap == "1":
+            # the exchange hidden behind the node projection and the interior rows' messages is the SAME arithmetic as
+            # the blocking exchange in front of the layer: bit-identical -- also with the halo rows poisoned (NaN) from
+            # the moment the all-to-all starts until its result is unpacked
+            os.environ["HERMNET_DEBUG_POISON"] = "1"
+            e3 = model(local)
+            f3 = -torch.autograd.grad(e3.sum(), local.pos)[0]
+            os.environ["HERMNET_DEBUG_POISON"] = "0"
+            os.environ["HERMNET_HALO_OVERLAP"] = "0"
+            e4 = model(local)
+            f4 = -torch.autograd.grad(e4.sum(), local.pos)[0]
+            os.environ["HERMNET_HALO_OVERLAP"] = "1"
+            res["same_poisoned"] = bool(torch.equal(e, e3) and torch.equal(f_local, f3))
+            res["same_as_blocking"] = bool(torch.equal(e, e4) and torch.equal(f_local, f4))
         if rank == 0:     # the same cell on ONE GPU, unsharded: the strong-scaling baseline
             d = synth.fcc_alloy(reps=reps, device=dev)
             d.pos.requires_grad_(True)
@@ -579,14 +603,15 @@ def test_slab_stepper_along_a_trajectory_matches_single_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,reps,overlap,kind", [(2, (10, 10, 250), "0", "hvnet"), (3, (10, 10, 25), "0", "hvnet"),
-                                                     (3, (10, 10, 25), "1", "hvnet"), (2, (6, 6, 12), "0", "htnet")])
+@pytest.mark.parametrize("world,reps,overlap,kind", [(2, (10, 10, 250), "1", "hvnet"), (3, (10, 10, 25), "0", "hvnet"),
+                                                     (3, (10, 10, 25), "1", "hvnet"), (2, (6, 6, 12), "1", "htnet")])
 def test_sharded_100k_cell_matches_single_gpu(world, reps, overlap, kind):
     """BASELINE configs[3] at full size (fcc 10x10x250 = 100,000 atoms) through the sharded HIP path with slab-local
     planning, ranks sharing the one GPU of the box; energy and forces must equal the unsharded evaluation of the
-    same cell on one GPU.  (world 3 on the 10k cell: uneven slabs; overlap = "1": the feature exchange inside the
-    consuming layer, between the two windowed launches of its node projection; kind = "htnet": the triadic model through
-    the same sharding.)"""
+    same cell on one GPU.  (world 3 on the 10k cell: uneven slabs; overlap = "1", the default: the feature exchange
+    inside the consuming layer, behind its node projection and the messages into the rows that read no halo row --
+    bit-identical to the blocking exchange ("0"), also with poisoned halo rows; kind = "htnet": the triadic model
+    through the same sharding (blocking exchange: its virtual target rows keep the plain form).)"""
     port = 37500 + (os.getpid() + world) % 2000
     out = mp.Manager().dict()
     mp.spawn(_gpu_slab_worker, args=(world, reps, port, out, overlap, kind), nprocs=world, join=True)
@@ -600,6 +625,7 @@ def test_sharded_100k_cell_matches_single_gpu(world, reps, overlap, kind):
         assert rel_err(torch.from_numpy(res["e"]), e_ref) < 1e-5
         assert res["nhalo"] > 0 and res["nlocal"] < n // world + 4000        # a slab and its halo, not the whole cell
         assert res["repro"]                                                   # deterministic accumulation everywhere
+        assert res.get("same_poisoned", True) and res.get("same_as_blocking", True)
         forces[res["owned"]] = res["f"]
         seen[res["owned"]] += 1
         edges += res["edges"]

@@ -59,7 +59,7 @@ def main():
 
     def fwd(v):
         return lib.hermnet_message_scatter_fwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(xb), P(v), P(x), P(wt), P(brbf),
-                                               P(edge), P(x1), P(vec1), _stream())
+                                               P(edge), P(x1), P(vec1), None, 1, _stream())
 
     # KBENCH_TABLE=0: without the per-edge radial table the backward takes its 16-lanes-per-edge (VW) form
     from hermnet_amd.ops import edge_radial_table
@@ -70,7 +70,7 @@ def main():
     def bwd(v):
         return lib.hermnet_message_scatter_bwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(xb), P(v), P(wt), P(brbf), P(edge),
                                                P(gx1), P(gvec1), P(gxh), P(gvec if v is not None else None), P(gx),
-                                               P(gedge), split, P(table), P(part), _stream())
+                                               P(gedge), split, P(table), P(part), None, None, 0, _stream())
 
     ab = algorithmic_bytes(E, N, H, T)
     res = {}
