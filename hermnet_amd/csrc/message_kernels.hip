@@ -935,7 +935,7 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
                                            const float* xh, const float* xh_bias, const float* vec, const float* x,
                                            const float* wt, const float* brbf, const float* edge,
                                            float* x1, float* vec1, const int* target_ranges, int zero_unknown_rows,
-                                           void* stream) {
+                                           int range_rows, void* stream) {
   MsgArgs a = {};
   int rc = fill_args(g, rbf, hidden, a);
   if (rc) return rc;
@@ -950,13 +950,16 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   static const int variant_vec = env_int("HERMNET_FWD_VARIANT", 8420);
   static const int variant_l0 = env_int("HERMNET_FWD_VARIANT_L0", 16420);
   const int variant = vec ? variant_vec : variant_l0;
-  a.rows_per_block = pick_rows(a.N, hidden / HN_CB, a.T * (hidden / HN_CB), rpb_fwd);
+  // (a launch over row ranges sizes its workgroups for the rows it covers: a workgroup of the full launch lives as long
+  // as the whole kernel, so a launch over a tenth of the rows with the same chunking would take just as long)
+  const int rows = (target_ranges && range_rows > 0 && range_rows < a.N) ? range_rows : a.N;
+  a.rows_per_block = pick_rows(rows, hidden / HN_CB, a.T * (hidden / HN_CB), rpb_fwd);
   static const int xcd = env_int("HERMNET_XCD_REMAP", 1);
   a.xcd_remap = xcd;
   const size_t lds = lds_bytes(a.R);
   if (lds > 160 * 1024) return HN_ERR_LDS;
   // blocks: sum_t ceil(N_t / rpb) <= N / rpb + T, plus one surplus block that zeroes unknown rows
-  dim3 grid((unsigned)(a.N / a.rows_per_block + a.T + 1), (unsigned)(hidden / HN_CB));
+  dim3 grid((unsigned)(rows / a.rows_per_block + a.T + 1), (unsigned)(hidden / HN_CB));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int nw = 16;
   kern_t k = vec ? pick_fwd<true>(variant, nw) : pick_fwd<false>(variant, nw);

@@ -118,10 +118,10 @@ class LayerWeights(object):
         return self
 
 
-def _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=True, ranges=None, zero_unknown=True, out=None):
+def _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=True, ranges=None, zero_unknown=True, out=None, range_rows=0):
     """`xh_bias=False`: xh already includes x_proj's bias (chain kernels).  `ranges` [T,2] int32 (device): only these
     target rows of every relation (atom shards: two launches over complementary ranges around the halo exchange;
-    the second passes the first one's result as `out`)."""
+    the second passes the first one's result as `out`); `range_rows`: how many rows they cover (host int)."""
     lib = _lib.load()
     b2 = w.b2 if xh_bias else None
     if out is None:
@@ -133,7 +133,8 @@ def _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=True, ranges=None, zero
     _lib.check(_launch("message_scatter_fwd" + ("" if vec is not None else "_l0"),
                        lambda: lib.hermnet_message_scatter_fwd(
                            ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(b2), P(vec), P(x), P(w.wt), P(w.brbf), P(edge),
-                           P(x1), P(vec1), P(ranges), 1 if zero_unknown else 0, _stream())), "hermnet_message_scatter_fwd")
+                           P(x1), P(vec1), P(ranges), 1 if zero_unknown else 0, int(range_rows), _stream())),
+               "hermnet_message_scatter_fwd")
     return x1, vec1
 
 
@@ -256,14 +257,17 @@ class FusedRelationalLayer(torch.autograd.Function):
                 if _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":
                     # (tests: nothing that runs before the unpack may depend on a halo row)
                     nodeops.halo_rows(2, x, vec, plan.recv_idx, torch.full_like(recv, float("nan")))
-                pre = nodeops.node_pre_fwd(x, w, T)
-                out = _msg_fwd(graph, rbf, H, pre[1], vec, x, w, edge, xh_bias=False, ranges=halo.fwd_early, zero_unknown=True)
+                hb, xh, mean, rstd = pre = nodeops.node_pre_fwd(x, w, T)
+                x1, vec1 = out = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False, ranges=halo.fwd_early,
+                                          zero_unknown=True, range_rows=halo.early_rows)
                 if work is not None:
                     work.wait()
-                nodeops.halo_rows(2, x, vec, plan.recv_idx, recv)
-                hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T, windows=halo.windows, mode=1, out=pre)
-                x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False, ranges=halo.fwd_late,
-                                    zero_unknown=False, out=out)
+                if plan.recv_idx.numel() > 0:  # (a rank without halo atoms has nothing to redo)
+                    nodeops.halo_rows(2, x, vec, plan.recv_idx, recv)
+                    nodeops.node_pre_fwd(x, w, T, windows=halo.windows, mode=1, out=pre)
+                if halo.late_rows > 0:
+                    _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False, ranges=halo.fwd_late, zero_unknown=False,
+                             out=out, range_rows=halo.late_rows)
             ctx.halo = halo
             x_out, vec_out, vp, h2b, q23, nrm = nodeops.node_update_fwd(x1, vec1, w, graph)
             ctx.save_for_backward(x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23, nrm)

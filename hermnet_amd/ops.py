@@ -184,7 +184,7 @@ class MessageScatter(torch.autograd.Function):
         gs, rs = graph.as_struct(), rbf.struct()
         _lib.check(_launch("message_scatter_fwd" + ("" if vec_c is not None else "_l0"), lambda: lib.hermnet_message_scatter_fwd(
             ctypes.byref(gs), ctypes.byref(rs), H, _lib.ptr(xh), None, _lib.ptr(vec_c), _lib.ptr(x),
-            _lib.ptr(wt), _lib.ptr(brbf), _lib.ptr(edge), _lib.ptr(x1), _lib.ptr(vec1), None, 1, _stream())),
+            _lib.ptr(wt), _lib.ptr(brbf), _lib.ptr(edge), _lib.ptr(x1), _lib.ptr(vec1), None, 1, 0, _stream())),
             "hermnet_message_scatter_fwd")
         ctx.save_for_backward(xh, vec_c, edge, wt, brbf)
         ctx.graph, ctx.rbf, ctx.H = graph, rbf, H

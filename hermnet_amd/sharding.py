@@ -344,8 +344,13 @@ class ShardPlan(object):
                 late = self.late_local
                 if late is None:                  # no classification: every owned atom may read a halo row
                     late = torch.ones(graph.row_of_node.numel(), dtype=torch.bool, device=graph.row_of_node.device)
+                if plan.recv_idx.numel() == 0:    # no halo atom here: nothing is late (the rank still joins the exchange)
+                    late = torch.zeros_like(late)
                 late_rows = graph.row_of_node.index_select(0, torch.nonzero(late).reshape(-1))
                 ov.fwd_early, ov.fwd_late = HaloOverlap.target_ranges(late_rows, graph.type_rowptr)
+                el = torch.stack([ov.fwd_early, ov.fwd_late]).cpu()          # (one more small host read per plan)
+                ov.early_rows = int((el[0, :, 1] - el[0, :, 0]).clamp(min=0).sum())
+                ov.late_rows = int((el[1, :, 1] - el[1, :, 0]).clamp(min=0).sum())
                 ov.bwd_first, ov.bwd_rest = HaloOverlap.source_ranges(win.cpu().tolist(), tile_rows, graph.N,
                                                                       graph.row_of_node.device)
             self._row_plan = self._row_plan[:2] + (ov,)
@@ -580,6 +585,148 @@ def plan_slab(pos, atomic_number, cell, rc, rank, world, axis=None, group=None, 
     return plan
 
 
+def block_grid(world, cell=None, pos=None):
+    """A (pa, pb, pc) factorisation of `world` for `plan_blocks`: the factors go to the longest extents first, so that the
+    blocks come out as cubic as the cell allows (a 36 x 36 x 900 A cell at world 8 -> (1, 1, 8): slabs; a 105 A cube ->
+    (2, 2, 2))."""
+    if cell is not None:
+        ext = [float(v) for v in cell.detach().double().reshape(-1, 3, 3)[0].norm(dim=1).cpu()]
+    else:
+        p = pos.detach().double()
+        ext = [float(v) for v in (p.max(0).values - p.min(0).values).cpu()] if p.size(0) else [1.0, 1.0, 1.0]
+    grid, n = [1, 1, 1], int(world)
+    f = 2
+    primes = []
+    while n > 1:
+        while n % f == 0:
+            primes.append(f)
+            n //= f
+        f += 1
+    for q in sorted(primes, reverse=True):           # largest factor to the currently longest block edge
+        a = max(range(3), key=lambda k: ext[k] / grid[k])
+        grid[a] *= q
+    return tuple(grid)
+
+
+def _equal_count_cuts(coord, groups, parts):
+    """Inside every group (`groups` [N] int64 group id, ids 0 .. G-1) split the atoms into `parts` equal-count pieces by
+    ascending `coord` (stable).  Returns the piece index [N] in 0 .. parts-1."""
+    n = coord.numel()
+    dev = coord.device
+    if parts == 1 or n == 0:
+        return torch.zeros(n, dtype=torch.long, device=dev)
+    G = int(groups.max()) + 1 if n else 1
+    # sort by (group, coord): a stable sort by coord followed by a stable sort by group
+    o1 = torch.argsort(coord, stable=True)
+    o2 = torch.argsort(groups[o1], stable=True)
+    order = o1[o2]
+    gs = groups[order]
+    cnt = torch.bincount(gs, minlength=G)
+    start = torch.cumsum(cnt, 0) - cnt
+    rank_in = torch.arange(n, device=dev) - start[gs]
+    piece_sorted = (rank_in * parts) // cnt[gs].clamp(min=1)          # pieces of floor / ceil(count / parts) atoms
+    piece = torch.empty(n, dtype=torch.long, device=dev)
+    piece[order] = piece_sorted.clamp(max=parts - 1)
+    return piece
+
+
+def plan_blocks(pos, atomic_number, cell, rc, rank, world, grid=None, group=None, skin=0.0):
+    """`plan_slab` in up to three dimensions ("spatial slabs (or blocks)"): the atoms are cut into pa equal-count
+    slabs along the first axis, every slab into pb equal-count strips along the second, every strip into pc boxes along
+    the third (grid = (pa, pb, pc), pa pb pc = world; default `block_grid`).  A rank's halo is everything within
+    rc + skin of its box along EVERY cut axis (periodic in fractional coordinates) -- geometric, so sender and receiver
+    derive identical lists independently, exactly as for slabs; for a near-cubic cell the halo of a box is a fraction of
+    a slab's.  Same plan object, same local order (interior | near a box face | halo)."""
+    dev = pos.device
+    n = pos.size(0)
+    if grid is None:
+        grid = block_grid(world, cell, pos)
+    grid = tuple(int(g_) for g_ in grid)
+    if grid[0] * grid[1] * grid[2] != world:
+        raise ValueError("grid %r does not multiply to the world size %d" % (grid, world))
+    periodic = cell is not None
+    p64 = pos.detach().double()
+    coords, margins = [], []
+    if periodic:
+        c = cell.detach().double().reshape(-1, 3, 3)[0].cpu()
+        inv = torch.linalg.inv(c)
+        for a in range(3):
+            col = inv[:, a].to(dev)
+            # elementwise, fixed order: every rank must get bit-identical coordinates (no BLAS here)
+            fr = p64[:, 0] * col[0] + p64[:, 1] * col[1] + p64[:, 2] * col[2]
+            coords.append(fr - torch.floor(fr))
+            margins.append(float(inv[:, a].norm()))
+    else:
+        for a in range(3):
+            coords.append(p64[:, a].clone())
+            margins.append(1.0)
+    owner = torch.zeros(n, dtype=torch.long, device=dev)
+    for a in range(3):                                    # hierarchical equal-count cuts
+        owner = owner * grid[a] + _equal_count_cuts(coords[a], owner, grid[a])
+    mine = owner == rank
+    # every rank's box along the cut axes: [lo, hi] of its atoms' coordinates (nan for an empty rank: reaches nothing)
+    near = torch.ones(world, n, dtype=torch.bool, device=dev)
+    near_face = torch.zeros(n, dtype=torch.bool, device=dev)
+    big = torch.full((world,), float("inf"), dtype=torch.float64, device=dev)
+    for a in range(3):
+        if grid[a] == 1:
+            continue
+        reach = (float(rc) + float(skin)) * margins[a] * (1.0 + 1e-9) + 1e-12
+        lo = big.clone().scatter_reduce(0, owner, coords[a], "amin")
+        hi = (-big).clone().scatter_reduce(0, owner, coords[a], "amax")
+        empty = lo > hi
+        lo = torch.where(empty, torch.full_like(lo, float("nan")), lo)
+        hi = torch.where(empty, torch.full_like(hi, float("nan")), hi)
+        near &= _within_cutoff_of_slab(coords[a][None, :], lo[:, None], hi[:, None], reach, periodic)
+        near_face |= mine & ((coords[a] - lo[rank] <= reach) | (hi[rank] - coords[a] <= reach))
+    return _finish_plan(pos, atomic_number, cell, rc, skin, rank, world, group, owner, mine, near, near_face)
+
+
+def _finish_plan(pos, atomic_number, cell, rc, skin, rank, world, group, owner, mine, near, near_face):
+    """Local order, exchange lists and plan object from the owners and the geometric reach masks (`plan_blocks`)."""
+    dev = pos.device
+    n = pos.size(0)
+    halo_mask = near[rank] & ~mine
+    send_mask = near & mine[None, :]
+    send_mask[rank] = False
+    interior = torch.nonzero(mine & ~near_face).reshape(-1)
+    boundary = torch.nonzero(near_face).reshape(-1)
+    owned = torch.cat([interior, boundary])
+    halo = torch.nonzero(halo_mask).reshape(-1)
+    local_ids = torch.cat([owned, halo])
+    n_owned = owned.numel()
+    g2l = torch.full((n,), -1, dtype=torch.long, device=dev)
+    g2l[local_ids] = torch.arange(local_ids.numel(), device=dev)
+    halo_owner = owner[halo]
+    recv_idx = g2l[halo[torch.argsort(halo_owner, stable=True)]]
+    pairs = torch.nonzero(send_mask)                                                # (peer, atom), peer-major
+    send_idx = g2l[pairs[:, 1]]
+    counts = torch.stack([torch.bincount(halo_owner, minlength=world),
+                          torch.bincount(pairs[:, 0], minlength=world)]).cpu().tolist()   # the host read of the plan
+    is_owned = torch.zeros(local_ids.numel(), dtype=torch.bool, device=dev)
+    is_owned[:n_owned] = True
+    plan = ShardPlan(rank, world, owned, halo, ExchangePlan(send_idx, counts[1], recv_idx, counts[0], group),
+                     is_owned, 1, group)
+    plan.owned_local = torch.arange(n_owned, device=dev)
+    plan.local_global = local_ids
+    plan.rc, plan.skin = float(rc), float(skin)
+    plan.pos_ref = pos.detach().clone()
+    plan.z_local = atomic_number[local_ids]
+    plan.batch_local = torch.zeros(local_ids.numel(), dtype=torch.long, device=dev)
+    plan.target_mask = is_owned.to(torch.uint8)
+    plan.cell = None if cell is None else cell.detach().reshape(1, 3, 3)
+    plan.halo_pos_local = True            # `slab_data` fills the halo coordinates itself
+    plan.late_local = torch.ones(local_ids.numel(), dtype=torch.bool, device=dev)
+    plan.late_local[:interior.numel()] = False
+    return plan
+
+
+def partition_blocks(pos, atomic_number, cell, rc, rank, world, grid=None, group=None, reference_compat=False, skin=0.0):
+    """`partition_slab` with boxes instead of slabs: `plan_blocks` + `slab_data`."""
+    plan = plan_blocks(pos, atomic_number, cell, rc, rank, world, grid=grid, group=group, skin=skin)
+    return slab_data(plan, pos, reference_compat), plan
+
+
 def slab_data(plan, pos, reference_compat=False):
     """This rank's `Data` for the current coordinates under a plan that is still valid (`plan_moved` says whether it
     is): the cutoff pairs among the local atoms whose TARGET is owned, listed directly by the neighbour search
@@ -671,9 +818,12 @@ class SlabStepper(object):
     re-plan step searches once).  The cell and the atomic numbers are watched by tensor identity and version: replace
     them or edit them in place, never through `.data` (writes through `.data` or a numpy view do not bump the version)."""
 
-    def __init__(self, atomic_number, cell, rc, rank, world, skin=1.0, axis=None, group=None, reference_compat=False):
+    def __init__(self, atomic_number, cell, rc, rank, world, skin=1.0, axis=None, group=None, reference_compat=False,
+                 grid=None):
+        """`grid` = (pa, pb, pc) or "auto" (`block_grid`): boxes instead of slabs (`plan_blocks`)."""
         self.z, self.cell, self.rc, self.skin = atomic_number, cell, float(rc), float(skin)
         self.rank, self.world, self.axis, self.group = rank, world, axis, group
+        self.grid = grid
         self.reference_compat = reference_compat
         self.plan = None
         self.replans = 0
@@ -681,8 +831,12 @@ class SlabStepper(object):
         self._z_key = (None, None)
 
     def _replan(self, pos):
-        self.plan = plan_slab(pos, self.z, self.cell, self.rc, self.rank, self.world, axis=self.axis, group=self.group,
-                              skin=self.skin)
+        if self.grid is not None:
+            self.plan = plan_blocks(pos, self.z, self.cell, self.rc, self.rank, self.world,
+                                    grid=None if self.grid == "auto" else self.grid, group=self.group, skin=self.skin)
+        else:
+            self.plan = plan_slab(pos, self.z, self.cell, self.rc, self.rank, self.world, axis=self.axis,
+                                  group=self.group, skin=self.skin)
         self.replans += 1
 
     def __call__(self, pos):

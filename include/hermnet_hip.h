@@ -210,11 +210,14 @@ int hermnet_edge_geometry_bwd_csc(const float* gD, const int* csr_rowptr, const 
  *   relation t; rows outside are left untouched.  Two launches over complementary ranges give bit for bit what one
  *   launch gives: the host runs the targets whose sources are all owned rows while the halo exchange is in flight and
  *   the others behind it.  zero_unknown_rows != 0: this launch also writes the zero rows >= type_rowptr[T] (always
- *   done when target_ranges is NULL). */
+ *   done when target_ranges is NULL).  range_rows: the number of rows the ranges cover (host value; sizes the grid and the
+ *   rows per workgroup; <= 0 = unknown, the whole row count is assumed -- correct, but a short launch then lasts as long
+ *   as a full one). */
 int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc* rbf, int hidden,
                                 const float* xh, const float* xh_bias, const float* vec, const float* x,
                                 const float* wt, const float* brbf, const float* edge,
-                                float* x1, float* vec1, const int* target_ranges, int zero_unknown_rows, void* stream);
+                                float* x1, float* vec1, const int* target_ranges, int zero_unknown_rows, int range_rows,
+                                void* stream);
 
 /* Backward of hermnet_message_scatter_fwd for the force path (first order).
  * in : gx1 [N,H], gvec1 [N,3,H] (gradients w.r.t. x1, vec1) + the forward inputs

@@ -370,7 +370,7 @@ def _rows_of_ranges(ranges, n):
     return sel
 
 
-def msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=True, ranges=None, zero_unknown=True, out=None):
+def msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=True, ranges=None, zero_unknown=True, out=None, range_rows=0):
     """`ranges` [T,2]: like the kernel, only these target rows are written (the rest keeps what `out` holds: poison
     when this call allocates it)."""
     edge = edge[0] if edge.dim() == 3 else edge

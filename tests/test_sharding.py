@@ -255,6 +255,58 @@ def test_partition_slab_is_consistent_and_covers_the_global_graph(case, world):
     assert seen == all_edges
 
 
+@pytest.mark.parametrize("case,grid", [("fcc6", (2, 2, 1)), ("fcc6", (1, 2, 3)), ("fcc6", (2, 2, 2)), ("slab864", (2, 1, 4)),
+                                       ("open", (2, 2, 1)), ("open", (1, 1, 5))])
+def test_partition_blocks_is_consistent_and_covers_the_global_graph(case, grid):
+    """`plan_blocks`: the slab planner in up to three dimensions ("slabs (or blocks)").  Hierarchical
+    equal-count cuts; a box's halo = everything within rc of it along every cut axis.  Every global cutoff edge lives on
+    exactly one rank (its target's), the exchange lists of any two ranks mirror each other (no negotiation), the owners
+    are balanced, and the atoms classified "interior" read no halo atom.  Includes boxes thinner than rc."""
+    from hermnet_amd import synth
+    from hermnet_amd.neighbor import neighbor_search
+    from hermnet_amd.sharding import block_grid, partition_blocks
+    import hermnet_amd as hn
+    world = grid[0] * grid[1] * grid[2]
+    if case == "fcc6":
+        d = synth.fcc_alloy(reps=(6, 6, 6))
+    elif case == "slab864":
+        d = synth.fcc_alloy(reps=(3, 3, 24))
+    else:
+        rs = np.random.RandomState(3)
+        pos = torch.from_numpy(rs.uniform(0, 1, size=(300, 3)) * np.array([19.0, 23.0, 40.0])).float()
+        d = hn.Data(pos=pos, atomic_number=torch.from_numpy(rs.choice([1, 6, 8], size=300)),
+                    edge_index=neighbor_search(pos, 5.0), batch=torch.zeros(300, dtype=torch.long))
+    cell = d.get("cell")
+    parts = [partition_blocks(d.pos, d.atomic_number, cell, 5.0, r, world, grid=grid) for r in range(world)]
+    glob = torch.cat([d.edge_index, d.edge_shift.long().T if cell is not None else torch.zeros(3, d.edge_index.size(1), dtype=torch.long)])
+    all_edges = set(map(tuple, glob.T.tolist()))
+    seen = set()
+    owned_all = torch.cat([p_[1].owned_global for p_ in parts])
+    assert torch.equal(torch.sort(owned_all).values, torch.arange(d.pos.size(0)))          # every atom owned once
+    sizes = [p_[1].n_owned for p_ in parts]
+    assert max(sizes) - min(sizes) <= 3                                                      # equal-count cuts
+    for r, (loc, plan) in enumerate(parts):
+        keys = _edge_keys(plan, loc)
+        assert len(keys) == loc.edge_index.size(1) and not (keys & seen)
+        seen |= keys
+        assert bool(plan.owned_mask[loc.edge_index[1]].all())
+        assert torch.equal(loc.pos, d.pos[plan.local_global])
+        late = plan.late_local
+        n_int = int((~late).sum())
+        assert not bool(late[:n_int].any()) and bool(late[n_int:].all()) and n_int <= plan.n_owned
+        assert bool(late[loc.edge_index[1][~plan.owned_mask[loc.edge_index[0]]]].all())
+        for p in range(world):
+            ap, q = plan.atom_plan, parts[p][1].atom_plan
+            send_idx = ap.send_idx[sum(ap.send_counts[:p]):sum(ap.send_counts[:p + 1])]
+            assert bool(plan.owned_mask[send_idx].all())
+            off = sum(q.recv_counts[:r])
+            recv_idx = q.recv_idx[off:off + q.recv_counts[r]]
+            assert torch.equal(plan.local_global[send_idx], parts[p][1].local_global[recv_idx])
+    assert seen == all_edges
+    assert block_grid(8, torch.eye(3) * 100.0) == (2, 2, 2) and block_grid(8, torch.diag(torch.tensor([36.0, 36.0, 900.0]))) == (1, 1, 8)
+    assert block_grid(6, torch.diag(torch.tensor([50.0, 100.0, 20.0])))[1] >= 2
+
+
 def test_neighbor_search_target_mask_is_the_filtered_list():
     """`target_mask` keeps exactly the edges whose target is flagged, in the same order (host path; the device path is
     checked against it in tests/test_gpu_parity.py)."""

@@ -59,7 +59,7 @@ def main():
 
     def fwd(v):
         return lib.hermnet_message_scatter_fwd(ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(xb), P(v), P(x), P(wt), P(brbf),
-                                               P(edge), P(x1), P(vec1), None, 1, _stream())
+                                               P(edge), P(x1), P(vec1), None, 1, 0, _stream())
 
     # KBENCH_TABLE=0: without the per-edge radial table the backward takes its 16-lanes-per-edge (VW) form
     from hermnet_amd.ops import edge_radial_table
