@@ -350,7 +350,7 @@ def gemm_flops_per_step(N, nk, H, T, layers):
     return 2 * layers * (pre + upd)
 
 
-def chain_kernel_bounds(gsum, N, nk, H, T):
+def chain_kernel_bounds(gsum, N, nk, H, T, graph=None):
     """The node chain kernels against their OWN bound (csrc/node_chain.hip): a launch is a few hundred workgroups,
     each a fixed number of v_mfma_f32_32x32x2_f32 on the four SIMDs of one CU, so the time cannot go below
     (most workgroups any CU gets) x (a workgroup's FLOPs) / (256 FLOP/clk per CU): the quantised form of the 155 TF
@@ -359,6 +359,8 @@ def chain_kernel_bounds(gsum, N, nk, H, T):
     cus, flop_per_clk_cu = 256, 256.0
     from hermnet_amd import nodeops
     tr_pre, tr_upd = nodeops.chain_tile_rows(H), nodeops.chain_tile_rows(H, update=True)
+    if graph is not None:          # the update kernels' tile height is picked per row layout (16-row form on small grids)
+        tr_upd = nodeops.update_tile_rows(graph, H) or tr_upd
     grids = {"node_pre_fwd": ((N + tr_pre - 1) // tr_pre * T, 8.0 * tr_pre * H * H),
              "node_pre_bwd": ((N + tr_pre - 1) // tr_pre * T, 8.0 * tr_pre * H * H),
              "node_update_fwd": ((nk + tr_upd - 1) // tr_upd, 22.0 * tr_upd * H * H),
@@ -370,7 +372,8 @@ def chain_kernel_bounds(gsum, N, nk, H, T):
         ms = gsum[name][1]
         per_cu = (grid + cus - 1) // cus
         bound_us = per_cu * flops_wg / flop_per_clk_cu / 2.4e9 * 1e6
-        out[name] = {"workgroups": grid, "most_per_cu": per_cu, "gflop_per_launch": grid * flops_wg / 1e9,
+        out[name] = {"workgroups": grid, "tile_rows": tr_upd if "update" in name else tr_pre, "most_per_cu": per_cu,
+                     "gflop_per_launch": grid * flops_wg / 1e9,
                      "bound_us": bound_us, "measured_us": ms * 1e3, "frac": bound_us / (ms * 1e3),
                      "frac_at_2GHz": bound_us * 1.2 / (ms * 1e3)}
     return out
@@ -714,7 +717,7 @@ def main():
                 "gflop_per_step": gflop, "ms_per_step": gemm_ms, "launches_per_step": sum(c for c, _ in gsum.values()) / 3.0,
                 "achieved_TFLOPs": (gflop / gemm_ms) if gemm_ms > 0 else None, "peak_TFLOPs_fp32_mfma": FP32_MFMA_PEAK_TF,
                 "mfma_util": (gflop / gemm_ms / FP32_MFMA_PEAK_TF) if gemm_ms > 0 else None,
-                "own_roofline": chain_kernel_bounds(gsum, N, nk, H, T),
+                "own_roofline": chain_kernel_bounds(gsum, N, nk, H, T, data.get("_hn_graph")),
                 "own_roofline_note": "per chain kernel: (most workgroups on one CU) x (FLOPs of a workgroup) / 256 FLOP/clk "
                                      "at 2.4 GHz = what the fp32 matrix pipe allows THIS grid; frac = bound / measured"}
         names = {"c2": "configs[1]: %d-atom 3-element fcc alloy (Al/Ni/Cu)",

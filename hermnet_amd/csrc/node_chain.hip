@@ -750,6 +750,11 @@ int hn_wide_pre_bwd(int hidden, const PreBwdArgs& a, void* stream);
 int hn_wide_update_fwd(int hidden, const UpdFwdArgs& a, int tiles, void* stream);
 int hn_wide_update_bwd(int hidden, const UpdBwdArgs& a, int tiles, void* stream);
 
+// node_chain16.hip: the update chain on 16-row tiles (v_mfma_f32_16x16x4_f32, frag16 weight copies)
+int hn_update16_supported(int hidden);
+int hn_update16_fwd(int hidden, const UpdFwdArgs& a, int tiles, void* stream);
+int hn_update16_bwd(int hidden, const UpdBwdArgs& a, int tiles, void* stream);
+
 // Widths 64 / 128 / 256 have tuned instances in this file; every other multiple of 64 up to 512 -- the reference's default
 // hidden_channels = 512 among them (hermnet.py:86) -- takes the panelled kernels.  HERMNET_NODE_CHAIN_WIDE=1 sends 128 and
 // 256 there too (tests, comparisons).
@@ -761,6 +766,22 @@ static bool use_wide(int hidden) {
 }
 // rows per tile of the pre kernels (the row windows of the halo overlap are cut at these boundaries)
 static int pre_tile_rows(int hidden) { return use_wide(hidden) ? 32 : (hidden == 256 ? 32 : 64); }
+
+// 16 or 32: the tile height the update kernels should run this grid at.  16-row tiles cost twice the weight bytes from L2,
+// so they are chosen only where they shorten the launch: the busiest CU's share (whole tiles) is at least ~15 % smaller.
+extern "C" int hermnet_node_update_tile_rows(const int* type_rowptr_host, int num_nodes, int num_rel, int hidden) {
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("HERMNET_UPDATE_TILE16"); force = e ? atoi(e) : 2; }   // 0 never, 1 always, 2 auto
+  if (!type_rowptr_host || !hermnet_node_chain_supported(hidden)) return 0;
+  const int base = use_wide(hidden) ? 32 : (hidden == 64 ? 64 : 32);
+  if (!hn_update16_supported(hidden) || use_wide(hidden) || force == 0) return base;
+  if (force == 1) return 16;
+  int cus = 256, dev = 0, v = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  const long t32 = tiles_of(type_rowptr_host, num_rel, num_nodes, 32), t16 = tiles_of(type_rowptr_host, num_rel, num_nodes, 16);
+  const long m32 = 2 * ((t32 + cus - 1) / cus), m16 = (t16 + cus - 1) / cus;      // busiest CU, in 16-row units
+  return (m16 * 100 <= m32 * 85) ? 16 : base;
+}
 
 extern "C" int hermnet_node_chain_supported(int hidden) { return hidden >= 64 && hidden <= 512 && hidden % 64 == 0; }
 extern "C" int hermnet_node_chain_tile_rows(int hidden, int update) {
@@ -816,7 +837,7 @@ extern "C" int hermnet_node_update_fwd(const float* x1, const float* vec1, const
                                        const float* bx0, const float* wx2_frag, const float* bx2,
                                        const float* row_active, const int* type_rowptr, const int* type_rowptr_host,
                                        float* vp, float* h2b, float* q23, float* nrm, float* x_out, float* vec_out,
-                                       int num_nodes, int num_rel, int hidden, void* stream) {
+                                       int num_nodes, int num_rel, int hidden, int tile_rows, void* stream) {
   if (num_nodes < 0 || num_rel <= 0 || !type_rowptr_host) return HN_ERR_BAD_ARG;
   if (!hermnet_node_chain_supported(hidden)) return HN_ERR_BAD_ARG;
   if (num_nodes == 0) return HN_OK;
@@ -825,6 +846,7 @@ extern "C" int hermnet_node_update_fwd(const float* x1, const float* vec1, const
     return HN_ERR_BAD_ARG;
   UpdFwdArgs a = {x1, vec1, wv_frag, wx0_frag, bx0, wx2_frag, bx2, row_active, type_rowptr, vp, h2b, q23, nrm, x_out,
                   vec_out, num_nodes, num_rel};
+  if (tile_rows == 16) return hn_update16_supported(hidden) ? hn_update16_fwd(hidden, a, HN_TILES(16), stream) : HN_ERR_BAD_ARG;
   if (use_wide(hidden)) return hn_wide_update_fwd(hidden, a, HN_TILES(32), stream);
   HN_UPDATE_DISPATCH(node_update_fwd_kernel, a);
 }
@@ -833,7 +855,7 @@ extern "C" int hermnet_node_update_bwd(const float* gx_out, const float* gvec_ou
                                        const float* q23, const float* nrm, const float* wx2t_frag, const float* wx0t_frag,
                                        const float* wvt_frag, const float* row_active, const int* type_rowptr,
                                        const int* type_rowptr_host, float* gx1, float* gvec1, int num_nodes, int num_rel,
-                                       int hidden, void* stream) {
+                                       int hidden, int tile_rows, void* stream) {
   if (num_nodes < 0 || num_rel <= 0 || !type_rowptr_host) return HN_ERR_BAD_ARG;
   if (!hermnet_node_chain_supported(hidden)) return HN_ERR_BAD_ARG;
   if (num_nodes == 0) return HN_OK;
@@ -842,6 +864,7 @@ extern "C" int hermnet_node_update_bwd(const float* gx_out, const float* gvec_ou
     return HN_ERR_BAD_ARG;
   UpdBwdArgs a = {gx_out, gvec_out, vp, h2b, q23, nrm, wx2t_frag, wx0t_frag, wvt_frag, row_active, type_rowptr, gx1, gvec1,
                   num_nodes, num_rel};
+  if (tile_rows == 16) return hn_update16_supported(hidden) ? hn_update16_bwd(hidden, a, HN_TILES(16), stream) : HN_ERR_BAD_ARG;
   if (use_wide(hidden)) return hn_wide_update_bwd(hidden, a, HN_TILES(32), stream);
   HN_UPDATE_DISPATCH(node_update_bwd_kernel, a);
 }

@@ -1,0 +1,470 @@
+// gfx950: the PaiNNUpdate chain (node_update_fwd / node_update_bwd of node_chain.hip; rmnet.py:94-107, 29-31) on 16-ROW
+// tiles with v_mfma_f32_16x16x4_f32 -- for grids that 32-row tiles quantise badly.
+//
+// Why: BASELINE configs[1] has 10,041 target rows = 314 tiles of 32 rows on 256 CUs: 58 CUs get two workgroups, 198 get
+// one, the launch lasts as long as the CUs with two (a makespan of 64 rows against 39 rows per CU on average: 0.61).  In
+// 16-row tiles the same rows are 628 workgroups, three or two per CU: 48 rows against 39 (0.82), and a CU's two or three
+// co-resident workgroups fill each other's epilogue phases.  The 16 x 16 x 4 form has the same FLOP rate as 32 x 32 x 2
+// (64 FLOP/clk/SIMD); what it costs is weight traffic (every fragment serves 16 rows instead of 32: twice the bytes
+// from L2), which is why the 32-row kernels stay in charge of large grids (node_chain.hip picks per launch).
+//
+// Data flow as in node_chain.hip: weights streamed from L2 in MFMA operand order -- here frag16(W)[(b * K/16 + Q) * 64 + l]
+// = float4 W[16 b + (l & 15)][16 Q + 4 (l >> 4) .. +3], one coalesced 1 KiB load per 16-channel block and 16-deep k-group --,
+// activations in [16][H + 8] LDS tiles (ds_read_b128 at row l & 15, k = 16 Q + 4 (l >> 4): conflict-free with the +8 pad),
+// accumulators transposed: lane l holds tile row l & 15 and the channels 16 b + 4 (l >> 4) .. +3 of block b as ONE float4.
+// A wave owns 32 channels (two blocks) of every output part, so vec_dot, q * vdot and r * v1 stay lane-local.
+#include "node_chain_common.h"
+
+#ifndef HN_U16_MINW
+#define HN_U16_MINW 3      // workgroups per CU the register budget allows (3: <= 168 registers)
+#endif
+
+namespace {
+
+constexpr int kTR16 = 16;
+constexpr int kScr16Ld = 36, kScr16Floats = 16 * kScr16Ld;     // per-wave transpose scratch [16][36]
+
+// k-groups of weight fragments in flight per block: a group is 4 NB MFMAs of 32 cycles, an L2 hit 500-800 cycles
+constexpr int ring16(int nb) { return nb >= 6 ? 2 : 4; }
+
+template <int NB>
+struct Ring16 { f32x4 v[ring16(NB)][NB]; };
+
+template <int NB>
+__device__ __forceinline__ void b16_preload(Ring16<NB>& r, const f32x4* const (&bp)[NB]) {
+#pragma unroll
+  for (int g = 0; g < ring16(NB) - 1; ++g)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) r.v[g][j] = bp[j][g * 64];
+}
+
+// acc[j] += W_j[k-groups 0 .. KP/16) . A^T; `As`: this lane's LDS read pointer &tile[(l & 15) * LD + 4 (l >> 4)].
+// The ring holds groups 0 .. RS-2 on entry; MORE: the stream continues behind the panel (its first RS-1 groups are
+// requested and sit in slots 0 .. RS-2 on exit).
+template <int KP, int NB, bool MORE>
+__device__ __forceinline__ void mma16_panel(f32x4 (&acc)[NB], const float* As, const f32x4* const (&bp)[NB], Ring16<NB>& ring) {
+  constexpr int NQ = KP / 16, RS = ring16(NB), PF = RS - 1;
+  static_assert(NQ % RS == 0, "panel / ring mismatch");
+  f32x4 a[2];
+  a[0] = *reinterpret_cast<const f32x4*>(As);
+  auto group = [&](int q0, int qq, bool load_b, bool load_a) {
+    const int q = q0 + qq;
+    if (load_b) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) ring.v[(qq + PF) % RS][j] = bp[j][(q + PF) * 64];
+    }
+    if (load_a) a[(qq + 1) & 1] = *reinterpret_cast<const f32x4*>(As + 16 * (q + 1));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring.v[qq % RS][j][i], a[qq & 1][i], acc[j], 0, 0, 0);
+  };
+#pragma unroll 1
+  for (int q0 = 0; q0 < NQ - RS; q0 += RS) {
+#pragma unroll
+    for (int qq = 0; qq < RS; ++qq) group(q0, qq, true, true);
+  }
+#pragma unroll
+  for (int qq = 0; qq < RS; ++qq) group(NQ - RS, qq, MORE || qq + PF < RS, qq + 1 < RS);
+}
+
+// Coalesced store / load of this wave's [16 rows][32 channels] block pair through the wave-private scratch: lane l owns
+// row l & 15 and the channels 16 s + 4 (l >> 4) .. +3 of sub-block s (v[s]); memory sees 2 x (8 rows x 128 bytes).
+template <int LDG>
+__device__ __forceinline__ void store16(float* scr, int lane, const f32x4 (&v)[2], rsrc_t r, int off) {
+  const int m = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(scr + m * kScr16Ld + 16 * s + 4 * g) = v[s];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int rr = it * 8 + (lane >> 3), c = (lane & 7) * 4;
+    bst4(r, off + rr * LDG + c, *reinterpret_cast<const f32x4*>(scr + rr * kScr16Ld + c));
+  }
+}
+struct Load16 { f32x4 v[2]; };
+template <int LDG>
+__device__ __forceinline__ void issue16(Load16& b, int lane, rsrc_t r, int off) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) b.v[it] = bld4(r, off + (it * 8 + (lane >> 3)) * LDG + (lane & 7) * 4);
+}
+__device__ __forceinline__ void finish16(float* scr, int lane, const Load16& b, f32x4 (&out)[2]) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+    *reinterpret_cast<f32x4*>(scr + (it * 8 + (lane >> 3)) * kScr16Ld + (lane & 7) * 4) = b.v[it];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    out[s] = *reinterpret_cast<const f32x4*>(scr + (lane & 15) * kScr16Ld + 16 * s + 4 * (lane >> 4));
+}
+
+__device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ f32x4 sqrt4(f32x4 v) { return (f32x4){sqrtf(v[0]), sqrtf(v[1]), sqrtf(v[2]), sqrtf(v[3])}; }
+__device__ __forceinline__ f32x4 rcp_clamped4(f32x4 n) {
+  return (f32x4){__builtin_amdgcn_rcpf(fmaxf(n[0], 1e-4f)), __builtin_amdgcn_rcpf(fmaxf(n[1], 1e-4f)),
+                 __builtin_amdgcn_rcpf(fmaxf(n[2], 1e-4f)), __builtin_amdgcn_rcpf(fmaxf(n[3], 1e-4f))};
+}
+
+// cooperative [16][H] tile copy through registers (H / 64 float4 per thread)
+template <int H>
+struct Tile16Regs { f32x4 v[kTR16 * H / 4 / 256]; };
+template <int H>
+__device__ __forceinline__ void tile16_load(Tile16Regs<H>& r, rsrc_t src, int ld_src, int off0, int tid) {
+  constexpr int V = H / 4, F4 = kTR16 * H / 4 / 256;
+#pragma unroll
+  for (int it = 0; it < F4; ++it) {
+    const int idx = tid + it * 256, row = idx / V, c4 = idx % V;
+    r.v[it] = bld4(src, row * ld_src + off0 + c4 * 4);
+  }
+}
+template <int H, int LD>
+__device__ __forceinline__ void tile16_store(float* tile, const Tile16Regs<H>& r, int tid) {
+  constexpr int V = H / 4, F4 = kTR16 * H / 4 / 256;
+#pragma unroll
+  for (int it = 0; it < F4; ++it) {
+    const int idx = tid + it * 256, row = idx / V, c4 = idx % V;
+    *reinterpret_cast<f32x4*>(tile + row * LD + c4 * 4) = r.v[it];
+  }
+}
+
+// =====================================================================================================================
+// node_update_fwd on 16-row tiles (H = 128: four waves x 32 channels)
+// =====================================================================================================================
+template <int H>
+__global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(UpdFwdArgs a) {
+  static_assert(H == 128, "four waves x 32 channels");
+  constexpr int TR = kTR16, LD = H + 8, NB16 = H / 16;       // NB16: 16-channel blocks per part
+  extern __shared__ __align__(16) float lds[];               // 2 x [TR][LD], then 4 x [16][36] scratch
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* scr = lds + 2 * TR * LD + wave * kScr16Floats;
+  const TileInfo ti = find_tile(a.type_rowptr, a.T, a.N, TR, blockIdx.x);
+  const int row0 = ti.row0, nrows = ti.nrows, t = ti.t;
+  if (t >= a.T) {                                 // rows of unknown elements: zero
+    constexpr int V = H / 4;
+    for (int idx = tid; idx < nrows * V; idx += 256) {
+      const int r = row0 + idx / V, c = (idx % V) * 4;
+      *reinterpret_cast<f32x4*>(a.x_out + (size_t)r * H + c) = zero4();
+#pragma unroll
+      for (int d = 0; d < 3; ++d) *reinterpret_cast<f32x4*>(a.vec_out + ((size_t)r * 3 + d) * H + c) = zero4();
+    }
+    return;
+  }
+  const f32x4* wv = reinterpret_cast<const f32x4*>(a.wvf + (size_t)t * 2 * H * H) + lane;
+  const f32x4* wx0 = reinterpret_cast<const f32x4*>(a.wx0f + (size_t)t * 2 * H * H) + lane;
+  const f32x4* wx2 = reinterpret_cast<const f32x4*>(a.wx2f + (size_t)t * 3 * H * H) + lane;
+  // this wave's blocks of part p: b = p * NB16 + 2 wave + s
+  const f32x4* bpv[4];
+  const f32x4* bpx[2];
+  const f32x4* bpq[6];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) bpv[2 * p + s] = wv + (size_t)(p * NB16 + 2 * wave + s) * (H / 16) * 64;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) bpx[s] = wx0 + (size_t)(2 * wave + s) * (2 * H / 16) * 64;
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) bpq[2 * p + s] = wx2 + (size_t)(p * NB16 + 2 * wave + s) * (H / 16) * 64;
+
+  const int mrow = lane & 15, ch = 4 * (lane >> 4), cw = 32 * wave;
+  const rsrc_t x1_r = tile_rsrc(a.x1 + (size_t)row0 * H, nrows * H);
+  const rsrc_t vec1_r = tile_rsrc(a.vec1 + (size_t)row0 * 3 * H, nrows * 3 * H);
+  const rsrc_t act_r = tile_rsrc(a.row_active ? a.row_active + row0 : a.x1, a.row_active ? nrows : 0);
+  const bool all_on = a.row_active == nullptr;
+  const rsrc_t vp_r = tile_rsrc(a.vp + (size_t)row0 * 6 * H, nrows * 6 * H);
+  const rsrc_t h2b_r = tile_rsrc(a.h2b + (size_t)row0 * H, nrows * H);
+  const rsrc_t q23_r = tile_rsrc(a.q23 + (size_t)row0 * 2 * H, nrows * 2 * H);
+  const rsrc_t xo_r = tile_rsrc(a.x_out + (size_t)row0 * H, nrows * H);
+  const rsrc_t vo_r = tile_rsrc(a.vec_out + (size_t)row0 * 3 * H, nrows * 3 * H);
+  const rsrc_t nrm_r = tile_rsrc(a.nrm + (size_t)row0 * H, nrows * H);
+  f32x4 dot[2] = {zero4(), zero4()}, sq[2] = {zero4(), zero4()}, kv1[3][2];
+
+  // ---- vp[d] = vec1[d] Wv^T; vec_dot and |v2|^2 accumulate in registers, v1 stays for dvec = r v1
+  Tile16Regs<H> regs;
+  tile16_load<H>(regs, vec1_r, 3 * H, 0, tid);
+  Ring16<4> rv;
+  b16_preload(rv, bpv);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float* buf = lds + (d & 1) * TR * LD;
+    tile16_store<H, LD>(buf, regs, tid);
+    __syncthreads();
+    if (d < 2) tile16_load<H>(regs, vec1_r, 3 * H, (d + 1) * H, tid);
+    else tile16_load<H>(regs, x1_r, H, 0, tid);
+    f32x4 accv[4] = {zero4(), zero4(), zero4(), zero4()};
+    mma16_panel<H, 4, false>(accv, buf + mrow * LD + ch, bpv, rv);
+    if (d < 2) b16_preload(rv, bpv);
+    fence_sched();
+    f32x4 v1[2] = {accv[0], accv[1]}, v2[2] = {accv[2], accv[3]};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      kv1[d][s] = v1[s];
+      dot[s] += v1[s] * v2[s];
+      sq[s] += v2[s] * v2[s];
+    }
+    store16<6 * H>(scr, lane, v1, vp_r, d * 2 * H + cw);
+    store16<6 * H>(scr, lane, v2, vp_r, d * 2 * H + H + cw);
+  }
+  // ---- xin = [x1 | sqrt(|v2|^2 + 1e-8)]: x1 -> buffer 1 (free since the product of d = 1), the norm -> buffer 0
+  float* bufx = lds + TR * LD;
+  float* bufn = lds;
+  tile16_store<H, LD>(bufx, regs, tid);
+  Ring16<2> rx;
+  b16_preload(rx, bpx);
+  __syncthreads();                                   // every wave has finished the product of d = 2 (buffer 0)
+  {
+    f32x4 nv[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      nv[s] = sqrt4(sq[s] + 1e-8f);
+      *reinterpret_cast<f32x4*>(bufn + mrow * LD + cw + 16 * s + ch) = nv[s];
+    }
+    store16<H>(scr, lane, nv, nrm_r, cw);
+  }
+  __syncthreads();
+  // ---- h2 = xin Wx0^T + bx0 (K = 2H: two panels)
+  f32x4 acch[2] = {zero4(), zero4()};
+  {
+    const f32x4* bpx1[2] = {bpx[0] + (size_t)(H / 16) * 64, bpx[1] + (size_t)(H / 16) * 64};
+    mma16_panel<H, 2, true>(acch, bufx + mrow * LD + ch, bpx, rx);
+    mma16_panel<H, 2, false>(acch, bufn + mrow * LD + ch, bpx1, rx);
+  }
+  Ring16<6> rq;
+  b16_preload(rq, bpq);
+  __syncthreads();                                   // buffer 0 is free (x1 stays in buffer 1)
+  {
+    f32x4 hv[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int c0 = cw + 16 * s + ch;
+      hv[s] = acch[s] + ld4g(a.bx0 + (size_t)t * H + c0);
+      *reinterpret_cast<f32x4*>(lds + mrow * LD + c0) = ssilu4(hv[s]);
+    }
+    store16<H>(scr, lane, hv, h2b_r, cw);
+  }
+  __syncthreads();
+  // ---- (p | q | r) = a2 Wx2^T + bx2, then the update and the residual; vec1 is requested before the product
+  Load16 lvv[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) issue16<3 * H>(lvv[d], lane, vec1_r, d * H + cw);
+  const float on = (all_on | (bld(act_r, mrow) != 0.f)) ? 1.f : 0.f;
+  fence_sched();
+  f32x4 accq[6] = {zero4(), zero4(), zero4(), zero4(), zero4(), zero4()};
+  mma16_panel<H, 6, false>(accq, lds + mrow * LD + ch, bpq, rq);
+  fence_sched();
+  const float inv_sqrt_h = rsqrtf((float)H);
+  f32x4 q[2], r[2], xo[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int c0 = cw + 16 * s + ch;
+    const float* bb = a.bx2 + (size_t)t * 3 * H + c0;
+    const f32x4 p = accq[s] + ld4g(bb);
+    q[s] = accq[2 + s] + ld4g(bb + H);
+    r[s] = accq[4 + s] + ld4g(bb + 2 * H);
+    const f32x4 x1v = *reinterpret_cast<const f32x4*>(bufx + mrow * LD + c0);
+    xo[s] = (x1v + (p + q[s] * dot[s] * inv_sqrt_h) * kInvSqrt2) * on;
+  }
+  store16<2 * H>(scr, lane, q, q23_r, cw);
+  store16<2 * H>(scr, lane, r, q23_r, H + cw);
+  store16<H>(scr, lane, xo, xo_r, cw);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    f32x4 vo[2];
+    finish16(scr, lane, lvv[d], vo);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) vo[s] = (vo[s] + r[s] * kv1[d][s]) * on;
+    store16<3 * H>(scr, lane, vo, vo_r, d * H + cw);
+  }
+}
+
+// =====================================================================================================================
+// node_update_bwd on 16-row tiles
+// =====================================================================================================================
+template <int H>
+__global__ __launch_bounds__(256, HN_U16_MINW) void node_update_bwd16_kernel(UpdBwdArgs a) {
+  static_assert(H == 128, "four waves x 32 channels");
+  constexpr int TR = kTR16, LD = H + 8, NB16 = H / 16, V = H / 4, F4 = TR * H / 4 / 256;
+  extern __shared__ __align__(16) float lds[];               // 2 x [TR][LD], then 4 x [16][36] scratch
+  float* buf0 = lds;
+  float* buf1 = lds + TR * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* scr = lds + 2 * TR * LD + wave * kScr16Floats;
+  const TileInfo ti = find_tile(a.type_rowptr, a.T, a.N, TR, blockIdx.x);
+  const int row0 = ti.row0, nrows = ti.nrows, t = ti.t;
+  if (t >= a.T) {
+    for (int idx = tid; idx < nrows * V; idx += 256) {
+      const int r = row0 + idx / V, c = (idx % V) * 4;
+      *reinterpret_cast<f32x4*>(a.gx1 + (size_t)r * H + c) = zero4();
+#pragma unroll
+      for (int d = 0; d < 3; ++d) *reinterpret_cast<f32x4*>(a.gvec1 + ((size_t)r * 3 + d) * H + c) = zero4();
+    }
+    return;
+  }
+  const f32x4* wx2t = reinterpret_cast<const f32x4*>(a.wx2tf + (size_t)t * 3 * H * H) + lane;   // [H, 3H]
+  const f32x4* wx0t = reinterpret_cast<const f32x4*>(a.wx0tf + (size_t)t * 2 * H * H) + lane;   // [2H, H]
+  const f32x4* wvt = reinterpret_cast<const f32x4*>(a.wvtf + (size_t)t * 2 * H * H) + lane;     // [H, 2H]
+  const f32x4* bpa[2];
+  const f32x4* bpx[4];
+  const f32x4* bpg[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bpa[s] = wx2t + (size_t)(2 * wave + s) * (3 * H / 16) * 64;
+    bpg[s] = wvt + (size_t)(2 * wave + s) * (2 * H / 16) * 64;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) bpx[2 * p + s] = wx0t + (size_t)(p * NB16 + 2 * wave + s) * (H / 16) * 64;
+  Ring16<2> ra;
+  b16_preload(ra, bpa);
+  const int mrow = lane & 15, ch = 4 * (lane >> 4), cw = 32 * wave;
+  const float inv_sqrt_h = rsqrtf((float)H);
+  const rsrc_t gxo_r = tile_rsrc(a.gxo + (size_t)row0 * H, nrows * H);
+  const rsrc_t gvo_r = tile_rsrc(a.gvo + (size_t)row0 * 3 * H, nrows * 3 * H);
+  const rsrc_t vp_r = tile_rsrc(a.vp + (size_t)row0 * 6 * H, nrows * 6 * H);
+  const rsrc_t h2b_r = tile_rsrc(a.h2b + (size_t)row0 * H, nrows * H);
+  const rsrc_t q23_r = tile_rsrc(a.q23 + (size_t)row0 * 2 * H, nrows * 2 * H);
+  const rsrc_t nrm_r = tile_rsrc(a.nrm + (size_t)row0 * H, nrows * H);
+  const rsrc_t act_r = tile_rsrc(a.row_active ? a.row_active + row0 : a.gxo, a.row_active ? nrows : 0);
+  const bool all_on = a.row_active == nullptr;
+  const rsrc_t gx1_r = tile_rsrc(a.gx1 + (size_t)row0 * H, nrows * H);
+  const rsrc_t gvec1_r = tile_rsrc(a.gvec1 + (size_t)row0 * 3 * H, nrows * 3 * H);
+
+  // ---- gq = (gx/sqrt2 | gx vdot/sqrt2 | sum_d gv[d] v1[d]) elementwise, a float4 per thread and position
+  Tile16Regs<H> g3;
+#pragma unroll
+  for (int it = 0; it < F4; ++it) {
+    const int idx = tid + it * 256, lr = idx / V, c = (idx % V) * 4;
+    const float on = (all_on | (bld(act_r, lr) != 0.f)) ? 1.f : 0.f;
+    const f32x4 gx = bld4(gxo_r, lr * H + c) * on;
+    f32x4 vd = zero4(), gq3 = zero4();
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const f32x4 v1 = bld4(vp_r, (lr * 3 + d) * 2 * H + c);
+      const f32x4 v2 = bld4(vp_r, (lr * 3 + d) * 2 * H + H + c);
+      const f32x4 gv = bld4(gvo_r, (lr * 3 + d) * H + c) * on;
+      vd += v1 * v2;
+      gq3 += gv * v1;
+    }
+    *reinterpret_cast<f32x4*>(buf0 + lr * LD + c) = gx * kInvSqrt2;
+    *reinterpret_cast<f32x4*>(buf1 + lr * LD + c) = gx * vd * (inv_sqrt_h * kInvSqrt2);
+    g3.v[it] = gq3;
+  }
+  // h2b, gx and q of this wave's accumulator positions: requested now, transposed behind the first product
+  Load16 lh2, lgx, lq2;
+  issue16<H>(lh2, lane, h2b_r, cw);
+  issue16<H>(lgx, lane, gxo_r, cw);
+  issue16<2 * H>(lq2, lane, q23_r, cw);
+  __syncthreads();
+  // ---- ga2 = gq Wx2  (K = 3H: three panels)
+  f32x4 acc[2] = {zero4(), zero4()};
+  {
+    const f32x4* bp1[2] = {bpa[0] + (size_t)(H / 16) * 64, bpa[1] + (size_t)(H / 16) * 64};
+    const f32x4* bp2[2] = {bpa[0] + (size_t)(2 * H / 16) * 64, bpa[1] + (size_t)(2 * H / 16) * 64};
+    mma16_panel<H, 2, true>(acc, buf0 + mrow * LD + ch, bpa, ra);
+    __syncthreads();                                 // buffer 0 is free
+    tile16_store<H, LD>(buf0, g3, tid);
+    mma16_panel<H, 2, true>(acc, buf1 + mrow * LD + ch, bp1, ra);
+    __syncthreads();                                 // third part in place, buffer 1 free
+    mma16_panel<H, 2, false>(acc, buf0 + mrow * LD + ch, bp2, ra);
+  }
+  Ring16<4> rx;
+  b16_preload(rx, bpx);
+  fence_sched();
+  // ---- gh2 = ga2 * ScaledSiLU'(h2b) -> buffer 1;  s = gvdot / sqrt(H) = gx q / sqrt(2H) per accumulator position
+  const float onr = (all_on | (bld(act_r, mrow) != 0.f)) ? 1.f : 0.f;
+  f32x4 s_[2], accx[4];
+  {
+    f32x4 ph2[2], gxv[2], q2[2];
+    finish16(scr, lane, lh2, ph2);
+    finish16(scr, lane, lgx, gxv);
+    finish16(scr, lane, lq2, q2);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      *reinterpret_cast<f32x4*>(buf1 + mrow * LD + cw + 16 * s + ch) = acc[s] * dssilu4(ph2[s]);
+      gxv[s] *= onr;
+      s_[s] = gxv[s] * q2[s] * (kInvSqrt2 * inv_sqrt_h);
+      accx[s] = gxv[s];                  // gxin's gx1 part accumulates onto the identity term gx
+      accx[2 + s] = zero4();
+    }
+  }
+  // inputs of the later epilogues, requested one product ahead
+  Load16 lnr, lgv, lq3, lw1, lw2;
+  issue16<H>(lnr, lane, nrm_r, cw);
+  issue16<3 * H>(lgv, lane, gvo_r, cw);
+  issue16<2 * H>(lq3, lane, q23_r, H + cw);
+  issue16<6 * H>(lw1, lane, vp_r, cw);
+  issue16<6 * H>(lw2, lane, vp_r, H + cw);
+  fence_sched();
+  __syncthreads();
+  // ---- gxin = gh2 Wx0 (gx1 part | g|v2| part)
+  mma16_panel<H, 4, false>(accx, buf1 + mrow * LD + ch, bpx, rx);
+  Ring16<2> rg;
+  b16_preload(rg, bpg);
+  fence_sched();
+  f32x4 gnn[2], pgv[2], pq3[2], pw1[2], pw2[2];
+  {
+    f32x4 nv[2], gx1v[2];
+    finish16(scr, lane, lnr, nv);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      gnn[s] = accx[2 + s] * rcp_clamped4(nv[s]);     // (rows past the tile's end load 0: their products are zero anyway)
+      gx1v[s] = accx[s];
+    }
+    store16<H>(scr, lane, gx1v, gx1_r, cw);
+  }
+  finish16(scr, lane, lgv, pgv);
+  finish16(scr, lane, lq3, pq3);
+  finish16(scr, lane, lw1, pw1);
+  finish16(scr, lane, lw2, pw2);
+  // ---- gvec1[d] = gv[d] + (gv1[d] | gv2[d]) Wv,  gv1 = gv q3 + s v2,  gv2 = s v1 + gnn v2  (the accumulator starts at gv[d])
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    f32x4 accg[2];
+    __syncthreads();                                 // the previous product has read both buffers
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int c0 = cw + 16 * s + ch;
+      const f32x4 gv = pgv[s] * onr;
+      accg[s] = gv;
+      *reinterpret_cast<f32x4*>(buf0 + mrow * LD + c0) = gv * pq3[s] + s_[s] * pw2[s];
+      *reinterpret_cast<f32x4*>(buf1 + mrow * LD + c0) = s_[s] * pw1[s] + gnn[s] * pw2[s];
+    }
+    fence_sched();
+    Load16 ngv, nw1, nw2;
+    if (d < 2) {                                     // in flight during the product below
+      issue16<3 * H>(ngv, lane, gvo_r, (d + 1) * H + cw);
+      issue16<6 * H>(nw1, lane, vp_r, (d + 1) * 2 * H + cw);
+      issue16<6 * H>(nw2, lane, vp_r, (d + 1) * 2 * H + H + cw);
+    }
+    fence_sched();
+    __syncthreads();
+    const f32x4* bpg1[2] = {bpg[0] + (size_t)(H / 16) * 64, bpg[1] + (size_t)(H / 16) * 64};
+    mma16_panel<H, 2, true>(accg, buf0 + mrow * LD + ch, bpg, rg);
+    mma16_panel<H, 2, false>(accg, buf1 + mrow * LD + ch, bpg1, rg);
+    if (d < 2) b16_preload(rg, bpg);
+    fence_sched();
+    if (d < 2) {
+      finish16(scr, lane, ngv, pgv);
+      finish16(scr, lane, nw1, pw1);
+      finish16(scr, lane, nw2, pw2);
+    }
+    store16<3 * H>(scr, lane, accg, gvec1_r, d * H + cw);
+  }
+}
+
+}  // namespace
+
+// Entry points of this translation unit (called by node_chain.hip's dispatch).  The weight pointers of the argument blocks
+// must hold frag16 copies (include/hermnet_hip.h: hermnet_node_update_fwd, "16-row form").
+int hn_update16_supported(int hidden) { return hidden == 128; }
+
+int hn_update16_fwd(int hidden, const UpdFwdArgs& a, int tiles, void* stream) {
+  if (hidden != 128) return HN_ERR_BAD_ARG;
+  return launch_chain(node_update_fwd16_kernel<128>, dim3((unsigned)tiles), (size_t)(2 * 16 * 136 + 4 * kScr16Floats) * 4, stream, a);
+}
+
+int hn_update16_bwd(int hidden, const UpdBwdArgs& a, int tiles, void* stream) {
+  if (hidden != 128) return HN_ERR_BAD_ARG;
+  return launch_chain(node_update_bwd16_kernel<128>, dim3((unsigned)tiles), (size_t)(2 * 16 * 136 + 4 * kScr16Floats) * 4, stream, a);
+}

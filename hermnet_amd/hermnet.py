@@ -42,6 +42,9 @@ class HeteroVertexConv(nn.Module):
         # form needs the chain kernels, HVNet's single row space and the channel-per-lane backward, which takes row ranges)
         if halo is not None and not (w is not None and w.chain and _node_chain_enabled() and g.num_src == 0
                                      and halo.fwd_early is not None and g.N * 3 * data.x.size(1) * 4 < 2 ** 32
+                                     # (a rank that neither sends nor receives joins the collective in its plain form:
+                                     # nothing to hide, and the asynchronous form costs ~15 us of stream hand-offs)
+                                     and sum(halo.plan.recv_counts) + sum(halo.plan.send_counts) > 0
                                      and os.environ.get("HERMNET_BWD_CL", "1") != "0"
                                      and os.environ.get("HERMNET_BWD_SPLIT_T", "0") == "0"
                                      and os.environ.get("HERMNET_HALO_OVERLAP", "1") != "0"):

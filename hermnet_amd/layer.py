@@ -114,6 +114,12 @@ class LayerWeights(object):
             self.wvf, self.wvtf = fr(self.wv_s), fr(self.wvt_s)
             self.wx0f, self.wx0tf = fr(self.wx0_s), fr(self.wx0t_s)
             self.wx2f, self.wx2tf = fr(self.wx2_s), fr(self.wx2t_s)
+            self.wvf16 = None
+            if Hp == 128:        # the update chain's 16-row form (csrc/node_chain16.hip) reads frag16 copies
+                f16 = nodeops.weight_fragments16
+                self.wvf16, self.wvtf16 = f16(self.wv_s), f16(self.wvt_s)
+                self.wx0f16, self.wx0tf16 = f16(self.wx0_s), f16(self.wx0t_s)
+                self.wx2f16, self.wx2tf16 = f16(self.wx2_s), f16(self.wx2t_s)
         self.key = key
         return self
 

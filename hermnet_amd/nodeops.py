@@ -187,6 +187,29 @@ def weight_fragments(w):
     return f.permute(*range(n), n, n + 2, n + 3, n + 1, n + 4).contiguous().reshape(*lead, o * k)
 
 
+def weight_fragments16(w):
+    """The same for the 16-row kernels' v_mfma_f32_16x16x4_f32 operands (include/hermnet_hip.h: frag16(W)):
+    out % 16 == 0, in % 16 == 0."""
+    lead = w.shape[:-2]
+    o, k = w.shape[-2:]
+    f = w.reshape(*lead, o // 16, 16, k // 16, 4, 4)
+    n = len(lead)
+    return f.permute(*range(n), n, n + 2, n + 3, n + 1, n + 4).contiguous().reshape(*lead, o * k)
+
+
+def update_tile_rows(graph, H):
+    """16 or the default tile height: which form of the update kernels shortens the launch for this row layout
+    (cached on the graph: it depends on the row counts only)."""
+    tr = getattr(graph, "_upd_tile", None)
+    if tr is None or tr[0] != H:
+        tr = (H, int(_lib.load().hermnet_node_update_tile_rows(_rowptr_host(graph), graph.N, graph.T, H)))
+        try:
+            graph._upd_tile = tr
+        except AttributeError:
+            pass
+    return tr[1]
+
+
 def _rowptr_host(graph):
     import ctypes
     c = getattr(graph, "_rowptr_c", None)
@@ -243,6 +266,8 @@ def node_update_fwd(x1, vec1, w, graph):
     (rmnet.py:94-107, 29-31)."""
     N, H = x1.shape
     dev, dt = x1.device, x1.dtype
+    t16 = update_tile_rows(graph, H) == 16 and getattr(w, "wvf16", None) is not None
+    wvf, wx0f, wx2f = (w.wvf16, w.wx0f16, w.wx2f16) if t16 else (w.wvf, w.wx0f, w.wx2f)
     vp = torch.empty(N, 3, 2 * H, dtype=dt, device=dev)
     h2b = torch.empty(N, H, dtype=dt, device=dev)
     q23 = torch.empty(N, 2 * H, dtype=dt, device=dev)
@@ -250,17 +275,20 @@ def node_update_fwd(x1, vec1, w, graph):
     xo = torch.empty(N, H, dtype=dt, device=dev)
     vo = torch.empty(N, 3, H, dtype=dt, device=dev)
     _lib.check(_launch("node_update_fwd", lambda: _lib.load().hermnet_node_update_fwd(
-        P(x1), P(vec1), P(w.wvf), P(w.wx0f), P(w.bx0_s), P(w.wx2f), P(w.bx2_s), P(graph.row_active), P(graph.type_rowptr),
-        _rowptr_host(graph), P(vp), P(h2b), P(q23), P(nrm), P(xo), P(vo), N, graph.T, H, _stream())), "hermnet_node_update_fwd")
+        P(x1), P(vec1), P(wvf), P(wx0f), P(w.bx0_s), P(wx2f), P(w.bx2_s), P(graph.row_active), P(graph.type_rowptr),
+        _rowptr_host(graph), P(vp), P(h2b), P(q23), P(nrm), P(xo), P(vo), N, graph.T, H, 16 if t16 else 0, _stream())),
+        "hermnet_node_update_fwd")
     return xo, vo, vp, h2b, q23, nrm
 
 
 def node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph):
     """Gradient of node_update_fwd w.r.t. (x1, vec1)."""
     N, H = gxo.shape
+    t16 = update_tile_rows(graph, H) == 16 and getattr(w, "wvf16", None) is not None
+    wx2tf, wx0tf, wvtf = (w.wx2tf16, w.wx0tf16, w.wvtf16) if t16 else (w.wx2tf, w.wx0tf, w.wvtf)
     gx1 = torch.empty_like(gxo)
     gvec1 = torch.empty_like(gvo)
     _lib.check(_launch("node_update_bwd", lambda: _lib.load().hermnet_node_update_bwd(
-        P(gxo), P(gvo), P(vp), P(h2b), P(q23), P(nrm), P(w.wx2tf), P(w.wx0tf), P(w.wvtf), P(graph.row_active), P(graph.type_rowptr),
-        _rowptr_host(graph), P(gx1), P(gvec1), N, graph.T, H, _stream())), "hermnet_node_update_bwd")
+        P(gxo), P(gvo), P(vp), P(h2b), P(q23), P(nrm), P(wx2tf), P(wx0tf), P(wvtf), P(graph.row_active), P(graph.type_rowptr),
+        _rowptr_host(graph), P(gx1), P(gvec1), N, graph.T, H, 16 if t16 else 0, _stream())), "hermnet_node_update_bwd")
     return gx1, gvec1

@@ -49,12 +49,14 @@ class RelationalGraph(object):
                  "type_rowptr", "type_rowptr_host", "csr_rowptr", "csr_src", "csr_perm", "csc_rowptr", "csc_tgt",
                  "csc_pos", "out_rowptr", "out_edges", "src_id", "tgt_id", "shift", "row_active", "row_real",
                  "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device", "_cstruct", "_rel_bounds",
-                 "edge_table", "num_src", "res_row", "triadic_pairs", "src_real", "_rowptr_c", "src_ranges", "_row_keys")
+                 "edge_table", "num_src", "res_row", "triadic_pairs", "src_real", "_rowptr_c", "src_ranges", "_row_keys",
+                 "_upd_tile")
 
     def __init__(self):
         self._cstruct = None
         self._rel_bounds = None
         self._rowptr_c = None      # type_rowptr_host as a ctypes int array (nodeops._rowptr_host)
+        self._upd_tile = None      # (H, tile rows of the update kernels for this row layout) (nodeops.update_tile_rows)
         self._row_keys = None      # gather / segmented-sum keys of the differentiable path (trainops._row_keys)
         self.edge_table = None     # [E+1,32] per-edge radial records of the current step, CSC order (set by HVNet.forward)
         self.num_src = 0           # separate source-row space (HTNet): rows of xh / vec; 0 = same rows as the targets

@@ -367,17 +367,23 @@ int hermnet_node_pre_bwd(const float* gxh, const float* hb, const float* w2t_fra
  *     NULL: all active) and rows >= type_rowptr[T] are written as zero.
  * type_rowptr [T+1] on the device and the same values on the host (`type_rowptr_host`: the launch geometry).
  * hermnet_node_update_bwd: (gx_out, gvec_out) -> (gx1, gvec1), the gradients w.r.t. x1 / vec1 (parameters are
- *     constants); wx2t_frag = frag(Wx2^T [H,3H]), wx0t_frag = frag(Wx0^T [2H,H]), wvt_frag = frag(Wv^T [H,2H]). */
+ *     constants); wx2t_frag = frag(Wx2^T [H,3H]), wx0t_frag = frag(Wx0^T [2H,H]), wvt_frag = frag(Wv^T [H,2H]).
+ * tile_rows (ABI v7): 0 = the width's default row tile (32; 64 at hidden 64); 16 = the 16-row form (hidden 128 only:
+ *     v_mfma_f32_16x16x4_f32, csrc/node_chain16.hip) -- every *_frag argument must then be the frag16 copy of the weight,
+ *     frag16(W)[((b * K/16 + Q) * 64 + l) * 4 + e] = W[16 b + (l & 15)][16 Q + 4 (l >> 4) + e].
+ *     hermnet_node_update_tile_rows says which form shortens the launch for a row layout (small grids: 32-row tiles
+ *     leave most CUs with one workgroup while a few get two; 16-row tiles cost twice the weight bytes from L2). */
+int hermnet_node_update_tile_rows(const int* type_rowptr_host, int num_nodes, int num_rel, int hidden);
 int hermnet_node_update_fwd(const float* x1, const float* vec1, const float* wv_frag, const float* wx0_frag,
                             const float* bx0, const float* wx2_frag, const float* bx2, const float* row_active,
                             const int* type_rowptr, const int* type_rowptr_host, float* vp, float* h2b, float* q23,
                             float* nrm, float* x_out, float* vec_out, int num_nodes, int num_rel, int hidden,
-                            void* stream);
+                            int tile_rows, void* stream);
 int hermnet_node_update_bwd(const float* gx_out, const float* gvec_out, const float* vp, const float* h2b,
                             const float* q23, const float* nrm, const float* wx2t_frag, const float* wx0t_frag,
                             const float* wvt_frag,
                             const float* row_active, const int* type_rowptr, const int* type_rowptr_host, float* gx1,
-                            float* gvec1, int num_nodes, int num_rel, int hidden, void* stream);
+                            float* gvec1, int num_nodes, int num_rel, int hidden, int tile_rows, void* stream);
 
 /* HTNet (hermnet.py:155-157 is a stub; DESIGN.md "HTNet"): a centre atom's P pair relations are averaged.  Target rows
  * are [num_elem][pairs][block] blocks of `block` rows ("virtual" rows, one per atom and pair relation):

@@ -159,7 +159,7 @@ def test_message_kernels_over_complementary_row_ranges_are_bit_identical(name, h
     ge = torch.full((H // 64, graph.E, 4), float("nan"), device=dev)     # (edges into unknown-element rows stay unwritten)
     gxh, gvec, gx = L._msg_bwd(graph, rbf, H, xh, vec, W, edge, gx1, gv1, ge, xh_bias=False)
     same = lambda p_, q_: bool(((p_ == q_) | (torch.isnan(p_) & torch.isnan(q_))).all())
-    a, b, c_ = N // 5, N // 5 + 37, N - 3
+    a, b, c_ = N // 5, min(N // 5 + 37, N - 5), N - 3
     for first, rest in [([(a, b), (c_, N)], [(0, a), (b, c_)]), ([(0, N)], []), ([(0, 1)], [(1, N)])]:
         ge2 = nan(ge)
         dv = lambda r: torch.tensor(r, dtype=torch.int32, device=dev).reshape(-1, 2)
@@ -329,6 +329,27 @@ def test_node_kernels_match_pytorch_restatement():
                                                    (384, 3, (33, 64, 31), False, 0), (448, 2, (50, 41), None, 0),
                                                    (512, 3, (40, 33, 50), None, 0), (512, 1, (700,), None, 0)])
 def test_node_chain_kernels_match_restatement(H, T, counts, uniform, hr):
+    _node_chain_case(H, T, counts, uniform, hr)
+
+
+@pytest.mark.parametrize("H,T,counts,uniform", [(128, 3, (70, 91, 45), None), (128, 3, (130, 3, 61), False), (128, 1, (300,), None),
+                                                (128, 3, (3300, 3400, 3341), None)])
+def test_update_chain_on_16_row_tiles_matches_restatement(H, T, counts, uniform, monkeypatch):
+    """csrc/node_chain16.hip: the PaiNNUpdate chain and its backward on 16-row tiles (v_mfma_f32_16x16x4_f32, frag16
+    weight copies) -- the form the library picks for grids that 32-row tiles quantise badly (10,041 rows: 314 tiles on 256
+    CUs) -- forced here for every layout, vs the fp64 restatement; and the library's own choice for configs[1]'s row counts."""
+    from hermnet_amd import nodeops, _lib
+    monkeypatch.setattr(nodeops, "update_tile_rows", lambda graph, H_: 16)
+    _node_chain_case(H, T, counts, uniform, 0)
+    monkeypatch.undo()
+    import ctypes
+    rp = (ctypes.c_int * 4)(0, 3347, 6694, 10041)
+    assert _lib.load().hermnet_node_update_tile_rows(rp, 10041, 3, 128) == 16       # configs[1]
+    rp = (ctypes.c_int * 4)(0, 33800, 67600, 101397)
+    assert _lib.load().hermnet_node_update_tile_rows(rp, 101397, 3, 128) == 32      # configs[3]: weight traffic wins
+
+
+def _node_chain_case(H, T, counts, uniform, hr):
     """csrc/node_chain.hip (LayerNorm + x_proj chain, PaiNNUpdate chain and their backward kernels on the fp32 matrix
     pipe) vs the fp64 PyTorch restatement of tests/ref_ops.py: ragged relation blocks, an inactive relation, rows of
     unknown elements, zero-padded channels (hidden_real), both 64- and 32-row tile instances at H = 128."""
