@@ -259,6 +259,39 @@ def reference_default_width_secondary(hn, synth, dev, data, model_kw, steps=10):
             "energy": float(en.detach()[0])}
 
 
+def decomposition_secondary(synth, dev, rc, world=8, skin=1.0):
+    """What the planners give at `world` ranks for configs[3]'s cell and for SURVEY 8(d) C4's near-cubic stress variant
+    (~100k atoms, 104 A cube): owned atoms, halo atoms, the share of owned atoms whose messages run while the halo
+    exchange is in flight ("interior"), peers per rank -- slabs against boxes (`sharding.plan_blocks`).  Planning only
+    (no multi-GPU run): the figures the exchange volume and the hidden share follow from."""
+    import numpy as np
+    from hermnet_amd.sharding import block_grid, plan_blocks, plan_slab
+    out = {}
+    for name, reps in (("configs[3] cell 36x36x900 A (fcc 10x10x250)", (10, 10, 250)),
+                       ("near-cubic stress variant 104 A cube (fcc 29x29x29)", (29, 29, 29))):
+        pos_np, cell_np, z_np = synth.fcc_alloy_atoms(reps=reps, seed=0)
+        pos = torch.from_numpy(pos_np.astype(np.float32)).to(dev)
+        cell = torch.from_numpy(cell_np.astype(np.float32)).to(dev)
+        z = torch.from_numpy(z_np).to(dev)
+        res = {"atoms": int(pos.size(0))}
+        for kind, grid in (("slabs", None), ("boxes", block_grid(world, cell))):
+            owned, halo, interior, peers = [], [], [], []
+            for r in range(world):
+                pl = (plan_slab(pos, z, cell, rc, r, world, skin=skin) if grid is None
+                      else plan_blocks(pos, z, cell, rc, r, world, grid=grid, skin=skin))
+                owned.append(pl.n_owned)
+                halo.append(int(pl.halo_global.numel()))
+                interior.append(int((~pl.late_local).sum()))
+                peers.append(sum(1 for c in pl.atom_plan.recv_counts if c))
+            res[kind] = {"grid": list(grid) if grid else [1, 1, world], "owned_max": max(owned), "halo_max": max(halo),
+                         "halo_over_owned": max(halo) / max(max(owned), 1),
+                         "interior_share_min": min(i / max(o, 1) for i, o in zip(interior, owned)),
+                         "peers_max": max(peers), "local_rows_max": max(o + h for o, h in zip(owned, halo))}
+        out[name] = res
+    out["note"] = "rc %.1f A + skin %.1f A; halo = geometric reach along every cut axis; one rank's figures are the maxima" % (rc, skin)
+    return out
+
+
 def graph_replay_secondary(hn, synth, dev, model, data, model_kw, steps=20):
     """ms per step of whole-step hipGraph replay: the headline workload and the 1024-molecule batch (launch-bound
     when enqueued eagerly)."""
@@ -778,6 +811,10 @@ def main():
                 out["secondary"]["launches_per_step"], out["secondary"]["launches_per_step_own_kernels"] = count_launches(step)
             except Exception as ex:
                 out["secondary"]["launches_per_step"] = {"error": repr(ex)}
+            try:
+                out["secondary"]["decomposition_at_8_ranks"] = decomposition_secondary(synth, dev, model_kw["rc"])
+            except Exception as ex:
+                out["secondary"]["decomposition_at_8_ranks"] = {"error": repr(ex)}
             if cfg == "c2":
                 try:
                     out["secondary"]["reference_default_width_h512"] = reference_default_width_secondary(
