@@ -63,6 +63,12 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
     for (int j = 0; j < CPW; ++j) bp2[p * CPW + j] = w2 + (size_t)(p * CB + wc * CPW + j) * (H / 8) * 64;
   BRing<CPW, ring_size(RB * CPW, false)> r1;
   b_preload(r1, bp1);
+  const int ch = 4 * (lane >> 5);
+  f32x4 bias1[CPW][4];                                // b1 of this wave's channels: the first product starts from it
+#pragma unroll
+  for (int j = 0; j < CPW; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias1[j][g] = ld4g(a.b1 + (size_t)t * H + (wc * CPW + j) * 32 + 8 * g + ch);
   STAMP(0);
   STAMP_HWID();
 
@@ -107,14 +113,20 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
   STAMP(2);
 
   // ---- h = n W1^T
-  const int mrow = wr * RB * 32 + (lane & 31), ch = 4 * (lane >> 5);
+  const int mrow = wr * RB * 32 + (lane & 31);
   const float* As = tile + mrow * LD + ch;
   f32x16 acc1[RB][CPW];
-  zero_acc(acc1);
+  bias_acc(acc1, bias1);
   mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, false), false>(acc1, As, bp1, r1);
   STAMP(3);
   BRing<3 * CPW, ring_size(RB * 3 * CPW, false)> r2;
   b_preload(r2, bp2);
+  f32x4 bias2[3 * CPW][4];                           // b2, requested in front of the epilogue's stores
+#pragma unroll
+  for (int jj = 0; jj < 3 * CPW; ++jj)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      bias2[jj][g] = ld4g(a.b2 + (size_t)t * 3 * H + (jj / CPW) * H + (wc * CPW + jj % CPW) * 32 + 8 * g + ch);
   __syncthreads();                                   // every wave has read n
   STAMP(4);
   // ---- + b1, save, ScaledSiLU -> the tile becomes the A operand of the second product
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int lr = mrow + rb * 32, c0 = (wc * CPW + j) * 32 + 8 * g + ch;
-        hv[g] = run4(acc1[rb][j], g) + ld4g(a.b1 + (size_t)t * H + c0);
+        hv[g] = run4(acc1[rb][j], g);                 // (incl. b1)
         *reinterpret_cast<f32x4*>(tile + lr * LD + c0) = ssilu4(hv[g]);
       }
       store_block<H>(scr, lane, hv, hb_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
   STAMP(6);
   // ---- xh = a W2^T + b2
   f32x16 acc2[RB][3 * CPW];
-  zero_acc(acc2);
+  bias_acc(acc2, bias2);
   mma_panel<H, LD, RB, 3 * CPW, ring_size(RB * 3 * CPW, false), false>(acc2, As, bp2, r2);
   STAMP(7);
 #pragma unroll
@@ -146,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
       const int cblk = (jj / CPW) * H + (wc * CPW + jj % CPW) * 32;
       f32x4 v[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) v[g] = run4(acc2[rb][jj], g) + ld4g(a.b2 + (size_t)t * 3 * H + cblk + 8 * g + ch);
+      for (int g = 0; g < 4; ++g) v[g] = run4(acc2[rb][jj], g);            // (incl. b2)
       store_block<3 * H>(scr, lane, v, xh_r, (wr * RB + rb) * 32 * 3 * H + cblk);
     }
   STAMP(8);

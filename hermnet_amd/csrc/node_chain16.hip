@@ -16,7 +16,7 @@
 #include "node_chain_common.h"
 
 #ifndef HN_U16_MINW
-#define HN_U16_MINW 3      // workgroups per CU the register budget allows (3: <= 168 registers)
+#define HN_U16_MINW 2      // workgroups per CU the register budget allows (2: <= 256 registers; 3 spills in the forward and measures the same)
 #endif
 
 namespace {
@@ -184,6 +184,9 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
   tile16_load<H>(regs, vec1_r, 3 * H, 0, tid);
   Ring16<4> rv;
   b16_preload(rv, bpv);
+  // (accumulators START at their bias -- a lane's float4 of a block is exactly the bias float4 of its channels --, loaded
+  // in front of the preceding epilogue's stores: vmcnt retires in order, a bias load issued behind stores waits for them)
+  f32x4 acch[2], accq[6];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     float* buf = lds + (d & 1) * TR * LD;
@@ -194,6 +197,10 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
     f32x4 accv[4] = {zero4(), zero4(), zero4(), zero4()};
     mma16_panel<H, 4, false>(accv, buf + mrow * LD + ch, bpv, rv);
     if (d < 2) b16_preload(rv, bpv);
+    if (d == 2) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) acch[s] = ld4g(a.bx0 + (size_t)t * H + cw + 16 * s + ch);
+    }
     fence_sched();
     f32x4 v1[2] = {accv[0], accv[1]}, v2[2] = {accv[2], accv[3]};
 #pragma unroll
@@ -223,7 +230,6 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
   }
   __syncthreads();
   // ---- h2 = xin Wx0^T + bx0 (K = 2H: two panels)
-  f32x4 acch[2] = {zero4(), zero4()};
   {
     const f32x4* bpx1[2] = {bpx[0] + (size_t)(H / 16) * 64, bpx[1] + (size_t)(H / 16) * 64};
     mma16_panel<H, 2, true>(acch, bufx + mrow * LD + ch, bpx, rx);
@@ -231,13 +237,17 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
   }
   Ring16<6> rq;
   b16_preload(rq, bpq);
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) accq[2 * p + s] = ld4g(a.bx2 + (size_t)t * 3 * H + p * H + cw + 16 * s + ch);
   __syncthreads();                                   // buffer 0 is free (x1 stays in buffer 1)
   {
     f32x4 hv[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int c0 = cw + 16 * s + ch;
-      hv[s] = acch[s] + ld4g(a.bx0 + (size_t)t * H + c0);
+      hv[s] = acch[s];                               // (incl. bx0)
       *reinterpret_cast<f32x4*>(lds + mrow * LD + c0) = ssilu4(hv[s]);
     }
     store16<H>(scr, lane, hv, h2b_r, cw);
@@ -249,7 +259,6 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
   for (int d = 0; d < 3; ++d) issue16<3 * H>(lvv[d], lane, vec1_r, d * H + cw);
   const float on = (all_on | (bld(act_r, mrow) != 0.f)) ? 1.f : 0.f;
   fence_sched();
-  f32x4 accq[6] = {zero4(), zero4(), zero4(), zero4(), zero4(), zero4()};
   mma16_panel<H, 6, false>(accq, lds + mrow * LD + ch, bpq, rq);
   fence_sched();
   const float inv_sqrt_h = rsqrtf((float)H);
@@ -257,10 +266,9 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int c0 = cw + 16 * s + ch;
-    const float* bb = a.bx2 + (size_t)t * 3 * H + c0;
-    const f32x4 p = accq[s] + ld4g(bb);
-    q[s] = accq[2 + s] + ld4g(bb + H);
-    r[s] = accq[4 + s] + ld4g(bb + 2 * H);
+    const f32x4 p = accq[s];                         // (incl. bx2)
+    q[s] = accq[2 + s];
+    r[s] = accq[4 + s];
     const f32x4 x1v = *reinterpret_cast<const f32x4*>(bufx + mrow * LD + c0);
     xo[s] = (x1v + (p + q[s] * dot[s] * inv_sqrt_h) * kInvSqrt2) * on;
   }

@@ -220,6 +220,23 @@ __device__ __forceinline__ void mma_panel(f32x16 (&acc)[RB][NJ], const float* As
   for (int qq = 0; qq < RS; ++qq) group(NQ - RS, qq, MORE || qq + PF < RS, qq + 1 < RS);
 }
 
+// Accumulators that START at the bias (acc[rb][j] = bias of the block's channels, every row): the bias loads are then
+// issued in front of the product, where nothing is queued in front of them -- an epilogue's bias load sits behind the
+// previous block's stores, and vmcnt retires in order -- and the epilogue has no add left.  bias[j][g]: the four channel
+// runs of block j of this lane (see run4).
+template <int RB, int NJ>
+__device__ __forceinline__ void bias_acc(f32x16 (&acc)[RB][NJ], const f32x4 (&bias)[NJ][4]) {
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        acc[rb][j][4 * g] = bias[j][g][0]; acc[rb][j][4 * g + 1] = bias[j][g][1];
+        acc[rb][j][4 * g + 2] = bias[j][g][2]; acc[rb][j][4 * g + 3] = bias[j][g][3];
+      }
+}
+
 template <int RB, int NJ>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RB][NJ]) {
 #pragma unroll

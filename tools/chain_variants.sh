@@ -3,10 +3,13 @@
 # variant built by tools/build_chain_variant.sh; one process per library (the library is chosen at import)
 OUT=$1; shift
 mkdir -p "$(dirname "$OUT")"
-echo "== default" > $OUT
-python tools/chain_bench.py 10000 128 3 200 >> $OUT 2>&1
+echo "== default (update chain on 16-row tiles where the library picks them)" > $OUT
+python tools/chain_bench.py 10000 128 3 200 2>&1 | grep -v amdgpu.ids >> $OUT
+echo "== HERMNET_UPDATE_TILE16=0 (32-row update tiles: the baseline of the variants below)" >> $OUT
+HERMNET_UPDATE_TILE16=0 python tools/chain_bench.py 10000 128 3 200 2>&1 | grep -v amdgpu.ids >> $OUT
 for v in "$@"; do
   echo "== $v" >> $OUT
-  HERMNET_LIB_PATH=hermnet_amd/csrc/variants/libhermnet_$v.so python tools/chain_bench.py 10000 128 3 200 >> $OUT 2>&1
+  case $v in u16*) T16=2;; *) T16=0;; esac
+  HERMNET_UPDATE_TILE16=$T16 HERMNET_LIB_PATH=hermnet_amd/csrc/variants/libhermnet_$v.so python tools/chain_bench.py 10000 128 3 200 2>&1 | grep -v amdgpu.ids >> $OUT
 done
 grep -v "^rows" $OUT
