@@ -694,6 +694,36 @@ def main():
             md_step()
         fence()
         md = max_over_ranks(time.perf_counter() - t1) / nmd
+        md_padded = None
+        if not sharded:
+            # the same MD-style step with the neighbour list built WITHOUT its host read: padded to a capacity, count and
+            # flags left on the device (checked once behind the timed loop here; a calculator checks them when it copies
+            # the results to the host)
+            from hermnet_amd.neighbor import neighbor_search_padded, padded_capacity, padded_list_ok
+            cap = padded_capacity(E)
+            totals = []
+
+            def md_step_padded():
+                ei, sh, total = neighbor_search_padded(pos0, model_kw["rc"], cell0, cap)
+                d = hn.Data(pos=pos0.clone(), atomic_number=data.atomic_number, batch=data.batch,
+                            cell=cell0, edge_index=ei, edge_shift=sh)
+                d._hn_edge_count = total
+                totals.append(total)
+                return step(d)
+
+            for _ in range(2):
+                e_p, _f = md_step_padded()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(nmd):
+                md_step_padded()
+            fence()
+            md_padded = (time.perf_counter() - t1) / nmd
+            ok, n_found = padded_list_ok(totals[-1])
+            md_padded = {"ms_per_step": md_padded * 1e3, "atom_steps_per_s": N_global / md_padded, "capacity": cap,
+                         "edges_found": n_found, "list_complete": bool(ok),
+                         "energy_equals_exact_list": bool(torch.equal(e_p.detach(), step()[0].detach())),
+                         "over_step": md_padded / (dt / args.steps)}
         replan_ms = None
         if sharded:       # what a re-plan costs when the skin is used up (every ~10-50 MD steps)
             fence()
@@ -785,6 +815,8 @@ def main():
                                          "atoms only) + relation build + energy + forces per step, max over ranks") if sharded else
                                         "device cell-list neighbour search + relation build + energy + forces per step"}
             out["secondary"]["incl_planning_over_step"] = md / (dt / args.steps)
+            if md_padded is not None:
+                out["secondary"]["incl_planning_padded_list"] = md_padded
             if sharded:
                 out["secondary"].update({"skin_A": SKIN, "replan_ms": replan_ms, "replans_in_run": stepper.replans,
                                          "planning_note": "plan reused under the Verlet skin (static coordinates here); a "

@@ -56,6 +56,8 @@ SIGNATURES = {
     "hermnet_neighbor_fill": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_double, c_fp, ctypes.c_size_t,
                                              ctypes.c_long, ctypes.c_float, ctypes.c_int, ctypes.c_int,
                                              c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "hermnet_neighbor_fill_padded": (ctypes.c_int, [ctypes.c_int, c_fp, ctypes.c_size_t, ctypes.c_long, ctypes.c_float,
+                                                    ctypes.c_int, c_fp, c_fp, c_fp, c_fp]),
     "hermnet_relation_counts": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp]),
     "hermnet_build_relations_workspace": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "hermnet_build_relations": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_int,

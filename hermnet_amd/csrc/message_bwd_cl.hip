@@ -50,11 +50,28 @@ constexpr int kRec = HN_EDGE_TABLE_FLOATS;   // floats per edge record
 __global__ __launch_bounds__(256) void edge_table_kernel(const float4* __restrict__ edge, const int* __restrict__ csc_pos,
                                                          int E, const float* __restrict__ offset, int R, float inv_rc,
                                                          float coeff, int env_kind, int env_p,
-                                                         float* __restrict__ table) {
+                                                         float* __restrict__ table, const int* __restrict__ csc_end) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= E) return;
+  // CSC positions behind the last segment (edges into unknown-element rows, the NULL edges of a padded list) belong to
+  // no row: csc_pos is not defined there.  Their records are never an edge's own record -- only the one a wave requests
+  // AHEAD of its last edge -- so they hold a valid tile row and zeros.
+  const int n_csc = csc_end[0];
+  if (q >= n_csc) {
+    float4* out = reinterpret_cast<float4*>(table + (size_t)q * kRec);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < kRec / 4; ++w) out[w] = z;
+    out[6] = make_float4(__int_as_float(HN_PAD), __int_as_float(HN_PAD), 0.f, 0.f);      // slots 24, 25: tile rows
+    if (q == E - 1) {
+#pragma unroll
+      for (int w = 0; w < kRec / 4; ++w) out[kRec / 4 + w] = z;
+      out[kRec / 4 + 6] = make_float4(__int_as_float(HN_PAD), __int_as_float(HN_PAD), 0.f, 0.f);
+    }
+    return;
+  }
   const float4 g = edge[csc_pos[q]];
-  const float d_next = edge[csc_pos[min(q + 1, E - 1)]].w;
+  const float d_next = edge[csc_pos[min(q + 1, n_csc - 1)]].w;
   const float u = g.w * inv_rc;
   const HnEnv env = hn_envelope(u, env_kind, env_p);
   const int lo = hn_window_lo(u, R);
@@ -594,9 +611,10 @@ extern "C" int hermnet_edge_radial_table(const hn_graph* g, const hn_rbf_desc* r
   if (!g || !rbf || rbf->num_rbf < 2 || g->num_edges < 0) return HN_ERR_BAD_ARG;
   const int num_edges = g->num_edges;
   if (num_edges == 0) return HN_OK;
-  if (!edge || !table || !rbf->offset || !g->csc_pos) return HN_ERR_BAD_ARG;
+  if (!edge || !table || !rbf->offset || !g->csc_pos || !g->csc_rowptr) return HN_ERR_BAD_ARG;
   hipLaunchKernelGGL(edge_table_kernel, dim3((num_edges + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float4*>(edge), g->csc_pos, num_edges, rbf->offset, rbf->num_rbf, rbf->inv_rc,
-                     rbf->coeff, rbf->env_kind, rbf->env_p, table);
+                     rbf->coeff, rbf->env_kind, rbf->env_p, table,
+                     g->csc_rowptr + (size_t)g->num_rel * (size_t)(g->num_src > 0 ? g->num_src : g->num_nodes));
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }

@@ -208,6 +208,8 @@ __global__ __launch_bounds__(kBlock) void nbr_decode_kernel(const unsigned long 
 
 // One wave per atom: rank sort of its keys (unique, so rank = number of smaller keys) and decode into the caller's
 // arrays at offset[i] + rank.  `stride` = kStash (stashed keys at src[i * kStash]) or 0 (keys at src[offset[i]]).
+// (E = columns of edge_index; in capacity mode the list may hold more pairs than that: positions >= E are dropped and
+// nbr_pad_kernel reports it)
 __global__ __launch_bounds__(kBlock) void nbr_sort_decode_kernel(const unsigned long long* __restrict__ src, int stride,
                                                                 const int* __restrict__ count, const long* __restrict__ offset,
                                                                 int N, long E, float sign, int swap_rows,
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void nbr_sort_decode_kernel(const unsigned 
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= N) return;
   const int lane = threadIdx.x & 63;
-  const int n = count[i];
+  const int n = stride ? min(count[i], stride) : count[i];     // (a stash holds at most `stride` keys of an atom)
   const long base = offset[i];
   const unsigned long long* keys = src + (stride ? (long)i * stride : base);
   const unsigned long long c3 = (unsigned long long)(kCode * kCode * kCode);
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(kBlock) void nbr_sort_decode_kernel(const unsigned 
     int rank = 0;
     for (int b = 0; b < n; ++b) rank += keys[b] < key ? 1 : 0;
     const long e = base + rank;
+    if (e >= E) continue;
     const unsigned long long pair = key / c3;
     const int code = (int)(key - pair * c3);
     const long j = (long)(pair - (unsigned long long)i * N);
@@ -235,6 +238,34 @@ __global__ __launch_bounds__(kBlock) void nbr_sort_decode_kernel(const unsigned 
       shift[3 * e + 2] = sign * (float)(code % kCode - kMaxImg);
     }
   }
+}
+
+// Capacity mode: the columns behind the list's last pair become NULL edges (-1, -1; shift 0) -- the relation build files
+// them behind every row, so no row-walking kernel ever meets one -- and total[0] = number of pairs found, total[1] = flags
+// (bit 0: image shift overflow, bit 1: an atom with more pairs than its stash slot, bit 2: more pairs than columns).
+// With bits 1 or 2 set the list is incomplete: the caller repeats the search in its exact (two-call) form.
+__global__ __launch_bounds__(kBlock) void nbr_pad_kernel(const long* __restrict__ offset, const int* __restrict__ overflow,
+                                                        int N, long cap, long* __restrict__ edge_index,
+                                                        float* __restrict__ shift, long* __restrict__ total) {
+  const long found = offset[N];
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0) {
+    total[0] = found;
+    total[1] = (long)(overflow[0] | (found > cap ? 4 : 0));
+  }
+  if (e < found || e >= cap) return;
+  edge_index[e] = -1;
+  edge_index[cap + e] = -1;
+  if (shift != nullptr) { shift[3 * e] = 0.f; shift[3 * e + 1] = 0.f; shift[3 * e + 2] = 0.f; }
+}
+
+// (set / copy as kernels, not hipMemsetAsync / hipMemcpyAsync: captured memset nodes did not survive eager memsets
+// between two replays on ROCm 7.2 -- csrc/relation_kernels.hip --, and the search is part of a captured MD step)
+__global__ void nbr_clear_kernel(int* __restrict__ count_end, int* __restrict__ overflow) {
+  if (threadIdx.x == 0) { count_end[0] = 0; overflow[0] = 0; overflow[1] = 0; }
+}
+__global__ void nbr_total_kernel(const long* __restrict__ offset_end, const int* __restrict__ overflow, long* __restrict__ total) {
+  if (threadIdx.x == 0) { total[0] = offset_end[0]; total[1] = (long)overflow[0]; }
 }
 
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -367,17 +398,31 @@ extern "C" int hermnet_neighbor_count(const float* pos, int num_atoms, const dou
   if (hipcub::DeviceRadixSort::SortPairs(w.temp, tb, w.bin, w.bin_sorted, w.ids, w.ids_sorted, N, 0, bits, s) != hipSuccess)
     return HN_ERR_LAUNCH;
   hipLaunchKernelGGL(nbr_binstart_kernel, grid_for(nbins + 1), dim3(kBlock), 0, s, w.bin_sorted, N, (int)nbins, w.bin_start);
-  if (hipMemsetAsync(w.count + N, 0, sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
-  if (hipMemsetAsync(w.overflow, 0, 2 * sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
+  hipLaunchKernelGGL(nbr_clear_kernel, dim3(1), dim3(64), 0, s, w.count + N, w.overflow);
   hipLaunchKernelGGL(nbr_pairs_kernel<0>, grid_for((long)N * 64), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N,
                      g, (const long*)nullptr, w.count, w.stash, w.overflow, target_ok, g.periodic);
   tb = w.temp_bytes;
   if (hipcub::DeviceScan::ExclusiveSum(w.temp, tb, w.count, w.offset, N + 1, s) != hipSuccess) return HN_ERR_LAUNCH;
-  if (hipMemcpyAsync(total_device, w.offset + N, sizeof(long), hipMemcpyDeviceToDevice, s) != hipSuccess)
-    return HN_ERR_LAUNCH;
-  // total_device[1] = flags of the pass (low 32 bits; the high half of the long is the zeroed word behind it)
-  if (hipMemcpyAsync(total_device + 1, w.overflow, sizeof(long), hipMemcpyDeviceToDevice, s) != hipSuccess)
-    return HN_ERR_LAUNCH;
+  // total_device = (pairs found, flags of the pass)
+  hipLaunchKernelGGL(nbr_total_kernel, dim3(1), dim3(64), 0, s, w.offset + N, w.overflow, total_device);
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}
+
+extern "C" int hermnet_neighbor_fill_padded(int num_atoms, void* workspace, size_t workspace_bytes, long capacity,
+                                            float shift_sign, int source_first, long* edge_index, float* edge_shift,
+                                            long* total_device, void* stream) {
+  const int N = num_atoms;
+  if (N <= 0 || capacity <= 0 || capacity > 0x7fffffffl || !workspace || !edge_index || !total_device) return HN_ERR_BAD_ARG;
+  if ((double)N * N * 4913.0 >= 1.8e19) return HN_ERR_BAD_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  NbrWork w;
+  carve(workspace, N, 8l * N + 64, w);
+  // the stashed keys of the counting pass, rank-sorted per atom, into the first `capacity` columns ...
+  hipLaunchKernelGGL(nbr_sort_decode_kernel, grid_for((long)N * 64), dim3(kBlock), 0, s, w.stash, kStash, w.count, w.offset, N,
+                     capacity, shift_sign, source_first, edge_index, edge_shift);
+  // ... NULL edges behind them, and the count + flags for whoever reads them (the host: at the END of the step)
+  hipLaunchKernelGGL(nbr_pad_kernel, grid_for(capacity), dim3(kBlock), 0, s, w.offset, w.overflow, N, capacity, edge_index,
+                     edge_shift, total_device);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
 

@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include "../../include/hermnet_hip.h"
 
+#include "scan_i32.h"
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -117,79 +119,6 @@ __global__ __launch_bounds__(kBlock) void group_rank_sort_kernel(const int* __re
   }
 }
 
-// ---- exclusive prefix sum of int32, three plain launches (block sums, scan of the block sums, local scan + offset).
-// Deliberately not hipcub::DeviceScan: a captured step is replayed as a hipGraph, and the library scan's look-back
-// state did not survive replays that were interleaved with eager runs (second replay: garbage row pointers ->
-// out-of-bounds scatter).  These kernels keep all their state in `temp`, rewritten on every run.
-constexpr int kScanTile = 1024;           // elements per block (256 threads x 4)
-
-__device__ __forceinline__ int block_exclusive_scan(int v, int* lds, int& total) {
-  // 256 threads: wave scans with shuffles, wave totals through LDS
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int u = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += u;
-  }
-  if (lane == 63) lds[wave] = inc;
-  __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wave; ++w) base += lds[w];
-  total = lds[0] + lds[1] + lds[2] + lds[3];
-  __syncthreads();
-  return base + inc - v;
-}
-
-__global__ __launch_bounds__(kBlock) void scan_block_sums_kernel(const int* __restrict__ in, int n, int* __restrict__ sums) {
-  __shared__ int lds[4];
-  const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
-  int v = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) v += (base + q < n) ? in[base + q] : 0;
-  int total;
-  (void)block_exclusive_scan(v, lds, total);
-  if (threadIdx.x == 0) sums[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(kBlock) void scan_sums_kernel(int* __restrict__ sums, int nb) {
-  // one block: every thread owns a contiguous chunk of the block sums
-  __shared__ int lds[4];
-  const int per = (nb + kBlock - 1) / kBlock;
-  const int lo = threadIdx.x * per, hi = min(lo + per, nb);
-  int v = 0;
-  for (int i = lo; i < hi; ++i) v += sums[i];
-  int total;
-  int run = block_exclusive_scan(v, lds, total);
-  for (int i = lo; i < hi; ++i) { const int x = sums[i]; sums[i] = run; run += x; }
-}
-
-__global__ __launch_bounds__(kBlock) void scan_apply_kernel(const int* __restrict__ in, int n, const int* __restrict__ sums,
-                                                           int* __restrict__ out) {
-  __shared__ int lds[4];
-  const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
-  int x[4], v = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { x[q] = (base + q < n) ? in[base + q] : 0; v += x[q]; }
-  int total;
-  int run = block_exclusive_scan(v, lds, total) + sums[blockIdx.x];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { if (base + q < n) out[base + q] = run; run += x[q]; }
-}
-
-size_t scan_temp_bytes(int n) { return ((size_t)(n + kScanTile - 1) / kScanTile + 1) * sizeof(int); }
-
-int exclusive_scan_i32(const int* in, int* out, int n, void* temp, size_t temp_bytes, hipStream_t s) {
-  if (n <= 0) return HN_OK;
-  const int nb = (n + kScanTile - 1) / kScanTile;
-  if (temp_bytes < scan_temp_bytes(n)) return HN_ERR_BAD_ARG;
-  int* sums = reinterpret_cast<int*>(temp);
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(kBlock), 0, s, in, n, sums);
-  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, s, sums, nb);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, s, in, n, sums, out);
-  return HN_OK;
-}
-
 // Zero fill and copy as kernels, not hipMemsetAsync / hipMemcpyAsync: under hipGraph replay (ROCm 7.2) the captured
 // memset nodes of this build did not survive eager memsets issued between two replays -- the second replay left the
 // histogram un-zeroed (bisected with tools/graph_probe.py: garbage row pointers, then an out-of-bounds rank sort).
@@ -237,7 +166,17 @@ __global__ __launch_bounds__(kBlock) void edge_keys_hist_kernel(const long* __re
                                                                int* __restrict__ hist) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  const int rs = row_of_node[edge_index[e]], rt = row_of_node[edge_index[(size_t)E + e]];
+  const long tgt = edge_index[(size_t)E + e];
+  if (tgt < 0) {
+    // a NULL edge of a padded list (hermnet_neighbor_fill_padded): the counters' closing slots -- row N of the CSR
+    // counters, key (T+1) N of the CSC ones -- so that it lands behind every row and in no segment
+    key1[e] = N;
+    key2[e] = (T + 1) * N;
+    atomicAdd(&hist[N], 1);
+    atomicAdd(&hist[N + 1 + (T + 1) * N], 1);
+    return;
+  }
+  const int rs = row_of_node[edge_index[e]], rt = row_of_node[tgt];
   const int k2 = relation_of_row(rt, row_start, T) * N + rs;        // == T*N + rs for unknown-element targets
   key1[e] = rt;
   key2[e] = k2;
@@ -275,9 +214,17 @@ __global__ __launch_bounds__(kBlock) void csr_gather_scatter_kernel(
     const long* __restrict__ edge_index, const float* __restrict__ shift, int E, int N,
     const int* __restrict__ row_of_node, const int* __restrict__ csr_perm, const int* __restrict__ key2,
     int* __restrict__ csr_src, int* __restrict__ src_id, int* __restrict__ tgt_id, float* __restrict__ shift_csr,
-    int* __restrict__ rt_csr, int* __restrict__ cursor2 /* counters of the second part */, int* __restrict__ slots2) {
+    int* __restrict__ rt_csr, int* __restrict__ cursor2 /* counters of the second part */, int* __restrict__ slots2,
+    const int* __restrict__ csr_rowptr_end /* &csr_rowptr[N] = number of real edges */) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= E) return;
+  if (k >= csr_rowptr_end[0]) {
+    // CSR positions behind the last row: the NULL edges of a padded list.  Benign values (atom 0 onto itself, no
+    // shift): the edge-parallel kernels (geometry, radial table) may compute on them, nothing reads the results.
+    csr_src[k] = 0; src_id[k] = 0; tgt_id[k] = 0; rt_csr[k] = 0;
+    if (shift != nullptr) { shift_csr[3 * k + 0] = 0.f; shift_csr[3 * k + 1] = 0.f; shift_csr[3 * k + 2] = 0.f; }
+    return;
+  }
   const int e = csr_perm[k];
   const int s = (int)edge_index[e], t = (int)edge_index[(size_t)E + e];
   csr_src[k] = row_of_node[s];
@@ -500,7 +447,7 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
     // key range [T*N, (T+1)*N) and are simply not covered by csc_rowptr[0 .. T*N]
     hipLaunchKernelGGL(csr_gather_scatter_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, shift, E, N, out->row_of_node,
                        out->csr_perm, key2, out->csr_src, out->src_id, out->tgt_id, out->shift_csr, rt_csr, cursor + N + 1,
-                       slots);
+                       slots, out->csr_rowptr + N);
     const int ng2 = (T + 1) * N;
     hipLaunchKernelGGL(csc_rank_sort_kernel, dim3((unsigned)((ng2 + 3) / 4)), dim3(kBlock), 0, s, rp_all + N + 1, E, ng2, slots,
                        rt_csr, out->csc_pos, out->csc_tgt);

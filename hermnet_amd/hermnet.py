@@ -165,6 +165,10 @@ class HVNet(nn.Module):
         zl = [atomic_numbers[el] for el in self.elems]
         # atom-sharded evaluation (hermnet_amd/sharding.py): this rank's atoms + one-hop halo
         shard = data.get("_hn_shard")
+        # a padded neighbour list (neighbor.neighbor_search_padded: NULL edges behind the real ones, the count on the device)
+        padded = data.get("_hn_edge_count") is not None
+        if padded and (train or shard is not None):
+            raise NotImplementedError("a padded neighbour list runs through the fused eval() path of one GPU")
         graph = self._build_graph(data, zl, shard)
         fused = self.radial_basis.fused and not train
         rbf = self.radial_basis.descriptor() if fused else None
@@ -214,7 +218,8 @@ class HVNet(nn.Module):
         if fused and edge.requires_grad and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0":
             # one reduction of the edge gradients per step instead of one per layer (layer.EdgeFanout)
             # (atoms of an unknown element own the rows past type_rowptr[T]; only edges INTO them go unwritten)
-            all_known = graph.num_src == 0 and graph.N == graph.type_rowptr_host[-1]
+            # (... and the slots of a padded list's NULL edges: they are in no row)
+            all_known = graph.num_src == 0 and graph.N == graph.type_rowptr_host[-1] and not padded
             data._hn_edge_sink = EdgeGradSink(len(self.hermconvs), Hp // 64, graph.E, pos.device, zero=not all_known)
             data._hn_edge_handles = EdgeFanout.apply(edge, data._hn_edge_sink)
         for li, conv in enumerate(self.hermconvs):
@@ -356,6 +361,8 @@ class HTNet(HVNet):
                 mods={k: PaiNNModule(hidden_channels=hidden_channels, num_rbf=num_rbf) for k in keys}))
 
     def _build_graph(self, data, zl, shard):
+        if data.get("_hn_edge_count") is not None:
+            raise NotImplementedError("HTNet's triadic relation build takes exact neighbour lists")
         return RelationalGraph.build_triadic(data.atomic_number, data.edge_index, zl,
                                              edge_shift=data.get("edge_shift") if data.get("cell") is not None else None,
                                              batch=data.batch,

@@ -195,6 +195,61 @@ def _neighbor_search_device(pos, rc, cell, reference_compat, target_mask=None):
     return (edge_index, shift) if periodic else edge_index
 
 
+def neighbor_search_padded(pos, rc, cell, capacity, reference_compat=False):
+    """The device cell list WITHOUT its host read: `capacity` columns are provided up front, the pairs
+    found fill the first E of them and the rest become NULL edges (-1, -1; shift 0), which the relation build files behind
+    every row -- the model runs on the padded list unchanged, with a launch geometry that does not depend on E.
+
+    Returns (edge_index [2, capacity] int64, edge_shift [capacity, 3] float32 or None, total [2] int64 ON THE DEVICE):
+    total[0] = E, total[1] = flags; read them when the step's results are copied to the host anyway.  The list is
+    complete iff `padded_list_ok(total)`; otherwise (more pairs than columns, an atom with more pairs than its stash slot,
+    coordinates many cells away from the cell) repeat with `neighbor_search` and a larger capacity.  GPU tensors only;
+    open systems need `reference_compat=False` (the 32-neighbour cap is a host-side filter)."""
+    import ctypes
+    from . import _lib
+    if not pos.is_cuda:
+        raise RuntimeError("neighbor_search_padded runs on the device list only")
+    if cell is None and reference_compat:
+        raise NotImplementedError("the reference pipeline's 32-neighbour cap needs the exact list (neighbor_search)")
+    lib = _lib.load()
+    P = _lib.ptr
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dev = pos.device
+    p32 = pos.detach().float().contiguous()
+    N, cap = int(p32.size(0)), int(capacity)
+    dbl3 = ctypes.c_double * 3
+    cell_h = lo_h = hi_h = None
+    if cell is not None:
+        cell_h = (ctypes.c_double * 9)(*_cell_on_host(cell))
+    else:       # (an open system's bounding box is a host read of its own: periodic cells are the MD case)
+        mm = torch.stack([p32.min(0).values, p32.max(0).values]).double().cpu().tolist()
+        lo_h, hi_h = dbl3(*mm[0]), dbl3(*mm[1])
+    ws_bytes = lib.hermnet_neighbor_workspace(N)
+    work = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    total = torch.empty(2, dtype=torch.long, device=dev)
+    edge_index = torch.empty(2, cap, dtype=torch.long, device=dev)
+    periodic = cell is not None
+    shift = torch.empty(cap, 3, dtype=torch.float32, device=dev) if periodic else None
+    _lib.check(lib.hermnet_neighbor_count(P(p32), N, cell_h, lo_h, hi_h, float(rc), P(work), ws_bytes, None, P(total), stream),
+               "hermnet_neighbor_count")
+    sign = 1.0 if reference_compat else -1.0
+    _lib.check(lib.hermnet_neighbor_fill_padded(N, P(work), ws_bytes, cap, sign, 0 if periodic else 1, P(edge_index), P(shift),
+                                                P(total), stream), "hermnet_neighbor_fill_padded")
+    return edge_index, shift, total
+
+
+def padded_list_ok(total):
+    """(complete?, E) of a padded list from its `total` tensor -- a host read: do it behind the step."""
+    E, flags = total.tolist()
+    return flags == 0, int(E)
+
+
+def padded_capacity(num_edges, margin=0.06, granule=4096):
+    """A column count for the next steps' lists: the last count plus a margin, rounded up (a stable launch geometry)."""
+    want = int(num_edges * (1.0 + margin)) + 64
+    return (want + granule - 1) // granule * granule
+
+
 def _cap_neighbors(edge_index, cap):
     """Keep at most `cap` in-edges per target (row 1), the ones with the lowest source index: the list is sorted
     by (target, source), so an edge's rank inside its target's run is its position minus the run's start."""

@@ -46,8 +46,25 @@ def _species_tensors(elements, device):
     return hit[1], hit[2]
 
 
-def build_graph(cell, elements, pos, rc, device=None, reference_compat=False):
+_CELLS = {}      # device -> (numpy cell, tensor) of the last call
+
+
+def _cell_tensor(cell, device):
+    """The cell as a [3,3] float32 tensor on `device`, REUSED while its values are unchanged (NVT / NVE: the neighbour
+    search then skips reading it back, `neighbor._cell_on_host`, and a captured step keeps seeing the same tensor)."""
+    c = np.asarray(cell, dtype=np.float64).reshape(3, 3)
+    key = str(device)
+    hit = _CELLS.get(key)
+    if hit is None or not np.array_equal(hit[0], c):
+        hit = _CELLS[key] = (c.copy(), torch.from_numpy(c).float().to(device))
+    return hit[1]
+
+
+def build_graph(cell, elements, pos, rc, device=None, reference_compat=False, capacity=None):
     """`calculator.py:10-27`: numpy (cell [3,3] or None, Z [N], pos [N,3]) -> `Data` with the cutoff graph.
+    `capacity` (periodic cells on the GPU): the neighbour list is built WITHOUT its host read, padded to that many columns
+    (`neighbor.neighbor_search_padded`); `data._hn_edge_count` then holds (E, flags) on the device for a check behind
+    the step (`NNCalculator.calculate` does it when the results are copied to the host anyway).
     With `device` set to the GPU the coordinates are uploaded first and the neighbour search runs on the
     device (`csrc/neighbor_kernels.hip`) instead of the host -- the reference rebuilds the list every step.
     `reference_compat`: the edge conventions of the reference's own pipeline (`neighbor.neighbor_search`),
@@ -60,9 +77,14 @@ def build_graph(cell, elements, pos, rc, device=None, reference_compat=False):
     if cell is None or not np.any(np.asarray(cell)):
         data.edge_index = neighbor_search(pos=pos_t, rc=rc, reference_compat=reference_compat)
     else:
-        cell_t = torch.from_numpy(np.asarray(cell, dtype=np.float64).reshape(3, 3)).float().to(pos_t.device)
-        data.edge_index, data.edge_shift = neighbor_search(pos=pos_t, rc=rc, cell=cell_t,
-                                                            reference_compat=reference_compat)
+        cell_t = _cell_tensor(cell, pos_t.device)
+        if capacity is not None and pos_t.is_cuda:
+            from ..neighbor import neighbor_search_padded
+            data.edge_index, data.edge_shift, data._hn_edge_count = neighbor_search_padded(
+                pos_t, rc, cell_t, capacity, reference_compat=reference_compat)
+        else:
+            data.edge_index, data.edge_shift = neighbor_search(pos=pos_t, rc=rc, cell=cell_t,
+                                                                reference_compat=reference_compat)
         data.cell = cell_t.reshape(1, 3, 3)
     return data
 
@@ -132,6 +154,7 @@ class NNCalculator(_Base):
             p.requires_grad_(False)
         self.trn_mean = trn_mean
         self.ensemble = ensemble
+        self._edge_capacity = None        # columns of the padded neighbour list of the next call (None: exact search)
 
     def calculate(self, atoms, properties=('energy',), system_changes=all_changes):
         super(NNCalculator, self).calculate(atoms, properties, system_changes)
@@ -139,12 +162,29 @@ class NNCalculator(_Base):
         cell = np.asarray(atoms.cell if not hasattr(atoms, "todict") else atoms.todict()['cell']) if pbc else None
         elems = np.array([atomic_numbers[s] for s in atoms.get_chemical_symbols()])
         dev = self.device_ if torch.device(self.device_).type == 'cuda' else None
+        # periodic cells on the GPU: from the second call on the neighbour list is built without its host read, padded to a
+        # capacity taken from the last edge count; count and flags are checked behind the step, where the results are
+        # copied to the host anyway (an overflow repeats the step on an exact list)
+        cap = self._edge_capacity if (dev is not None and cell is not None) else None
         data = build_graph(cell=cell, elements=elems, pos=atoms.positions, rc=self.model.rc, device=dev,
-                           reference_compat=self.reference_compat)
+                           reference_compat=self.reference_compat, capacity=cap)
         # stress whenever ASE asks for it (or the ensemble is NPT) on a periodic cell; an open system has none
         want = pbc and cell is not None and (self.ensemble.lower() == 'npt' or 'stress' in tuple(properties))
         energy, forces, w = _evaluate(self.model, data, self.device_, pbc, want, self.trn_mean)
         energy = energy.cpu().item()
+        if dev is not None and cell is not None:
+            from ..neighbor import padded_capacity, padded_list_ok
+            if cap is not None:
+                ok, n_edges = padded_list_ok(data._hn_edge_count)
+                if not ok or n_edges > cap:            # the padded list was incomplete: this step again, exactly
+                    self._edge_capacity = None
+                    return self.calculate(atoms, properties, system_changes)
+            else:
+                n_edges = int(data.edge_index.size(1))
+            # (kept while it still fits with a margin and is not wastefully large: a stable launch geometry)
+            if cap is None or not (n_edges * 1.02 + 64 <= cap <= n_edges * 1.25 + 8192):
+                cap = padded_capacity(n_edges)
+            self._edge_capacity = cap
         self.results['energy'] = energy
         self.results['free_energy'] = energy
         self.results['forces'] = forces.cpu().numpy().reshape(-1, 3)

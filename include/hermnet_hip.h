@@ -101,6 +101,17 @@ typedef struct hn_graph {
  * target_ok (ABI v6; NULL = every atom): [num_atoms] bytes, only pairs whose TARGET atom (row 1 of edge_index) is
  * flagged are counted and listed -- the list of an atom shard (owned + halo atoms in, edges into owned atoms out);
  * pass the same pointer to both calls. */
+/* hermnet_neighbor_fill_padded (ABI v7; SURVEY 8(f) row 1: no host round-trip inside an MD step): instead of reading E
+ * between the two calls, the caller provides `capacity` columns; the pairs found fill the first E of them, the rest
+ * become NULL edges (-1, -1; shift 0), and total_device = (E, flags) is written for a read at the END of the step
+ * (flags as above, plus bit 2: E > capacity).  With bit 1 or 2 set the list is incomplete: repeat the search in its
+ * two-call form with a larger capacity.  hermnet_build_relations files NULL edges behind every row (they are in no CSR /
+ * CSC segment), so every kernel of the step runs on the padded arrays with num_edges = capacity -- a fixed launch
+ * geometry: search + step can be captured into ONE hipGraph that stays valid across list rebuilds.  Call after
+ * hermnet_neighbor_count on the same workspace. */
+int hermnet_neighbor_fill_padded(int num_atoms, void* workspace, size_t workspace_bytes, long capacity, float shift_sign,
+                                 int source_first, long* edge_index /* [2, capacity] */, float* edge_shift /* [capacity, 3] */,
+                                 long* total_device /* [2] */, void* stream);
 size_t hermnet_neighbor_workspace(int num_atoms);
 int hermnet_neighbor_count(const float* pos, int num_atoms, const double* cell_host, const double* lo_host,
                            const double* hi_host, double rc, void* workspace, size_t workspace_bytes,

@@ -1130,6 +1130,87 @@ def _oracle_vs_hip(data, elems, kw, seed, tol=TOL, e_floor=0.1):
     return e.detach().cpu(), f.cpu()
 
 
+@pytest.mark.parametrize("case", ["fcc", "triclinic", "unknown_element"])
+def test_padded_neighbour_list_gives_the_exact_lists_results_bit_for_bit(case):
+    """SURVEY 8(f) row 1 (data.py:14-24 is rebuilt every step, calculator.py:49): the device list WITHOUT its host read --
+    `neighbor_search_padded` fills a capacity with the pairs found and NULL edges (-1, -1) behind them, the relation build
+    files those behind every row, and every kernel of the step runs on the padded arrays.  Energy and forces must be
+    bit-identical to the exact list's; count and flags arrive on the device; a capacity that is too small is reported."""
+    from hermnet_amd.neighbor import neighbor_search_padded, padded_list_ok
+    dev = _dev()
+    if case == "triclinic":
+        rs = np.random.RandomState(4)
+        cell = np.array([[11.0, 0.0, 0.0], [2.5, 12.0, 0.0], [-1.5, 3.0, 13.0]])
+        pos = rs.rand(260, 3) @ cell
+        z = rs.choice([13, 28, 29], size=260)
+    else:
+        pos, cell, z = synth.fcc_alloy_atoms(reps=(3, 3, 5))
+        if case == "unknown_element":
+            z = z.copy()
+            z[::7] = 79
+    pos_t = torch.from_numpy(pos.astype(np.float32)).to(dev)
+    cell_t = torch.from_numpy(cell.astype(np.float32)).to(dev)
+    z_t = torch.from_numpy(z).to(dev)
+    kw = dict(rc=5.0, num_layers=3, hidden_channels=128, num_rbf=64)
+    model = hn.HVNet(["Al", "Ni", "Cu"], **kw).eval()
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), 5))
+    model = model.to(dev)
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    ei, sh = hn.neighbor_search(pos_t, 5.0, cell_t)
+    E = int(ei.size(1))
+    batch = torch.zeros(len(z), dtype=torch.long, device=dev)
+
+    def run(ei_, sh_, total=None):
+        d = hn.Data(pos=pos_t.clone().requires_grad_(True), atomic_number=z_t, batch=batch, cell=cell_t.reshape(1, 3, 3),
+                    edge_index=ei_, edge_shift=sh_)
+        if total is not None:
+            d._hn_edge_count = total
+        e = model(d)
+        return e.detach(), -torch.autograd.grad(e.sum(), d.pos)[0]
+
+    e0, f0 = run(ei, sh)
+    for cap in (E + 777, E):
+        eip, shp, total = neighbor_search_padded(pos_t, 5.0, cell_t, cap)
+        assert padded_list_ok(total) == (True, E)
+        assert torch.equal(eip[:, :E], ei) and torch.equal(shp[:E], sh)
+        assert bool((eip[:, E:] == -1).all()) and float(shp[E:].abs().sum()) == 0.0
+        os.environ["HERMNET_DEBUG_POISON"] = "1"          # unwritten edge-gradient slots would poison the forces
+        try:
+            e1, f1 = run(eip, shp, total)
+        finally:
+            os.environ["HERMNET_DEBUG_POISON"] = "0"
+        assert torch.equal(e0, e1) and torch.equal(f0, f1)
+    _, _, total = neighbor_search_padded(pos_t, 5.0, cell_t, E - 5)
+    ok, found = padded_list_ok(total)
+    assert not ok and found == E
+
+
+def test_calculator_builds_its_lists_without_a_host_read_after_the_first_call():
+    """`NNCalculator.calculate` along a trajectory: the first call searches exactly (and learns a capacity), the following
+    ones use padded lists checked behind the step; results equal a fresh calculator's exact evaluation of the same
+    coordinates, also when the list outgrows its capacity (that step is repeated exactly)."""
+    from hermnet_amd.plugin import NNCalculator
+    _dev()
+    g = Golden("alloy108")
+    d = g.data()
+    z, cell = d.atomic_number.numpy(), d.cell[0].numpy().astype("float64")
+    rs = np.random.RandomState(1)
+    calc = NNCalculator(g.model(), None, trn_mean=0.0, device_="cuda:0")
+    ref = NNCalculator(g.model(), None, trn_mean=0.0, device_="cuda:0")
+    pos = d.pos.numpy().astype("float64")
+    for it in range(4):
+        if it == 3:
+            calc._edge_capacity = 256                    # far too few columns: the step must notice and redo
+        calc.calculate(_FakeAtoms(pos, z, cell), ["energy", "forces"])
+        ref._edge_capacity = None                        # always the exact search
+        ref.calculate(_FakeAtoms(pos, z, cell), ["energy", "forces"])
+        assert calc.results["energy"] == ref.results["energy"]
+        assert np.array_equal(calc.results["forces"], ref.results["forces"])
+        assert (calc._edge_capacity is not None) and (it == 0 or calc._edge_capacity >= 256)
+        pos = pos + rs.normal(scale=0.03, size=pos.shape)
+
+
 def test_edge_cases_empty_and_degenerate_graphs():
     """Ragged / empty inputs: no edges at all, a single atom, only atoms of unlisted elements, an
     isolated atom next to a bonded cluster, a listed element without atoms (the reference crashes
