@@ -16,7 +16,7 @@
 // second pass over the candidates (0.07 ms) are gone.  An atom with more than kStash pairs makes the caller take the
 // two-pass form (count, then fill).  Integer/streaming work.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "scan_i32.h"
 #include <stdint.h>
 #include "../../include/hermnet_hip.h"
 
@@ -54,7 +54,7 @@ __device__ __forceinline__ void cart_of(const NbrGeom& g, const double* f, doubl
 // wrapped fractional coordinate, integer wrap, bin id
 __global__ __launch_bounds__(kBlock) void nbr_bin_kernel(const float* __restrict__ pos, int N, NbrGeom g,
                                                         double* __restrict__ fw, int* __restrict__ wrap,
-                                                        unsigned* __restrict__ bin, int* __restrict__ ids) {
+                                                        unsigned* __restrict__ bin) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const double p[3] = {(double)pos[3 * i], (double)pos[3 * i + 1], (double)pos[3 * i + 2]};
@@ -79,16 +79,26 @@ __global__ __launch_bounds__(kBlock) void nbr_bin_kernel(const float* __restrict
   }
   fw[3 * i] = f[0]; fw[3 * i + 1] = f[1]; fw[3 * i + 2] = f[2];
   bin[i] = (unsigned)((b[0] * g.nbins[1] + b[1]) * g.nbins[2] + b[2]);
-  ids[i] = i;
 }
 
-__global__ __launch_bounds__(kBlock) void nbr_binstart_kernel(const unsigned* __restrict__ sorted_bin, int N,
-                                                             int nbin_total, int* __restrict__ start) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r > nbin_total) return;
-  int lo = 0, hi = N;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_bin[mid] < (unsigned)r) lo = mid + 1; else hi = mid; }
-  start[r] = lo;
+// Atoms grouped by bin with a counting sort (histogram -> exclusive scan = bin_start -> scatter through per-bin cursors).
+// The order INSIDE a bin is whatever the atomics give: it only decides the order in which an atom's keys reach its
+// stash slot, and those are rank-sorted before they are decoded -- the list does not depend on it.  (Round 4: replaces a
+// library radix sort + scan, whose look-back state does not survive hipGraph replays interleaved with eager runs --
+// csrc/relation_kernels.hip found that out for the relation build -- so that search + step can be ONE captured graph.)
+__global__ __launch_bounds__(kBlock) void nbr_zero_kernel(int* __restrict__ dst, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = 0;
+}
+__global__ __launch_bounds__(kBlock) void nbr_bin_hist_kernel(const unsigned* __restrict__ bin, int N, int* __restrict__ hist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) atomicAdd(&hist[bin[i]], 1);
+}
+__global__ __launch_bounds__(kBlock) void nbr_bin_scatter_kernel(const unsigned* __restrict__ bin, int N,
+                                                                const int* __restrict__ start, int* __restrict__ fill,
+                                                                int* __restrict__ ids_sorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) ids_sorted[start[bin[i]] + atomicAdd(&fill[bin[i]], 1)] = i;
 }
 
 // Visit every candidate (j, image) of atom i.  MODE 0 counts and stashes the keys at keys[i * kStash ...] (flags: bit 0
@@ -278,16 +288,12 @@ int key_bits(int N) {
 }
 
 struct NbrWork {
-  double* fw; int* wrap; unsigned* bin; unsigned* bin_sorted; int* ids; int* ids_sorted; int* bin_start;
+  double* fw; int* wrap; unsigned* bin; int* bin_fill; int* ids_sorted; int* bin_start;
   int* count; long* offset; int* overflow; unsigned long long* stash; void* temp; size_t temp_bytes;
 };
 
-size_t temp_bytes_for(int N) {
-  size_t a = 0, b = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
-                                           (int*)nullptr, N, 0, 32, (hipStream_t)0);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const int*)nullptr, (long*)nullptr, N + 1, (hipStream_t)0);
-  return a > b ? a : b;
+size_t temp_bytes_for(int N) {      // scan scratch for the longer of the two scans (bins: <= 8 N + 65 counters; atoms: N + 1)
+  return scan_temp_bytes(8 * N + 66);
 }
 
 int make_geom(const double* cell_host, const double* lo_host, const double* hi_host, double rc, NbrGeom& g, long& nbins) {
@@ -337,10 +343,9 @@ void carve(void* workspace, int N, long nbins, NbrWork& w) {
   w.fw = (double*)take(sizeof(double) * 3 * (size_t)N);
   w.wrap = (int*)take(sizeof(int) * 3 * (size_t)N);
   w.bin = (unsigned*)take(sizeof(unsigned) * (size_t)N);
-  w.bin_sorted = (unsigned*)take(sizeof(unsigned) * (size_t)N);
-  w.ids = (int*)take(sizeof(int) * (size_t)N);
   w.ids_sorted = (int*)take(sizeof(int) * (size_t)N);
   w.bin_start = (int*)take(sizeof(int) * (size_t)(nbins + 1));
+  w.bin_fill = (int*)take(sizeof(int) * (size_t)(nbins + 1));
   w.count = (int*)take(sizeof(int) * (size_t)(N + 1));
   w.offset = (long*)take(sizeof(long) * (size_t)(N + 1));
   w.overflow = (int*)take(256);
@@ -349,8 +354,8 @@ void carve(void* workspace, int N, long nbins, NbrWork& w) {
 }
 
 size_t fixed_bytes(int N, long nbins) {
-  return align256(sizeof(double) * 3 * (size_t)N) + align256(sizeof(int) * 3 * (size_t)N) + 4 * align256(sizeof(int) * (size_t)N) +
-         align256(sizeof(int) * (size_t)(nbins + 1)) + align256(sizeof(int) * (size_t)(N + 1)) +
+  return align256(sizeof(double) * 3 * (size_t)N) + align256(sizeof(int) * 3 * (size_t)N) + 2 * align256(sizeof(int) * (size_t)N) +
+         2 * align256(sizeof(int) * (size_t)(nbins + 1)) + align256(sizeof(int) * (size_t)(N + 1)) +
          align256(sizeof(long) * (size_t)(N + 1)) + 256 + align256(sizeof(unsigned long long) * (size_t)N * kStash);
 }
 
@@ -391,18 +396,16 @@ extern "C" int hermnet_neighbor_count(const float* pos, int num_atoms, const dou
   NbrWork w;
   carve(workspace, N, 8l * N + 64, w);
   w.temp_bytes = workspace_bytes - (size_t)((char*)w.temp - (char*)workspace);
-  hipLaunchKernelGGL(nbr_bin_kernel, grid_for(N), dim3(kBlock), 0, s, pos, N, g, w.fw, w.wrap, w.bin, w.ids);
-  int bits = 1;
-  while (bits < 32 && (1l << bits) < nbins) ++bits;
-  size_t tb = w.temp_bytes;
-  if (hipcub::DeviceRadixSort::SortPairs(w.temp, tb, w.bin, w.bin_sorted, w.ids, w.ids_sorted, N, 0, bits, s) != hipSuccess)
-    return HN_ERR_LAUNCH;
-  hipLaunchKernelGGL(nbr_binstart_kernel, grid_for(nbins + 1), dim3(kBlock), 0, s, w.bin_sorted, N, (int)nbins, w.bin_start);
+  hipLaunchKernelGGL(nbr_bin_kernel, grid_for(N), dim3(kBlock), 0, s, pos, N, g, w.fw, w.wrap, w.bin);
+  hipLaunchKernelGGL(nbr_zero_kernel, grid_for(nbins + 1), dim3(kBlock), 0, s, w.bin_fill, nbins + 1);
+  hipLaunchKernelGGL(nbr_bin_hist_kernel, grid_for(N), dim3(kBlock), 0, s, w.bin, N, w.bin_fill);
+  if (exclusive_scan_i32(w.bin_fill, w.bin_start, (int)nbins + 1, w.temp, w.temp_bytes, s) != HN_OK) return HN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(nbr_zero_kernel, grid_for(nbins + 1), dim3(kBlock), 0, s, w.bin_fill, nbins + 1);
+  hipLaunchKernelGGL(nbr_bin_scatter_kernel, grid_for(N), dim3(kBlock), 0, s, w.bin, N, w.bin_start, w.bin_fill, w.ids_sorted);
   hipLaunchKernelGGL(nbr_clear_kernel, dim3(1), dim3(64), 0, s, w.count + N, w.overflow);
   hipLaunchKernelGGL(nbr_pairs_kernel<0>, grid_for((long)N * 64), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N,
                      g, (const long*)nullptr, w.count, w.stash, w.overflow, target_ok, g.periodic);
-  tb = w.temp_bytes;
-  if (hipcub::DeviceScan::ExclusiveSum(w.temp, tb, w.count, w.offset, N + 1, s) != hipSuccess) return HN_ERR_LAUNCH;
+  if (exclusive_scan_i32_to_long(w.count, w.offset, N + 1, w.temp, w.temp_bytes, s) != HN_OK) return HN_ERR_BAD_ARG;
   // total_device = (pairs found, flags of the pass)
   hipLaunchKernelGGL(nbr_total_kernel, dim3(1), dim3(64), 0, s, w.offset + N, w.overflow, total_device);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;

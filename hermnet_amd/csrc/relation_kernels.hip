@@ -98,10 +98,22 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const int* __restrict__ ke
   if (i < n) atomicAdd(&hist[key[i]], 1);
 }
 
+// `shared_key` (or -1): a key that many entries carry (the closing row of a padded list's NULL edges): its lanes take their
+// slots through ONE atomic per wave
 __global__ __launch_bounds__(kBlock) void scatter_kernel(const int* __restrict__ key, int n, int* __restrict__ cursor,
-                                                        int* __restrict__ slots) {
+                                                        int* __restrict__ slots, int shared_key) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) slots[atomicAdd(&cursor[key[i]], 1)] = i;
+  const int k = i < n ? key[i] : -2;
+  const unsigned long long same = __ballot(k == shared_key);
+  if (k == shared_key) {
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)same) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&cursor[k], __popcll(same));
+    base = __shfl(base, leader, 64);
+    slots[base + __popcll(same & ((1ull << lane) - 1ull))] = i;
+  } else if (i < n) {
+    slots[atomicAdd(&cursor[k], 1)] = i;
+  }
 }
 
 // one wave per group: out[rowptr[g] + rank(v)] = v, rank = number of smaller members (members are unique)
@@ -151,7 +163,7 @@ int group_by_key(const int* key, int n, int nkeys, int* rowptr, int* out, const 
   if (exclusive_scan_i32(w.cursor, rowptr, nkeys + 1, w.scan_temp, w.scan_bytes, s) != HN_OK) return HN_ERR_LAUNCH;
   if (n == 0) return HN_OK;
   hipLaunchKernelGGL(copy_i32_kernel, grid_for(nkeys), dim3(kBlock), 0, s, rowptr, nkeys, w.cursor);
-  hipLaunchKernelGGL(scatter_kernel, grid_for(n), dim3(kBlock), 0, s, key, n, w.cursor, w.slots);
+  hipLaunchKernelGGL(scatter_kernel, grid_for(n), dim3(kBlock), 0, s, key, n, w.cursor, w.slots, -1);
   hipLaunchKernelGGL(group_rank_sort_kernel, dim3((unsigned)((nkeys + 3) / 4)), dim3(kBlock), 0, s, rowptr, nkeys, w.slots, out);
   return HN_OK;
 }
@@ -167,13 +179,17 @@ __global__ __launch_bounds__(kBlock) void edge_keys_hist_kernel(const long* __re
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const long tgt = edge_index[(size_t)E + e];
+  // a NULL edge of a padded list (hermnet_neighbor_fill_padded): the counters' closing slots -- row N of the CSR
+  // counters, key (T+1) N of the CSC ones -- so that it lands behind every row and in no segment.  Thousands of them
+  // meet ONE counter: the wave adds its count once (an atomic per lane on one address costs ~10 ns each, serialised).
+  const unsigned long long nulls = __ballot(tgt < 0);
   if (tgt < 0) {
-    // a NULL edge of a padded list (hermnet_neighbor_fill_padded): the counters' closing slots -- row N of the CSR
-    // counters, key (T+1) N of the CSC ones -- so that it lands behind every row and in no segment
     key1[e] = N;
     key2[e] = (T + 1) * N;
-    atomicAdd(&hist[N], 1);
-    atomicAdd(&hist[N + 1 + (T + 1) * N], 1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)nulls) - 1) {
+      atomicAdd(&hist[N], __popcll(nulls));
+      atomicAdd(&hist[N + 1 + (T + 1) * N], __popcll(nulls));
+    }
     return;
   }
   const int rs = row_of_node[edge_index[e]], rt = row_of_node[tgt];
@@ -441,7 +457,7 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
     // (the scan wrote its offsets to rp_all; the scatters advance a copy: hist is reused for it)
     hipLaunchKernelGGL(copy_i32_kernel, grid_for((long)nall), dim3(kBlock), 0, s, rp_all, (int)nall, cursor);
     // CSR: edges grouped by row(target), ascending edge id inside a row
-    hipLaunchKernelGGL(scatter_kernel, grid_for(E), dim3(kBlock), 0, s, key1, E, cursor, slots);
+    hipLaunchKernelGGL(scatter_kernel, grid_for(E), dim3(kBlock), 0, s, key1, E, cursor, slots, N);
     hipLaunchKernelGGL(group_rank_sort_kernel, dim3((unsigned)((N + 3) / 4)), dim3(kBlock), 0, s, rp_all, N, slots, out->csr_perm);
     // CSC: CSR positions grouped by (relation(target), row(source)); edges to unknown-element targets fall into the extra
     // key range [T*N, (T+1)*N) and are simply not covered by csc_rowptr[0 .. T*N]
@@ -528,7 +544,7 @@ extern "C" int hermnet_build_triadic(const long* atomic_number, const long* edge
   }
   if (E > 0) {
     hipLaunchKernelGGL(copy_i32_kernel, grid_for((long)nall), dim3(kBlock), 0, s, rp_all, (int)nall, cursor);
-    hipLaunchKernelGGL(scatter_kernel, grid_for(E), dim3(kBlock), 0, s, key1, (int)E, cursor, slots);
+    hipLaunchKernelGGL(scatter_kernel, grid_for(E), dim3(kBlock), 0, s, key1, (int)E, cursor, slots, -1);
     hipLaunchKernelGGL(group_rank_sort_kernel, dim3((unsigned)((Nt + 3) / 4)), dim3(kBlock), 0, s, rp_all, (int)Nt, slots, perm_x);
     hipLaunchKernelGGL(tri_gather_scatter_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, shift, E0, (int)E, m,
                        out->row_of_node, perm_x, out->csr_perm, out->csr_src, out->src_id, out->tgt_id, out->shift_csr, rt_csr,

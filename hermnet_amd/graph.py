@@ -71,3 +71,82 @@ class GraphedStep(object):
                 self.pos.copy_(pos)
         self.graph.replay()
         return self.energy, self.forces
+
+
+class GraphedMDStep(object):
+    """energy, forces = step(pos) INCLUDING the neighbour search: cell list -> padded neighbour list -> relation build ->
+    forward -> force backward as ONE hipGraph launch that stays valid across list rebuilds (the
+    reference rebuilds its list on the host every step, `plugin/ase_interface/calculator.py:49`).
+
+    What makes the launch geometry independent of the edge count: the list is padded to `capacity` columns with NULL
+    edges that the relation build files behind every row (`neighbor.neighbor_search_padded`), and the search itself runs
+    without a host read, library sort or memset.  model: HVNet in eval(), parameters not requiring grad; one periodic
+    structure (atomic_number [N], cell [3,3], both on the GPU and unchanged for the life of the object; `pos` [N,3] gives
+    the first coordinates).  `capacity` defaults to the first list's edge count + 6 %.
+
+        step = GraphedMDStep(model, z, cell, pos0)
+        e, f = step(pos)            # static outputs: valid until the next call
+        ok, n_edges = step.check()  # a host read -- do it when e / f are copied to the host anyway; not ok: the list
+                                    # outgrew the capacity (or left the cell by > 8 images): `step.recapture(pos)`"""
+
+    def __init__(self, model, atomic_number, cell, pos, capacity=None, warmup=3):
+        from .neighbor import neighbor_search, padded_capacity
+        if not pos.is_cuda or cell is None:
+            raise RuntimeError("GraphedMDStep needs GPU tensors and a periodic cell")
+        if model.training:
+            raise RuntimeError("GraphedMDStep captures the eval() path")
+        self.model, self.z, self.cell = model, atomic_number, cell
+        self.batch = torch.zeros(atomic_number.numel(), dtype=torch.long, device=pos.device)
+        self.pos = pos.detach().clone().float().requires_grad_(True)      # static input
+        self._warmup = warmup
+        if capacity is None:
+            capacity = padded_capacity(int(neighbor_search(self.pos.detach(), model.rc, cell)[0].size(1)))
+        self._capture(int(capacity))
+
+    def _eager(self):
+        from .data import Data
+        from .neighbor import neighbor_search_padded
+        ei, sh, total = neighbor_search_padded(self.pos.detach(), self.model.rc, self.cell, self.capacity)
+        d = Data(pos=self.pos, atomic_number=self.z, batch=self.batch, cell=self.cell.reshape(1, 3, 3), edge_index=ei,
+                 edge_shift=sh)
+        d._hn_edge_count = total
+        e = self.model(d)
+        f = -torch.autograd.grad(e.sum(), self.pos)[0]
+        return e.detach(), f, total
+
+    def _capture(self, capacity):
+        self.capacity = capacity
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self._warmup):        # caches (cell on the host, element counts, row layout), library state
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.energy, self.forces, self.total = self._eager()
+        torch.cuda.synchronize()
+
+    def __call__(self, pos=None):
+        if pos is not None:
+            with torch.no_grad():
+                self.pos.copy_(pos)
+        self.graph.replay()
+        return self.energy, self.forces
+
+    def check(self):
+        """(list complete?, edges found) of the last call: one host read."""
+        from .neighbor import padded_list_ok
+        return padded_list_ok(self.total)
+
+    def recapture(self, pos=None, capacity=None):
+        """A new graph for a larger capacity (default: from the last edge count); returns the step's results."""
+        from .neighbor import padded_capacity
+        if pos is not None:
+            with torch.no_grad():
+                self.pos.copy_(pos)
+        if capacity is None:
+            capacity = padded_capacity(max(int(self.total[0]), self.capacity))
+        self._capture(int(capacity))
+        return self.__call__()

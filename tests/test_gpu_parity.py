@@ -1186,6 +1186,55 @@ def test_padded_neighbour_list_gives_the_exact_lists_results_bit_for_bit(case):
     assert not ok and found == E
 
 
+def test_md_step_with_list_rebuild_replays_as_one_graph():
+    """`GraphedMDStep`: neighbour search + relation build + forward + force backward captured ONCE, replayed along a random
+    walk on which the list changes (different edge counts), with eager steps and unrelated work in between; every replay
+    must equal the eager step on the exact list of the same coordinates bit for bit, and the list's edge count arrives
+    with the results.  A capacity that becomes too small is reported and repaired by a recapture."""
+    from hermnet_amd.graph import GraphedMDStep
+    dev = _dev()
+    pos, cell, z = synth.fcc_alloy_atoms(reps=(3, 3, 4))
+    pos_t = torch.from_numpy(pos.astype(np.float32)).to(dev)
+    cell_t = torch.from_numpy(cell.astype(np.float32)).to(dev)
+    z_t = torch.from_numpy(z).to(dev)
+    kw = dict(rc=5.0, num_layers=3, hidden_channels=128, num_rbf=64)
+    model = hn.HVNet(["Al", "Ni", "Cu"], **kw).eval()
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), 8))
+    model = model.to(dev)
+    for p_ in model.parameters():
+        p_.requires_grad_(False)
+    batch = torch.zeros(len(z), dtype=torch.long, device=dev)
+
+    def exact(p):
+        ei, sh = hn.neighbor_search(p, 5.0, cell_t)
+        d = hn.Data(pos=p.clone().requires_grad_(True), atomic_number=z_t, batch=batch, cell=cell_t.reshape(1, 3, 3),
+                    edge_index=ei, edge_shift=sh)
+        e = model(d)
+        return e.detach(), -torch.autograd.grad(e.sum(), d.pos)[0], int(ei.size(1))
+
+    step = GraphedMDStep(model, z_t, cell_t, pos_t)
+    gen = torch.Generator().manual_seed(2)
+    cur = pos_t.clone()
+    counts = set()
+    for it in range(12):
+        cur = cur + (0.25 * (torch.rand(cur.shape, generator=gen) - 0.5)).to(dev)
+        e, f = step(cur)
+        e, f = e.clone(), f.clone()
+        ok, n = step.check()
+        e0, f0, n0 = exact(cur)                                   # eager work between replays (memsets, sorts, ...)
+        torch.zeros(1 << 16, device=dev).sum()
+        assert ok and n == n0, (it, n, n0)
+        assert torch.equal(e, e0) and torch.equal(f, f0), it
+        counts.add(n)
+    assert len(counts) > 3                                        # the list really changed along the walk
+    small = GraphedMDStep(model, z_t, cell_t, pos_t, capacity=1024)
+    small(cur)
+    ok, n = small.check()
+    assert not ok and n == n0
+    e, f = small.recapture(cur)
+    assert small.check() == (True, n0) and torch.equal(e, e0) and torch.equal(f, f0)
+
+
 def test_calculator_builds_its_lists_without_a_host_read_after_the_first_call():
     """`NNCalculator.calculate` along a trajectory: the first call searches exactly (and learns a capacity), the following
     ones use padded lists checked behind the step; results equal a fresh calculator's exact evaluation of the same
