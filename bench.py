@@ -336,6 +336,31 @@ def graph_replay_secondary(hn, synth, dev, model, data, model_kw, steps=20):
                      "eager_ms_per_step_same_settings": t["eager"] * 1e3}
     res["note"] = ("one hipGraph launch per step (relation build + forward + force backward captured once); valid while "
                    "the neighbour list is unchanged; library-default GEMM solutions")
+    # the MD-style step -- neighbour search INCLUDED -- as one graph launch (graph.GraphedMDStep: padded list, no host read;
+    # the same graph stays valid when the list changes)
+    try:
+        from hermnet_amd.graph import GraphedMDStep
+        md = {}
+        for name, m, d in cases:
+            if d.get("cell") is None:
+                continue
+            cell = d.cell.reshape(3, 3)
+            g = GraphedMDStep(m, d.atomic_number, cell, d.pos.detach())
+            jitter = 0.01 * torch.randn_like(d.pos.detach())
+            for _ in range(3):
+                g()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                g(d.pos.detach() + (jitter if k & 1 else -jitter))       # (moving coordinates: the list is rebuilt anyway)
+            torch.cuda.synchronize()
+            dt_g = (time.perf_counter() - t0) / steps
+            ok, n_edges = g.check()
+            md[name] = {"ms_per_step": dt_g * 1e3, "atom_steps_per_s": d.pos.size(0) / dt_g, "capacity": g.capacity,
+                        "edges_found": n_edges, "list_complete": bool(ok)}
+        res["md_step_incl_neighbour_search_as_one_graph"] = md
+    except Exception as ex:
+        res["md_step_incl_neighbour_search_as_one_graph"] = {"error": repr(ex)}
     return res
 
 

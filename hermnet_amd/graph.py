@@ -82,7 +82,7 @@ class GraphedMDStep(object):
     edges that the relation build files behind every row (`neighbor.neighbor_search_padded`), and the search itself runs
     without a host read, library sort or memset.  model: HVNet in eval(), parameters not requiring grad; one periodic
     structure (atomic_number [N], cell [3,3], both on the GPU and unchanged for the life of the object; `pos` [N,3] gives
-    the first coordinates).  `capacity` defaults to the first list's edge count + 6 %.
+    the first coordinates).  `capacity` defaults to the first list's edge count + 4 %.
 
         step = GraphedMDStep(model, z, cell, pos0)
         e, f = step(pos)            # static outputs: valid until the next call

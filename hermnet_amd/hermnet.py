@@ -218,8 +218,9 @@ class HVNet(nn.Module):
         if fused and edge.requires_grad and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0":
             # one reduction of the edge gradients per step instead of one per layer (layer.EdgeFanout)
             # (atoms of an unknown element own the rows past type_rowptr[T]; only edges INTO them go unwritten)
-            # (... and the slots of a padded list's NULL edges: they are in no row)
-            all_known = graph.num_src == 0 and graph.N == graph.type_rowptr_host[-1] and not padded
+            # (the slots of a padded list's NULL edges stay unwritten too, but nothing reads them: the position gradient
+            # walks the CSC segments, and NULL edges are in none)
+            all_known = graph.num_src == 0 and graph.N == graph.type_rowptr_host[-1]
             data._hn_edge_sink = EdgeGradSink(len(self.hermconvs), Hp // 64, graph.E, pos.device, zero=not all_known)
             data._hn_edge_handles = EdgeFanout.apply(edge, data._hn_edge_sink)
         for li, conv in enumerate(self.hermconvs):

@@ -244,7 +244,7 @@ def padded_list_ok(total):
     return flags == 0, int(E)
 
 
-def padded_capacity(num_edges, margin=0.06, granule=4096):
+def padded_capacity(num_edges, margin=0.04, granule=4096):
     """A column count for the next steps' lists: the last count plus a margin, rounded up (a stable launch geometry)."""
     want = int(num_edges * (1.0 + margin)) + 64
     return (want + granule - 1) // granule * granule
