@@ -97,7 +97,7 @@ SIGNATURES = {
     "hermnet_node_update_fwd": (ctypes.c_int, [c_fp] * 16 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_node_update_bwd": (ctypes.c_int, [c_fp] * 14 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_pair_mean": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                         ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_fp]),
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_fp, ctypes.c_int, c_fp]),
     "hermnet_halo_rows": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "hermnet_halo_accumulate": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "hermnet_stream_copy": (ctypes.c_int, [c_fp, c_fp, ctypes.c_size_t, ctypes.c_int, c_fp]),

@@ -466,12 +466,18 @@ __global__ __launch_bounds__(256) void energy_head_fused_kernel(const float* __r
 template <int MODE>   // 0 FWD, 1 BWD, 2 ACC
 __global__ __launch_bounds__(256) void pair_mean_kernel(const float* __restrict__ xin, const float* __restrict__ vin,
                                                         float* __restrict__ xout, float* __restrict__ vout, int Te, int P,
-                                                        int B, int rows_out, int H, float sx, float sv) {
+                                                        int B, int rows_out, int H, float sx, float sv,
+                                                        const int* __restrict__ ranges, int num_ranges) {
   const int q4 = H;                                     // float4 per packed row of 4H floats
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long rows = MODE == 0 ? rows_out : (MODE == 1 ? (long)Te * P * B : (long)Te * B);
   if (i >= rows * q4) return;
   const long r = i / q4;
+  if (MODE == 2 && num_ranges > 0) {       // only the output rows of these [lo, hi) ranges (atom shards: two launches
+    bool in = false;                       // over complementary row ranges around the halo exchange)
+    for (int k = 0; k < num_ranges; ++k) in |= r >= ranges[2 * k] && r < ranges[2 * k + 1];
+    if (!in) return;
+  }
   const int c = (int)(i % q4) * 4;                     // in [0, 4H)
   const float sc = c < H ? sx : sv;
   auto at = [&](const float* x, const float* v, long row) {
@@ -670,9 +676,9 @@ extern "C" int hermnet_energy_head_fused_bwd(const float* ge, const float* h, co
 
 extern "C" int hermnet_pair_mean(int mode, const float* x_in, const float* vec_in, float* x_out, float* vec_out,
                                  int num_elem, int pairs, int block, int rows_out, int hidden, float scale_x,
-                                 float scale_vec, void* stream) {
+                                 float scale_vec, const int* row_ranges, int num_ranges, void* stream) {
   if (num_elem < 0 || pairs <= 0 || block < 0 || hidden <= 0 || (hidden & 3) || rows_out < (long)num_elem * block ||
-      mode < 0 || mode > 2)
+      mode < 0 || mode > 2 || num_ranges < 0 || (num_ranges > 0 && (!row_ranges || mode != 2)))
     return HN_ERR_BAD_ARG;
   const long rows = mode == 0 ? (long)rows_out : (mode == 1 ? (long)num_elem * pairs * block : (long)num_elem * block);
   if (rows == 0) return HN_OK;
@@ -680,9 +686,9 @@ extern "C" int hermnet_pair_mean(int mode, const float* x_in, const float* vec_i
   const dim3 grid = grid_for(rows * hidden, 256);
   hipStream_t s = (hipStream_t)stream;
   switch (mode) {
-    case 0: hipLaunchKernelGGL(pair_mean_kernel<0>, grid, dim3(256), 0, s, x_in, vec_in, x_out, vec_out, num_elem, pairs, block, rows_out, hidden, scale_x, scale_vec); break;
-    case 1: hipLaunchKernelGGL(pair_mean_kernel<1>, grid, dim3(256), 0, s, x_in, vec_in, x_out, vec_out, num_elem, pairs, block, rows_out, hidden, scale_x, scale_vec); break;
-    default: hipLaunchKernelGGL(pair_mean_kernel<2>, grid, dim3(256), 0, s, x_in, vec_in, x_out, vec_out, num_elem, pairs, block, rows_out, hidden, scale_x, scale_vec); break;
+    case 0: hipLaunchKernelGGL(pair_mean_kernel<0>, grid, dim3(256), 0, s, x_in, vec_in, x_out, vec_out, num_elem, pairs, block, rows_out, hidden, scale_x, scale_vec, (const int*)nullptr, 0); break;
+    case 1: hipLaunchKernelGGL(pair_mean_kernel<1>, grid, dim3(256), 0, s, x_in, vec_in, x_out, vec_out, num_elem, pairs, block, rows_out, hidden, scale_x, scale_vec, (const int*)nullptr, 0); break;
+    default: hipLaunchKernelGGL(pair_mean_kernel<2>, grid, dim3(256), 0, s, x_in, vec_in, x_out, vec_out, num_elem, pairs, block, rows_out, hidden, scale_x, scale_vec, row_ranges, num_ranges); break;
   }
   HN_LAUNCH_END;
 }

@@ -39,8 +39,8 @@ class HeteroVertexConv(nn.Module):
                 self._weights = LayerWeights(self.mods.values())
             w = self._weights.refresh()
         # (default ON: HERMNET_HALO_OVERLAP=0 runs the blocking exchange in front of the layer instead; the overlapped
-        # form needs the chain kernels, HVNet's single row space and the channel-per-lane backward, which takes row ranges)
-        if halo is not None and not (w is not None and w.chain and _node_chain_enabled() and g.num_src == 0
+        # form needs the chain kernels and the channel-per-lane backward, which takes row ranges)
+        if halo is not None and not (w is not None and w.chain and _node_chain_enabled()
                                      and halo.fwd_early is not None and g.N * 3 * data.x.size(1) * 4 < 2 ** 32
                                      # (a rank that neither sends nor receives joins the collective in its plain form:
                                      # nothing to hide, and the asynchronous form costs ~15 us of stream hand-offs)

@@ -181,6 +181,26 @@ def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True, r
     return gxh, gvec, gx
 
 
+def _virtual_residual(graph, gx1, gvec1, gx_in, gvec_in, H, ranges=None):
+    """HTNet: the residual (rmnet.py:24-26) reads the atom's own row from each of its P virtual target rows; its gradient
+    returns as the sum over those rows (the message backward adds no identity term with virtual targets).  `ranges`
+    (device [k,2], host list): only these source rows (the ranged launches of the halo overlap)."""
+    if not graph.num_src:
+        return
+    P_, B_, Te = graph.triadic_pairs, graph.block, graph.T // graph.triadic_pairs
+    if gx_in.is_cuda and gvec_in is not None:
+        nodeops.pair_sum_accumulate(gx1, gvec1, gx_in, gvec_in, Te, P_, B_, 0.5 ** 0.5, 1.0, ranges=ranges)
+        return
+    sel = slice(0, Te * B_)
+    if ranges is not None:
+        sel = torch.zeros(Te * B_, dtype=torch.bool)
+        for lo, hi in ranges[1]:
+            sel[lo:min(hi, Te * B_)] = True
+    gx_in[:Te * B_][sel] += (gx1.view(Te, P_, B_, H).sum(1).reshape(Te * B_, H) * (0.5 ** 0.5))[sel]
+    if gvec_in is not None:
+        gvec_in[:Te * B_][sel] += gvec1.view(Te, P_, B_, 3, H).sum(1).reshape(Te * B_, 3, H)[sel]
+
+
 class EdgeGradSink(object):
     """One buffer [layers, H/64, E, 4] for the edge gradients of a whole step: every layer's backward kernel
     writes its slice, and `EdgeFanout.backward` reduces all slices in ONE pass (instead of a zero-fill, a
@@ -263,14 +283,14 @@ class FusedRelationalLayer(torch.autograd.Function):
                 if _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":
                     # (tests: nothing that runs before the unpack may depend on a halo row)
                     nodeops.halo_rows(2, x, vec, plan.recv_idx, torch.full_like(recv, float("nan")))
-                hb, xh, mean, rstd = pre = nodeops.node_pre_fwd(x, w, T)
+                hb, xh, mean, rstd = pre = nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges)
                 x1, vec1 = out = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False, ranges=halo.fwd_early,
                                           zero_unknown=True, range_rows=halo.early_rows)
                 if work is not None:
                     work.wait()
                 if plan.recv_idx.numel() > 0:  # (a rank without halo atoms has nothing to redo)
                     nodeops.halo_rows(2, x, vec, plan.recv_idx, recv)
-                    nodeops.node_pre_fwd(x, w, T, windows=halo.windows, mode=1, out=pre)
+                    nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges, windows=halo.windows, mode=1, out=pre)
                 if halo.late_rows > 0:
                     _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False, ranges=halo.fwd_late, zero_unknown=False,
                              out=out, range_rows=halo.late_rows)
@@ -384,7 +404,9 @@ class FusedRelationalLayer(torch.autograd.Function):
             if halo.bwd_first[1]:
                 bufs = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=False, ranges=halo.bwd_first)
                 gxh, gvec_in, gx_in, _ = bufs
-                out = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, windows=halo.windows, mode=1)
+                _virtual_residual(graph, gx1, gvec1, gx_in, gvec_in, H, halo.bwd_first)
+                out = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, src_ranges=graph.src_ranges,
+                                           windows=halo.windows, mode=1)
                 gsend = nodeops.halo_rows(1, out[0], gvec_in, plan.recv_idx)           # pack and clear: none stays here
             else:                                                                   # (a rank without halo atoms)
                 out = None
@@ -393,8 +415,10 @@ class FusedRelationalLayer(torch.autograd.Function):
             if halo.bwd_rest[1]:
                 bufs = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=False, ranges=halo.bwd_rest,
                                 out=bufs)
+                _virtual_residual(graph, gx1, gvec1, bufs[2], bufs[1], H, halo.bwd_rest)
             gxh, gvec_in, gx_in, _ = bufs
-            res = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, windows=halo.windows, mode=2, out=out)
+            res = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, src_ranges=graph.src_ranges,
+                                       windows=halo.windows, mode=2, out=out)
             gx_total = res[0]
             if work is not None:
                 work.wait()
@@ -402,16 +426,7 @@ class FusedRelationalLayer(torch.autograd.Function):
             ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
             return gx_total, gvec_in, ge, None, None, None, None, None, None
         gxh, gvec_in, gx_in = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=not ctx.chain)
-        if graph.num_src:
-            # HTNet: the residual (rmnet.py:24-26) reads the atom's own row from each of its P virtual target rows;
-            # its gradient returns as the sum over those rows (the kernel adds no identity term in this mode)
-            P_, B_, Te = graph.triadic_pairs, graph.block, graph.T // graph.triadic_pairs
-            if gx_in.is_cuda and gvec_in is not None:
-                nodeops.pair_sum_accumulate(gx1, gvec1, gx_in, gvec_in, Te, P_, B_, 0.5 ** 0.5, 1.0)
-            else:
-                gx_in[:Te * B_] += gx1.view(Te, P_, B_, H).sum(1).reshape(Te * B_, H) * (0.5 ** 0.5)
-                if gvec_in is not None:
-                    gvec_in[:Te * B_] += gvec1.view(Te, P_, B_, 3, H).sum(1).reshape(Te * B_, 3, H)
+        _virtual_residual(graph, gx1, gvec1, gx_in, gvec_in, H)
         gx_total = None
         if ctx.needs_input_grad[0]:
             if ctx.chain:

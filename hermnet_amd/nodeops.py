@@ -131,17 +131,18 @@ def pair_mean(x, vec, Te, P_, B, rows_out, backward=False):
     xo = torch.empty(rows, H, dtype=x.dtype, device=x.device)
     vo = torch.empty(rows, 3, H, dtype=x.dtype, device=x.device)
     _lib.check(_launch("pair_mean", lambda: _lib.load().hermnet_pair_mean(
-        1 if backward else 0, P(x), P(vec), P(xo), P(vo), Te, P_, B, rows_out, H, 1.0 / P_, 1.0 / P_, _stream())),
+        1 if backward else 0, P(x), P(vec), P(xo), P(vo), Te, P_, B, rows_out, H, 1.0 / P_, 1.0 / P_, None, 0, _stream())),
         "hermnet_pair_mean")
     return xo, vo
 
 
-def pair_sum_accumulate(x, vec, x_acc, vec_acc, Te, P_, B, scale_x, scale_vec):
+def pair_sum_accumulate(x, vec, x_acc, vec_acc, Te, P_, B, scale_x, scale_vec, ranges=None):
     """x_acc[c*B + i] += scale_x * sum_k x[(c*P + k)*B + i] (and vec likewise): the residual's gradient of HTNet's virtual
-    target rows, one launch."""
+    target rows, one launch.  `ranges` = (device [k,2] int32, host list): only these rows of x_acc / vec_acc."""
     H = x.size(1)
+    rd, nr = (None, 0) if ranges is None else (ranges[0], len(ranges[1]))
     _lib.check(_launch("pair_sum", lambda: _lib.load().hermnet_pair_mean(
-        2, P(x), P(vec), P(x_acc), P(vec_acc), Te, P_, B, x_acc.size(0), H, scale_x, scale_vec, _stream())),
+        2, P(x), P(vec), P(x_acc), P(vec_acc), Te, P_, B, x_acc.size(0), H, scale_x, scale_vec, P(rd), nr, _stream())),
         "hermnet_pair_mean")
 
 

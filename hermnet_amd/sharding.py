@@ -337,22 +337,34 @@ class ShardPlan(object):
         T + 1 halo windows when it is made).  `tile_rows`: rows per tile of the node pre kernels at the model's width."""
         plan = self.row_plan(graph.row_of_node)
         if self._row_plan[2] is None or self._row_plan[2].tile_rows != tile_rows:
-            win = HaloOverlap.row_windows(plan.recv_idx, graph.type_rowptr, graph.N)
+            dev = graph.row_of_node.device
+            if graph.num_src:      # HTNet: the exchange and the node projection live in SOURCE rows (blocks of B rows per
+                Te, B = graph.T // graph.triadic_pairs, graph.block          # element), the messages land in virtual rows
+                src_rowptr = torch.arange(Te + 1, dtype=torch.int32, device=dev) * B
+                n_src = graph.num_src
+            else:
+                src_rowptr, n_src = graph.type_rowptr, graph.N
+            win = HaloOverlap.row_windows(plan.recv_idx, src_rowptr, n_src)
             ov = HaloOverlap(plan, win)
             ov.tile_rows = tile_rows
-            if graph.num_src == 0:
+            if True:
                 late = self.late_local
                 if late is None:                  # no classification: every owned atom may read a halo row
-                    late = torch.ones(graph.row_of_node.numel(), dtype=torch.bool, device=graph.row_of_node.device)
+                    late = torch.ones(graph.row_of_node.numel(), dtype=torch.bool, device=dev)
                 if plan.recv_idx.numel() == 0:    # no halo atom here: nothing is late (the rank still joins the exchange)
                     late = torch.zeros_like(late)
                 late_rows = graph.row_of_node.index_select(0, torch.nonzero(late).reshape(-1))
+                if graph.num_src:                 # a late atom is late in every pair relation of its element
+                    P_ = graph.triadic_pairs
+                    c, ii = late_rows // B, late_rows % B
+                    k = torch.arange(P_, device=dev)
+                    late_rows = ((c[:, None] * P_ + k[None, :]) * B + ii[:, None]).reshape(-1)
+                    late_rows = late_rows[c.repeat_interleave(P_) < Te]          # (atoms of unlisted elements: no target rows)
                 ov.fwd_early, ov.fwd_late = HaloOverlap.target_ranges(late_rows, graph.type_rowptr)
                 el = torch.stack([ov.fwd_early, ov.fwd_late]).cpu()          # (one more small host read per plan)
                 ov.early_rows = int((el[0, :, 1] - el[0, :, 0]).clamp(min=0).sum())
                 ov.late_rows = int((el[1, :, 1] - el[1, :, 0]).clamp(min=0).sum())
-                ov.bwd_first, ov.bwd_rest = HaloOverlap.source_ranges(win.cpu().tolist(), tile_rows, graph.N,
-                                                                      graph.row_of_node.device)
+                ov.bwd_first, ov.bwd_rest = HaloOverlap.source_ranges(win.cpu().tolist(), tile_rows, n_src, dev)
             self._row_plan = self._row_plan[:2] + (ov,)
         return self._row_plan[2]
 

@@ -404,9 +404,12 @@ int hermnet_node_update_bwd(const float* gx_out, const float* gvec_out, const fl
  *   mode 1:  x_out / vec_out [num_elem*pairs*block, ...] = the gradient w.r.t. the virtual rows: scale * in[c*block + i]
  *            (x_in / vec_in then hold the [rows_out, ...] gradient)
  *   mode 2:  as mode 0 for the rows < num_elem*block, ACCUMULATED into x_out / vec_out (the residual's gradient summed
- *            over a centre's virtual rows: scale_x = 1/sqrt(2), scale_vec = 1, rmnet.py:24-26). */
+ *            over a centre's virtual rows: scale_x = 1/sqrt(2), scale_vec = 1, rmnet.py:24-26).  row_ranges (ABI v7;
+ *            device [num_ranges][2] int32, 0 = every row; mode 2 only): only the output rows of these ranges (atom
+ *            shards: the message backward runs in two launches over complementary source-row ranges). */
 int hermnet_pair_mean(int mode, const float* x_in, const float* vec_in, float* x_out, float* vec_out, int num_elem,
-                      int pairs, int block, int rows_out, int hidden, float scale_x, float scale_vec, void* stream);
+                      int pairs, int block, int rows_out, int hidden, float scale_x, float scale_vec,
+                      const int* row_ranges, int num_ranges, void* stream);
 
 /* ---- the training step's per-edge message algebra (rmnet.py:58-66 inside example/dist_train.py:86-99, where the
  * forces are differentiated w.r.t. the parameters: every op needs a second derivative).  ABI v6; csrc/train_kernels.hip.
