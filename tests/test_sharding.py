@@ -547,8 +547,19 @@ def _gpu_slab_worker(rank, world, reps, port, out, overlap, kind="hvnet"):
         z_t = torch.from_numpy(z).to(dev)
         local, plan = partition_slab(pos_t, z_t, cell_t, 5.0, rank, world)
         local.pos.requires_grad_(True)
+        # (count the message launches that cover a row range: the overlapped exchange is really taken, by both models)
+        import hermnet_amd.layer as lmod
+        ranged = {"n": 0}
+        inner_fwd = lmod._msg_fwd
+
+        def counting_fwd(*a, **k):
+            ranged["n"] += 1 if k.get("ranges") is not None else 0
+            return inner_fwd(*a, **k)
+        lmod._msg_fwd = counting_fwd
         e = model(local)
         f_local = -torch.autograd.grad(e.sum(), local.pos)[0]
+        lmod._msg_fwd = inner_fwd
+        assert (ranged["n"] > 0) == (overlap == "1"), (overlap, kind, ranged)
         res = dict(e=e.detach().cpu().numpy(), owned=plan.owned_global.cpu().numpy(),
                    f=f_local[plan.owned_local].cpu().numpy(), nhalo=int(plan.halo_global.numel()),
                    nlocal=int(local.pos.size(0)), edges=int(local.edge_index.size(1)))
