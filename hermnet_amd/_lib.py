@@ -51,6 +51,7 @@ SIGNATURES = {
                                                    c_fp, c_fp, ctypes.c_int, c_fp]),
     "hermnet_edge_radial_table": (ctypes.c_int, [ctypes.POINTER(Graph), ctypes.POINTER(RbfDesc), c_fp, c_fp, c_fp]),
     "hermnet_neighbor_workspace": (ctypes.c_size_t, [ctypes.c_int]),
+    "hermnet_neighbor_workspace_for": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "hermnet_neighbor_count": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_double, c_fp,
                                               ctypes.c_size_t, c_fp, c_fp, c_fp]),
     "hermnet_neighbor_fill": (ctypes.c_int, [c_fp, ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_double, c_fp, ctypes.c_size_t,

@@ -111,7 +111,8 @@ __global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restr
                                                           const long* __restrict__ offset, int* __restrict__ count,
                                                           unsigned long long* __restrict__ keys,
                                                           int* __restrict__ overflow,
-                                                          const unsigned char* __restrict__ target_ok, int target_is_j) {
+                                                          const unsigned char* __restrict__ target_ok, int target_is_j,
+                                                          int stash) {
   // one WAVE per atom: the lanes share the candidates of a bin (one atom per thread left the chip at 40 workgroups
   // for 10k atoms, each thread walking ~200 candidates serially: 0.2 ms per pass)
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restr
     bi[k] = bk < 0 ? 0 : (bk >= g.nbins[k] ? g.nbins[k] - 1 : bk);
   }
   constexpr bool FILL = MODE == 1;
-  long out = FILL ? offset[i] : (long)i * kStash;
+  long out = FILL ? offset[i] : (long)i * stash;
   int n = 0;
   for (int ox = -g.reach[0]; ox <= g.reach[0]; ++ox)
     for (int oy = -g.reach[1]; oy <= g.reach[1]; ++oy)
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restr
             // position inside the atom's key range: hits of earlier lanes first (the keys are sorted afterwards,
             // so only "each slot written once" matters)
             const int slot = __popcll(m & ((1ull << lane) - 1ull));
-            if (FILL || n + slot < kStash)
+            if (FILL || n + slot < stash)
               keys[out + slot] = ((unsigned long long)i * (unsigned long long)N + (unsigned long long)j) *
                                      (unsigned long long)(kCode * kCode * kCode) + code;
           }
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void nbr_pairs_kernel(const double* __restr
       }
   if (!FILL && lane == 0) {
     count[i] = n;
-    if (n > kStash) atomicOr(overflow, 2);
+    if (n > stash) atomicOr(overflow, 2);
   }
 }
 
@@ -337,7 +338,7 @@ int make_geom(const double* cell_host, const double* lo_host, const double* hi_h
   return HN_OK;
 }
 
-void carve(void* workspace, int N, long nbins, NbrWork& w) {
+void carve(void* workspace, int N, long nbins, int stash, NbrWork& w) {
   char* p = reinterpret_cast<char*>(workspace);
   auto take = [&](size_t bytes) { void* r = p; p += align256(bytes); return r; };
   w.fw = (double*)take(sizeof(double) * 3 * (size_t)N);
@@ -349,23 +350,47 @@ void carve(void* workspace, int N, long nbins, NbrWork& w) {
   w.count = (int*)take(sizeof(int) * (size_t)(N + 1));
   w.offset = (long*)take(sizeof(long) * (size_t)(N + 1));
   w.overflow = (int*)take(256);
-  w.stash = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)N * kStash);
+  w.stash = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)N * stash);
   w.temp = p;
 }
 
-size_t fixed_bytes(int N, long nbins) {
+size_t fixed_bytes(int N, long nbins, int stash) {
   return align256(sizeof(double) * 3 * (size_t)N) + align256(sizeof(int) * 3 * (size_t)N) + 2 * align256(sizeof(int) * (size_t)N) +
          2 * align256(sizeof(int) * (size_t)(nbins + 1)) + align256(sizeof(int) * (size_t)(N + 1)) +
-         align256(sizeof(long) * (size_t)(N + 1)) + 256 + align256(sizeof(unsigned long long) * (size_t)N * kStash);
+         align256(sizeof(long) * (size_t)(N + 1)) + 256 + align256(sizeof(unsigned long long) * (size_t)N * stash);
+}
+
+size_t workspace_for(int num_atoms, int stash) {
+  // the bin grid is coarsened to at most 8 bins per atom
+  const long nbins = 8l * (num_atoms > 0 ? num_atoms : 1) + 64;
+  return fixed_bytes(num_atoms, nbins, stash) + align256(temp_bytes_for(num_atoms > 0 ? num_atoms : 1)) + 512;
+}
+
+// the per-atom stash slot a workspace of this size provides: the largest value <= kStash whose workspace fits
+// (both calls of a search derive it from the same (num_atoms, workspace_bytes), so they agree)
+int stash_of(int num_atoms, size_t workspace_bytes) {
+  int lo = 0, hi = kStash;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) / 2;
+    if (workspace_for(num_atoms, mid) <= workspace_bytes) lo = mid; else hi = mid - 1;
+  }
+  return lo;
 }
 
 }  // namespace
 
-extern "C" size_t hermnet_neighbor_workspace(int num_atoms) {
-  // the bin grid is coarsened to at most 8 bins per atom
-  const long nbins = 8l * (num_atoms > 0 ? num_atoms : 1) + 64;
-  return fixed_bytes(num_atoms, nbins) + align256(temp_bytes_for(num_atoms > 0 ? num_atoms : 1)) + 512;
+extern "C" size_t hermnet_neighbor_workspace(int num_atoms) { return workspace_for(num_atoms, kStash); }
+extern "C" size_t hermnet_neighbor_workspace_for(int num_atoms, int stash_per_atom) {
+  const int st = stash_per_atom < 8 ? 8 : (stash_per_atom > kStash ? kStash : stash_per_atom);
+  return workspace_for(num_atoms, st);
 }
+
+namespace {
+int stash_checked(int num_atoms, size_t workspace_bytes) {
+  const int st = stash_of(num_atoms, workspace_bytes);
+  return st >= 8 ? st : 0;
+}
+}  // namespace
 
 extern "C" int hermnet_neighbor_count(const float* pos, int num_atoms, const double* cell_host,
                                       const double* lo_host, const double* hi_host, double rc,
@@ -392,9 +417,10 @@ extern "C" int hermnet_neighbor_count(const float* pos, int num_atoms, const dou
       nbins = (long)g.nbins[0] * g.nbins[1] * g.nbins[2];
     }
   }
-  if (workspace_bytes < fixed_bytes(N, nbins) + 512) return HN_ERR_BAD_ARG;
+  const int stash = stash_checked(N, workspace_bytes);
+  if (stash == 0) return HN_ERR_BAD_ARG;
   NbrWork w;
-  carve(workspace, N, 8l * N + 64, w);
+  carve(workspace, N, 8l * N + 64, stash, w);
   w.temp_bytes = workspace_bytes - (size_t)((char*)w.temp - (char*)workspace);
   hipLaunchKernelGGL(nbr_bin_kernel, grid_for(N), dim3(kBlock), 0, s, pos, N, g, w.fw, w.wrap, w.bin);
   hipLaunchKernelGGL(nbr_zero_kernel, grid_for(nbins + 1), dim3(kBlock), 0, s, w.bin_fill, nbins + 1);
@@ -404,7 +430,7 @@ extern "C" int hermnet_neighbor_count(const float* pos, int num_atoms, const dou
   hipLaunchKernelGGL(nbr_bin_scatter_kernel, grid_for(N), dim3(kBlock), 0, s, w.bin, N, w.bin_start, w.bin_fill, w.ids_sorted);
   hipLaunchKernelGGL(nbr_clear_kernel, dim3(1), dim3(64), 0, s, w.count + N, w.overflow);
   hipLaunchKernelGGL(nbr_pairs_kernel<0>, grid_for((long)N * 64), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N,
-                     g, (const long*)nullptr, w.count, w.stash, w.overflow, target_ok, g.periodic);
+                     g, (const long*)nullptr, w.count, w.stash, w.overflow, target_ok, g.periodic, stash);
   if (exclusive_scan_i32_to_long(w.count, w.offset, N + 1, w.temp, w.temp_bytes, s) != HN_OK) return HN_ERR_BAD_ARG;
   // total_device = (pairs found, flags of the pass)
   hipLaunchKernelGGL(nbr_total_kernel, dim3(1), dim3(64), 0, s, w.offset + N, w.overflow, total_device);
@@ -418,10 +444,12 @@ extern "C" int hermnet_neighbor_fill_padded(int num_atoms, void* workspace, size
   if (N <= 0 || capacity <= 0 || capacity > 0x7fffffffl || !workspace || !edge_index || !total_device) return HN_ERR_BAD_ARG;
   if ((double)N * N * 4913.0 >= 1.8e19) return HN_ERR_BAD_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int stash = stash_checked(N, workspace_bytes);
+  if (stash == 0) return HN_ERR_BAD_ARG;
   NbrWork w;
-  carve(workspace, N, 8l * N + 64, w);
+  carve(workspace, N, 8l * N + 64, stash, w);
   // the stashed keys of the counting pass, rank-sorted per atom, into the first `capacity` columns ...
-  hipLaunchKernelGGL(nbr_sort_decode_kernel, grid_for((long)N * 64), dim3(kBlock), 0, s, w.stash, kStash, w.count, w.offset, N,
+  hipLaunchKernelGGL(nbr_sort_decode_kernel, grid_for((long)N * 64), dim3(kBlock), 0, s, w.stash, stash, w.count, w.offset, N,
                      capacity, shift_sign, source_first, edge_index, edge_shift);
   // ... NULL edges behind them, and the count + flags for whoever reads them (the host: at the END of the step)
   hipLaunchKernelGGL(nbr_pad_kernel, grid_for(capacity), dim3(kBlock), 0, s, w.offset, w.overflow, N, capacity, edge_index,
@@ -453,14 +481,16 @@ extern "C" int hermnet_neighbor_fill(const float* pos, int num_atoms, const doub
     g.nbins[kmax] = nb;
     nbins = (long)g.nbins[0] * g.nbins[1] * g.nbins[2];
   }
+  const int stash = stash_checked(N, workspace_bytes);
+  if (stash == 0) return HN_ERR_BAD_ARG;
   NbrWork w;
-  carve(workspace, N, 8l * N + 64, w);
+  carve(workspace, N, 8l * N + 64, stash, w);
   w.temp_bytes = workspace_bytes - (size_t)((char*)w.temp - (char*)workspace);
   if (!stash_ok)    // an atom had more pairs than its stash slot: second pass over the candidates into `keys`
     hipLaunchKernelGGL(nbr_pairs_kernel<1>, grid_for((long)N * 64), dim3(kBlock), 0, s, w.fw, w.wrap, w.ids_sorted, w.bin_start, N,
-                       g, w.offset, (int*)nullptr, keys, w.overflow, target_ok, g.periodic);
+                       g, w.offset, (int*)nullptr, keys, w.overflow, target_ok, g.periodic, 0);
   hipLaunchKernelGGL(nbr_sort_decode_kernel, grid_for((long)N * 64), dim3(kBlock), 0, s,
-                     stash_ok ? w.stash : keys, stash_ok ? kStash : 0, w.count, w.offset, N, num_edges, shift_sign,
+                     stash_ok ? w.stash : keys, stash_ok ? stash : 0, w.count, w.offset, N, num_edges, shift_sign,
                      source_first, edge_index, edge_shift);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }

@@ -149,6 +149,21 @@ def _cell_on_host(cell):
     return vals
 
 
+_STASH = {}       # device -> keys per atom of the search's stash slot (csrc/neighbor_kernels.hip)
+_STASH_DEFAULT = 96       # fcc at rc = 5 A: 43 pairs per atom; 8 bytes per key and atom of workspace
+
+
+def _stash_workspace_bytes(lib, N, dev):
+    """Workspace of a search whose per-atom stash slot holds the current hint of this device (the slot size follows from
+    the workspace size: include/hermnet_hip.h, hermnet_neighbor_workspace_for)."""
+    return lib.hermnet_neighbor_workspace_for(N, _STASH.get(str(dev), _STASH_DEFAULT))
+
+
+def _stash_overflowed(dev):
+    """An atom had more pairs than its slot (flag bit 1): the following searches get the largest slot."""
+    _STASH[str(dev)] = 160
+
+
 def _neighbor_search_device(pos, rc, cell, reference_compat, target_mask=None):
     """Device cell list (`csrc/neighbor_kernels.hip`); same result as the host path, tensors stay on the GPU.
     `target_mask` [N] bool/uint8: list only the pairs whose target atom (row 1) is flagged (atom shards)."""
@@ -175,12 +190,14 @@ def _neighbor_search_device(pos, rc, cell, reference_compat, target_mask=None):
         mask = mask.contiguous()
         if mask.numel() != N or mask.device != dev:
             raise ValueError("target_mask must be [N] on the device of pos")
-    ws_bytes = lib.hermnet_neighbor_workspace(N)
+    ws_bytes = _stash_workspace_bytes(lib, N, dev)
     work = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     total = torch.zeros(2, dtype=torch.long, device=dev)
     args = (P(p32), N, cell_h, lo_h, hi_h, float(rc), P(work), ws_bytes)
     _lib.check(lib.hermnet_neighbor_count(*args, P(mask), P(total), stream), "hermnet_neighbor_count")
     E, flags = total.tolist()                                # the one host read of the search
+    if flags & 2:
+        _stash_overflowed(dev)                               # (this search finishes in its two-pass form)
     if flags & 1:                                            # an image shift beyond +-8 cells: the host path handles it
         return None
     edge_index = torch.empty(2, E, dtype=torch.long, device=dev)
@@ -224,7 +241,7 @@ def neighbor_search_padded(pos, rc, cell, capacity, reference_compat=False):
     else:       # (an open system's bounding box is a host read of its own: periodic cells are the MD case)
         mm = torch.stack([p32.min(0).values, p32.max(0).values]).double().cpu().tolist()
         lo_h, hi_h = dbl3(*mm[0]), dbl3(*mm[1])
-    ws_bytes = lib.hermnet_neighbor_workspace(N)
+    ws_bytes = _stash_workspace_bytes(lib, N, dev)
     work = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     total = torch.empty(2, dtype=torch.long, device=dev)
     edge_index = torch.empty(2, cap, dtype=torch.long, device=dev)
@@ -241,6 +258,8 @@ def neighbor_search_padded(pos, rc, cell, capacity, reference_compat=False):
 def padded_list_ok(total):
     """(complete?, E) of a padded list from its `total` tensor -- a host read: do it behind the step."""
     E, flags = total.tolist()
+    if flags & 2:
+        _stash_overflowed(total.device)           # an atom had more pairs than its stash slot: the repeat gets a larger one
     return flags == 0, int(E)
 
 

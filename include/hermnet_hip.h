@@ -112,7 +112,11 @@ typedef struct hn_graph {
 int hermnet_neighbor_fill_padded(int num_atoms, void* workspace, size_t workspace_bytes, long capacity, float shift_sign,
                                  int source_first, long* edge_index /* [2, capacity] */, float* edge_shift /* [capacity, 3] */,
                                  long* total_device /* [2] */, void* stream);
-size_t hermnet_neighbor_workspace(int num_atoms);
+size_t hermnet_neighbor_workspace(int num_atoms);      /* with the largest stash slot (160 keys per atom: 1.3 kB/atom) */
+/* ... or with a smaller one (8 .. 160 keys per atom): every call of a search derives the slot size from the workspace
+ * size it is handed, so the workspace a caller allocates decides it.  An atom with more pairs than the slot holds sets
+ * flag bit 1: the exact search then takes its two-pass form, the padded one must be repeated with a larger slot. */
+size_t hermnet_neighbor_workspace_for(int num_atoms, int stash_per_atom);
 int hermnet_neighbor_count(const float* pos, int num_atoms, const double* cell_host, const double* lo_host,
                            const double* hi_host, double rc, void* workspace, size_t workspace_bytes,
                            const unsigned char* target_ok, long* total_device /* [2] */, void* stream);
