@@ -58,6 +58,25 @@ def main():
             len(uniq), len(st), dict(zip(*np.unique(cnt, return_counts=True)))))
         for k, nm in enumerate(NAMES[name]):
             print("   %-24s mean %7d  max %7d" % (nm, d[:, k].mean(), d[:, k].max()))
+        # co-resident pairs: do the two workgroups of a CU walk through their matrix phases in lockstep?
+        gemm = [k for k, nm in enumerate(NAMES[name]) if nm.startswith("GEMM")]
+        slot = (raw & np.uint64(0xf)).astype(np.int64)
+        offs, share, slots = [], [], []
+        for u in uniq[cnt == 2]:
+            a_, b_ = np.nonzero(key == u)[0]
+            if st[a_, 0] > st[b_, 0]:
+                a_, b_ = b_, a_
+            offs.append(st[b_, 0] - st[a_, 0])
+            ia = [(st[a_, k], st[a_, k + 1]) for k in gemm]
+            ib = [(st[b_, k], st[b_, k + 1]) for k in gemm]
+            both = sum(max(0, min(x1_, y1_) - max(x0_, y0_)) for x0_, x1_ in ia for y0_, y1_ in ib)
+            share.append(both / max(1, sum(x1_ - x0_ for x0_, x1_ in ia)))
+            slots.append((int(slot[a_]), int(slot[b_])))
+        if offs:
+            print("   CUs with two workgroups: start offset mean %d max %d cycles; share of the first one's matrix phases during "
+                  "which the second is in a matrix phase too: mean %.2f; wave slots of wave 0 (first, second): %s" % (
+                      np.mean(offs), np.max(offs), np.mean(share), dict(zip(*np.unique(np.array(slots), axis=0, return_counts=True))) if False else
+                      sorted(set(slots))[:6]))
 
 
 if __name__ == "__main__":
