@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
   const float* As = tile + mrow * LD + ch;
   f32x16 acc1[RB][CPW];
   bias_acc(acc1, bias1);
-  mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, false), false>(acc1, As, bp1, r1);
+  mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, false), false, HN_PIN_PRE>(acc1, As, bp1, r1);
   STAMP(3);
   BRing<3 * CPW, ring_size(RB * 3 * CPW, false)> r2;
   b_preload(r2, bp2);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
   // ---- xh = a W2^T + b2
   f32x16 acc2[RB][3 * CPW];
   bias_acc(acc2, bias2);
-  mma_panel<H, LD, RB, 3 * CPW, ring_size(RB * 3 * CPW, false), false>(acc2, As, bp2, r2);
+  mma_panel<H, LD, RB, 3 * CPW, ring_size(RB * 3 * CPW, false), false, HN_PIN_PRE>(acc2, As, bp2, r2);
   STAMP(7);
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)

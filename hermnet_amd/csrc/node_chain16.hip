@@ -54,6 +54,7 @@ __device__ __forceinline__ void mma16_panel(f32x4 (&acc)[NB], const float* As, c
       for (int j = 0; j < NB; ++j) ring.v[(qq + PF) % RS][j] = bp[j][(q + PF) * 64];
     }
     if (load_a) a[(qq + 1) & 1] = *reinterpret_cast<const f32x4*>(As + 16 * (q + 1));
+    if (HN_PIN_LOADS) fence_sched();       // (the requests stay in front of the group's MFMAs: node_chain_common.h)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -181,7 +181,15 @@ __device__ __forceinline__ void b_preload(BRing<NJ, RS>& r, const f32x4* const (
 // of the panel).  `As`: this lane's LDS read pointer, &tile[(first row of the wave + (l & 31)) * LD + 4 (l >> 5)].
 // The ring holds groups 0 .. RS-2 on entry.  MORE: the stream continues behind this panel (next panel of the same
 // product): its first RS - 1 groups are requested too and sit in slots 0 .. RS-2 on exit (needs KP/8 % RS == 0).
-template <int KP, int LD, int RB, int NJ, int RS, bool MORE>
+// PIN: the group's requests stay in front of its MFMAs (see below); the pre-forward kernels, whose loops hipcc leaves alone
+// anyway, run 5x slower with the fence in place (found by measurement, not understood) and pass false.
+#ifndef HN_PIN_LOADS
+#define HN_PIN_LOADS 1
+#endif
+#ifndef HN_PIN_PRE
+#define HN_PIN_PRE false     // the pre-forward kernels' products
+#endif
+template <int KP, int LD, int RB, int NJ, int RS, bool MORE, bool PIN = true>
 __device__ __forceinline__ void mma_panel(f32x16 (&acc)[RB][NJ], const float* As, const f32x4* const (&bp)[NJ],
                                           BRing<NJ, RS>& ring) {
   constexpr int NQ = KP / 8, PF = RS - 1;
@@ -203,6 +211,10 @@ __device__ __forceinline__ void mma_panel(f32x16 (&acc)[RB][NJ], const float* As
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) a[(qq + 1) & 1][rb] = *reinterpret_cast<const f32x4*>(As + rb * 32 * LD + 8 * (q + 1));
     }
+    // the requests stay HERE, in front of the group's MFMAs: left alone, hipcc's scheduler sinks a weight request towards its
+    // use three groups later (fewer live registers) and the product waits for L2 every few groups (round 4: read off the
+    // ISA of the update kernels' loops; -18 ... -23 % on the wide kernels at H = 512, -10 % on the 16-row update backward)
+    if (PIN && HN_PIN_LOADS) fence_sched();
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -50,9 +50,9 @@ struct Blocks {
 };
 
 // acc[0][j] += W_{blocks} . A^T over K panel `KP` for all NP blocks at once
-template <int KP, int LD, int NP, bool MORE>
+template <int KP, int LD, int NP, bool MORE, bool PIN = true>
 __device__ __forceinline__ void mma_all(f32x16 (&acc)[1][NP], const float* As, const f32x4* const (&bp)[NP], BRing<NP, 4>& ring) {
-  mma_panel<KP, LD, 1, NP, 4, MORE>(acc, As, bp, ring);
+  mma_panel<KP, LD, 1, NP, 4, MORE, PIN>(acc, As, bp, ring);
 }
 
 // =====================================================================================================================
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void node_pre_fwd_wide_kernel(PreFwdArgs a)
   const float* As = tile + mrow * LD + ch;
   f32x16 acc1[1][NP];
   zero_acc(acc1);
-  mma_all<H, LD, NP, false>(acc1, As, bp1, r1);
+  mma_all<H, LD, NP, false, HN_PIN_PRE>(acc1, As, bp1, r1);
   __syncthreads();                                   // every wave has read n
   // ---- + b1, save, ScaledSiLU -> the tile becomes the A operand of the second product
 #pragma unroll
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void node_pre_fwd_wide_kernel(PreFwdArgs a)
       b_preload(r2, bp2);
       f32x16 acc2[1][3];
       zero_acc(acc2);
-      mma_panel<H, LD, 1, 3, 4, false>(acc2, As, bp2, r2);
+      mma_panel<H, LD, 1, 3, 4, false, HN_PIN_PRE>(acc2, As, bp2, r2);
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         const int cblk = p * H + B.cb[j] * 32;

@@ -41,6 +41,10 @@ def main():
         "node_update_bwd": (lambda: nodeops.node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, g), 2 * N * 11 * H * H),
     }
     print("rows %d (atoms %d), H %d, T %d" % (N, n, H, T))
+    for _ in range(3):                    # every case a few times before any is timed (allocator growth, code objects:
+        for fn, _f in cases.values():     # a one-time stall otherwise lands in the first case's interval)
+            fn()
+    torch.cuda.synchronize()
     for name, (fn, flop) in cases.items():
         for _ in range(5):
             fn()
