@@ -15,7 +15,7 @@ _ERR = {1: "HN_ERR_BAD_ARG (unsupported shape or null pointer)",
         3: "HN_ERR_LAUNCH (kernel launch failed)"}
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers
-ABI_VERSION = 7          # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
+ABI_VERSION = 8          # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
 
 
 class RbfDesc(ctypes.Structure):
@@ -28,6 +28,12 @@ class Graph(ctypes.Structure):
                 ("type_rowptr", c_fp), ("csr_rowptr", c_fp), ("csr_src", c_fp),
                 ("csc_rowptr", c_fp), ("csc_tgt", c_fp), ("csc_pos", c_fp),
                 ("num_src", ctypes.c_int), ("res_row", c_fp)]
+
+
+class PendingGrads(ctypes.Structure):
+    """hn_pending_grads (include/hermnet_hip.h): the incoming gradients of an update backward, still in partial sums."""
+    _fields_ = [(n, c_fp) for n in ("gn_parts", "gvec_parts", "x", "mean", "rstd", "gx1", "gvec1")] + \
+               [("num_parts", ctypes.c_int), ("hidden_real", ctypes.c_int)]
 
 
 class RelationsOut(ctypes.Structure):
@@ -96,7 +102,8 @@ SIGNATURES = {
                                                         ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_node_update_tile_rows": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "hermnet_node_update_fwd": (ctypes.c_int, [c_fp] * 16 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
-    "hermnet_node_update_bwd": (ctypes.c_int, [c_fp] * 14 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_node_update_bwd": (ctypes.c_int, [c_fp] * 14 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp,
+                                                           c_fp]),
     "hermnet_pair_mean": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_fp, ctypes.c_int, c_fp]),
     "hermnet_halo_rows": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),

@@ -595,6 +595,7 @@ int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, const int* 
   }
   dim3 grid((unsigned)chunks, (unsigned)ncb, (unsigned)a.T);
   hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, a);
+  if (a.gx == nullptr) return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;   // (left to the consumer)
   // partial sums over the relations + identity terms -> gvec, gx
   const long n4v = has_vec ? (long)a.Nsrc * 3 * a.H / 4 : 0, n4x = (long)a.Nsrc * a.H / 4;
   const long n4 = n4v > n4x ? n4v : n4x;

@@ -979,8 +979,9 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   MsgArgs a = {};
   int rc = fill_args(g, rbf, hidden, a);
   if (rc) return rc;
-  if (!xh || !wt || !brbf || !gx1 || !gvec1 || !gxh || !gx || (g->num_edges > 0 && !gedge)) return HN_ERR_BAD_ARG;
-  if (vec && !gvec) return HN_ERR_BAD_ARG;
+  if (!xh || !wt || !brbf || !gx1 || !gvec1 || !gxh || (g->num_edges > 0 && !gedge)) return HN_ERR_BAD_ARG;
+  if (vec && !gvec && gx) return HN_ERR_BAD_ARG;
+  const bool no_finish = gx == nullptr;        // the consumer sums the partials (include/hermnet_hip.h)
   if (g->num_edges > 0 && !edge) return HN_ERR_BAD_ARG;
   if (a.N == 0) return HN_OK;
   static const int use_cl = env_int("HERMNET_BWD_CL", 1);
@@ -992,6 +993,8 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
                      (!vec || a.T == 1 || gvec_partials);
   if (virtual_targets && !cl_ok) return HN_ERR_BAD_ARG;
   if (num_ranges < 0 || (num_ranges > 0 && !(cl_ok && (use_cl || virtual_targets)))) return HN_ERR_BAD_ARG;   // ranges: that form only
+  if (no_finish && !(cl_ok && use_cl && !virtual_targets && num_ranges == 0 && (!vec || gvec_partials)))
+    return HN_ERR_BAD_ARG;
   if (cl_ok && (use_cl || virtual_targets)) {
     HnBwdClArgs b = {};
     b.N = a.N; b.Nsrc = g->num_src > 0 ? g->num_src : a.N; b.E = a.E; b.T = a.T;
@@ -999,7 +1002,7 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
     b.csc_rowptr = a.csc_rowptr; b.csc_tgt = a.csc_tgt; b.csc_pos = a.csc_pos;
     b.R = a.R; b.H = hidden; b.table = edge_table; b.edge = reinterpret_cast<const float4*>(edge);
     b.xh = xh; b.xh_bias = xh_bias; b.vec = vec; b.wt = wt; b.brbf = brbf; b.gx1 = gx1; b.gvec1 = gvec1;
-    b.gxh = gxh; b.gvec = (a.T == 1) ? gvec : gvec_partials; b.gvec_out = gvec; b.gx = gx;
+    b.gxh = gxh; b.gvec = (a.T == 1 && !no_finish) ? gvec : gvec_partials; b.gvec_out = gvec; b.gx = gx;
     b.gedge = reinterpret_cast<float4*>(gedge);
     b.type_rowptr = g->type_rowptr;
     static const int rpb_cl = env_int("HERMNET_BWD_CL_ROWS", 0);

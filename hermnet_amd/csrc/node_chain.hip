@@ -504,6 +504,7 @@ __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a
     }
     return;
   }
+  if (a.pend.gn != nullptr) materialise_pending<H, TR>(a, row0, nrows, tid);   // (incoming gradients still in partial sums)
   const f32x4* wx2t = reinterpret_cast<const f32x4*>(a.wx2tf + (size_t)t * 3 * H * H) + lane;
   const f32x4* wx0t = reinterpret_cast<const f32x4*>(a.wx0tf + (size_t)t * 2 * H * H) + lane;
   const f32x4* wvt = reinterpret_cast<const f32x4*>(a.wvtf + (size_t)t * 2 * H * H) + lane;
@@ -827,7 +828,8 @@ extern "C" int hermnet_node_pre_bwd(const float* gxh, const float* hb, const flo
   if (window_mode < 0 || window_mode > 2 || (window_mode && (!row_windows || num_windows < 0))) return HN_ERR_BAD_ARG;
   if (!hermnet_node_chain_supported(hidden)) return HN_ERR_BAD_ARG;
   if (num_src == 0) return HN_OK;
-  if (!gxh || !hb || !w2t_frag || !w1t_frag || !gn_parts || !x || !mean || !rstd || !gx) return HN_ERR_BAD_ARG;
+  if (!gxh || !hb || !w2t_frag || !w1t_frag || !gn_parts || (gx && (!x || !mean || !rstd))) return HN_ERR_BAD_ARG;
+  if (!gx && window_mode) return HN_ERR_BAD_ARG;
   PreBwdArgs a = {gxh, hb, w2t_frag, w1t_frag, gn_parts, src_ranges, num_src, num_rel, row_windows, num_windows, window_mode};
   // chunk buffers: 2 x [TR][min(H,128) + 4]
   int rc;
@@ -838,7 +840,7 @@ extern "C" int hermnet_node_pre_bwd(const float* gxh, const float* hb, const flo
     default: rc = launch_chain(node_pre_bwd_kernel<256, 32>, HN_GRID(32), (size_t)pre_bwd_lds_floats(256, 32) * 4, stream, a); break;
   }
 #undef HN_GRID
-  if (rc != HN_OK) return rc;
+  if (rc != HN_OK || !gx) return rc;              // (gx == NULL: the consumer runs the LayerNorm backward over the parts)
   hipLaunchKernelGGL(layernorm_bwd_parts_kernel, dim3((unsigned)((num_src + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      gn_parts, num_rel, (long)num_src * hidden, x, mean, rstd, add, gx, num_src, hidden,
                      hidden_real > 0 ? hidden_real : hidden, row_windows, num_windows, window_mode, pre_tile_rows(hidden));
@@ -867,7 +869,7 @@ extern "C" int hermnet_node_update_bwd(const float* gx_out, const float* gvec_ou
                                        const float* q23, const float* nrm, const float* wx2t_frag, const float* wx0t_frag,
                                        const float* wvt_frag, const float* row_active, const int* type_rowptr,
                                        const int* type_rowptr_host, float* gx1, float* gvec1, int num_nodes, int num_rel,
-                                       int hidden, int tile_rows, void* stream) {
+                                       int hidden, int tile_rows, const hn_pending_grads* pending, void* stream) {
   if (num_nodes < 0 || num_rel <= 0 || !type_rowptr_host) return HN_ERR_BAD_ARG;
   if (!hermnet_node_chain_supported(hidden)) return HN_ERR_BAD_ARG;
   if (num_nodes == 0) return HN_OK;
@@ -875,7 +877,15 @@ extern "C" int hermnet_node_update_bwd(const float* gx_out, const float* gvec_ou
       !gvec1 || type_rowptr_host[num_rel] > num_nodes)
     return HN_ERR_BAD_ARG;
   UpdBwdArgs a = {gx_out, gvec_out, vp, h2b, q23, nrm, wx2t_frag, wx0t_frag, wvt_frag, row_active, type_rowptr, gx1, gvec1,
-                  num_nodes, num_rel};
+                  num_nodes, num_rel, {}};
+  if (pending) {
+    const hn_pending_grads& p = *pending;
+    if (!p.gn_parts || !p.gvec_parts || !p.x || !p.mean || !p.rstd || !p.gx1 || !p.gvec1 || p.num_parts < 1 ||
+        p.hidden_real > hidden)
+      return HN_ERR_BAD_ARG;
+    a.pend = {p.gn_parts, p.gvec_parts, p.x, p.mean, p.rstd, p.gx1, p.gvec1, p.num_parts,
+              p.hidden_real > 0 ? p.hidden_real : hidden};
+  }
   if (tile_rows == 16) return hn_update16_supported(hidden) ? hn_update16_bwd(hidden, a, HN_TILES(16), stream) : HN_ERR_BAD_ARG;
   if (use_wide(hidden)) return hn_wide_update_bwd(hidden, a, HN_TILES(32), stream);
   HN_UPDATE_DISPATCH(node_update_bwd_kernel, a);

@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_bwd16_kernel(Upd
     }
     return;
   }
+  if (a.pend.gn != nullptr) materialise_pending<H, TR>(a, row0, nrows, tid);   // (incoming gradients still in partial sums)
   const f32x4* wx2t = reinterpret_cast<const f32x4*>(a.wx2tf + (size_t)t * 3 * H * H) + lane;   // [H, 3H]
   const f32x4* wx0t = reinterpret_cast<const f32x4*>(a.wx0tf + (size_t)t * 2 * H * H) + lane;   // [2H, H]
   const f32x4* wvt = reinterpret_cast<const f32x4*>(a.wvtf + (size_t)t * 2 * H * H) + lane;     // [H, 2H]

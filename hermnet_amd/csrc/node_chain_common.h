@@ -58,8 +58,21 @@ struct UpdFwdArgs {
   int N, T;
 };
 
+// Incoming gradients that still sit in the partial sums of the layer ABOVE (include/hermnet_hip.h: hn_pending_grads): the
+// update backward forms them for its own rows first (materialise_pending) instead of two small launches doing it.
+struct PendingGrads {
+  const float* gn;          // [nparts, N, H]     node_pre_bwd's per-relation partial sums (null: nothing pending)
+  const float* gv;          // [nparts, N, 3, H]  message_scatter_bwd's per-relation partial sums
+  const float* x;           // [N, H]  that layer's LayerNorm input, mean / rstd [N] its statistics
+  const float* mean;
+  const float* rstd;
+  const float* gx1;         // [N, H]     that layer's update-backward results: the residual's identity terms
+  const float* gvec1;       // [N, 3, H]
+  int nparts, Hr;
+};
+
 struct UpdBwdArgs {
-  const float* gxo;         // [N, H]
+  const float* gxo;         // [N, H]     (with `pend`: written by this launch before it is read)
   const float* gvo;         // [N, 3, H]
   const float* vp;          // [N, 3, 2H]
   const float* h2b;         // [N, H]
@@ -73,6 +86,7 @@ struct UpdBwdArgs {
   float* gx1;               // [N, H]
   float* gvec1;             // [N, 3, H]
   int N, T;
+  PendingGrads pend;
 };
 }  // namespace hn_chain
 using namespace hn_chain;
@@ -436,6 +450,69 @@ int launch_chain(void (*kernel)(Args), dim3 grid, size_t lds_bytes, void* stream
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
 
+// The two elementwise halves of the LayerNorm backward, shared by every kernel that runs it (they must agree bit for bit:
+// the two products of ln_out are made opaque -- pin -- so that no context contracts one of them with the final sum).
+__device__ __forceinline__ void ln_prep(const f32x4& gg, const f32x4& xv, float mu, float rs, int c, int Hr, f32x4& gv,
+                                        f32x4& nh, float& s1, float& s2) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float m = c + e < Hr ? 1.f : 0.f;
+    gv[e] = gg[e] * m;
+    nh[e] = (xv[e] - mu) * rs * m;
+    s1 += gv[e];
+    s2 = fmaf(gv[e], nh[e], s2);
+  }
+}
+__device__ __forceinline__ f32x4 ln_out(const f32x4& gv, const f32x4& nh, float m1, float m2, float rs, int c, int Hr,
+                                        bool has_add, const f32x4& av, float add_scale) {
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v = rs * fmaf(-nh[e], m2, gv[e] - m1);
+    pin(v);
+    o[e] = c + e < Hr ? v : 0.f;
+  }
+  if (has_add) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float b = av[e] * add_scale;
+      pin(b);
+      o[e] += b;
+    }
+  }
+  return o;
+}
+
+// One row of gx = LayerNorm'(x)^T (sum_p g[p]) + add_scale * add, a wave per row (lane l: channels 4 (64 k + l) .. + 3).
+__device__ __forceinline__ void layernorm_bwd_row(const float* __restrict__ g, int nparts, long part_stride,
+                                                  const float* __restrict__ x, float mu, float rs,
+                                                  const float* __restrict__ add, float add_scale, float* __restrict__ gx,
+                                                  size_t r, int H, int Hr, int lane) {
+  constexpr int KMAX = 4;                        // H <= 1024
+  f32x4 gv[KMAX], nh[KMAX];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    gv[k] = nh[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (c < H) {
+      f32x4 gg = *reinterpret_cast<const f32x4*>(g + r * H + c);
+      for (int p = 1; p < nparts; ++p) gg += *reinterpret_cast<const f32x4*>(g + p * part_stride + r * H + c);
+      ln_prep(gg, *reinterpret_cast<const f32x4*>(x + r * H + c), mu, rs, c, Hr, gv[k], nh[k], s1, s2);
+    }
+  }
+  const float m1 = wave_sum(s1) / (float)Hr, m2 = wave_sum(s2) / (float)Hr;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < H) {
+      f32x4 av = {0.f, 0.f, 0.f, 0.f};
+      if (add != nullptr) av = *reinterpret_cast<const f32x4*>(add + r * H + c);
+      *reinterpret_cast<f32x4*>(gx + r * H + c) = ln_out(gv[k], nh[k], m1, m2, rs, c, Hr, add != nullptr, av, add_scale);
+    }
+  }
+}
+
 // gx = LayerNorm'(x)^T (sum_p g[p]) + add : the backward of the LayerNorm in front of the T relations' projections
 __global__ __launch_bounds__(256) void layernorm_bwd_parts_kernel(const float* __restrict__ g, int nparts, long part_stride,
                                                                   const float* __restrict__ x, const float* __restrict__ mean,
@@ -446,41 +523,98 @@ __global__ __launch_bounds__(256) void layernorm_bwd_parts_kernel(const float* _
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   if (!tile_selected(windows, nwin, wmode, r / TR * TR, TR)) return;     // the rows of the pre kernel's tiles
-  const int lane = threadIdx.x & 63;
-  const float mu = mean[r], rs = rstd[r];
-  constexpr int KMAX = 4;                        // H <= 1024
-  f32x4 gv[KMAX], nh[KMAX];
-  float s1 = 0.f, s2 = 0.f;
+  layernorm_bwd_row(g, nparts, part_stride, x, mean[r], rstd[r], add, 1.f, gx, (size_t)r, H, Hr, threadIdx.x & 63);
+}
+
+// The prologue of the update backward when its incoming gradients are still `pending` (UpdBwdArgs::pend): what
+// message_bwd_finish_kernel and layernorm_bwd_parts_kernel would have written for the rows [row0, row0 + nrows) of this
+// workgroup's tile, in the same order of operations (bit-identical), into gxo / gvo; the barrier at the end makes the rows
+// visible to the whole workgroup, which then reads them like any other input.  Rows >= identity_rows (atoms of an unknown
+// element) have no residual term.
+template <int H, int TR>
+__device__ __forceinline__ void materialise_pending(const UpdBwdArgs& a, int row0, int nrows, int tid) {
+  const PendingGrads& p = a.pend;
+  const int identity_rows = a.type_rowptr[a.T];
+  float* gxo = const_cast<float*>(a.gxo);
+  const int lane = tid & 63, wave = tid >> 6;
+  // ---- gvec_out: every load of a relation's slice is issued before the first one is used (one round trip per relation)
+  constexpr int V3 = 3 * H / 4, NIT = (TR * V3 + 255) / 256;
+  const long stride4 = (long)a.N * V3;
+  const f32x4* part = reinterpret_cast<const f32x4*>(p.gv) + (long)row0 * V3;
+  const f32x4* g1 = reinterpret_cast<const f32x4*>(p.gvec1) + (long)row0 * V3;
+  f32x4* gvo = reinterpret_cast<f32x4*>(const_cast<float*>(a.gvo)) + (long)row0 * V3;
+  const int nv = nrows * V3;
+  f32x4 acc[NIT];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    const int c = (k * 64 + lane) * 4;
-    gv[k] = nh[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (c < H) {
-      f32x4 gg = *reinterpret_cast<const f32x4*>(g + (size_t)r * H + c);
-      for (int p = 1; p < nparts; ++p) gg += *reinterpret_cast<const f32x4*>(g + p * part_stride + (size_t)r * H + c);
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)r * H + c);
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = tid + it * 256;
+    acc[it] = part[idx < nv ? idx : 0];
+  }
+  // ---- gx_out (requested behind the first slice of gvec, finished while the others arrive)
+  if (H == 128) {
+    // half a wave per row: lanes 0-31 / 32-63 hold one row each (channels 4 (l & 31) .. + 3), TR / 8 passes; the sums over
+    // a row are the xor tree of wave_sum without its first step, whose partner is zero at this width: the same bits
+    constexpr int RP = TR / 8;
+    const int c = (lane & 31) * 4;
+    const long ps = (long)a.N * H;
+    f32x4 gg[RP], xv[RP], av[RP];
+    float mu[RP], rs[RP];
+    int rr[RP];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float m = c + e < Hr ? 1.f : 0.f;
-        gv[k][e] = gg[e] * m;
-        nh[k][e] = (xv[e] - mu) * rs * m;
-        s1 += gv[k][e];
-        s2 = fmaf(gv[k][e], nh[k][e], s2);
+    for (int it = 0; it < RP; ++it) {
+      const int lr = it * 8 + wave * 2 + (lane >> 5);
+      rr[it] = lr < nrows ? row0 + lr : -1;
+      const size_t r = (size_t)(rr[it] >= 0 ? rr[it] : row0);
+      gg[it] = *reinterpret_cast<const f32x4*>(p.gn + r * H + c);
+      xv[it] = *reinterpret_cast<const f32x4*>(p.x + r * H + c);
+      av[it] = *reinterpret_cast<const f32x4*>(p.gx1 + r * H + c);
+      mu[it] = p.mean[r];
+      rs[it] = p.rstd[r];
+    }
+    for (int t = 1; t < p.nparts; ++t) {
+#pragma unroll
+      for (int it = 0; it < RP; ++it) {
+        const size_t r = (size_t)(rr[it] >= 0 ? rr[it] : row0);
+        gg[it] += *reinterpret_cast<const f32x4*>(p.gn + t * ps + r * H + c);
       }
     }
-  }
-  const float m1 = wave_sum(s1) / (float)Hr, m2 = wave_sum(s2) / (float)Hr;
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    const int c = (k * 64 + lane) * 4;
-    if (c < H) {
-      f32x4 o;
+    for (int it = 0; it < RP; ++it) {
+      f32x4 gv, nh;
+      float s1 = 0.f, s2 = 0.f;
+      ln_prep(gg[it], xv[it], mu[it], rs[it], c, p.Hr, gv, nh, s1, s2);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = c + e < Hr ? rs * (gv[k][e] - m1 - nh[k][e] * m2) : 0.f;
-      if (add != nullptr) o += *reinterpret_cast<const f32x4*>(add + (size_t)r * H + c);
-      *reinterpret_cast<f32x4*>(gx + (size_t)r * H + c) = o;
+      for (int m = 16; m >= 1; m >>= 1) {
+        s1 += __shfl_xor(s1, m, 64);
+        s2 += __shfl_xor(s2, m, 64);
+      }
+      const float m1 = s1 / (float)p.Hr, m2 = s2 / (float)p.Hr;
+      const f32x4 o = ln_out(gv, nh, m1, m2, rs[it], c, p.Hr, rr[it] >= 0 && rr[it] < identity_rows, av[it], kInvSqrt2);
+      if (rr[it] >= 0) *reinterpret_cast<f32x4*>(gxo + (size_t)rr[it] * H + c) = o;
+    }
+  } else {
+    for (int lr = wave; lr < nrows; lr += 4) {
+      const int r = row0 + lr;
+      layernorm_bwd_row(p.gn, p.nparts, (long)a.N * H, p.x, p.mean[r], p.rstd[r], r < identity_rows ? p.gx1 : nullptr,
+                        kInvSqrt2, gxo, (size_t)r, H, p.Hr, lane);
     }
   }
+  for (int t = 1; t < p.nparts; ++t) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * 256;
+      acc[it] += part[t * stride4 + (idx < nv ? idx : 0)];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = tid + it * 256;
+    if (idx < nv) {
+      if (row0 + idx / V3 < identity_rows) acc[it] += g1[idx];
+      gvo[idx] = acc[it];
+    }
+  }
+  __syncthreads();
 }
 
 }  // namespace

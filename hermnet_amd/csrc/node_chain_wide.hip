@@ -450,6 +450,7 @@ __global__ __launch_bounds__(256, 1) void node_update_bwd_wide_kernel(UpdBwdArgs
     }
     return;
   }
+  if (a.pend.gn != nullptr) materialise_pending<H, TR>(a, row0, nrows, tid);   // (incoming gradients still in partial sums)
   const Blocks<CB, NP> B(wave);
   const f32x4* wx2t = reinterpret_cast<const f32x4*>(a.wx2tf + (size_t)t * 3 * H * H) + lane;
   const f32x4* wx0t = reinterpret_cast<const f32x4*>(a.wx0tf + (size_t)t * 2 * H * H) + lane;

@@ -10,7 +10,7 @@ from .elements import atomic_numbers
 from .ops import EdgeGeometry, TrueEdgeGradient, edge_radial_table
 from .relations import RelationalGraph
 from .sharding import HaloExchange, HaloExchangeFeatures, HaloGradReturn, SumAcrossRanks
-from .layer import EdgeFanout, EdgeGradSink, EnergyHead, FusedRelationalLayer, LayerWeights, _node_chain_enabled
+from .layer import EdgeFanout, EdgeGradSink, EnergyHead, FusedRelationalLayer, LayerWeights, _node_chain_enabled, _PENDING
 from .rmnet import PaiNNModule, RadialBasis, ScaledSiLU, relational_layer
 
 
@@ -63,9 +63,16 @@ class HeteroVertexConv(nn.Module):
             self._weights = LayerWeights(self.mods.values())
         handles, li = data.get("_hn_edge_handles"), data.get("_hn_layer", 0)
         edge = data._hn_edge if handles is None else handles[li]
-        data.x, data.vec = FusedRelationalLayer.apply(data.x, data.vec, edge, g, data._hn_rbf,
-                                                      w if w is not None else self._weights.refresh(),
-                                                      data.get("_hn_edge_sink"), li, halo)
+        w = w if w is not None else self._weights.refresh()
+        # (x, vec) straight from the chain layer below, which is their only reader's only source: this layer's backward
+        # may hand its input gradients down as partial sums (layer.FusedRelationalLayer, `defer`)
+        tag = getattr(data.x, "_hn_chain_out", None)
+        defer = (tag is not None and data.vec is not None and getattr(data.vec, "_hn_chain_out", None) is tag
+                 and halo is None and not g.num_src)
+        data.x, data.vec = FusedRelationalLayer.apply(data.x, data.vec, edge, g, data._hn_rbf, w,
+                                                      data.get("_hn_edge_sink"), li, halo, defer)
+        if w.chain and _node_chain_enabled() and not g.num_src:
+            data.x._hn_chain_out = data.vec._hn_chain_out = object()
         return data
 
 
@@ -223,6 +230,7 @@ class HVNet(nn.Module):
             all_known = graph.num_src == 0 and graph.N == graph.type_rowptr_host[-1]
             data._hn_edge_sink = EdgeGradSink(len(self.hermconvs), Hp // 64, graph.E, pos.device, zero=not all_known)
             data._hn_edge_handles = EdgeFanout.apply(edge, data._hn_edge_sink)
+        _PENDING.clear()                      # (leftovers of a backward pass that did not complete)
         for li, conv in enumerate(self.hermconvs):
             data._hn_layer = li
             data = conv(data)

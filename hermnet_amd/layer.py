@@ -144,13 +144,37 @@ def _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=True, ranges=None, zero
     return x1, vec1
 
 
-def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True, ranges=None, out=None):
+def _bwd_sums_deferrable(graph, H):
+    """The message backward can leave its finishing launch to the consumer (hermnet_message_scatter_bwd with gx = NULL):
+    channel-per-lane form, targets = sources (HVNet rows), 32-bit offsets.  Width 128 only: there the update backward
+    keeps two or three workgroups per CU and forms the sums half a wave per row (measured, same job: 2.98 vs 3.01 ms at
+    configs[1], 27.2 vs 27.6 ms at 100k atoms); the wide kernels (one workgroup per CU) lose more in their prologue than
+    the two launches cost (H = 512: 22.5 vs 20.8 ms), so they keep the launches."""
+    return (H == 128 and graph.edge_table is not None and not graph.num_src and getattr(graph, "res_row", None) is None
+            and not _split_t(graph) and _os.environ.get("HERMNET_BWD_CL", "1") != "0"
+            and graph.N * 3 * H * 4 < 2 ** 32 and _os.environ.get("HERMNET_DEFER_SUMS", "1") != "0")
+
+
+def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True, ranges=None, out=None, finish=True):
     """`gedge` [H/64, E, 4] (zero-filled by the caller) receives the per-column-block Cartesian edge gradients.
     `ranges` = (device [k,2] int32, host list of (lo, hi)): only these SOURCE rows (atom shards: the halo rows first,
-    the others while their gradients travel; the second call passes the first one's buffers as `out`)."""
+    the others while their gradients travel; the second call passes the first one's buffers as `out`).
+    `finish=False` (only where `_bwd_sums_deferrable`): no finishing launch -- returns (gxh, per-relation partial sums of
+    gvec [T,N,3,H] or None); the sums over the relations and the residual's identity terms are the consumer's."""
     lib = _lib.load()
     b2 = w.b2 if xh_bias else None
     split = _split_t(graph)
+    if not finish:
+        gxh = torch.empty_like(xh)
+        part = None if vec is None else torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
+        gs, rs = graph.as_struct(), rbf.struct()
+        _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"),
+                           lambda: lib.hermnet_message_scatter_bwd(
+                               ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(b2), P(vec), P(w.wt), P(w.brbf), P(edge),
+                               P(gx1), P(gvec1), P(gxh), None, None, P(gedge), 0, P(graph.edge_table), P(part),
+                               None, None, 0, _stream())),
+                   "hermnet_message_scatter_bwd")
+        return gxh, part
     if out is None:
         gxh = torch.empty_like(xh)
         gvec = None if vec is None else (torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
@@ -244,17 +268,25 @@ class EdgeFanout(torch.autograd.Function):
         return (torch.stack(live, 0).sum(0) if live else None), None
 
 
+# gradients handed down as partial sums, keyed by the addresses of the buffers the consumer fills (nodeops.PendingGrads);
+# an entry lives from one layer's backward to the next one's (HVNet.forward clears leftovers of an interrupted pass)
+_PENDING = {}
+
+
 class FusedRelationalLayer(torch.autograd.Function):
     """(x, vec, edge) -> (x_out, vec_out) for one layer, relation (row) order."""
 
     @staticmethod
-    def forward(ctx, x, vec, edge, graph, rbf, w, sink=None, li=0, halo=None):
+    def forward(ctx, x, vec, edge, graph, rbf, w, sink=None, li=0, halo=None, defer=False):
         """`edge`: [E,4], or this layer's handle from `EdgeFanout` ([H/64,E,4] stride-0 view; same memory).
         x / vec live in SOURCE rows, the outputs in TARGET rows; the two coincide for HVNet and differ for HTNet
         (`graph.num_src`: one target row per atom and pair relation, relations.build_triadic).
         `halo` (atom shards, chain path only; `sharding.HaloOverlap`): the exchange of the halo rows of (x, vec) is
         still due -- it runs here, around the node projection: pack, start the all-to-all, project the row tiles
-        that hold no halo row, wait, unpack IN PLACE, project the rest.  The backward mirrors it."""
+        that hold no halo row, wait, unpack IN PLACE, project the rest.  The backward mirrors it.
+        `defer` (HeteroVertexConv.forward: x and vec are the outputs of the chain layer below and of nothing else): the
+        backward hands its input gradients down as partial sums (`nodeops.PendingGrads`) and the update backward of the
+        layer below forms them in its own launch -- two small launches per layer boundary less, same bits."""
         Ns, H = x.shape
         N = graph.N
         T = graph.T
@@ -295,6 +327,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                     _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False, ranges=halo.fwd_late, zero_unknown=False,
                              out=out, range_rows=halo.late_rows)
             ctx.halo = halo
+            ctx.defer = bool(defer) and halo is None and vec is not None
             x_out, vec_out, vp, h2b, q23, nrm = nodeops.node_update_fwd(x1, vec1, w, graph)
             ctx.save_for_backward(x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23, nrm)
             ctx.graph, ctx.rbf, ctx.w, ctx.sink, ctx.li = graph, rbf, w, sink, li
@@ -356,7 +389,9 @@ class FusedRelationalLayer(torch.autograd.Function):
         if ctx.chain:
             x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23, nrm = ctx.saved_tensors
             Ns, H = x.shape
-            gx1, gvec1 = nodeops.node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph)
+            # (the layer above may have left its finishing launches to this one: the buffers arrive unfilled)
+            pend = _PENDING.pop((gxo.data_ptr(), gvo.data_ptr()), None)
+            gx1, gvec1 = nodeops.node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph, pending=pend)
         else:
             x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q = ctx.saved_tensors
             Ns, H = x.shape
@@ -424,7 +459,22 @@ class FusedRelationalLayer(torch.autograd.Function):
                 work.wait()
             nodeops.halo_accumulate(gx_total, gvec_in, plan, back)                  # gradients of my atoms used elsewhere
             ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
-            return gx_total, gvec_in, ge, None, None, None, None, None, None
+            return gx_total, gvec_in, ge, None, None, None, None, None, None, None
+        ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
+        if ctx.chain and _bwd_sums_deferrable(graph, H):
+            if ctx.defer and ctx.needs_input_grad[0]:
+                gxh, gv_parts = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=False, finish=False)
+                gn_parts = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, src_ranges=graph.src_ranges, parts_only=True)
+                gx_total, gvec_in = torch.empty_like(x), torch.empty_like(vec)      # filled by the layer below
+                if _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":            # (tests: nothing reads them before that)
+                    gx_total.fill_(float("nan"))
+                    gvec_in.fill_(float("nan"))
+                _PENDING[(gx_total.data_ptr(), gvec_in.data_ptr())] = nodeops.PendingGrads(
+                    gx_total, gvec_in, gn_parts, gv_parts, x, mean, rstd, gx1, gvec1, w.h_real)
+                return gx_total, gvec_in, ge, None, None, None, None, None, None, None
+            if vec is None and not ctx.needs_input_grad[0]:     # the first layer: nothing below wants gx / gvec
+                _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=False, finish=False)
+                return None, None, ge, None, None, None, None, None, None, None
         gxh, gvec_in, gx_in = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=not ctx.chain)
         _virtual_residual(graph, gx1, gvec1, gx_in, gvec_in, H)
         gx_total = None
@@ -436,8 +486,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                 gh = nodeops.ssilu_bwd(ga, h, Ns, T, H, H, Ns * H)                   # [Ns, T*H]
                 gn = _launch("gemm", lambda: torch.mm(gh, w.w1cat))                                           # [N, H]
                 gx_total = nodeops.layernorm_bwd(gn, x, mean, rstd, add=gx_in, h_real=w.h_real)
-        ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
-        return gx_total, gvec_in, ge, None, None, None, None, None, None
+        return gx_total, gvec_in, ge, None, None, None, None, None, None, None
 
 
 class EnergyHead(torch.autograd.Function):

@@ -1,6 +1,8 @@
 """Thin Python wrappers (allocate outputs, pass pointers) around the node-level fused
 kernels of `csrc/node_kernels.hip`.  One call = one kernel launch on the current stream."""
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -246,10 +248,17 @@ def node_pre_fwd(x, w, T, src_ranges=None, windows=None, mode=0, out=None):
     return hb, xh, mean, rstd
 
 
-def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None, src_ranges=None, windows=None, mode=0, out=None):
+def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None, src_ranges=None, windows=None, mode=0, out=None, parts_only=False):
     """Gradient of node_pre_fwd w.r.t. x (+ add).  `windows` / `mode` / `out` as in node_pre_fwd (`out` = (gx, parts) of
-    the first call)."""
+    the first call).  `parts_only`: no LayerNorm-backward launch -- returns the per-relation partial sums [T,Ns,H] for a
+    consumer that runs it itself (node_update_bwd's `pending`)."""
     T, Ns, H = hb.shape
+    if parts_only:
+        parts = torch.empty(T, Ns, H, dtype=x.dtype, device=x.device)
+        _lib.check(_launch("node_pre_bwd", lambda: _lib.load().hermnet_node_pre_bwd(
+            P(gxh), P(hb), P(w.w2tf), P(w.w1tf), P(parts), None, None, None, None, None, P(src_ranges), Ns, T, H, w.h_real,
+            None, 0, 0, _stream())), "hermnet_node_pre_bwd")
+        return parts
     if out is None:
         parts = torch.empty(T, Ns, H, dtype=x.dtype, device=x.device)
         gx = torch.empty_like(x)
@@ -282,8 +291,19 @@ def node_update_fwd(x1, vec1, w, graph):
     return xo, vo, vp, h2b, q23, nrm
 
 
-def node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph):
-    """Gradient of node_update_fwd w.r.t. (x1, vec1)."""
+class PendingGrads(object):
+    """The gradients a layer's backward hands DOWN while they still sit in partial sums (hn_pending_grads): `gx` / `gvec`
+    are the buffers the consumer -- the update backward of the layer below -- fills before it reads them."""
+
+    def __init__(self, gx, gvec, gn_parts, gvec_parts, x, mean, rstd, gx1, gvec1, h_real):
+        self.gx, self.gvec = gx, gvec
+        self.tensors = (gn_parts, gvec_parts, x, mean, rstd, gx1, gvec1)        # (kept alive until consumed)
+        self.struct = _lib.PendingGrads(*[P(t) for t in self.tensors], gn_parts.size(0), h_real)
+
+
+def node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph, pending=None):
+    """Gradient of node_update_fwd w.r.t. (x1, vec1).  `pending` (PendingGrads whose gx / gvec ARE gxo / gvo): the kernel
+    forms the incoming gradients from the partial sums of the layer above first."""
     N, H = gxo.shape
     t16 = update_tile_rows(graph, H) == 16 and getattr(w, "wvf16", None) is not None
     wx2tf, wx0tf, wvtf = (w.wx2tf16, w.wx0tf16, w.wvtf16) if t16 else (w.wx2tf, w.wx0tf, w.wvtf)
@@ -291,5 +311,6 @@ def node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph):
     gvec1 = torch.empty_like(gvo)
     _lib.check(_launch("node_update_bwd", lambda: _lib.load().hermnet_node_update_bwd(
         P(gxo), P(gvo), P(vp), P(h2b), P(q23), P(nrm), P(wx2tf), P(wx0tf), P(wvtf), P(graph.row_active), P(graph.type_rowptr),
-        _rowptr_host(graph), P(gx1), P(gvec1), N, graph.T, H, 16 if t16 else 0, _stream())), "hermnet_node_update_bwd")
+        _rowptr_host(graph), P(gx1), P(gvec1), N, graph.T, H, 16 if t16 else 0,
+        None if pending is None else ctypes.byref(pending.struct), _stream())), "hermnet_node_update_bwd")
     return gx1, gvec1

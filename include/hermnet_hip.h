@@ -246,7 +246,11 @@ int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc* rbf, int h
  *   row): this launch writes gxh / gvec / gx only for the SOURCE rows of the given disjoint ascending ranges (gedge: the
  *   edges leaving those rows).  Two launches over complementary ranges give bit for bit what one gives: the host runs
  *   the halo rows first, sends their gradients home and runs the rest while they travel.  Channel-per-lane form only
- *   (edge_table given): HN_ERR_BAD_ARG otherwise. */
+ *   (edge_table given): HN_ERR_BAD_ARG otherwise.
+ * gx == NULL (ABI v8; channel-per-lane form, HVNet rows, no ranges): the finishing launch is left out -- gvec_partials
+ *   [T,N,3,H] keeps the per-relation sums (required then whenever vec != NULL, also for T == 1) and neither gvec nor gx is
+ *   written: the consumer forms gvec = sum_t gvec_partials[t] + gvec1 and gx = gx1 / sqrt2 itself
+ *   (hermnet_node_update_bwd's `pending`), or needs neither (the first layer, whose inputs carry no gradient). */
 int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc* rbf, int hidden,
                                 const float* xh, const float* xh_bias, const float* vec,
                                 const float* wt, const float* brbf, const float* edge,
@@ -357,7 +361,8 @@ int hermnet_energy_head_fused_bwd(const float* ge, const float* h, const float* 
  *     the backward contributes zero for them.
  * hermnet_node_pre_bwd: gx = LayerNorm'(x)^T sum_t ((gxh[t] W2_t) * ScaledSiLU'(hb[t])) W1_t + add
  *     (w2t_frag = frag(W2_t^T [H, 3H]), w1t_frag = frag(W1_t^T [H, H]); gn_parts [T, num_src, H] is workspace; add may
- *     be NULL; gx may alias add).
+ *     be NULL; gx may alias add).  gx == NULL (ABI v8): only the per-relation partial sums gn_parts are produced -- the
+ *     LayerNorm backward over their sum is left to the consumer (hn_pending_grads below); x / mean / rstd / add unused.
  * row_windows (device, [num_windows][2] int32 row ranges) + window_mode (ABI v6; atom shards, no reference counterpart):
  *     0 = every row tile (row_windows may be NULL); 1 = only the tiles (hermnet_node_chain_tile_rows) that touch a window;
  *     2 = only the others.  Two calls with modes 2 and 1 on the same buffers compute what one call with mode 0 does:
@@ -387,7 +392,26 @@ int hermnet_node_pre_bwd(const float* gxh, const float* hb, const float* w2t_fra
  *     v_mfma_f32_16x16x4_f32, csrc/node_chain16.hip) -- every *_frag argument must then be the frag16 copy of the weight,
  *     frag16(W)[((b * K/16 + Q) * 64 + l) * 4 + e] = W[16 b + (l & 15)][16 Q + 4 (l >> 4) + e].
  *     hermnet_node_update_tile_rows says which form shortens the launch for a row layout (small grids: 32-row tiles
- *     leave most CUs with one workgroup while a few get two; 16-row tiles cost twice the weight bytes from L2). */
+ *     leave most CUs with one workgroup while a few get two; 16-row tiles cost twice the weight bytes from L2).
+ * pending (ABI v8; may be NULL): the incoming gradients of this layer's outputs have not been formed yet -- they still sit
+ *     in the partial sums of the layer above, which skipped its two small finishing launches (hermnet_message_scatter_bwd
+ *     and hermnet_node_pre_bwd, each called with gx == NULL).  The update backward then forms them for the rows of each of
+ *     its tiles first, with the same operations in the same order (bit-identical to the separate launches),
+ *         gx_out[r]   = LayerNorm'(x[r])^T (sum_p gn_parts[p][r]) + gx1[r] / sqrt2
+ *         gvec_out[r] = sum_p gvec_parts[p][r] + gvec1[r]             (the "+" terms on rows < type_rowptr[T] only),
+ *     WRITES them to gx_out / gvec_out (buffers of the caller; the `const` is nominal in this mode) and goes on as usual.
+ *     Needs num_src == num_nodes (HVNet rows) in the layer above.  Saves two launches per layer boundary. */
+typedef struct hn_pending_grads {
+  const float* gn_parts;    /* [num_parts][num_nodes][hidden]     from hermnet_node_pre_bwd(gx = NULL) */
+  const float* gvec_parts;  /* [num_parts][num_nodes][3][hidden]  from hermnet_message_scatter_bwd(gx = NULL) */
+  const float* x;           /* [num_nodes][hidden]  the layer above's input, mean / rstd [num_nodes] its LayerNorm statistics */
+  const float* mean;
+  const float* rstd;
+  const float* gx1;         /* [num_nodes][hidden], [num_nodes][3][hidden]: the layer above's update-backward results */
+  const float* gvec1;
+  int num_parts;            /* the relations T of the layer above */
+  int hidden_real;          /* as in hermnet_node_pre_bwd (0 = hidden) */
+} hn_pending_grads;
 int hermnet_node_update_tile_rows(const int* type_rowptr_host, int num_nodes, int num_rel, int hidden);
 int hermnet_node_update_fwd(const float* x1, const float* vec1, const float* wv_frag, const float* wx0_frag,
                             const float* bx0, const float* wx2_frag, const float* bx2, const float* row_active,
@@ -398,7 +422,8 @@ int hermnet_node_update_bwd(const float* gx_out, const float* gvec_out, const fl
                             const float* q23, const float* nrm, const float* wx2t_frag, const float* wx0t_frag,
                             const float* wvt_frag,
                             const float* row_active, const int* type_rowptr, const int* type_rowptr_host, float* gx1,
-                            float* gvec1, int num_nodes, int num_rel, int hidden, int tile_rows, void* stream);
+                            float* gvec1, int num_nodes, int num_rel, int hidden, int tile_rows,
+                            const hn_pending_grads* pending, void* stream);
 
 /* HTNet (hermnet.py:155-157 is a stub; DESIGN.md "HTNet"): a centre atom's P pair relations are averaged.  Target rows
  * are [num_elem][pairs][block] blocks of `block` rows ("virtual" rows, one per atom and pair relation):

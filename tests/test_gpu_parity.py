@@ -831,6 +831,92 @@ def test_fused_layer_equals_autograd_composed_layer(name, monkeypatch):
     assert rel_err(res[0][1], res[1][1]) < 5e-6
 
 
+class _LaunchCounter(object):
+    """ops.set_kernel_timer hook that only counts the library launches by name."""
+
+    def __init__(self):
+        self.names = []
+
+    def launch(self, name, fn):
+        self.names.append(name)
+        return fn()
+
+
+@pytest.mark.parametrize("name,width", [("alloy108", None), ("alloy108_unknown_type", None), ("mol16", None),
+                                        ("alloy108", 192), ("alloy108", 256)])
+def test_deferred_gradient_sums_equal_the_finishing_launches_bit_for_bit(name, width, monkeypatch):
+    """a layer's backward hands (gx, gvec) down as per-relation partial sums and the update backward of
+    the layer below forms them in its own launch (hn_pending_grads) -- no message_bwd_finish / layernorm_bwd_parts
+    launches, the same bits in energy and forces."""
+    from hermnet_amd import ops
+    from hermnet_amd.layer import _PENDING
+    dev = _dev()
+    g = Golden(name)
+    if width is None:
+        model = g.model().to(dev)
+    else:
+        from hermnet_amd import HVNet
+        torch.manual_seed(5)
+        kw = dict(g.model_kw)
+        kw["hidden_channels"] = width
+        model = HVNet(g.elems, **kw).to(dev).eval()
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("HERMNET_DEFER_SUMS", flag)
+        d = g.data().to(dev)
+        d.pos.requires_grad_(True)
+        cnt = _LaunchCounter()
+        ops.set_kernel_timer(cnt)
+        try:
+            e = model(d)
+            f = -torch.autograd.grad(e.sum(), d.pos)[0]
+        finally:
+            ops.set_kernel_timer(None)
+        torch.cuda.synchronize()
+        res.append((e.detach().clone(), f.clone(), cnt.names))
+        assert not _PENDING                     # every handed-down gradient was picked up
+    assert torch.isfinite(res[1][1]).all()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert len(res[1][2]) == len(res[0][2])     # (the same library calls: the launches they no longer make are inside them)
+
+
+def test_pending_gradients_in_every_update_backward_form():
+    """hn_pending_grads straight through the C ABI for the kernel families the model does not defer to by default (the
+    wide kernels, 32-row tiles): gx_out / gvec_out formed inside hermnet_node_update_bwd equal the separate launches'."""
+    from hermnet_amd import nodeops
+    from hermnet_amd.layer import LayerWeights
+    from hermnet_amd.relations import RelationalGraph
+    from hermnet_amd.rmnet import PaiNNModule
+    dev = _dev()
+    for H, n in ((128, 333), (128, 40000), (192, 333), (256, 333), (64, 333)):     # (16-row tiles at 333 rows, 32 at 40k)
+        torch.manual_seed(H)
+        T = 3
+        zs = [13, 28, 29]
+        mods = [PaiNNModule(hidden_channels=H, num_rbf=16).to(dev) for _ in range(T)]
+        w = LayerWeights(mods).refresh()
+        z = torch.tensor(zs + [1], device=dev)[torch.randint(0, T + 1, (n,), device=dev)]      # (some atoms of an unknown element)
+        g = RelationalGraph.build(z, torch.stack([torch.randint(0, n, (4 * n,), device=dev),
+                                                  torch.randint(0, n, (4 * n,), device=dev)]), zs)
+        N = g.N
+        r = lambda *s: torch.randn(*s, device=dev)
+        gn, gv, x, gx1, gvec1 = r(T, N, H), r(T, N, 3, H), r(N, H), r(N, H), r(N, 3, H)
+        mean, rstd = x.mean(1), 1.0 / (x.var(1, unbiased=False) + 1e-5).sqrt()
+        vp, h2b, q23, nrm = r(N, 3, 2 * H), r(N, H), r(N, 2 * H), r(N, H).abs() + 0.5
+        # the separate launches: LayerNorm backward over the parts + residual, sums of the gvec slices + residual
+        ident = torch.zeros(N, 1, device=dev)
+        ident[:g.type_rowptr_host[-1]] = 1.0
+        gxo = nodeops.layernorm_bwd(gn.sum(0) if False else (gn[0] + gn[1] + gn[2]), x, mean, rstd,
+                                    add=gx1 * 0.70710678118654752 * ident)
+        gvo = gv[0] + gv[1] + gv[2] + gvec1 * ident[:, :, None]
+        want = nodeops.node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, g)
+        bx, bv = torch.full_like(gxo, float("nan")), torch.full_like(gvo, float("nan"))
+        pend = nodeops.PendingGrads(bx, bv, gn, gv, x, mean, rstd, gx1, gvec1, 0)
+        got = nodeops.node_update_bwd(bx, bv, vp, h2b, q23, nrm, w, g, pending=pend)
+        k = g.type_rowptr_host[-1]
+        assert rel_err(bx[:k], gxo[:k]) < 2e-6 and rel_err(bv[:k], gvo[:k]) < 2e-6, H
+        assert rel_err(got[0], want[0]) < 5e-6 and rel_err(got[1], want[1]) < 5e-6, H
+
+
 class _FakeAtoms(object):
     """Duck-typed stand-in for ase.Atoms (ASE is not installed on the MI355X image)."""
 
