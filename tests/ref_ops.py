@@ -219,11 +219,14 @@ def node_pre_fwd(x, w, T, src_ranges=None, windows=None, mode=0, out=None):
     return out
 
 
-def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None, src_ranges=None, windows=None, mode=0, out=None):
+def node_pre_bwd(gxh, hb, x, mean, rstd, w, add=None, src_ranges=None, windows=None, mode=0, out=None, parts_only=False):
     T, Ns, H = hb.shape
     dt = x.dtype
     gh = torch.bmm(gxh, w.w2.to(dt)) * _dssilu(hb)                                                   # [T, Ns, H]
-    gn = torch.bmm(gh, w.w1cat.to(dt).view(T, H, H)).sum(0)
+    gn = torch.bmm(gh, w.w1cat.to(dt).view(T, H, H))
+    if parts_only:            # (hermnet_node_pre_bwd with gx = NULL: the per-relation partial sums only)
+        return gn
+    gn = gn.sum(0)
     gx = layernorm_bwd(gn, x, mean, rstd, add=add, h_real=w.h_real)
     if windows is None or mode == 0:
         return gx
@@ -322,11 +325,18 @@ def node_update_fwd(x1, vec1, w, graph):
         return _node_update(x1, vec1, w, graph)
 
 
-def node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph):
+def node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph, pending=None):
     """The kernel's backward formulas from the saved (vp, h2b, q23) (checked against autograd of the forward in
-    tests/test_host_logic.py)."""
+    tests/test_host_logic.py).  `pending` (hn_pending_grads): gxo / gvo are formed here first, from the partial sums of
+    the layer above, and written into the caller's buffers."""
     N, H = gxo.shape
     dt = gxo.dtype
+    if pending is not None:
+        gn, gv, x, mean, rstd, gx1_up, gvec1_up = pending.tensors
+        ident = (torch.arange(N) < graph.type_rowptr_host[-1]).to(dt)
+        gxo.copy_(layernorm_bwd(gn.sum(0), x, mean, rstd, add=gx1_up * ident[:, None] / math.sqrt(2.0),
+                                h_real=pending.struct.hidden_real))
+        gvo.copy_(gv.sum(0) + gvec1_up * ident[:, None, None])
     act = torch.ones(N, dtype=dt) if graph.row_active is None else graph.row_active.to(dt)
     gx1 = torch.zeros(N, H, dtype=dt)
     gvec1 = torch.zeros(N, 3, H, dtype=dt)
@@ -386,10 +396,20 @@ def msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=True, ranges=None, zero_
     return out
 
 
-def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True, ranges=None, out=None):
+def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True, ranges=None, out=None, finish=True):
     """Backward contract of hermnet_message_scatter_bwd via autograd of the dense restatement;
     the edge gradient is Cartesian (w.r.t. D = rhat * d).  `ranges` = (tensor, [(lo, hi)]): only these SOURCE rows (and
-    the edges leaving them) are written, the call returns its buffers (gxh, gvec, gx, None) for the complementary call."""
+    the edges leaving them) are written, the call returns its buffers (gxh, gvec, gx, None) for the complementary call.
+    `finish=False` (gx = NULL in the C call): (gxh, per-relation partial sums of gvec WITHOUT the residual's identity term)."""
+    if not finish:
+        T = xh.size(0)
+        gxh, gv, _ = msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=xh_bias)
+        if gv is None:
+            return gxh, None
+        ident = (torch.arange(graph.N) < int(graph.type_rowptr[T])).to(gv.dtype)
+        part = torch.zeros((T,) + tuple(gv.shape), dtype=gv.dtype)
+        part[0] = gv - gvec1 * ident[:, None, None]      # (the split over the relations is the kernel's own business)
+        return gxh, part
     with torch.enable_grad():
         xh_ = (xh + w.b2 if xh_bias else xh).detach().requires_grad_(True)
         x_ = torch.zeros(xh.size(1), H, dtype=xh.dtype).requires_grad_(True)

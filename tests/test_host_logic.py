@@ -209,12 +209,17 @@ def test_fused_layer_orchestration_matches_golden(name, monkeypatch):
         monkeypatch.setattr(lmod.nodeops, fn, getattr(ref_ops, fn))
     monkeypatch.setattr(lmod, "_msg_fwd", ref_ops.msg_fwd)
     monkeypatch.setattr(lmod, "_msg_bwd", ref_ops.msg_bwd)
-    d = g.data()
-    d.pos.requires_grad_(True)
-    e = model(d)
-    f = -torch.autograd.grad(e.sum(), d.pos)[0]
-    assert rel_err(e.detach(), g.energy) < 2e-6
-    assert rel_err(f, g.forces) < 1e-5
+    # both forms of the backward hand-over between layers: finished gradients, and partial sums the update backward of the
+    # layer below finishes (hn_pending_grads; on the GPU the form is picked by `_bwd_sums_deferrable`)
+    for deferred in (False, True):
+        monkeypatch.setattr(lmod, "_bwd_sums_deferrable", lambda graph, H, v=deferred: v)
+        d = g.data()
+        d.pos.requires_grad_(True)
+        e = model(d)
+        f = -torch.autograd.grad(e.sum(), d.pos)[0]
+        assert not lmod._PENDING
+        assert rel_err(e.detach(), g.energy) < 2e-6
+        assert rel_err(f, g.forces) < 1e-5
 
 
 def test_lammps_plugin_helpers():
