@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 from .elements import atomic_numbers
-from .ops import EdgeGeometry, TrueEdgeGradient, edge_radial_table
+from .ops import EdgeGeometry, TrueEdgeGradient, edge_radial_table, side_stream
 from .relations import RelationalGraph
 from .sharding import HaloExchange, HaloExchangeFeatures, HaloGradReturn, SumAcrossRanks
 from .layer import EdgeFanout, EdgeGradSink, EnergyHead, FusedRelationalLayer, LayerWeights, _node_chain_enabled, _PENDING
@@ -64,15 +64,19 @@ class HeteroVertexConv(nn.Module):
         handles, li = data.get("_hn_edge_handles"), data.get("_hn_layer", 0)
         edge = data._hn_edge if handles is None else handles[li]
         w = w if w is not None else self._weights.refresh()
-        # (x, vec) straight from the chain layer below, which is their only reader's only source: this layer's backward
-        # may hand its input gradients down as partial sums (layer.FusedRelationalLayer, `defer`)
-        tag = getattr(data.x, "_hn_chain_out", None)
-        defer = (tag is not None and data.vec is not None and getattr(data.vec, "_hn_chain_out", None) is tag
-                 and halo is None and not g.num_src)
+        # (x, vec) straight from the chain layer below -- both still carry THAT autograd node (an in-place exchange of halo
+        # rows or any other op in between replaces it) -- and this layer is their only reader: its backward may hand its
+        # input gradients down as partial sums (layer.FusedRelationalLayer, `defer`)
+        node = data.get("_hn_chain_node")
+        defer = (node is not None and data.vec is not None and data.x.grad_fn is node and data.vec.grad_fn is node
+                 and halo is None and not g.num_src and data.get("_hn_shard") is None)
+        pre, data._hn_pre0 = data.get("_hn_pre0"), None      # (the first layer's node projection, launched by HVNet.forward)
+        if pre is not None and not (w.chain and _node_chain_enabled() and halo is None and pre[0] is data.x):
+            pre = None
         data.x, data.vec = FusedRelationalLayer.apply(data.x, data.vec, edge, g, data._hn_rbf, w,
-                                                      data.get("_hn_edge_sink"), li, halo, defer)
-        if w.chain and _node_chain_enabled() and not g.num_src:
-            data.x._hn_chain_out = data.vec._hn_chain_out = object()
+                                                      data.get("_hn_edge_sink"), li, halo, defer,
+                                                      None if pre is None else pre[1])
+        data._hn_chain_node = data.x.grad_fn if (w.chain and _node_chain_enabled() and not g.num_src) else None
         return data
 
 
@@ -133,12 +137,12 @@ class HVNet(nn.Module):
             raise TypeError("hermnet_amd.HVNet computes in float32: parameters are %s, data.pos is %s "
                             "(call model.float() / pos.float())" % (wd, pos.dtype))
 
-    def _build_graph(self, data, zl, shard):
+    def _build_graph(self, data, zl, shard, side=None):
         """Relation-ordered graph of this neighbour list (the replacement of `in_subgraph`, utils.py:11-24)."""
         rel_active = None if shard is None else shard.rel_active(zl)
         return RelationalGraph.build(data.atomic_number, data.edge_index, zl,
                                      edge_shift=data.get("edge_shift") if data.get("cell") is not None else None,
-                                     batch=data.batch, rel_active=rel_active)
+                                     batch=data.batch, rel_active=rel_active, side=side)
 
     @staticmethod
     def _edge_geometry_autograd(pos, cell, graph):
@@ -176,8 +180,20 @@ class HVNet(nn.Module):
         padded = data.get("_hn_edge_count") is not None
         if padded and (train or shard is not None):
             raise NotImplementedError("a padded neighbour list runs through the fused eval() path of one GPU")
-        graph = self._build_graph(data, zl, shard)
         fused = self.radial_basis.fused and not train
+        # Two things of a step are not on its critical path: the first layer's node projection needs the
+        # atoms only, not the edges, and the radial table is read by the backward only.  HERMNET_SIDE_STREAM=1 sends the edge
+        # part of the relation build to a second stream while this one embeds the atoms and projects them, and the table to
+        # the second stream while the forward layers run here (2 = the table only, 3 = the build only); the streams join
+        # before the first reader of each.  OFF by default -- measured: the two fork / join pairs cost
+        # what the overlap gains (bench line 3.06-3.08 vs 3.02 ms; whole-step hipGraph replay 2.94 ms either way; only an
+        # eager loop without event timers gains, 2.96 vs 3.01 ms).
+        side = None
+        side_mode = int(os.environ.get("HERMNET_SIDE_STREAM", "0"))
+        if (side_mode and fused and shard is None and pos.is_cuda and type(self)._build_graph is HVNet._build_graph
+                and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0"):
+            side = side_stream(pos.device)
+        graph = self._build_graph(data, zl, shard, side) if side is not None and side_mode != 2 else self._build_graph(data, zl, shard)
         rbf = self.radial_basis.descriptor() if fused else None
         row_plan = None
         if shard is not None:
@@ -191,11 +207,6 @@ class HVNet(nn.Module):
             else:
                 pos = HaloExchange.apply(pos, shard.atom_plan)              # halo coordinates from their owners
             row_plan = shard.row_plan(graph.row_of_node)
-        if train:
-            edge = self._edge_geometry_autograd(pos, data.get("cell"), graph)
-        else:
-            edge = EdgeGeometry.apply(pos, data.get("cell"), graph)      # with_edge, hermnet.py:133-152
-
         # hermnet.py:123, row order (pads: Z=0).  eval(): every parameter is a constant, the embedding included
         # (the fused layers produce no parameter gradients; a partial set would be worse than none)
         x = self.embed(graph.z_rows) if train else torch.nn.functional.embedding(graph.z_rows, self.embed.weight.detach())
@@ -204,13 +215,34 @@ class HVNet(nn.Module):
         if Hp != H:
             # widths that are not a multiple of 64 run on the same kernels with zero-padded channels (layer.LayerWeights)
             x = torch.nn.functional.pad(x, (0, Hp - H))
+        data._hn_pre0 = None
+        if graph.ready is not None:
+            # (the edge part of the build is still running on the side stream: the row arrays above are the cached ones)
+            conv0 = self.hermconvs[0]
+            if conv0._weights is None:
+                conv0._weights = LayerWeights(conv0.mods.values())
+            w0 = conv0._weights.refresh()
+            if w0.chain and _node_chain_enabled():
+                from . import nodeops
+                data._hn_pre0 = (x, nodeops.node_pre_fwd(x, w0, graph.T, src_ranges=graph.src_ranges))
+            torch.cuda.current_stream().wait_event(graph.ready)
+            graph.ready = None
+        if train:
+            edge = self._edge_geometry_autograd(pos, data.get("cell"), graph)
+        else:
+            edge = EdgeGeometry.apply(pos, data.get("cell"), graph)      # with_edge, hermnet.py:133-152
+
         vec = None                                                          # zeros, hermnet.py:124
         if not fused and not train:
             edge = TrueEdgeGradient.apply(edge)      # autograd's (rhat, d) gradients -> Cartesian for the kernel
         data._hn_graph, data._hn_edge, data._hn_rbf = graph, edge, rbf
+        table_ready = None
         if fused and edge.requires_grad and edge.is_cuda:
             # forces wanted: the backward message kernels read the radial quantities of an edge from this table
-            graph.edge_table = edge_radial_table(graph, rbf, edge.detach())
+            if side is not None and side_mode != 3:
+                graph.edge_table, table_ready = edge_radial_table(graph, rbf, edge.detach(), side)
+            else:
+                graph.edge_table = edge_radial_table(graph, rbf, edge.detach())
         # rmnet.py:168-172 for the optional bases only: [E,R] basis from the kernel's distances
         if fused:
             data._hn_edge_embed = None
@@ -221,7 +253,7 @@ class HVNet(nn.Module):
         else:
             data._hn_edge_embed = self.radial_basis(edge[:, 3])
         data.x, data.vec = x, vec
-        data._hn_edge_handles = data._hn_edge_sink = data._hn_halo = None
+        data._hn_edge_handles = data._hn_edge_sink = data._hn_halo = data._hn_chain_node = None
         if fused and edge.requires_grad and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0":
             # one reduction of the edge gradients per step instead of one per layer (layer.EdgeFanout)
             # (atoms of an unknown element own the rows past type_rowptr[T]; only edges INTO them go unwritten)
@@ -238,6 +270,9 @@ class HVNet(nn.Module):
                 # one exchange per layer: (x | vec) rows of halo atoms, 4H floats each -- due before the next layer reads
                 # them, run BY that layer (overlapped with its node projection where it can, HeteroVertexConv.forward)
                 data._hn_halo = shard.halo_overlap(graph, nodeops_tile_rows(Hp))
+        if table_ready is not None:             # (the backward reads the table; by now it has long been written)
+            torch.cuda.current_stream().wait_event(table_ready)
+        graph._keep = None
         x = data.x
         if Hp != H:
             x = x[:, :H]                                                    # the read-out sees the real channels

@@ -277,7 +277,7 @@ class FusedRelationalLayer(torch.autograd.Function):
     """(x, vec, edge) -> (x_out, vec_out) for one layer, relation (row) order."""
 
     @staticmethod
-    def forward(ctx, x, vec, edge, graph, rbf, w, sink=None, li=0, halo=None, defer=False):
+    def forward(ctx, x, vec, edge, graph, rbf, w, sink=None, li=0, halo=None, defer=False, pre=None):
         """`edge`: [E,4], or this layer's handle from `EdgeFanout` ([H/64,E,4] stride-0 view; same memory).
         x / vec live in SOURCE rows, the outputs in TARGET rows; the two coincide for HVNet and differ for HTNet
         (`graph.num_src`: one target row per atom and pair relation, relations.build_triadic).
@@ -286,7 +286,9 @@ class FusedRelationalLayer(torch.autograd.Function):
         that hold no halo row, wait, unpack IN PLACE, project the rest.  The backward mirrors it.
         `defer` (HeteroVertexConv.forward: x and vec are the outputs of the chain layer below and of nothing else): the
         backward hands its input gradients down as partial sums (`nodeops.PendingGrads`) and the update backward of the
-        layer below forms them in its own launch -- two small launches per layer boundary less, same bits."""
+        layer below forms them in its own launch -- two small launches per layer boundary less, same bits.
+        `pre` (chain path without halo): the node projection of THIS x, already launched by the caller (HVNet.forward runs the
+        first layer's beside the relation build)."""
         Ns, H = x.shape
         N = graph.N
         T = graph.T
@@ -300,7 +302,7 @@ class FusedRelationalLayer(torch.autograd.Function):
         if ctx.chain:
             # three launches: node_pre_fwd (LayerNorm + x_proj of every relation), the message kernel, node_update_fwd
             if halo is None:
-                hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges)
+                hb, xh, mean, rstd = pre if pre is not None else nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges)
                 x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False)
             else:
                 # The exchange runs behind the node projection AND the message kernel of every target that reads no
@@ -459,7 +461,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                 work.wait()
             nodeops.halo_accumulate(gx_total, gvec_in, plan, back)                  # gradients of my atoms used elsewhere
             ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
-            return gx_total, gvec_in, ge, None, None, None, None, None, None, None
+            return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None
         ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
         if ctx.chain and _bwd_sums_deferrable(graph, H):
             if ctx.defer and ctx.needs_input_grad[0]:
@@ -471,10 +473,10 @@ class FusedRelationalLayer(torch.autograd.Function):
                     gvec_in.fill_(float("nan"))
                 _PENDING[(gx_total.data_ptr(), gvec_in.data_ptr())] = nodeops.PendingGrads(
                     gx_total, gvec_in, gn_parts, gv_parts, x, mean, rstd, gx1, gvec1, w.h_real)
-                return gx_total, gvec_in, ge, None, None, None, None, None, None, None
+                return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None
             if vec is None and not ctx.needs_input_grad[0]:     # the first layer: nothing below wants gx / gvec
                 _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=False, finish=False)
-                return None, None, ge, None, None, None, None, None, None, None
+                return None, None, ge, None, None, None, None, None, None, None, None
         gxh, gvec_in, gx_in = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=not ctx.chain)
         _virtual_residual(graph, gx1, gvec1, gx_in, gvec_in, H)
         gx_total = None
@@ -486,7 +488,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                 gh = nodeops.ssilu_bwd(ga, h, Ns, T, H, H, Ns * H)                   # [Ns, T*H]
                 gn = _launch("gemm", lambda: torch.mm(gh, w.w1cat))                                           # [N, H]
                 gx_total = nodeops.layernorm_bwd(gn, x, mean, rstd, add=gx_in, h_real=w.h_real)
-        return gx_total, gvec_in, ge, None, None, None, None, None, None, None
+        return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None
 
 
 class EnergyHead(torch.autograd.Function):

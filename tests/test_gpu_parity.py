@@ -880,6 +880,34 @@ def test_deferred_gradient_sums_equal_the_finishing_launches_bit_for_bit(name, w
     assert len(res[1][2]) == len(res[0][2])     # (the same library calls: the launches they no longer make are inside them)
 
 
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
+def test_side_stream_front_of_the_step_changes_no_bit(mode, monkeypatch):
+    """HERMNET_SIDE_STREAM (off by default): relation build beside the first node projection, radial table beside the forward
+    layers, on a second stream -- the same energies and forces, eager and as a captured graph."""
+    from hermnet_amd.graph import GraphedStep
+    dev = _dev()
+    g = Golden("alloy108")
+    model = g.model().to(dev)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    res = []
+    for flag in ("0", mode):
+        monkeypatch.setenv("HERMNET_SIDE_STREAM", flag)
+        d = g.data().to(dev)
+        for _ in range(3):                        # (the second call on the same atoms is the one with a cached row layout)
+            d.pos.requires_grad_(True)
+            e = model(d)
+            f = -torch.autograd.grad(e.sum(), d.pos)[0]
+        torch.cuda.synchronize()
+        step = GraphedStep(model, d)
+        eg, fg = step(d.pos.detach())
+        torch.cuda.synchronize()
+        res.append((e.detach().clone(), f.clone(), eg.clone(), fg.clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[1][0], res[1][2]) and torch.equal(res[1][1], res[1][3])
+
+
 def test_pending_gradients_in_every_update_backward_form():
     """hn_pending_grads straight through the C ABI for the kernel families the model does not defer to by default (the
     wide kernels, 32-row tiles): gx_out / gvec_out formed inside hermnet_node_update_bwd equal the separate launches'."""
