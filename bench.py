@@ -808,6 +808,11 @@ def main():
                 "own_roofline": chain_kernel_bounds(gsum, N, nk, H, T, data.get("_hn_graph")),
                 "own_roofline_note": "per chain kernel: (most workgroups on one CU) x (FLOPs of a workgroup) / 256 FLOP/clk "
                                      "at 2.4 GHz = what the fp32 matrix pipe allows THIS grid; frac = bound / measured"}
+        if H == 128 and os.environ.get("HERMNET_DEFER_SUMS", "1") != "0" and not sharded:
+            mfma["note_pending_grads"] = ("node_update_bwd of layers 0..L-2 also forms its incoming gradients from the partial sums "
+                                          "of the layer above (hn_pending_grads: what message_bwd_finish + layernorm_bwd_parts did "
+                                          "in two launches outside this section): +12-15 us per launch of memory-bound work counted "
+                                          "here, 1 % off the step; HERMNET_DEFER_SUMS=0 gives the separate launches (mfma_util 0.50)")
         names = {"c2": "configs[1]: %d-atom 3-element fcc alloy (Al/Ni/Cu)",
                  "c4": "configs[3]: FIXED %d-atom 3-element fcc alloy cell (10x10x250, 36x36x900 A)",
                  "weak": "weak-scaling variant: %d-atom 3-element fcc alloy cell (10x10x25N)"}

@@ -282,7 +282,13 @@ class HVNet(nn.Module):
         single = shard is None and graph.num_graphs == 1
         if (train or not fused or (self.hidden_channels // 2) % 4 != 0
                 or os.environ.get("HERMNET_FUSED_LAYER", "1") == "0"):
-            e_rows = self.out_energy(x).squeeze(1)                          # hermnet.py:129, row order
+            if train and x.is_cuda and os.environ.get("HERMNET_TRAIN_TALL", "1") != "0":
+                # (the same nn.Sequential, its two Linears through trainops.TallBmm: weight gradients over ~2e4 rows)
+                from .trainops import tall_linear
+                h_ = tall_linear(x, self.out_energy[0].weight, self.out_energy[0].bias)
+                e_rows = tall_linear(self.out_energy[1](h_), self.out_energy[2].weight, self.out_energy[2].bias).squeeze(1)
+            else:
+                e_rows = self.out_energy(x).squeeze(1)                      # hermnet.py:129, row order
             if single:
                 e_rows = e_rows * graph.row_real
         else:

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .ops import MessageScatter, RbfDescriptor
-from .trainops import BucketedBasis, message_scatter_generic
+from .trainops import BucketedBasis, TallBmm, message_scatter_generic
 
 
 class ScaledSiLU(nn.Module):
@@ -284,9 +284,14 @@ def _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed):
     # [T,N,H]-sized ones in every order of differentiation), and the T first Linears become ONE [N,H] x [H,T H] product
     w1f = (w1 * g[:, None, :]).reshape(T * H, H)
     b1f = (b1 + torch.bmm(w1, b[:, :, None]).squeeze(2)).reshape(T * H)
-    h = torch.addmm(b1f, n, w1f.t()).view(-1, T, H).transpose(0, 1)                                   # [T,N,H]
+    # (every node-level Linear below: trainops.TallBmm -- the weight gradients reduce over ~2e4 rows into [H..3H]^2 results,
+    # which the library's single GEMM spreads over a handful of workgroups; there they are batched products over row chunks)
+    tall = x.is_cuda and os.environ.get("HERMNET_TRAIN_TALL", "1") != "0"
+    bmm_b = (lambda a, w, b: TallBmm.apply(a, w, b)) if tall else \
+        (lambda a, w, b: torch.bmm(a, w) if b is None else torch.baddbmm(b[:, None, :], a, w))
+    h = bmm_b(n[None], w1f.t()[None], b1f[None])[0].view(-1, T, H).transpose(0, 1)                    # [T,N,H]
     # (ScaledSiLU's constant factor rides on the following weight, not on the [T,N,H] activations)
-    xh = torch.baddbmm(b2[:, None, :], F.silu(h), (w2 * ml[0].x_proj[1].scale_factor).transpose(1, 2))  # [T,N,3H]
+    xh = bmm_b(F.silu(h), (w2 * ml[0].x_proj[1].scale_factor).transpose(1, 2), b2)                    # [T,N,3H]
     x1, vec1 = message_scatter_generic(xh, vec, x, edge, edge_embed, [m.rbf_proj.weight for m in ml],
                                        [m.rbf_proj.bias for m in ml], graph)
     # --- PaiNNUpdate on the rows of each relation (rmnet.py:94-107), blocks of B rows
@@ -294,12 +299,12 @@ def _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed):
     wx0, bx0 = st(u.xvec_proj[0].weight for u in ul), st(u.xvec_proj[0].bias for u in ul)           # [T,H,2H], [T,H]
     wx2, bx2 = st(u.xvec_proj[2].weight for u in ul), st(u.xvec_proj[2].bias for u in ul)           # [T,3H,H], [T,3H]
     xt, vt = x1[:nk].view(T, B, H), vec1[:nk].view(T, B, 3, H)
-    vp = torch.bmm(vt.reshape(T, B * 3, H), wv.transpose(1, 2)).view(T, B, 3, 2 * H)
+    vp = bmm_b(vt.reshape(T, B * 3, H), wv.transpose(1, 2), None).view(T, B, 3, 2 * H)
     v1, v2 = vp.view(T, B, 3, 2, H).unbind(3)
     vdot = (v1 * v2).sum(dim=2) * ul[0].inv_sqrt_h
     xin = torch.cat([xt, torch.sqrt((v2 ** 2).sum(dim=2) + 1e-8)], dim=-1)                           # [T,B,2H]
-    h2 = torch.baddbmm(bx0[:, None, :], xin, wx0.transpose(1, 2))
-    q = torch.baddbmm(bx2[:, None, :], F.silu(h2), (wx2 * ul[0].xvec_proj[1].scale_factor).transpose(1, 2))
+    h2 = bmm_b(xin, wx0.transpose(1, 2), bx0)
+    q = bmm_b(F.silu(h2), (wx2 * ul[0].xvec_proj[1].scale_factor).transpose(1, 2), bx2)
     q1, q2, q3 = q.view(T, B, 3, H).unbind(2)
     xo = xt + (q1 + q2 * vdot) * ul[0].inv_sqrt_2
     vo = vt + q3.unsqueeze(2) * v1

@@ -124,6 +124,58 @@ class TallLinear(torch.autograd.Function):
         return ga, gw, gb
 
 
+_SPLIT_K_ROWS = 2048          # target rows per chunk (tests shrink it)
+
+
+def _split_k_chunk(K):
+    """A chunk length that divides K (so the chunked views are free), between an eighth of the target and the target."""
+    for n in range(max(1, (K + _SPLIT_K_ROWS - 1) // _SPLIT_K_ROWS), K // max(1, _SPLIT_K_ROWS // 8) + 1):
+        if K % n == 0:
+            return K // n
+    return 0
+
+
+def _gram_over_rows(a, g):
+    """a^T g per relation, [T,K,I] x [T,K,O] -> [T,I,O], as a batched product over K-chunks plus a sum (differentiable torch
+    ops): the reduction over ~2e4 rows into a [128..384]^2 result is a handful of output tiles for the whole chip when left
+    to the library as ONE product (14-24 TFLOP/s measured on the training step's node-level weight gradients)."""
+    T, K, I = a.shape
+    O = g.size(2)
+    C = _split_k_chunk(K) if a.is_contiguous() and g.is_contiguous() else 0
+    if C == 0 or C == K:
+        return torch.bmm(a.transpose(1, 2), g)
+    n = K // C
+    return torch.bmm(a.view(T * n, C, I).transpose(1, 2), g.view(T * n, C, O)).view(T, n, I, O).sum(1)
+
+
+class TallBmm(torch.autograd.Function):
+    """y[t] = a[t] @ w[t] (+ b[t]) for TALL a [T,K,I] (K = the rows of a relation) and small w [T,I,O]: the node-level
+    linears of the training step (rmnet.py:52, 94-100) and the read-out.  Forward and input gradient are ordinary batched
+    GEMMs; the weight gradient goes through `_gram_over_rows`.  The input gradient is again a TallBmm (its own weight
+    gradient, needed by the second-order pass, is the same tall reduction), everything else is differentiable torch code."""
+
+    @staticmethod
+    def forward(ctx, a, w, b):
+        a = a.contiguous()
+        ctx.save_for_backward(a, w)
+        return torch.bmm(a, w) if b is None else torch.baddbmm(b[:, None, :], a, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, w = ctx.saved_tensors
+        g = g.contiguous()
+        ga = TallBmm.apply(g, w.transpose(1, 2), None) if ctx.needs_input_grad[0] else None
+        gw = _gram_over_rows(a, g) if ctx.needs_input_grad[1] else None
+        gb = g.sum(1) if ctx.needs_input_grad[2] else None
+        return ga, gw, gb
+
+
+def tall_linear(a, weight, bias=None):
+    """nn.Linear semantics (y = a W^T + b) for a tall 2-D a through TallBmm."""
+    y = TallBmm.apply(a[None], weight.t()[None], None if bias is None else bias[None])
+    return y[0]
+
+
 def _edge_message_torch(X, R, V, U):
     """The per-edge message algebra of rmnet.py:58-66 in differentiable torch ops (host tensors, widths that are not a
     multiple of 4): S = Xs Rs, M_d = (Xb Rb) U_d + V_d (Xa Ra)."""

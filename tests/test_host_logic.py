@@ -405,3 +405,22 @@ def test_node_chain_restatements_are_consistent(H, T, counts, uniform):
     for (t, cb, q, l, e) in [(0, 0, 0, 0, 0), (T - 1, H // 32 - 1, 2 * H // 8 - 1, 63, 3), (0, 1, 5, 37, 2)]:
         assert float(f[t, cb, q, l, e]) == float(W[t, 32 * cb + (l & 31), 8 * q + 4 * (l >> 5) + e])
     assert torch.equal(f.reshape(T, -1), w.wx0f)
+
+
+def test_tall_bmm_is_a_linear_to_second_order(monkeypatch):
+    """trainops.TallBmm / tall_linear (the node-level linears of the training step): y = a w + b with the weight gradient as a
+    batched product over row chunks -- gradient and gradient-of-gradient vs finite differences in float64, chunked path on."""
+    import hermnet_amd.trainops as tr
+    from torch.autograd import gradcheck, gradgradcheck
+    monkeypatch.setattr(tr, "_SPLIT_K_ROWS", 8)
+    assert tr._split_k_chunk(24) == 8
+    torch.manual_seed(0)
+    mk = lambda *s: torch.randn(*s, dtype=torch.float64, requires_grad=True)
+    a, w, b = mk(2, 24, 3), mk(2, 3, 4), mk(2, 4)
+    f = lambda a, w, b: tr.TallBmm.apply(a, w, b)
+    assert torch.allclose(f(a, w, b), torch.baddbmm(b[:, None, :], a, w))
+    assert gradcheck(f, (a, w, b)) and gradgradcheck(f, (a, w, b))
+    assert gradgradcheck(lambda a, w: tr.TallBmm.apply(a, w, None), (mk(1, 23, 3), mk(1, 3, 2)))     # (no divisor: one product)
+    x, W, bb = mk(24, 5), mk(3, 5), mk(3)
+    assert torch.allclose(tr.tall_linear(x, W, bb), torch.nn.functional.linear(x, W, bb))
+    assert gradgradcheck(lambda x, W, bb: tr.tall_linear(x, W, bb), (x, W, bb))
