@@ -74,6 +74,8 @@ SIGNATURES = {
     "hermnet_build_triadic": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_int,
                                              c_fp, c_fp, ctypes.POINTER(RelationsOut), c_fp, c_fp, ctypes.c_int, c_fp,
                                              ctypes.c_size_t, c_fp]),
+    "hermnet_train_node_op": (ctypes.c_int, [ctypes.c_int, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_long, ctypes.c_int,
+                                             ctypes.c_float, ctypes.c_float, c_fp]),
     "hermnet_segment_sum": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_long, ctypes.c_int, c_fp, c_fp]),
     "hermnet_edge_message_fwd": (ctypes.c_int, [c_fp] * 4 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 6),
     "hermnet_edge_message_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 9),

@@ -14,7 +14,8 @@ import torch.nn.functional as F
 
 from . import _lib
 from .ops import MessageScatter, RbfDescriptor
-from .trainops import BucketedBasis, TallBmm, message_scatter_generic
+from .trainops import (BucketedBasis, LayerNorm2, SiLU2, TallBmm, UpdateMid, UpdateOut, message_scatter_generic,
+                       node_kernels_ok)
 
 
 class ScaledSiLU(nn.Module):
@@ -276,7 +277,11 @@ def _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed):
     ul = [m.update_layer for m in mlist]
     st = lambda ts: torch.stack(list(ts), 0)
     # --- x_proj(LayerNorm(x)) of every relation for every row (rmnet.py:52)
-    n = F.layer_norm(x, (H,))
+    # (LayerNorm, SiLU and the two elementwise stages of PaiNNUpdate: one launch per order of differentiation each,
+    # trainops / csrc/train_node_kernels.hip, where torch's autograd spreads ~120 small launches per layer)
+    fusedn = node_kernels_ok(x)
+    silu = SiLU2.apply if fusedn else F.silu
+    n = LayerNorm2.apply(x, 1e-5) if fusedn else F.layer_norm(x, (H,))
     g, b = st(m.x_layernorm.weight for m in ml), st(m.x_layernorm.bias for m in ml)                 # [T,H]
     w1, b1 = st(m.x_proj[0].weight for m in ml), st(m.x_proj[0].bias for m in ml)                   # [T,H,H], [T,H]
     w2, b2 = st(m.x_proj[2].weight for m in ml), st(m.x_proj[2].bias for m in ml)                   # [T,3H,H], [T,3H]
@@ -291,7 +296,7 @@ def _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed):
         (lambda a, w, b: torch.bmm(a, w) if b is None else torch.baddbmm(b[:, None, :], a, w))
     h = bmm_b(n[None], w1f.t()[None], b1f[None])[0].view(-1, T, H).transpose(0, 1)                    # [T,N,H]
     # (ScaledSiLU's constant factor rides on the following weight, not on the [T,N,H] activations)
-    xh = bmm_b(F.silu(h), (w2 * ml[0].x_proj[1].scale_factor).transpose(1, 2), b2)                    # [T,N,3H]
+    xh = bmm_b(silu(h), (w2 * ml[0].x_proj[1].scale_factor).transpose(1, 2), b2)                      # [T,N,3H]
     x1, vec1 = message_scatter_generic(xh, vec, x, edge, edge_embed, [m.rbf_proj.weight for m in ml],
                                        [m.rbf_proj.bias for m in ml], graph)
     # --- PaiNNUpdate on the rows of each relation (rmnet.py:94-107), blocks of B rows
@@ -300,6 +305,17 @@ def _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed):
     wx2, bx2 = st(u.xvec_proj[2].weight for u in ul), st(u.xvec_proj[2].bias for u in ul)           # [T,3H,H], [T,3H]
     xt, vt = x1[:nk].view(T, B, H), vec1[:nk].view(T, B, 3, H)
     vp = bmm_b(vt.reshape(T, B * 3, H), wv.transpose(1, 2), None).view(T, B, 3, 2 * H)
+    if fusedn:
+        R_ = T * B
+        vdot, xin = UpdateMid.apply(vp.view(R_, 3, 2 * H), xt.reshape(R_, H), ul[0].inv_sqrt_h, 1e-8)
+        h2 = bmm_b(xin.view(T, B, 2 * H), wx0.transpose(1, 2), bx0)
+        q = bmm_b(silu(h2), (wx2 * ul[0].xvec_proj[1].scale_factor).transpose(1, 2), bx2)
+        x_out, v_out = UpdateOut.apply(q.view(R_, 3 * H), vdot, vp.view(R_, 3, 2 * H), xt.reshape(R_, H), vt.reshape(R_, 3, H),
+                                       graph.row_active[:nk].contiguous(), ul[0].inv_sqrt_2)        # (row mask inside)
+        if nk < N:   # atoms whose element is not in `elems`: zero rows (hermnet.py:51)
+            x_out = torch.cat([x_out, x.new_zeros(N - nk, H)], 0)
+            v_out = torch.cat([v_out, x.new_zeros(N - nk, 3, H)], 0)
+        return x_out, v_out
     v1, v2 = vp.view(T, B, 3, 2, H).unbind(3)
     vdot = (v1 * v2).sum(dim=2) * ul[0].inv_sqrt_h
     xin = torch.cat([xt, torch.sqrt((v2 ** 2).sum(dim=2) + 1e-8)], dim=-1)                           # [T,B,2H]

@@ -11,6 +11,8 @@ the parameters, so every op here is differentiable TWICE): the autograd function
 import math
 import os
 
+import ctypes
+
 import torch
 import torch.nn.functional as F
 
@@ -174,6 +176,180 @@ def tall_linear(a, weight, bias=None):
     """nn.Linear semantics (y = a W^T + b) for a tall 2-D a through TallBmm."""
     y = TallBmm.apply(a[None], weight.t()[None], None if bias is None else bias[None])
     return y[0]
+
+
+# ---- node-level stages of the training step as one launch per order of differentiation (csrc/train_node_kernels.hip) ----
+def _node_op(op, ins, outs, rows, H, c0=0.0, c1=0.0):
+    from . import _lib
+    from .ops import _stream
+    ai = (ctypes.c_void_p * len(ins))(*[None if t is None else t.data_ptr() for t in ins])
+    ao = (ctypes.c_void_p * len(outs))(*[None if t is None else t.data_ptr() for t in outs])
+    _lib.check(_lib.load().hermnet_train_node_op(op, ai, len(ins), ao, len(outs), rows, H, c0, c1, _stream()),
+               "hermnet_train_node_op")
+
+
+def node_kernels_ok(x):
+    """The fused node-level stages take fp32 GPU rows whose width is a multiple of 4 (<= 1024)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.size(-1) % 4 == 0 and x.size(-1) <= 1024
+            and os.environ.get("HERMNET_TRAIN_NODE_KERNELS", "1") != "0")
+
+
+class SiLU2(torch.autograd.Function):
+    """x sigmoid(x), differentiable twice with ONE launch per order (torch's own double backward of silu is ~10)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.nn.functional.silu(x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return _SiLUBwd.apply(gy, x)
+
+
+class _SiLUBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy, x):
+        gy, x = _c(gy), _c(x)
+        ctx.save_for_backward(gy, x)
+        gx = torch.empty_like(x)
+        _node_op(1, [gy, x], [gx], x.numel() // 4, 4)
+        return gx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, u):
+        gy, x = ctx.saved_tensors
+        cg, cx = torch.empty_like(x), torch.empty_like(x)
+        _node_op(2, [_c(u), gy, x], [cg, cx], x.numel() // 4, 4)
+        return cg, cx
+
+
+class LayerNorm2(torch.autograd.Function):
+    """LayerNorm without affine over the last axis (rows [N,H]), differentiable twice with one launch per order."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return torch.nn.functional.layer_norm(x, (x.size(-1),), eps=eps)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return _LayerNormBwd.apply(gy, x, ctx.eps), None
+
+
+class _LayerNormBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy, x, eps):
+        gy, x = _c(gy), _c(x)
+        ctx.save_for_backward(gy, x)
+        ctx.eps = eps
+        gx = torch.empty_like(x)
+        _node_op(9, [gy, x], [gx], x.numel() // x.size(-1), x.size(-1), eps)
+        return gx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v):
+        gy, x = ctx.saved_tensors
+        cg, cx = torch.empty_like(x), torch.empty_like(x)
+        _node_op(10, [_c(v), gy, x], [cg, cx], x.numel() // x.size(-1), x.size(-1), ctx.eps)
+        return cg, cx, None
+
+
+class UpdateMid(torch.autograd.Function):
+    """(vp [R,3,2H] = (v1 | v2), xt [R,H]) -> (vec_dot [R,H], [xt | sqrt(sum_d v2^2 + eps)] [R,2H])   (rmnet.py:96-99)."""
+
+    @staticmethod
+    def forward(ctx, vp, xt, c, eps):
+        vp, xt = _c(vp), _c(xt)
+        R, H = xt.shape
+        ctx.save_for_backward(vp)
+        ctx.c, ctx.eps = c, eps
+        vdot, xin = torch.empty_like(xt), torch.empty(R, 2 * H, dtype=xt.dtype, device=xt.device)
+        _node_op(3, [vp, xt], [vdot, xin], R, H, c, eps)
+        return vdot, xin
+
+    @staticmethod
+    def backward(ctx, g_vdot, g_xin):
+        (vp,) = ctx.saved_tensors
+        g_vp, g_xt = _UpdateMidBwd.apply(g_vdot, g_xin, vp, ctx.c, ctx.eps)
+        return g_vp, g_xt, None, None
+
+
+class _UpdateMidBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g_vdot, g_xin, vp, c, eps):
+        g_vdot, g_xin = _c(g_vdot), _c(g_xin)
+        R, H = g_vdot.shape
+        ctx.save_for_backward(g_vdot, g_xin, vp)
+        ctx.c, ctx.eps = c, eps
+        ctx.set_materialize_grads(False)
+        g_vp, g_xt = torch.empty_like(vp), torch.empty_like(g_vdot)
+        _node_op(4, [g_vdot, g_xin, vp], [g_vp, g_xt], R, H, c, eps)
+        return g_vp, g_xt
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, u_vp, u_xt):
+        g_vdot, g_xin, vp = ctx.saved_tensors
+        R, H = g_vdot.shape
+        c_a, c_b, c_vp = torch.empty_like(g_vdot), torch.empty_like(g_xin), torch.empty_like(vp)
+        _node_op(5, [_c(u_vp), _c(u_xt), g_vdot, g_xin, vp], [c_a, c_b, c_vp], R, H, ctx.c, ctx.eps)
+        return c_a, c_b, c_vp, None, None
+
+
+class UpdateOut(torch.autograd.Function):
+    """(q [R,3H], vec_dot, vp, xt, vt [R,3,H], mask [R] | None) -> (m (xt + (q1 + q2 vec_dot) s), m (vt + q3 v1))
+    (rmnet.py:101-107, 29-31; the row mask of hermnet.py:51,56-57)."""
+
+    @staticmethod
+    def forward(ctx, q, vdot, vp, xt, vt, mask, s):
+        q, vdot, vp, xt, vt = _c(q), _c(vdot), _c(vp), _c(xt), _c(vt)
+        R, H = xt.shape
+        ctx.save_for_backward(q, vdot, vp, mask)
+        ctx.s = s
+        ctx.set_materialize_grads(False)
+        xo, vo = torch.empty_like(xt), torch.empty_like(vt)
+        _node_op(6, [q, vdot, vp, xt, vt, mask], [xo, vo], R, H, s)
+        return xo, vo
+
+    @staticmethod
+    def backward(ctx, gx, gv):
+        q, vdot, vp, mask = ctx.saved_tensors
+        if gx is None:
+            gx = torch.zeros_like(vdot)
+        g_q, g_vdot, g_vp, g_xt, g_vt = _UpdateOutBwd.apply(gx, gv, q, vdot, vp, mask, ctx.s)
+        return g_q, g_vdot, g_vp, g_xt, g_vt, None, None
+
+
+class _UpdateOutBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gx, gv, q, vdot, vp, mask, s):
+        gx, gv = _c(gx), _c(gv)
+        R, H = gx.shape
+        ctx.save_for_backward(gx, gv, q, vdot, vp, mask)
+        ctx.s = s
+        ctx.set_materialize_grads(False)
+        g_q, g_vdot, g_vp = torch.empty_like(q), torch.empty_like(vdot), torch.empty_like(vp)
+        g_xt = torch.empty_like(gx)
+        g_vt = torch.empty(R, 3, H, dtype=gx.dtype, device=gx.device)
+        _node_op(7, [gx, gv, q, vdot, vp, mask], [g_q, g_vdot, g_vp, g_xt, g_vt], R, H, s)
+        return g_q, g_vdot, g_vp, g_xt, g_vt
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, c_q, c_vdot, c_vp, c_xt, c_vt):
+        gx, gv, q, vdot, vp, mask = ctx.saved_tensors
+        R, H = gx.shape
+        d_gx, d_q, d_vdot, d_vp = torch.empty_like(gx), torch.empty_like(q), torch.empty_like(vdot), torch.empty_like(vp)
+        d_gv = torch.empty(R, 3, H, dtype=gx.dtype, device=gx.device)
+        _node_op(8, [_c(c_q), _c(c_vdot), _c(c_vp), _c(c_xt), _c(c_vt), gx, gv, q, vdot, vp, mask],
+                 [d_gx, d_gv, d_q, d_vdot, d_vp], R, H, ctx.s)
+        return d_gx, (d_gv if gv is not None else None), d_q, d_vdot, d_vp, None, None
 
 
 def _edge_message_torch(X, R, V, U):

@@ -474,6 +474,28 @@ int hermnet_edge_message_bwd2(const float* cX, const float* cR, const float* cV,
 int hermnet_segment_sum(const float* x, const long* perm, const long* rowptr, long num_rows, int width, float* out,
                         void* stream);
 
+/* Node-level stages of the TRAINING step (train() mode; no reference counterpart beyond the formulas: rmnet.py:52, 94-107,
+ * 110-117, differentiated twice by autograd there).  ONE entry point, ten kernels (csrc/train_node_kernels.hip); `in` / `out`
+ * are host arrays of device pointers, rows x hidden fp32 row-major unless noted, hidden % 4 == 0, hidden <= 1024.
+ * Stages:  SILU y = x sigmoid(x);  LN y = LayerNorm(x) without affine, eps = c0;
+ *          MID (vp [R,3,2H] = (v1 | v2), xt) -> vdot = c0 sum_d v1 v2, xin [R,2H] = (xt | sqrt(sum_d v2^2 + c1));
+ *          OUT (q [R,3H] = (q1|q2|q3), vdot, vp, xt, vt [R,3,H], m [R] or NULL) -> xo = m (xt + (q1 + q2 vdot) c0), vo_d = m (vt_d + q3 v1_d).
+ * `bwd` maps the cotangents of a stage's outputs to those of its inputs, `bwd2` does the same for `bwd` itself.
+ *  op  kernel     in                                                                   out
+ *   1  silu_bwd   gy, x                 (rows = number of float4 elements)              gx
+ *   2  silu_bwd2  u (cot. of gx), gy, x                                                 c_gy, c_x
+ *   3  mid_fwd    vp, xt                                                                vdot, xin
+ *   4  mid_bwd    g_vdot, g_xin, vp                                                     g_vp, g_xt
+ *   5  mid_bwd2   u_vp*, u_xt*, g_vdot, g_xin, vp                                       c_gvdot, c_gxin, c_vp
+ *   6  out_fwd    q, vdot, vp, xt, vt, m*                                               xo, vo
+ *   7  out_bwd    gx, gv, q, vdot, vp, m*                                               g_q, g_vdot, g_vp, g_xt*, g_vt*
+ *   8  out_bwd2   c_gq*, c_gvdot*, c_gvp*, c_gxt*, c_gvt*, gx, gv, q, vdot, vp, m*      d_gx, d_gv, d_q, d_vdot, d_vp
+ *   9  ln_bwd     gy, x                                                                 gx
+ *  10  ln_bwd2    v (cot. of gx), gy, x                                                 c_gy, c_x
+ * (* = may be NULL: a zero cotangent / no mask / an output nobody reads).  num_in / num_out must be the counts above. */
+int hermnet_train_node_op(int op, const float* const* in, int num_in, float* const* out, int num_out, long rows, int hidden,
+                          float c0, float c1, void* stream);
+
 /* Halo exchange packing for atom-sharded runs (one process per GPU; the exchange itself is an RCCL all-to-all made
  * by the host code, hermnet_amd/sharding.py).  A packed row = [ x (H) | vec (3H) ]; idx [n] (int64) holds rows.
  *   mode 0  buf[k] = rows[idx[k]]                         pack what the neighbours need

@@ -453,6 +453,71 @@ def test_edge_message_kernels_match_autograd_to_second_order(E, H, has_v):
             assert rel_err(got[k], ref[k]) < 1e-5, (k, rel_err(got[k], ref[k]))
 
 
+def _second_order_vs_float64(fn_gpu, fn_ref, inputs, dev, tol=2e-5):
+    """outputs, first-order gradients (create_graph=True) and the gradients of a functional of those w.r.t. every input and
+    every first cotangent: a float32 GPU function against its torch expression in float64 on the host."""
+    gen = torch.Generator().manual_seed(7)
+
+    def run(fn, device, dtype):
+        g = torch.Generator().manual_seed(11)
+        t = [None if v is None else v.to(device=device, dtype=dtype).requires_grad_(v.is_floating_point() and v.dim() > 1)
+             for v in inputs]
+        outs = fn(*t)
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        w1 = [torch.randn(o.shape, generator=g).to(device=device, dtype=dtype).requires_grad_(True) for o in outs]
+        leaves = [v for v in t if v is not None and v.requires_grad]
+        L1 = sum((o * w).sum() for o, w in zip(outs, w1))
+        first = torch.autograd.grad(L1, leaves, create_graph=True)
+        w2 = [torch.randn(f.shape, generator=g).to(device=device, dtype=dtype) for f in first]
+        L2 = sum((f * w).sum() for f, w in zip(first, w2))
+        second = torch.autograd.grad(L2, leaves + w1, allow_unused=True)
+        res = list(outs) + list(first) + list(second)
+        return [None if v is None else v.detach().double().cpu() for v in res]
+
+    got, ref = run(fn_gpu, dev, torch.float32), run(fn_ref, torch.device("cpu"), torch.float64)
+    assert len(got) == len(ref)
+    for k, (a, b) in enumerate(zip(got, ref)):
+        if b is None or float(b.abs().max()) == 0.0:
+            assert a is None or float(a.abs().max()) < 1e-6, k
+        else:
+            assert a is not None and rel_err(a, b) < tol, (k, rel_err(a, b))
+
+
+@pytest.mark.parametrize("R,H", [(700, 128), (33, 36), (5, 512)])
+def test_training_node_stage_kernels_match_autograd_to_second_order(R, H):
+    """csrc/train_node_kernels.hip behind trainops.{LayerNorm2, SiLU2, UpdateMid, UpdateOut} (the node-level stages of the
+    training step, one launch per order of differentiation) vs float64 autograd of the torch expressions of rmnet.py:52,
+    94-107, 110-117."""
+    import math
+    import torch.nn.functional as F
+    from hermnet_amd import trainops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(R + H)
+    rnd = lambda *s_: torch.randn(*s_, generator=gen)
+    c, s2 = 1.0 / math.sqrt(H), 1.0 / math.sqrt(2.0)
+    _second_order_vs_float64(lambda x: trainops.LayerNorm2.apply(x, 1e-5), lambda x: F.layer_norm(x, (H,), eps=1e-5),
+                             [rnd(R, H) * 2 + 0.3], dev, tol=1e-4)
+    _second_order_vs_float64(trainops.SiLU2.apply, F.silu, [rnd(R, H) * 2], dev)
+
+    def mid_ref(vp, xt):
+        v1, v2 = vp[..., :H], vp[..., H:]
+        return (v1 * v2).sum(1) * c, torch.cat([xt, torch.sqrt((v2 ** 2).sum(1) + 1e-8)], -1)
+
+    _second_order_vs_float64(lambda vp, xt: trainops.UpdateMid.apply(vp, xt, c, 1e-8), mid_ref, [rnd(R, 3, 2 * H), rnd(R, H)], dev)
+    for mask in (None, (torch.rand(R, generator=gen) > 0.3).float()):
+        def out_ref(q, vdot, vp, xt, vt, m=mask):
+            q1, q2, q3 = q[:, :H], q[:, H:2 * H], q[:, 2 * H:]
+            xo, vo = xt + (q1 + q2 * vdot) * s2, vt + q3[:, None, :] * vp[..., :H]
+            if m is not None:
+                mm = m.to(device=q.device, dtype=q.dtype)
+                xo, vo = xo * mm[:, None], vo * mm[:, None, None]
+            return xo, vo
+
+        mg = None if mask is None else mask.to(dev)
+        _second_order_vs_float64(lambda q, vdot, vp, xt, vt: trainops.UpdateOut.apply(q, vdot, vp, xt, vt, mg, s2), out_ref,
+                                 [rnd(R, 3 * H), rnd(R, H), rnd(R, 3, 2 * H), rnd(R, H), rnd(R, 3, H)], dev)
+
+
 @pytest.mark.parametrize("E,H,R,T,env", [(6000, 128, 128, 3, "polynomial"), (900, 64, 50, 2, "polynomial"), (700, 32, 20, 1, "exponential")])
 def test_bucketed_basis_projection_matches_dense_to_second_order(E, H, R, T, env):
     """`trainops.BucketedBasis` (edges sorted by (relation, distance bucket), 32-centre windows, one batched product) vs the
