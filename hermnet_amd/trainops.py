@@ -150,6 +150,16 @@ def _gram_over_rows(a, g):
     return torch.bmm(a.view(T * n, C, I).transpose(1, 2), g.view(T * n, C, O)).view(T, n, I, O).sum(1)
 
 
+def _col_sum_over_rows(g):
+    """g.sum(1) for a tall [T,K,O]: two stages over row chunks (torch's single reduction over a non-innermost axis runs at
+    0.75 TB/s on these shapes -- 122 us for [3,20172,384] -- the two-stage form at 35 us)."""
+    T, K, O = g.shape
+    C = _split_k_chunk(K) if g.is_contiguous() else 0
+    if C == 0 or C == K:
+        return g.sum(1)
+    return g.view(T, K // C, C, O).sum(2).sum(1)
+
+
 class TallBmm(torch.autograd.Function):
     """y[t] = a[t] @ w[t] (+ b[t]) for TALL a [T,K,I] (K = the rows of a relation) and small w [T,I,O]: the node-level
     linears of the training step (rmnet.py:52, 94-100) and the read-out.  Forward and input gradient are ordinary batched
@@ -168,7 +178,7 @@ class TallBmm(torch.autograd.Function):
         g = g.contiguous()
         ga = TallBmm.apply(g, w.transpose(1, 2), None) if ctx.needs_input_grad[0] else None
         gw = _gram_over_rows(a, g) if ctx.needs_input_grad[1] else None
-        gb = g.sum(1) if ctx.needs_input_grad[2] else None
+        gb = _col_sum_over_rows(g) if ctx.needs_input_grad[2] else None
         return ga, gw, gb
 
 
