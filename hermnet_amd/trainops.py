@@ -80,6 +80,7 @@ class BucketedBasis(object):
     def __init__(self, phi, group, slot, nb, num_radial, pad=None):
         self.phi, self.group, self.slot, self.nb, self.num_radial = phi, group, slot, int(nb), int(num_radial)
         self.pad = pad        # [n_pad] rows of the sorted order that hold no edge
+        self._phi1 = None     # phi with a ones column (project)
 
     def project(self, w_rbf, b_rbf, scale):
         """rbf_proj of every relation (rmnet.py:55) on the bucketed basis -> R [nc * C, 3H] in the sorted edge order;
@@ -93,7 +94,18 @@ class BucketedBasis(object):
         bias = torch.stack([b_rbf[t] * scale for t in range(T)])                             # [T, 3H]
         wc = win.index_select(0, self.group)
         bc = bias.index_select(0, self.group // self.nb)
-        return torch.baddbmm(bc[:, None, :], self.phi, wc).reshape(-1, wc.size(2))
+        if not self.phi.is_cuda or os.environ.get("HERMNET_TRAIN_BIAS_COLUMN", "1") == "0":
+            return torch.baddbmm(bc[:, None, :], self.phi, wc).reshape(-1, wc.size(2))
+        # The bias rides in the product: a column of ones behind the 32 basis columns (4 columns, so that rows stay 16-byte
+        # multiples), the bias as weight row 32.  `baddbmm` with a broadcast bias first COPIES it over the whole [nc, C, 3H]
+        # output (0.2 ms per layer here) and reads it back, and its bias gradient is a reduction over the same 610 MB; this
+        # way the weight-gradient product delivers it in its row 32.
+        if self._phi1 is None:
+            one = self.phi.new_zeros(self.phi.size(0), self.phi.size(1), 4)
+            one[..., 0] = 1.0
+            self._phi1 = torch.cat([self.phi, one], 2)                                        # once per step, all layers
+        w1 = torch.cat([wc, bc[:, None, :], wc.new_zeros(wc.size(0), 3, wc.size(2))], 1)      # [nc, 36, 3H]
+        return torch.bmm(self._phi1, w1).reshape(-1, wc.size(2))
 
 
 class TallLinear(torch.autograd.Function):
