@@ -173,9 +173,9 @@ class RadialBasis(nn.Module):
         order = torch.argsort(key, stable=True)
         ks = key[order]
         slot = torch.empty(Ek, dtype=torch.long, device=dev)
-        slot[order] = start_pad[ks] + torch.arange(Ek, device=dev) - start[ks]
+        slot.scatter_(0, order, start_pad[ks] + torch.arange(Ek, device=dev) - start[ks])     # (a permutation: plain scatter)
         src = torch.full((nc * C,), Ek, dtype=torch.long, device=dev)                        # padding rows -> the dummy entry
-        src[slot] = torch.arange(Ek, device=dev)
+        src.scatter_(0, slot, torch.arange(Ek, device=dev))
         group = torch.repeat_interleave(torch.arange(T * nb, device=dev), torch.tensor(chunks, device=dev))
         # the padding rows (no edge points to them): the edge kernels' R gradients zero these instead of the whole buffer
         import numpy as np
