@@ -76,6 +76,12 @@ SIGNATURES = {
                                              ctypes.c_size_t, c_fp]),
     "hermnet_train_node_op": (ctypes.c_int, [ctypes.c_int, c_fp, ctypes.c_int, c_fp, ctypes.c_int, ctypes.c_long, ctypes.c_int,
                                              ctypes.c_float, ctypes.c_float, c_fp]),
+    "hermnet_edge_message_fwd_rows": (ctypes.c_int, [c_fp] * 4 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 5 + [ctypes.c_long] +
+                                      [c_fp] * 3),
+    "hermnet_edge_message_bwd_rows": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 6 + [ctypes.c_long] +
+                                      [c_fp] * 5),
+    "hermnet_edge_message_bwd2_rows": (ctypes.c_int, [c_fp] * 10 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 6 + [ctypes.c_long] +
+                                       [c_fp] * 7),
     "hermnet_segment_sum": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_long, ctypes.c_int, c_fp, c_fp]),
     "hermnet_edge_message_fwd": (ctypes.c_int, [c_fp] * 4 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 6),
     "hermnet_edge_message_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_long, ctypes.c_int] + [c_fp] * 9),

@@ -47,6 +47,10 @@ struct EdgeMsgArgs {
   // ri: R (and cR) of edge e is row ri[e]; gR / dR are written to that row as well (R may be stored in another edge order,
   // e.g. sorted by distance bucket: rmnet.BucketedBasis)
   const long *xi, *vi, *ti, *ri;
+  // the *_rows kernels: one lane group per OUTPUT ROW g of a grouping of the edges -- its edges are gp[q] (or q itself when
+  // gp is null) for q in [grp[g], grp[g+1]) -- and the quantities that are summed over that grouping never leave registers
+  const long *grp, *gp;
+  long G;
 };
 
 __device__ __forceinline__ size_t row_of(const long* idx, long e) { return (size_t)(idx ? idx[e] : e); }
@@ -168,6 +172,164 @@ __global__ __launch_bounds__(256) void edge_msg_bwd2_kernel(EdgeMsgArgs a) {
 
 
 
+// ---- the same algebra with the row sums inside (MessageAlgebra: node-level inputs AND outputs).  The per-edge kernels
+// above write [E, .] arrays that a segmented sum reads back; here a lane group owns an output row, walks the row's edge
+// list and keeps the sums in registers: forward by TARGET row (both outputs are sums), backward and backward-of-backward by
+// (relation, source) row -- the rows of xh -- so that gX / dX are sums, gV / dV partial sums per relation (the caller adds
+// the T slices: node-sized), and what stays per edge (gR, gU; dGS, dGM, dR, dU) is written as before.
+#define HN_GROUP_PROLOGUE                                                         \
+  constexpr int GPB = 256 / LPE;                                                  \
+  const int l = threadIdx.x % LPE;                                                \
+  const long g = (long)blockIdx.x * GPB + threadIdx.x / LPE;                      \
+  const bool live = g < a.G;                                                      \
+  const int H = a.H, Q = H >> 2;                                                  \
+  const long q0 = live ? a.grp[g] : 0, q1 = live ? a.grp[g + 1] : 0
+
+template <int LPE, bool HAS_V>
+__global__ __launch_bounds__(256) void edge_msg_fwd_rows_kernel(EdgeMsgArgs a) {
+  // o0 = dx [G,H], o1 = dv [G,3,H]
+  HN_GROUP_PROLOGUE;
+  if (!live) return;
+  for (int q = l; q < Q; q += LPE) {
+    const int c = 4 * q;
+    f4 as = (f4){0.f, 0.f, 0.f, 0.f}, m0 = as, m1 = as, m2 = as;
+    for (long k = q0; k < q1; ++k) {
+      const long e = a.gp ? a.gp[k] : k;
+      const float u0 = a.U[3 * e], u1 = a.U[3 * e + 1], u2 = a.U[3 * e + 2];
+      const float* X = a.X + row_of(a.xi, e) * 3 * H;
+      const float* R = a.R + row_of(a.ri, e) * 3 * H;
+      const f4 xs = ld4(X + c), xa = ld4(X + H + c), xb = ld4(X + 2 * H + c);
+      const f4 rs = ld4(R + c), ra = ld4(R + H + c), rb = ld4(R + 2 * H + c);
+      as += xs * rs;
+      const f4 B = xb * rb;
+      m0 += B * u0; m1 += B * u1; m2 += B * u2;
+      if (HAS_V) {
+        const f4 A = xa * ra;
+        const float* V = a.V + row_of(a.vi, e) * 3 * H + c;
+        m0 += ld4(V) * A; m1 += ld4(V + H) * A; m2 += ld4(V + 2 * H) * A;
+      }
+    }
+    st4(a.o0 + (size_t)g * H + c, as);
+    float* M = a.o1 + (size_t)g * 3 * H + c;
+    st4(M, m0); st4(M + H, m1); st4(M + 2 * H, m2);
+  }
+}
+
+template <int LPE, bool HAS_V>
+__global__ __launch_bounds__(256) void edge_msg_bwd_rows_kernel(EdgeMsgArgs a) {
+  // o0 = gX summed [G,3H], o1 = gR [rows of R,3H] per edge, o2 = gV summed per group [G,3,H] (HAS_V), o3 = gU [E,3] per edge
+  HN_GROUP_PROLOGUE;
+  if (!live) return;          // (the channel sums below are shuffles INSIDE a lane group: groups need not walk in step)
+  for (int q = l, pass = 0; q < ((Q + LPE - 1) / LPE) * LPE; q += LPE, ++pass) {
+    const int c = 4 * q;
+    const bool qok = q < Q;
+    f4 sXs = (f4){0.f, 0.f, 0.f, 0.f}, sXa = sXs, sXb = sXs, sV0 = sXs, sV1 = sXs, sV2 = sXs;
+    for (long k = q0; k < q1; ++k) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      const long e = a.gp ? a.gp[k] : k;
+      {
+        if (qok) {
+          const float u0 = a.U[3 * e], u1 = a.U[3 * e + 1], u2 = a.U[3 * e + 2];
+          const size_t bx = row_of(a.xi, e) * 3 * H, bt = row_of(a.ti, e), br = row_of(a.ri, e) * 3 * H;
+          const f4 xs = ld4(a.X + bx + c), xa = ld4(a.X + bx + H + c), xb = ld4(a.X + bx + 2 * H + c);
+          const f4 rs = ld4(a.R + br + c), ra = ld4(a.R + br + H + c), rb = ld4(a.R + br + 2 * H + c);
+          const f4 gs = ld4(a.GS + bt * H + c);
+          const f4 g0 = ld4(a.GM + bt * 3 * H + c), g1 = ld4(a.GM + bt * 3 * H + H + c), g2 = ld4(a.GM + bt * 3 * H + 2 * H + c);
+          const f4 gB = g0 * u0 + g1 * u1 + g2 * u2;
+          f4 gRa = (f4){0.f, 0.f, 0.f, 0.f};
+          if (HAS_V) {
+            const size_t bw = row_of(a.vi, e) * 3 * H;
+            const f4 v0 = ld4(a.V + bw + c), v1 = ld4(a.V + bw + H + c), v2 = ld4(a.V + bw + 2 * H + c);
+            const f4 gA = g0 * v0 + g1 * v1 + g2 * v2, A = xa * ra;
+            sXa += gA * ra; gRa = gA * xa;
+            sV0 += g0 * A; sV1 += g1 * A; sV2 += g2 * A;
+          }
+          sXs += gs * rs; sXb += gB * rb;
+          st4(a.o1 + br + c, gs * xs); st4(a.o1 + br + H + c, gRa); st4(a.o1 + br + 2 * H + c, gB * xb);
+          const f4 B = xb * rb;
+          s0 = hsum(g0 * B); s1 = hsum(g1 * B); s2 = hsum(g2 * B);
+        }
+      }
+      s0 = group_sum<LPE>(s0); s1 = group_sum<LPE>(s1); s2 = group_sum<LPE>(s2);
+      if (l == 0) {
+        if (pass == 0) { a.o3[3 * e] = s0; a.o3[3 * e + 1] = s1; a.o3[3 * e + 2] = s2; }
+        else { a.o3[3 * e] += s0; a.o3[3 * e + 1] += s1; a.o3[3 * e + 2] += s2; }
+      }
+    }
+    if (qok) {
+      float* o = a.o0 + (size_t)g * 3 * H + c;
+      st4(o, sXs); st4(o + H, sXa); st4(o + 2 * H, sXb);
+      if (HAS_V) {
+        float* v = a.o2 + (size_t)g * 3 * H + c;
+        st4(v, sV0); st4(v + H, sV1); st4(v + 2 * H, sV2);
+      }
+    }
+  }
+}
+
+template <int LPE, bool HAS_V>
+__global__ __launch_bounds__(256) void edge_msg_bwd2_rows_kernel(EdgeMsgArgs a) {
+  // o0 = dGS [E,H], o1 = dGM [E,3,H] per edge; o2 = dX summed [G,3H]; o3 = dR per edge; o4 = dV summed per group [G,3,H]
+  // (HAS_V); o5 = dU [E,3] per edge
+  HN_GROUP_PROLOGUE;
+  if (!live) return;
+  for (int q = l, pass = 0; q < ((Q + LPE - 1) / LPE) * LPE; q += LPE, ++pass) {
+    const int c = 4 * q;
+    const bool qok = q < Q;
+    f4 sXs = (f4){0.f, 0.f, 0.f, 0.f}, sXa = sXs, sXb = sXs, sV0 = sXs, sV1 = sXs, sV2 = sXs;
+    for (long k = q0; k < q1; ++k) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      const long e = a.gp ? a.gp[k] : k;
+      {
+        if (qok) {
+          const float u0 = a.U[3 * e], u1 = a.U[3 * e + 1], u2 = a.U[3 * e + 2];
+          const float k0 = a.cU ? a.cU[3 * e] : 0.f, k1 = a.cU ? a.cU[3 * e + 1] : 0.f, k2 = a.cU ? a.cU[3 * e + 2] : 0.f;
+          const size_t b3 = (size_t)e * 3 * H;
+          const size_t bx = row_of(a.xi, e) * 3 * H, bt = row_of(a.ti, e), br = row_of(a.ri, e) * 3 * H;
+          const f4 xs = ld4(a.X + bx + c), xa = ld4(a.X + bx + H + c), xb = ld4(a.X + bx + 2 * H + c);
+          const f4 rs = ld4(a.R + br + c), ra = ld4(a.R + br + H + c), rb = ld4(a.R + br + 2 * H + c);
+          const f4 gs = ld4(a.GS + bt * H + c);
+          const f4 g0 = ld4(a.GM + bt * 3 * H + c), g1 = ld4(a.GM + bt * 3 * H + H + c), g2 = ld4(a.GM + bt * 3 * H + 2 * H + c);
+          const f4 cXs = ld4z(a.cX, bx + c), cXa = ld4z(a.cX, bx + H + c), cXb = ld4z(a.cX, bx + 2 * H + c);
+          const f4 cRs = ld4z(a.cR, br + c), cRa = ld4z(a.cR, br + H + c), cRb = ld4z(a.cR, br + 2 * H + c);
+          st4(a.o0 + (size_t)e * H + c, cXs * rs + cRs * xs);
+          const f4 tB = cXb * rb + cRb * xb, B = xb * rb;
+          const f4 gB = g0 * u0 + g1 * u1 + g2 * u2, sU = g0 * k0 + g1 * k1 + g2 * k2;
+          f4 d0 = tB * u0 + B * k0, d1 = tB * u1 + B * k1, d2 = tB * u2 + B * k2;
+          f4 dRa = (f4){0.f, 0.f, 0.f, 0.f};
+          if (HAS_V) {
+            const size_t bw = row_of(a.vi, e) * 3 * H;
+            const f4 v0 = ld4(a.V + bw + c), v1 = ld4(a.V + bw + H + c), v2 = ld4(a.V + bw + 2 * H + c);
+            const f4 w0 = ld4z(a.cV, bw + c), w1 = ld4z(a.cV, bw + H + c), w2 = ld4z(a.cV, bw + 2 * H + c);
+            const f4 tA = cXa * ra + cRa * xa, A = xa * ra;
+            const f4 gA = g0 * v0 + g1 * v1 + g2 * v2, sV = g0 * w0 + g1 * w1 + g2 * w2;
+            d0 += tA * v0 + w0 * A; d1 += tA * v1 + w1 * A; d2 += tA * v2 + w2 * A;
+            sXa += cRa * gA + ra * sV; dRa = cXa * gA + xa * sV;
+            sV0 += tA * g0; sV1 += tA * g1; sV2 += tA * g2;
+          }
+          st4(a.o1 + b3 + c, d0); st4(a.o1 + b3 + H + c, d1); st4(a.o1 + b3 + 2 * H + c, d2);
+          sXs += cRs * gs; sXb += cRb * gB + rb * sU;
+          st4(a.o3 + br + c, cXs * gs); st4(a.o3 + br + H + c, dRa); st4(a.o3 + br + 2 * H + c, cXb * gB + xb * sU);
+          s0 = hsum(tB * g0); s1 = hsum(tB * g1); s2 = hsum(tB * g2);
+        }
+      }
+      s0 = group_sum<LPE>(s0); s1 = group_sum<LPE>(s1); s2 = group_sum<LPE>(s2);
+      if (l == 0) {
+        if (pass == 0) { a.o5[3 * e] = s0; a.o5[3 * e + 1] = s1; a.o5[3 * e + 2] = s2; }
+        else { a.o5[3 * e] += s0; a.o5[3 * e + 1] += s1; a.o5[3 * e + 2] += s2; }
+      }
+    }
+    if (qok) {
+      float* o = a.o2 + (size_t)g * 3 * H + c;
+      st4(o, sXs); st4(o + H, sXa); st4(o + 2 * H, sXb);
+      if (HAS_V) {
+        float* v = a.o4 + (size_t)g * 3 * H + c;
+        st4(v, sV0); st4(v + H, sV1); st4(v + 2 * H, sV2);
+      }
+    }
+  }
+}
+
 #define HN_EDGE_LAUNCH(KERNEL)                                                                                    \
   do {                                                                                                            \
     const int Q = a.H >> 2;                                                                                       \
@@ -233,6 +395,76 @@ extern "C" int hermnet_edge_message_bwd2(const float* cX, const float* cR, const
   a.xi = x_rows; a.vi = v_rows; a.ti = t_rows; a.ri = r_rows;
   const bool has_v = V != nullptr;
   HN_EDGE_LAUNCH(edge_msg_bwd2_kernel);
+}
+
+#define HN_GROUP_LAUNCH(KERNEL)                                                                                   \
+  do {                                                                                                            \
+    const int Q = a.H >> 2;                                                                                       \
+    int lpe = 1;                                                                                                  \
+    while (lpe < Q && lpe < 64) lpe <<= 1;                                                                        \
+    const unsigned blocks = (unsigned)((a.G + (256 / lpe) - 1) / (256 / lpe));                                    \
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);                                                        \
+    switch (lpe) {                                                                                                \
+      case 1: if (has_v) hipLaunchKernelGGL((KERNEL<1, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<1, false>), dim3(blocks), dim3(256), 0, s, a); break;      \
+      case 2: if (has_v) hipLaunchKernelGGL((KERNEL<2, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<2, false>), dim3(blocks), dim3(256), 0, s, a); break;      \
+      case 4: if (has_v) hipLaunchKernelGGL((KERNEL<4, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<4, false>), dim3(blocks), dim3(256), 0, s, a); break;      \
+      case 8: if (has_v) hipLaunchKernelGGL((KERNEL<8, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<8, false>), dim3(blocks), dim3(256), 0, s, a); break;      \
+      case 16: if (has_v) hipLaunchKernelGGL((KERNEL<16, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<16, false>), dim3(blocks), dim3(256), 0, s, a); break;  \
+      case 32: if (has_v) hipLaunchKernelGGL((KERNEL<32, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<32, false>), dim3(blocks), dim3(256), 0, s, a); break;  \
+      default: if (has_v) hipLaunchKernelGGL((KERNEL<64, true>), dim3(blocks), dim3(256), 0, s, a); else hipLaunchKernelGGL((KERNEL<64, false>), dim3(blocks), dim3(256), 0, s, a); break; \
+    }                                                                                                             \
+    return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;                                               \
+  } while (0)
+
+extern "C" int hermnet_edge_message_fwd_rows(const float* X, const float* R, const float* V, const float* U, long num_edges,
+                                             int hidden, const long* x_rows, const long* v_rows, const long* r_rows,
+                                             const long* group_rowptr, const long* group_edges, long num_groups, float* dx,
+                                             float* dv, void* stream) {
+  if (bad_shape(num_edges, hidden) || num_groups < 0) return HN_ERR_BAD_ARG;
+  if (num_groups == 0) return HN_OK;
+  if (!X || !R || !U || !dx || !dv || !group_rowptr) return HN_ERR_BAD_ARG;
+  EdgeMsgArgs a = {};
+  a.X = X; a.R = R; a.V = V; a.U = U; a.o0 = dx; a.o1 = dv; a.E = num_edges; a.H = hidden; a.xi = x_rows; a.vi = v_rows; a.ri = r_rows;
+  a.grp = group_rowptr; a.gp = group_edges; a.G = num_groups;
+  const bool has_v = V != nullptr;
+  HN_GROUP_LAUNCH(edge_msg_fwd_rows_kernel);
+}
+
+extern "C" int hermnet_edge_message_bwd_rows(const float* GS, const float* GM, const float* X, const float* R, const float* V,
+                                             const float* U, long num_edges, int hidden, const long* x_rows,
+                                             const long* v_rows, const long* t_rows, const long* r_rows,
+                                             const long* group_rowptr, const long* group_edges, long num_groups,
+                                             float* gX_rows, float* gR, float* gV_rows, float* gU, void* stream) {
+  if (bad_shape(num_edges, hidden) || num_groups < 0) return HN_ERR_BAD_ARG;
+  if (num_groups == 0) return HN_OK;
+  if (!GS || !GM || !X || !R || !U || !gX_rows || !gR || !gU || (V && !gV_rows) || !group_rowptr) return HN_ERR_BAD_ARG;
+  EdgeMsgArgs a = {};
+  a.X = X; a.R = R; a.V = V; a.U = U; a.GS = GS; a.GM = GM;
+  a.o0 = gX_rows; a.o1 = gR; a.o2 = gV_rows; a.o3 = gU; a.E = num_edges; a.H = hidden;
+  a.xi = x_rows; a.vi = v_rows; a.ti = t_rows; a.ri = r_rows;
+  a.grp = group_rowptr; a.gp = group_edges; a.G = num_groups;
+  const bool has_v = V != nullptr;
+  HN_GROUP_LAUNCH(edge_msg_bwd_rows_kernel);
+}
+
+extern "C" int hermnet_edge_message_bwd2_rows(const float* cX, const float* cR, const float* cV, const float* cU,
+                                              const float* GS, const float* GM, const float* X, const float* R,
+                                              const float* V, const float* U, long num_edges, int hidden,
+                                              const long* x_rows, const long* v_rows, const long* t_rows,
+                                              const long* r_rows, const long* group_rowptr, const long* group_edges,
+                                              long num_groups, float* dGS, float* dGM, float* dX_rows, float* dR,
+                                              float* dV_rows, float* dU, void* stream) {
+  if (bad_shape(num_edges, hidden) || num_groups < 0) return HN_ERR_BAD_ARG;
+  if (num_groups == 0) return HN_OK;
+  if (!GS || !GM || !X || !R || !U || !dGS || !dGM || !dX_rows || !dR || !dU || (V && !dV_rows) || !group_rowptr)
+    return HN_ERR_BAD_ARG;
+  EdgeMsgArgs a = {};
+  a.X = X; a.R = R; a.V = V; a.U = U; a.GS = GS; a.GM = GM; a.cX = cX; a.cR = cR; a.cV = V ? cV : nullptr; a.cU = cU;
+  a.o0 = dGS; a.o1 = dGM; a.o2 = dX_rows; a.o3 = dR; a.o4 = dV_rows; a.o5 = dU; a.E = num_edges; a.H = hidden;
+  a.xi = x_rows; a.vi = v_rows; a.ti = t_rows; a.ri = r_rows;
+  a.grp = group_rowptr; a.gp = group_edges; a.G = num_groups;
+  const bool has_v = V != nullptr;
+  HN_GROUP_LAUNCH(edge_msg_bwd2_rows_kernel);
 }
 
 // ---- segmented row sum with an optional gather: out[r] = sum_{q in [rowptr[r], rowptr[r+1])} x[perm ? perm[q] : q]

@@ -496,13 +496,21 @@ class MessageAlgebra(torch.autograd.Function):
         k_tgt, k_all, k_xh, r_rows = keys[:4]
         xh, vec, R, U = _c(xh), _c(vec), _c(R), _c(U)
         E, H = U.size(0), R.size(1) // 3
-        S = torch.empty(E, H, dtype=R.dtype, device=R.device)
-        M = torch.empty(E, 3, H, dtype=R.dtype, device=R.device)
         P = _lib.ptr
-        _lib.check(_lib.load().hermnet_edge_message_fwd(P(xh), P(R), P(vec), P(U), E, H, P(k_xh.idx), P(k_all.idx), P(r_rows),
-                                                        P(S), P(M), _stream()), "hermnet_edge_message_fwd")
         ctx.save_for_backward(xh, vec, R, U)
         ctx.keys = keys
+        if _row_sums_inside():
+            # (the sums over a target's edges stay in registers: no [E,4H] round trip through HBM)
+            dx = torch.empty(k_tgt.n_rows, H, dtype=R.dtype, device=R.device)
+            dv = torch.empty(k_tgt.n_rows, 3, H, dtype=R.dtype, device=R.device)
+            _lib.check(_lib.load().hermnet_edge_message_fwd_rows(
+                P(xh), P(R), P(vec), P(U), E, H, P(k_xh.idx), P(k_all.idx), P(r_rows), P(k_tgt.rowptr), P(k_tgt.perm),
+                k_tgt.n_rows, P(dx), P(dv), _stream()), "hermnet_edge_message_fwd_rows")
+            return dx, dv
+        S = torch.empty(E, H, dtype=R.dtype, device=R.device)
+        M = torch.empty(E, 3, H, dtype=R.dtype, device=R.device)
+        _lib.check(_lib.load().hermnet_edge_message_fwd(P(xh), P(R), P(vec), P(U), E, H, P(k_xh.idx), P(k_all.idx), P(r_rows),
+                                                        P(S), P(M), _stream()), "hermnet_edge_message_fwd")
         return _segsum(S, k_tgt), _segsum(M, k_tgt)
 
     @staticmethod
@@ -520,17 +528,26 @@ class MessageAlgebraGrad(torch.autograd.Function):
         E, H = U.size(0), R.size(1) // 3
         g_dx = torch.zeros(k_tgt.n_rows, H, dtype=R.dtype, device=R.device) if g_dx is None else _c(g_dx)
         g_dv = torch.zeros(k_tgt.n_rows, 3, H, dtype=R.dtype, device=R.device) if g_dv is None else _c(g_dv)
-        gX = torch.empty(E, 3 * H, dtype=R.dtype, device=R.device)
         # (R kept in another edge order with padding rows: rows no edge points to get no gradient)
         gR = _rows_buffer(R, r_rows, keys)
-        gV = None if vec is None else torch.empty(E, 3, H, dtype=R.dtype, device=R.device)
         gU = torch.empty_like(U)
         P = _lib.ptr
+        ctx.save_for_backward(g_dx, g_dv, xh, vec, R, U)
+        ctx.keys = keys
+        if _row_sums_inside() and _groups_of_sources(k_xh, k_all):
+            # groups = the (relation, source) rows of xh: gX arrives summed, gV as one partial sum per relation
+            G, Ns = k_xh.n_rows, k_all.n_rows
+            gX = torch.empty(G, 3 * H, dtype=R.dtype, device=R.device)
+            gVp = None if vec is None else torch.empty(G, 3, H, dtype=R.dtype, device=R.device)
+            _lib.check(_lib.load().hermnet_edge_message_bwd_rows(
+                P(g_dx), P(g_dv), P(xh), P(R), P(vec), P(U), E, H, P(k_xh.idx), P(k_all.idx), P(k_tgt.idx), P(r_rows),
+                P(k_xh.rowptr), P(k_xh.perm), G, P(gX), P(gR), P(gVp), P(gU), _stream()), "hermnet_edge_message_bwd_rows")
+            return gX, (None if vec is None else gVp.view(G // Ns, Ns, 3, H).sum(0)), gR, gU
+        gX = torch.empty(E, 3 * H, dtype=R.dtype, device=R.device)
+        gV = None if vec is None else torch.empty(E, 3, H, dtype=R.dtype, device=R.device)
         _lib.check(_lib.load().hermnet_edge_message_bwd(P(g_dx), P(g_dv), P(xh), P(R), P(vec), P(U), E, H, P(k_xh.idx),
                                                         P(k_all.idx), P(k_tgt.idx), P(r_rows), P(gX), P(gR), P(gV), P(gU),
                                                         _stream()), "hermnet_edge_message_bwd")
-        ctx.save_for_backward(g_dx, g_dv, xh, vec, R, U)
-        ctx.keys = keys
         return _segsum(gX, k_xh), (None if vec is None else _segsum(gV, k_all)), gR, gU
 
     @staticmethod
@@ -541,16 +558,35 @@ class MessageAlgebraGrad(torch.autograd.Function):
         E, H = U.size(0), R.size(1) // 3
         c_xh, c_vec, cR, cU = _c(c_xh), _c(c_vec), _c(cR), _c(cU)
         new = lambda *shape: torch.empty(*shape, dtype=R.dtype, device=R.device)
-        dGS, dGM, dX, dU = new(E, H), new(E, 3, H), new(E, 3 * H), new(E, 3)
         dR = _rows_buffer(R, r_rows, ctx.keys)
-        dV = None if vec is None else new(E, 3, H)
         P = _lib.ptr
+        if _row_sums_inside() and _groups_of_sources(k_xh, k_all):
+            G, Ns = k_xh.n_rows, k_all.n_rows
+            dGS, dGM, dX, dU = new(E, H), new(E, 3, H), new(G, 3 * H), new(E, 3)
+            dVp = None if vec is None else new(G, 3, H)
+            _lib.check(_lib.load().hermnet_edge_message_bwd2_rows(
+                P(c_xh), P(cR), P(c_vec), P(cU), P(g_dx), P(g_dv), P(xh), P(R), P(vec), P(U), E, H, P(k_xh.idx), P(k_all.idx),
+                P(k_tgt.idx), P(r_rows), P(k_xh.rowptr), P(k_xh.perm), G, P(dGS), P(dGM), P(dX), P(dR), P(dVp), P(dU),
+                _stream()), "hermnet_edge_message_bwd2_rows")
+            return (_segsum(dGS, k_tgt), _segsum(dGM, k_tgt), dX, (None if vec is None else dVp.view(G // Ns, Ns, 3, H).sum(0)),
+                    dR, dU, None)
+        dGS, dGM, dX, dU = new(E, H), new(E, 3, H), new(E, 3 * H), new(E, 3)
+        dV = None if vec is None else new(E, 3, H)
         _lib.check(_lib.load().hermnet_edge_message_bwd2(P(c_xh), P(cR), P(c_vec), P(cU), P(g_dx), P(g_dv), P(xh), P(R), P(vec),
                                                          P(U), E, H, P(k_xh.idx), P(k_all.idx), P(k_tgt.idx), P(r_rows), P(dGS),
                                                          P(dGM), P(dX), P(dR), P(dV), P(dU), _stream()),
                    "hermnet_edge_message_bwd2")
         return (_segsum(dGS, k_tgt), _segsum(dGM, k_tgt), _segsum(dX, k_xh), (None if vec is None else _segsum(dV, k_all)),
                 dR, dU, None)
+
+
+def _row_sums_inside():
+    return os.environ.get("HERMNET_TRAIN_ROW_SUMS", "1") != "0"
+
+
+def _groups_of_sources(k_xh, k_all):
+    """The (relation, source) groups of k_xh tile the source rows of k_all: T groups per source row."""
+    return k_all.n_rows > 0 and k_xh.n_rows % k_all.n_rows == 0
 
 
 def _train_kernels(t):

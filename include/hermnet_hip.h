@@ -471,6 +471,25 @@ int hermnet_edge_message_bwd2(const float* cX, const float* cR, const float* cV,
 /* Segmented row sum with an optional gather (the adjoint of a row gather; training path, ABI v6):
  * out[r] = sum over q in [rowptr[r], rowptr[r+1]) of x[perm ? perm[q] : q], rows of `width` floats (a multiple of 4),
  * members added in list order (deterministic).  perm [rowptr[num_rows]] int64 or NULL; rowptr [num_rows + 1] int64. */
+/* The same three kernels with the ROW SUMS inside (ABI v8): one lane group per output row of a grouping of the edges --
+ * group g holds the edges group_edges[q] (q itself when group_edges is NULL), q in [group_rowptr[g], group_rowptr[g+1]) --
+ * and whatever is summed over that grouping never reaches HBM per edge.  fwd: groups = target rows, dx [G,H] and dv [G,3,H]
+ * are the sums of S and M.  bwd / bwd2: groups = the (relation, source) rows of xh: gX_rows / dX_rows [G,3H] are the sums,
+ * gV_rows / dV_rows [G,3,H] the per-group partial sums (the caller adds a source's T groups); gR, gU, dGS, dGM, dR, dU stay
+ * per edge as in the kernels above.  Edges in no group are not visited. */
+int hermnet_edge_message_fwd_rows(const float* X, const float* R, const float* V, const float* U, long num_edges, int hidden,
+                                  const long* x_rows, const long* v_rows, const long* r_rows, const long* group_rowptr,
+                                  const long* group_edges, long num_groups, float* dx, float* dv, void* stream);
+int hermnet_edge_message_bwd_rows(const float* GS, const float* GM, const float* X, const float* R, const float* V,
+                                  const float* U, long num_edges, int hidden, const long* x_rows, const long* v_rows,
+                                  const long* t_rows, const long* r_rows, const long* group_rowptr, const long* group_edges,
+                                  long num_groups, float* gX_rows, float* gR, float* gV_rows, float* gU, void* stream);
+int hermnet_edge_message_bwd2_rows(const float* cX, const float* cR, const float* cV, const float* cU, const float* GS,
+                                   const float* GM, const float* X, const float* R, const float* V, const float* U,
+                                   long num_edges, int hidden, const long* x_rows, const long* v_rows, const long* t_rows,
+                                   const long* r_rows, const long* group_rowptr, const long* group_edges, long num_groups,
+                                   float* dGS, float* dGM, float* dX_rows, float* dR, float* dV_rows, float* dU,
+                                   void* stream);
 int hermnet_segment_sum(const float* x, const long* perm, const long* rowptr, long num_rows, int width, float* out,
                         void* stream);
 

@@ -453,6 +453,40 @@ def test_edge_message_kernels_match_autograd_to_second_order(E, H, has_v):
             assert rel_err(got[k], ref[k]) < 1e-5, (k, rel_err(got[k], ref[k]))
 
 
+def test_message_algebra_with_row_sums_inside_equals_the_per_edge_kernels(monkeypatch):
+    """hermnet_edge_message_{fwd,bwd,bwd2}_rows (sums over a row's edges kept in registers) vs the per-edge kernels followed by
+    segmented sums, through a whole training step: loss, energies, forces and every parameter gradient (HVNet with an
+    unknown element in the batch, and HTNet: two row spaces)."""
+    import torch.nn.functional as F
+    import hermnet_amd as hn
+    from hermnet_amd import synth
+    dev = _dev()
+    for cls, elems in ((hn.HVNet, ["H", "C", "O"]), (hn.HVNet, ["H", "C"]), (hn.HTNet, ["H", "C", "O"])):
+        torch.manual_seed(3)
+        d = synth.molecule_batch(num_graphs=24).to(dev)
+        model = cls(elems, rc=5.0, num_layers=3, hidden_channels=64, num_rbf=32)
+        model.load_state_dict(synth.synth_state_dict(model.state_dict(), 12))
+        model = model.to(dev).train()
+        gen = torch.Generator().manual_seed(0)
+        y = torch.randn(24, generator=gen).to(dev)
+        ft = (0.5 * torch.randn(d.pos.shape, generator=gen)).to(dev)
+        res = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("HERMNET_TRAIN_ROW_SUMS", flag)
+            model.zero_grad()
+            d.pos.requires_grad_(True)
+            e = model(d)
+            f = -torch.autograd.grad(e.sum(), d.pos, create_graph=True)[0]
+            loss = 0.2 * F.mse_loss(e, y) + 0.8 * F.mse_loss(f, ft)
+            loss.backward()
+            res.append((e.detach().clone(), f.detach().clone(),
+                        {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+        assert rel_err(res[1][0], res[0][0]) < 2e-6 and rel_err(res[1][1], res[0][1]) < 5e-6
+        assert set(res[0][2]) == set(res[1][2]) and len(res[0][2]) > 0
+        for n in res[0][2]:
+            assert rel_err(res[1][2][n], res[0][2][n]) < 2e-5, n
+
+
 def _second_order_vs_float64(fn_gpu, fn_ref, inputs, dev, tol=2e-5):
     """outputs, first-order gradients (create_graph=True) and the gradients of a functional of those w.r.t. every input and
     every first cotangent: a float32 GPU function against its torch expression in float64 on the host."""
