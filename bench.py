@@ -589,7 +589,19 @@ def main():
     torch.cuda.set_device(dev)
     if sharded:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # (this pool exports NCCL_DEBUG=VERSION and RCCL prints its banner with printf: it would land on stdout in front
+            # of the JSON line -- the communicator is created with file descriptor 1 pointing at stderr)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+                dist.barrier(device_ids=[dev.index])
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
         else:
             dist.init_process_group("gloo")
 
