@@ -197,6 +197,26 @@ __global__ __launch_bounds__(256) void out_bwd2_kernel(NodeOpArgs a) {
   st(a.out[3], r * H + c, gx * k2 * a.c0);
 }
 
+// ---- RES: the residual behind the message (rmnet.py:24-26) with the row mask of hermnet.py:51:
+//   x1 = m c0 (x + dx),  v1_d = m (v_d + dv_d)        (v may be NULL: layer 0, vec = 0)
+// Linear, so its backward is the mask-and-scale  (g1, gv1) -> (m c0 g1, m gv1)  for BOTH summands, and that map is its own
+// backward.
+__global__ __launch_bounds__(256) void res_fwd_kernel(NodeOpArgs a) {
+  HN_ROW_QUAD;
+  const float m = a.in[4] ? a.in[4][r] : 1.0f;
+  st(a.out[0], r * H + c, (ld(a.in[0], r * H + c) + ld(a.in[1], r * H + c)) * (m * a.c0));
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+    st(a.out[1], (r * 3 + d) * H + c, (ldz(a.in[2], (r * 3 + d) * H + c) + ld(a.in[3], (r * 3 + d) * H + c)) * m);
+}
+__global__ __launch_bounds__(256) void mask_scale_kernel(NodeOpArgs a) {
+  HN_ROW_QUAD;
+  const float m = a.in[2] ? a.in[2][r] : 1.0f;
+  st(a.out[0], r * H + c, ldz(a.in[0], r * H + c) * (m * a.c0));
+#pragma unroll
+  for (int d = 0; d < 3; ++d) st(a.out[1], (r * 3 + d) * H + c, ldz(a.in[1], (r * 3 + d) * H + c) * m);
+}
+
 // ---- LN (one wave per row; lane l: channel quads l, l + 64, ...; H <= 1024) --------------------------------------------
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
@@ -288,11 +308,11 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(NodeOpArgs a) {
 
 }  // namespace
 
-// One entry point for the ten kernels (include/hermnet_hip.h lists the operands of every op).
+// One entry point for the twelve kernels (include/hermnet_hip.h lists the operands of every op).
 extern "C" int hermnet_train_node_op(int op, const float* const* in, int num_in, float* const* out, int num_out, long rows,
                                      int hidden, float c0, float c1, void* stream) {
-  static const int need_in[11] = {0, 2, 3, 2, 3, 5, 6, 6, 11, 2, 3}, need_out[11] = {0, 1, 2, 2, 2, 3, 2, 5, 5, 1, 2};
-  if (op < 1 || op > 10 || !in || !out || num_in != need_in[op] || num_out != need_out[op]) return HN_ERR_BAD_ARG;
+  static const int need_in[13] = {0, 2, 3, 2, 3, 5, 6, 6, 11, 2, 3, 5, 3}, need_out[13] = {0, 1, 2, 2, 2, 3, 2, 5, 5, 1, 2, 2, 2};
+  if (op < 1 || op > 12 || !in || !out || num_in != need_in[op] || num_out != need_out[op]) return HN_ERR_BAD_ARG;
   if (rows < 0 || hidden <= 0 || (hidden & 3) != 0 || hidden > 1024) return HN_ERR_BAD_ARG;
   if (rows == 0) return HN_OK;
   NodeOpArgs a = {};
@@ -306,6 +326,8 @@ extern "C" int hermnet_train_node_op(int op, const float* const* in, int num_in,
       case 6: return i == 5;                 // mask
       case 7: return i == 1 || i == 5;       // gv (the last layer's vec output feeds nothing), mask
       case 8: return i <= 4 || i == 6 || i == 10;      // the five cotangents, gv, mask
+      case 11: return i == 2 || i == 4;                // vec (layer 0), mask
+      case 12: return true;                            // either cotangent, mask
       default: return false;
     }
   };
@@ -325,6 +347,8 @@ extern "C" int hermnet_train_node_op(int op, const float* const* in, int num_in,
     case 6: hipLaunchKernelGGL(out_fwd_kernel, dim3(gq), dim3(256), 0, s, a); break;
     case 7: hipLaunchKernelGGL(out_bwd_kernel, dim3(gq), dim3(256), 0, s, a); break;
     case 8: hipLaunchKernelGGL(out_bwd2_kernel, dim3(gq), dim3(256), 0, s, a); break;
+    case 11: hipLaunchKernelGGL(res_fwd_kernel, dim3(gq), dim3(256), 0, s, a); break;
+    case 12: hipLaunchKernelGGL(mask_scale_kernel, dim3(gq), dim3(256), 0, s, a); break;
     case 9: hipLaunchKernelGGL(ln_bwd_kernel, dim3(gr), dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL(ln_bwd2_kernel, dim3(gr), dim3(256), 0, s, a); break;
   }

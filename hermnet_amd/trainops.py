@@ -282,6 +282,51 @@ class _LayerNormBwd(torch.autograd.Function):
         return cg, cx, None
 
 
+class Residual(torch.autograd.Function):
+    """x1 = m c (x + dx), vec1 = m (vec + dvec): the residual behind the message (rmnet.py:24-26) with the row mask of
+    hermnet.py:51 -- one launch instead of five; its backward `_MaskScale` (one launch) serves both summands and is its own
+    backward."""
+
+    @staticmethod
+    def forward(ctx, x, dx, vec, dv, mask, c):
+        x, dx, vec, dv = _c(x), _c(dx), _c(vec), _c(dv)
+        R, H = x.shape
+        ctx.save_for_backward(mask)
+        ctx.c, ctx.has_vec = c, vec is not None
+        ctx.set_materialize_grads(False)
+        x1, v1 = torch.empty_like(x), torch.empty_like(dv)
+        _node_op(11, [x, dx, vec, dv, mask], [x1, v1], R, H, c)
+        return x1, v1
+
+    @staticmethod
+    def backward(ctx, g1, gv1):
+        (mask,) = ctx.saved_tensors
+        gx, gv = _MaskScale.apply(g1, gv1, mask, ctx.c)
+        return gx, gx, (gv if ctx.has_vec else None), gv, None, None
+
+
+class _MaskScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g1, gv1, mask, c):
+        ref = g1 if g1 is not None else gv1
+        R, H = ref.size(0), ref.size(-1)
+        ctx.save_for_backward(mask)
+        ctx.c = c
+        ctx.set_materialize_grads(False)
+        o1 = torch.empty(R, H, dtype=ref.dtype, device=ref.device)
+        o2 = torch.empty(R, 3, H, dtype=ref.dtype, device=ref.device)
+        _node_op(12, [_c(g1), _c(gv1), mask], [o1, o2], R, H, c)
+        return o1, o2
+
+    @staticmethod
+    def backward(ctx, u1, uv):
+        (mask,) = ctx.saved_tensors
+        if u1 is None and uv is None:
+            return None, None, None, None
+        a, b = _MaskScale.apply(u1, uv, mask, ctx.c)
+        return a, b, None, None
+
+
 class UpdateMid(torch.autograd.Function):
     """(vp [R,3,2H] = (v1 | v2), xt [R,H]) -> (vec_dot [R,H], [xt | sqrt(sum_d v2^2 + eps)] [R,2H])   (rmnet.py:96-99)."""
 
@@ -684,6 +729,8 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     # the residual (rmnet.py:24-26) reads the target atom's own row: the same row for HVNet, `res_row` for HTNet
     xr = x if k_res is None else GatherRows.apply(x, k_res)
     vr = 0 if vec is None else (vec if k_res is None else GatherRows.apply(vec, k_res))
+    if node_kernels_ok(x) and torch.is_tensor(dx) and dx.size(0) == xr.size(0):
+        return Residual.apply(xr, dx, (None if vec is None else vr), dv, known, 1 / math.sqrt(2.0))
     x1 = (xr + dx) * (1 / math.sqrt(2.0)) * known[:, None]
     vec1 = (vr + dv) * known[:, None, None]
     return x1, vec1

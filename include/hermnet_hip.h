@@ -494,7 +494,7 @@ int hermnet_segment_sum(const float* x, const long* perm, const long* rowptr, lo
                         void* stream);
 
 /* Node-level stages of the TRAINING step (train() mode; no reference counterpart beyond the formulas: rmnet.py:52, 94-107,
- * 110-117, differentiated twice by autograd there).  ONE entry point, ten kernels (csrc/train_node_kernels.hip); `in` / `out`
+ * 110-117, differentiated twice by autograd there).  ONE entry point, twelve kernels (csrc/train_node_kernels.hip); `in` / `out`
  * are host arrays of device pointers, rows x hidden fp32 row-major unless noted, hidden % 4 == 0, hidden <= 1024.
  * Stages:  SILU y = x sigmoid(x);  LN y = LayerNorm(x) without affine, eps = c0;
  *          MID (vp [R,3,2H] = (v1 | v2), xt) -> vdot = c0 sum_d v1 v2, xin [R,2H] = (xt | sqrt(sum_d v2^2 + c1));
@@ -511,6 +511,8 @@ int hermnet_segment_sum(const float* x, const long* perm, const long* rowptr, lo
  *   8  out_bwd2   c_gq*, c_gvdot*, c_gvp*, c_gxt*, c_gvt*, gx, gv, q, vdot, vp, m*      d_gx, d_gv, d_q, d_vdot, d_vp
  *   9  ln_bwd     gy, x                                                                 gx
  *  10  ln_bwd2    v (cot. of gx), gy, x                                                 c_gy, c_x
+ *  11  res_fwd    x, dx, v* [R,3,H], dv, m*    (rmnet.py:24-26: x1 = m c0 (x + dx), v1 = m (v + dv))   x1, v1
+ *  12  mask_scale g1*, gv1*, m*   (its backward, for both summands, and its own backward)         m c0 g1, m gv1
  * (* = may be NULL: a zero cotangent / no mask / an output nobody reads).  num_in / num_out must be the counts above. */
 int hermnet_train_node_op(int op, const float* const* in, int num_in, float* const* out, int num_out, long rows, int hidden,
                           float c0, float c1, void* stream);

@@ -550,6 +550,16 @@ def test_training_node_stage_kernels_match_autograd_to_second_order(R, H):
         mg = None if mask is None else mask.to(dev)
         _second_order_vs_float64(lambda q, vdot, vp, xt, vt: trainops.UpdateOut.apply(q, vdot, vp, xt, vt, mg, s2), out_ref,
                                  [rnd(R, 3 * H), rnd(R, H), rnd(R, 3, 2 * H), rnd(R, H), rnd(R, 3, H)], dev)
+        for has_vec in (True, False):
+            def res_ref(x, dx, v, dv, m=mask):
+                x1, v1 = (x + dx) * s2, (dv if v is None else v + dv)
+                if m is not None:
+                    mm = m.to(device=x.device, dtype=x.dtype)
+                    x1, v1 = x1 * mm[:, None], v1 * mm[:, None, None]
+                return x1, v1
+
+            _second_order_vs_float64(lambda x, dx, v, dv: trainops.Residual.apply(x, dx, v, dv, mg, s2), res_ref,
+                                     [rnd(R, H), rnd(R, H), rnd(R, 3, H) if has_vec else None, rnd(R, 3, H)], dev)
 
 
 @pytest.mark.parametrize("E,H,R,T,env", [(6000, 128, 128, 3, "polynomial"), (900, 64, 50, 2, "polynomial"), (700, 32, 20, 1, "exponential")])
