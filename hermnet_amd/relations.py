@@ -200,9 +200,12 @@ class RelationalGraph(object):
         g.batch32 = rows["batch32"]
         g.batch_rows = None
         if batch is not None and g.num_graphs > 1:
-            g.graph_perm = torch.argsort(batch.long(), stable=True)
-            g.graph_lengths = torch.zeros(g.num_graphs, dtype=torch.long, device=dev).index_add_(
-                0, batch.long(), torch.ones_like(batch.long()))
+            if "graph_perm" not in rows:          # (depends on the batch vector only, like the row layout: once per atom set)
+                b64 = batch.long()
+                rows["graph_perm"] = torch.argsort(b64, stable=True)
+                rows["graph_lengths"] = torch.zeros(g.num_graphs, dtype=torch.long, device=dev).index_add_(
+                    0, b64, torch.ones_like(b64))
+            g.graph_perm, g.graph_lengths = rows["graph_perm"], rows["graph_lengths"]
         else:
             g.graph_perm = None
             g.graph_lengths = None
