@@ -322,7 +322,10 @@ class HVNet(nn.Module):
         else:
             # (unsafe=True: no host-side validation of `lengths` -- they come from the same `batch` vector; the check
             # would synchronise, which also forbids capturing the step into a hipGraph)
-            energy = torch.segment_reduce(per_atom_energy[graph.graph_perm], "sum", lengths=graph.graph_lengths, unsafe=True)
+            # (index_select, not [perm]: the backward of advanced indexing sorts its indices -- a dozen launches -- where a
+            # permutation needs none; index_select's backward adds without collisions here, so it stays deterministic)
+            energy = torch.segment_reduce(per_atom_energy.index_select(0, graph.graph_perm), "sum", lengths=graph.graph_lengths,
+                                          unsafe=True)
         if self.intensive:
             energy = energy / graph.graph_lengths.clamp(min=1).to(energy.dtype)
         return energy
