@@ -126,3 +126,34 @@ def test_default_message_kernels_fit_their_register_budget(tmp_path):
         assert get("vgpr_count") <= 128, (name, get("vgpr_count"))
         assert get("vgpr_spill_count") == 0 and get("sgpr_spill_count") == 0, name
         assert get("private_segment_fixed_size") == 0, name
+
+
+def test_argument_checks_of_the_round_4_entry_points_need_no_gpu():
+    """The entry points added with ABI v8 refuse malformed calls before anything is launched (and treat empty inputs as
+    done), so their argument contracts can be checked here: hermnet_train_node_op (operand counts per op), the *_rows edge
+    kernels, hn_pending_grads of hermnet_node_update_bwd."""
+    lib = _lib.load()
+    HN_OK, BAD = 0, lib.hermnet_train_node_op(0, None, 0, None, 0, 0, 4, 0.0, 0.0, None)
+    assert BAD != HN_OK
+    buf = np.zeros(64, dtype=np.float32)
+    ptr = buf.ctypes.data
+    arr = lambda n: (ctypes.c_void_p * max(n, 1))(*([ptr] * n))
+    need_in = {1: 2, 2: 3, 3: 2, 4: 3, 5: 5, 6: 6, 7: 6, 8: 11, 9: 2, 10: 3, 11: 5, 12: 3}
+    need_out = {1: 1, 2: 2, 3: 2, 4: 2, 5: 3, 6: 2, 7: 5, 8: 5, 9: 1, 10: 2, 11: 2, 12: 2}
+    for op in need_in:
+        ni, no = need_in[op], need_out[op]
+        assert lib.hermnet_train_node_op(op, arr(ni), ni, arr(no), no, 0, 128, 0.0, 0.0, None) == HN_OK        # no rows: done
+        assert lib.hermnet_train_node_op(op, arr(ni), ni + 1, arr(no), no, 0, 128, 0.0, 0.0, None) == BAD     # operand count
+        assert lib.hermnet_train_node_op(op, arr(ni), ni, arr(no), no, 0, 130, 0.0, 0.0, None) == BAD         # width % 4
+    assert lib.hermnet_train_node_op(13, arr(2), 2, arr(1), 1, 0, 128, 0.0, 0.0, None) == BAD
+    # the row-sum edge kernels: a negative group count is refused, no groups = nothing to do
+    assert lib.hermnet_edge_message_fwd_rows(ptr, ptr, None, ptr, 0, 128, None, None, None, ptr, None, -1, ptr, ptr, None) == BAD
+    assert lib.hermnet_edge_message_fwd_rows(ptr, ptr, None, ptr, 0, 128, None, None, None, ptr, None, 0, ptr, ptr, None) == HN_OK
+    assert lib.hermnet_edge_message_fwd_rows(ptr, ptr, None, ptr, 0, 130, None, None, None, ptr, None, 0, ptr, ptr, None) == BAD
+    # hn_pending_grads: every pointer of the record is required
+    rp = (ctypes.c_int * 2)(0, 5)
+    pend = _lib.PendingGrads(ptr, None, ptr, ptr, ptr, ptr, ptr, 1, 0)
+    assert lib.hermnet_node_update_bwd(ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, None, ptr, rp, ptr, ptr, 5, 1, 128, 0,
+                                       ctypes.byref(pend), None) == BAD
+    assert lib.hermnet_node_update_bwd(ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, None, ptr, rp, ptr, ptr, 0, 1, 128, 0,
+                                       None, None) == HN_OK                                                 # no rows
