@@ -149,8 +149,13 @@ class HVNet(nn.Module):
         """`with_edge` (hermnet.py:133-152) as differentiable device ops, CSR order -> edge[E,4] = (rhat, d).
         Training path only: `create_graph=True` needs second derivatives, which the geometry kernel's
         hand-written backward does not provide."""
-        src, tgt = graph.src_id.long(), graph.tgt_id.long()
-        D = pos[src] - pos[tgt]
+        src = graph.src_id.long()
+        if (pos.is_cuda and not graph.num_src and graph.csc_pos is not None
+                and os.environ.get("HERMNET_TRAIN_KERNELS", "1") != "0"):
+            from .trainops import EdgeDiff
+            D = EdgeDiff.apply(pos, graph)          # (gather and its adjoint as a closed pair: no index sort, no atomics)
+        else:
+            D = pos[src] - pos[graph.tgt_id.long()]
         if graph.shift is not None and cell is not None:
             c = cell.reshape(-1, 3, 3)
             D = D + torch.einsum("ni,nij->nj", graph.shift.to(D.dtype), c[graph.batch32.long()[src]])

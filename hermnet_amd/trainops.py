@@ -26,7 +26,7 @@ class _RowKey(object):
 
     def __init__(self, idx, perm, lengths, n_rows):
         self.idx, self.perm, self.lengths, self.n_rows = idx, perm, lengths, int(n_rows)
-        self.rowptr = torch.zeros(self.n_rows + 1, dtype=torch.long, device=idx.device)
+        self.rowptr = torch.zeros(self.n_rows + 1, dtype=torch.long, device=lengths.device)
         self.rowptr[1:] = torch.cumsum(lengths, 0)
 
 
@@ -64,6 +64,59 @@ class SumRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return GatherRows.apply(g, ctx.key), None
+
+
+class EdgeDiff(torch.autograd.Function):
+    """D[e] = pos[source(e)] - pos[target(e)] over the CSR edges (hermnet.py:135-139) and its adjoint `_EdgeDiffT`, each the
+    other's backward (both are linear): differentiable to any order without `index_put_(accumulate=True)` -- the backward of
+    `pos[idx]`, which sorts its 4e5 indices every time (0.27 ms per call here) -- and without float atomics.  The adjoint
+    sums the edge gradients per TARGET row (the CSR segments) and per (relation, SOURCE row) (the CSC segments; edges into
+    atoms of an unknown element are in none of them and carry no gradient), then reads each atom's row."""
+
+    @staticmethod
+    def forward(ctx, pos, graph):
+        ctx.graph = graph
+        s, t = _edge_atoms(graph)
+        return pos.index_select(0, s) - pos.index_select(0, t)
+
+    @staticmethod
+    def backward(ctx, gD):
+        return _EdgeDiffT.apply(gD, ctx.graph), None
+
+
+class _EdgeDiffT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gD, graph):
+        ctx.graph = graph
+        k_t, k_s, T, N = _edge_sum_keys(graph)
+        g4 = F.pad(gD, (0, 1)).contiguous()                               # (the sum kernel takes float4 rows)
+        rows = _segsum(g4, k_s).view(T, N, 4).sum(0) - _segsum(g4, k_t)     # per row: + as a source, - as a target
+        return rows.index_select(0, graph.row_of_node)[:, :3]
+
+    @staticmethod
+    def backward(ctx, c):
+        return EdgeDiff.apply(c.contiguous(), ctx.graph), None
+
+
+def _edge_atoms(graph):
+    """(source atom, target atom) of every CSR edge as int64, once per graph."""
+    ea = getattr(graph, "_edge_atoms64", None)
+    if ea is None:
+        ea = graph._edge_atoms64 = (graph.src_id.long(), graph.tgt_id.long())
+    return ea
+
+
+def _edge_sum_keys(graph):
+    """Row keys of the adjoint of EdgeDiff: every CSR edge by its target row; the CSC edges by (relation, source row)."""
+    ks = getattr(graph, "_edge_sum_keys", None)
+    if ks is None:
+        T, N = graph.T, graph.N
+        rp = graph.csr_rowptr.long()
+        k_t = _RowKey(None, None, rp[1:] - rp[:-1], N)
+        crp = graph.csc_rowptr.long()[:T * N + 1]
+        k_s = _RowKey(None, graph.csc_pos.long(), crp[1:] - crp[:-1], T * N)
+        ks = graph._edge_sum_keys = (k_t, k_s, T, N)
+    return ks
 
 
 class BucketedBasis(object):

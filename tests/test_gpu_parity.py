@@ -487,6 +487,35 @@ def test_message_algebra_with_row_sums_inside_equals_the_per_edge_kernels(monkey
             assert rel_err(res[1][2][n], res[0][2][n]) < 2e-5, n
 
 
+@pytest.mark.parametrize("name", ["alloy108", "alloy108_unknown_type", "mol16"])
+def test_edge_difference_and_its_adjoint_match_indexing_to_second_order(name):
+    """trainops.EdgeDiff (D = pos[source] - pos[target] with a sort-free, atomics-free adjoint built from the CSR / CSC
+    segments) vs plain tensor indexing: values, gradient, gradient of a functional of the gradient."""
+    from hermnet_amd import trainops
+    from hermnet_amd.elements import atomic_numbers
+    dev = _dev()
+    g = Golden(name)
+    d = g.data().to(dev)
+    graph = RelationalGraph.build(d.atomic_number, d.edge_index, [atomic_numbers[e] for e in g.elems],
+                                  d.get("edge_shift") if d.get("cell") is not None else None, d.batch)
+    src, tgt = graph.src_id.long(), graph.tgt_id.long()
+    gen = torch.Generator().manual_seed(1)
+    w1 = torch.randn(graph.E, 3, generator=gen).to(dev)
+    w2 = torch.randn(d.pos.shape, generator=gen).to(dev)
+    T = graph.T
+    known = (torch.arange(graph.E, device=dev) < int(graph.csr_rowptr[int(graph.type_rowptr_host[-1])])).float()[:, None]
+    res = []
+    for fn in (lambda p: trainops.EdgeDiff.apply(p, graph), lambda p: p[src] - p[tgt]):
+        p = d.pos.clone().requires_grad_(True)
+        D = fn(p)
+        # (edges into atoms of an unknown element carry no gradient in the model: the adjoint leaves them out on purpose)
+        (g1,) = torch.autograd.grad(((D ** 2) * w1 * known).sum(), p, create_graph=True)
+        (g2,) = torch.autograd.grad((g1 * w2).sum(), p)
+        res.append((D.detach(), g1.detach(), g2))
+    assert torch.equal(res[0][0], res[1][0])
+    assert rel_err(res[0][1], res[1][1]) < 1e-5 and rel_err(res[0][2], res[1][2]) < 1e-5
+
+
 def _second_order_vs_float64(fn_gpu, fn_ref, inputs, dev, tol=2e-5):
     """outputs, first-order gradients (create_graph=True) and the gradients of a functional of those w.r.t. every input and
     every first cotangent: a float32 GPU function against its torch expression in float64 on the host."""
