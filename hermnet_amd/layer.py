@@ -268,7 +268,7 @@ class EdgeFanout(torch.autograd.Function):
         return (torch.stack(live, 0).sum(0) if live else None), None
 
 
-# gradients handed down as partial sums, keyed by the addresses of the buffers the consumer fills (nodeops.PendingGrads);
+# gradients handed down as partial sums, keyed by (graph, index of the consuming layer) (nodeops.PendingGrads);
 # an entry lives from one layer's backward to the next one's (HVNet.forward clears leftovers of an interrupted pass)
 _PENDING = {}
 
@@ -391,8 +391,12 @@ class FusedRelationalLayer(torch.autograd.Function):
         if ctx.chain:
             x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23, nrm = ctx.saved_tensors
             Ns, H = x.shape
-            # (the layer above may have left its finishing launches to this one: the buffers arrive unfilled)
-            pend = _PENDING.pop((gxo.data_ptr(), gvo.data_ptr()), None)
+            # (the layer above may have left its finishing launches to this one: the buffers arrive unfilled -- and they must be
+            # the very buffers it registered: a copy made on the way would hold garbage, so that is refused loudly)
+            pend = _PENDING.pop((id(graph), ctx.li), None)
+            if pend is not None and (pend.gx.data_ptr() != gxo.data_ptr() or pend.gvec.data_ptr() != gvo.data_ptr()):
+                raise RuntimeError("hermnet_amd: the gradients handed down as partial sums (layer %d) did not arrive in the "
+                                   "buffers they were registered with; set HERMNET_DEFER_SUMS=0" % (ctx.li + 1))
             gx1, gvec1 = nodeops.node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph, pending=pend)
         else:
             x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q = ctx.saved_tensors
@@ -471,7 +475,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                 if _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":            # (tests: nothing reads them before that)
                     gx_total.fill_(float("nan"))
                     gvec_in.fill_(float("nan"))
-                _PENDING[(gx_total.data_ptr(), gvec_in.data_ptr())] = nodeops.PendingGrads(
+                _PENDING[(id(graph), ctx.li - 1)] = nodeops.PendingGrads(
                     gx_total, gvec_in, gn_parts, gv_parts, x, mean, rstd, gx1, gvec1, w.h_real)
                 return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None
             if vec is None and not ctx.needs_input_grad[0]:     # the first layer: nothing below wants gx / gvec
