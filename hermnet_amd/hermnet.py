@@ -86,6 +86,33 @@ def nodeops_tile_rows(Hp):
     return nodeops.chain_tile_rows(Hp) or 64
 
 
+class GraphEnergies(torch.autograd.Function):
+    """Per-graph sums of the per-row energies (hermnet.py:130: scatter(per_atom_energy, batch)) as an ORDERED segment
+    reduction -- rows -> atoms -> atoms sorted by graph -> segment sums: no atomics, bit-reproducible -- with a two-launch
+    backward (every row reads its graph's gradient) where autograd's own chain through the three steps takes ~15."""
+
+    @staticmethod
+    def forward(ctx, e_rows, graph, batch):
+        ctx.graph, ctx.batch, ctx.rows = graph, batch, e_rows.size(0)
+        pa = e_rows.index_select(0, graph.row_of_node).index_select(0, graph.graph_perm)
+        # (unsafe=True: no host-side validation of `lengths` -- they come from the same `batch` vector; the check would
+        # synchronise, which also forbids capturing the step into a hipGraph)
+        return torch.segment_reduce(pa, "sum", lengths=graph.graph_lengths, unsafe=True)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ge):
+        graph = ctx.graph
+        rg = getattr(graph, "_row_graph", None)
+        if rg is None or rg[0].numel() != ctx.rows:
+            # graph index of every row of e_rows and a 0 / 1 mask of the rows that hold an atom (HTNet: source rows)
+            idx = torch.zeros(ctx.rows, dtype=torch.long, device=ge.device).scatter_(0, graph.row_of_node, ctx.batch)
+            real = torch.zeros(ctx.rows, dtype=ge.dtype, device=ge.device).scatter_(
+                0, graph.row_of_node, torch.ones(graph.row_of_node.numel(), dtype=ge.dtype, device=ge.device))
+            rg = graph._row_graph = (idx, real)
+        return ge.index_select(0, rg[0]) * rg[1], None, None
+
+
 class HVNet(nn.Module):
     """Heterogeneous Vertex Network (`hermnet.py:68-152`).
 
@@ -306,8 +333,15 @@ class HVNet(nn.Module):
             if self.intensive:
                 energy = energy / max(graph.num_atoms, 1)
             return energy
-        per_atom_energy = e_rows.index_select(0, graph.row_of_node)         # back in atom order
         batch = data.batch.long()
+        if shard is None and not train:
+            # scatter(per_atom_energy, batch, reduce=sum|mean) (hermnet.py:130) as an ordered segment reduction: no atomics,
+            # so the energies are bit-reproducible run to run
+            energy = GraphEnergies.apply(e_rows, graph, batch)
+            if self.intensive:
+                energy = energy / graph.graph_lengths.clamp(min=1).to(energy.dtype)
+            return energy
+        per_atom_energy = e_rows.index_select(0, graph.row_of_node)         # back in atom order
         if shard is not None:
             own = shard.owned_mask.to(per_atom_energy.dtype)
             e_own = per_atom_energy * own
@@ -320,17 +354,8 @@ class HVNet(nn.Module):
             if self.intensive:
                 energy = energy / SumAcrossRanks.apply(cnt, shard.group).clamp(min=1)
             return energy
-        # scatter(per_atom_energy, batch, reduce=sum|mean) (hermnet.py:130) as an ordered segment
-        # reduction: no atomics, so the energies are bit-reproducible run to run
-        if train:   # segment_reduce has no second derivative
-            energy = torch.zeros(graph.num_graphs, dtype=x.dtype, device=x.device).index_add(0, batch, per_atom_energy)
-        else:
-            # (unsafe=True: no host-side validation of `lengths` -- they come from the same `batch` vector; the check
-            # would synchronise, which also forbids capturing the step into a hipGraph)
-            # (index_select, not [perm]: the backward of advanced indexing sorts its indices -- a dozen launches -- where a
-            # permutation needs none; index_select's backward adds without collisions here, so it stays deterministic)
-            energy = torch.segment_reduce(per_atom_energy.index_select(0, graph.graph_perm), "sum", lengths=graph.graph_lengths,
-                                          unsafe=True)
+        # (train(): segment_reduce has no second derivative)
+        energy = torch.zeros(graph.num_graphs, dtype=x.dtype, device=x.device).index_add(0, batch, per_atom_energy)
         if self.intensive:
             energy = energy / graph.graph_lengths.clamp(min=1).to(energy.dtype)
         return energy

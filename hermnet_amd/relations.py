@@ -50,7 +50,7 @@ class RelationalGraph(object):
                  "csc_pos", "out_rowptr", "out_edges", "src_id", "tgt_id", "shift", "row_active", "row_real",
                  "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device", "_cstruct", "_rel_bounds",
                  "edge_table", "num_src", "res_row", "triadic_pairs", "src_real", "_rowptr_c", "src_ranges", "_row_keys",
-                 "_upd_tile", "ready", "_keep", "_edge_atoms64", "_edge_sum_keys")
+                 "_upd_tile", "ready", "_keep", "_edge_atoms64", "_edge_sum_keys", "_row_graph")
 
     def __init__(self):
         self._cstruct = None
@@ -67,6 +67,7 @@ class RelationalGraph(object):
         self.ready = None          # event of the side stream the edge part was built on (RelationalGraph.build, `side`)
         self._edge_atoms64 = None  # trainops.EdgeDiff: (source, target) atom of every edge as int64
         self._edge_sum_keys = None
+        self._row_graph = None     # hermnet.GraphEnergies: graph index of every row
         self._keep = None
 
     def rel_edge_bounds(self):
