@@ -196,7 +196,7 @@ class RadialBasis(nn.Module):
         mu = off[k.clamp(0, R - 1)]
         colok = ((k >= 0) & (k < R)).to(up.dtype)
         phi = torch.exp(self.rbf.coeff * (up.view(nc, C, 1) - mu[:, None, :]) ** 2) * (env.view(nc, C, 1) * colok[:, None, :])
-        return BucketedBasis(phi, group, slot, nb, R, pad)
+        return BucketedBasis(phi, group, slot, nb, R, pad, torch.tensor(chunks, device=dev))
 
     def descriptor(self):
         if self.rbf_name != "gaussian":

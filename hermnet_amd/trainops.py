@@ -130,9 +130,17 @@ class BucketedBasis(object):
 
     WIDTH, CHUNK = 32, 1024
 
-    def __init__(self, phi, group, slot, nb, num_radial, pad=None):
+    def __init__(self, phi, group, slot, nb, num_radial, pad=None, chunks_per_group=None):
         self.phi, self.group, self.slot, self.nb, self.num_radial = phi, group, slot, int(nb), int(num_radial)
         self.pad = pad        # [n_pad] rows of the sorted order that hold no edge
+        # (chunks are listed group by group: the weight / bias rows of a chunk are a gather whose adjoint is an ORDERED sum
+        # over the chunks of a group -- index_select's own backward adds them with float atomics, the one place where the
+        # training step's gradients were not bit-reproducible from run to run)
+        self.key_w = self.key_b = None
+        if chunks_per_group is not None and chunks_per_group.numel() % self.nb == 0:
+            cg = chunks_per_group.long()
+            self.key_w = _RowKey(group, None, cg, cg.numel())
+            self.key_b = _RowKey(group // self.nb, None, cg.view(-1, self.nb).sum(1), cg.numel() // self.nb)
         self._phi1 = None     # phi with a ones column (project)
 
     def project(self, w_rbf, b_rbf, scale):
@@ -145,8 +153,12 @@ class BucketedBasis(object):
         win = wt.unfold(1, BucketedBasis.WIDTH, S)[:, :self.nb]                              # [T, nb, 3H, 32]
         win = win.permute(0, 1, 3, 2).reshape(T * self.nb, BucketedBasis.WIDTH, -1)
         bias = torch.stack([b_rbf[t] * scale for t in range(T)])                             # [T, 3H]
-        wc = win.index_select(0, self.group)
-        bc = bias.index_select(0, self.group // self.nb)
+        if self.key_w is not None:
+            wc = GatherRows.apply(win.reshape(win.size(0), -1), self.key_w).view(-1, win.size(1), win.size(2))
+            bc = GatherRows.apply(bias, self.key_b)
+        else:
+            wc = win.index_select(0, self.group)
+            bc = bias.index_select(0, self.group // self.nb)
         if not self.phi.is_cuda or os.environ.get("HERMNET_TRAIN_BIAS_COLUMN", "1") == "0":
             return torch.baddbmm(bc[:, None, :], self.phi, wc).reshape(-1, wc.size(2))
         # The bias rides in the product: a column of ones behind the 32 basis columns (4 columns, so that rows stay 16-byte

@@ -453,6 +453,37 @@ def test_edge_message_kernels_match_autograd_to_second_order(E, H, has_v):
             assert rel_err(got[k], ref[k]) < 1e-5, (k, rel_err(got[k], ref[k]))
 
 
+def test_training_step_is_bit_reproducible_run_to_run():
+    """No float atomics with colliding addresses are left on the training path (segmented sums for every scatter, ordered
+    sums for the weight windows of the bucketed basis): loss, energies, forces and EVERY parameter gradient of a step repeat
+    bit for bit.  (The reference's own step does not: torch_scatter / index_add accumulate in arrival order.)"""
+    import torch.nn.functional as F
+    import hermnet_amd as hn
+    from hermnet_amd import synth
+    dev = _dev()
+    d = synth.molecule_batch(num_graphs=96).to(dev)
+    model = hn.HVNet(["H", "C", "O"], rc=5.0, num_layers=3, hidden_channels=128, num_rbf=64)
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), 12))
+    model = model.to(dev).train()
+    gen = torch.Generator().manual_seed(0)
+    y = torch.randn(96, generator=gen).to(dev)
+    ft = (0.5 * torch.randn(d.pos.shape, generator=gen)).to(dev)
+    runs = []
+    for _ in range(3):
+        model.zero_grad()
+        d.pos.requires_grad_(True)
+        e = model(d)
+        f = -torch.autograd.grad(e.sum(), d.pos, create_graph=True)[0]
+        loss = 0.2 * F.mse_loss(e, y) + 0.8 * F.mse_loss(f, ft)
+        loss.backward()
+        runs.append((loss.detach().clone(), e.detach().clone(), f.detach().clone(),
+                     {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    for other in runs[1:]:
+        assert torch.equal(runs[0][0], other[0]) and torch.equal(runs[0][1], other[1]) and torch.equal(runs[0][2], other[2])
+        assert len(other[3]) == len(runs[0][3]) > 0
+        assert [n for n in runs[0][3] if not torch.equal(runs[0][3][n], other[3][n])] == []
+
+
 def test_message_algebra_with_row_sums_inside_equals_the_per_edge_kernels(monkeypatch):
     """hermnet_edge_message_{fwd,bwd,bwd2}_rows (sums over a row's edges kept in registers) vs the per-edge kernels followed by
     segmented sums, through a whole training step: loss, energies, forces and every parameter gradient (HVNet with an
