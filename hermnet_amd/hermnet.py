@@ -88,8 +88,9 @@ def nodeops_tile_rows(Hp):
 
 class GraphEnergies(torch.autograd.Function):
     """Per-graph sums of the per-row energies (hermnet.py:130: scatter(per_atom_energy, batch)) as an ORDERED segment
-    reduction -- rows -> atoms -> atoms sorted by graph -> segment sums: no atomics, bit-reproducible -- with a two-launch
-    backward (every row reads its graph's gradient) where autograd's own chain through the three steps takes ~15."""
+    reduction -- rows -> atoms -> atoms sorted by graph -> segment sums: no atomics, bit-reproducible -- and its adjoint
+    `_GraphSpread` (every row reads its graph's gradient: two launches where autograd's own chain through the three steps
+    takes ~15).  Both maps are linear and each is the other's backward, so the pair differentiates to any order."""
 
     @staticmethod
     def forward(ctx, e_rows, graph, batch):
@@ -100,17 +101,26 @@ class GraphEnergies(torch.autograd.Function):
         return torch.segment_reduce(pa, "sum", lengths=graph.graph_lengths, unsafe=True)
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, ge):
-        graph = ctx.graph
+        return _GraphSpread.apply(ge, ctx.graph, ctx.batch, ctx.rows), None, None
+
+
+class _GraphSpread(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ge, graph, batch, rows):
+        ctx.graph, ctx.batch = graph, batch
         rg = getattr(graph, "_row_graph", None)
-        if rg is None or rg[0].numel() != ctx.rows:
+        if rg is None or rg[0].numel() != rows:
             # graph index of every row of e_rows and a 0 / 1 mask of the rows that hold an atom (HTNet: source rows)
-            idx = torch.zeros(ctx.rows, dtype=torch.long, device=ge.device).scatter_(0, graph.row_of_node, ctx.batch)
-            real = torch.zeros(ctx.rows, dtype=ge.dtype, device=ge.device).scatter_(
+            idx = torch.zeros(rows, dtype=torch.long, device=ge.device).scatter_(0, graph.row_of_node, batch)
+            real = torch.zeros(rows, dtype=ge.dtype, device=ge.device).scatter_(
                 0, graph.row_of_node, torch.ones(graph.row_of_node.numel(), dtype=ge.dtype, device=ge.device))
             rg = graph._row_graph = (idx, real)
-        return ge.index_select(0, rg[0]) * rg[1], None, None
+        return ge.index_select(0, rg[0]) * rg[1]
+
+    @staticmethod
+    def backward(ctx, c_rows):
+        return GraphEnergies.apply(c_rows.contiguous(), ctx.graph, ctx.batch), None, None, None
 
 
 class HVNet(nn.Module):
@@ -334,7 +344,7 @@ class HVNet(nn.Module):
                 energy = energy / max(graph.num_atoms, 1)
             return energy
         batch = data.batch.long()
-        if shard is None and not train:
+        if shard is None and graph.graph_perm is not None:
             # scatter(per_atom_energy, batch, reduce=sum|mean) (hermnet.py:130) as an ordered segment reduction: no atomics,
             # so the energies are bit-reproducible run to run
             energy = GraphEnergies.apply(e_rows, graph, batch)
