@@ -492,14 +492,17 @@ def test_message_algebra_with_row_sums_inside_equals_the_per_edge_kernels(monkey
     import hermnet_amd as hn
     from hermnet_amd import synth
     dev = _dev()
-    for cls, elems in ((hn.HVNet, ["H", "C", "O"]), (hn.HVNet, ["H", "C"]), (hn.HTNet, ["H", "C", "O"])):
+    # (widths: 64 = 16 lanes per row group; 320 and 512 = a whole wave per group and TWO passes over the channel quads, the
+    # second one partly empty at 320: the per-edge channel sums are then accumulated across the passes)
+    for cls, elems, width in ((hn.HVNet, ["H", "C", "O"], 64), (hn.HVNet, ["H", "C"], 64), (hn.HTNet, ["H", "C", "O"], 64),
+                              (hn.HVNet, ["H", "C", "O"], 320), (hn.HVNet, ["H", "C", "O"], 512)):
         torch.manual_seed(3)
-        d = synth.molecule_batch(num_graphs=24).to(dev)
-        model = cls(elems, rc=5.0, num_layers=3, hidden_channels=64, num_rbf=32)
+        d = synth.molecule_batch(num_graphs=24 if width == 64 else 8).to(dev)
+        model = cls(elems, rc=5.0, num_layers=3 if width == 64 else 2, hidden_channels=width, num_rbf=32)
         model.load_state_dict(synth.synth_state_dict(model.state_dict(), 12))
         model = model.to(dev).train()
         gen = torch.Generator().manual_seed(0)
-        y = torch.randn(24, generator=gen).to(dev)
+        y = torch.randn(int(d.batch.max()) + 1, generator=gen).to(dev)
         ft = (0.5 * torch.randn(d.pos.shape, generator=gen)).to(dev)
         res = []
         for flag in ("0", "1"):
