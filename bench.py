@@ -449,8 +449,11 @@ def self_launch(ngpus, argv, timeout=None):
     if tools:
         # under rocprofv3 this process would be an idle relay and the ranks unprofiled children: refuse
         print("bench.py: --gpus %d would start the ranks as child processes, which the profiler attached to THIS process "
-              "(%s) does not see.  Profile one rank instead: rocprofv3 ... -- python3 -m torch.distributed.run "
-              "--nproc-per-node 1 bench.py --shard-anyway (tools/profile_shard1.sh)." % (ngpus, tools[0]), file=sys.stderr)
+              "(%s) does not see.  Profile one rank instead, with NO launcher between `--` and the program (the "
+              "profiler's preloaded library has initialised the GPU by then, and a launcher would fork / exec the rank "
+              "from such a process): MASTER_ADDR=127.0.0.1 MASTER_PORT=29555 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 "
+              "rocprofv3 ... -- python3 bench.py --shard-anyway (tools/profile_shard1.sh)." % (ngpus, tools[0]),
+              file=sys.stderr)
         return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

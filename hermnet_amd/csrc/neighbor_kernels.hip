@@ -228,7 +228,8 @@ __global__ __launch_bounds__(kBlock) void nbr_sort_decode_kernel(const unsigned 
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= N) return;
   const int lane = threadIdx.x & 63;
-  const int n = stride ? min(count[i], stride) : count[i];     // (a stash holds at most `stride` keys of an atom)
+  const int cnt = count[i];
+  const int n = stride ? min(cnt, stride) : cnt;               // (a stash holds at most `stride` keys of an atom)
   const long base = offset[i];
   const unsigned long long* keys = src + (stride ? (long)i * stride : base);
   const unsigned long long c3 = (unsigned long long)(kCode * kCode * kCode);
@@ -240,14 +241,29 @@ __global__ __launch_bounds__(kBlock) void nbr_sort_decode_kernel(const unsigned 
     if (e >= E) continue;
     const unsigned long long pair = key / c3;
     const int code = (int)(key - pair * c3);
-    const long j = (long)(pair - (unsigned long long)i * N);
-    edge_index[e] = swap_rows ? j : (long)i;
-    edge_index[E + e] = swap_rows ? (long)i : j;
+    const unsigned long long ii = pair / (unsigned long long)N;
+    const long j = (long)(pair - ii * (unsigned long long)N);
+    // a key whose image shift left the code's range (flag bit 0) has spilled into the pair field: the pair it decodes to is
+    // not this atom's -- such a column becomes a NULL edge, never an index that a later kernel would follow out of bounds
+    const bool ok = ii == (unsigned long long)i;
+    edge_index[e] = ok ? (swap_rows ? j : (long)i) : -1;
+    edge_index[E + e] = ok ? (swap_rows ? (long)i : j) : -1;
     if (shift != nullptr) {
-      shift[3 * e + 0] = sign * (float)(code / (kCode * kCode) - kMaxImg);
-      shift[3 * e + 1] = sign * (float)((code / kCode) % kCode - kMaxImg);
-      shift[3 * e + 2] = sign * (float)(code % kCode - kMaxImg);
+      shift[3 * e + 0] = ok ? sign * (float)(code / (kCode * kCode) - kMaxImg) : 0.f;
+      shift[3 * e + 1] = ok ? sign * (float)((code / kCode) % kCode - kMaxImg) : 0.f;
+      shift[3 * e + 2] = ok ? sign * (float)(code % kCode - kMaxImg) : 0.f;
     }
+  }
+  // An atom with more pairs than its stash slot (flag bit 1): offset[] counts ALL its pairs, the stash holds the first
+  // `stride` -- the columns base + n .. base + cnt - 1 belong to keys that were never kept.  They become NULL edges (the
+  // list is incomplete and the caller repeats the search, but whatever runs on it before the flags are read -- the model
+  // step of an MD loop does -- must not meet uninitialised indices).
+  for (int a = n + lane; a < cnt; a += 64) {
+    const long e = base + a;
+    if (e >= E) break;
+    edge_index[e] = -1;
+    edge_index[E + e] = -1;
+    if (shift != nullptr) { shift[3 * e] = 0.f; shift[3 * e + 1] = 0.f; shift[3 * e + 2] = 0.f; }
   }
 }
 

@@ -174,11 +174,15 @@ int group_by_key(const int* key, int n, int nkeys, int* rowptr, int* out, const 
 __global__ __launch_bounds__(kBlock) void edge_keys_hist_kernel(const long* __restrict__ edge_index, int E,
                                                                const int* __restrict__ row_of_node,
                                                                const int* __restrict__ row_start, int T, int N,
-                                                               int* __restrict__ key1, int* __restrict__ key2,
+                                                               int NA, int* __restrict__ key1, int* __restrict__ key2,
                                                                int* __restrict__ hist) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  const long tgt = edge_index[(size_t)E + e];
+  long tgt = edge_index[(size_t)E + e];
+  const long src = edge_index[e];
+  // (an endpoint outside [0, NA) is not followed: the edge is filed as a NULL edge -- a damaged list gives a wrong energy,
+  // never an out-of-bounds read or counter)
+  if (src < 0 || src >= NA || tgt >= NA) tgt = -1;
   // a NULL edge of a padded list (hermnet_neighbor_fill_padded): the counters' closing slots -- row N of the CSR
   // counters, key (T+1) N of the CSC ones -- so that it lands behind every row and in no segment.  Thousands of them
   // meet ONE counter: the wave adds its count once (an atomic per lane on one address costs ~10 ns each, serialised).
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void edge_keys_hist_kernel(const long* __re
     }
     return;
   }
-  const int rs = row_of_node[edge_index[e]], rt = row_of_node[tgt];
+  const int rs = row_of_node[src], rt = row_of_node[tgt];
   const int k2 = relation_of_row(rt, row_start, T) * N + rs;        // == T*N + rs for unknown-element targets
   key1[e] = rt;
   key2[e] = k2;
@@ -443,7 +447,7 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
   hipLaunchKernelGGL(zero_i32_kernel, grid_for((long)nall), dim3(kBlock), 0, s, hist, (long)nall);
   if (E > 0)
     hipLaunchKernelGGL(edge_keys_hist_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, E, out->row_of_node, row_start, T,
-                       N, key1, key2, hist);
+                       N, NA, key1, key2, hist);
   {
     const int n = (int)nall, nb = (n + kScanTile - 1) / kScanTile;
     int* sums = reinterpret_cast<int*>(temp);

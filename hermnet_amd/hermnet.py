@@ -68,8 +68,12 @@ class HeteroVertexConv(nn.Module):
         # rows or any other op in between replaces it) -- and this layer is their only reader: its backward may hand its
         # input gradients down as partial sums (layer.FusedRelationalLayer, `defer`)
         node = data.get("_hn_chain_node")
+        # (not under anomaly detection -- its NaN check would read the not-yet-filled buffers -- and not when a tensor hook
+        # would: both are debugging situations, which get the finishing launches; HERMNET_DEFER_SUMS=0 forces them)
         defer = (node is not None and data.vec is not None and data.x.grad_fn is node and data.vec.grad_fn is node
-                 and halo is None and not g.num_src and data.get("_hn_shard") is None)
+                 and halo is None and not g.num_src and data.get("_hn_shard") is None
+                 and not torch.is_anomaly_enabled()
+                 and not getattr(data.x, "_backward_hooks", None) and not getattr(data.vec, "_backward_hooks", None))
         pre, data._hn_pre0 = data.get("_hn_pre0"), None      # (the first layer's node projection, launched by HVNet.forward)
         if pre is not None and not (w.chain and _node_chain_enabled() and halo is None and pre[0] is data.x):
             pre = None

@@ -19,6 +19,8 @@ reproduces `data.py:19-24` literally (edge_shift = +S, the sign quirk described
 in SURVEY.md section 0) for pipeline-level parity tests.
 """
 import numpy as np
+import os
+
 import torch
 
 
@@ -247,6 +249,11 @@ def neighbor_search_padded(pos, rc, cell, capacity, reference_compat=False):
     edge_index = torch.empty(2, cap, dtype=torch.long, device=dev)
     periodic = cell is not None
     shift = torch.empty(cap, 3, dtype=torch.float32, device=dev) if periodic else None
+    if os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":
+        # (tests: a column the search leaves unwritten would send the relation build far out of bounds)
+        edge_index.fill_(0x3f3f3f3f3f3f3f3f)
+        if shift is not None:
+            shift.fill_(float("nan"))
     _lib.check(lib.hermnet_neighbor_count(P(p32), N, cell_h, lo_h, hi_h, float(rc), P(work), ws_bytes, None, P(total), stream),
                "hermnet_neighbor_count")
     sign = 1.0 if reference_compat else -1.0

@@ -191,8 +191,13 @@ class NNCalculator(_Base):
         if want:
             volume = abs(float(np.linalg.det(np.asarray(cell, dtype=np.float64).reshape(3, 3))))
             self.results['stress'] = stress_from_virial(w.cpu().numpy(), volume)
+        elif not (pbc and cell is not None):
+            self.results['stress'] = np.zeros(6)          # an open system has no stress: zeros, as the reference stores
         else:
-            self.results['stress'] = np.zeros(6)
+            # Periodic cell, stress not asked for in this call: NOT stored.  ASE's `calculation_required` only looks whether
+            # a property's name is in `results`, so a cached zero vector would be handed to a later `atoms.get_stress()`
+            # (cell filters, NPT dynamics) without a recomputation; absent, ASE calls `calculate(['stress'])` again.
+            self.results.pop('stress', None)
 
     def model_calc(self, data, device, pbc, ensemble='NVT'):
         """`calculator.py:59-98`: (energy, forces [N,3], LAMMPS-packed virial [6]) -- see the module-level function."""

@@ -1472,6 +1472,56 @@ def test_padded_neighbour_list_gives_the_exact_lists_results_bit_for_bit(case):
     assert not ok and found == E
 
 
+def test_padded_list_with_an_overflowing_stash_holds_no_uninitialised_column():
+    """an atom with more pairs than its stash slot (flag bit 1) left the columns offset[i] + stride ..
+    offset[i] + count - 1 of the padded list unwritten, and the model -- which an MD loop runs BEFORE the host reads the
+    flags -- followed whatever int64 sat there out of bounds.  With the smallest slot (8 keys; fcc at 5 A has 42 pairs per
+    atom) every atom overflows: every column must be a real pair of the exact list or a NULL edge, the buffers being
+    poisoned first; the step on that list must run (its energy is meaningless, the flags say so), and the repeat on the
+    exact list gives the right answer."""
+    from hermnet_amd import neighbor as nb
+    dev = _dev()
+    pos, cell, z = synth.fcc_alloy_atoms(reps=(3, 3, 4))
+    pos_t = torch.from_numpy(pos.astype(np.float32)).to(dev)
+    cell_t = torch.from_numpy(cell.astype(np.float32)).to(dev)
+    z_t = torch.from_numpy(z).to(dev)
+    ei, sh = hn.neighbor_search(pos_t, 5.0, cell_t)
+    E, N = int(ei.size(1)), len(z)
+    exact = set(map(tuple, torch.cat([ei.t(), sh.long()], 1).tolist()))
+    saved = dict(nb._STASH)
+    os.environ["HERMNET_DEBUG_POISON"] = "1"
+    try:
+        nb._STASH[str(dev)] = 8
+        eip, shp, total = nb.neighbor_search_padded(pos_t, 5.0, cell_t, E + 333)
+        found, flags = total.tolist()
+        assert found == E and (flags & 2)
+        null = eip[0] < 0
+        assert bool((eip[1][null] == -1).all()) and bool((eip[0][null] == -1).all()) and float(shp[null].abs().sum()) == 0.0
+        real = torch.cat([eip.t()[~null], shp[~null].long()], 1).tolist()
+        assert 0 < len(real) <= 8 * N and all(tuple(r) in exact for r in real)        # (a NaN shift would not be in the set)
+        assert int(eip.max()) < N
+        kw = dict(rc=5.0, num_layers=2, hidden_channels=128, num_rbf=64)
+        model = hn.HVNet(["Al", "Ni", "Cu"], **kw).eval()
+        model.load_state_dict(synth.synth_state_dict(model.state_dict(), 5))
+        model = model.to(dev)
+        d = hn.Data(pos=pos_t.clone().requires_grad_(True), atomic_number=z_t, batch=torch.zeros(N, dtype=torch.long, device=dev),
+                    cell=cell_t.reshape(1, 3, 3), edge_index=eip, edge_shift=shp)
+        d._hn_edge_count = total
+        e = model(d)
+        f = torch.autograd.grad(e.sum(), d.pos)[0]
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(e).all()) and bool(torch.isfinite(f).all())
+        ok, _ = nb.padded_list_ok(total)
+        assert not ok and nb._STASH[str(dev)] == 160                     # the repeat gets the largest slot
+        eip2, shp2, total2 = nb.neighbor_search_padded(pos_t, 5.0, cell_t, E + 333)
+        assert nb.padded_list_ok(total2) == (True, E)
+        assert torch.equal(eip2[:, :E], ei) and torch.equal(shp2[:E], sh) and bool((eip2[:, E:] == -1).all())
+    finally:
+        os.environ["HERMNET_DEBUG_POISON"] = "0"
+        nb._STASH.clear()
+        nb._STASH.update(saved)
+
+
 def test_md_step_with_list_rebuild_replays_as_one_graph():
     """`GraphedMDStep`: neighbour search + relation build + forward + force backward captured ONCE, replayed along a random
     walk on which the list changes (different edge counts), with eager steps and unrelated work in between; every replay

@@ -240,3 +240,25 @@ def test_ipi_client_against_stub_socketclient_gpu(monkeypatch):
     res = _ipi_session(g, "cuda", monkeypatch)
     assert abs(res[0]["energy"] - (float(g.energy[0]) + 0.5)) < 5e-6 * abs(float(g.energy[0]))
     assert rel_err(torch.from_numpy(res[0]["forces"]), g.forces) < 1e-5
+
+
+def test_ase_calculator_never_caches_a_stress_it_did_not_compute(monkeypatch):
+    """ASE's `calculation_required` only asks whether a property's NAME is in `results`.  A periodic call
+    that was not asked for the stress (NVT, properties=('energy',)) used to store zeros there, so a following
+    `atoms.get_stress()` on the same atoms got the cached zeros without a recomputation.  Now the key is absent until the
+    stress has been computed; an open system keeps its zeros (it has none)."""
+    _cpu_ops(monkeypatch)
+    g = Golden("alloy108")
+    calc = A.NNCalculator(g.model(), None, trn_mean=0.0, device_="cpu")
+    atoms = _FakeAtoms(g)
+    calc.calculate(atoms, ["energy"])
+    assert "stress" not in calc.results and "energy" in calc.results and "forces" in calc.results
+    calc.calculate(atoms, ["stress"])                      # (what ASE does next, the name being absent)
+    st = np.asarray(calc.results["stress"])
+    assert st.shape == (6,) and np.abs(st).max() > 0
+    calc.calculate(atoms, ["energy", "forces"])            # and a later call without it drops the stale value again
+    assert "stress" not in calc.results
+    mol = Golden("mol16")
+    calc2 = A.NNCalculator(mol.model(), None, trn_mean=0.0, device_="cpu")
+    calc2.calculate(_FakeAtoms(mol), ["energy"])
+    assert np.abs(calc2.results["stress"]).max() == 0
