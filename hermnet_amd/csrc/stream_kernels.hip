@@ -29,7 +29,48 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restric
   }
 }
 
+// ---- parameter guard ------------------------------------------------------------------------------------------------
+// The host keeps kernel-ready copies of the model's parameters (MFMA operand order, folded LayerNorm affine, transposes:
+// hermnet_amd/layer.py LayerWeights) and rebuilds them when a parameter's identity, version counter or address changes.
+// A write THROUGH `.data` (EMA / SWA swaps, old-style `p.data.copy_`) changes none of the three.  This kernel closes the
+// gap on the device, without a host read: one workgroup per parameter tensor sums its 32-bit words weighted by position
+// (wrapping arithmetic: exact, order-independent between lanes, so deterministic) and either records the sum or compares
+// it with the recorded one; on a difference it raises `flag` and writes a NaN over `poison[0]` -- a value every result of
+// the step depends on -- so that a step on stale copies yields NaN, never the old numbers.
+__global__ __launch_bounds__(256) void param_guard_kernel(const unsigned* const* __restrict__ ptrs,
+                                                          const long* __restrict__ counts, unsigned* __restrict__ fp,
+                                                          int check, float* __restrict__ poison, int* __restrict__ flag) {
+  __shared__ unsigned part[4];
+  const unsigned* p = ptrs[blockIdx.x];
+  const long n = counts[blockIdx.x];
+  unsigned acc = 0;
+  for (long i = threadIdx.x; i < n; i += 256) acc += p[i] * (2u * (unsigned)i + 1u);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned v = part[0] + part[1] + part[2] + part[3];
+    if (!check) {
+      fp[blockIdx.x] = v;
+    } else if (fp[blockIdx.x] != v) {
+      flag[0] = 1;
+      if (poison != nullptr) poison[0] = __uint_as_float(0x7fc00000u);
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int hermnet_param_guard(const void* const* tensor_ptrs, const long* word_counts, int num_tensors,
+                                   unsigned* fingerprints, int check, float* poison, int* flag, void* stream) {
+  if (num_tensors < 0 || (num_tensors > 0 && (!tensor_ptrs || !word_counts || !fingerprints)) || (check && !flag))
+    return HN_ERR_BAD_ARG;
+  if (num_tensors == 0) return HN_OK;
+  hipLaunchKernelGGL(param_guard_kernel, dim3((unsigned)num_tensors), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const unsigned* const*>(tensor_ptrs), word_counts, fingerprints, check, poison, flag);
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}
 
 extern "C" int hermnet_stream_copy(const float* src, float* dst, size_t num_floats, int workgroups, void* stream) {
   if (!src || !dst || (num_floats & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return HN_ERR_BAD_ARG;

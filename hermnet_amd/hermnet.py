@@ -33,7 +33,10 @@ class HeteroVertexConv(nn.Module):
         # it first.
         halo, data._hn_halo = data.get("_hn_halo"), None
         w = None
-        if (halo is not None and data.get("_hn_edge_embed") is None
+        ready = data.get("_hn_weights")          # (HVNet.forward refreshed every layer's copies up front: guard.ParamGuard)
+        if ready is not None and ready[data.get("_hn_layer", 0)].mods[0] is next(iter(self.mods.values())):
+            w = ready[data.get("_hn_layer", 0)]
+        if (w is None and halo is not None and data.get("_hn_edge_embed") is None
                 and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0"):
             if self._weights is None:
                 self._weights = LayerWeights(self.mods.values())
@@ -160,6 +163,58 @@ class HVNet(nn.Module):
             nn.Linear(hidden_channels // 2, 1),
         )
 
+    # ---- cached kernel-ready parameter copies (layer.LayerWeights) and their guard (guard.ParamGuard) -----------------
+    def invalidate_caches(self):
+        """Drop every derived copy of the parameters (MFMA-order weights, folded biases, transposes): the next forward
+        rebuilds them.  Runs by itself on `load_state_dict`, `.to()` / `.cuda()` / `.float()` (`_apply`) and `train()` /
+        `eval()` transitions; call it after writing parameters through `.data` (a write the caches' keys cannot see --
+        the device-side guard would otherwise answer the next step with NaN and repair on the one after)."""
+        from . import layer as _layer
+        for conv in self.hermconvs:
+            if getattr(conv, "_weights", None) is not None:
+                conv._weights.key = None
+        del _layer._T_CACHE[:]
+        g = self.__dict__.get("_guard")
+        if g is not None:
+            g.armed_for, g._event = None, None
+        return self
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_caches()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if "hermconvs" in self._modules:
+            self.invalidate_caches()
+        return out
+
+    def train(self, mode=True):
+        if "hermconvs" in self._modules and mode != self.training:
+            self.invalidate_caches()
+        return super().train(mode)
+
+    def _refresh_weights(self, dev):
+        """Every layer's kernel-ready copies, current; fingerprints recorded / checked on the device (one launch)."""
+        from .guard import ParamGuard
+        guard_on = os.environ.get("HERMNET_PARAM_GUARD", "1") != "0"
+        for _ in range(2):
+            ws = []
+            for conv in self.hermconvs:
+                if conv._weights is None:
+                    conv._weights = LayerWeights(conv.mods.values())
+                ws.append(conv._weights.refresh())
+            if not guard_on or not ws:
+                return ws
+            g = self.__dict__.get("_guard")
+            if g is None:
+                g = self.__dict__["_guard"] = ParamGuard(self)
+            if not g.step(dev, tuple((id(w), w.builds) for w in ws), ws[0].b1cat):
+                return ws
+            self.invalidate_caches()            # the previous step ran on stale copies (its result was NaN): rebuild
+        return ws
+
     # eval() treats parameters as constants (energy / force evaluation).  Set True to take the differentiable
     # device-op path in eval() as well (fine-tuning or gradient diagnostics with dropout-free eval semantics).
     eval_param_grads = False
@@ -262,6 +317,9 @@ class HVNet(nn.Module):
             # widths that are not a multiple of 64 run on the same kernels with zero-padded channels (layer.LayerWeights)
             x = torch.nn.functional.pad(x, (0, Hp - H))
         data._hn_pre0 = None
+        data._hn_weights = None
+        if fused and pos.is_cuda and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0":
+            data._hn_weights = self._refresh_weights(pos.device)
         if graph.ready is not None:
             # (the edge part of the build is still running on the side stream: the row arrays above are the cached ones)
             conv0 = self.hermconvs[0]

@@ -28,6 +28,7 @@ class LayerWeights(object):
     def __init__(self, mods):
         self.mods = list(mods)
         self.key = None
+        self.builds = 0               # how often the copies were (re)built (guard.ParamGuard stamps its fingerprints with it)
         # (owner module, name) of every parameter, collected once: walking `module.parameters()` on every
         # forward costs ~0.13 ms of host time per layer
         self._slots = [(sub, name) for m in self.mods for sub in m.modules() for name in sub._parameters]
@@ -121,6 +122,7 @@ class LayerWeights(object):
                 self.wx0f16, self.wx0tf16 = f16(self.wx0_s), f16(self.wx0t_s)
                 self.wx2f16, self.wx2tf16 = f16(self.wx2_s), f16(self.wx2t_s)
         self.key = key
+        self.builds += 1
         return self
 
 

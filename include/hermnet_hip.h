@@ -536,6 +536,16 @@ int hermnet_halo_accumulate(float* x, float* vec, const long* seg_rows, const lo
  * MI355X_MICROARCH.md's 6.29 TB/s figure).  `workgroups` <= 0: 8 per CU. */
 int hermnet_stream_copy(const float* src, float* dst, size_t num_floats, int workgroups, void* stream);
 
+/* Parameter guard (ABI v9).  The host side caches kernel-ready copies of the module's parameters and rebuilds them when a
+ * parameter's identity / version / address changes; a write through `.data` changes none of these (the reference has no such
+ * cache: /root/reference/HermNet/hermnet.py:118-131 reads nn.Parameters directly on every call).  `tensor_ptrs` [n] device array
+ * of device pointers to the parameter tensors, `word_counts` [n] their sizes in 32-bit words, `fingerprints` [n] uint32.
+ * check == 0: record a position-weighted wrapping sum of every tensor's words.  check != 0: compare; on any difference
+ * flag[0] = 1 and, if `poison` is given, poison[0] = NaN (the caller passes a cached value every result depends on, so a step on
+ * stale copies yields NaN instead of the old numbers).  One launch, no host read. */
+int hermnet_param_guard(const void* const* tensor_ptrs, const long* word_counts, int num_tensors, unsigned* fingerprints,
+                        int check, float* poison, int* flag, void* stream);
+
 /* Host-side (CPU) evaluation of the per-edge radial contraction exactly as the device code
  * computes it (banded 12-tap Gaussian window): rb[c] = b[c] + env(u) * sum_k W[c,k] g_k(u) and
  * its derivative d rb / d d.  Used by the CPU test-suite to check the banded formulation

@@ -131,6 +131,10 @@ def cases(full):
               envelope={"name": "exponential"}), 8, True, False),
         ("alloy32_bernstein", synth.fcc_alloy(reps=(2, 2, 2), rc=4.0), ["Al", "Ni", "Cu"],
          dict(num_layers=2, rc=4.0, hidden_channels=64, num_rbf=16, rbf={"name": "bernstein"}), 9, True, False),
+        # the reference's DEFAULT configuration (hermnet.py:84-88: num_layers=5, hidden_channels=512, num_rbf=128) -- what
+        # `HVNet(elems)` builds and what example/dist_train.py:63 trains
+        ("alloy108_h512_default", synth.fcc_alloy(reps=(3, 3, 3)), ["Al", "Ni", "Cu"],
+         dict(num_layers=5, rc=5.0, hidden_channels=512, num_rbf=128), 14, True, False),
     ]
     if full:
         out.append(("c2_alloy10k", synth.fcc_alloy(), ["Al", "Ni", "Cu"], dict(num_layers=5, **H128), 10, False, False))

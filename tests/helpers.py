@@ -15,9 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden")
 
 SMALL_CASES = ["c1_si64", "c1_si64_refcompat", "alloy108", "alloy108_unknown_type", "alloy108_h64",
-               "alloy32_h256", "mol16", "mol16_intensive"]
+               "alloy32_h256", "mol16", "mol16_intensive",
+               "alloy108_h512_default"]       # the reference's default constructor arguments (hermnet.py:84-88)
 NONGAUSS_CASES = ["alloy32_bessel_expenv", "alloy32_bernstein"]
-TRAIN_CASES = ["train_alloy108_h64", "train_mol8_h64", "train_si64_intensive_h64"]
+TRAIN_CASES = ["train_alloy108_h64", "train_mol8_h64", "train_si64_intensive_h64", "train_si64_h128"]
 
 
 def sd_checksum(sd):

@@ -1472,6 +1472,55 @@ def test_padded_neighbour_list_gives_the_exact_lists_results_bit_for_bit(case):
     assert not ok and found == E
 
 
+def test_a_weight_written_through_dot_data_never_gives_the_old_numbers():
+    """the kernel-ready parameter copies are keyed on (identity, version, address) of every parameter; a
+    write through `.data` changes none of them.  The device-side guard (`hermnet_param_guard`, one launch per forward)
+    must answer the first step after such a write with NaN -- never with the OLD numbers -- and the following step, which
+    reads the guard's flag, with the NEW numbers (equal to a model whose caches were invalidated by hand)."""
+    import warnings
+    dev = _dev()
+    g = Golden("alloy108")
+    model = g.model().to(dev).eval()
+    d0 = g.data().to(dev)
+
+    def run(m):
+        d = g.data().to(dev)
+        d.pos = d0.pos.detach().clone().requires_grad_(True)
+        e = m(d)
+        f = -torch.autograd.grad(e.sum(), d.pos)[0]
+        return e.detach().clone(), f.clone()
+
+    e_old, f_old = run(model)
+    assert rel_err(e_old.cpu(), g.energy) < TOL
+    e_again, _ = run(model)
+    assert torch.equal(e_old, e_again)                       # an unchanged model passes its checks
+    name, p_ = [(n, p) for n, p in model.named_parameters() if n.endswith("update_layer.xvec_proj.2.weight")][1]
+    v0 = p_._version
+    p_.data.mul_(1.5)
+    assert p_._version == v0                                 # (the hazard: nothing the cache key looks at has moved)
+    e1, f1 = run(model)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(e1).all()) and bool(torch.isnan(f1).any()), "a step on stale copies must not give numbers"
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        e2, f2 = run(model)
+    assert any("modified behind the cached" in str(w.message) for w in rec)
+    assert bool(torch.isfinite(e2).all()) and not torch.equal(e2, e_old)
+    model.invalidate_caches()
+    e3, f3 = run(model)
+    assert torch.equal(e2, e3) and torch.equal(f2, f3)
+    # the same weights loaded into a fresh module agree with the oracle
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    from oracle import hermnet_oracle as orc
+    e_ref, f_ref = orc.energy_and_forces(sd, g.elems, g.data(), **g.oracle_kwargs())
+    assert rel_err(e2.cpu(), e_ref) < TOL and rel_err(f2.cpu(), f_ref) < TOL
+    # load_state_dict / .to() / train()-eval() transitions invalidate by themselves, and a second write is caught again
+    p_.data.mul_(1.0 / 1.5)
+    model.load_state_dict(model.state_dict())
+    e4, _ = run(model)
+    assert rel_err(e4.cpu(), g.energy) < TOL
+
+
 def test_padded_list_with_an_overflowing_stash_holds_no_uninitialised_column():
     """an atom with more pairs than its stash slot (flag bit 1) left the columns offset[i] + stride ..
     offset[i] + count - 1 of the padded list unwritten, and the model -- which an MD loop runs BEFORE the host reads the
