@@ -33,7 +33,8 @@ class Graph(ctypes.Structure):
 class PendingGrads(ctypes.Structure):
     """hn_pending_grads (include/hermnet_hip.h): the incoming gradients of an update backward, still in partial sums."""
     _fields_ = [(n, c_fp) for n in ("gn_parts", "gvec_parts", "x", "mean", "rstd", "gx1", "gvec1")] + \
-               [("num_parts", ctypes.c_int), ("hidden_real", ctypes.c_int)]
+               [("num_parts", ctypes.c_int), ("hidden_real", ctypes.c_int)] + \
+               [(n, c_fp) for n in ("gxh", "hb", "w2t_frag16", "w1t_frag16")]
 
 
 class RelationsOut(ctypes.Structure):
@@ -112,6 +113,12 @@ SIGNATURES = {
     "hermnet_node_update_fwd": (ctypes.c_int, [c_fp] * 16 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_node_update_bwd": (ctypes.c_int, [c_fp] * 14 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp,
                                                            c_fp]),
+    "hermnet_node_fused_supported": (ctypes.c_int, [ctypes.c_int]),
+    "hermnet_node_update_pre_fwd": (ctypes.c_int, [c_fp] * 16 + [ctypes.c_int, ctypes.c_int, ctypes.c_int] + [c_fp] * 8 +
+                                    [ctypes.c_int, ctypes.c_int, ctypes.c_float, c_fp]),
+    "hermnet_node_pre_fwd16": (ctypes.c_int, [c_fp] * 9 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                          ctypes.c_float, c_fp]),
+    "hermnet_node_pre_bwd16": (ctypes.c_int, [c_fp] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_pair_mean": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_fp, ctypes.c_int, c_fp]),
     "hermnet_halo_rows": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),

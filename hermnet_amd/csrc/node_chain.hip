@@ -767,6 +767,9 @@ int hn_wide_update_bwd(int hidden, const UpdBwdArgs& a, int tiles, void* stream)
 int hn_update16_supported(int hidden);
 int hn_update16_fwd(int hidden, const UpdFwdArgs& a, int tiles, void* stream);
 int hn_update16_bwd(int hidden, const UpdBwdArgs& a, int tiles, void* stream);
+int hn_update16_pre_fwd(int hidden, const UpdFwdArgs& a, const PreFwdArgs& p, int tiles, void* stream);
+int hn_pre16_fwd(int hidden, const PreFwdArgs& p, void* stream);
+int hn_pre16_bwd(int hidden, const PreBwdArgs& a, void* stream);
 
 // Widths 64 / 128 / 256 have tuned instances in this file; every other multiple of 64 up to 512 -- the reference's default
 // hidden_channels = 512 among them (hermnet.py:86) -- takes the panelled kernels.  HERMNET_NODE_CHAIN_WIDE=1 sends 128 and
@@ -880,13 +883,59 @@ extern "C" int hermnet_node_update_bwd(const float* gx_out, const float* gvec_ou
                   num_nodes, num_rel, {}};
   if (pending) {
     const hn_pending_grads& p = *pending;
-    if (!p.gn_parts || !p.gvec_parts || !p.x || !p.mean || !p.rstd || !p.gx1 || !p.gvec1 || p.num_parts < 1 ||
+    if ((!p.gn_parts && !p.gxh) || !p.gvec_parts || !p.x || !p.mean || !p.rstd || !p.gx1 || !p.gvec1 || p.num_parts < 1 ||
         p.hidden_real > hidden)
       return HN_ERR_BAD_ARG;
     a.pend = {p.gn_parts, p.gvec_parts, p.x, p.mean, p.rstd, p.gx1, p.gvec1, p.num_parts,
-              p.hidden_real > 0 ? p.hidden_real : hidden};
+              p.hidden_real > 0 ? p.hidden_real : hidden, p.gxh, p.hb, p.w2t_frag16, p.w1t_frag16};
+    // fused form: the projection's backward of the layer above runs inside this launch (16-row tiles only)
+    if (p.gxh && (tile_rows != 16 || !p.hb || !p.w2t_frag16 || !p.w1t_frag16)) return HN_ERR_BAD_ARG;
   }
   if (tile_rows == 16) return hn_update16_supported(hidden) ? hn_update16_bwd(hidden, a, HN_TILES(16), stream) : HN_ERR_BAD_ARG;
   if (use_wide(hidden)) return hn_wide_update_bwd(hidden, a, HN_TILES(32), stream);
   HN_UPDATE_DISPATCH(node_update_bwd_kernel, a);
+}
+
+// ---- round 5: the layer boundary as ONE node launch each way (csrc/node_chain16.hip) ------------------------------------------
+extern "C" int hermnet_node_fused_supported(int hidden) { return hn_update16_supported(hidden); }
+
+extern "C" int hermnet_node_update_pre_fwd(const float* x1, const float* vec1, const float* wv_frag16, const float* wx0_frag16,
+                                           const float* bx0, const float* wx2_frag16, const float* bx2,
+                                           const float* row_active, const int* type_rowptr, const int* type_rowptr_host,
+                                           float* vp, float* h2b, float* q23, float* nrm, float* x_out, float* vec_out,
+                                           int num_nodes, int num_rel, int hidden, const float* w1_frag16, const float* b1,
+                                           const float* w2_frag16, const float* b2, float* hb, float* xh, float* mean,
+                                           float* rstd, int next_num_rel, int hidden_real, float eps, void* stream) {
+  if (num_nodes < 0 || num_rel <= 0 || next_num_rel <= 0 || !type_rowptr_host || hidden_real > hidden) return HN_ERR_BAD_ARG;
+  if (!hn_update16_supported(hidden)) return HN_ERR_BAD_ARG;
+  if (num_nodes == 0) return HN_OK;
+  if (!x1 || !vec1 || !wv_frag16 || !wx0_frag16 || !bx0 || !wx2_frag16 || !bx2 || !type_rowptr || !vp || !h2b || !q23 || !nrm ||
+      !x_out || !vec_out || !w1_frag16 || !b1 || !w2_frag16 || !b2 || !hb || !xh || !mean || !rstd ||
+      type_rowptr_host[num_rel] > num_nodes)
+    return HN_ERR_BAD_ARG;
+  UpdFwdArgs a = {x1, vec1, wv_frag16, wx0_frag16, bx0, wx2_frag16, bx2, row_active, type_rowptr, vp, h2b, q23, nrm, x_out,
+                  vec_out, num_nodes, num_rel};
+  PreFwdArgs p = {x_out, w1_frag16, b1, w2_frag16, b2, hb, xh, mean, rstd, nullptr, num_nodes, next_num_rel,
+                  hidden_real > 0 ? hidden_real : hidden, eps, nullptr, 0, 0};
+  return hn_update16_pre_fwd(hidden, a, p, HN_TILES(16), stream);
+}
+
+extern "C" int hermnet_node_pre_fwd16(const float* x, const float* w1_frag16, const float* b1, const float* w2_frag16,
+                                      const float* b2, float* hb, float* xh, float* mean, float* rstd, int num_src,
+                                      int num_rel, int hidden, int hidden_real, float eps, void* stream) {
+  if (num_src < 0 || num_rel <= 0 || hidden_real > hidden || !hn_update16_supported(hidden)) return HN_ERR_BAD_ARG;
+  if (num_src == 0) return HN_OK;
+  if (!x || !w1_frag16 || !b1 || !w2_frag16 || !b2 || !hb || !xh || !mean || !rstd) return HN_ERR_BAD_ARG;
+  PreFwdArgs p = {x, w1_frag16, b1, w2_frag16, b2, hb, xh, mean, rstd, nullptr, num_src, num_rel,
+                  hidden_real > 0 ? hidden_real : hidden, eps, nullptr, 0, 0};
+  return hn_pre16_fwd(hidden, p, stream);
+}
+
+extern "C" int hermnet_node_pre_bwd16(const float* gxh, const float* hb, const float* w2t_frag16, const float* w1t_frag16,
+                                      float* gn_parts, int num_src, int num_rel, int hidden, void* stream) {
+  if (num_src < 0 || num_rel <= 0 || !hn_update16_supported(hidden)) return HN_ERR_BAD_ARG;
+  if (num_src == 0) return HN_OK;
+  if (!gxh || !hb || !w2t_frag16 || !w1t_frag16 || !gn_parts) return HN_ERR_BAD_ARG;
+  PreBwdArgs a = {gxh, hb, w2t_frag16, w1t_frag16, gn_parts, nullptr, num_src, num_rel, nullptr, 0, 0};
+  return hn_pre16_bwd(hidden, a, stream);
 }

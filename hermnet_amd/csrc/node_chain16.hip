@@ -13,6 +13,14 @@
 // activations in [16][H + 8] LDS tiles (ds_read_b128 at row l & 15, k = 16 Q + 4 (l >> 4): conflict-free with the +8 pad),
 // accumulators transposed: lane l holds tile row l & 15 and the channels 16 b + 4 (l >> 4) .. +3 of block b as ONE float4.
 // A wave owns 32 channels (two blocks) of every output part, so vec_dot, q * vdot and r * v1 stay lane-local.
+//
+// Round 5: ONE node launch per layer boundary, each way.  A tile's update (layer l) and the node projection of the rows it has
+// just produced (layer l + 1: LayerNorm -> [H -> H] -> ScaledSiLU -> [H -> 3H] for every relation; rmnet.py:52 behind
+// rmnet.py:29-31, 94-107) are row-local, so `node_update_pre_fwd16_kernel` runs both: x_out never leaves the chip between
+// them.  The mirror `node_pre_update_bwd16_kernel` runs the projection's backward of layer l + 1 in front of the update
+// backward of layer l: the per-relation sums stay in registers (no [T, N, H] partial sums in memory), the LayerNorm backward
+// runs on the tile.  The same phases also exist as kernels of their own (`node_pre_fwd16_kernel`, `node_pre_bwd16_kernel`):
+// the unfused form is the A/B and the bit-for-bit check of the fused one.
 #include "node_chain_common.h"
 
 #ifndef HN_U16_MINW
@@ -128,15 +136,138 @@ __device__ __forceinline__ void tile16_store(float* tile, const Tile16Regs<H>& r
 }
 
 // =====================================================================================================================
-// node_update_fwd on 16-row tiles (H = 128: four waves x 32 channels)
+// The node projection of one 16-row tile (rmnet.py:52 for every relation): the tile's LayerNorm input sits in `bufN`.
 // =====================================================================================================================
+// LayerNorm without affine of a [16][H] LDS tile, in place; statistics over the first Hr channels.  Four adjacent lanes share a
+// row, its float4s dealt round-robin -- the operation order of node_pre_fwd_kernel<128, 64> (node_chain.hip) --, one wave does
+// the whole tile (64 lanes x 32 values).  The caller puts a barrier in front (tile written) and behind (tile normalised).
 template <int H>
-__global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(UpdFwdArgs a) {
+__device__ __forceinline__ void layernorm_tile16(float* tile, int tid, int nrows, int Hr, float eps, float* mean0, float* rstd0) {
+  constexpr int LD = H + 8, TPR = 4, NF = H / 4 / TPR;
+  if (tid >= 64) return;
+  const int lr = tid / TPR, q = tid % TPR;
+  f32x4 v[NF];
+#pragma unroll
+  for (int k = 0; k < NF; ++k) v[k] = *reinterpret_cast<const f32x4*>(tile + lr * LD + (k * TPR + q) * 4);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NF; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if ((k * TPR + q) * 4 + e >= Hr) v[k][e] = 0.f;
+      s += v[k][e];
+    }
+#pragma unroll
+  for (int m = 1; m < TPR; m <<= 1) s += __shfl_xor(s, m, 64);
+  const float mu = s / (float)Hr;
+  float qq = 0.f;
+#pragma unroll
+  for (int k = 0; k < NF; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[k][e] = (k * TPR + q) * 4 + e < Hr ? v[k][e] - mu : 0.f;
+      qq = fmaf(v[k][e], v[k][e], qq);
+    }
+#pragma unroll
+  for (int m = 1; m < TPR; m <<= 1) qq += __shfl_xor(qq, m, 64);
+  const float rs = rsqrtf(qq / (float)Hr + eps);
+#pragma unroll
+  for (int k = 0; k < NF; ++k) *reinterpret_cast<f32x4*>(tile + lr * LD + (k * TPR + q) * 4) = v[k] * rs;
+  if (q == 0 && lr < nrows) { mean0[lr] = mu; rstd0[lr] = rs; }
+}
+
+// xh[t] = x_proj_t(LayerNorm(x)) for every relation t of `p`, rows [row0, row0 + nrows) -- their x in bufN, raw, behind a
+// barrier.  bufA0 / bufA1: two more [16][H + 8] tiles (the hidden activations of even / odd relations: one barrier per
+// relation).  Saves hb (pre-activations incl. bias), mean, rstd like node_pre_fwd_kernel.  Per wave and relation 64 + 192 MFMAs.
+template <int H>
+__device__ __forceinline__ void pre_fwd16_phase(const PreFwdArgs& p, float* bufN, float* bufA0, float* bufA1, float* scr,
+                                                int row0, int nrows, int tid, int lane, int wave) {
+  constexpr int LD = H + 8, NB16 = H / 16;
+  const int mrow = lane & 15, ch = 4 * (lane >> 4), cw = 32 * wave;
+  const f32x4* bp1[2];
+  Ring16<2> r1;
+  f32x4 acc1[2];
+  // the first product's operands of relation t: requested in front of whatever stores precede the product (vmcnt is in order)
+  auto request1 = [&](int t) {
+    const f32x4* w1 = reinterpret_cast<const f32x4*>(p.w1f + (size_t)t * H * H) + lane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) bp1[s] = w1 + (size_t)(2 * wave + s) * (H / 16) * 64;
+    b16_preload(r1, bp1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acc1[s] = ld4g(p.b1 + (size_t)t * H + cw + 16 * s + ch);
+  };
+  request1(0);
+  layernorm_tile16<H>(bufN, tid, nrows, p.Hr, p.eps, p.mean + row0, p.rstd + row0);
+  __syncthreads();
+  const float* An = bufN + mrow * LD + ch;
+#pragma unroll 1
+  for (int t = 0; t < p.T; ++t) {
+    float* bufA = (t & 1) ? bufA1 : bufA0;
+    const rsrc_t hb_r = tile_rsrc(p.hb + ((size_t)t * p.Ns + row0) * H, nrows * H);
+    const rsrc_t xh_r = tile_rsrc(p.xh + ((size_t)t * p.Ns + row0) * 3 * H, nrows * 3 * H);
+    // ---- h = n W1^T + b1
+    mma16_panel<H, 2, false>(acc1, An, bp1, r1);
+    const f32x4* w2 = reinterpret_cast<const f32x4*>(p.w2f + (size_t)t * 3 * H * H) + lane;
+    const f32x4* bp2[6];
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) bp2[2 * pp + s] = w2 + (size_t)(pp * NB16 + 2 * wave + s) * (H / 16) * 64;
+    Ring16<6> r2;
+    b16_preload(r2, bp2);
+    f32x4 acc2[6];
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) acc2[2 * pp + s] = ld4g(p.b2 + (size_t)t * 3 * H + pp * H + cw + 16 * s + ch);
+    fence_sched();
+    {
+      f32x4 hv[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        hv[s] = acc1[s];                               // (incl. b1)
+        *reinterpret_cast<f32x4*>(bufA + mrow * LD + cw + 16 * s + ch) = ssilu4(hv[s]);
+      }
+      store16<H>(scr, lane, hv, hb_r, cw);
+    }
+    __syncthreads();
+    // ---- xh = a W2^T + b2
+    mma16_panel<H, 6, false>(acc2, bufA + mrow * LD + ch, bp2, r2);
+    if (t + 1 < p.T) request1(t + 1);
+    fence_sched();
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) {
+      const f32x4 v[2] = {acc2[2 * pp], acc2[2 * pp + 1]};
+      store16<3 * H>(scr, lane, v, xh_r, pp * H + cw);
+    }
+  }
+}
+
+// The projection as a kernel of its own (the unfused form: A/B and bit-for-bit check of the fused kernel's second half)
+template <int H>
+__global__ __launch_bounds__(256, HN_U16_MINW) void node_pre_fwd16_kernel(PreFwdArgs p) {
+  constexpr int TR = kTR16, LD = H + 8;
+  extern __shared__ __align__(16) float lds[];               // 3 x [TR][LD], then 4 x [16][36] scratch
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * TR, nrows = min(TR, p.Ns - row0);
+  const rsrc_t x_r = tile_rsrc(p.x + (size_t)row0 * H, nrows * H);
+  Tile16Regs<H> regs;
+  tile16_load<H>(regs, x_r, H, 0, tid);
+  tile16_store<H, LD>(lds + 2 * TR * LD, regs, tid);
+  __syncthreads();
+  pre_fwd16_phase<H>(p, lds + 2 * TR * LD, lds, lds + TR * LD, lds + 3 * TR * LD + wave * kScr16Floats, row0, nrows, tid, lane, wave);
+}
+
+// =====================================================================================================================
+// node_update_fwd on 16-row tiles (H = 128: four waves x 32 channels); FUSE: + the next layer's node projection of the tile
+// =====================================================================================================================
+template <int H, bool FUSE>
+__global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(UpdFwdArgs a, PreFwdArgs p) {
   static_assert(H == 128, "four waves x 32 channels");
   constexpr int TR = kTR16, LD = H + 8, NB16 = H / 16;       // NB16: 16-channel blocks per part
-  extern __shared__ __align__(16) float lds[];               // 2 x [TR][LD], then 4 x [16][36] scratch
+  extern __shared__ __align__(16) float lds[];               // 2 (FUSE: 3) x [TR][LD], then 4 x [16][36] scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* scr = lds + 2 * TR * LD + wave * kScr16Floats;
+  float* scr = lds + (FUSE ? 3 : 2) * TR * LD + wave * kScr16Floats;
   const TileInfo ti = find_tile(a.type_rowptr, a.T, a.N, TR, blockIdx.x);
   const int row0 = ti.row0, nrows = ti.nrows, t = ti.t;
   if (t >= a.T) {                                 // rows of unknown elements: zero
@@ -146,6 +277,12 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
       *reinterpret_cast<f32x4*>(a.x_out + (size_t)r * H + c) = zero4();
 #pragma unroll
       for (int d = 0; d < 3; ++d) *reinterpret_cast<f32x4*>(a.vec_out + ((size_t)r * 3 + d) * H + c) = zero4();
+    }
+    if constexpr (FUSE) {                         // (they are sources all the same: their projection runs on x = 0)
+      for (int idx = tid; idx < TR * (H / 4); idx += 256)
+        *reinterpret_cast<f32x4*>(lds + 2 * TR * LD + (idx / (H / 4)) * LD + (idx % (H / 4)) * 4) = zero4();
+      __syncthreads();
+      pre_fwd16_phase<H>(p, lds + 2 * TR * LD, lds, lds + TR * LD, scr, row0, nrows, tid, lane, wave);
     }
     return;
   }
@@ -276,6 +413,12 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
   store16<2 * H>(scr, lane, q, q23_r, cw);
   store16<2 * H>(scr, lane, r, q23_r, H + cw);
   store16<H>(scr, lane, xo, xo_r, cw);
+  if constexpr (FUSE) {
+    // the rows this tile has just produced are the next layer's LayerNorm input: a third tile takes them (buffers 0 / 1 may
+    // still be read by slower waves), the barrier behind the vec_out stores publishes it
+#pragma unroll
+    for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(lds + 2 * TR * LD + mrow * LD + cw + 16 * s + ch) = xo[s];
+  }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     f32x4 vo[2];
@@ -284,20 +427,121 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
     for (int s = 0; s < 2; ++s) vo[s] = (vo[s] + r[s] * kv1[d][s]) * on;
     store16<3 * H>(scr, lane, vo, vo_r, d * H + cw);
   }
+  if constexpr (FUSE) {
+    __syncthreads();
+    pre_fwd16_phase<H>(p, lds + 2 * TR * LD, lds, lds + TR * LD, scr, row0, nrows, tid, lane, wave);
+  }
 }
 
 // =====================================================================================================================
-// node_update_bwd on 16-row tiles
+// The backward of the node projection on one 16-row tile:  gn_t = ((gxh[t] W2_t) * ScaledSiLU'(hb[t])) W1_t  per relation.
 // =====================================================================================================================
+// LDS floats of the phase: the gxh tile [16][3H + 8] (3H + 8 = 8 mod 64 like H + 8: the same conflict-free ds_read_b128 pattern),
+// then the gh tile [16][H + 8]
+constexpr int pre_bwd16_tile_floats(int H) { return kTR16 * (3 * H + 8); }
+
 template <int H>
+struct Tile16Regs3 { f32x4 v[kTR16 * 3 * H / 4 / 256]; };
+
+// `parts` != null: gn_t goes to parts[t] (the unfused form: the consumer sums the relations and runs the LayerNorm backward);
+// null: gsum = (gn_0 + gn_1) + gn_2 ... in this lane's accumulator positions (the same additions in the same order as the
+// consumer's).  Per wave and relation 192 + 64 MFMAs, two barriers; relation t + 1's gxh tile travels during relation t's products.
+template <int H>
+__device__ __forceinline__ void pre_bwd16_phase(const float* gxh, const float* hb, const float* w2tf, const float* w1tf,
+                                                float* parts, int Ns, int T, float* tileA, float* bufG, float* scr,
+                                                int row0, int nrows, int tid, int lane, int wave, f32x4 (&gsum)[2]) {
+  constexpr int LD = H + 8, LDA = 3 * H + 8, V3 = 3 * H / 4, F4 = kTR16 * 3 * H / 4 / 256;
+  const int mrow = lane & 15, ch = 4 * (lane >> 4), cw = 32 * wave;
+  Tile16Regs3<H> regs;
+  Load16 lhb;
+  Ring16<2> ra;
+  const f32x4* bpa[2];
+  auto request = [&](int t) {          // relation t's gxh tile (cooperative, coalesced), hb block and first weight groups
+    const rsrc_t g_r = tile_rsrc(gxh + ((size_t)t * Ns + row0) * 3 * H, nrows * 3 * H);
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + it * 256;
+      regs.v[it] = bld4(g_r, (idx / V3) * 3 * H + (idx % V3) * 4);
+    }
+    issue16<H>(lhb, lane, tile_rsrc(hb + ((size_t)t * Ns + row0) * H, nrows * H), cw);
+  };
+  auto request_w = [&](int t) {
+    const f32x4* w2t = reinterpret_cast<const f32x4*>(w2tf + (size_t)t * 3 * H * H) + lane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) bpa[s] = w2t + (size_t)(2 * wave + s) * (3 * H / 16) * 64;
+    b16_preload(ra, bpa);
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < F4; ++it) {
+      const int idx = tid + it * 256;
+      *reinterpret_cast<f32x4*>(tileA + (idx / V3) * LDA + (idx % V3) * 4) = regs.v[it];
+    }
+  };
+  request(0);
+  request_w(0);
+  stage();
+  __syncthreads();
+#pragma unroll 1
+  for (int t = 0; t < T; ++t) {
+    Load16 hb_now = lhb;
+    if (t + 1 < T) request(t + 1);                   // in flight during the product below
+    fence_sched();
+    // ---- ga = gxh[t] W2_t   (K = 3H)
+    f32x4 acc[2] = {zero4(), zero4()};
+    mma16_panel<3 * H, 2, false>(acc, tileA + mrow * LDA + ch, bpa, ra);
+    const f32x4* w1t = reinterpret_cast<const f32x4*>(w1tf + (size_t)t * H * H) + lane;
+    const f32x4* bpb[2] = {w1t + (size_t)(2 * wave) * (H / 16) * 64, w1t + (size_t)(2 * wave + 1) * (H / 16) * 64};
+    Ring16<2> rb;
+    b16_preload(rb, bpb);
+    fence_sched();
+    __syncthreads();                                 // every wave has read the gxh tile (and the previous relation's gh tile)
+    {
+      f32x4 hbv[2];
+      finish16(scr, lane, hb_now, hbv);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(bufG + mrow * LD + cw + 16 * s + ch) = acc[s] * dssilu4(hbv[s]);
+    }
+    if (t + 1 < T) { stage(); request_w(t + 1); }
+    fence_sched();
+    __syncthreads();
+    // ---- gn_t = gh W1_t
+    f32x4 acc2[2] = {zero4(), zero4()};
+    mma16_panel<H, 2, false>(acc2, bufG + mrow * LD + ch, bpb, rb);
+    if (parts != nullptr) {
+      store16<H>(scr, lane, acc2, tile_rsrc(parts + ((size_t)t * Ns + row0) * H, nrows * H), cw);
+    } else if (t == 0) {
+      gsum[0] = acc2[0]; gsum[1] = acc2[1];
+    } else {
+      gsum[0] += acc2[0]; gsum[1] += acc2[1];
+    }
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(256, HN_U16_MINW) void node_pre_bwd16_kernel(PreBwdArgs a) {
+  constexpr int TR = kTR16, LD = H + 8;
+  extern __shared__ __align__(16) float lds[];               // [TR][3H + 8], [TR][LD], then 4 x [16][36] scratch
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * TR, nrows = min(TR, a.Ns - row0);
+  f32x4 unused[2];
+  pre_bwd16_phase<H>(a.gxh, a.hb, a.w2tf, a.w1tf, a.gn, a.Ns, a.T, lds, lds + pre_bwd16_tile_floats(H),
+                     lds + pre_bwd16_tile_floats(H) + TR * LD + wave * kScr16Floats, row0, nrows, tid, lane, wave, unused);
+}
+
+// =====================================================================================================================
+// node_update_bwd on 16-row tiles; FUSE: the backward of the layer ABOVE's node projection runs in front, on the same rows
+// =====================================================================================================================
+template <int H, bool FUSE>
 __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_bwd16_kernel(UpdBwdArgs a) {
   static_assert(H == 128, "four waves x 32 channels");
   constexpr int TR = kTR16, LD = H + 8, NB16 = H / 16, V = H / 4, F4 = TR * H / 4 / 256;
-  extern __shared__ __align__(16) float lds[];               // 2 x [TR][LD], then 4 x [16][36] scratch
+  // 2 x [TR][LD], then 4 x [16][36] scratch; FUSE: [TR][3H + 8] (later the two tiles), [TR][LD], then the scratch
+  extern __shared__ __align__(16) float lds[];
   float* buf0 = lds;
   float* buf1 = lds + TR * LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* scr = lds + 2 * TR * LD + wave * kScr16Floats;
+  float* scr = lds + (FUSE ? pre_bwd16_tile_floats(H) + TR * LD : 2 * TR * LD) + wave * kScr16Floats;
   const TileInfo ti = find_tile(a.type_rowptr, a.T, a.N, TR, blockIdx.x);
   const int row0 = ti.row0, nrows = ti.nrows, t = ti.t;
   if (t >= a.T) {
@@ -309,7 +553,21 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_bwd16_kernel(Upd
     }
     return;
   }
-  if (a.pend.gn != nullptr) materialise_pending<H, TR>(a, row0, nrows, tid);   // (incoming gradients still in partial sums)
+  if constexpr (FUSE) {
+    // the projection's backward of the layer above on these rows: its sum over the relations stays in registers, goes through
+    // one LDS tile into the LayerNorm backward, and gx_out / gvec_out of the tile are formed as in the unfused form
+    f32x4 gsum[2];
+    float* bufG = lds + pre_bwd16_tile_floats(H);
+    pre_bwd16_phase<H>(a.pend.gxh, a.pend.hb, a.pend.w2tf, a.pend.w1tf, nullptr, a.N, a.pend.nparts, lds, bufG, scr, row0, nrows,
+                       tid, lane, wave, gsum);
+    // (into the gxh tile's space: its last readers -- the last relation's first product -- are two barriers back)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(lds + (lane & 15) * LD + 32 * wave + 16 * s + 4 * (lane >> 4)) = gsum[s];
+    __syncthreads();
+    materialise_pending<H, TR, true>(a, row0, nrows, tid, lds, LD);
+  } else {
+    if (a.pend.gn != nullptr) materialise_pending<H, TR>(a, row0, nrows, tid);   // (incoming gradients still in partial sums)
+  }
   const f32x4* wx2t = reinterpret_cast<const f32x4*>(a.wx2tf + (size_t)t * 3 * H * H) + lane;   // [H, 3H]
   const f32x4* wx0t = reinterpret_cast<const f32x4*>(a.wx0tf + (size_t)t * 2 * H * H) + lane;   // [2H, H]
   const f32x4* wvt = reinterpret_cast<const f32x4*>(a.wvtf + (size_t)t * 2 * H * H) + lane;     // [H, 2H]
@@ -469,12 +727,42 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_bwd16_kernel(Upd
 // must hold frag16 copies (include/hermnet_hip.h: hermnet_node_update_fwd, "16-row form").
 int hn_update16_supported(int hidden) { return hidden == 128; }
 
+namespace {
+constexpr size_t kLdsUpd16 = (size_t)(2 * 16 * 136 + 4 * kScr16Floats) * 4;
+constexpr size_t kLdsFwdFused16 = (size_t)(3 * 16 * 136 + 4 * kScr16Floats) * 4;
+constexpr size_t kLdsBwdFused16 = (size_t)(pre_bwd16_tile_floats(128) + 16 * 136 + 4 * kScr16Floats) * 4;
+
+int launch_fwd16(bool fuse, int tiles, size_t lds_bytes, void* stream, const UpdFwdArgs& a, const PreFwdArgs& p) {
+  if (fuse) hipLaunchKernelGGL((node_update_fwd16_kernel<128, true>), dim3((unsigned)tiles), dim3(256), lds_bytes, (hipStream_t)stream, a, p);
+  else hipLaunchKernelGGL((node_update_fwd16_kernel<128, false>), dim3((unsigned)tiles), dim3(256), lds_bytes, (hipStream_t)stream, a, p);
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}
+}  // namespace
+
 int hn_update16_fwd(int hidden, const UpdFwdArgs& a, int tiles, void* stream) {
   if (hidden != 128) return HN_ERR_BAD_ARG;
-  return launch_chain(node_update_fwd16_kernel<128>, dim3((unsigned)tiles), (size_t)(2 * 16 * 136 + 4 * kScr16Floats) * 4, stream, a);
+  return launch_fwd16(false, tiles, kLdsUpd16, stream, a, PreFwdArgs{});
+}
+
+// update of layer l + node projection of layer l + 1 on the same 16-row tiles (p.x is unused: the rows come from the update)
+int hn_update16_pre_fwd(int hidden, const UpdFwdArgs& a, const PreFwdArgs& p, int tiles, void* stream) {
+  if (hidden != 128 || p.Ns != a.N || p.src_ranges != nullptr || p.wmode != 0) return HN_ERR_BAD_ARG;
+  return launch_fwd16(true, tiles, kLdsFwdFused16, stream, a, p);
 }
 
 int hn_update16_bwd(int hidden, const UpdBwdArgs& a, int tiles, void* stream) {
   if (hidden != 128) return HN_ERR_BAD_ARG;
-  return launch_chain(node_update_bwd16_kernel<128>, dim3((unsigned)tiles), (size_t)(2 * 16 * 136 + 4 * kScr16Floats) * 4, stream, a);
+  if (a.pend.gxh != nullptr)
+    return launch_chain(node_update_bwd16_kernel<128, true>, dim3((unsigned)tiles), kLdsBwdFused16, stream, a);
+  return launch_chain(node_update_bwd16_kernel<128, false>, dim3((unsigned)tiles), kLdsUpd16, stream, a);
+}
+
+int hn_pre16_fwd(int hidden, const PreFwdArgs& p, void* stream) {
+  if (hidden != 128 || p.src_ranges != nullptr || p.wmode != 0) return HN_ERR_BAD_ARG;
+  return launch_chain(node_pre_fwd16_kernel<128>, dim3((unsigned)((p.Ns + 15) / 16)), kLdsFwdFused16, stream, p);
+}
+
+int hn_pre16_bwd(int hidden, const PreBwdArgs& a, void* stream) {
+  if (hidden != 128 || a.src_ranges != nullptr || a.wmode != 0) return HN_ERR_BAD_ARG;
+  return launch_chain(node_pre_bwd16_kernel<128>, dim3((unsigned)((a.Ns + 15) / 16)), kLdsBwdFused16, stream, a);
 }

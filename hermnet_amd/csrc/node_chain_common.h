@@ -69,6 +69,11 @@ struct PendingGrads {
   const float* gx1;         // [N, H]     that layer's update-backward results: the residual's identity terms
   const float* gvec1;       // [N, 3, H]
   int nparts, Hr;
+  // fused form (node_chain16.hip: node_pre_bwd of the layer above inside this launch): gn is null, the chain runs on
+  const float* gxh;         // [nparts, N, 3H]  that layer's message-backward result (null: gn holds the partial sums)
+  const float* hb;          // [nparts, N, H]   its saved pre-activations
+  const float* w2tf;        // [nparts] frag16 of W2_t^T [H, 3H]
+  const float* w1tf;        // [nparts] frag16 of W1_t^T [H, H]
 };
 
 struct UpdBwdArgs {
@@ -531,8 +536,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_parts_kernel(const float* _
 // workgroup's tile, in the same order of operations (bit-identical), into gxo / gvo; the barrier at the end makes the rows
 // visible to the whole workgroup, which then reads them like any other input.  Rows >= identity_rows (atoms of an unknown
 // element) have no residual term.
-template <int H, int TR>
-__device__ __forceinline__ void materialise_pending(const UpdBwdArgs& a, int row0, int nrows, int tid) {
+// TILE (fused form, H = 128): the sum over the relations of gn for the rows of this tile already sits in `gn_tile` ([TR][ld_tile]
+// in LDS, written by the chain that ran in this launch) instead of p.gn's partial sums in memory.
+template <int H, int TR, bool TILE = false>
+__device__ __forceinline__ void materialise_pending(const UpdBwdArgs& a, int row0, int nrows, int tid,
+                                                    const float* gn_tile = nullptr, int ld_tile = 0) {
+  static_assert(!TILE || H == 128, "the fused form exists at width 128");
   const PendingGrads& p = a.pend;
   const int identity_rows = a.type_rowptr[a.T];
   float* gxo = const_cast<float*>(a.gxo);
@@ -565,17 +574,20 @@ __device__ __forceinline__ void materialise_pending(const UpdBwdArgs& a, int row
       const int lr = it * 8 + wave * 2 + (lane >> 5);
       rr[it] = lr < nrows ? row0 + lr : -1;
       const size_t r = (size_t)(rr[it] >= 0 ? rr[it] : row0);
-      gg[it] = *reinterpret_cast<const f32x4*>(p.gn + r * H + c);
+      if (TILE) gg[it] = *reinterpret_cast<const f32x4*>(gn_tile + (rr[it] >= 0 ? lr : 0) * ld_tile + c);
+      else gg[it] = *reinterpret_cast<const f32x4*>(p.gn + r * H + c);
       xv[it] = *reinterpret_cast<const f32x4*>(p.x + r * H + c);
       av[it] = *reinterpret_cast<const f32x4*>(p.gx1 + r * H + c);
       mu[it] = p.mean[r];
       rs[it] = p.rstd[r];
     }
-    for (int t = 1; t < p.nparts; ++t) {
+    if (!TILE) {
+      for (int t = 1; t < p.nparts; ++t) {
 #pragma unroll
-      for (int it = 0; it < RP; ++it) {
-        const size_t r = (size_t)(rr[it] >= 0 ? rr[it] : row0);
-        gg[it] += *reinterpret_cast<const f32x4*>(p.gn + t * ps + r * H + c);
+        for (int it = 0; it < RP; ++it) {
+          const size_t r = (size_t)(rr[it] >= 0 ? rr[it] : row0);
+          gg[it] += *reinterpret_cast<const f32x4*>(p.gn + t * ps + r * H + c);
+        }
       }
     }
 #pragma unroll

@@ -10,7 +10,8 @@ from .elements import atomic_numbers
 from .ops import EdgeGeometry, TrueEdgeGradient, edge_radial_table, side_stream
 from .relations import RelationalGraph
 from .sharding import HaloExchange, HaloExchangeFeatures, HaloGradReturn, SumAcrossRanks
-from .layer import EdgeFanout, EdgeGradSink, EnergyHead, FusedRelationalLayer, LayerWeights, _node_chain_enabled, _PENDING
+from .layer import (EdgeFanout, EdgeGradSink, EnergyHead, FusedRelationalLayer, LayerWeights, _node_chain_enabled, _PENDING,
+                    _PRE_NEXT)
 from .rmnet import PaiNNModule, RadialBasis, ScaledSiLU, relational_layer
 
 
@@ -77,12 +78,20 @@ class HeteroVertexConv(nn.Module):
                  and halo is None and not g.num_src and data.get("_hn_shard") is None
                  and not torch.is_anomaly_enabled()
                  and not getattr(data.x, "_backward_hooks", None) and not getattr(data.vec, "_backward_hooks", None))
-        pre, data._hn_pre0 = data.get("_hn_pre0"), None      # (the first layer's node projection, launched by HVNet.forward)
-        if pre is not None and not (w.chain and _node_chain_enabled() and halo is None and pre[0] is data.x):
+        # the node projection of THIS x, already computed: the first layer's by HVNet.forward (side stream), every later layer's
+        # by the fused update launch of the layer below (round 5)
+        pre, data._hn_pre0 = data.get("_hn_pre0"), None
+        if pre is not None and not (w.chain and _node_chain_enabled() and halo is None
+                                    and pre[0].data_ptr() == data.x.data_ptr() and pre[0].shape == data.x.shape):
             pre = None
+        # the next layer's weights: its projection of the rows this layer produces can run inside this layer's update launch
+        w_next = None
+        if ready is not None and li + 1 < len(ready) and halo is None and data.get("_hn_shard") is None:
+            w_next = ready[li + 1]
         data.x, data.vec = FusedRelationalLayer.apply(data.x, data.vec, edge, g, data._hn_rbf, w,
                                                       data.get("_hn_edge_sink"), li, halo, defer,
-                                                      None if pre is None else pre[1])
+                                                      None if pre is None else pre[1], w_next)
+        data._hn_pre0 = _PRE_NEXT.pop((id(g), li + 1), None)
         data._hn_chain_node = data.x.grad_fn if (w.chain and _node_chain_enabled() and not g.num_src) else None
         return data
 
@@ -198,7 +207,7 @@ class HVNet(nn.Module):
     def _refresh_weights(self, dev):
         """Every layer's kernel-ready copies, current; fingerprints recorded / checked on the device (one launch)."""
         from .guard import ParamGuard
-        guard_on = os.environ.get("HERMNET_PARAM_GUARD", "1") != "0"
+        guard_on = dev.type == "cuda" and os.environ.get("HERMNET_PARAM_GUARD", "1") != "0"
         for _ in range(2):
             ws = []
             for conv in self.hermconvs:
@@ -318,7 +327,7 @@ class HVNet(nn.Module):
             x = torch.nn.functional.pad(x, (0, Hp - H))
         data._hn_pre0 = None
         data._hn_weights = None
-        if fused and pos.is_cuda and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0":
+        if fused and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0":
             data._hn_weights = self._refresh_weights(pos.device)
         if graph.ready is not None:
             # (the edge part of the build is still running on the side stream: the row arrays above are the cached ones)
@@ -367,6 +376,7 @@ class HVNet(nn.Module):
             data._hn_edge_sink = EdgeGradSink(len(self.hermconvs), Hp // 64, graph.E, pos.device, zero=not all_known)
             data._hn_edge_handles = EdgeFanout.apply(edge, data._hn_edge_sink)
         _PENDING.clear()                      # (leftovers of a backward pass that did not complete)
+        _PRE_NEXT.clear()
         for li, conv in enumerate(self.hermconvs):
             data._hn_layer = li
             data = conv(data)

@@ -115,12 +115,15 @@ class LayerWeights(object):
             self.wvf, self.wvtf = fr(self.wv_s), fr(self.wvt_s)
             self.wx0f, self.wx0tf = fr(self.wx0_s), fr(self.wx0t_s)
             self.wx2f, self.wx2tf = fr(self.wx2_s), fr(self.wx2t_s)
-            self.wvf16 = None
+            self.wvf16 = self.w1f16 = None
             if Hp == 128:        # the update chain's 16-row form (csrc/node_chain16.hip) reads frag16 copies
                 f16 = nodeops.weight_fragments16
                 self.wvf16, self.wvtf16 = f16(self.wv_s), f16(self.wvt_s)
                 self.wx0f16, self.wx0tf16 = f16(self.wx0_s), f16(self.wx0t_s)
                 self.wx2f16, self.wx2tf16 = f16(self.wx2_s), f16(self.wx2t_s)
+                # the node projection on 16-row tiles (the fused layer boundary, csrc/node_chain16.hip)
+                self.w1f16, self.w1tf16 = f16(w1s), f16(w1s.transpose(1, 2).contiguous())
+                self.w2f16, self.w2tf16 = f16(self.w2), f16(self.w2t)
         self.key = key
         self.builds += 1
         return self
@@ -273,13 +276,23 @@ class EdgeFanout(torch.autograd.Function):
 # gradients handed down as partial sums, keyed by (graph, index of the consuming layer) (nodeops.PendingGrads);
 # an entry lives from one layer's backward to the next one's (HVNet.forward clears leftovers of an interrupted pass)
 _PENDING = {}
+# the NEXT layer's node projection, computed by a layer's fused update launch: (graph, index of the next layer) ->
+# (x_out, (hb, xh, mean, rstd)); HeteroVertexConv.forward hands it to that layer (`pre`)
+_PRE_NEXT = {}
+
+
+def _boundary_mode():
+    """HERMNET_FUSE_BOUNDARY: 1 (default) = one node launch per layer boundary each way where it is supported (width 128,
+    16-row update tiles, HVNet rows: csrc/node_chain16.hip); 2 = the same 16-row phases as separate launches (the A/B and
+    bit-for-bit check of the fused kernels); 0 = the round-4 form (64-row projection kernels)."""
+    return int(_os.environ.get("HERMNET_FUSE_BOUNDARY", "1"))
 
 
 class FusedRelationalLayer(torch.autograd.Function):
     """(x, vec, edge) -> (x_out, vec_out) for one layer, relation (row) order."""
 
     @staticmethod
-    def forward(ctx, x, vec, edge, graph, rbf, w, sink=None, li=0, halo=None, defer=False, pre=None):
+    def forward(ctx, x, vec, edge, graph, rbf, w, sink=None, li=0, halo=None, defer=False, pre=None, w_next=None):
         """`edge`: [E,4], or this layer's handle from `EdgeFanout` ([H/64,E,4] stride-0 view; same memory).
         x / vec live in SOURCE rows, the outputs in TARGET rows; the two coincide for HVNet and differ for HTNet
         (`graph.num_src`: one target row per atom and pair relation, relations.build_triadic).
@@ -290,7 +303,10 @@ class FusedRelationalLayer(torch.autograd.Function):
         backward hands its input gradients down as partial sums (`nodeops.PendingGrads`) and the update backward of the
         layer below forms them in its own launch -- two small launches per layer boundary less, same bits.
         `pre` (chain path without halo): the node projection of THIS x, already launched by the caller (HVNet.forward runs the
-        first layer's beside the relation build)."""
+        first layer's beside the relation build; round 5: every later layer's comes out of the fused update launch of the
+        layer below).
+        `w_next` (round 5): the NEXT layer's weights -- its node projection of the rows this layer produces runs inside this
+        layer's update launch where `nodeops.fused_boundary_supported` (result left in `_PRE_NEXT`)."""
         Ns, H = x.shape
         N = graph.N
         T = graph.T
@@ -332,7 +348,17 @@ class FusedRelationalLayer(torch.autograd.Function):
                              out=out, range_rows=halo.late_rows)
             ctx.halo = halo
             ctx.defer = bool(defer) and halo is None and vec is not None
-            x_out, vec_out, vp, h2b, q23, nrm = nodeops.node_update_fwd(x1, vec1, w, graph)
+            mode = _boundary_mode()
+            if (w_next is not None and halo is None and mode in (1, 2)
+                    and nodeops.fused_boundary_supported(graph, H, w, w_next)):
+                if mode == 1:
+                    x_out, vec_out, vp, h2b, q23, nrm, pre_next = nodeops.node_update_pre_fwd(x1, vec1, w, graph, w_next)
+                else:
+                    x_out, vec_out, vp, h2b, q23, nrm = nodeops.node_update_fwd(x1, vec1, w, graph)
+                    pre_next = nodeops.node_pre_fwd16(x_out, w_next, T)
+                _PRE_NEXT[(id(graph), li + 1)] = (x_out, pre_next)
+            else:
+                x_out, vec_out, vp, h2b, q23, nrm = nodeops.node_update_fwd(x1, vec1, w, graph)
             ctx.save_for_backward(x, mean, rstd, hb, xh, vec, edge, vp, h2b, q23, nrm)
             ctx.graph, ctx.rbf, ctx.w, ctx.sink, ctx.li = graph, rbf, w, sink, li
             return x_out, vec_out
@@ -467,22 +493,32 @@ class FusedRelationalLayer(torch.autograd.Function):
                 work.wait()
             nodeops.halo_accumulate(gx_total, gvec_in, plan, back)                  # gradients of my atoms used elsewhere
             ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
-            return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None
+            return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None, None
         ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
         if ctx.chain and _bwd_sums_deferrable(graph, H):
             if ctx.defer and ctx.needs_input_grad[0]:
                 gxh, gv_parts = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=False, finish=False)
-                gn_parts = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, src_ranges=graph.src_ranges, parts_only=True)
+                mode, chain = _boundary_mode(), None
+                if mode in (1, 2) and nodeops.fused_boundary_supported(graph, H, w):
+                    # round 5: this layer's projection backward runs inside the update backward of the layer below (1), or as
+                    # the same 16-row phase in a launch of its own (2)
+                    if mode == 1:
+                        gn_parts, chain = None, (gxh, hb, w.w2tf16, w.w1tf16)
+                    else:
+                        gn_parts = nodeops.node_pre_bwd16(gxh, hb, w)
+                else:
+                    gn_parts = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, src_ranges=graph.src_ranges, parts_only=True)
                 gx_total, gvec_in = torch.empty_like(x), torch.empty_like(vec)      # filled by the layer below
                 if _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":            # (tests: nothing reads them before that)
                     gx_total.fill_(float("nan"))
                     gvec_in.fill_(float("nan"))
-                _PENDING[(id(graph), ctx.li - 1)] = nodeops.PendingGrads(
-                    gx_total, gvec_in, gn_parts, gv_parts, x, mean, rstd, gx1, gvec1, w.h_real)
-                return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None
+                pend = _PENDING[(id(graph), ctx.li - 1)] = nodeops.PendingGrads(
+                    gx_total, gvec_in, gn_parts, gv_parts, x, mean, rstd, gx1, gvec1, w.h_real, chain=chain)
+                pend.w_above = w            # (keeps the fragment copies alive; the CPU restatement of the tests reads it)
+                return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None, None
             if vec is None and not ctx.needs_input_grad[0]:     # the first layer: nothing below wants gx / gvec
                 _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=False, finish=False)
-                return None, None, ge, None, None, None, None, None, None, None, None
+                return None, None, ge, None, None, None, None, None, None, None, None, None
         gxh, gvec_in, gx_in = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=not ctx.chain)
         _virtual_residual(graph, gx1, gvec1, gx_in, gvec_in, H)
         gx_total = None
@@ -494,7 +530,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                 gh = nodeops.ssilu_bwd(ga, h, Ns, T, H, H, Ns * H)                   # [Ns, T*H]
                 gn = _launch("gemm", lambda: torch.mm(gh, w.w1cat))                                           # [N, H]
                 gx_total = nodeops.layernorm_bwd(gn, x, mean, rstd, add=gx_in, h_real=w.h_real)
-        return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None
+        return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None, None
 
 
 class EnergyHead(torch.autograd.Function):

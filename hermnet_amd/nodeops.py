@@ -293,12 +293,76 @@ def node_update_fwd(x1, vec1, w, graph):
 
 class PendingGrads(object):
     """The gradients a layer's backward hands DOWN while they still sit in partial sums (hn_pending_grads): `gx` / `gvec`
-    are the buffers the consumer -- the update backward of the layer below -- fills before it reads them."""
+    are the buffers the consumer -- the update backward of the layer below -- fills before it reads them.
+    `chain` = (gxh, hb, w2tf16, w1tf16) (round 5, the fused form): the layer above has not even run its node_pre_bwd --
+    the consumer runs that chain on its own tiles first; `gn_parts` is then None."""
 
-    def __init__(self, gx, gvec, gn_parts, gvec_parts, x, mean, rstd, gx1, gvec1, h_real):
+    def __init__(self, gx, gvec, gn_parts, gvec_parts, x, mean, rstd, gx1, gvec1, h_real, chain=None):
         self.gx, self.gvec = gx, gvec
         self.tensors = (gn_parts, gvec_parts, x, mean, rstd, gx1, gvec1)        # (kept alive until consumed)
-        self.struct = _lib.PendingGrads(*[P(t) for t in self.tensors], gn_parts.size(0), h_real)
+        self.chain = chain
+        nparts = gvec_parts.size(0)
+        extra = [None] * 4 if chain is None else [P(t) for t in chain]
+        self.struct = _lib.PendingGrads(*[P(t) for t in self.tensors], nparts, h_real, *extra)
+
+
+def fused_boundary_supported(graph, H, w, w_next=None):
+    """The layer boundary as one node launch each way (csrc/node_chain16.hip): width 128, HVNet rows, and a row layout whose
+    update kernels run on 16-row tiles (small grids: nodeops.update_tile_rows).  `w_next`: the next layer's weights (forward
+    fusion: same width and relation count)."""
+    if H != 128 or getattr(w, "w1f16", None) is None or graph.num_src or getattr(graph, "res_row", None) is not None:
+        return False
+    if w_next is not None and (getattr(w_next, "w1f16", None) is None or w_next.b1cat.numel() != graph.T * H):
+        return False
+    return update_tile_rows(graph, H) == 16
+
+
+def node_update_pre_fwd(x1, vec1, w, graph, w_next):
+    """node_update_fwd of this layer + node_pre_fwd of the NEXT layer (weights `w_next`) on the rows it produces, ONE launch:
+    returns (x_out, vec_out, vp, h2b, q23, nrm, (hb, xh, mean, rstd))."""
+    N, H = x1.shape
+    T = graph.T
+    dev, dt = x1.device, x1.dtype
+    vp = torch.empty(N, 3, 2 * H, dtype=dt, device=dev)
+    h2b = torch.empty(N, H, dtype=dt, device=dev)
+    q23 = torch.empty(N, 2 * H, dtype=dt, device=dev)
+    nrm = torch.empty(N, H, dtype=dt, device=dev)
+    xo = torch.empty(N, H, dtype=dt, device=dev)
+    vo = torch.empty(N, 3, H, dtype=dt, device=dev)
+    hb = torch.empty(T, N, H, dtype=dt, device=dev)
+    xh = torch.empty(T, N, 3 * H, dtype=dt, device=dev)
+    mean = torch.empty(N, dtype=dt, device=dev)
+    rstd = torch.empty(N, dtype=dt, device=dev)
+    _lib.check(_launch("node_update_pre_fwd", lambda: _lib.load().hermnet_node_update_pre_fwd(
+        P(x1), P(vec1), P(w.wvf16), P(w.wx0f16), P(w.bx0_s), P(w.wx2f16), P(w.bx2_s), P(graph.row_active), P(graph.type_rowptr),
+        _rowptr_host(graph), P(vp), P(h2b), P(q23), P(nrm), P(xo), P(vo), N, T, H,
+        P(w_next.w1f16), P(w_next.b1cat), P(w_next.w2f16), P(w_next.b2), P(hb), P(xh), P(mean), P(rstd), T, w_next.h_real,
+        1e-5, _stream())), "hermnet_node_update_pre_fwd")
+    return xo, vo, vp, h2b, q23, nrm, (hb, xh, mean, rstd)
+
+
+def node_pre_fwd16(x, w, T):
+    """node_pre_fwd on 16-row tiles (the second half of node_update_pre_fwd as a launch of its own: A/B, bit-for-bit check)."""
+    Ns, H = x.shape
+    dev, dt = x.device, x.dtype
+    hb = torch.empty(T, Ns, H, dtype=dt, device=dev)
+    xh = torch.empty(T, Ns, 3 * H, dtype=dt, device=dev)
+    mean = torch.empty(Ns, dtype=dt, device=dev)
+    rstd = torch.empty(Ns, dtype=dt, device=dev)
+    _lib.check(_launch("node_pre_fwd16", lambda: _lib.load().hermnet_node_pre_fwd16(
+        P(x), P(w.w1f16), P(w.b1cat), P(w.w2f16), P(w.b2), P(hb), P(xh), P(mean), P(rstd), Ns, T, H, w.h_real, 1e-5,
+        _stream())), "hermnet_node_pre_fwd16")
+    return hb, xh, mean, rstd
+
+
+def node_pre_bwd16(gxh, hb, w):
+    """Per-relation partial sums gn [T,Ns,H] of node_pre_bwd on 16-row tiles (the first half of the fused update backward as
+    a launch of its own)."""
+    T, Ns, H = hb.shape
+    parts = torch.empty(T, Ns, H, dtype=hb.dtype, device=hb.device)
+    _lib.check(_launch("node_pre_bwd16", lambda: _lib.load().hermnet_node_pre_bwd16(
+        P(gxh), P(hb), P(w.w2tf16), P(w.w1tf16), P(parts), Ns, T, H, _stream())), "hermnet_node_pre_bwd16")
+    return parts
 
 
 def node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph, pending=None):

@@ -16,7 +16,9 @@
  *   - float = IEEE fp32 (the reference is fp32-only), indices = int32 (int64 where a parameter says so:
  *     the caller's edge_index / atomic_number / halo index lists arrive as torch LongTensors).
  *
- * ABI version 7 (`hermnet_abi_version`): v7 adds the row windows of the message kernels (interior / boundary launches
+ * ABI version 9 (`hermnet_abi_version`): v9 adds the fused layer-boundary node kernels (hermnet_node_update_pre_fwd, the `gxh`
+ * form of hn_pending_grads, hermnet_node_pre_fwd16 / _bwd16) and hermnet_param_guard; v8 the gradients handed down as partial sums
+ * (hn_pending_grads); v7 adds the row windows of the message kernels (interior / boundary launches
  * around the halo exchange), node chain kernels for every width that is a multiple of 64 up to 512, hermnet_stream_copy, and drops
  * the float-atomic mode 3 of hermnet_halo_rows; v6 added the target mask of the neighbour search (lists of an atom shard) and the
  * row windows of the node pre kernels (halo exchange overlap); v5 replaces the stand-alone node GEMM by the node chain kernels
@@ -411,6 +413,15 @@ typedef struct hn_pending_grads {
   const float* gvec1;
   int num_parts;            /* the relations T of the layer above */
   int hidden_real;          /* as in hermnet_node_pre_bwd (0 = hidden) */
+  /* ABI v9, fused form (tile_rows == 16 only; gn_parts is then unused and may be NULL): the layer above did not run
+   * hermnet_node_pre_bwd at all -- the update backward runs that chain for the rows of each of its tiles first,
+   *     gn_t = ((gxh[t] W2_t) * ScaledSiLU'(hb[t])) W1_t,   sum_t in registers in the order (gn_0 + gn_1) + gn_2 ...,
+   * then the LayerNorm backward on the tile: no [T, num_nodes, hidden] partial sums in memory, one launch less per layer
+   * boundary.  Bit-identical to hermnet_node_pre_bwd16 followed by the `gn_parts` form. */
+  const float* gxh;         /* [num_parts][num_nodes][3 hidden]  from hermnet_message_scatter_bwd (NULL: the gn_parts form) */
+  const float* hb;          /* [num_parts][num_nodes][hidden]    saved by the layer above's node projection */
+  const float* w2t_frag16;  /* [num_parts] frag16(W2_t^T [hidden, 3 hidden]), frag16(W1_t^T [hidden, hidden]) of the layer above */
+  const float* w1t_frag16;
 } hn_pending_grads;
 int hermnet_node_update_tile_rows(const int* type_rowptr_host, int num_nodes, int num_rel, int hidden);
 int hermnet_node_update_fwd(const float* x1, const float* vec1, const float* wv_frag, const float* wx0_frag,
@@ -424,6 +435,29 @@ int hermnet_node_update_bwd(const float* gx_out, const float* gvec_out, const fl
                             const float* row_active, const int* type_rowptr, const int* type_rowptr_host, float* gx1,
                             float* gvec1, int num_nodes, int num_rel, int hidden, int tile_rows,
                             const hn_pending_grads* pending, void* stream);
+
+/* ---- ABI v9: one node launch per layer boundary, each way (csrc/node_chain16.hip; hidden 128, 16-row tiles).
+ * A tile's PaiNNUpdate of layer l (rmnet.py:94-107, 29-31) and the node projection of layer l + 1 on the rows it has just
+ * produced (rmnet.py:52 for every relation of the NEXT layer) are row-local: hermnet_node_update_pre_fwd runs both in one
+ * launch -- the arguments of hermnet_node_update_fwd (16-row form: frag16 weights) followed by those of the next layer's
+ * projection (w1_frag16 = frag16 of [next_num_rel] W1 with the LayerNorm affine folded in, b1, w2_frag16, b2; outputs hb, xh,
+ * mean, rstd as hermnet_node_pre_fwd writes them, for all num_nodes rows).  The backward mirror is hermnet_node_update_bwd with
+ * pending->gxh set.  hermnet_node_pre_fwd16 / hermnet_node_pre_bwd16 run the same projection phases as kernels of their own
+ * (16-row tiles, frag16 weights; pre_bwd16 writes the per-relation partial sums gn_parts only): update_fwd(tile_rows = 16) +
+ * pre_fwd16 is bit-identical to update_pre_fwd, pre_bwd16 + update_bwd(pending->gn_parts) to update_bwd(pending->gxh). */
+int hermnet_node_fused_supported(int hidden);
+int hermnet_node_update_pre_fwd(const float* x1, const float* vec1, const float* wv_frag16, const float* wx0_frag16,
+                                const float* bx0, const float* wx2_frag16, const float* bx2, const float* row_active,
+                                const int* type_rowptr, const int* type_rowptr_host, float* vp, float* h2b, float* q23,
+                                float* nrm, float* x_out, float* vec_out, int num_nodes, int num_rel, int hidden,
+                                const float* w1_frag16, const float* b1, const float* w2_frag16, const float* b2, float* hb,
+                                float* xh, float* mean, float* rstd, int next_num_rel, int hidden_real, float eps,
+                                void* stream);
+int hermnet_node_pre_fwd16(const float* x, const float* w1_frag16, const float* b1, const float* w2_frag16, const float* b2,
+                           float* hb, float* xh, float* mean, float* rstd, int num_src, int num_rel, int hidden,
+                           int hidden_real, float eps, void* stream);
+int hermnet_node_pre_bwd16(const float* gxh, const float* hb, const float* w2t_frag16, const float* w1t_frag16,
+                           float* gn_parts, int num_src, int num_rel, int hidden, void* stream);
 
 /* HTNet (hermnet.py:155-157 is a stub; DESIGN.md "HTNet"): a centre atom's P pair relations are averaged.  Target rows
  * are [num_elem][pairs][block] blocks of `block` rows ("virtual" rows, one per atom and pair relation):

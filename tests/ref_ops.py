@@ -325,6 +325,23 @@ def node_update_fwd(x1, vec1, w, graph):
         return _node_update(x1, vec1, w, graph)
 
 
+def node_update_pre_fwd(x1, vec1, w, graph, w_next):
+    """hermnet_node_update_pre_fwd: this layer's update and the NEXT layer's node projection of the rows it produces."""
+    out = node_update_fwd(x1, vec1, w, graph)
+    return tuple(out) + (node_pre_fwd(out[0], w_next, graph.T),)
+
+
+def node_pre_fwd16(x, w, T):
+    return node_pre_fwd(x, w, T)
+
+
+def node_pre_bwd16(gxh, hb, w):
+    T, Ns, H = hb.shape
+    dt = hb.dtype
+    gh = torch.bmm(gxh, w.w2.to(dt)) * _dssilu(hb)
+    return torch.bmm(gh, w.w1cat.to(dt).view(T, H, H))
+
+
 def node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph, pending=None):
     """The kernel's backward formulas from the saved (vp, h2b, q23) (checked against autograd of the forward in
     tests/test_host_logic.py).  `pending` (hn_pending_grads): gxo / gvo are formed here first, from the partial sums of
@@ -333,6 +350,8 @@ def node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph, pending=None):
     dt = gxo.dtype
     if pending is not None:
         gn, gv, x, mean, rstd, gx1_up, gvec1_up = pending.tensors
+        if pending.chain is not None:       # the fused form: the layer above's projection backward runs here, on gxh
+            gn = node_pre_bwd16(pending.chain[0], pending.chain[1], pending.w_above)
         ident = (torch.arange(N) < graph.type_rowptr_host[-1]).to(dt)
         gxo.copy_(layernorm_bwd(gn.sum(0), x, mean, rstd, add=gx1_up * ident[:, None] / math.sqrt(2.0),
                                 h_real=pending.struct.hidden_real))

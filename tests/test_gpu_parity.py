@@ -349,6 +349,120 @@ def test_update_chain_on_16_row_tiles_matches_restatement(H, T, counts, uniform,
     assert _lib.load().hermnet_node_update_tile_rows(rp, 101397, 3, 128) == 32      # configs[3]: weight traffic wins
 
 
+@pytest.mark.parametrize("T,counts,uniform", [(3, (70, 91, 45), None), (3, (130, 3, 61), False), (1, (300,), None),
+                                              (3, (3300, 3400, 3341), None)])
+def test_layer_boundary_as_one_node_launch_each_way(T, counts, uniform, monkeypatch):
+    """Round 5 (rmnet.py:29-31, 94-107 then :52 of the next layer): csrc/node_chain16.hip.
+    (i)  The node projection and its backward on 16-row tiles (`hermnet_node_pre_fwd16` / `_bwd16`) vs the fp64 restatement.
+    (ii) `hermnet_node_update_pre_fwd` -- a tile's update and the NEXT layer's projection of the rows it has just produced in
+         ONE launch -- equals update (16-row form) + pre_fwd16 bit for bit, every output buffer NaN-poisoned beforehand; rows
+         of unknown elements and of an inactive relation included (their projection runs on x = 0).
+    (iii) `hermnet_node_update_bwd` with `pending->gxh` -- the projection's backward of the layer above inside the update
+         backward, sums over the relations in registers, LayerNorm backward on the tile -- equals pre_bwd16 + the `gn_parts`
+         form bit for bit (poisoned gx_out / gvec_out), and the fp64 restatement to rounding."""
+    from test_host_logic import _layer_weights_and_graph
+    from hermnet_amd import nodeops
+    import copy
+    H = 128
+    dev = _dev()
+    monkeypatch.setattr(nodeops, "update_tile_rows", lambda graph, H_: 16)
+    w, g = _layer_weights_and_graph(H, T, counts, uniform=uniform, unknown=5)
+    w2_, _ = _layer_weights_and_graph(H, T, counts, seed=7, uniform=uniform, unknown=5)      # the next layer's weights
+    gen = torch.Generator().manual_seed(3)
+    N = g.N
+    rnd = lambda *s_: torch.randn(*s_, generator=gen)
+    x1, vec1 = rnd(N, H), rnd(N, 3, H)
+
+    def on_dev(w_):
+        wd_ = copy.copy(w_)
+        for k, v in vars(w_).items():
+            if torch.is_tensor(v):
+                setattr(wd_, k, v.to(dev))
+        return wd_
+    wd, wn = on_dev(w), on_dev(w2_)
+    gd = copy.copy(g)
+    gd.row_active, gd.type_rowptr = g.row_active.to(dev), g.type_rowptr.to(dev)
+    gd._rowptr_c = None
+    c = lambda t: t.to(dev)
+    d64 = lambda t: t.double()
+    assert nodeops.fused_boundary_supported(gd, H, wd, wn)
+    # ---- (i) the projection phases as kernels of their own
+    x = rnd(N, H)
+    hb, xh, mean, rstd = nodeops.node_pre_fwd16(c(x), wn, T)
+    hb_r, xh_r, mean_r, rstd_r = ref_ops.node_pre_fwd(d64(x), w2_, T)
+    assert rel_err(hb.cpu().double(), hb_r) < 2e-6 and rel_err(xh.cpu().double(), xh_r) < 2e-6
+    assert rel_err(mean.cpu().double(), mean_r) < 2e-6 and rel_err(rstd.cpu().double(), rstd_r) < 2e-6
+    gxh = rnd(T, N, 3 * H) * 0.3
+    parts = nodeops.node_pre_bwd16(c(gxh), hb, wn)
+    parts_r = ref_ops.node_pre_bwd(d64(gxh), hb_r, d64(x), mean_r, rstd_r, w2_, parts_only=True)
+    assert rel_err(parts.cpu().double(), parts_r) < 5e-6
+    # ---- (ii) forward: fused == update + projection, bit for bit
+    xo, vo, vp, h2b, q23, nrm = nodeops.node_update_fwd(c(x1), c(vec1), wd, gd)
+    pre_u = nodeops.node_pre_fwd16(xo, wn, T)
+    real_empty = torch.empty
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **k).fill_(float("nan"))
+                        if k.get("dtype", torch.float32).is_floating_point else real_empty(*a, **k))
+    fused = nodeops.node_update_pre_fwd(c(x1), c(vec1), wd, gd, wn)
+    monkeypatch.setattr(torch, "empty", real_empty)
+    nk = g.type_rowptr_host[-1]
+    for k_, (a, b) in enumerate(zip(fused[:6], (xo, vo, vp, h2b, q23, nrm))):
+        if k_ >= 2:                     # saved tensors: defined on the rows of known elements
+            a, b = a[:nk], b[:nk]
+        assert torch.equal(a, b), k_
+    for a, b in zip(fused[6], pre_u):
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    # (and against the restatement through both stages)
+    refs = ref_ops.node_update_fwd(d64(x1), d64(vec1), w, g)
+    pre_r = ref_ops.node_pre_fwd(refs[0], w2_, T)
+    assert rel_err(fused[6][1].cpu().double(), pre_r[1]) < 5e-6
+    # ---- (iii) backward: fused == pre_bwd16 + the partial-sum form, bit for bit
+    hb2, xh2, mean2, rstd2 = fused[6]
+    gv_parts, gx1_up, gvec1_up = c(rnd(T, N, 3, H)), c(rnd(N, H)), c(rnd(N, 3, H))
+    gxh_d = c(gxh)
+    gn_parts = nodeops.node_pre_bwd16(gxh_d, hb2, wn)
+    nan = lambda *s_: torch.full(s_, float("nan"), device=dev)
+    bx, bv = nan(N, H), nan(N, 3, H)
+    want = nodeops.node_update_bwd(bx, bv, vp, h2b, q23, nrm, wd, gd,
+                                   pending=nodeops.PendingGrads(bx, bv, gn_parts, gv_parts, xo, mean2, rstd2, gx1_up, gvec1_up, 0))
+    fx, fv = nan(N, H), nan(N, 3, H)
+    got = nodeops.node_update_bwd(fx, fv, vp, h2b, q23, nrm, wd, gd,
+                                  pending=nodeops.PendingGrads(fx, fv, None, gv_parts, xo, mean2, rstd2, gx1_up, gvec1_up, 0,
+                                                               chain=(gxh_d, hb2, wn.w2tf16, wn.w1tf16)))
+    assert torch.equal(fx[:nk], bx[:nk]) and torch.equal(fv[:nk], bv[:nk])
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    assert bool(torch.isfinite(got[0]).all()) and bool(torch.isfinite(got[1]).all())
+    # restatement: LayerNorm backward over the summed parts + the residual's identity term, then the update backward
+    ident = (torch.arange(N) < nk).double()
+    gn_r = ref_ops.node_pre_bwd(d64(gxh), pre_r[0], refs[0], pre_r[2], pre_r[3], w2_, parts_only=True).sum(0)
+    gxo_r = ref_ops.layernorm_bwd(gn_r, refs[0], pre_r[2], pre_r[3], add=gx1_up.cpu().double() * ident[:, None] / math.sqrt(2.0))
+    gvo_r = gv_parts.cpu().double().sum(0) + gvec1_up.cpu().double() * ident[:, None, None]
+    gx1_r, gvec1_r = ref_ops.node_update_bwd(gxo_r, gvo_r, refs[2], refs[3], refs[4], refs[5], w, g)
+    assert rel_err(got[0].cpu().double(), gx1_r) < 1e-5 and rel_err(got[1].cpu().double(), gvec1_r) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["alloy108", "c1_si64", "alloy108_unknown_type", "mol16"])
+def test_fused_layer_boundary_changes_no_bit_of_the_model(name, monkeypatch):
+    """Model level: HERMNET_FUSE_BOUNDARY=1 (one node launch per layer boundary each way, the default) gives bit for bit the
+    energies and forces of the same 16-row phases run as separate launches (=2), with every buffer the consuming launches
+    must fill NaN-poisoned; the round-4 form (=0: 64-row projection kernels, another summation order) agrees to rounding;
+    all three meet the reference's golden."""
+    dev = _dev()
+    g = Golden(name)
+    model = g.model().to(dev)
+    out = {}
+    monkeypatch.setenv("HERMNET_DEBUG_POISON", "1")
+    for mode in ("1", "2", "0"):
+        monkeypatch.setenv("HERMNET_FUSE_BOUNDARY", mode)
+        d = g.data().to(dev)
+        d.pos.requires_grad_(True)
+        e = model(d)
+        f = -torch.autograd.grad(e.sum(), d.pos)[0]
+        out[mode] = (e.detach().clone(), f.clone())
+        assert rel_err(e.detach().cpu(), g.energy) < TOL and rel_err(f.cpu(), g.forces) < TOL, mode
+    assert torch.equal(out["1"][0], out["2"][0]) and torch.equal(out["1"][1], out["2"][1])
+    assert rel_err(out["1"][0], out["0"][0]) < 2e-6 and rel_err(out["1"][1], out["0"][1]) < 5e-6
+
+
 def _node_chain_case(H, T, counts, uniform, hr):
     """csrc/node_chain.hip (LayerNorm + x_proj chain, PaiNNUpdate chain and their backward kernels on the fp32 matrix
     pipe) vs the fp64 PyTorch restatement of tests/ref_ops.py: ragged relation blocks, an inactive relation, rows of

@@ -205,21 +205,44 @@ def test_fused_layer_orchestration_matches_golden(name, monkeypatch):
     monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
     monkeypatch.setattr(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
     for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid", "update_out", "update_out_bwd",
-               "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd", "node_update_bwd"]:
+               "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd", "node_update_bwd", "node_update_pre_fwd", "node_pre_fwd16", "node_pre_bwd16"]:
         monkeypatch.setattr(lmod.nodeops, fn, getattr(ref_ops, fn))
     monkeypatch.setattr(lmod, "_msg_fwd", ref_ops.msg_fwd)
     monkeypatch.setattr(lmod, "_msg_bwd", ref_ops.msg_bwd)
     # both forms of the backward hand-over between layers: finished gradients, and partial sums the update backward of the
     # layer below finishes (hn_pending_grads; on the GPU the form is picked by `_bwd_sums_deferrable`)
+    # ... and the three forms of the layer boundary (round 5): one node launch each way (HERMNET_FUSE_BOUNDARY=1: the next
+    # layer's projection inside this layer's update launch, its backward inside the update backward of the layer below), the
+    # same 16-row phases as launches of their own (2), the round-4 form (0)
+    calls = {}
+    for fn in ("node_update_pre_fwd", "node_pre_fwd16", "node_pre_bwd16", "node_pre_fwd", "node_pre_bwd"):
+        def counted(*a, _f=getattr(ref_ops, fn), _n=fn, **k):
+            calls[_n] = calls.get(_n, 0) + 1
+            return _f(*a, **k)
+        monkeypatch.setattr(lmod.nodeops, fn, counted)
+    L = g.model_kw["num_layers"]
     for deferred in (False, True):
         monkeypatch.setattr(lmod, "_bwd_sums_deferrable", lambda graph, H, v=deferred: v)
-        d = g.data()
-        d.pos.requires_grad_(True)
-        e = model(d)
-        f = -torch.autograd.grad(e.sum(), d.pos)[0]
-        assert not lmod._PENDING
-        assert rel_err(e.detach(), g.energy) < 2e-6
-        assert rel_err(f, g.forces) < 1e-5
+        for boundary in ("1", "2", "0"):
+            monkeypatch.setenv("HERMNET_FUSE_BOUNDARY", boundary)
+            calls.clear()
+            d = g.data()
+            d.pos.requires_grad_(True)
+            e = model(d)
+            f = -torch.autograd.grad(e.sum(), d.pos)[0]
+            assert not lmod._PENDING and not lmod._PRE_NEXT
+            assert rel_err(e.detach(), g.energy) < 2e-6
+            assert rel_err(f, g.forces) < 1e-5
+            if g.model_kw["hidden_channels"] == 128 and name != "alloy108_unknown_type_":
+                want = {"1": dict(node_update_pre_fwd=L - 1, node_pre_fwd=1),
+                        "2": dict(node_pre_fwd16=L - 1, node_pre_fwd=1),
+                        "0": dict(node_pre_fwd=L)}[boundary]
+                for k, v in want.items():
+                    assert calls.get(k, 0) == v, (boundary, deferred, calls)
+                if deferred and boundary == "1":       # no projection backward launch at all: it runs in the update backward
+                    assert calls.get("node_pre_bwd", 0) == 0 and calls.get("node_pre_bwd16", 0) == 0, calls
+                if deferred and boundary == "2":
+                    assert calls.get("node_pre_bwd16", 0) == L - 1 and calls.get("node_pre_bwd", 0) == 0, calls
 
 
 def test_lammps_plugin_helpers():
@@ -294,7 +317,7 @@ def test_eval_mode_parameters_are_constants_unless_asked(monkeypatch):
     monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
     monkeypatch.setattr(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
     for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid",
-               "update_out", "update_out_bwd", "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd", "node_update_bwd"]:
+               "update_out", "update_out_bwd", "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd", "node_update_bwd", "node_update_pre_fwd", "node_pre_fwd16", "node_pre_bwd16"]:
         monkeypatch.setattr(lmod.nodeops, fn, getattr(ref_ops, fn))
     monkeypatch.setattr(lmod, "_msg_fwd", ref_ops.msg_fwd)
     monkeypatch.setattr(lmod, "_msg_bwd", ref_ops.msg_bwd)
@@ -331,7 +354,7 @@ def test_width_not_multiple_of_64_runs_on_zero_padded_channels(H, monkeypatch):
     monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
     monkeypatch.setattr(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
     for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid",
-               "update_out", "update_out_bwd", "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd", "node_update_bwd"]:
+               "update_out", "update_out_bwd", "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd", "node_update_bwd", "node_update_pre_fwd", "node_pre_fwd16", "node_pre_bwd16"]:
         monkeypatch.setattr(lmod.nodeops, fn, getattr(ref_ops, fn))
     monkeypatch.setattr(lmod, "_msg_fwd", ref_ops.msg_fwd)
     monkeypatch.setattr(lmod, "_msg_bwd", ref_ops.msg_bwd)

@@ -25,7 +25,7 @@ def _patch_cpu_ops(monkeypatch=None):
     put(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
     put(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
     for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid", "update_out", "update_out_bwd",
-               "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd", "node_update_bwd", "halo_rows",
+               "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd", "node_update_bwd", "node_update_pre_fwd", "node_pre_fwd16", "node_pre_bwd16", "halo_rows",
                "halo_accumulate"]:
         put(lmod.nodeops, fn, getattr(ref_ops, fn))
     put(lmod, "_msg_fwd", ref_ops.msg_fwd)

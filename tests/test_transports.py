@@ -75,7 +75,7 @@ def _cpu_ops(monkeypatch):
     monkeypatch.setattr(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
     for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd",
                "update_mid", "update_out", "update_out_bwd", "update_mid_bwd", "node_pre_fwd", "node_pre_bwd", "node_update_fwd",
-               "node_update_bwd"]:
+               "node_update_bwd", "node_update_pre_fwd", "node_pre_fwd16", "node_pre_bwd16"]:
         monkeypatch.setattr(lmod.nodeops, fn, getattr(ref_ops, fn))
     monkeypatch.setattr(lmod, "_msg_fwd", ref_ops.msg_fwd)
     monkeypatch.setattr(lmod, "_msg_bwd", ref_ops.msg_bwd)
