@@ -24,7 +24,11 @@
 #include "node_chain_common.h"
 
 #ifndef HN_U16_MINW
-#define HN_U16_MINW 2      // workgroups per CU the register budget allows (2: <= 256 registers; 3 spills in the forward and measures the same)
+// workgroups per CU the register budget allows.  Round 5: 3 (<= 168 registers, no spills) -- a CU's third tile no longer waits for
+// one of the first two to finish and then runs alone (stamps: two workgroups from cycle 0, the third from cycle 112k of 222k).
+// What it took: the vec_dot sums pinned where they are formed (hipcc had sunk them behind the last product and kept v1 / v2 of
+// all three components alive), v1 re-read from vp instead of held in registers, a weight ring of two for four-block products.
+#define HN_U16_MINW 3
 #endif
 
 namespace {
@@ -33,7 +37,7 @@ constexpr int kTR16 = 16;
 constexpr int kScr16Ld = 36, kScr16Floats = 16 * kScr16Ld;     // per-wave transpose scratch [16][36]
 
 // k-groups of weight fragments in flight per block: a group is 4 NB MFMAs of 32 cycles, an L2 hit 500-800 cycles
-constexpr int ring16(int nb) { return nb >= 6 ? 2 : 4; }
+constexpr int ring16(int nb) { return nb >= 4 ? 2 : 4; }     // (64 registers for a ring of four at NB = 4 kept a third workgroup off the CU)
 
 template <int NB>
 struct Ring16 { f32x4 v[ring16(NB)][NB]; };
@@ -138,13 +142,13 @@ __device__ __forceinline__ void tile16_store(float* tile, const Tile16Regs<H>& r
 // =====================================================================================================================
 // The node projection of one 16-row tile (rmnet.py:52 for every relation): the tile's LayerNorm input sits in `bufN`.
 // =====================================================================================================================
-// LayerNorm without affine of a [16][H] LDS tile, in place; statistics over the first Hr channels.  Four adjacent lanes share a
-// row, its float4s dealt round-robin -- the operation order of node_pre_fwd_kernel<128, 64> (node_chain.hip) --, one wave does
-// the whole tile (64 lanes x 32 values).  The caller puts a barrier in front (tile written) and behind (tile normalised).
+// LayerNorm without affine of a [16][H] LDS tile, in place; statistics over the first Hr channels.  Sixteen adjacent lanes share
+// a row, its float4s dealt round-robin (a wave normalises four rows: the four waves work side by side -- one wave doing the
+// whole tile with four lanes per row took 7.9k cycles of a workgroup's life in which the other three waited at the barrier).
+// The caller puts a barrier in front (tile written) and behind (tile normalised).
 template <int H>
 __device__ __forceinline__ void layernorm_tile16(float* tile, int tid, int nrows, int Hr, float eps, float* mean0, float* rstd0) {
-  constexpr int LD = H + 8, TPR = 4, NF = H / 4 / TPR;
-  if (tid >= 64) return;
+  constexpr int LD = H + 8, TPR = 16, NF = H / 4 / TPR;
   const int lr = tid / TPR, q = tid % TPR;
   f32x4 v[NF];
 #pragma unroll
@@ -159,7 +163,8 @@ __device__ __forceinline__ void layernorm_tile16(float* tile, int tid, int nrows
     }
 #pragma unroll
   for (int m = 1; m < TPR; m <<= 1) s += __shfl_xor(s, m, 64);
-  const float mu = s / (float)Hr;
+  const float inv_h = 1.0f / (float)Hr;
+  const float mu = s * inv_h;
   float qq = 0.f;
 #pragma unroll
   for (int k = 0; k < NF; ++k)
@@ -170,7 +175,9 @@ __device__ __forceinline__ void layernorm_tile16(float* tile, int tid, int nrows
     }
 #pragma unroll
   for (int m = 1; m < TPR; m <<= 1) qq += __shfl_xor(qq, m, 64);
-  const float rs = rsqrtf(qq / (float)Hr + eps);
+  float var = qq * inv_h;
+  pin(var);                       // (the product stays a product: no contraction with the sum behind it, in any kernel)
+  const float rs = rsqrtf(var + eps);
 #pragma unroll
   for (int k = 0; k < NF; ++k) *reinterpret_cast<f32x4*>(tile + lr * LD + (k * TPR + q) * 4) = v[k] * rs;
   if (q == 0 && lr < nrows) { mean0[lr] = mu; rstd0[lr] = rs; }
@@ -199,6 +206,7 @@ __device__ __forceinline__ void pre_fwd16_phase(const PreFwdArgs& p, float* bufN
   request1(0);
   layernorm_tile16<H>(bufN, tid, nrows, p.Hr, p.eps, p.mean + row0, p.rstd + row0);
   __syncthreads();
+  STAMP(10);
   const float* An = bufN + mrow * LD + ch;
 #pragma unroll 1
   for (int t = 0; t < p.T; ++t) {
@@ -240,6 +248,7 @@ __device__ __forceinline__ void pre_fwd16_phase(const PreFwdArgs& p, float* bufN
       const f32x4 v[2] = {acc2[2 * pp], acc2[2 * pp + 1]};
       store16<3 * H>(scr, lane, v, xh_r, pp * H + cw);
     }
+    STAMP(11 + (t < 3 ? t : 3));
   }
 }
 
@@ -315,9 +324,12 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
   const rsrc_t xo_r = tile_rsrc(a.x_out + (size_t)row0 * H, nrows * H);
   const rsrc_t vo_r = tile_rsrc(a.vec_out + (size_t)row0 * 3 * H, nrows * 3 * H);
   const rsrc_t nrm_r = tile_rsrc(a.nrm + (size_t)row0 * H, nrows * H);
-  f32x4 dot[2] = {zero4(), zero4()}, sq[2] = {zero4(), zero4()}, kv1[3][2];
+  f32x4 dot[2] = {zero4(), zero4()}, sq[2] = {zero4(), zero4()};
 
-  // ---- vp[d] = vec1[d] Wv^T; vec_dot and |v2|^2 accumulate in registers, v1 stays for dvec = r v1
+  // ---- vp[d] = vec1[d] Wv^T; vec_dot and |v2|^2 accumulate in registers (v1 is re-read from vp for dvec = r v1: round 5 --
+  // 24 registers held across the whole kernel were what kept a third workgroup off the CU)
+  STAMP(0);
+  STAMP_HWID();
   Tile16Regs<H> regs;
   tile16_load<H>(regs, vec1_r, 3 * H, 0, tid);
   Ring16<4> rv;
@@ -343,12 +355,16 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
     f32x4 v1[2] = {accv[0], accv[1]}, v2[2] = {accv[2], accv[3]};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      kv1[d][s] = v1[s];
       dot[s] += v1[s] * v2[s];
       sq[s] += v2[s] * v2[s];
+      // (the sums are formed HERE: left alone, hipcc sinks them to their first use behind the last product and keeps the v1 / v2
+      // of all three components alive -- spilled -- until then: node_chain_common.h, pin)
+      pin4(dot[s]);
+      pin4(sq[s]);
     }
     store16<6 * H>(scr, lane, v1, vp_r, d * 2 * H + cw);
     store16<6 * H>(scr, lane, v2, vp_r, d * 2 * H + H + cw);
+    STAMP(1 + d);
   }
   // ---- xin = [x1 | sqrt(|v2|^2 + 1e-8)]: x1 -> buffer 1 (free since the product of d = 1), the norm -> buffer 0
   float* bufx = lds + TR * LD;
@@ -367,12 +383,14 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
     store16<H>(scr, lane, nv, nrm_r, cw);
   }
   __syncthreads();
+  STAMP(4);
   // ---- h2 = xin Wx0^T + bx0 (K = 2H: two panels)
   {
     const f32x4* bpx1[2] = {bpx[0] + (size_t)(H / 16) * 64, bpx[1] + (size_t)(H / 16) * 64};
     mma16_panel<H, 2, true>(acch, bufx + mrow * LD + ch, bpx, rx);
     mma16_panel<H, 2, false>(acch, bufn + mrow * LD + ch, bpx1, rx);
   }
+  STAMP(5);
   Ring16<6> rq;
   b16_preload(rq, bpq);
 #pragma unroll
@@ -392,13 +410,18 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
   }
   __syncthreads();
   // ---- (p | q | r) = a2 Wx2^T + bx2, then the update and the residual; vec1 is requested before the product
-  Load16 lvv[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) issue16<3 * H>(lvv[d], lane, vec1_r, d * H + cw);
+  // vec1 and v1 of component 0, requested before the product; the components behind it one epilogue step ahead.  (v1 was
+  // stored by this wave's own lanes: the wait makes the stores of the three vp epilogues final before it is read back.)
+  Load16 lvv, lv1;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  issue16<3 * H>(lvv, lane, vec1_r, cw);
+  issue16<6 * H>(lv1, lane, vp_r, cw);
   const float on = (all_on | (bld(act_r, mrow) != 0.f)) ? 1.f : 0.f;
   fence_sched();
+  STAMP(6);
   mma16_panel<H, 6, false>(accq, lds + mrow * LD + ch, bpq, rq);
   fence_sched();
+  STAMP(7);
   const float inv_sqrt_h = rsqrtf((float)H);
   f32x4 q[2], r[2], xo[2];
 #pragma unroll
@@ -421,14 +444,21 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(Upd
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    f32x4 vo[2];
-    finish16(scr, lane, lvv[d], vo);
+    f32x4 vo[2], v1[2];
+    finish16(scr, lane, lvv, vo);
+    finish16(scr, lane, lv1, v1);
+    if (d < 2) {
+      issue16<3 * H>(lvv, lane, vec1_r, (d + 1) * H + cw);
+      issue16<6 * H>(lv1, lane, vp_r, (d + 1) * 2 * H + cw);
+    }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) vo[s] = (vo[s] + r[s] * kv1[d][s]) * on;
+    for (int s = 0; s < 2; ++s) vo[s] = (vo[s] + r[s] * v1[s]) * on;
     store16<3 * H>(scr, lane, vo, vo_r, d * H + cw);
   }
+  STAMP(8);
   if constexpr (FUSE) {
     __syncthreads();
+    STAMP(9);
     pre_fwd16_phase<H>(p, lds + 2 * TR * LD, lds, lds + TR * LD, scr, row0, nrows, tid, lane, wave);
   }
 }
@@ -482,6 +512,7 @@ __device__ __forceinline__ void pre_bwd16_phase(const float* gxh, const float* h
   request_w(0);
   stage();
   __syncthreads();
+  STAMP(1);
 #pragma unroll 1
   for (int t = 0; t < T; ++t) {
     Load16 hb_now = lhb;
@@ -515,6 +546,7 @@ __device__ __forceinline__ void pre_bwd16_phase(const float* gxh, const float* h
     } else {
       gsum[0] += acc2[0]; gsum[1] += acc2[1];
     }
+    STAMP(2 + (t < 3 ? t : 3));
   }
 }
 
@@ -553,6 +585,8 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_bwd16_kernel(Upd
     }
     return;
   }
+  STAMP(0);
+  STAMP_HWID();
   if constexpr (FUSE) {
     // the projection's backward of the layer above on these rows: its sum over the relations stays in registers, goes through
     // one LDS tile into the LayerNorm backward, and gx_out / gvec_out of the tile are formed as in the unfused form
@@ -565,6 +599,7 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_bwd16_kernel(Upd
     for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(lds + (lane & 15) * LD + 32 * wave + 16 * s + 4 * (lane >> 4)) = gsum[s];
     __syncthreads();
     materialise_pending<H, TR, true>(a, row0, nrows, tid, lds, LD);
+    STAMP(6);
   } else {
     if (a.pend.gn != nullptr) materialise_pending<H, TR>(a, row0, nrows, tid);   // (incoming gradients still in partial sums)
   }
@@ -624,6 +659,7 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_bwd16_kernel(Upd
   issue16<H>(lgx, lane, gxo_r, cw);
   issue16<2 * H>(lq2, lane, q23_r, cw);
   __syncthreads();
+  STAMP(7);
   // ---- ga2 = gq Wx2  (K = 3H: three panels)
   f32x4 acc[2] = {zero4(), zero4()};
   {
@@ -636,6 +672,7 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_bwd16_kernel(Upd
     __syncthreads();                                 // third part in place, buffer 1 free
     mma16_panel<H, 2, false>(acc, buf0 + mrow * LD + ch, bp2, ra);
   }
+  STAMP(8);
   Ring16<4> rx;
   b16_preload(rx, bpx);
   fence_sched();
@@ -665,8 +702,10 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_bwd16_kernel(Upd
   issue16<6 * H>(lw2, lane, vp_r, H + cw);
   fence_sched();
   __syncthreads();
+  STAMP(9);
   // ---- gxin = gh2 Wx0 (gx1 part | g|v2| part)
   mma16_panel<H, 4, false>(accx, buf1 + mrow * LD + ch, bpx, rx);
+  STAMP(10);
   Ring16<2> rg;
   b16_preload(rg, bpg);
   fence_sched();
@@ -718,6 +757,7 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_update_bwd16_kernel(Upd
       finish16(scr, lane, nw2, pw2);
     }
     store16<3 * H>(scr, lane, accg, gvec1_r, d * H + cw);
+    STAMP(11 + d);
   }
 }
 
@@ -766,3 +806,9 @@ int hn_pre16_bwd(int hidden, const PreBwdArgs& a, void* stream) {
   if (hidden != 128 || a.src_ranges != nullptr || a.wmode != 0) return HN_ERR_BAD_ARG;
   return launch_chain(node_pre_bwd16_kernel<128>, dim3((unsigned)((a.Ns + 15) / 16)), kLdsBwdFused16, stream, a);
 }
+
+#ifdef HN_STAMPS
+extern "C" int hermnet_debug_stamps16(unsigned long long* out_host, int count) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(hn_stamps), (size_t)count * sizeof(unsigned long long)) == hipSuccess ? 0 : 3;
+}
+#endif

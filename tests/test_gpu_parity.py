@@ -1138,6 +1138,9 @@ def test_deferred_gradient_sums_equal_the_finishing_launches_bit_for_bit(name, w
     from hermnet_amd.layer import _PENDING
     dev = _dev()
     g = Golden(name)
+    # (the round-4 forms of both sides: with the layer boundary fused -- round 5's default at width 128 -- the deferred side runs
+    # the projection's backward on 16-row tiles, another summation order: test_fused_layer_boundary_changes_no_bit_of_the_model)
+    monkeypatch.setenv("HERMNET_FUSE_BOUNDARY", "0")
     if width is None:
         model = g.model().to(dev)
     else:
