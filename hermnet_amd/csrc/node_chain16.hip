@@ -23,12 +23,18 @@
 // the unfused form is the A/B and the bit-for-bit check of the fused one.
 #include "node_chain_common.h"
 
-#ifndef HN_U16_MINW
-// workgroups per CU the register budget allows.  Round 5: 3 (<= 168 registers, no spills) -- a CU's third tile no longer waits for
-// one of the first two to finish and then runs alone (stamps: two workgroups from cycle 0, the third from cycle 112k of 222k).
-// What it took: the vec_dot sums pinned where they are formed (hipcc had sunk them behind the last product and kept v1 / v2 of
-// all three components alive), v1 re-read from vp instead of held in registers, a weight ring of two for four-block products.
-#define HN_U16_MINW 3
+// Workgroups per CU the register budget is cut for (launch bounds).  Round 5: every kernel here FITS three (<= 168 registers,
+// no spills) -- what it took: the vec_dot sums pinned where they are formed (hipcc had sunk them behind the last product and
+// kept v1 / v2 of all three components alive, spilled), v1 re-read from vp instead of held in registers, a weight ring of two
+// for four-block products.  Measured (tools/chain_bench.py, 10,041 rows, same box, alternating builds, profiles/r05_chain_bench1.log):
+// the backward kernels gain a little from the third workgroup (fused 100.0 vs 101.8 us), the forward kernels LOSE (fused 102.0
+// vs 97.2 us) -- with three resident the products of each run slower and the launch ends no earlier: the matrix pipe is not
+// what a third workgroup's waves were waiting for.  So: forward 2, backward 3.
+#ifndef HN_U16_MINW_FWD
+#define HN_U16_MINW_FWD 2
+#endif
+#ifndef HN_U16_MINW_BWD
+#define HN_U16_MINW_BWD 3
 #endif
 
 namespace {
@@ -254,7 +260,7 @@ __device__ __forceinline__ void pre_fwd16_phase(const PreFwdArgs& p, float* bufN
 
 // The projection as a kernel of its own (the unfused form: A/B and bit-for-bit check of the fused kernel's second half)
 template <int H>
-__global__ __launch_bounds__(256, HN_U16_MINW) void node_pre_fwd16_kernel(PreFwdArgs p) {
+__global__ __launch_bounds__(256, HN_U16_MINW_FWD) void node_pre_fwd16_kernel(PreFwdArgs p) {
   constexpr int TR = kTR16, LD = H + 8;
   extern __shared__ __align__(16) float lds[];               // 3 x [TR][LD], then 4 x [16][36] scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_pre_fwd16_kernel(PreFwd
 // node_update_fwd on 16-row tiles (H = 128: four waves x 32 channels); FUSE: + the next layer's node projection of the tile
 // =====================================================================================================================
 template <int H, bool FUSE>
-__global__ __launch_bounds__(256, HN_U16_MINW) void node_update_fwd16_kernel(UpdFwdArgs a, PreFwdArgs p) {
+__global__ __launch_bounds__(256, HN_U16_MINW_FWD) void node_update_fwd16_kernel(UpdFwdArgs a, PreFwdArgs p) {
   static_assert(H == 128, "four waves x 32 channels");
   constexpr int TR = kTR16, LD = H + 8, NB16 = H / 16;       // NB16: 16-channel blocks per part
   extern __shared__ __align__(16) float lds[];               // 2 (FUSE: 3) x [TR][LD], then 4 x [16][36] scratch
@@ -551,7 +557,7 @@ __device__ __forceinline__ void pre_bwd16_phase(const float* gxh, const float* h
 }
 
 template <int H>
-__global__ __launch_bounds__(256, HN_U16_MINW) void node_pre_bwd16_kernel(PreBwdArgs a) {
+__global__ __launch_bounds__(256, HN_U16_MINW_BWD) void node_pre_bwd16_kernel(PreBwdArgs a) {
   constexpr int TR = kTR16, LD = H + 8;
   extern __shared__ __align__(16) float lds[];               // [TR][3H + 8], [TR][LD], then 4 x [16][36] scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(256, HN_U16_MINW) void node_pre_bwd16_kernel(PreBwd
 // node_update_bwd on 16-row tiles; FUSE: the backward of the layer ABOVE's node projection runs in front, on the same rows
 // =====================================================================================================================
 template <int H, bool FUSE>
-__global__ __launch_bounds__(256, HN_U16_MINW) void node_update_bwd16_kernel(UpdBwdArgs a) {
+__global__ __launch_bounds__(256, HN_U16_MINW_BWD) void node_update_bwd16_kernel(UpdBwdArgs a) {
   static_assert(H == 128, "four waves x 32 channels");
   constexpr int TR = kTR16, LD = H + 8, NB16 = H / 16, V = H / 4, F4 = TR * H / 4 / 256;
   // 2 x [TR][LD], then 4 x [16][36] scratch; FUSE: [TR][3H + 8] (later the two tiles), [TR][LD], then the scratch

@@ -40,6 +40,19 @@ def main():
         "node_update_fwd": (lambda: nodeops.node_update_fwd(x1, vec1, w, g), 2 * N * 11 * H * H),
         "node_update_bwd": (lambda: nodeops.node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, g), 2 * N * 11 * H * H),
     }
+    if nodeops.fused_boundary_supported(g, H, w, w):        # round 5: the layer boundary as one launch each way (16-row tiles)
+        gv_parts, gx1u, gvec1u = torch.randn(T, N, 3, H, device=dev), torch.randn(N, H, device=dev), torch.randn(N, 3, H, device=dev)
+        bx, bv = torch.empty(N, H, device=dev), torch.empty(N, 3, H, device=dev)
+        gn_parts = nodeops.node_pre_bwd16(gxh, hb, w)
+        pend_parts = nodeops.PendingGrads(bx, bv, gn_parts, gv_parts, xo, mean, rstd, gx1u, gvec1u, 0)
+        pend_chain = nodeops.PendingGrads(bx, bv, None, gv_parts, xo, mean, rstd, gx1u, gvec1u, 0, chain=(gxh, hb, w.w2tf16, w.w1tf16))
+        cases.update({
+            "pre_fwd16": (lambda: nodeops.node_pre_fwd16(x, w, T), 2 * N * T * 4 * H * H),
+            "pre_bwd16": (lambda: nodeops.node_pre_bwd16(gxh, hb, w), 2 * N * T * 4 * H * H),
+            "update_bwd(parts)": (lambda: nodeops.node_update_bwd(bx, bv, vp, h2b, q23, nrm, w, g, pending=pend_parts), 2 * N * 11 * H * H),
+            "update_pre_fwd": (lambda: nodeops.node_update_pre_fwd(x1, vec1, w, g, w), 2 * N * (11 + 4 * T) * H * H),
+            "pre_update_bwd": (lambda: nodeops.node_update_bwd(bx, bv, vp, h2b, q23, nrm, w, g, pending=pend_chain), 2 * N * (11 + 4 * T) * H * H),
+        })
     print("rows %d (atoms %d), H %d, T %d" % (N, n, H, T))
     for _ in range(3):                    # every case a few times before any is timed (allocator growth, code objects:
         for fn, _f in cases.values():     # a one-time stall otherwise lands in the first case's interval)
