@@ -288,8 +288,8 @@ class HVNet(nn.Module):
         shard = data.get("_hn_shard")
         # a padded neighbour list (neighbor.neighbor_search_padded: NULL edges behind the real ones, the count on the device)
         padded = data.get("_hn_edge_count") is not None
-        if padded and (train or shard is not None):
-            raise NotImplementedError("a padded neighbour list runs through the fused eval() path of one GPU")
+        if padded and train:
+            raise NotImplementedError("a padded neighbour list runs through the fused eval() path")
         fused = self.radial_basis.fused and not train
         # Two things of a step are not on its critical path: the first layer's node projection needs the
         # atoms only, not the edges, and the radial table is read by the backward only.  HERMNET_SIDE_STREAM=1 sends the edge
@@ -429,9 +429,12 @@ class HVNet(nn.Module):
             e_own = per_atom_energy * own
             if shard.num_graphs == 1:      # one structure (the sharded MD case): ordered sums, bit-reproducible
                 energy, cnt = e_own.sum().reshape(1), own.sum().reshape(1)
-            else:                          # (index_add accumulates with atomics: order-dependent last bits)
-                energy = torch.zeros(shard.num_graphs, dtype=e_own.dtype, device=x.device).index_add(0, batch, e_own)
-                cnt = torch.zeros(shard.num_graphs, dtype=e_own.dtype, device=x.device).index_add(0, batch, own)
+            else:
+                # several graphs on a shard: the local atoms sorted by graph (stable, cached with the plan), then ORDERED
+                # segment sums -- no index_add atomics, so a rank's share is bit-reproducible run to run like everything else
+                perm, lengths = shard.graph_order(batch)
+                energy = torch.segment_reduce(e_own.index_select(0, perm), "sum", lengths=lengths, unsafe=True)
+                cnt = torch.segment_reduce(own.index_select(0, perm), "sum", lengths=lengths, unsafe=True)
             energy = SumAcrossRanks.apply(energy, shard.group)
             if self.intensive:
                 energy = energy / SumAcrossRanks.apply(cnt, shard.group).clamp(min=1)

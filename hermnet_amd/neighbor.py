@@ -214,7 +214,7 @@ def _neighbor_search_device(pos, rc, cell, reference_compat, target_mask=None):
     return (edge_index, shift) if periodic else edge_index
 
 
-def neighbor_search_padded(pos, rc, cell, capacity, reference_compat=False):
+def neighbor_search_padded(pos, rc, cell, capacity, reference_compat=False, target_mask=None):
     """The device cell list WITHOUT its host read: `capacity` columns are provided up front, the pairs
     found fill the first E of them and the rest become NULL edges (-1, -1; shift 0), which the relation build files behind
     every row -- the model runs on the padded list unchanged, with a launch geometry that does not depend on E.
@@ -223,7 +223,8 @@ def neighbor_search_padded(pos, rc, cell, capacity, reference_compat=False):
     total[0] = E, total[1] = flags; read them when the step's results are copied to the host anyway.  The list is
     complete iff `padded_list_ok(total)`; otherwise (more pairs than columns, an atom with more pairs than its stash slot,
     coordinates many cells away from the cell) repeat with `neighbor_search` and a larger capacity.  GPU tensors only;
-    open systems need `reference_compat=False` (the 32-neighbour cap is a host-side filter)."""
+    open systems need `reference_compat=False` (the 32-neighbour cap is a host-side filter).
+    `target_mask` [N] bool / uint8 (atom shards): list only the pairs whose target atom (row 1) is flagged."""
     import ctypes
     from . import _lib
     if not pos.is_cuda:
@@ -243,6 +244,11 @@ def neighbor_search_padded(pos, rc, cell, capacity, reference_compat=False):
     else:       # (an open system's bounding box is a host read of its own: periodic cells are the MD case)
         mm = torch.stack([p32.min(0).values, p32.max(0).values]).double().cpu().tolist()
         lo_h, hi_h = dbl3(*mm[0]), dbl3(*mm[1])
+    mask = None
+    if target_mask is not None:
+        mask = (target_mask if target_mask.dtype == torch.uint8 else target_mask.to(torch.uint8)).contiguous()
+        if mask.numel() != N or mask.device != dev:
+            raise ValueError("target_mask must be [N] on the device of pos")
     ws_bytes = _stash_workspace_bytes(lib, N, dev)
     work = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     total = torch.empty(2, dtype=torch.long, device=dev)
@@ -254,7 +260,7 @@ def neighbor_search_padded(pos, rc, cell, capacity, reference_compat=False):
         edge_index.fill_(0x3f3f3f3f3f3f3f3f)
         if shift is not None:
             shift.fill_(float("nan"))
-    _lib.check(lib.hermnet_neighbor_count(P(p32), N, cell_h, lo_h, hi_h, float(rc), P(work), ws_bytes, None, P(total), stream),
+    _lib.check(lib.hermnet_neighbor_count(P(p32), N, cell_h, lo_h, hi_h, float(rc), P(work), ws_bytes, P(mask), P(total), stream),
                "hermnet_neighbor_count")
     sign = 1.0 if reference_compat else -1.0
     _lib.check(lib.hermnet_neighbor_fill_padded(N, P(work), ws_bytes, cap, sign, 0 if periodic else 1, P(edge_index), P(shift),

@@ -182,7 +182,8 @@ class HaloExchange(torch.autograd.Function):
         if back.size(0) > 0:
             # an atom that is a halo atom of several peers gets its returns summed in send-list order (no atomics)
             rows, ptr, pos = plan.accumulate_lists()
-            seg = torch.segment_reduce(back.index_select(0, pos), "sum", lengths=ptr[1:] - ptr[:-1])
+            # (unsafe=True: no host-side validation of `lengths` -- it would synchronise every step)
+            seg = torch.segment_reduce(back.index_select(0, pos), "sum", lengths=ptr[1:] - ptr[:-1], unsafe=True)
             gx.index_add_(0, rows, seg)                # `rows` is unique
         return gx, None
 
@@ -324,6 +325,16 @@ class ShardPlan(object):
             return (self.has_in_pairs.index_select(0, idx[0]) | self.has_in_pairs.index_select(0, idx[1])).to(torch.uint8)
         zz = self.zz_with_in_edges
         return [((zl[c], zl[p]) in zz) or ((zl[c], zl[q]) in zz) for c, p, q in trip]
+
+    def graph_order(self, batch):
+        """(perm, lengths): the local atoms sorted by graph id (stable) and the number of local atoms of each of the
+        `num_graphs` graphs -- what an ordered per-graph reduction needs; cached per `batch` tensor (one sort per plan)."""
+        c = getattr(self, "_graph_order", None)
+        if c is None or c[0] is not batch or c[1] != batch._version:
+            perm = torch.argsort(batch, stable=True)
+            lengths = torch.bincount(batch, minlength=self.num_graphs)
+            c = self._graph_order = (batch, batch._version, perm, lengths)
+        return c[2], c[3]
 
     def row_plan(self, row_of_node):
         """The atom exchange lists in the relation-row order of `row_of_node` (cached per tensor: the row layout of an
@@ -739,18 +750,24 @@ def partition_blocks(pos, atomic_number, cell, rc, rank, world, grid=None, group
     return slab_data(plan, pos, reference_compat), plan
 
 
-def slab_data(plan, pos, reference_compat=False):
+def slab_data(plan, pos, reference_compat=False, capacity=None):
     """This rank's `Data` for the current coordinates under a plan that is still valid (`plan_moved` says whether it
     is): the cutoff pairs among the local atoms whose TARGET is owned, listed directly by the neighbour search
     (`target_mask`; nothing of the other pairs is built or filtered afterwards).  Halo rows of `pos` hold the atoms'
     coordinates (every rank has them all): no coordinate exchange in the forward pass, HVNet.forward only routes the
     halo rows' force contributions back to the owners (`HaloGradReturn`).  One host read (the edge count of the
-    search)."""
-    from .neighbor import neighbor_search
+    search) -- or none: with `capacity` (periodic cells on the GPU) the list is padded to that many columns with NULL edges
+    (`neighbor.neighbor_search_padded`), `local._hn_edge_count` holds (E, flags) on the device, and the caller checks
+    them when it copies the step's results to the host anyway (`SlabStepper.check`)."""
+    from .neighbor import neighbor_search, neighbor_search_padded
     dev = pos.device
     pos_l = pos.detach().index_select(0, plan.local_global)
     cell = plan.cell
-    if cell is not None:
+    total = None
+    if cell is not None and capacity is not None and pos_l.is_cuda:
+        ei, sh, total = neighbor_search_padded(pos_l, plan.rc, cell, int(capacity), reference_compat=reference_compat,
+                                               target_mask=plan.target_mask)
+    elif cell is not None:
         ei, sh = neighbor_search(pos_l, plan.rc, cell, reference_compat=reference_compat, target_mask=plan.target_mask)
     else:
         ei, sh = neighbor_search(pos_l, plan.rc, None, target_mask=plan.target_mask), None
@@ -765,12 +782,20 @@ def slab_data(plan, pos, reference_compat=False):
         kw["cell"] = cell
         kw["edge_shift"] = sh
     local = Data(**kw)
+    if total is not None:
+        local._hn_edge_count = total
     # hermnet.py:56-57: a relation is skipped when NO atom of its element receives an edge anywhere in the structure;
     # kept on the device (the relation build takes the flags as a device array: no host read per step)
     # (flags per (target element, source element): HTNet's relations are skipped pair-wise; HVNet reads the row maxima)
-    has_in = torch.zeros(128 * 128, dtype=torch.int32, device=dev)
+    # (the NULL edges of a padded list -- endpoints -1 -- raise the spare slot behind the table)
+    # (slot 128 * 128: where the NULL edges of a padded list -- endpoints -1 -- land; slot 128 * 128 + 1: "this rank's padded
+    # list is incomplete", so that the SAME reduction tells every rank whether the step has to be repeated anywhere)
+    has_in = torch.zeros(128 * 128 + 2, dtype=torch.int32, device=dev)
     if ei.size(1) > 0:
-        has_in[z[ei[1]].clamp(max=127) * 128 + z[ei[0]].clamp(max=127)] = 1
+        zt, zs = z[ei[1].clamp(min=0)].clamp(max=127), z[ei[0].clamp(min=0)].clamp(max=127)
+        has_in.index_fill_(0, torch.where(ei[1] >= 0, zt * 128 + zs, torch.full_like(zt, 128 * 128)), 1)
+    if total is not None:
+        has_in[128 * 128 + 1:] = ((total[1:] != 0) | (total[:1] > int(capacity))).to(torch.int32)
     if plan.world > 1 and dist.is_available() and dist.is_initialized():
         if _host_staged(plan.group, has_in):
             h = has_in.cpu()
@@ -778,6 +803,8 @@ def slab_data(plan, pos, reference_compat=False):
             has_in = h.to(dev)
         else:
             dist.all_reduce(has_in, op=dist.ReduceOp.MAX, group=plan.group)
+    local._hn_list_bad = has_in[128 * 128 + 1]               # 0-d, on the device, the same on every rank
+    has_in = has_in[:128 * 128]
     plan.has_in_pairs = has_in
     plan.has_in_edges = has_in.view(128, 128).amax(dim=1)
     local._hn_shard = plan
@@ -828,19 +855,34 @@ class SlabStepper(object):
     coordinates and the has-in-edges reduction; the slab plan itself (owners, halo, exchange lists, their host read)
     only when an atom has moved further than skin/2 since it was made (the check's flag is read back first, so a
     re-plan step searches once).  The cell and the atomic numbers are watched by tensor identity and version: replace
-    them or edit them in place, never through `.data` (writes through `.data` or a numpy view do not bump the version)."""
+    them or edit them in place, never through `.data` (writes through `.data` or a numpy view do not bump the version).
+
+    `deferred=True` (round 5; periodic cells on the GPU): NO host read per step.  The step runs optimistically on the plan
+    it has and on a neighbour list padded to a capacity (`slab_data(capacity=...)`); the displacement flag and the list's
+    (count, flags) stay on the device, and
+
+        ok = stepper.check()                # ONE host read -- do it when the step's results go to the host anyway
+
+    says whether the step just taken was valid (every atom within skin/2 of the plan, list complete).  If not, the caller
+    repeats the step: the next `stepper(pos)` plans again and / or searches exactly.  The first call of a plan runs the
+    exact search (its count sizes the capacity)."""
 
     def __init__(self, atomic_number, cell, rc, rank, world, skin=1.0, axis=None, group=None, reference_compat=False,
-                 grid=None):
+                 grid=None, deferred=False):
         """`grid` = (pa, pb, pc) or "auto" (`block_grid`): boxes instead of slabs (`plan_blocks`)."""
         self.z, self.cell, self.rc, self.skin = atomic_number, cell, float(rc), float(skin)
         self.rank, self.world, self.axis, self.group = rank, world, axis, group
         self.grid = grid
         self.reference_compat = reference_compat
+        self.deferred = bool(deferred)
         self.plan = None
         self.replans = 0
+        self.repeats = 0                 # steps that `check` asked to be taken again
         self._cell_key = None
         self._z_key = (None, None)
+        self._capacity = None            # columns of the next padded list (None: exact search)
+        self._pending = None             # (moved flag [0-d bool], total [2] or None) of the step not checked yet
+        self._force_replan = False
 
     def _replan(self, pos):
         if self.grid is not None:
@@ -850,6 +892,46 @@ class SlabStepper(object):
             self.plan = plan_slab(pos, self.z, self.cell, self.rc, self.rank, self.world, axis=self.axis,
                                   group=self.group, skin=self.skin)
         self.replans += 1
+        self._capacity = None
+        self._force_replan = False
+
+    def _exact(self, pos):
+        from .neighbor import padded_capacity
+        local = slab_data(self.plan, pos, self.reference_compat)
+        self._pending = None
+        if self.deferred and self.cell is not None and pos.is_cuda:
+            self._capacity = padded_capacity(int(local.edge_index.size(1)))     # (the count is on the host already)
+            # (another rank may be on a padded list that turns out incomplete: every rank reads the same reduced flag)
+            self._pending = (plan_moved(self.plan, pos), None, local._hn_list_bad)
+        return local, self.plan
+
+    def check(self):
+        """Deferred mode: was the step on the data of the last call valid -- on EVERY rank (the answer is the same
+        everywhere: the displacement flag is computed from the same coordinates, the list flags are reduced over the
+        ranks)?  One host read; on False every rank repeats the step (the next call plans again and / or searches
+        exactly).  True when nothing is pending."""
+        if self._pending is None:
+            return True
+        from .neighbor import padded_capacity
+        moved, total, bad = self._pending
+        self._pending = None
+        parts = [moved.reshape(1).to(torch.long), bad.reshape(1).to(torch.long)] + ([] if total is None else [total])
+        vals = torch.cat(parts).tolist()
+        ok = not (vals[0] or vals[1])
+        if vals[0]:
+            self._force_replan = True
+        if total is not None:
+            E, flags = vals[2], vals[3]
+            if flags & 2:
+                from .neighbor import _stash_overflowed
+                _stash_overflowed(total.device)
+            if flags or E > self._capacity:
+                self._capacity = None                            # this rank searches exactly next (its count sizes the capacity)
+            elif not (E * 1.02 + 64 <= self._capacity <= E * 1.25 + 8192):
+                self._capacity = padded_capacity(E)              # (still valid, but re-sized for the following steps)
+        if not ok:
+            self.repeats += 1
+        return ok
 
     def __call__(self, pos):
         # (a cell that was replaced or edited in place -- NPT -- moves the slab bounds: plan again)
@@ -863,9 +945,18 @@ class SlabStepper(object):
         if self.plan is not None and cell_key is not None and (cell_key[0] is not self._cell_key[0] or cell_key[1] != self._cell_key[1]):
             self.plan = None
         self._cell_key = cell_key
-        if self.plan is None or self.plan.pos_ref.shape != pos.shape:
+        if self.plan is None or self.plan.pos_ref.shape != pos.shape or self._force_replan:
             self._replan(pos)
-            return slab_data(self.plan, pos, self.reference_compat), self.plan
+            return self._exact(pos)
+        if self.deferred and self.cell is not None and pos.is_cuda:
+            if self._capacity is None:
+                if bool(plan_moved(self.plan, pos)):             # (an exact step reads the host anyway)
+                    self._replan(pos)
+                return self._exact(pos)
+            # optimistic: the plan as it is, the list padded; both flags stay on the device until `check`
+            local = slab_data(self.plan, pos, self.reference_compat, capacity=self._capacity)
+            self._pending = (plan_moved(self.plan, pos), local.get("_hn_edge_count"), local._hn_list_bad)
+            return local, self.plan
         # one 0-d read-back decides (the search's own host read follows anyway): on a re-plan step the search and the
         # relation-flag reduction then run ONCE, on the new plan
         if bool(plan_moved(self.plan, pos)):

@@ -188,6 +188,119 @@ def test_rccl_backend_single_rank_smoke():
     assert rel_err(torch.from_numpy(forces), g.forces) < 1e-5
 
 
+def _rccl_syncfree_worker(rank, world, port, out):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        import hermnet_amd as hn
+        from hermnet_amd import synth
+        from hermnet_amd.neighbor import neighbor_search
+        from hermnet_amd.sharding import SlabStepper
+        kw = dict(rc=5.0, num_layers=3, hidden_channels=128, num_rbf=128)
+        model = hn.HVNet(["Al", "Ni", "Cu"], **kw).eval()
+        model.load_state_dict(synth.synth_state_dict(model.state_dict(), 10))
+        model = model.to(dev)
+        for p in model.parameters():
+            p.requires_grad_(False)
+        pos, cell, z = synth.fcc_alloy_atoms(reps=(5, 5, 12))
+        pos_t = torch.from_numpy(pos.astype(np.float32)).to(dev)
+        cell_t = torch.from_numpy(cell.astype(np.float32)).to(dev)
+        z_t = torch.from_numpy(z).to(dev)
+        stepper = SlabStepper(z_t, cell_t, 5.0, rank, world, skin=0.8, deferred=True)
+        gen = torch.Generator().manual_seed(3)
+        walks = [torch.zeros_like(pos_t)]
+        for it in range(1, 7):
+            w = walks[-1] + (0.1 * (torch.rand(pos_t.shape, generator=gen) - 0.5)).to(dev)
+            if it == 5:
+                w = w.clone()
+                w[11] += torch.tensor([0.0, 0.0, 1.3], device=dev)        # past skin / 2: the check must say so
+            walks.append(w)
+        coords = [pos_t + w for w in walks]
+        torch.cuda.synchronize()
+
+        def step(cur):
+            local, plan = stepper(cur)
+            local.pos.requires_grad_(True)
+            e = model(local)
+            f = -torch.autograd.grad(e.sum(), local.pos)[0]
+            return e.detach(), f.index_select(0, plan.owned_local), plan.owned_global
+
+        res = []
+        e, f, owned = step(coords[0])                    # the first step of a plan: exact list, host reads allowed
+        assert stepper.check()
+        res.append((e.cpu().numpy(), f.cpu().numpy(), owned.cpu().numpy()))
+        step(coords[0])                                  # (one padded step outside the guarded region: caches, workspaces)
+        assert stepper.check()
+        synced = []
+        for it in range(1, 7):
+            torch.cuda.set_sync_debug_mode("error")      # any host synchronisation inside the step raises
+            try:
+                e, f, owned = step(coords[it])
+            except RuntimeError as err:                  # (reported through `out`, not as a crash of the worker)
+                synced.append((it, str(err)[:300]))
+                torch.cuda.set_sync_debug_mode("default")
+                break
+            torch.cuda.set_sync_debug_mode("default")
+            ok = stepper.check()                         # ONE host read, outside the step
+            if not ok:                                   # the step must be taken again (here: the atom that jumped)
+                e, f, owned = step(coords[it])
+                assert stepper.check()
+            res.append((e.cpu().numpy(), f.cpu().numpy(), owned.cpu().numpy(), ok))
+        ref = []
+        for it in (0, 3, 5, 6):
+            ei, sh = neighbor_search(coords[it], 5.0, cell_t)
+            d = hn.Data(pos=coords[it].clone().requires_grad_(True), atomic_number=z_t, edge_index=ei, edge_shift=sh,
+                        cell=cell_t.reshape(1, 3, 3), batch=torch.zeros(z_t.numel(), dtype=torch.long, device=dev))
+            eg = model(d)
+            ref.append((it, eg.detach().cpu().numpy(), (-torch.autograd.grad(eg.sum(), d.pos)[0]).cpu().numpy()))
+        # control: the plain stepper (a host read of the edge count and of the displacement flag per step) must trip the guard
+        plain = SlabStepper(z_t, cell_t, 5.0, rank, world, skin=0.8)
+        plain(coords[0])
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            plain(coords[1])
+            control = False
+        except RuntimeError:
+            control = True
+        torch.cuda.set_sync_debug_mode("default")
+        out[rank] = dict(res=res, ref=ref, synced=synced, replans=stepper.replans, repeats=stepper.repeats, control=control)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_step_takes_no_host_synchronisation():
+    """the sharded step used to read its edge count (and the displacement flag of the Verlet skin) on
+    the host every step.  `SlabStepper(deferred=True)`: the neighbour list of a shard is padded to a capacity (NULL edges
+    masked out of the relation flags), the flags stay on the device, and ONE `check()` behind the step reads them.  Here:
+    one rank over RCCL (the production backend), six steps of a random walk with `torch.cuda.set_sync_debug_mode("error")`
+    around every step -- any `.item()`, `.tolist()`, `nonzero`, pageable copy ... inside raises; the step after which an atom
+    has jumped past skin / 2 is reported by `check()` and taken again on a new plan; energies and forces equal the
+    unsharded evaluation."""
+    port = 36200 + os.getpid() % 2000
+    out = mp.Manager().dict()
+    mp.spawn(_rccl_syncfree_worker, args=(1, port, out), nprocs=1, join=True)
+    r = out[0]
+    assert r["control"], "the guard did not notice the plain stepper's host reads: the test has no teeth"
+    assert not r["synced"], "a host synchronisation inside the sharded step: %s" % (r["synced"],)
+    assert r["replans"] == 2 and r["repeats"] == 1
+    oks = [x[3] for x in r["res"][1:]]
+    assert oks == [True, True, True, True, False, True]
+    for it, e_ref, f_ref in r["ref"]:
+        e, f, owned = r["res"][it][:3]
+        forces = np.zeros_like(f_ref)
+        forces[owned] = f
+        assert rel_err(torch.from_numpy(e), torch.from_numpy(e_ref)) < 1e-5, it
+        assert rel_err(torch.from_numpy(forces), torch.from_numpy(f_ref)) < 1e-5, it
+
+
 # ---------------------------------------------------------------------------------------------
 # Slab-local planning (`partition_slab`): geometry only, neighbour search over owned + halo atoms.
 # ---------------------------------------------------------------------------------------------
