@@ -550,6 +550,90 @@ def launch_rehearsal(args, world, rank):
     return 0
 
 
+def comm_block(step, plan, data, dev, backend, world, H, layers, kernel_ms_per_step, step_ms_local):
+    """What the halo exchanges of the sharded step cost, per rank and over the ranks: every
+    rank times its stream waits with HIP events (sharding.CommProbe) in a short pass behind the timed region, times the same
+    all-to-all in isolation, and the per-rank figures are gathered to rank 0.  hidden fraction = 1 - (time the compute
+    stream waited for an exchange) / (time the exchange takes by itself)."""
+    from hermnet_amd import sharding
+    probe = sharding.CommProbe()
+    sharding.set_comm_probe(probe)
+    nprobe = 5
+    try:
+        for _ in range(nprobe):
+            step()
+        rec = probe.summary()
+    finally:
+        sharding.set_comm_probe(None)
+    ap = plan.atom_plan
+    n_send, n_recv = sum(ap.send_counts), sum(ap.recv_counts)
+    # the layer exchange by itself: the same packed rows (4H floats per halo atom), nothing else on the GPU
+    iso = float("nan")
+    try:
+        buf = torch.zeros(n_send, 4 * H, device=dev)
+        for _ in range(3):
+            sharding._all_to_all_rows(buf, ap.send_counts, ap.recv_counts, ap.group)
+        torch.cuda.synchronize()
+        dist.barrier(**({"device_ids": [dev.index]} if backend == "nccl" else {}))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            sharding._all_to_all_rows(buf, ap.send_counts, ap.recv_counts, ap.group)
+        b.record()
+        torch.cuda.synchronize()
+        iso = a.elapsed_time(b) / 20
+    except Exception:
+        pass
+    g = lambda tag, key: rec.get(tag, {}).get(key, 0)
+    per_step = lambda tag: g(tag, "ms_total") / nprobe
+    vals = [kernel_ms_per_step, step_ms_local, per_step("fwd"), per_step("bwd"), per_step("blocking"),
+            g("fwd", "count") / nprobe, g("bwd", "count") / nprobe, g("blocking", "count") / nprobe, iso,
+            float(n_send), float(n_recv), float(sum(1 for c in ap.send_counts if c)), float(sum(1 for c in ap.recv_counts if c)),
+            float(plan.halo_global.numel()), float(plan.owned_global.numel()), float(data.edge_index.size(1))]
+    names = ["kernel_ms_per_step", "step_ms_local", "wait_fwd_ms_per_step", "wait_bwd_ms_per_step", "blocking_ms_per_step",
+             "async_exchanges_fwd_per_step", "async_exchanges_bwd_per_step", "blocking_exchanges_per_step",
+             "all_to_all_ms_isolated", "rows_sent_per_exchange", "rows_received_per_exchange", "peers_sent_to", "peers_received_from",
+             "halo_atoms", "owned_atoms", "edges"]
+    t = torch.tensor(vals, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    allv = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allv, t)
+    m = torch.stack(allv).cpu()
+    col = {n: m[:, i] for i, n in enumerate(names)}
+    mm = lambda n: {"max": float(col[n].max()), "min": float(col[n].min()), "mean": float(col[n].mean())}
+    nf, nb = float(col["async_exchanges_fwd_per_step"].max()), float(col["async_exchanges_bwd_per_step"].max())
+    iso_max = float(col["all_to_all_ms_isolated"].max())
+    out = {
+        "what": "halo exchange of the sharded step: per layer ONE variable-size all_to_all_single of packed (x | vec) rows each way, "
+                "started asynchronously and waited for by the compute STREAM behind the interior node / message launches",
+        "exchanges_per_step": {"features_forward": layers - 1, "gradients_backward": layers - 1, "position_gradient_return": 1,
+                               "scalar_all_reduces": 2, "asynchronous_forward": nf, "asynchronous_backward": nb,
+                               "blocking": float(col["blocking_exchanges_per_step"].max())},
+        "bytes_per_row": 4 * H * 4,
+        "rows_sent_per_exchange": mm("rows_sent_per_exchange"), "rows_received_per_exchange": mm("rows_received_per_exchange"),
+        "bytes_sent_per_exchange": {k: v * 4 * H * 4 for k, v in mm("rows_sent_per_exchange").items()},
+        "peers": {"sent_to": mm("peers_sent_to"), "received_from": mm("peers_received_from")},
+        "bytes_per_exchange_per_peer_mean": float((col["rows_sent_per_exchange"] / col["peers_sent_to"].clamp(min=1)).mean()) * 4 * H * 4,
+        "all_to_all_ms_isolated": mm("all_to_all_ms_isolated"),
+        "stream_wait_ms_per_exchange": {
+            "forward": {k: v / max(nf, 1.0) for k, v in mm("wait_fwd_ms_per_step").items()},
+            "backward": {k: v / max(nb, 1.0) for k, v in mm("wait_bwd_ms_per_step").items()}},
+        "hidden_fraction": {
+            "forward": None if not (nf and iso_max > 0) else 1.0 - float(col["wait_fwd_ms_per_step"].max()) / nf / iso_max,
+            "backward": None if not (nb and iso_max > 0) else 1.0 - float(col["wait_bwd_ms_per_step"].max()) / nb / iso_max,
+            "note": "1 - (slowest rank's stream wait per exchange) / (slowest rank's isolated all-to-all); <= 0: nothing hidden"},
+        "wait_ms_per_step": {k: v for k, v in zip(("max", "min", "mean"), (
+            float((col["wait_fwd_ms_per_step"] + col["wait_bwd_ms_per_step"] + col["blocking_ms_per_step"]).max()),
+            float((col["wait_fwd_ms_per_step"] + col["wait_bwd_ms_per_step"] + col["blocking_ms_per_step"]).min()),
+            float((col["wait_fwd_ms_per_step"] + col["wait_bwd_ms_per_step"] + col["blocking_ms_per_step"]).mean())))},
+        "kernel_ms_per_step": mm("kernel_ms_per_step"), "step_ms_local": mm("step_ms_local"),
+        "halo_atoms": mm("halo_atoms"), "owned_atoms": mm("owned_atoms"), "edges": mm("edges"),
+        "per_rank": {n: [float(v) for v in col[n]] for n in ("step_ms_local", "kernel_ms_per_step", "wait_fwd_ms_per_step",
+                                                              "wait_bwd_ms_per_step", "blocking_ms_per_step",
+                                                              "all_to_all_ms_isolated", "rows_sent_per_exchange", "halo_atoms")},
+    }
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -606,7 +690,18 @@ def main():
                 os.dup2(saved, 1)
                 os.close(saved)
         else:
-            dist.init_process_group("gloo")
+            # (gloo announces its peers with printf as well: "[Gloo] Rank 0 is connected to 1 peer ranks" would land on stdout in
+            # front of the JSON line)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo")
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
 
     import numpy as np
     import hermnet_amd as hn
@@ -696,6 +791,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
+    dt_local = dt
     dt = max_over_ranks(dt)
 
     # ---- after the timed region: the dense linears, timed with HIP events in a short pass of their own (an event
@@ -706,6 +802,18 @@ def main():
         step()
     torch.cuda.synchronize()
     ops.set_kernel_timer(None)
+
+    # ---- sharded runs: what the halo exchanges cost (every rank takes part; rank 0 prints)
+    comm = None
+    if sharded:
+        try:
+            # this rank's own kernels per step: message kernels (timed region) + node chain kernels (the pass above)
+            own_ms = (sum(c * ms for _, (c, ms) in timer.summary().items()) / args.steps
+                      + sum(c * ms for _, (c, ms) in gtimer.summary().items()) / 3.0)
+            comm = comm_block(step, plan, data, dev, args.backend, world, model_kw["hidden_channels"], model_kw["num_layers"],
+                              own_ms, dt_local / args.steps * 1e3)
+        except Exception as ex:      # (never lose the headline over diagnostics -- but every rank must fail alike: collectives)
+            comm = {"error": repr(ex)}
 
     # ---- secondary, all ranks: the step INCLUDING planning (sharded: slab plan + slab-local neighbour search;
     # single GPU: the device neighbour search), i.e. what one MD step costs end to end
@@ -854,6 +962,8 @@ def main():
             "energy": float(e.detach()[0]),
             "library": _lib.build_info(),
         }
+        if comm is not None:
+            out["comm"] = comm
         if md is not None:
             out["secondary"] = {"atom_steps_per_s_incl_planning": N_global / md, "ms_per_step_incl_planning": md * 1e3,
                                 "note": ("displacement check + slab-local device neighbour search (edges into owned "
@@ -880,6 +990,11 @@ def main():
                 one = (time.perf_counter() - t1) / 5
                 out["secondary"]["single_gpu_same_cell"] = {"ms_per_step": one * 1e3, "atom_steps_per_s": N_global / one}
                 out["secondary"]["speedup_vs_single_gpu"] = one / (dt / args.steps)
+                # (top level too: `--gpus 1` runs configs[1], the cell the metric is quoted on, `--gpus N` this cell -- a ratio
+                # of the two lines' `value`s would compare different workloads; this is the same cell on ONE GPU of this run)
+                out["single_gpu_same_workload"] = {"value": N_global / one, "unit": "atom-steps/s", "ms_per_step": one * 1e3,
+                                                   "where": "rank 0's GPU, unsharded, timed in this process"}
+                out["speedup_vs_single_gpu_same_workload"] = one / (dt / args.steps)
                 del d1
             except Exception as ex:
                 out["secondary"]["single_gpu_same_cell"] = {"error": repr(ex)}

@@ -338,8 +338,8 @@ class FusedRelationalLayer(torch.autograd.Function):
                 hb, xh, mean, rstd = pre = nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges)
                 x1, vec1 = out = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False, ranges=halo.fwd_early,
                                           zero_unknown=True, range_rows=halo.early_rows)
-                if work is not None:
-                    work.wait()
+                from .sharding import comm_wait
+                comm_wait(work, "fwd", sum(plan.send_counts), sum(plan.recv_counts))
                 if plan.recv_idx.numel() > 0:  # (a rank without halo atoms has nothing to redo)
                     nodeops.halo_rows(2, x, vec, plan.recv_idx, recv)
                     nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges, windows=halo.windows, mode=1, out=pre)
@@ -489,8 +489,8 @@ class FusedRelationalLayer(torch.autograd.Function):
             res = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, add=gx_in, src_ranges=graph.src_ranges,
                                        windows=halo.windows, mode=2, out=out)
             gx_total = res[0]
-            if work is not None:
-                work.wait()
+            from .sharding import comm_wait
+            comm_wait(work, "bwd", sum(plan.recv_counts), sum(plan.send_counts))
             nodeops.halo_accumulate(gx_total, gvec_in, plan, back)                  # gradients of my atoms used elsewhere
             ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
             return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None, None

@@ -72,13 +72,78 @@ def _host_staged(group, t):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
+class CommProbe(object):
+    """Diagnostics of the halo exchanges of a sharded step (bench.py's `comm` block): HIP events on the compute
+    stream around every point where it waits for a collective.  `wait(work, tag)` replaces `work.wait()`; the blocking
+    exchanges are bracketed whole.  Off (None) in production: an event pair costs ~15 us of host time."""
+
+    def __init__(self):
+        self.records = []          # (tag, rows_out, rows_in, start event, end event)
+
+    def _pair(self):
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def wait(self, work, tag, rows_out=0, rows_in=0):
+        a, b = self._pair()
+        a.record()
+        work.wait()
+        b.record()
+        self.records.append((tag, int(rows_out), int(rows_in), a, b))
+
+    def bracket(self, tag, rows_out, rows_in, fn):
+        a, b = self._pair()
+        a.record()
+        out = fn()
+        b.record()
+        self.records.append((tag, int(rows_out), int(rows_in), a, b))
+        return out
+
+    def summary(self):
+        """tag -> dict(count, ms_total, rows_out, rows_in) (synchronises)."""
+        torch.cuda.synchronize()
+        out = {}
+        for tag, ro, ri, a, b in self.records:
+            d = out.setdefault(tag, dict(count=0, ms_total=0.0, rows_out=0, rows_in=0))
+            d["count"] += 1
+            d["ms_total"] += a.elapsed_time(b)
+            d["rows_out"] += ro
+            d["rows_in"] += ri
+        return out
+
+
+_PROBE = None
+
+
+def set_comm_probe(probe):
+    global _PROBE
+    _PROBE = probe
+
+
+def comm_wait(work, tag, rows_out=0, rows_in=0):
+    """The compute stream waits for an asynchronous exchange (`_all_to_all_rows_start`); timed when a probe is set."""
+    if work is None:
+        return
+    if _PROBE is not None and torch.cuda.is_available():
+        _PROBE.wait(work, tag, rows_out, rows_in)
+    else:
+        work.wait()
+
+
 def _all_to_all_rows(buf, in_counts, out_counts, group):
     if _host_staged(group, buf):
-        return _all_to_all_rows(buf.cpu(), in_counts, out_counts, group).to(buf.device)
+        staged = lambda: _all_to_all_rows(buf.cpu(), in_counts, out_counts, group).to(buf.device)
+        if _PROBE is not None:      # (rehearsal: the host-staged exchange shows up as a blocking one)
+            return _PROBE.bracket("blocking", sum(in_counts), sum(out_counts), staged)
+        return staged()
     out = buf.new_empty((sum(out_counts),) + tuple(buf.shape[1:]))
-    dist.all_to_all_single(out, buf.contiguous(), output_split_sizes=out_counts, input_split_sizes=in_counts,
-                           group=group)
-    return out
+
+    def go():
+        dist.all_to_all_single(out, buf.contiguous(), output_split_sizes=out_counts, input_split_sizes=in_counts,
+                               group=group)
+        return out
+    if _PROBE is not None and buf.is_cuda:
+        return _PROBE.bracket("blocking", sum(in_counts), sum(out_counts), go)
+    return go()
 
 
 def _all_to_all_rows_start(buf, in_counts, out_counts, group):
