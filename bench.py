@@ -741,7 +741,9 @@ def main():
         # the slab plan (owners, halo = rc + skin, exchange lists) is kept while no atom has moved further than skin/2;
         # per step only the displacement check and the slab-local neighbour search run (sharding.SlabStepper)
         SKIN = 1.0
-        stepper = SlabStepper(gz, gcell, model_kw["rc"], rank, world, skin=SKIN, group=group)
+        # (deferred: no host read per step -- the displacement flag and the padded list's count stay on the device until ONE
+        # check() behind the step; the first call of a plan searches exactly, which is also the Data of the timed region)
+        stepper = SlabStepper(gz, gcell, model_kw["rc"], rank, world, skin=SKIN, group=group, deferred=True)
 
         def plan_shard():
             return stepper(gpos)
@@ -821,9 +823,12 @@ def main():
     if not args.no_secondary:
         from hermnet_amd.neighbor import neighbor_search
         if sharded:
+            md_valid = []
+
             def md_step():
                 d, _ = plan_shard()
-                return step(d)
+                out_ = step(d)
+                return out_
         else:
             pos0, cell0 = data.pos.detach(), data.cell
 
@@ -842,6 +847,9 @@ def main():
             md_step()
         fence()
         md = max_over_ranks(time.perf_counter() - t1) / nmd
+        if sharded:
+            md_valid.append(bool(stepper.check()))       # ONE host read for the last step (a calculator does it per step, when
+                                                         # it copies the results to the host anyway)
         md_padded = None
         if not sharded:
             # the same MD-style step with the neighbour list built WITHOUT its host read: padded to a capacity, count and
@@ -974,6 +982,8 @@ def main():
                 out["secondary"]["incl_planning_padded_list"] = md_padded
             if sharded:
                 out["secondary"].update({"skin_A": SKIN, "replan_ms": replan_ms, "replans_in_run": stepper.replans,
+                                         "host_reads_per_step": 0, "last_step_valid": md_valid[-1] if md_valid else None,
+                                         "steps_repeated": stepper.repeats,
                                          "planning_note": "plan reused under the Verlet skin (static coordinates here); a "
                                                           "re-plan costs replan_ms more on the step that needs it"})
         if sharded and not args.no_secondary and cfg != "weak":

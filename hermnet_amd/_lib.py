@@ -103,6 +103,9 @@ SIGNATURES = {
     "hermnet_energy_head_bwd": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_energy_head_fused_fwd": (ctypes.c_int, [c_fp] * 8 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_energy_head_fused_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_energy_head16_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "hermnet_energy_head16_fwd": (ctypes.c_int, [c_fp] * 8 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_energy_head16_bwd": (ctypes.c_int, [c_fp] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_node_chain_supported": (ctypes.c_int, [ctypes.c_int]),
     "hermnet_node_chain_tile_rows": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "hermnet_node_pre_fwd": (ctypes.c_int, [c_fp] * 10 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

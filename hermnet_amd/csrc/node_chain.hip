@@ -770,6 +770,11 @@ int hn_update16_bwd(int hidden, const UpdBwdArgs& a, int tiles, void* stream);
 int hn_update16_pre_fwd(int hidden, const UpdFwdArgs& a, const PreFwdArgs& p, int tiles, void* stream);
 int hn_pre16_fwd(int hidden, const PreFwdArgs& p, void* stream);
 int hn_pre16_bwd(int hidden, const PreBwdArgs& a, void* stream);
+int hn_head16_supported(int hidden, int cols);
+int hn_head16_fwd(const float* x, const float* w0_frag16, const float* b0, const float* w2, const float* b2, const float* mask,
+                  float* h, float* e, int rows, void* stream);
+int hn_head16_bwd(const float* ge, const float* h, const float* w0t_frag16, const float* w2, const float* mask, float* gx,
+                  int rows, void* stream);
 
 // Widths 64 / 128 / 256 have tuned instances in this file; every other multiple of 64 up to 512 -- the reference's default
 // hidden_channels = 512 among them (hermnet.py:86) -- takes the panelled kernels.  HERMNET_NODE_CHAIN_WIDE=1 sends 128 and
@@ -938,4 +943,23 @@ extern "C" int hermnet_node_pre_bwd16(const float* gxh, const float* hb, const f
   if (!gxh || !hb || !w2t_frag16 || !w1t_frag16 || !gn_parts) return HN_ERR_BAD_ARG;
   PreBwdArgs a = {gxh, hb, w2t_frag16, w1t_frag16, gn_parts, nullptr, num_src, num_rel, nullptr, 0, 0};
   return hn_pre16_bwd(hidden, a, stream);
+}
+
+// ---- the read-out on the matrix pipe (csrc/node_chain16.hip: 16-row tiles, hidden 128 -> 64) --------------------------------------
+extern "C" int hermnet_energy_head16_supported(int hidden, int cols) { return hn_head16_supported(hidden, cols); }
+
+extern "C" int hermnet_energy_head16_fwd(const float* x, const float* w0_frag16, const float* b0, const float* w2, const float* b2,
+                                         const float* row_mask, float* h, float* e, int rows, int hidden, int cols, void* stream) {
+  if (rows < 0 || !hn_head16_supported(hidden, cols)) return HN_ERR_BAD_ARG;
+  if (rows == 0) return HN_OK;
+  if (!x || !w0_frag16 || !b0 || !w2 || !h || !e) return HN_ERR_BAD_ARG;
+  return hn_head16_fwd(x, w0_frag16, b0, w2, b2, row_mask, h, e, rows, stream);
+}
+
+extern "C" int hermnet_energy_head16_bwd(const float* ge, const float* h, const float* w0t_frag16, const float* w2,
+                                         const float* row_mask, float* gx, int rows, int hidden, int cols, void* stream) {
+  if (rows < 0 || !hn_head16_supported(hidden, cols)) return HN_ERR_BAD_ARG;
+  if (rows == 0) return HN_OK;
+  if (!ge || !h || !w0t_frag16 || !w2 || !gx) return HN_ERR_BAD_ARG;
+  return hn_head16_bwd(ge, h, w0t_frag16, w2, row_mask, gx, rows, stream);
 }

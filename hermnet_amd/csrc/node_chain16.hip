@@ -767,6 +767,107 @@ __global__ __launch_bounds__(256, HN_U16_MINW_BWD) void node_update_bwd16_kernel
   }
 }
 
+// =====================================================================================================================
+// The read-out (hermnet.py:112-116, 129) on 16-row tiles: Linear(H -> C) on the matrix pipe, ScaledSiLU and the C -> 1 Linear in
+// the epilogue; H = 128, C = 64.  Round 5: the VALU form of csrc/node_kernels.hip (every workgroup stages the whole weight in LDS)
+// took 24 us forward + 16 us backward at 10k rows for 0.3 GFLOP.
+// =====================================================================================================================
+struct HeadArgs {
+  const float* x;        // fwd: x [N, H];  bwd: h [N, C] (saved pre-activations)
+  const float* wf;       // fwd: frag16(W0 [C, H]);  bwd: frag16(W0^T [H, C])
+  const float* b0;       // [C]
+  const float* w2;       // [C]
+  const float* b2;       // [1] or null
+  const float* ge;       // bwd: [N]
+  const float* mask;     // [N] or null
+  float* h;              // fwd: [N, C] saved
+  float* out;            // fwd: e [N];  bwd: gx [N, H]
+  int N;
+};
+
+template <int H, int C>
+__global__ __launch_bounds__(256) void energy_head16_fwd_kernel(HeadArgs a) {
+  static_assert(H == 128 && C == 64, "four waves x 16 output channels");
+  constexpr int TR = kTR16, LD = H + 8;
+  extern __shared__ __align__(16) float lds[];               // [TR][LD], then [4][16] partial row sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * TR, nrows = min(TR, a.N - row0);
+  const int mrow = lane & 15, ch = 4 * (lane >> 4);
+  const f32x4* bp[1] = {reinterpret_cast<const f32x4*>(a.wf) + (size_t)wave * (H / 16) * 64 + lane};
+  Ring16<1> ring;
+  b16_preload(ring, bp);
+  f32x4 acc[1] = {ld4g(a.b0 + 16 * wave + ch)};
+  const f32x4 w2v = ld4g(a.w2 + 16 * wave + ch);
+  Tile16Regs<H> regs;
+  tile16_load<H>(regs, tile_rsrc(a.x + (size_t)row0 * H, nrows * H), H, 0, tid);
+  tile16_store<H, LD>(lds, regs, tid);
+  __syncthreads();
+  mma16_panel<H, 1, false>(acc, lds + mrow * LD + ch, bp, ring);
+  const f32x4 hv = acc[0];
+  if (mrow < nrows) *reinterpret_cast<f32x4*>(a.h + (size_t)(row0 + mrow) * C + 16 * wave + ch) = hv;
+  const f32x4 av = ssilu4(hv);                               // (incl. the 1 / 0.6)
+  float s = av[0] * w2v[0];
+  s = fmaf(av[1], w2v[1], s);
+  s = fmaf(av[2], w2v[2], s);
+  s = fmaf(av[3], w2v[3], s);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  float* part = lds + TR * LD;
+  if (lane < 16) part[wave * 16 + lane] = s;
+  __syncthreads();
+  if (tid < nrows) {
+    const float e = ((part[tid] + part[16 + tid]) + (part[32 + tid] + part[48 + tid])) + (a.b2 ? a.b2[0] : 0.f);
+    a.out[row0 + tid] = e * (a.mask ? a.mask[row0 + tid] : 1.0f);
+  }
+}
+
+template <int H, int C>
+__global__ __launch_bounds__(256) void energy_head16_bwd_kernel(HeadArgs a) {
+  static_assert(H == 128 && C == 64, "four waves x 32 output channels");
+  constexpr int TR = kTR16, LDC = C + 8;
+  extern __shared__ __align__(16) float lds[];               // [TR][LDC], then 4 x [16][36] scratch
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * TR, nrows = min(TR, a.N - row0);
+  const int mrow = lane & 15, ch = 4 * (lane >> 4);
+  float* scr = lds + TR * LDC + wave * kScr16Floats;
+  const f32x4* w = reinterpret_cast<const f32x4*>(a.wf) + lane;
+  const f32x4* bp[2] = {w + (size_t)(2 * wave) * (C / 16) * 64, w + (size_t)(2 * wave + 1) * (C / 16) * 64};
+  Ring16<2> ring;
+  b16_preload(ring, bp);
+  {   // gh = ge mask w2 ScaledSiLU'(h): one float4 per thread
+    const int lr = tid / (C / 4), c = (tid % (C / 4)) * 4;
+    f32x4 g = zero4();
+    if (lr < nrows) {
+      const int row = row0 + lr;
+      const float f = a.ge[row] * (a.mask ? a.mask[row] : 1.0f);
+      g = dssilu4(ld4g(a.x + (size_t)row * C + c)) * ld4g(a.w2 + c) * f;
+    }
+    *reinterpret_cast<f32x4*>(lds + lr * LDC + c) = g;
+  }
+  __syncthreads();
+  f32x4 acc[2] = {zero4(), zero4()};
+  mma16_panel<C, 2, false>(acc, lds + mrow * LDC + ch, bp, ring);
+  store16<H>(scr, lane, acc, tile_rsrc(a.out + (size_t)row0 * H, nrows * H), 32 * wave);
+}
+
+}  // namespace
+
+int hn_head16_supported(int hidden, int cols) { return hidden == 128 && cols == 64; }
+
+int hn_head16_fwd(const float* x, const float* w0_frag16, const float* b0, const float* w2, const float* b2, const float* mask,
+                  float* h, float* e, int rows, void* stream) {
+  HeadArgs a = {x, w0_frag16, b0, w2, b2, nullptr, mask, h, e, rows};
+  return launch_chain(energy_head16_fwd_kernel<128, 64>, dim3((unsigned)((rows + 15) / 16)), (size_t)(16 * 136 + 64) * 4, stream, a);
+}
+
+int hn_head16_bwd(const float* ge, const float* h, const float* w0t_frag16, const float* w2, const float* mask, float* gx,
+                  int rows, void* stream) {
+  HeadArgs a = {h, w0t_frag16, nullptr, w2, nullptr, ge, mask, nullptr, gx, rows};
+  return launch_chain(energy_head16_bwd_kernel<128, 64>, dim3((unsigned)((rows + 15) / 16)), (size_t)(16 * 72 + 4 * kScr16Floats) * 4,
+                      stream, a);
+}
+
+namespace {
 }  // namespace
 
 // Entry points of this translation unit (called by node_chain.hip's dispatch).  The weight pointers of the argument blocks

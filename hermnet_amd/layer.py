@@ -543,6 +543,14 @@ class EnergyHead(torch.autograd.Function):
         """`mask` [N] (optional) multiplies the per-row energies: padding rows of the relation order -> 0."""
         w2v = w2.reshape(-1).contiguous()
         ctx.mask = mask
+        ctx.mfma = x.is_cuda and nodeops.head16_supported(x.size(1), w0.size(0)) and _os.environ.get("HERMNET_HEAD16", "1") != "0"
+        if ctx.mfma:       # the H -> C product on the matrix pipe (csrc/node_chain16.hip), one launch each way
+            w0c = w0.contiguous()
+            wf, wtf = _head_fragments(w0c)
+            h, e = nodeops.energy_head16_fwd(x, wf, b0, w2v, b2, mask)
+            ctx.save_for_backward(h, wtf, w2v)
+            ctx.fused, ctx.H = True, x.size(1)
+            return e
         ctx.fused = x.is_cuda and nodeops.head_fused_supported(x.size(1), w0.size(0))
         if ctx.fused:      # one launch each way, no library GEMM (csrc/node_kernels.hip: energy_head_fused_kernel)
             w0c = w0.contiguous()
@@ -556,6 +564,8 @@ class EnergyHead(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ge):
         h, w0, w2v = ctx.saved_tensors
+        if ctx.mfma:
+            return nodeops.energy_head16_bwd(ge.contiguous(), h, w0, w2v, ctx.H, ctx.mask), None, None, None, None, None
         if ctx.fused:
             return nodeops.energy_head_fused_bwd(ge.contiguous(), h, w0, w2v, ctx.mask), None, None, None, None, None
         gh = nodeops.energy_head_bwd(ge.contiguous(), h, w2v, ctx.mask)
@@ -563,6 +573,19 @@ class EnergyHead(torch.autograd.Function):
 
 
 _T_CACHE = []
+
+
+def _head_fragments(w):
+    """(frag16(W0), frag16(W0^T)) of the read-out's first weight, rebuilt only when it changes (the cache of `_transposed_once`;
+    guard.ParamGuard covers writes through `.data`)."""
+    key = ("frag16", w.data_ptr(), w._version, tuple(w.shape))
+    for ent in _T_CACHE:
+        if ent[0] == key:
+            return ent[2]
+    fr = (nodeops.weight_fragments16(w), nodeops.weight_fragments16(w.t().contiguous()))
+    _T_CACHE.insert(0, (key, w, fr))
+    del _T_CACHE[4:]
+    return fr
 
 
 def _transposed_once(w):

@@ -125,6 +125,29 @@ def energy_head_fused_bwd(ge, h, w0, w2, mask=None):
     return gx
 
 
+def head16_supported(H, C):
+    return bool(_lib.load().hermnet_energy_head16_supported(int(H), int(C)))
+
+
+def energy_head16_fwd(x, w0f16, b0, w2, b2, mask=None):
+    """The read-out with its H -> C product on the matrix pipe (16-row tiles, H = 128, C = 64): (h [rows,C], e [rows])."""
+    rows, H = x.shape
+    C = b0.numel()
+    h = torch.empty(rows, C, dtype=x.dtype, device=x.device)
+    e = torch.empty(rows, dtype=x.dtype, device=x.device)
+    _lib.check(_launch("energy_head16_fwd", lambda: _lib.load().hermnet_energy_head16_fwd(
+        P(x), P(w0f16), P(b0), P(w2), P(b2), P(mask), P(h), P(e), rows, H, C, _stream())), "hermnet_energy_head16_fwd")
+    return h, e
+
+
+def energy_head16_bwd(ge, h, w0tf16, w2, H, mask=None):
+    rows, C = h.shape
+    gx = torch.empty(rows, H, dtype=h.dtype, device=h.device)
+    _lib.check(_launch("energy_head16_bwd", lambda: _lib.load().hermnet_energy_head16_bwd(
+        P(ge), P(h), P(w0tf16), P(w2), P(mask), P(gx), rows, H, C, _stream())), "hermnet_energy_head16_bwd")
+    return gx
+
+
 def pair_mean(x, vec, Te, P_, B, rows_out, backward=False):
     """HTNet: mean over a centre atom's P virtual target rows (backward=False: [Te*P*B, ...] -> [rows_out, ...], zero
     rows behind Te*B) or its gradient (backward=True: [rows_out, ...] -> [Te*P*B, ...])."""

@@ -343,6 +343,16 @@ int hermnet_energy_head_fused_fwd(const float* x, const float* w0t, const float*
 int hermnet_energy_head_fused_bwd(const float* ge, const float* h, const float* w0, const float* w2,
                                   const float* row_mask, float* gx, int rows, int hidden, int cols, void* stream);
 
+/* ABI v9: the same read-out with its H -> C product on the fp32 matrix pipe (csrc/node_chain16.hip; hidden 128, cols 64: the
+ * width of BASELINE configs[1]): w0_frag16 = frag16(out_energy[0].weight [cols, hidden]), w0t_frag16 = frag16 of its transpose
+ * (frag16: hermnet_node_update_fwd, "16-row form").  Same results to rounding (another summation order); ~4 us each way at
+ * 10k rows where the staged-weight form above takes 24 / 16 us. */
+int hermnet_energy_head16_supported(int hidden, int cols);
+int hermnet_energy_head16_fwd(const float* x, const float* w0_frag16, const float* b0, const float* w2, const float* b2,
+                              const float* row_mask, float* h, float* e, int rows, int hidden, int cols, void* stream);
+int hermnet_energy_head16_bwd(const float* ge, const float* h, const float* w0t_frag16, const float* w2,
+                              const float* row_mask, float* gx, int rows, int hidden, int cols, void* stream);
+
 /* ---- A7 (node MLP) + A11 + A12 as chain kernels on the fp32 matrix pipe (csrc/node_chain.hip) -----------------------
  * One launch per chain instead of library GEMMs joined by elementwise launches; hidden activations never reach HBM.
  * hidden must be 64, 128 or 256 (hermnet_node_chain_supported; other widths: the stage-wise entry points above around

@@ -463,6 +463,36 @@ def test_fused_layer_boundary_changes_no_bit_of_the_model(name, monkeypatch):
     assert rel_err(out["1"][0], out["0"][0]) < 2e-6 and rel_err(out["1"][1], out["0"][1]) < 5e-6
 
 
+@pytest.mark.parametrize("rows", [1, 16, 333, 10041])
+def test_read_out_on_the_matrix_pipe_matches_the_staged_weight_form(rows, monkeypatch):
+    """hermnet_energy_head16_fwd / _bwd (hermnet.py:112-116,129 with its 128 -> 64 product on v_mfma_f32_16x16x4_f32) vs the
+    round-3 kernels (weights staged in LDS, VALU) and vs the fp64 torch expression: per-row energies, saved pre-activations,
+    the gradient w.r.t. x; a row mask; row counts that leave the last tile ragged."""
+    from hermnet_amd.layer import EnergyHead
+    dev = _dev()
+    gen = torch.Generator().manual_seed(rows)
+    H, C = 128, 64
+    x = torch.randn(rows, H, generator=gen)
+    w0, b0 = torch.randn(C, H, generator=gen) * 0.2, torch.randn(C, generator=gen) * 0.2
+    w2, b2 = torch.randn(1, C, generator=gen) * 0.3, torch.randn(1, generator=gen)
+    mask = (torch.rand(rows, generator=gen) > 0.2).float()
+    ge = torch.randn(rows, generator=gen)
+    xd = x.double().requires_grad_(True)
+    hr = xd @ w0.double().t() + b0.double()
+    er = ((torch.nn.functional.silu(hr) / 0.6) @ w2.double().t()).squeeze(1) + b2.double()
+    er = er * mask.double()
+    (gr,) = torch.autograd.grad(er, xd, ge.double())
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("HERMNET_HEAD16", flag)
+        xg = x.to(dev).requires_grad_(True)
+        e = EnergyHead.apply(xg, w0.to(dev), b0.to(dev), w2.to(dev), b2.to(dev), mask.to(dev))
+        (g,) = torch.autograd.grad(e, xg, ge.to(dev))
+        out[flag] = (e.detach().cpu(), g.cpu())
+        assert rel_err(e.detach().cpu().double(), er.detach()) < 2e-6 and rel_err(g.cpu().double(), gr) < 2e-6, flag
+    assert rel_err(out["1"][0], out["0"][0]) < 2e-6 and rel_err(out["1"][1], out["0"][1]) < 2e-6
+
+
 def _node_chain_case(H, T, counts, uniform, hr):
     """csrc/node_chain.hip (LayerNorm + x_proj chain, PaiNNUpdate chain and their backward kernels on the fp32 matrix
     pipe) vs the fp64 PyTorch restatement of tests/ref_ops.py: ragged relation blocks, an inactive relation, rows of
