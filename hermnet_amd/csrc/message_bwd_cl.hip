@@ -47,58 +47,64 @@ constexpr int kRec = HN_EDGE_TABLE_FLOATS;   // floats per edge record
 // The envelope factors are folded into the tap pairs, so the contraction yields rbfh and its distance derivative
 // directly (no per-channel envelope arithmetic in the message kernel).
 
+// Records leave through a wave-private LDS transpose: a lane computes one record (128 B), and written straight from its
+// registers every store instruction would touch 64 different 128-byte lines with 16 bytes each (measured 25.7 us for the 55 MB
+// table of configs[1]); through the tile the wave writes its 64 records as eight fully coalesced 1-KiB stores.
 __global__ __launch_bounds__(256) void edge_table_kernel(const float4* __restrict__ edge, const int* __restrict__ csc_pos,
                                                          int E, const float* __restrict__ offset, int R, float inv_rc,
                                                          float coeff, int env_kind, int env_p,
                                                          float* __restrict__ table, const int* __restrict__ csc_end) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= E) return;
+  constexpr int kLd = kRec + 4;                          // 36 floats: 16-byte aligned rows, 8 lanes per 128 B then a 144-B step
+  __shared__ __align__(16) float stage[4][64 * kLd];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q0 = (blockIdx.x * 4 + wave) * 64;           // first record of this wave
+  if (q0 >= E) return;
+  const int q = q0 + lane;
+  const int n_csc = csc_end[0];
+  float rec[kRec];
+#pragma unroll
+  for (int w = 0; w < kRec; ++w) rec[w] = 0.f;
   // CSC positions behind the last segment (edges into unknown-element rows, the NULL edges of a padded list) belong to
   // no row: csc_pos is not defined there.  Their records are never an edge's own record -- only the one a wave requests
   // AHEAD of its last edge -- so they hold a valid tile row and zeros.
-  const int n_csc = csc_end[0];
-  if (q >= n_csc) {
-    float4* out = reinterpret_cast<float4*>(table + (size_t)q * kRec);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  rec[24] = __int_as_float(HN_PAD);
+  rec[25] = __int_as_float(HN_PAD);
+  if (q < n_csc) {
+    const float4 g = edge[csc_pos[q]];
+    const float d_next = edge[csc_pos[min(q + 1, n_csc - 1)]].w;
+    const float u = g.w * inv_rc;
+    const HnEnv env = hn_envelope(u, env_kind, env_p);
+    const int lo = hn_window_lo(u, R);
+    const float c0 = inv_rc * env.der, c1 = inv_rc * env.val * 2.0f * coeff;    // d rbfh / d d = c0 S0 + c1 S1
 #pragma unroll
-    for (int w = 0; w < kRec / 4; ++w) out[w] = z;
-    out[6] = make_float4(__int_as_float(HN_PAD), __int_as_float(HN_PAD), 0.f, 0.f);      // slots 24, 25: tile rows
-    if (q == E - 1) {
-#pragma unroll
-      for (int w = 0; w < kRec / 4; ++w) out[kRec / 4 + w] = z;
-      out[kRec / 4 + 6] = make_float4(__int_as_float(HN_PAD), __int_as_float(HN_PAD), 0.f, 0.f);
+    for (int m = 0; m < HN_TAPS; ++m) {
+      int k = lo + m;
+      k = k < 0 ? 0 : (k >= R ? R - 1 : k);                 // (rows outside [0, R) hold zero weights)
+      const float diff = u - offset[k];
+      const float gm = __expf(coeff * (diff * diff));        // same fp32 operation order as rmnet.py:156-172
+      rec[2 * m] = env.val * gm;
+      rec[2 * m + 1] = c0 * gm + c1 * (gm * diff);
     }
-    return;
+    rec[24] = __int_as_float(lo + HN_PAD);                  // padded tile row of tap 0
+    rec[25] = __int_as_float(hn_window_lo(d_next * inv_rc, R) + HN_PAD);
+    rec[28] = g.x; rec[29] = g.y; rec[30] = g.z;
+    rec[31] = __builtin_amdgcn_rcpf(g.w);
   }
-  const float4 g = edge[csc_pos[q]];
-  const float d_next = edge[csc_pos[min(q + 1, n_csc - 1)]].w;
-  const float u = g.w * inv_rc;
-  const HnEnv env = hn_envelope(u, env_kind, env_p);
-  const int lo = hn_window_lo(u, R);
-  float rec[kRec];
-  const float c0 = inv_rc * env.der, c1 = inv_rc * env.val * 2.0f * coeff;    // d rbfh / d d = c0 S0 + c1 S1
+  float* st = stage[wave];
 #pragma unroll
-  for (int m = 0; m < HN_TAPS; ++m) {
-    int k = lo + m;
-    k = k < 0 ? 0 : (k >= R ? R - 1 : k);                 // (rows outside [0, R) hold zero weights)
-    const float diff = u - offset[k];
-    const float gm = __expf(coeff * (diff * diff));        // same fp32 operation order as rmnet.py:156-172
-    rec[2 * m] = env.val * gm;
-    rec[2 * m + 1] = c0 * gm + c1 * (gm * diff);
+  for (int w = 0; w < kRec / 4; ++w)
+    *reinterpret_cast<float4*>(st + lane * kLd + 4 * w) = make_float4(rec[4 * w], rec[4 * w + 1], rec[4 * w + 2], rec[4 * w + 3]);
+  // (LDS operations of one wave execute in order: no barrier between its own writes and reads)
+  const int nrec = min(64, E - q0);                       // records of this wave that exist
+  float4* out = reinterpret_cast<float4*>(table + (size_t)q0 * kRec);
+#pragma unroll
+  for (int j = 0; j < kRec / 4; ++j) {
+    const int idx = j * 64 + lane, r = idx / (kRec / 4), w = idx % (kRec / 4);
+    if (r < nrec) out[idx] = *reinterpret_cast<const float4*>(st + r * kLd + 4 * w);
   }
-  rec[24] = __int_as_float(lo + HN_PAD);                  // padded tile row of tap 0
-  rec[25] = __int_as_float(hn_window_lo(d_next * inv_rc, R) + HN_PAD);
-  rec[26] = 0.f;
-  rec[27] = 0.f;
-  rec[28] = g.x; rec[29] = g.y; rec[30] = g.z;
-  rec[31] = __builtin_amdgcn_rcpf(g.w);
-  float4* out = reinterpret_cast<float4*>(table + (size_t)q * kRec);
-#pragma unroll
-  for (int w = 0; w < kRec / 4; ++w) out[w] = make_float4(rec[4 * w], rec[4 * w + 1], rec[4 * w + 2], rec[4 * w + 3]);
-  if (q == E - 1) {       // record E: a copy of the last one -- the kernel requests record q+1 without a bounds check
-#pragma unroll
-    for (int w = 0; w < kRec / 4; ++w) out[kRec / 4 + w] = make_float4(rec[4 * w], rec[4 * w + 1], rec[4 * w + 2], rec[4 * w + 3]);
-  }
+  // record E: a copy of the last one -- the message kernel requests record q + 1 without a bounds check
+  if (q0 + nrec == E && lane < kRec / 4)
+    out[(size_t)nrec * (kRec / 4) + lane] = *reinterpret_cast<const float4*>(st + (nrec - 1) * kLd + 4 * lane);
 }
 
 template <int CTRL>

@@ -37,14 +37,35 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restric
 // (wrapping arithmetic: exact, order-independent between lanes, so deterministic) and either records the sum or compares
 // it with the recorded one; on a difference it raises `flag` and writes a NaN over `poison[0]` -- a value every result of
 // the step depends on -- so that a step on stale copies yields NaN, never the old numbers.
+// One workgroup per CHUNK of at most 4096 words (the host cuts every tensor into chunks: ~1,000 workgroups for 3.5 M
+// parameters, 16 bytes per lane and load -- the first version gave each tensor to one workgroup, 192 dependent round trips for
+// the largest: 41 us per step; this one reads the 14 MB at the cache rate, a few microseconds).
 __global__ __launch_bounds__(256) void param_guard_kernel(const unsigned* const* __restrict__ ptrs,
                                                           const long* __restrict__ counts, unsigned* __restrict__ fp,
                                                           int check, float* __restrict__ poison, int* __restrict__ flag) {
   __shared__ unsigned part[4];
   const unsigned* p = ptrs[blockIdx.x];
-  const long n = counts[blockIdx.x];
+  const int n = (int)counts[blockIdx.x];
   unsigned acc = 0;
-  for (long i = threadIdx.x; i < n; i += 256) acc += p[i] * (2u * (unsigned)i + 1u);
+  if ((((unsigned long long)p) & 15ull) == 0) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4* p4 = reinterpret_cast<const u4*>(p);
+    const int n4 = n >> 2;
+    u4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      v[k] = i < n4 ? p4[i] : (u4){0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned i0 = 4u * (threadIdx.x + 256u * k);
+      acc += v[k][0] * (2u * i0 + 1u) + v[k][1] * (2u * i0 + 3u) + v[k][2] * (2u * i0 + 5u) + v[k][3] * (2u * i0 + 7u);
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) acc += p[i] * (2u * (unsigned)i + 1u);
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) acc += p[i] * (2u * (unsigned)i + 1u);
+  }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
@@ -64,6 +85,7 @@ __global__ __launch_bounds__(256) void param_guard_kernel(const unsigned* const*
 
 extern "C" int hermnet_param_guard(const void* const* tensor_ptrs, const long* word_counts, int num_tensors,
                                    unsigned* fingerprints, int check, float* poison, int* flag, void* stream) {
+  // (`tensor_ptrs` / `word_counts` describe CHUNKS of at most 4096 words: the caller cuts larger tensors)
   if (num_tensors < 0 || (num_tensors > 0 && (!tensor_ptrs || !word_counts || !fingerprints)) || (check && !flag))
     return HN_ERR_BAD_ARG;
   if (num_tensors == 0) return HN_OK;

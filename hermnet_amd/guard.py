@@ -38,9 +38,12 @@ class ParamGuard(object):
         ts = self._tensors()
         key = tuple((t.data_ptr(), t.numel()) for t in ts)
         if key != self.key:
-            self.ptrs = torch.tensor([k[0] for k in key], dtype=torch.long, device=dev)
-            self.counts = torch.tensor([k[1] for k in key], dtype=torch.long, device=dev)
-            self.fp = torch.zeros(max(len(key), 1), dtype=torch.int32, device=dev)
+            # one workgroup per chunk of at most CHUNK words (hermnet_param_guard)
+            CHUNK = 4096
+            chunks = [(ptr + 4 * off, min(CHUNK, n - off)) for ptr, n in key for off in range(0, n, CHUNK)]
+            self.ptrs = torch.tensor([c[0] for c in chunks], dtype=torch.long, device=dev)
+            self.counts = torch.tensor([c[1] for c in chunks], dtype=torch.long, device=dev)
+            self.fp = torch.zeros(max(len(chunks), 1), dtype=torch.int32, device=dev)
             self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
             self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self.key, self.armed_for, self._event = key, None, None

@@ -583,7 +583,8 @@ int hermnet_stream_copy(const float* src, float* dst, size_t num_floats, int wor
 /* Parameter guard (ABI v9).  The host side caches kernel-ready copies of the module's parameters and rebuilds them when a
  * parameter's identity / version / address changes; a write through `.data` changes none of these (the reference has no such
  * cache: /root/reference/HermNet/hermnet.py:118-131 reads nn.Parameters directly on every call).  `tensor_ptrs` [n] device array
- * of device pointers to the parameter tensors, `word_counts` [n] their sizes in 32-bit words, `fingerprints` [n] uint32.
+ * of device pointers to CHUNKS of the parameter tensors (at most 4096 32-bit words each: one workgroup per chunk),
+ * `word_counts` [n] their sizes in words, `fingerprints` [n] uint32.
  * check == 0: record a position-weighted wrapping sum of every tensor's words.  check != 0: compare; on any difference
  * flag[0] = 1 and, if `poison` is given, poison[0] = NaN (the caller passes a cached value every result depends on, so a step on
  * stale copies yields NaN instead of the old numbers).  One launch, no host read. */
