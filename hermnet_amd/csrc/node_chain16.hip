@@ -48,12 +48,32 @@ constexpr int ring16(int nb) { return nb >= 4 ? 2 : 4; }     // (64 registers fo
 template <int NB>
 struct Ring16 { f32x4 v[ring16(NB)][NB]; };
 
+// Diagnostic builds (results wrong, time meaningful): -DHN_KO_BSTREAM=1 every weight request reads the stream's FIRST fragment
+// (same instructions, every request an L1 hit: what the weight stream's bytes cost), =2 no weight request at all (what its
+// instructions cost).  Round 5, 10,041 rows (profiles/r05_chain_ko.log): fused forward 98.4 / 96.2 / 75.2 us, fused backward
+// 99.9 / 94.8 / 74.3 us for 0 / 1 / 2 -- the REQUESTS (one 1-KiB load per four MFMAs at 16 rows), not their bytes or their
+// latency, are a quarter of these kernels' time.  Halving them with two row blocks per fragment (mixed 32- / 16-row tiles so
+// that the busiest CU still holds three blocks) was prototyped on the projection kernel: bit-identical, 64.0 -> 59.6 us -- the
+// 64-row kernel of node_chain.hip does the same work in 48 us; not pursued.
+#ifndef HN_KO_BSTREAM
+#define HN_KO_BSTREAM 0
+#endif
+__device__ __forceinline__ f32x4 wfrag(const f32x4* p, int idx) {
+#if HN_KO_BSTREAM == 1
+  return p[idx & 0];
+#elif HN_KO_BSTREAM == 2
+  return (f32x4){0.01f, -0.02f, 0.03f, 0.015f};
+#else
+  return p[idx];
+#endif
+}
+
 template <int NB>
 __device__ __forceinline__ void b16_preload(Ring16<NB>& r, const f32x4* const (&bp)[NB]) {
 #pragma unroll
   for (int g = 0; g < ring16(NB) - 1; ++g)
 #pragma unroll
-    for (int j = 0; j < NB; ++j) r.v[g][j] = bp[j][g * 64];
+    for (int j = 0; j < NB; ++j) r.v[g][j] = wfrag(bp[j], g * 64);
 }
 
 // acc[j] += W_j[k-groups 0 .. KP/16) . A^T; `As`: this lane's LDS read pointer &tile[(l & 15) * LD + 4 (l >> 4)].
@@ -69,7 +89,7 @@ __device__ __forceinline__ void mma16_panel(f32x4 (&acc)[NB], const float* As, c
     const int q = q0 + qq;
     if (load_b) {
 #pragma unroll
-      for (int j = 0; j < NB; ++j) ring.v[(qq + PF) % RS][j] = bp[j][(q + PF) * 64];
+      for (int j = 0; j < NB; ++j) ring.v[(qq + PF) % RS][j] = wfrag(bp[j], (q + PF) * 64);
     }
     if (load_a) a[(qq + 1) & 1] = *reinterpret_cast<const f32x4*>(As + 16 * (q + 1));
     if (HN_PIN_LOADS) fence_sched();       // (the requests stay in front of the group's MFMAs: node_chain_common.h)
