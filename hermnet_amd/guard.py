@@ -71,6 +71,8 @@ class ParamGuard(object):
         """Called once per eval() forward, after the cached copies are current for `stamp` (the tuple of the layers' cache
         keys): records the fingerprints when the copies were just (re)built, otherwise checks them.  Returns True when the
         PREVIOUS check had found a difference (the caller invalidates, rebuilds and calls again)."""
+        # (host cost matters: a step that reads the host once -- an MD step with an exact neighbour list -- pays every
+        # microsecond spent here in full; the parameter table is only rebuilt when the caches were)
         capturing = torch.cuda.is_current_stream_capturing()
         if not capturing and self.tripped():
             self._event = None
@@ -79,10 +81,9 @@ class ParamGuard(object):
                           "`.data`?): the previous result was NaN by design; the copies are rebuilt now.  Call "
                           "model.invalidate_caches() after such writes.", RuntimeWarning, stacklevel=3)
             return True
-        n = self._table(dev)
-        if n == 0:
-            return False
         if self.armed_for != stamp:
+            if self._table(dev) == 0:
+                return False
             self.flag.zero_()
             self._launch(False, None)
             self.armed_for = stamp

@@ -219,7 +219,11 @@ class HVNet(nn.Module):
             g = self.__dict__.get("_guard")
             if g is None:
                 g = self.__dict__["_guard"] = ParamGuard(self)
-            if not g.step(dev, tuple((id(w), w.builds) for w in ws), ws[0].b1cat):
+            # (the stamp: which builds of the layers' copies + which tensors the embedding and the read-out are right now)
+            extra = tuple((p_.data_ptr(), p_._version) for p_ in (self.embed.weight, self.out_energy[0].weight,
+                                                                 self.out_energy[0].bias, self.out_energy[2].weight,
+                                                                 self.out_energy[2].bias))
+            if not g.step(dev, tuple((id(w), w.builds) for w in ws) + extra, ws[0].b1cat):
                 return ws
             self.invalidate_caches()            # the previous step ran on stale copies (its result was NaN): rebuild
         return ws

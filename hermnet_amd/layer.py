@@ -282,10 +282,18 @@ _PRE_NEXT = {}
 
 
 def _boundary_mode():
-    """HERMNET_FUSE_BOUNDARY: 1 (default) = one node launch per layer boundary each way where it is supported (width 128,
-    16-row update tiles, HVNet rows: csrc/node_chain16.hip); 2 = the same 16-row phases as separate launches (the A/B and
-    bit-for-bit check of the fused kernels); 0 = the round-4 form (64-row projection kernels)."""
-    return int(_os.environ.get("HERMNET_FUSE_BOUNDARY", "1"))
+    """HERMNET_FUSE_BOUNDARY -- how the node launches of a layer boundary are cut, where `nodeops.fused_boundary_supported`
+    (width 128, 16-row update tiles, HVNet rows: csrc/node_chain16.hip):
+      4 (default)  the BACKWARD boundary as one launch: the projection's backward of layer l + 1 runs inside the update backward
+                   of layer l (sums over the relations in registers, LayerNorm backward on the tile: no [T, N, H] partial sums in
+                   memory); the forward keeps its two launches (64-row projection kernel + 16-row update kernel);
+      1            both boundaries as one launch each (the next layer's projection inside the update launch as well);
+      3            only the forward boundary;    0   neither (the round-4 form);
+      2            the 16-row phases of mode 1 as launches of their own (the bit-for-bit check of the fused kernels).
+    Measured in the model (configs[1], one box, three interleaved rounds, profiles/r05_boundary_ab.log): 0: 2.944, 4: 2.945,
+    3: 2.971, 1: 2.988 ms per step -- the fused forward loses what the 64-row projection kernel gains from its four-times smaller
+    weight stream; the fused backward is as fast as its two launches and saves four launches and 60 MB of traffic per step."""
+    return int(_os.environ.get("HERMNET_FUSE_BOUNDARY", "4"))
 
 
 class FusedRelationalLayer(torch.autograd.Function):
@@ -349,9 +357,9 @@ class FusedRelationalLayer(torch.autograd.Function):
             ctx.halo = halo
             ctx.defer = bool(defer) and halo is None and vec is not None
             mode = _boundary_mode()
-            if (w_next is not None and halo is None and mode in (1, 2)
+            if (w_next is not None and halo is None and mode in (1, 2, 3)
                     and nodeops.fused_boundary_supported(graph, H, w, w_next)):
-                if mode == 1:
+                if mode != 2:
                     x_out, vec_out, vp, h2b, q23, nrm, pre_next = nodeops.node_update_pre_fwd(x1, vec1, w, graph, w_next)
                 else:
                     x_out, vec_out, vp, h2b, q23, nrm = nodeops.node_update_fwd(x1, vec1, w, graph)
@@ -499,10 +507,10 @@ class FusedRelationalLayer(torch.autograd.Function):
             if ctx.defer and ctx.needs_input_grad[0]:
                 gxh, gv_parts = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=False, finish=False)
                 mode, chain = _boundary_mode(), None
-                if mode in (1, 2) and nodeops.fused_boundary_supported(graph, H, w):
+                if mode in (1, 2, 4) and nodeops.fused_boundary_supported(graph, H, w):
                     # round 5: this layer's projection backward runs inside the update backward of the layer below (1), or as
                     # the same 16-row phase in a launch of its own (2)
-                    if mode == 1:
+                    if mode != 2:
                         gn_parts, chain = None, (gxh, hb, w.w2tf16, w.w1tf16)
                     else:
                         gn_parts = nodeops.node_pre_bwd16(gxh, hb, w)
