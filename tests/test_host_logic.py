@@ -169,7 +169,8 @@ class _FakeFn(object):
         self.apply = fn
 
 
-@pytest.mark.parametrize("name", SMALL_CASES)
+# (the reference-default width, hidden 512, is covered by the oracle tests on the CPU and by the HIP path on the GPU: 45 s here)
+@pytest.mark.parametrize("name", [c for c in SMALL_CASES if "h512" not in c])
 def test_host_pipeline_with_reference_ops_matches_golden(name, monkeypatch):
     """Everything around the two kernels (row ordering, per-relation node algebra, masks,
     read-out) on CPU, with the kernels replaced by tests/ref_ops.py: must reproduce the
