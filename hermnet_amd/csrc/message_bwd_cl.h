@@ -33,6 +33,11 @@ struct HnBwdClArgs {
   // whose gradients travel to other ranks first, the rest while they travel); 0 ranges = every row
   const int* src_ranges;     // [num_ranges][2] device
   int num_ranges;
+  // tap-row windows (set by hn_bwd_cl_launch when the whole tile does not fit the LDS, num_rbf > 137): this launch stages
+  // the padded tile rows [win_base, win_base + win_rows) only and OWNS the edges whose first tap row lies in
+  // [win_lo, win_hi); every other edge contributes nothing and its gedge slot is left alone.  win_accumulate = 1: the
+  // row sums are added to what the launch over the other window wrote.
+  int win_base, win_rows, win_lo, win_hi, win_accumulate;
 };
 
 size_t hn_bwd_cl_lds_bytes(int R);

@@ -192,10 +192,17 @@ struct EdgeIn {          // what one edge needs from memory (vector part)
 // gvec is written per relation ([T, Nsrc, 3, H] partial sums: three workgroups never read-modify-write the same row);
 // message_bwd_finish_kernel adds the T slices in a fixed order together with the residual's identity terms
 // (rmnet.py:24-26: gx = gx1 / sqrt2, gvec += gvec1 on target rows).
-template <bool HAS_VEC>
+//
+// WIN = true (num_rbf > 137: the whole tile would take more than the 160 KiB of LDS): the launch stages a WINDOW of the
+// tile's rows and owns the edges whose twelve taps lie inside it (HnBwdClArgs::win_*); two launches with windows that
+// overlap by eleven rows cover every edge exactly once.  Ownership is wave-uniform like everything else about an edge: a
+// foreign edge walks through the same pipeline with its target gradients multiplied by zero (every sum of the kernel is
+// linear in them) and a clamped tile row; the second launch adds its row sums to the first one's.
+template <bool HAS_VEC, bool WIN>
 __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdClArgs a) {
   extern __shared__ __align__(16) float4 tile[];     // [tap row][64] of (s, a, b, 0)
-  const int tile_rows = a.R + 2 * HN_PAD + 1;
+  const int tile_rows = WIN ? a.win_rows : a.R + 2 * HN_PAD + 1;
+  const int tile_base = WIN ? a.win_base : 0;        // padded tile row held by tile[0..63]
 
   // XCD-aware order (see message_kernels.hip: xcd_contiguous): the dispatcher deals the linearised grid round-robin over
   // the 8 XCDs; XCD k gets the k-th contiguous eighth of (relation, column block, row chunk), i.e. a slab of source rows
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
 
   // ---- stage the weight tile of (relation t, column block cb): rows outside [0, R) are zero
   for (int idx = threadIdx.x; idx < tile_rows * HN_CB; idx += blockDim.x) {
-    const int k = idx / HN_CB - HN_PAD, ch = idx % HN_CB;
+    const int k = idx / HN_CB + tile_base - HN_PAD, ch = idx % HN_CB;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k >= 0 && k < a.R) {
       const float* w = a.wt + ((size_t)(t * a.R + k) * 3 * H + cb * HN_CB + ch);
@@ -326,12 +333,26 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
     auto row_epilogue = [&](int r) {                 // every lane owns its channel: plain coalesced stores
       const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(r * (3 * H));
       const hn_rsrc go = row_rsrc(gxh_t, ro, H);
-      buf_store(go, c4, 0, gs * inv_sqrt2); buf_store(go, c4, h4, ga); buf_store(go, c4, 2 * h4, gb * inv_sqrth);
+      if constexpr (WIN) {
+        float o0 = gs * inv_sqrt2, o1 = ga, o2 = gb * inv_sqrth;
+        if (a.win_accumulate) { o0 += buf_load(go, c4, 0); o1 += buf_load(go, c4, h4); o2 += buf_load(go, c4, 2 * h4); }
+        buf_store(go, c4, 0, o0); buf_store(go, c4, h4, o1); buf_store(go, c4, 2 * h4, o2);
+      } else {
+        buf_store(go, c4, 0, gs * inv_sqrt2); buf_store(go, c4, h4, ga); buf_store(go, c4, 2 * h4, gb * inv_sqrth);
+      }
       if (HAS_VEC) {
         const hn_rsrc gvo = row_rsrc(gvec_t, ro, H);
+        if constexpr (WIN) {
+          if (a.win_accumulate) { gv0 += buf_load(gvo, c4, 0); gv1 += buf_load(gvo, c4, h4); gv2 += buf_load(gvo, c4, 2 * h4); }
+        }
         buf_store(gvo, c4, 0, gv0); buf_store(gvo, c4, h4, gv1); buf_store(gvo, c4, 2 * h4, gv2);
       }
     };
+    // (WIN) tile row of an edge inside this launch's window, clamped for the edges it does not own; and who owns it
+    auto win_row = [&](int prow) { return min(max(prow - a.win_base, 0), a.win_rows - HN_TAPS); };
+    auto win_owns = [&](int prow) { return (prow >= a.win_lo && prow < a.win_hi) ? 1u : 0u; };
+    unsigned own_cur = 1u;                             // (WIN) 1 if this launch owns the edge the stream is at
+    unsigned own_mask = 0u;                            // ... bit j: it owns edge j of the current group of four
     row_request(row);
 
     // The record stream and the weight-row reads run CONTINUOUSLY over the wave's edges: while edge q is in its channel
@@ -362,7 +383,13 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
     };
     if (e_begin < e_end) {
       load_record(tl0);
-      issue_weights((unsigned)__float_as_int(rp[24]) * (HN_CB * 16) + tile_lane);
+      if constexpr (WIN) {
+        const int prow0 = __float_as_int(rp[24]);
+        own_cur = win_owns(prow0);
+        issue_weights((unsigned)win_row(prow0) * (HN_CB * 16) + tile_lane);
+      } else {
+        issue_weights((unsigned)__float_as_int(rp[24]) * (HN_CB * 16) + tile_lane);
+      }
     }
     for (int base = e_begin; base < e_end; base += 64) {
       const int cnt = min(64, e_end - base);
@@ -416,7 +443,17 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
         taps4(0, wA);
         taps4(4, wB);
         taps4(8, wC);
-        const unsigned waddr_next = (unsigned)__float_as_int(tl[0]) * (HN_CB * 16) + tile_lane;
+        unsigned waddr_next;
+        float own = 1.0f;
+        if constexpr (WIN) {
+          const int prow_next = __float_as_int(tl[0]);
+          waddr_next = (unsigned)win_row(prow_next) * (HN_CB * 16) + tile_lane;
+          own = own_cur ? 1.0f : 0.0f;
+          own_mask = j == 0 ? own_cur : (own_mask | (own_cur << j));
+          own_cur = win_owns(prow_next);
+        } else {
+          waddr_next = (unsigned)__float_as_int(tl[0]) * (HN_CB * 16) + tile_lane;
+        }
         // the taps are consumed: request the NEXT edge's record (taps into the same scalar registers, tail into the other
         // set) and its weight rows into the same vector registers; their latency hides behind the rest of this edge
         __builtin_amdgcn_sched_barrier(0);
@@ -427,7 +464,8 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
         __builtin_amdgcn_sched_barrier(0);
         if (fresh) row_scale();                               // (wave-uniform) first edge of a row
         const float rx = tl[1], ry = tl[2], rz = tl[3], invd = tl[4];
-        const float gx1 = cur.gx1, g0 = cur.g0, g1 = cur.g1, g2 = cur.g2;
+        const float gx1 = WIN ? cur.gx1 * own : cur.gx1, g0 = WIN ? cur.g0 * own : cur.g0;
+        const float g1 = WIN ? cur.g1 * own : cur.g1, g2 = WIN ? cur.g2 * own : cur.g2;
         // (the .x sums are rbfh - bias, the .y sums d rbfh / d d: see the record layout)
         // ---- part s: dx = sum xs * rs
         const float rs = Ss.x + bs;
@@ -463,7 +501,11 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
         const int p0 = __builtin_amdgcn_readlane(my_pos, k4), p1 = __builtin_amdgcn_readlane(my_pos, min(k4 + 1, cnt - 1));
         const int p2 = __builtin_amdgcn_readlane(my_pos, min(k4 + 2, cnt - 1)), p3 = __builtin_amdgcn_readlane(my_pos, min(k4 + 3, cnt - 1));
         const int pw = (row16 == 0) ? p0 : (row16 == 1 ? p2 : (row16 == 2 ? p1 : p3));
-        if ((lane & 15) == 0 && k4 + je < cnt) gedge[pw] = make_float4(sx, sy, sz, 0.f);
+        if constexpr (WIN) {
+          if ((lane & 15) == 0 && k4 + je < cnt && ((own_mask >> je) & 1u)) gedge[pw] = make_float4(sx, sy, sz, 0.f);
+        } else {
+          if ((lane & 15) == 0 && k4 + je < cnt) gedge[pw] = make_float4(sx, sy, sz, 0.f);
+        }
       };
       using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
@@ -554,16 +596,26 @@ size_t hn_bwd_cl_lds_bytes(int R) {
 }
 
 int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, const int* ranges_host, hipStream_t s) {
-  const size_t lds = hn_bwd_cl_lds_bytes(a.R);
-  if (lds > 160 * 1024) return HN_ERR_LDS;
+  // The whole tile (num_rbf + 23 rows of 1 KiB) fits the LDS up to num_rbf = 137.  Beyond that: two launches over
+  // tap-row windows.  The first owns the edges whose first tap row is below `split` and stages rows [0, split + 11), the
+  // second owns the rest and stages [split, rows): 145 rows each at num_rbf = 256, 160 at 286 (the limit).
+  constexpr int kMaxRows = 160;
+  const int rows_all = a.R + 2 * HN_PAD + 1;
+  const bool windowed = rows_all > kMaxRows;
+  const int split = (rows_all - HN_PAD + 1) / 2;
+  if (windowed && (split + HN_PAD > kMaxRows || rows_all - split > kMaxRows)) return HN_ERR_LDS;
+  const size_t lds = windowed ? (size_t)(split + HN_PAD > rows_all - split ? split + HN_PAD : rows_all - split) * HN_CB * sizeof(float4)
+                              : hn_bwd_cl_lds_bytes(a.R);
   typedef void (*kern_t)(HnBwdClArgs);
-  kern_t k = has_vec ? message_scatter_bwd_cl_kernel<true> : message_scatter_bwd_cl_kernel<false>;
-  static bool done[2] = {false, false};
-  if (!done[has_vec]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
+  kern_t k = windowed ? (has_vec ? message_scatter_bwd_cl_kernel<true, true> : message_scatter_bwd_cl_kernel<false, true>)
+                      : (has_vec ? message_scatter_bwd_cl_kernel<true, false> : message_scatter_bwd_cl_kernel<false, false>);
+  static bool done[4] = {false, false, false, false};
+  const int which = (windowed ? 2 : 0) + (has_vec ? 1 : 0);
+  if (!done[which]) {      // (once per kernel, for the largest tile it can be given: a host-side attribute)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kMaxRows * HN_CB * (int)sizeof(float4)) != hipSuccess)
       return HN_ERR_LDS;
-    done[has_vec] = true;
+    done[which] = true;
   }
   // one (relation, column block, row chunk) per workgroup; the chunk is sized for a whole number of rounds of one
   // workgroup per CU (the 154 KB tile allows one resident workgroup): ~256 rows = 16 rows per wave
@@ -600,7 +652,14 @@ int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, const int* 
     }
   }
   dim3 grid((unsigned)chunks, (unsigned)ncb, (unsigned)a.T);
-  hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, a);
+  if (!windowed) {
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, a);
+  } else {
+    a.win_base = 0; a.win_rows = split + HN_PAD; a.win_lo = 0; a.win_hi = split; a.win_accumulate = 0;
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, a);
+    a.win_base = split; a.win_rows = rows_all - split; a.win_lo = split; a.win_hi = 0x7fffffff; a.win_accumulate = 1;
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, a);
+  }
   if (a.gx == nullptr) return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;   // (left to the consumer)
   // partial sums over the relations + identity terms -> gvec, gx
   const long n4v = has_vec ? (long)a.Nsrc * 3 * a.H / 4 : 0, n4x = (long)a.Nsrc * a.H / 4;

@@ -81,6 +81,10 @@ struct MsgArgs {
   int split_t;         // bwd: 1 = one relation per workgroup (blockIdx.z), gvec is [T,N,3,H] partial sums
   const int* row_ranges;   // fwd: [T][2] target rows [lo, hi) of every relation this launch covers, or null = whole blocks
   int zero_unknown;        // fwd: 1 = this launch also zeroes the rows of unknown-element atoms
+  // fwd, tap-row windows (num_rbf too large for one LDS tile; see hermnet_message_scatter_fwd): the launch stages the
+  // padded tile rows [win_base, win_base + win_rows) and owns the edges whose first tap row lies in [win_lo, win_hi);
+  // win_accumulate = 1: its sums are added to the rows the launch over the other window wrote (residual included there)
+  int win_base, win_rows, win_lo, win_hi, win_accumulate;
 };
 
 // ---- VW-wide per-lane vectors ------------------------------------------------------------------
@@ -207,10 +211,12 @@ __device__ __forceinline__ float group_allsum(float v) {
 // Zero-padded weight tile of (relation t, column block cb) and the tap centres:
 //   wl[(k + HN_PAD) * 192 + part * 64 + c] = wt[t][k][part * H + cb * 64 + c]   (0 outside 0 <= k < R)
 //   mu[k + HN_PAD] = offset[clamp(k)]
+// (`row0`, `nrows`: the window of padded rows held by wl -- all of them unless the launch works on a tap-row window; mu
+// always covers every row)
 template <int NTHREADS>
-__device__ __forceinline__ void stage_weights(const MsgArgs& a, int t, int cb, float* wl, float* mu) {
+__device__ __forceinline__ void stage_weights(const MsgArgs& a, int t, int cb, float* wl, float* mu, int row0, int nrows) {
   const int rows = a.R + 2 * HN_PAD + 1;
-  const int n4 = rows * (HN_LDS_ROW / 4);
+  const int n4 = nrows * (HN_LDS_ROW / 4);
   constexpr int INFLIGHT = 8;   // independent 16-byte loads per thread before the first LDS write
   for (int base = threadIdx.x; base < n4; base += NTHREADS * INFLIGHT) {
     float4 v[INFLIGHT];
@@ -219,7 +225,7 @@ __device__ __forceinline__ void stage_weights(const MsgArgs& a, int t, int cb, f
       const int idx = base + q8 * NTHREADS;
       const int kk = idx / (HN_LDS_ROW / 4);
       const int q = idx - kk * (HN_LDS_ROW / 4);
-      const int k = kk - HN_PAD;
+      const int k = kk + row0 - HN_PAD;
       v[q8] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < n4 && k >= 0 && k < a.R) {
         // 16 float4 per 64-channel part: part = q >> 4, c4 = q & 15
@@ -366,11 +372,15 @@ struct FwdIn {
   bool live;
 };
 
-template <bool HAS_VEC, int NW, int VW, int PF, bool FUSED>
+// WIN: the launch works on a window of the tap rows (MsgArgs::win_*): an edge it does not own is a padding slot (lv = 0)
+// reading a clamped tile row; with win_accumulate the epilogue adds to the other launch's rows.
+template <bool HAS_VEC, int NW, int VW, int PF, bool FUSED, bool WIN = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(MsgArgs a) {
+  static_assert(!WIN || VW == 4, "the windowed form exists for the default (VW = 4) variants");
   extern __shared__ __align__(16) float lds[];
+  const int tile_rows = WIN ? a.win_rows : a.R + 2 * HN_PAD + 1;
   float* wl = lds;
-  float* mu = lds + (a.R + 2 * HN_PAD + 1) * HN_LDS_ROW;
+  float* mu = lds + tile_rows * HN_LDS_ROW;
   float2* tapbase = reinterpret_cast<float2*>(mu + ((a.R + 2 * HN_PAD + 1 + 3) & ~3));
   constexpr int LPE = 64 / VW;   // lanes per edge
 
@@ -389,7 +399,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
     }
     return;
   }
-  stage_weights<NW * 64>(a, t, cb, wl, mu);
+  stage_weights<NW * 64>(a, t, cb, wl, mu, WIN ? a.win_base : 0, tile_rows);
   // more than 8 waves per workgroup live on <= 168 VGPRs: with vec rows in flight the six bias vectors (24 registers
   // at VW = 4) then stay in LDS and are re-read where they are used (layer 0, without vec rows, fits 16 waves as is)
   constexpr bool LEAN = HAS_VEC && NW > 8 && VW == 4;
@@ -479,7 +489,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
         const float u = cur.g.w * a.inv_rc;
         const HnEnv env = hn_envelope(u, a.env_kind, a.env_p);
         const int lo = hn_window_lo(u, a.R);
-        const float* wcol = wl + (lo + HN_PAD) * HN_LDS_ROW + VW * gl;
+        int trow = lo + HN_PAD;                               // padded tile row of tap 0
+        bool own = true;
+        if (WIN) { own = trow >= a.win_lo && trow < a.win_hi; trow = min(max(trow - a.win_base, 0), a.win_rows - HN_TAPS); }
+        const float* wcol = wl + trow * HN_LDS_ROW + VW * gl;
         float g[HN_TAPS], gd[HN_TAPS];
         Vec<VW> S0p[3], S1p[3];
         coop_taps(mu, tb, lo, u, a.coeff, gl);
@@ -488,7 +501,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
         HN_SB;
         // padding slots (segment length not a multiple of VW) contribute nothing: every term is
         // linear in rbfh = bias + env * S0 (rmnet.py:55), so scale it by 0 for them
-        const float lv = cur.live ? 1.0f : 0.0f;
+        const float lv = (cur.live && own) ? 1.0f : 0.0f;
         const float ev = env.val * lv;
         Vec<VW> S0, S1;
         // message (rmnet.py:61-67), one part at a time to keep the register footprint small
@@ -519,6 +532,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_fwd_kernel(Ms
       // rows_reduce4 leaves ONE channel (col + grp) of every reduced row in each lane: dword accesses, all lanes
       const int c1 = col + grp;
       const size_t xo = (size_t)r * H + c1;
+      if (WIN && a.win_accumulate) {          // the other launch wrote residual + its edges' sums
+        a.x1[xo] += rows_reduce4(ax) * 0.70710678118654752f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) a.vec1[((size_t)r * 3 + d) * H + c1] += rows_reduce4(av[d]);
+        continue;
+      }
       a.x1[xo] = (a.x[(size_t)rres * H + c1] + rows_reduce4(ax)) * 0.70710678118654752f;
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
@@ -597,7 +616,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void message_scatter_bwd_kernel(Ms
     HN_T(st_s0);
 #endif
     __syncthreads();   // previous tile no longer in use
-    stage_weights<NW * 64>(a, t, cb, wl, mu);
+    stage_weights<NW * 64>(a, t, cb, wl, mu, 0, a.R + 2 * HN_PAD + 1);
     __syncthreads();
 #if defined(HN_STAMPS)
     HN_T(st_s1);
@@ -865,9 +884,11 @@ int pick_rows(int rows, int ncb, int slack, int override_rows) {
 
 // LDS image: weight tile [rows][192] | tap centres mu [rows, padded to 4] | per-wave tap scratch
 // (float2 {g, g*diff} x 16 per lane group).
-size_t lds_bytes(int R) {
+// (`tile_rows`: rows of the weight tile held at once -- all of them unless the launch works on a tap-row window)
+size_t lds_bytes(int R, int tile_rows = 0) {
   const size_t rows = (size_t)(R + 2 * HN_PAD + 1);
-  return (rows * HN_LDS_ROW + ((rows + 3) & ~(size_t)3)) * sizeof(float) + 16 * 4 * 16 * sizeof(float2) +
+  const size_t held = tile_rows > 0 ? (size_t)tile_rows : rows;
+  return (held * HN_LDS_ROW + ((rows + 3) & ~(size_t)3)) * sizeof(float) + 16 * 4 * 16 * sizeof(float2) +
          6 * HN_CB * sizeof(float);      // + the column block's rbf_proj / x_proj biases (register-lean variants)
 }
 
@@ -956,11 +977,28 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   a.rows_per_block = pick_rows(rows, hidden / HN_CB, a.T * (hidden / HN_CB), rpb_fwd);
   static const int xcd = env_int("HERMNET_XCD_REMAP", 1);
   a.xcd_remap = xcd;
-  const size_t lds = lds_bytes(a.R);
-  if (lds > 160 * 1024) return HN_ERR_LDS;
   // blocks: sum_t ceil(N_t / rpb) <= N / rpb + T, plus one surplus block that zeroes unknown rows
   dim3 grid((unsigned)(rows / a.rows_per_block + a.T + 1), (unsigned)(hidden / HN_CB));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  size_t lds = lds_bytes(a.R);
+  if (lds > 160 * 1024) {
+    // num_rbf > 185: the tile of one (relation, column block) no longer fits the LDS.  Two launches over tap-row windows
+    // (the same split as the backward's, message_bwd_cl.hip: hn_bwd_cl_launch): the first owns the edges whose first tap
+    // row is below `split`, writes residual + their sums; the second owns the rest and adds its sums.
+    const int rows_all = a.R + 2 * HN_PAD + 1, split = (rows_all - HN_PAD + 1) / 2;
+    const int held = split + HN_PAD > rows_all - split ? split + HN_PAD : rows_all - split;
+    lds = lds_bytes(a.R, held);
+    if (lds > 160 * 1024) return HN_ERR_LDS;
+    kern_t k = vec ? message_scatter_fwd_kernel<true, 8, 4, 2, false, true> : message_scatter_fwd_kernel<false, 16, 4, 2, false, true>;
+    const int nw = vec ? 8 : 16;
+    if (ensure_lds(k, lds) != HN_OK) return HN_ERR_LDS;
+    a.win_base = 0; a.win_rows = split + HN_PAD; a.win_lo = 0; a.win_hi = split; a.win_accumulate = 0;
+    hipLaunchKernelGGL(k, grid, dim3(nw * 64), lds, s, a);
+    a.win_base = split; a.win_rows = rows_all - split; a.win_lo = split; a.win_hi = 0x7fffffff; a.win_accumulate = 1;
+    a.zero_unknown = 0;
+    hipLaunchKernelGGL(k, grid, dim3(nw * 64), lds, s, a);
+    return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+  }
   int nw = 16;
   kern_t k = vec ? pick_fwd<true>(variant, nw) : pick_fwd<false>(variant, nw);
   if (ensure_lds(k, lds) != HN_OK) return HN_ERR_LDS;

@@ -113,9 +113,11 @@ class RadialBasis(nn.Module):
             raise ValueError(f"Unknown radial basis function '{rbf_name}'.")
         self._desc = None
 
-    # largest Gaussian basis whose rbf_proj column block fits the backward kernel's LDS tile ((R + 23) tap rows x 64
-    # channels x 16 B <= 160 KiB, csrc/message_bwd_cl.hip; the forward tile would take R <= 190)
-    FUSED_MAX_RBF = 137
+    # largest Gaussian basis the fused kernels take.  One LDS tile of the backward kernel holds (R + 23) tap rows x 64
+    # channels x 16 B <= 160 KiB, i.e. R <= 137 (csrc/message_bwd_cl.hip; the forward tile: R <= 176); wider bases run as
+    # TWO launches over tap-row windows of <= 160 rows that overlap by eleven rows, each edge owned by the window that
+    # holds its twelve taps (hn_bwd_cl_launch, hermnet_message_scatter_fwd): R <= 286
+    FUSED_MAX_RBF = 286
 
     @property
     def fused(self):

@@ -1859,16 +1859,21 @@ def test_other_widths_vs_oracle(H, R, layers):
     _oracle_vs_hip(data, ["Al", "Ni", "Cu"], dict(rc=5.0, num_layers=layers, hidden_channels=H, num_rbf=R), 40 + H)
 
 
-@pytest.mark.parametrize("R", [137, 138, 192, 256])
+@pytest.mark.parametrize("R", [137, 138, 177, 192, 256, 286, 287])
 def test_large_gaussian_basis_vs_oracle(R):
-    """The reference accepts any `num_rbf` (hermnet.py:86, rmnet.py:155-158).  Up to RadialBasis.FUSED_MAX_RBF = 137 the
-    rbf_proj column block fits the fused kernels' LDS tile; beyond it the Gaussian basis takes the materialised route
-    (forward AND forces), which used to raise HN_ERR_LDS at the first force call."""
+    """The reference accepts any `num_rbf` (hermnet.py:86, rmnet.py:155-158).  Up to 137 the rbf_proj column block fits one
+    LDS tile of both message kernels; up to RadialBasis.FUSED_MAX_RBF = 286 the fused kernels run as two launches over
+    tap-row windows (backward from 138, forward from 177); beyond it the Gaussian basis takes the materialised route
+    (forward AND forces).  HERMNET_DEBUG_POISON: an edge owned by neither window would leave NaN in its gradient slot."""
     from hermnet_amd.rmnet import RadialBasis
     data = synth.fcc_alloy(reps=(2, 2, 3))
     kw = dict(rc=5.0, num_layers=2, hidden_channels=128, num_rbf=R)
     assert hn.HVNet(["Al"], **kw).radial_basis.fused == (R <= RadialBasis.FUSED_MAX_RBF)
-    _oracle_vs_hip(data, ["Al", "Ni", "Cu"], kw, 300 + R)
+    os.environ["HERMNET_DEBUG_POISON"] = "1"
+    try:
+        _oracle_vs_hip(data, ["Al", "Ni", "Cu"], kw, 300 + R)
+    finally:
+        del os.environ["HERMNET_DEBUG_POISON"]
 
 
 @pytest.mark.parametrize("env", [{}, {"HERMNET_BWD_CL": "0"}, {"HERMNET_NODE_CHAIN": "0"}])
