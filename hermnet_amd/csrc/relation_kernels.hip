@@ -384,6 +384,31 @@ int build_rows(const long* atomic_number, int NA, const int* z_list, int T, cons
   return HN_OK;
 }
 
+// Per-step flags of an atom-sharded step (hermnet_shard_step_flags): which (target element, source element) pairs are joined
+// by an edge of this rank's list, whether the padded list is complete, whether an atom has left the plan's skin.
+__global__ __launch_bounds__(kBlock) void shard_flags_kernel(const long* __restrict__ ei, long columns, const long* __restrict__ z,
+                                                             int num_atoms, const long* __restrict__ total, long capacity,
+                                                             int* __restrict__ has_in, const float* __restrict__ pos,
+                                                             const float* __restrict__ pos_ref, long num_pos, float max_dist2,
+                                                             int* __restrict__ moved) {
+  const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (i < columns) {
+    const long src = ei[i], tgt = ei[columns + i];
+    int slot = 128 * 128;                                   // NULL edges of a padded list
+    if (tgt >= 0 && tgt < num_atoms && src >= 0 && src < num_atoms) {
+      const long zt = z[tgt], zs = z[src];
+      slot = (int)(zt < 0 ? 0 : (zt > 127 ? 127 : zt)) * 128 + (int)(zs < 0 ? 0 : (zs > 127 ? 127 : zs));
+    }
+    if (has_in[slot] == 0) has_in[slot] = 1;               // (every writer writes 1)
+  }
+  if (i < num_pos) {
+    const float dx = pos[3 * i] - pos_ref[3 * i], dy = pos[3 * i + 1] - pos_ref[3 * i + 1], dz = pos[3 * i + 2] - pos_ref[3 * i + 2];
+    if (dx * dx + dy * dy + dz * dz > max_dist2) moved[0] = 1;
+  }
+  if (i == 0 && total != nullptr) has_in[128 * 128 + 1] = (total[1] != 0 || total[0] > capacity) ? 1 : 0;
+}
+
+
 }  // namespace
 
 extern "C" int hermnet_relation_counts(const long* atomic_number, int num_atoms, const int* z_list, int num_rel,
@@ -560,5 +585,20 @@ extern "C" int hermnet_build_triadic(const long* atomic_number, const long* edge
   if (Nt > 0)
     hipLaunchKernelGGL(tri_rows_kernel, grid_for(Nt), dim3(kBlock), 0, s, m, (int)Nt, elem_counts, out->csr_rowptr, rel_active,
                        tgt_row_real, out->row_active, res_row);
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}
+
+extern "C" int hermnet_shard_step_flags(const long* edge_index, long columns, const long* atomic_number, int num_atoms,
+                                        const long* total, long capacity, int* has_in, const float* pos, const float* pos_ref,
+                                        long num_pos, float max_dist2, int* moved, void* stream) {
+  if (columns < 0 || num_atoms < 0 || num_pos < 0 || !has_in || (columns > 0 && (!edge_index || !atomic_number)) ||
+      (num_pos > 0 && (!pos || !pos_ref || !moved)))
+    return HN_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(has_in, 0, (128 * 128 + 2) * sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
+  if (moved && hipMemsetAsync(moved, 0, sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
+  const long n = columns > num_pos ? columns : num_pos;
+  hipLaunchKernelGGL(shard_flags_kernel, grid_for(n > 0 ? n : 1), dim3(kBlock), 0, s, edge_index, columns, atomic_number, num_atoms,
+                     total, capacity, has_in, pos, pos_ref, num_pos, max_dist2, moved);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }

@@ -815,7 +815,7 @@ def partition_blocks(pos, atomic_number, cell, rc, rank, world, grid=None, group
     return slab_data(plan, pos, reference_compat), plan
 
 
-def slab_data(plan, pos, reference_compat=False, capacity=None):
+def slab_data(plan, pos, reference_compat=False, capacity=None, want_moved=False):
     """This rank's `Data` for the current coordinates under a plan that is still valid (`plan_moved` says whether it
     is): the cutoff pairs among the local atoms whose TARGET is owned, listed directly by the neighbour search
     (`target_mask`; nothing of the other pairs is built or filtered afterwards).  Halo rows of `pos` hold the atoms'
@@ -823,7 +823,8 @@ def slab_data(plan, pos, reference_compat=False, capacity=None):
     halo rows' force contributions back to the owners (`HaloGradReturn`).  One host read (the edge count of the
     search) -- or none: with `capacity` (periodic cells on the GPU) the list is padded to that many columns with NULL edges
     (`neighbor.neighbor_search_padded`), `local._hn_edge_count` holds (E, flags) on the device, and the caller checks
-    them when it copies the step's results to the host anyway (`SlabStepper.check`)."""
+    them when it copies the step's results to the host anyway (`SlabStepper.check`).  `want_moved`: `local._hn_moved` =
+    `plan_moved(plan, pos)` (on the GPU from the same launch as the relation flags)."""
     from .neighbor import neighbor_search, neighbor_search_padded
     dev = pos.device
     pos_l = pos.detach().index_select(0, plan.local_global)
@@ -855,12 +856,31 @@ def slab_data(plan, pos, reference_compat=False, capacity=None):
     # (the NULL edges of a padded list -- endpoints -1 -- raise the spare slot behind the table)
     # (slot 128 * 128: where the NULL edges of a padded list -- endpoints -1 -- land; slot 128 * 128 + 1: "this rank's padded
     # list is incomplete", so that the SAME reduction tells every rank whether the step has to be repeated anywhere)
-    has_in = torch.zeros(128 * 128 + 2, dtype=torch.int32, device=dev)
-    if ei.size(1) > 0:
-        zt, zs = z[ei[1].clamp(min=0)].clamp(max=127), z[ei[0].clamp(min=0)].clamp(max=127)
-        has_in.index_fill_(0, torch.where(ei[1] >= 0, zt * 128 + zs, torch.full_like(zt, 128 * 128)), 1)
-    if total is not None:
-        has_in[128 * 128 + 1:] = ((total[1:] != 0) | (total[:1] > int(capacity))).to(torch.int32)
+    moved = None
+    if (pos_l.is_cuda and z.dtype == torch.long and ei.dtype == torch.long and ei.is_contiguous() and z.is_contiguous()
+            and pos.dtype == torch.float32 and plan.pos_ref.dtype == torch.float32):
+        # ONE launch (csrc/relation_kernels.hip: hermnet_shard_step_flags) for what is sixteen small ones below
+        from . import _lib
+        P = _lib.ptr
+        has_in = torch.empty(128 * 128 + 2, dtype=torch.int32, device=dev)
+        ask = bool(want_moved) and plan.pos_ref.shape == pos.shape
+        if ask:
+            moved = torch.empty((), dtype=torch.int32, device=dev)
+            cur, ref = pos.detach().contiguous(), plan.pos_ref.contiguous()
+        _lib.check(_lib.load().hermnet_shard_step_flags(
+            P(ei), int(ei.size(1)), P(z), int(z.numel()), None if total is None else P(total),
+            0 if capacity is None else int(capacity), P(has_in), P(cur) if ask else None, P(ref) if ask else None,
+            int(pos.size(0)) if ask else 0, float((0.5 * plan.skin) ** 2), P(moved) if ask else None,
+            torch.cuda.current_stream(dev).cuda_stream), "hermnet_shard_step_flags")
+    else:
+        has_in = torch.zeros(128 * 128 + 2, dtype=torch.int32, device=dev)
+        if ei.size(1) > 0:
+            zt, zs = z[ei[1].clamp(min=0)].clamp(max=127), z[ei[0].clamp(min=0)].clamp(max=127)
+            has_in.index_fill_(0, torch.where(ei[1] >= 0, zt * 128 + zs, torch.full_like(zt, 128 * 128)), 1)
+        if total is not None:
+            has_in[128 * 128 + 1:] = ((total[1:] != 0) | (total[:1] > int(capacity))).to(torch.int32)
+    if want_moved and moved is None:
+        moved = plan_moved(plan, pos)
     if plan.world > 1 and dist.is_available() and dist.is_initialized():
         if _host_staged(plan.group, has_in):
             h = has_in.cpu()
@@ -869,6 +889,7 @@ def slab_data(plan, pos, reference_compat=False, capacity=None):
         else:
             dist.all_reduce(has_in, op=dist.ReduceOp.MAX, group=plan.group)
     local._hn_list_bad = has_in[128 * 128 + 1]               # 0-d, on the device, the same on every rank
+    local._hn_moved = moved
     has_in = has_in[:128 * 128]
     plan.has_in_pairs = has_in
     plan.has_in_edges = has_in.view(128, 128).amax(dim=1)
@@ -1019,8 +1040,8 @@ class SlabStepper(object):
                     self._replan(pos)
                 return self._exact(pos)
             # optimistic: the plan as it is, the list padded; both flags stay on the device until `check`
-            local = slab_data(self.plan, pos, self.reference_compat, capacity=self._capacity)
-            self._pending = (plan_moved(self.plan, pos), local.get("_hn_edge_count"), local._hn_list_bad)
+            local = slab_data(self.plan, pos, self.reference_compat, capacity=self._capacity, want_moved=True)
+            self._pending = (local._hn_moved, local.get("_hn_edge_count"), local._hn_list_bad)
             return local, self.plan
         # one 0-d read-back decides (the search's own host read follows anyway): on a re-plan step the search and the
         # relation-flag reduction then run ONCE, on the new plan

@@ -138,6 +138,8 @@ def _dev():
 @pytest.mark.parametrize("name,elems,kw", [
     ("alloy108", ["Al", "Ni", "Cu"], KW),
     ("alloy108", ["Al", "Ni", "Cu"], dict(rc=5.0, num_layers=3, hidden_channels=128, num_rbf=128)),
+    # a basis wider than one LDS tile: virtual target rows through the two tap-row windows of both message kernels
+    ("alloy108", ["Al", "Ni", "Cu"], dict(rc=5.0, num_layers=2, hidden_channels=128, num_rbf=200)),
     ("alloy108_unknown_type", ["Al", "Ni"], KW),
     ("mol16", ["H", "C", "O"], KW),
     ("mol16_intensive", ["H", "C", "O"], dict(KW, intensive=True)),

@@ -301,6 +301,46 @@ def test_sharded_step_takes_no_host_synchronisation():
         assert rel_err(torch.from_numpy(forces), torch.from_numpy(f_ref)) < 1e-5, it
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["padded", "padded_overfull", "padded_flagged", "exact", "empty"])
+def test_shard_step_flags_kernel_is_the_torch_expression(case):
+    """`hermnet_shard_step_flags` (ONE launch) against the sixteen small torch launches it replaces in `slab_data` /
+    `plan_moved`: relation flags per (target element, source element) with elements clamped to 127, the NULL-edge slot, the
+    incomplete-list flag, the displacement flag just below and just above skin / 2."""
+    from hermnet_amd import _lib
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    n, cols = 700, 0 if case == "empty" else 5000
+    z = torch.randint(0, 140, (n,), generator=g).to(dev)
+    ei = torch.randint(0, n, (2, cols), generator=g)
+    if case.startswith("padded"):
+        ei[:, 4000:] = -1
+    ei = ei.to(dev)
+    capacity = 5000
+    total = {"padded": [4000, 0], "padded_overfull": [5001, 0], "padded_flagged": [4000, 2]}.get(case)
+    total = None if total is None else torch.tensor(total, dtype=torch.long, device=dev)
+    ref = torch.zeros(128 * 128 + 2, dtype=torch.int32, device=dev)
+    if cols:
+        zt, zs = z[ei[1].clamp(min=0)].clamp(max=127), z[ei[0].clamp(min=0)].clamp(max=127)
+        ref.index_fill_(0, torch.where(ei[1] >= 0, zt * 128 + zs, torch.full_like(zt, 128 * 128)), 1)
+    if total is not None:
+        ref[128 * 128 + 1:] = ((total[1:] != 0) | (total[:1] > capacity)).to(torch.int32)
+    pos_ref = torch.randn(900, 3, generator=g).to(dev)
+    for shift, expect in [(0.499, 0), (0.501, 1)]:
+        pos = pos_ref.clone()
+        pos[123, 1] += shift
+        has_in = torch.full((128 * 128 + 2,), 7, dtype=torch.int32, device=dev)
+        moved = torch.full((), 7, dtype=torch.int32, device=dev)
+        P = _lib.ptr
+        _lib.check(_lib.load().hermnet_shard_step_flags(P(ei), cols, P(z), n, None if total is None else P(total), capacity,
+                                                        P(has_in), P(pos), P(pos_ref), 900, 0.25, P(moved),
+                                                        torch.cuda.current_stream().cuda_stream), "hermnet_shard_step_flags")
+        assert torch.equal(has_in, ref)
+        assert int(moved) == expect
+        assert int(ref[128 * 128]) == (1 if case.startswith("padded") else 0)
+        assert int(ref[128 * 128 + 1]) == (1 if case in ("padded_overfull", "padded_flagged") else 0)
+
+
 # ---------------------------------------------------------------------------------------------
 # Slab-local planning (`partition_slab`): geometry only, neighbour search over owned + halo atoms.
 # ---------------------------------------------------------------------------------------------

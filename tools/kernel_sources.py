@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Every device kernel / memcpy of one energy+forces step in launch order with the host op that issued it:
-    python tools/kernel_sources.py [htnet]"""
+    python tools/kernel_sources.py [htnet | shard]      (shard: the atom-sharded step on ONE rank over RCCL)"""
 import os
 import sys
 
@@ -18,10 +18,28 @@ model.load_state_dict(synth.synth_state_dict(model.state_dict(), 10))
 model = model.to(dev)
 for p in model.parameters():
     p.requires_grad_(False)
-data = synth.fcc_alloy(reps=(10, 10, 25), seed=0, device=dev)
+stepper = None
+if len(sys.argv) > 1 and sys.argv[1] == "shard":
+    import numpy as np
+    import torch.distributed as dist
+    from hermnet_amd.sharding import SlabStepper
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29543")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    pos, cell, z = synth.fcc_alloy_atoms(reps=(10, 10, 25), seed=0)
+    stepper = SlabStepper(torch.from_numpy(z).to(dev), torch.from_numpy(cell.astype(np.float32)).to(dev), 5.0, 0, 1, skin=1.0,
+                          group=dist.group.WORLD, deferred=True)
+    gpos = torch.from_numpy(pos.astype(np.float32)).to(dev)
+    data, _plan = stepper(gpos)
+else:
+    data = synth.fcc_alloy(reps=(10, 10, 25), seed=0, device=dev)
 
 
 def step():
+    global data
+    if stepper is not None:          # as bench.py's sharded step: planning under the skin + neighbour list, every step
+        data, _p = stepper(gpos)
     data.pos.requires_grad_(True)
     e = model(data)
     return e, -torch.autograd.grad(e.sum(), data.pos)[0]
