@@ -89,8 +89,9 @@ class GraphedMDStep(object):
         ok, n_edges = step.check()  # a host read -- do it when e / f are copied to the host anyway; not ok: the list
                                     # outgrew the capacity (or left the cell by > 8 images): `step.recapture(pos)`"""
 
-    def __init__(self, model, atomic_number, cell, pos, capacity=None, warmup=3):
+    def __init__(self, model, atomic_number, cell, pos, capacity=None, warmup=3, reference_compat=False):
         from .neighbor import neighbor_search, padded_capacity
+        self.reference_compat = bool(reference_compat)      # edge conventions of the reference's own pipeline (neighbor.py)
         if not pos.is_cuda or cell is None:
             raise RuntimeError("GraphedMDStep needs GPU tensors and a periodic cell")
         if model.training:
@@ -100,13 +101,15 @@ class GraphedMDStep(object):
         self.pos = pos.detach().clone().float().requires_grad_(True)      # static input
         self._warmup = warmup
         if capacity is None:
-            capacity = padded_capacity(int(neighbor_search(self.pos.detach(), model.rc, cell)[0].size(1)))
+            capacity = padded_capacity(int(neighbor_search(self.pos.detach(), model.rc, cell,
+                                                           reference_compat=self.reference_compat)[0].size(1)))
         self._capture(int(capacity))
 
     def _eager(self):
         from .data import Data
         from .neighbor import neighbor_search_padded
-        ei, sh, total = neighbor_search_padded(self.pos.detach(), self.model.rc, self.cell, self.capacity)
+        ei, sh, total = neighbor_search_padded(self.pos.detach(), self.model.rc, self.cell, self.capacity,
+                                               reference_compat=self.reference_compat)
         d = Data(pos=self.pos, atomic_number=self.z, batch=self.batch, cell=self.cell.reshape(1, 3, 3), edge_index=ei,
                  edge_shift=sh)
         d._hn_edge_count = total
@@ -114,8 +117,14 @@ class GraphedMDStep(object):
         f = -torch.autograd.grad(e.sum(), self.pos)[0]
         return e.detach(), f, total
 
+    def stale(self):
+        """True once the model's derived weight copies were dropped after the capture (`load_state_dict`, `.to()`,
+        `train()` / `eval()`, `invalidate_caches()`): the captured launches read the OLD copies -- capture again."""
+        return self.model.__dict__.get("_cache_epoch", 0) != self._epoch
+
     def _capture(self, capacity):
         self.capacity = capacity
+        self._epoch = self.model.__dict__.get("_cache_epoch", 0)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -126,14 +135,35 @@ class GraphedMDStep(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.energy, self.forces, self.total = self._eager()
+            # everything a caller copies to the host per step, as ONE array (`fetch`): energies | (edges, flags) | forces
+            self.packed = torch.cat([self.energy.double().reshape(-1), self.total.double(), self.forces.double().reshape(-1)])
+        self._host = None
         torch.cuda.synchronize()
 
     def __call__(self, pos=None):
+        """`pos` [N,3]: a device tensor, or a float32 host tensor (uploaded straight into the captured input)."""
         if pos is not None:
             with torch.no_grad():
                 self.pos.copy_(pos)
         self.graph.replay()
         return self.energy, self.forces
+
+    def fetch(self):
+        """The last call's results on the host through ONE device-to-host copy and one synchronisation (separate reads of
+        the energy, the forces and the list's counters cost a round trip each -- as much as the whole replay of a small
+        cell): (energy [graphs] float32 array, forces [N,3] float32 array, list complete?, edges found)."""
+        import numpy as np
+        from .neighbor import _stash_overflowed
+        if self._host is None:
+            self._host = torch.empty(self.packed.shape, dtype=torch.float64).pin_memory()
+        self._host.copy_(self.packed, non_blocking=True)
+        torch.cuda.current_stream(self.packed.device).synchronize()
+        h = self._host.numpy()
+        ng = self.energy.numel()
+        n_edges, flags = int(h[ng]), int(h[ng + 1])
+        if flags & 2:
+            _stash_overflowed(self.packed.device)        # (the repeat gets a larger stash slot per atom)
+        return h[:ng].astype(np.float32), h[ng + 2:].astype(np.float32).reshape(-1, 3), flags == 0, n_edges
 
     def check(self):
         """(list complete?, edges found) of the last call: one host read."""

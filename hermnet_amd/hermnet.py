@@ -179,6 +179,7 @@ class HVNet(nn.Module):
         `eval()` transitions; call it after writing parameters through `.data` (a write the caches' keys cannot see --
         the device-side guard would otherwise answer the next step with NaN and repair on the one after)."""
         from . import layer as _layer
+        self.__dict__["_cache_epoch"] = self.__dict__.get("_cache_epoch", 0) + 1    # (captured steps compare it: graph.py)
         for conv in self.hermconvs:
             if getattr(conv, "_weights", None) is not None:
                 conv._weights.key = None

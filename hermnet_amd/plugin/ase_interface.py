@@ -99,7 +99,8 @@ def _evaluate(model, data, device, pbc, want_virial, trn_mean=0.0):
     periodic = bool(pbc) and data.get('cell') is not None
     if want_virial and periodic:
         data.cell.requires_grad = True
-    model.eval()
+    if model.training:      # (not unconditionally: `eval()` walks every submodule -- 0.85 ms per call for a 5-layer model)
+        model.eval()
     energy = model(data) + trn_mean
     forces = -torch.autograd.grad(energy.sum(), data.pos, retain_graph=want_virial and periodic)[0]
     w = None
@@ -142,9 +143,20 @@ class NNCalculator(_Base):
     """`calculator.py:30-57`.  `model_path=None` keeps the weights already in `model`."""
     implemented_properties = ['energy', 'free_energy', 'forces', 'stress']
 
-    def __init__(self, model, model_path, trn_mean, device_='cuda', ensemble='NVT', reference_compat=False):
+    def __init__(self, model, model_path, trn_mean, device_='cuda', ensemble='NVT', reference_compat=False,
+                 graph_replay=False):
+        """`graph_replay=True` (GPU, periodic cell, forces without stress): neighbour search + relation build + forward +
+        force backward are captured ONCE as a hipGraph and replayed every call (`graph.GraphedMDStep`; the same kernels, no
+        per-launch host work: 2-3x on cells of a few hundred atoms, where the eager step is bound by launch overhead).
+        The capture is renewed by itself when the species, the cell, the atom count or the model's weights
+        (`load_state_dict`, `.to()`, `invalidate_caches()`) change or the list outgrows its capacity; weights written
+        through `.data` need `model.invalidate_caches()` as everywhere else.  Calls that need the stress, open systems and
+        CPU runs take the eager path."""
         super(NNCalculator, self).__init__()
         self.reference_compat = reference_compat     # see `build_graph`
+        self.graph_replay = bool(graph_replay)
+        self._graphed = None              # ((z tensor, cell tensor, N), GraphedMDStep)
+        self.graph_captures = 0           # how often a step was captured (diagnostics / tests)
         self.device_ = device_
         device = torch.device(device_)
         self.model = model.to(device)
@@ -156,12 +168,50 @@ class NNCalculator(_Base):
         self.ensemble = ensemble
         self._edge_capacity = None        # columns of the padded neighbour list of the next call (None: exact search)
 
+    def _replayed(self, cell, elems, positions):
+        """(energy tensor, forces tensor) from the captured step, or None when this call has to run eagerly."""
+        from ..graph import GraphedMDStep
+        dev = torch.device(self.device_)
+        z, _batch = _species_tensors(elems, dev)
+        cell_t = _cell_tensor(cell, dev)
+        pos_t = torch.from_numpy(np.ascontiguousarray(positions, dtype=np.float32))     # host: copied into the captured input
+        g = self._graphed
+        if (g is None or g[0][0] is not z or g[0][1] is not cell_t or g[0][2] != pos_t.size(0) or g[1].stale()
+                or g[1].model is not self.model):
+            if self.model.training:
+                self.model.eval()
+            step = GraphedMDStep(self.model, z, cell_t, pos_t.to(dev), reference_compat=self.reference_compat)
+            self._graphed = g = ((z, cell_t, pos_t.size(0)), step)
+            self.graph_captures += 1
+        g[1](pos_t)
+        e, f, ok, _n = g[1].fetch()            # ONE device-to-host copy: energy, forces and the list's counters
+        if not ok:                             # the list outgrew its columns: a larger capture, this step again
+            g[1].recapture(pos_t)
+            self.graph_captures += 1
+            e, f, ok, _n = g[1].fetch()
+            if not ok:                         # (coordinates many images outside the cell ...): the eager path decides
+                self._graphed = None
+                return None
+        return float(np.float32(e[0]) + np.float32(self.trn_mean)), f
+
     def calculate(self, atoms, properties=('energy',), system_changes=all_changes):
         super(NNCalculator, self).calculate(atoms, properties, system_changes)
         pbc = bool(np.any(atoms.pbc))
         cell = np.asarray(atoms.cell if not hasattr(atoms, "todict") else atoms.todict()['cell']) if pbc else None
-        elems = np.array([atomic_numbers[s] for s in atoms.get_chemical_symbols()])
+        # (`atoms.numbers` is what ASE keeps; the symbols -- `calculator.py:46` -- cost a dictionary lookup per atom and call)
+        numbers = getattr(atoms, "numbers", None)
+        elems = (np.asarray(numbers) if numbers is not None
+                 else np.array([atomic_numbers[s] for s in atoms.get_chemical_symbols()]))
         dev = self.device_ if torch.device(self.device_).type == 'cuda' else None
+        if (self.graph_replay and dev is not None and pbc and cell is not None and np.any(cell)
+                and self.ensemble.lower() != 'npt' and 'stress' not in tuple(properties)):
+            out = self._replayed(cell, elems, atoms.positions)
+            if out is not None:
+                self.results['energy'] = out[0]
+                self.results['free_energy'] = out[0]
+                self.results['forces'] = out[1]
+                self.results.pop('stress', None)      # (not computed: see the end of this method)
+                return
         # periodic cells on the GPU: from the second call on the neighbour list is built without its host read, padded to a
         # capacity taken from the last edge count; count and flags are checked behind the step, where the results are
         # copied to the host anyway (an overflow repeats the step on an exact list)

@@ -1792,6 +1792,60 @@ def test_calculator_builds_its_lists_without_a_host_read_after_the_first_call():
         pos = pos + rs.normal(scale=0.03, size=pos.shape)
 
 
+def test_calculator_replays_a_captured_step_and_renews_the_capture_when_it_must():
+    """`NNCalculator(graph_replay=True)`: the calls of a trajectory replay ONE captured hipGraph (search + relation build +
+    forward + force backward); results equal the eager calculator's on the same coordinates (same kernels, same order:
+    bit for bit).  The capture is renewed when the weights are reloaded (the derived copies a capture points at are gone)
+    and when the list outgrows its columns; a call that needs the stress takes the eager path and leaves the capture
+    alone; other species capture again."""
+    from hermnet_amd.plugin import NNCalculator
+    _dev()
+    g = Golden("alloy108")
+    d = g.data()
+    z, cell = d.atomic_number.numpy(), d.cell[0].numpy().astype("float64")
+    rs = np.random.RandomState(2)
+    calc = NNCalculator(g.model(), None, trn_mean=0.25, device_="cuda:0", graph_replay=True)
+    ref = NNCalculator(g.model(), None, trn_mean=0.25, device_="cuda:0")
+    pos = d.pos.numpy().astype("float64")
+
+    def both(pos, z=z, props=("energy", "forces")):
+        calc.calculate(_FakeAtoms(pos, z, cell), list(props))
+        ref._edge_capacity = None
+        ref.calculate(_FakeAtoms(pos, z, cell), list(props))
+        assert calc.results["energy"] == ref.results["energy"]
+        assert np.array_equal(calc.results["forces"], ref.results["forces"])
+
+    for it in range(4):
+        both(pos)
+        assert "stress" not in calc.results
+        pos = pos + rs.normal(scale=0.03, size=pos.shape)
+    assert calc.graph_captures == 1
+    both(pos, props=("energy", "forces", "stress"))                 # eager, with the stress
+    assert np.allclose(calc.results["stress"], ref.results["stress"]) and calc.graph_captures == 1
+    sd = {k: v.clone() for k, v in calc.model.state_dict().items()}
+    sd["out_energy.2.bias"] = sd["out_energy.2.bias"] + 1.0         # new weights: every atom's energy + 1
+    e_before = calc.results["energy"]
+    calc.model.load_state_dict(sd)
+    ref.model.load_state_dict(sd)
+    both(pos)
+    assert calc.graph_captures == 2 and abs(calc.results["energy"] - e_before - len(z)) < 1e-2
+    z2 = z.copy()
+    z2[:5] = z2[5:10]                                                # other species: another capture
+    both(pos, z=z2)
+    assert calc.graph_captures == 3
+    # a list that outgrows the captured capacity: squeeze the cell's atoms together -> more pairs than columns
+    small = NNCalculator(g.model(), None, trn_mean=0.0, device_="cuda:0", graph_replay=True)
+    small.calculate(_FakeAtoms(pos, z, cell), ["energy", "forces"])
+    step = small._graphed[1]
+    step.recapture(capacity=1024)                                    # far too few columns for this cell
+    small.graph_captures = 1
+    small.calculate(_FakeAtoms(pos, z, cell), ["energy", "forces"])
+    ref = NNCalculator(g.model(), None, trn_mean=0.0, device_="cuda:0")
+    ref.calculate(_FakeAtoms(pos, z, cell), ["energy", "forces"])
+    assert small.graph_captures == 2 and small._graphed[1].capacity > 1024
+    assert small.results["energy"] == ref.results["energy"] and np.array_equal(small.results["forces"], ref.results["forces"])
+
+
 def test_edge_cases_empty_and_degenerate_graphs():
     """Ragged / empty inputs: no edges at all, a single atom, only atoms of unlisted elements, an
     isolated atom next to a bonded cluster, a listed element without atoms (the reference crashes
