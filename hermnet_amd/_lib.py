@@ -129,7 +129,7 @@ SIGNATURES = {
     "hermnet_stream_copy": (ctypes.c_int, [c_fp, c_fp, ctypes.c_size_t, ctypes.c_int, c_fp]),
     "hermnet_param_guard": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),
     "hermnet_shard_step_flags": (ctypes.c_int, [c_fp, ctypes.c_long, c_fp, ctypes.c_int, c_fp, ctypes.c_long, c_fp, c_fp, c_fp,
-                                                ctypes.c_long, ctypes.c_float, c_fp, c_fp]),
+                                                ctypes.c_long, ctypes.c_float, c_fp]),
     "hermnet_host_rbf_row": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                             ctypes.c_int, c_fp, c_fp, ctypes.c_int, ctypes.c_float, c_fp, c_fp]),
 }

@@ -1,5 +1,6 @@
 // gfx950: the PaiNNUpdate chain (node_update_fwd / node_update_bwd of node_chain.hip; rmnet.py:94-107, 29-31) on 16-ROW
-// tiles with v_mfma_f32_16x16x4_f32 -- for grids that 32-row tiles quantise badly.
+// tiles -- for grids that 32-row tiles quantise badly.  (Written for v_mfma_f32_16x16x4_f32; since the second half of round 5
+// the products run as three-way bf16 splits on v_mfma_f32_16x16x32_bf16 at fp32 accuracy: see mma16_panel.)
 //
 // Why: BASELINE configs[1] has 10,041 target rows = 314 tiles of 32 rows on 256 CUs: 58 CUs get two workgroups, 198 get
 // one, the launch lasts as long as the CUs with two (a makespan of 64 rows against 39 rows per CU on average: 0.61).  In
@@ -76,36 +77,81 @@ __device__ __forceinline__ void b16_preload(Ring16<NB>& r, const f32x4* const (&
     for (int j = 0; j < NB; ++j) r.v[g][j] = wfrag(bp[j], g * 64);
 }
 
-// acc[j] += W_j[k-groups 0 .. KP/16) . A^T; `As`: this lane's LDS read pointer &tile[(l & 15) * LD + 4 (l >> 4)].
-// The ring holds groups 0 .. RS-2 on entry; MORE: the stream continues behind the panel (its first RS-1 groups are
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5 (second half): the products run on the BF16 matrix pipe at fp32 accuracy.  v_mfma_f32_16x16x4_f32 delivers 64
+// FLOP/clk/SIMD, v_mfma_f32_16x16x32_bf16 1024: an fp32 value split THREE ways into bf16 planes (x = x0 + x1 + x2 exactly: 3 x 8
+// significant bits) and the six largest of the nine partial products -- w2 x0, w1 x1, w1 x0, w0 x2, w0 x1, w0 x0, accumulated in
+// fp32 by the MFMA; the three dropped ones are <= 2^-24 of the product each -- cost 6 / 16 of the fp32 instruction's pipe time
+// (the "BF16x6 / BF16x9" emulation of fp32 GEMMs).  Weights are split once on the host (nodeops.weight_fragments16: three
+// planes, 6 bytes per weight instead of 4); activations stay fp32 in LDS and are split by the consuming wave in registers
+// (~37 VALU instructions per eight values, shared by the wave's NB blocks, issued between the MFMAs of the previous k-group).
+// Measured before it was built, with the instruction mix alone (a diagnostic build, results wrong, time meaningful:
+// profiles/r05_split_timing.log): update_fwd 55 -> 32 us, pre_fwd16 64 -> 30, fused forward 98 -> 61.
+//
+// Stream: a block's fragments are consumed as STEPS of one 1-KiB load each (lane l: 16 bytes = 8 bf16 of one weight plane,
+// W_p[16 b + (l & 15)][32 Q + 8 (l >> 4) .. +7]), in the order [k-group Q of 32][plane 2, 1, 0]: three steps per 32 k where
+// the fp32 form took two 16-deep groups -- 1.5 x the requests and bytes.  frag16(W)[((b * K/32 + Q) * 3 + s) * 64 + l].
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 hn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hn_f32x2 __attribute__((ext_vector_type(2)));
+struct Split8 { hn_bf16x8 p[3]; };          // p[0] + p[1] + p[2] == the eight fp32 values (exactly, barring under/overflow)
+
+__device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, Split8& o) {
+  float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const hn_f32x2 v = {x[e], x[e + 1]};
+      const hn_bf16x2 h = __builtin_convertvector(v, hn_bf16x2);          // v_cvt_pk_bf16_f32: round to nearest even
+      o.p[p][e] = h[0]; o.p[p][e + 1] = h[1];
+      if (p < 2) {
+        const hn_f32x2 back = __builtin_convertvector(h, hn_f32x2);
+        x[e] -= back[0]; x[e + 1] -= back[1];                             // exact: the residual fits fp32
+      }
+    }
+  }
+}
+
+// float4s of one 16-channel block's fragment stream over K inputs (3 K / 32 steps of 64 lanes), floats of an [O, K] weight
+constexpr int frag16_f4(int K) { return K * 6; }
+constexpr size_t frag16_floats(size_t O, size_t K) { return O * K * 3 / 2; }
+
+// acc[j] += W_j[:, 0 .. KP) . A^T; `As`: this lane's LDS pointer &tile[(l & 15) * LD + 4 (l >> 4)] (the tile is fp32).
+// The ring holds steps 0 .. RS-2 on entry; MORE: the stream continues behind the panel (its first RS-1 steps are
 // requested and sit in slots 0 .. RS-2 on exit).
 template <int KP, int NB, bool MORE>
 __device__ __forceinline__ void mma16_panel(f32x4 (&acc)[NB], const float* As, const f32x4* const (&bp)[NB], Ring16<NB>& ring) {
-  constexpr int NQ = KP / 16, RS = ring16(NB), PF = RS - 1;
-  static_assert(NQ % RS == 0, "panel / ring mismatch");
-  f32x4 a[2];
-  a[0] = *reinterpret_cast<const f32x4*>(As);
-  auto group = [&](int q0, int qq, bool load_b, bool load_a) {
-    const int q = q0 + qq;
-    if (load_b) {
+  constexpr int GT = KP / 32, NSTEP = 3 * GT, RS = ring16(NB), PF = RS - 1;
+  static_assert(KP % 32 == 0 && (!MORE || NSTEP % RS == 0), "panel / ring mismatch");
+  const float* A8 = As + 4 * ((threadIdx.x & 63) >> 4);          // &tile[(l & 15) * LD + 8 (l >> 4)]
+  f32x4 lo = *reinterpret_cast<const f32x4*>(A8), hi = *reinterpret_cast<const f32x4*>(A8 + 4);
+  Split8 X[2];
+  split8(lo, hi, X[0]);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) ring.v[(qq + PF) % RS][j] = wfrag(bp[j], (q + PF) * 64);
+  for (int Q = 0; Q < GT; ++Q) {
+    const Split8& x = X[Q & 1];
+    if (Q + 1 < GT) {
+      lo = *reinterpret_cast<const f32x4*>(A8 + 32 * (Q + 1));
+      hi = *reinterpret_cast<const f32x4*>(A8 + 32 * (Q + 1) + 4);
     }
-    if (load_a) a[(qq + 1) & 1] = *reinterpret_cast<const f32x4*>(As + 16 * (q + 1));
-    if (HN_PIN_LOADS) fence_sched();       // (the requests stay in front of the group's MFMAs: node_chain_common.h)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int ps = 0; ps < 3; ++ps) {                 // the step of weight plane 2 - ps
+      const int n = 3 * Q + ps;
+      if (MORE || n + PF < NSTEP) {
 #pragma unroll
-      for (int j = 0; j < NB; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring.v[qq % RS][j][i], a[qq & 1][i], acc[j], 0, 0, 0);
-  };
-#pragma unroll 1
-  for (int q0 = 0; q0 < NQ - RS; q0 += RS) {
+        for (int j = 0; j < NB; ++j) ring.v[(n + PF) % RS][j] = wfrag(bp[j], (n + PF) * 64);
+      }
+      if (HN_PIN_LOADS) fence_sched();               // (the requests stay in front of the step's MFMAs: node_chain_common.h)
 #pragma unroll
-    for (int qq = 0; qq < RS; ++qq) group(q0, qq, true, true);
+      for (int m = ps; m >= 0; --m)                  // activation planes ps .. 0: the smaller partial products first
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hn_bf16x8, ring.v[n % RS][j]), x.p[m], acc[j], 0, 0, 0);
+      if (ps == 1 && Q + 1 < GT) split8(lo, hi, X[(Q + 1) & 1]);   // (VALU work beside the matrix pipe's)
+    }
   }
-#pragma unroll
-  for (int qq = 0; qq < RS; ++qq) group(NQ - RS, qq, MORE || qq + PF < RS, qq + 1 < RS);
 }
 
 // Coalesced store / load of this wave's [16 rows][32 channels] block pair through the wave-private scratch: lane l owns
@@ -222,9 +268,9 @@ __device__ __forceinline__ void pre_fwd16_phase(const PreFwdArgs& p, float* bufN
   f32x4 acc1[2];
   // the first product's operands of relation t: requested in front of whatever stores precede the product (vmcnt is in order)
   auto request1 = [&](int t) {
-    const f32x4* w1 = reinterpret_cast<const f32x4*>(p.w1f + (size_t)t * H * H) + lane;
+    const f32x4* w1 = reinterpret_cast<const f32x4*>(p.w1f + (size_t)t * frag16_floats(H, H)) + lane;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) bp1[s] = w1 + (size_t)(2 * wave + s) * (H / 16) * 64;
+    for (int s = 0; s < 2; ++s) bp1[s] = w1 + (size_t)(2 * wave + s) * frag16_f4(H);
     b16_preload(r1, bp1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) acc1[s] = ld4g(p.b1 + (size_t)t * H + cw + 16 * s + ch);
@@ -241,12 +287,12 @@ __device__ __forceinline__ void pre_fwd16_phase(const PreFwdArgs& p, float* bufN
     const rsrc_t xh_r = tile_rsrc(p.xh + ((size_t)t * p.Ns + row0) * 3 * H, nrows * 3 * H);
     // ---- h = n W1^T + b1
     mma16_panel<H, 2, false>(acc1, An, bp1, r1);
-    const f32x4* w2 = reinterpret_cast<const f32x4*>(p.w2f + (size_t)t * 3 * H * H) + lane;
+    const f32x4* w2 = reinterpret_cast<const f32x4*>(p.w2f + (size_t)t * frag16_floats(3 * H, H)) + lane;
     const f32x4* bp2[6];
 #pragma unroll
     for (int pp = 0; pp < 3; ++pp)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) bp2[2 * pp + s] = w2 + (size_t)(pp * NB16 + 2 * wave + s) * (H / 16) * 64;
+      for (int s = 0; s < 2; ++s) bp2[2 * pp + s] = w2 + (size_t)(pp * NB16 + 2 * wave + s) * frag16_f4(H);
     Ring16<6> r2;
     b16_preload(r2, bp2);
     f32x4 acc2[6];
@@ -321,9 +367,9 @@ __global__ __launch_bounds__(256, HN_U16_MINW_FWD) void node_update_fwd16_kernel
     }
     return;
   }
-  const f32x4* wv = reinterpret_cast<const f32x4*>(a.wvf + (size_t)t * 2 * H * H) + lane;
-  const f32x4* wx0 = reinterpret_cast<const f32x4*>(a.wx0f + (size_t)t * 2 * H * H) + lane;
-  const f32x4* wx2 = reinterpret_cast<const f32x4*>(a.wx2f + (size_t)t * 3 * H * H) + lane;
+  const f32x4* wv = reinterpret_cast<const f32x4*>(a.wvf + (size_t)t * frag16_floats(2 * H, H)) + lane;
+  const f32x4* wx0 = reinterpret_cast<const f32x4*>(a.wx0f + (size_t)t * frag16_floats(H, 2 * H)) + lane;
+  const f32x4* wx2 = reinterpret_cast<const f32x4*>(a.wx2f + (size_t)t * frag16_floats(3 * H, H)) + lane;
   // this wave's blocks of part p: b = p * NB16 + 2 wave + s
   const f32x4* bpv[4];
   const f32x4* bpx[2];
@@ -331,13 +377,13 @@ __global__ __launch_bounds__(256, HN_U16_MINW_FWD) void node_update_fwd16_kernel
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int s = 0; s < 2; ++s) bpv[2 * p + s] = wv + (size_t)(p * NB16 + 2 * wave + s) * (H / 16) * 64;
+    for (int s = 0; s < 2; ++s) bpv[2 * p + s] = wv + (size_t)(p * NB16 + 2 * wave + s) * frag16_f4(H);
 #pragma unroll
-  for (int s = 0; s < 2; ++s) bpx[s] = wx0 + (size_t)(2 * wave + s) * (2 * H / 16) * 64;
+  for (int s = 0; s < 2; ++s) bpx[s] = wx0 + (size_t)(2 * wave + s) * frag16_f4(2 * H);
 #pragma unroll
   for (int p = 0; p < 3; ++p)
 #pragma unroll
-    for (int s = 0; s < 2; ++s) bpq[2 * p + s] = wx2 + (size_t)(p * NB16 + 2 * wave + s) * (H / 16) * 64;
+    for (int s = 0; s < 2; ++s) bpq[2 * p + s] = wx2 + (size_t)(p * NB16 + 2 * wave + s) * frag16_f4(H);
 
   const int mrow = lane & 15, ch = 4 * (lane >> 4), cw = 32 * wave;
   const rsrc_t x1_r = tile_rsrc(a.x1 + (size_t)row0 * H, nrows * H);
@@ -412,7 +458,7 @@ __global__ __launch_bounds__(256, HN_U16_MINW_FWD) void node_update_fwd16_kernel
   STAMP(4);
   // ---- h2 = xin Wx0^T + bx0 (K = 2H: two panels)
   {
-    const f32x4* bpx1[2] = {bpx[0] + (size_t)(H / 16) * 64, bpx[1] + (size_t)(H / 16) * 64};
+    const f32x4* bpx1[2] = {bpx[0] + (size_t)frag16_f4(H), bpx[1] + (size_t)frag16_f4(H)};
     mma16_panel<H, 2, true>(acch, bufx + mrow * LD + ch, bpx, rx);
     mma16_panel<H, 2, false>(acch, bufn + mrow * LD + ch, bpx1, rx);
   }
@@ -522,9 +568,9 @@ __device__ __forceinline__ void pre_bwd16_phase(const float* gxh, const float* h
     issue16<H>(lhb, lane, tile_rsrc(hb + ((size_t)t * Ns + row0) * H, nrows * H), cw);
   };
   auto request_w = [&](int t) {
-    const f32x4* w2t = reinterpret_cast<const f32x4*>(w2tf + (size_t)t * 3 * H * H) + lane;
+    const f32x4* w2t = reinterpret_cast<const f32x4*>(w2tf + (size_t)t * frag16_floats(H, 3 * H)) + lane;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) bpa[s] = w2t + (size_t)(2 * wave + s) * (3 * H / 16) * 64;
+    for (int s = 0; s < 2; ++s) bpa[s] = w2t + (size_t)(2 * wave + s) * frag16_f4(3 * H);
     b16_preload(ra, bpa);
   };
   auto stage = [&]() {
@@ -547,8 +593,8 @@ __device__ __forceinline__ void pre_bwd16_phase(const float* gxh, const float* h
     // ---- ga = gxh[t] W2_t   (K = 3H)
     f32x4 acc[2] = {zero4(), zero4()};
     mma16_panel<3 * H, 2, false>(acc, tileA + mrow * LDA + ch, bpa, ra);
-    const f32x4* w1t = reinterpret_cast<const f32x4*>(w1tf + (size_t)t * H * H) + lane;
-    const f32x4* bpb[2] = {w1t + (size_t)(2 * wave) * (H / 16) * 64, w1t + (size_t)(2 * wave + 1) * (H / 16) * 64};
+    const f32x4* w1t = reinterpret_cast<const f32x4*>(w1tf + (size_t)t * frag16_floats(H, H)) + lane;
+    const f32x4* bpb[2] = {w1t + (size_t)(2 * wave) * frag16_f4(H), w1t + (size_t)(2 * wave + 1) * frag16_f4(H)};
     Ring16<2> rb;
     b16_preload(rb, bpb);
     fence_sched();
@@ -629,21 +675,21 @@ __global__ __launch_bounds__(256, HN_U16_MINW_BWD) void node_update_bwd16_kernel
   } else {
     if (a.pend.gn != nullptr) materialise_pending<H, TR>(a, row0, nrows, tid);   // (incoming gradients still in partial sums)
   }
-  const f32x4* wx2t = reinterpret_cast<const f32x4*>(a.wx2tf + (size_t)t * 3 * H * H) + lane;   // [H, 3H]
-  const f32x4* wx0t = reinterpret_cast<const f32x4*>(a.wx0tf + (size_t)t * 2 * H * H) + lane;   // [2H, H]
-  const f32x4* wvt = reinterpret_cast<const f32x4*>(a.wvtf + (size_t)t * 2 * H * H) + lane;     // [H, 2H]
+  const f32x4* wx2t = reinterpret_cast<const f32x4*>(a.wx2tf + (size_t)t * frag16_floats(H, 3 * H)) + lane;   // [H, 3H]
+  const f32x4* wx0t = reinterpret_cast<const f32x4*>(a.wx0tf + (size_t)t * frag16_floats(2 * H, H)) + lane;   // [2H, H]
+  const f32x4* wvt = reinterpret_cast<const f32x4*>(a.wvtf + (size_t)t * frag16_floats(H, 2 * H)) + lane;     // [H, 2H]
   const f32x4* bpa[2];
   const f32x4* bpx[4];
   const f32x4* bpg[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    bpa[s] = wx2t + (size_t)(2 * wave + s) * (3 * H / 16) * 64;
-    bpg[s] = wvt + (size_t)(2 * wave + s) * (2 * H / 16) * 64;
+    bpa[s] = wx2t + (size_t)(2 * wave + s) * frag16_f4(3 * H);
+    bpg[s] = wvt + (size_t)(2 * wave + s) * frag16_f4(2 * H);
   }
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int s = 0; s < 2; ++s) bpx[2 * p + s] = wx0t + (size_t)(p * NB16 + 2 * wave + s) * (H / 16) * 64;
+    for (int s = 0; s < 2; ++s) bpx[2 * p + s] = wx0t + (size_t)(p * NB16 + 2 * wave + s) * frag16_f4(H);
   Ring16<2> ra;
   b16_preload(ra, bpa);
   const int mrow = lane & 15, ch = 4 * (lane >> 4), cw = 32 * wave;
@@ -689,8 +735,8 @@ __global__ __launch_bounds__(256, HN_U16_MINW_BWD) void node_update_bwd16_kernel
   // ---- ga2 = gq Wx2  (K = 3H: three panels)
   f32x4 acc[2] = {zero4(), zero4()};
   {
-    const f32x4* bp1[2] = {bpa[0] + (size_t)(H / 16) * 64, bpa[1] + (size_t)(H / 16) * 64};
-    const f32x4* bp2[2] = {bpa[0] + (size_t)(2 * H / 16) * 64, bpa[1] + (size_t)(2 * H / 16) * 64};
+    const f32x4* bp1[2] = {bpa[0] + (size_t)frag16_f4(H), bpa[1] + (size_t)frag16_f4(H)};
+    const f32x4* bp2[2] = {bpa[0] + (size_t)frag16_f4(2 * H), bpa[1] + (size_t)frag16_f4(2 * H)};
     mma16_panel<H, 2, true>(acc, buf0 + mrow * LD + ch, bpa, ra);
     __syncthreads();                                 // buffer 0 is free
     tile16_store<H, LD>(buf0, g3, tid);
@@ -772,7 +818,7 @@ __global__ __launch_bounds__(256, HN_U16_MINW_BWD) void node_update_bwd16_kernel
     }
     fence_sched();
     __syncthreads();
-    const f32x4* bpg1[2] = {bpg[0] + (size_t)(H / 16) * 64, bpg[1] + (size_t)(H / 16) * 64};
+    const f32x4* bpg1[2] = {bpg[0] + (size_t)frag16_f4(H), bpg[1] + (size_t)frag16_f4(H)};
     mma16_panel<H, 2, true>(accg, buf0 + mrow * LD + ch, bpg, rg);
     mma16_panel<H, 2, false>(accg, buf1 + mrow * LD + ch, bpg1, rg);
     if (d < 2) b16_preload(rg, bpg);
@@ -813,7 +859,7 @@ __global__ __launch_bounds__(256) void energy_head16_fwd_kernel(HeadArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row0 = blockIdx.x * TR, nrows = min(TR, a.N - row0);
   const int mrow = lane & 15, ch = 4 * (lane >> 4);
-  const f32x4* bp[1] = {reinterpret_cast<const f32x4*>(a.wf) + (size_t)wave * (H / 16) * 64 + lane};
+  const f32x4* bp[1] = {reinterpret_cast<const f32x4*>(a.wf) + (size_t)wave * frag16_f4(H) + lane};
   Ring16<1> ring;
   b16_preload(ring, bp);
   f32x4 acc[1] = {ld4g(a.b0 + 16 * wave + ch)};
@@ -851,7 +897,7 @@ __global__ __launch_bounds__(256) void energy_head16_bwd_kernel(HeadArgs a) {
   const int mrow = lane & 15, ch = 4 * (lane >> 4);
   float* scr = lds + TR * LDC + wave * kScr16Floats;
   const f32x4* w = reinterpret_cast<const f32x4*>(a.wf) + lane;
-  const f32x4* bp[2] = {w + (size_t)(2 * wave) * (C / 16) * 64, w + (size_t)(2 * wave + 1) * (C / 16) * 64};
+  const f32x4* bp[2] = {w + (size_t)(2 * wave) * frag16_f4(C), w + (size_t)(2 * wave + 1) * frag16_f4(C)};
   Ring16<2> ring;
   b16_preload(ring, bp);
   {   // gh = ge mask w2 ScaledSiLU'(h): one float4 per thread

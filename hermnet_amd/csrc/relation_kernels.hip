@@ -389,8 +389,7 @@ int build_rows(const long* atomic_number, int NA, const int* z_list, int T, cons
 __global__ __launch_bounds__(kBlock) void shard_flags_kernel(const long* __restrict__ ei, long columns, const long* __restrict__ z,
                                                              int num_atoms, const long* __restrict__ total, long capacity,
                                                              int* __restrict__ has_in, const float* __restrict__ pos,
-                                                             const float* __restrict__ pos_ref, long num_pos, float max_dist2,
-                                                             int* __restrict__ moved) {
+                                                             const float* __restrict__ pos_ref, long num_pos, float max_dist2) {
   const long i = (long)blockIdx.x * kBlock + threadIdx.x;
   if (i < columns) {
     const long src = ei[i], tgt = ei[columns + i];
@@ -403,7 +402,7 @@ __global__ __launch_bounds__(kBlock) void shard_flags_kernel(const long* __restr
   }
   if (i < num_pos) {
     const float dx = pos[3 * i] - pos_ref[3 * i], dy = pos[3 * i + 1] - pos_ref[3 * i + 1], dz = pos[3 * i + 2] - pos_ref[3 * i + 2];
-    if (dx * dx + dy * dy + dz * dz > max_dist2) moved[0] = 1;
+    if (dx * dx + dy * dy + dz * dz > max_dist2) has_in[128 * 128 + 2] = 1;
   }
   if (i == 0 && total != nullptr) has_in[128 * 128 + 1] = (total[1] != 0 || total[0] > capacity) ? 1 : 0;
 }
@@ -590,15 +589,15 @@ extern "C" int hermnet_build_triadic(const long* atomic_number, const long* edge
 
 extern "C" int hermnet_shard_step_flags(const long* edge_index, long columns, const long* atomic_number, int num_atoms,
                                         const long* total, long capacity, int* has_in, const float* pos, const float* pos_ref,
-                                        long num_pos, float max_dist2, int* moved, void* stream) {
+                                        long num_pos, float max_dist2, void* stream) {
   if (columns < 0 || num_atoms < 0 || num_pos < 0 || !has_in || (columns > 0 && (!edge_index || !atomic_number)) ||
-      (num_pos > 0 && (!pos || !pos_ref || !moved)))
+      (num_pos > 0 && (!pos || !pos_ref)))
     return HN_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(has_in, 0, (128 * 128 + 2) * sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
-  if (moved && hipMemsetAsync(moved, 0, sizeof(int), s) != hipSuccess) return HN_ERR_LAUNCH;
+  // (a kernel, not hipMemsetAsync: captured memset nodes do not survive eager memsets between two replays, see above)
+  hipLaunchKernelGGL(zero_i32_kernel, grid_for(128 * 128 + 3), dim3(kBlock), 0, s, has_in, (long)(128 * 128 + 3));
   const long n = columns > num_pos ? columns : num_pos;
   hipLaunchKernelGGL(shard_flags_kernel, grid_for(n > 0 ? n : 1), dim3(kBlock), 0, s, edge_index, columns, atomic_number, num_atoms,
-                     total, capacity, has_in, pos, pos_ref, num_pos, max_dist2, moved);
+                     total, capacity, has_in, pos, pos_ref, num_pos, max_dist2);
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }

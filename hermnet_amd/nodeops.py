@@ -214,13 +214,23 @@ def weight_fragments(w):
 
 
 def weight_fragments16(w):
-    """The same for the 16-row kernels' v_mfma_f32_16x16x4_f32 operands (include/hermnet_hip.h: frag16(W)):
-    out % 16 == 0, in % 16 == 0."""
+    """The 16-row kernels' weight stream (csrc/node_chain16.hip: mma16_panel; include/hermnet_hip.h: frag16(W)).  Their products
+    run on the bf16 matrix pipe at fp32 accuracy: every weight is split three ways, w = w0 + w1 + w2 exactly (bf16 planes, round
+    to nearest even, each the rounding of what the planes before it leave), and stored in the order the kernels consume it --
+    per 16-row block b of W and 32-deep k-group Q the three planes, smallest first, as v_mfma_f32_16x16x32_bf16 operands:
+        frag16(W)[((b * K/32 + Q) * 3 + s) * 64 + l] = 8 bf16  W_(2-s)[16 b + (l & 15)][32 Q + 8 (l >> 4) .. +7]
+    W [..., out, in], out % 16 == 0, in % 32 == 0 -> float32 [..., out * in * 3 / 2] (6 bytes per weight, opaque)."""
     lead = w.shape[:-2]
     o, k = w.shape[-2:]
-    f = w.reshape(*lead, o // 16, 16, k // 16, 4, 4)
+    w32 = w.float()
+    p0 = w32.to(torch.bfloat16)
+    r1 = w32 - p0.float()
+    p1 = r1.to(torch.bfloat16)
+    p2 = (r1 - p1.float()).to(torch.bfloat16)
     n = len(lead)
-    return f.permute(*range(n), n, n + 2, n + 3, n + 1, n + 4).contiguous().reshape(*lead, o * k)
+    f = torch.stack([p2, p1, p0], dim=n).reshape(*lead, 3, o // 16, 16, k // 32, 4, 8)     # [s, b, m, Q, g, e]
+    f = f.permute(*range(n), n + 1, n + 3, n, n + 4, n + 2, n + 5).contiguous()              # [b, Q, s, g, m, e]
+    return f.reshape(*lead, o * k * 3).view(torch.float32)
 
 
 def update_tile_rows(graph, H):

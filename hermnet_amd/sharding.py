@@ -859,19 +859,21 @@ def slab_data(plan, pos, reference_compat=False, capacity=None, want_moved=False
     moved = None
     if (pos_l.is_cuda and z.dtype == torch.long and ei.dtype == torch.long and ei.is_contiguous() and z.is_contiguous()
             and pos.dtype == torch.float32 and plan.pos_ref.dtype == torch.float32):
-        # ONE launch (csrc/relation_kernels.hip: hermnet_shard_step_flags) for what is sixteen small ones below
+        # clear + mark (csrc/relation_kernels.hip: hermnet_shard_step_flags) for what is sixteen small launches below
         from . import _lib
         P = _lib.ptr
-        has_in = torch.empty(128 * 128 + 2, dtype=torch.int32, device=dev)
+        flags = torch.empty(128 * 128 + 3, dtype=torch.int32, device=dev)
         ask = bool(want_moved) and plan.pos_ref.shape == pos.shape
         if ask:
-            moved = torch.empty((), dtype=torch.int32, device=dev)
             cur, ref = pos.detach().contiguous(), plan.pos_ref.contiguous()
         _lib.check(_lib.load().hermnet_shard_step_flags(
             P(ei), int(ei.size(1)), P(z), int(z.numel()), None if total is None else P(total),
-            0 if capacity is None else int(capacity), P(has_in), P(cur) if ask else None, P(ref) if ask else None,
-            int(pos.size(0)) if ask else 0, float((0.5 * plan.skin) ** 2), P(moved) if ask else None,
+            0 if capacity is None else int(capacity), P(flags), P(cur) if ask else None, P(ref) if ask else None,
+            int(pos.size(0)) if ask else 0, float((0.5 * plan.skin) ** 2),
             torch.cuda.current_stream(dev).cuda_stream), "hermnet_shard_step_flags")
+        has_in = flags[:128 * 128 + 2]
+        if ask:
+            moved = flags[128 * 128 + 2]
     else:
         has_in = torch.zeros(128 * 128 + 2, dtype=torch.int32, device=dev)
         if ei.size(1) > 0:

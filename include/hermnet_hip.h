@@ -591,18 +591,18 @@ int hermnet_stream_copy(const float* src, float* dst, size_t num_floats, int wor
 int hermnet_param_guard(const void* const* tensor_ptrs, const long* word_counts, int num_tensors, unsigned* fingerprints,
                         int check, float* poison, int* flag, void* stream);
 
-/* Per-step flags of an atom-sharded step in ONE launch (ABI v10; hermnet_amd/sharding.py: slab_data, plan_moved -- sixteen
- * elementwise / index launches before).  The reference skips a relation when no atom of its element receives an edge anywhere
+/* Per-step flags of an atom-sharded step in two launches (clear + mark; ABI v10; hermnet_amd/sharding.py: slab_data,
+ * plan_moved -- sixteen elementwise / index launches before).  The reference skips a relation when no atom of its element receives an edge anywhere
  * in the structure (/root/reference/HermNet/hermnet.py:56-57): every rank marks the (target element, source element) pairs its
  * own list joins and the ranks reduce the table.  `edge_index` [2, columns] (rows: source, target; NULL edges of a padded list
  * = -1), `atomic_number` [num_atoms] of the LOCAL atoms, `total` [2] = (pairs found, flags) of a padded list or null,
- * `capacity` its columns.  `has_in` [128 * 128 + 2] int32 is zeroed here, then: [zt * 128 + zs] = 1 per joined pair (elements
+ * `capacity` its columns.  `has_in` [128 * 128 + 3] int32 is zeroed here, then: [zt * 128 + zs] = 1 per joined pair (elements
  * clamped to 127), [128 * 128] = 1 if the list holds NULL edges, [128 * 128 + 1] = 1 if the padded list is incomplete
- * (flags != 0 or more pairs than columns).  `pos`, `pos_ref` [num_pos, 3] and `moved` [1] (zeroed here): moved[0] = 1 if an
- * atom is further than sqrt(max_dist2) from its reference position (num_pos = 0: not asked).  No host read. */
+ * (flags != 0 or more pairs than columns), [128 * 128 + 2] = 1 if an atom of `pos` [num_pos, 3] is further than
+ * sqrt(max_dist2) from its position in `pos_ref` (num_pos = 0: not asked).  No host read, no memset node. */
 int hermnet_shard_step_flags(const long* edge_index, long columns, const long* atomic_number, int num_atoms, const long* total,
                              long capacity, int* has_in, const float* pos, const float* pos_ref, long num_pos, float max_dist2,
-                             int* moved, void* stream);
+                             void* stream);
 
 /* Host-side (CPU) evaluation of the per-edge radial contraction exactly as the device code
  * computes it (banded 12-tap Gaussian window): rb[c] = b[c] + env(u) * sum_k W[c,k] g_k(u) and

@@ -304,7 +304,7 @@ def test_sharded_step_takes_no_host_synchronisation():
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["padded", "padded_overfull", "padded_flagged", "exact", "empty"])
 def test_shard_step_flags_kernel_is_the_torch_expression(case):
-    """`hermnet_shard_step_flags` (ONE launch) against the sixteen small torch launches it replaces in `slab_data` /
+    """`hermnet_shard_step_flags` (clear + mark) against the sixteen small torch launches it replaces in `slab_data` /
     `plan_moved`: relation flags per (target element, source element) with elements clamped to 127, the NULL-edge slot, the
     incomplete-list flag, the displacement flag just below and just above skin / 2."""
     from hermnet_amd import _lib
@@ -329,14 +329,13 @@ def test_shard_step_flags_kernel_is_the_torch_expression(case):
     for shift, expect in [(0.499, 0), (0.501, 1)]:
         pos = pos_ref.clone()
         pos[123, 1] += shift
-        has_in = torch.full((128 * 128 + 2,), 7, dtype=torch.int32, device=dev)
-        moved = torch.full((), 7, dtype=torch.int32, device=dev)
+        has_in = torch.full((128 * 128 + 3,), 7, dtype=torch.int32, device=dev)
         P = _lib.ptr
         _lib.check(_lib.load().hermnet_shard_step_flags(P(ei), cols, P(z), n, None if total is None else P(total), capacity,
-                                                        P(has_in), P(pos), P(pos_ref), 900, 0.25, P(moved),
+                                                        P(has_in), P(pos), P(pos_ref), 900, 0.25,
                                                         torch.cuda.current_stream().cuda_stream), "hermnet_shard_step_flags")
-        assert torch.equal(has_in, ref)
-        assert int(moved) == expect
+        assert torch.equal(has_in[:128 * 128 + 2], ref)
+        assert int(has_in[128 * 128 + 2]) == expect
         assert int(ref[128 * 128]) == (1 if case.startswith("padded") else 0)
         assert int(ref[128 * 128 + 1]) == (1 if case in ("padded_overfull", "padded_flagged") else 0)
 
