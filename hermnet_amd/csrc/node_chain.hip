@@ -51,16 +51,16 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
   const rsrc_t xh_r = tile_rsrc(a.xh + ((size_t)t * a.Ns + row0) * 3 * H, nrows * 3 * H);
 
   // weight streams of this wave (requested before anything else: they do not depend on the rows)
-  const f32x4* w1 = reinterpret_cast<const f32x4*>(a.w1f + (size_t)t * H * H) + lane;
-  const f32x4* w2 = reinterpret_cast<const f32x4*>(a.w2f + (size_t)t * 3 * H * H) + lane;
+  const f32x4* w1 = reinterpret_cast<const f32x4*>(a.w1f + (size_t)t * H * H * 3 / 2) + lane;
+  const f32x4* w2 = reinterpret_cast<const f32x4*>(a.w2f + (size_t)t * 3 * H * H * 3 / 2) + lane;
   const f32x4* bp1[CPW];
   const f32x4* bp2[3 * CPW];
 #pragma unroll
-  for (int j = 0; j < CPW; ++j) bp1[j] = w1 + (size_t)(wc * CPW + j) * (H / 8) * 64;
+  for (int j = 0; j < CPW; ++j) bp1[j] = w1 + (size_t)(wc * CPW + j) * frag_f4(H);
 #pragma unroll
   for (int p = 0; p < 3; ++p)
 #pragma unroll
-    for (int j = 0; j < CPW; ++j) bp2[p * CPW + j] = w2 + (size_t)(p * CB + wc * CPW + j) * (H / 8) * 64;
+    for (int j = 0; j < CPW; ++j) bp2[p * CPW + j] = w2 + (size_t)(p * CB + wc * CPW + j) * frag_f4(H);
   BRing<CPW, ring_size(RB * CPW, false)> r1;
   b_preload(r1, bp1);
   const int ch = 4 * (lane >> 5);
@@ -197,14 +197,14 @@ __global__ __launch_bounds__(256, 2) void node_pre_bwd_kernel(PreBwdArgs a) {
     return;
   }
 
-  const f32x4* w2t = reinterpret_cast<const f32x4*>(a.w2tf + (size_t)t * 3 * H * H) + lane;
-  const f32x4* w1t = reinterpret_cast<const f32x4*>(a.w1tf + (size_t)t * H * H) + lane;
+  const f32x4* w2t = reinterpret_cast<const f32x4*>(a.w2tf + (size_t)t * 3 * H * H * 3 / 2) + lane;
+  const f32x4* w1t = reinterpret_cast<const f32x4*>(a.w1tf + (size_t)t * H * H * 3 / 2) + lane;
   const f32x4* bpa[CPW];
   const f32x4* bpb[CPW];
 #pragma unroll
   for (int j = 0; j < CPW; ++j) {
-    bpa[j] = w2t + (size_t)(wc * CPW + j) * (3 * H / 8) * 64;
-    bpb[j] = w1t + (size_t)(wc * CPW + j) * (H / 8) * 64;
+    bpa[j] = w2t + (size_t)(wc * CPW + j) * frag_f4(3 * H);
+    bpb[j] = w1t + (size_t)(wc * CPW + j) * frag_f4(H);
   }
   BRing<CPW, ring_size(RB * CPW, true)> ra;
   b_preload(ra, bpa);
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void node_pre_bwd_kernel(PreBwdArgs a) {
     const float* As = buf + mrow * LDC + ch;
     const f32x4* bpk[CPW];
 #pragma unroll
-    for (int j = 0; j < CPW; ++j) bpk[j] = bpa[j] + (size_t)kc * (KC / 8) * 64;
+    for (int j = 0; j < CPW; ++j) bpk[j] = bpa[j] + (size_t)kc * frag_f4(KC);
     if (kc + 1 < NCH) mma_panel<KC, LDC, RB, CPW, ring_size(RB * CPW, true), true>(acc, As, bpk, ra);
     else mma_panel<KC, LDC, RB, CPW, ring_size(RB * CPW, true), false>(acc, As, bpk, ra);
   }
@@ -293,22 +293,22 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
     }
     return;
   }
-  const f32x4* wv = reinterpret_cast<const f32x4*>(a.wvf + (size_t)t * 2 * H * H) + lane;
-  const f32x4* wx0 = reinterpret_cast<const f32x4*>(a.wx0f + (size_t)t * 2 * H * H) + lane;
-  const f32x4* wx2 = reinterpret_cast<const f32x4*>(a.wx2f + (size_t)t * 3 * H * H) + lane;
+  const f32x4* wv = reinterpret_cast<const f32x4*>(a.wvf + (size_t)t * 2 * H * H * 3 / 2) + lane;
+  const f32x4* wx0 = reinterpret_cast<const f32x4*>(a.wx0f + (size_t)t * 2 * H * H * 3 / 2) + lane;
+  const f32x4* wx2 = reinterpret_cast<const f32x4*>(a.wx2f + (size_t)t * 3 * H * H * 3 / 2) + lane;
   const f32x4* bpv[2 * CPW];
   const f32x4* bpx[CPW];
   const f32x4* bpq[3 * CPW];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int j = 0; j < CPW; ++j) bpv[p * CPW + j] = wv + (size_t)(p * CB + wc * CPW + j) * (H / 8) * 64;
+    for (int j = 0; j < CPW; ++j) bpv[p * CPW + j] = wv + (size_t)(p * CB + wc * CPW + j) * frag_f4(H);
 #pragma unroll
-  for (int j = 0; j < CPW; ++j) bpx[j] = wx0 + (size_t)(wc * CPW + j) * (2 * H / 8) * 64;
+  for (int j = 0; j < CPW; ++j) bpx[j] = wx0 + (size_t)(wc * CPW + j) * frag_f4(2 * H);
 #pragma unroll
   for (int p = 0; p < 3; ++p)
 #pragma unroll
-    for (int j = 0; j < CPW; ++j) bpq[p * CPW + j] = wx2 + (size_t)(p * CB + wc * CPW + j) * (H / 8) * 64;
+    for (int j = 0; j < CPW; ++j) bpq[p * CPW + j] = wx2 + (size_t)(p * CB + wc * CPW + j) * frag_f4(H);
 
   const int mrow = wr * RB * 32 + (lane & 31), ch = 4 * (lane >> 5);
   const rsrc_t x1_r = tile_rsrc(a.x1 + (size_t)row0 * H, nrows * H);
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
   {
     const f32x4* bpx1[CPW];
 #pragma unroll
-    for (int j = 0; j < CPW; ++j) bpx1[j] = bpx[j] + (size_t)(H / 8) * 64;
+    for (int j = 0; j < CPW; ++j) bpx1[j] = bpx[j] + (size_t)frag_f4(H);
     mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true>(acch, bufx + mrow * LD + ch, bpx, rx);
     mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), false>(acch, bufn + mrow * LD + ch, bpx1, rx);
   }
@@ -505,21 +505,21 @@ __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a
     return;
   }
   if (a.pend.gn != nullptr) materialise_pending<H, TR>(a, row0, nrows, tid);   // (incoming gradients still in partial sums)
-  const f32x4* wx2t = reinterpret_cast<const f32x4*>(a.wx2tf + (size_t)t * 3 * H * H) + lane;
-  const f32x4* wx0t = reinterpret_cast<const f32x4*>(a.wx0tf + (size_t)t * 2 * H * H) + lane;
-  const f32x4* wvt = reinterpret_cast<const f32x4*>(a.wvtf + (size_t)t * 2 * H * H) + lane;
+  const f32x4* wx2t = reinterpret_cast<const f32x4*>(a.wx2tf + (size_t)t * 3 * H * H * 3 / 2) + lane;
+  const f32x4* wx0t = reinterpret_cast<const f32x4*>(a.wx0tf + (size_t)t * 2 * H * H * 3 / 2) + lane;
+  const f32x4* wvt = reinterpret_cast<const f32x4*>(a.wvtf + (size_t)t * 2 * H * H * 3 / 2) + lane;
   const f32x4* bpa[CPW];
   const f32x4* bpx[2 * CPW];
   const f32x4* bpg[CPW];
 #pragma unroll
   for (int j = 0; j < CPW; ++j) {
-    bpa[j] = wx2t + (size_t)(wc * CPW + j) * (3 * H / 8) * 64;
-    bpg[j] = wvt + (size_t)(wc * CPW + j) * (2 * H / 8) * 64;
+    bpa[j] = wx2t + (size_t)(wc * CPW + j) * frag_f4(3 * H);
+    bpg[j] = wvt + (size_t)(wc * CPW + j) * frag_f4(2 * H);
   }
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int j = 0; j < CPW; ++j) bpx[p * CPW + j] = wx0t + (size_t)(p * CB + wc * CPW + j) * (H / 8) * 64;
+    for (int j = 0; j < CPW; ++j) bpx[p * CPW + j] = wx0t + (size_t)(p * CB + wc * CPW + j) * frag_f4(H);
   BRing<CPW, ring_size(RB * CPW, true)> ra;
   b_preload(ra, bpa);
   const int mrow = wr * RB * 32 + (lane & 31), ch = 4 * (lane >> 5);
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a
     const f32x4* bp1[CPW];
     const f32x4* bp2[CPW];
 #pragma unroll
-    for (int j = 0; j < CPW; ++j) { bp1[j] = bpa[j] + (size_t)(H / 8) * 64; bp2[j] = bpa[j] + (size_t)(2 * H / 8) * 64; }
+    for (int j = 0; j < CPW; ++j) { bp1[j] = bpa[j] + (size_t)frag_f4(H); bp2[j] = bpa[j] + (size_t)frag_f4(2 * H); }
     mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true>(acc, buf0 + mrow * LD + ch, bpa, ra);
     __syncthreads();                                 // buffer 0 is free
     tile_store<TR, H, LD>(buf0, g3, tid);
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a
     __syncthreads();
     const f32x4* bpg1[CPW];
 #pragma unroll
-    for (int j = 0; j < CPW; ++j) bpg1[j] = bpg[j] + (size_t)(H / 8) * 64;
+    for (int j = 0; j < CPW; ++j) bpg1[j] = bpg[j] + (size_t)frag_f4(H);
     mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true>(accg, buf0 + mrow * LD + ch, bpg, rg);
     mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), false>(accg, buf1 + mrow * LD + ch, bpg1, rg);
     if (d < 2) b_preload(rg, bpg);

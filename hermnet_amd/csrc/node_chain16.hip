@@ -78,13 +78,8 @@ __device__ __forceinline__ void b16_preload(Ring16<NB>& r, const f32x4* const (&
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Round 5 (second half): the products run on the BF16 matrix pipe at fp32 accuracy.  v_mfma_f32_16x16x4_f32 delivers 64
-// FLOP/clk/SIMD, v_mfma_f32_16x16x32_bf16 1024: an fp32 value split THREE ways into bf16 planes (x = x0 + x1 + x2 exactly: 3 x 8
-// significant bits) and the six largest of the nine partial products -- w2 x0, w1 x1, w1 x0, w0 x2, w0 x1, w0 x0, accumulated in
-// fp32 by the MFMA; the three dropped ones are <= 2^-24 of the product each -- cost 6 / 16 of the fp32 instruction's pipe time
-// (the "BF16x6 / BF16x9" emulation of fp32 GEMMs).  Weights are split once on the host (nodeops.weight_fragments16: three
-// planes, 6 bytes per weight instead of 4); activations stay fp32 in LDS and are split by the consuming wave in registers
-// (~37 VALU instructions per eight values, shared by the wave's NB blocks, issued between the MFMAs of the previous k-group).
+// Round 5 (second half): the products run on the BF16 matrix pipe at fp32 accuracy -- three-way bf16 splits, six partial
+// products per k-group on v_mfma_f32_16x16x32_bf16 (node_chain_common.h: split8, "fp32 products on the BF16 matrix pipe").
 // Measured before it was built, with the instruction mix alone (a diagnostic build, results wrong, time meaningful:
 // profiles/r05_split_timing.log): update_fwd 55 -> 32 us, pre_fwd16 64 -> 30, fused forward 98 -> 61.
 //
@@ -92,28 +87,6 @@ __device__ __forceinline__ void b16_preload(Ring16<NB>& r, const f32x4* const (&
 // W_p[16 b + (l & 15)][32 Q + 8 (l >> 4) .. +7]), in the order [k-group Q of 32][plane 2, 1, 0]: three steps per 32 k where
 // the fp32 form took two 16-deep groups -- 1.5 x the requests and bytes.  frag16(W)[((b * K/32 + Q) * 3 + s) * 64 + l].
 // ---------------------------------------------------------------------------------------------------------------------
-typedef __bf16 hn_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 hn_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float hn_f32x2 __attribute__((ext_vector_type(2)));
-struct Split8 { hn_bf16x8 p[3]; };          // p[0] + p[1] + p[2] == the eight fp32 values (exactly, barring under/overflow)
-
-__device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, Split8& o) {
-  float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      const hn_f32x2 v = {x[e], x[e + 1]};
-      const hn_bf16x2 h = __builtin_convertvector(v, hn_bf16x2);          // v_cvt_pk_bf16_f32: round to nearest even
-      o.p[p][e] = h[0]; o.p[p][e + 1] = h[1];
-      if (p < 2) {
-        const hn_f32x2 back = __builtin_convertvector(h, hn_f32x2);
-        x[e] -= back[0]; x[e + 1] -= back[1];                             // exact: the residual fits fp32
-      }
-    }
-  }
-}
-
 // float4s of one 16-channel block's fragment stream over K inputs (3 K / 32 steps of 64 lanes), floats of an [O, K] weight
 constexpr int frag16_f4(int K) { return K * 6; }
 constexpr size_t frag16_floats(size_t O, size_t K) { return O * K * 3 / 2; }

@@ -164,9 +164,9 @@ struct Cfg {
   static_assert(CB % WC == 0 && (TR / 32) % WR == 0 && RB >= 1 && F4 >= 1, "unsupported tile");
 };
 
-// ---- B operand: a ring of RS weight fragments per column block, RS - 1 k-groups ahead of use -------------------------
-// One wave per SIMD has nobody to hide a late operand: a k-group is RB * NJ * 4 MFMAs = RB * NJ * 256 cycles, an L2 hit
-// under load 500-800: three groups ahead.
+// ---- B operand: a ring of RS weight fragments per column block, RS - 1 steps ahead of use ----------------------------
+// (written for the fp32 MFMAs: a k-group was RB * NJ * 4 MFMAs = RB * NJ * 256 cycles, an L2 hit under load 500-800: three
+// groups ahead.  Since the products run as bf16 splits a slot holds one STEP: see mma_panel)
 template <int NJ, int RS>
 struct BRing { f32x4 v[RS][NJ]; };
 
@@ -187,7 +187,43 @@ __device__ __forceinline__ void stagger_start() {
 #endif
 }
 
-// first RS - 1 k-groups of a stream (call it early: before the barrier / epilogue that precedes the product)
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 products on the BF16 matrix pipe (round 5).  The fp32 MFMAs (v_mfma_f32_32x32x2_f32 / 16x16x4) deliver 64 FLOP/clk/SIMD,
+// the bf16 ones (32x32x16 / 16x16x32) 1024.  An fp32 value split THREE ways into bf16 planes, x = x0 + x1 + x2 EXACTLY (3 x 8
+// significant bits; each plane the round-to-nearest-even of what the planes before it leave), and the six largest of the nine
+// partial products -- w2 x0, w1 x1, w1 x0, w0 x2, w0 x1, w0 x0, smallest first, accumulated in fp32 by the MFMA; the three dropped
+// ones are each <= 2^-24 of the product -- cost 6 / 16 of the fp32 instruction's pipe time at fp32 accuracy (the "BF16x6 / x9"
+// emulation of fp32 GEMMs).  Weights are split once on the host (nodeops.weight_fragments / weight_fragments16: three planes in
+// stream order, 6 bytes per weight instead of 4); activations stay fp32 in the LDS tiles and are split by the consuming wave in
+// registers (~37 VALU instructions per eight values, issued between the MFMAs of the previous k-group).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 hn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hn_f32x2 __attribute__((ext_vector_type(2)));
+struct Split8 { hn_bf16x8 p[3]; };          // p[0] + p[1] + p[2] == the eight fp32 values (exactly, barring under/overflow)
+
+__device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, Split8& o) {
+  float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const hn_f32x2 v = {x[e], x[e + 1]};
+      const hn_bf16x2 h = __builtin_convertvector(v, hn_bf16x2);          // v_cvt_pk_bf16_f32: round to nearest even
+      o.p[p][e] = h[0]; o.p[p][e + 1] = h[1];
+      if (p < 2) {
+        const hn_f32x2 back = __builtin_convertvector(h, hn_f32x2);
+        x[e] -= back[0]; x[e + 1] -= back[1];                             // exact: the residual fits fp32
+      }
+    }
+  }
+}
+
+// float4s of one 32-channel block's fragment stream over K inputs (K/16 k-groups x 3 planes x 64 lanes); floats of a
+// fragment-ordered [O, K] weight
+constexpr int frag_f4(int K) { return K * 12; }
+
+// first RS - 1 steps of a stream (call it early: before the barrier / epilogue that precedes the product)
 template <int NJ, int RS>
 __device__ __forceinline__ void b_preload(BRing<NJ, RS>& r, const f32x4* const (&bp)[NJ]) {
 #pragma unroll
@@ -196,12 +232,16 @@ __device__ __forceinline__ void b_preload(BRing<NJ, RS>& r, const f32x4* const (
     for (int j = 0; j < NJ; ++j) r.v[g][j] = bp[j][g * 64];
 }
 
-// acc[rb][j] += W_j[k-groups 0 .. KP/8) . A[rows of block rb]^T, W_j streamed from bp[j] (this lane's pointer at group 0
-// of the panel).  `As`: this lane's LDS read pointer, &tile[(first row of the wave + (l & 31)) * LD + 4 (l >> 5)].
-// The ring holds groups 0 .. RS-2 on entry.  MORE: the stream continues behind this panel (next panel of the same
-// product): its first RS - 1 groups are requested too and sit in slots 0 .. RS-2 on exit (needs KP/8 % RS == 0).
-// PIN: the group's requests stay in front of its MFMAs (see below); the pre-forward kernels, whose loops hipcc leaves alone
-// anyway, run 5x slower with the fence in place (found by measurement, not understood) and pass false.
+// acc[rb][j] += W_j[:, 0 .. KP) . A[rows of block rb]^T, W_j streamed from bp[j] (this lane's pointer at step 0 of the panel).
+// A block's fragments are consumed as STEPS of one 1-KiB load each (lane l: 16 bytes = 8 bf16 of one weight plane,
+// W_p[32 cb + (l & 31)][16 Q + 8 (l >> 5) .. +7]) in the order [k-group Q of 16][plane 2, 1, 0]:
+//     frag(W)[((cb * K/16 + Q) * 3 + s) * 64 + l],   step s of a group runs s + 1 MFMAs per accumulator block
+// (activation planes s .. 0) -- three steps per 16 k where the fp32 form took two 8-deep groups: 1.5 x the requests and bytes.
+// `As`: this lane's LDS read pointer, &tile[(first row of the wave + (l & 31)) * LD + 4 (l >> 5)] (the tile is fp32).
+// The ring holds steps 0 .. RS-2 on entry.  MORE: the stream continues behind this panel (next panel of the same
+// product): its first RS - 1 steps are requested too and sit in slots 0 .. RS-2 on exit.
+// PIN: a step's requests stay in front of its MFMAs (see below); the pre-forward kernels, whose loops hipcc leaves alone
+// anyway, ran 5x slower with the fence in place (found by measurement, not understood) and pass false.
 #ifndef HN_PIN_LOADS
 #define HN_PIN_LOADS 1
 #endif
@@ -211,44 +251,59 @@ __device__ __forceinline__ void b_preload(BRing<NJ, RS>& r, const f32x4* const (
 template <int KP, int LD, int RB, int NJ, int RS, bool MORE, bool PIN = true>
 __device__ __forceinline__ void mma_panel(f32x16 (&acc)[RB][NJ], const float* As, const f32x4* const (&bp)[NJ],
                                           BRing<NJ, RS>& ring) {
-  constexpr int NQ = KP / 8, PF = RS - 1;
-  static_assert(NQ % RS == 0 && RS % 2 == 0, "panel / ring mismatch");
-  f32x4 a[2][RB];                                       // LDS reads one k-group ahead
+  constexpr int GT = KP / 16, PF = RS - 1, CH = 4, CS = 3 * CH;     // k-groups; groups / steps of one pass of the rolled loop
+  static_assert(KP % (16 * CH) == 0 && CS % RS == 0, "panel / ring mismatch");
+  const float* A8 = As + 4 * ((threadIdx.x & 63) >> 5);             // &tile[row * LD + 8 (l >> 5)]
+  Split8 X[2][RB];                                                  // the planes of k-group g in X[g & 1]
+  f32x4 lo[RB], hi[RB];
 #pragma unroll
-  for (int rb = 0; rb < RB; ++rb) a[0][rb] = *reinterpret_cast<const f32x4*>(As + rb * 32 * LD);
-  // One k-group: request the weight group PF ahead and the tile group 1 ahead, then RB x NJ x 4 MFMAs.  The groups
-  // run RS at a time in a ROLLED loop (ring slots are then compile-time constants): a fully unrolled chain kernel is
-  // 50-60 KB of code -- more than the instruction cache -- and hipcc's scheduler, handed a whole panel as one region,
-  // spills what the caller keeps in flight around the product.
-  auto group = [&](int q0, int qq, bool load_b, bool load_a) {
-    const int q = q0 + qq;
-    if (load_b) {
+  for (int rb = 0; rb < RB; ++rb) {
+    lo[rb] = *reinterpret_cast<const f32x4*>(A8 + rb * 32 * LD);
+    hi[rb] = *reinterpret_cast<const f32x4*>(A8 + rb * 32 * LD + 4);
+    split8(lo[rb], hi[rb], X[0][rb]);
+  }
+  // Four k-groups = twelve steps per pass of a ROLLED loop (ring slots are then compile-time constants): a fully unrolled chain
+  // kernel is more code than the instruction cache holds, and hipcc's scheduler, handed a whole panel as one region, spills
+  // what the caller keeps in flight around the product.
+  auto chunk = [&](int g0, bool last) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) ring.v[(qq + PF) % RS][j] = bp[j][(q + PF) * 64];
+    for (int gq = 0; gq < CH; ++gq) {
+      const bool has_next = !last || gq + 1 < CH;                   // the panel has a group behind this one
+      if (has_next) {                                               // its tile values: LDS reads one group ahead
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          lo[rb] = *reinterpret_cast<const f32x4*>(A8 + rb * 32 * LD + 16 * (g0 + gq + 1));
+          hi[rb] = *reinterpret_cast<const f32x4*>(A8 + rb * 32 * LD + 16 * (g0 + gq + 1) + 4);
+        }
+      }
+#pragma unroll
+      for (int ps = 0; ps < 3; ++ps) {                              // the step of weight plane 2 - ps
+        const int sl = 3 * gq + ps;
+        if (MORE || !last || sl + PF < CS) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) ring.v[(sl + PF) % RS][j] = bp[j][(3 * g0 + sl + PF) * 64];
+        }
+        // the requests stay HERE, in front of the step's MFMAs: left alone, hipcc's scheduler sinks a weight request towards
+        // its use (fewer live registers) and the product waits for L2 every few steps (round 4: read off the ISA)
+        if (PIN && HN_PIN_LOADS) fence_sched();
+#pragma unroll
+        for (int m = ps; m >= 0; --m)                               // activation planes ps .. 0
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hn_bf16x8, ring.v[sl % RS][j]),
+                                                                   X[gq & 1][rb].p[m], acc[rb][j], 0, 0, 0);
+        if (ps == 1 && has_next) {                                  // (VALU work beside the matrix pipe's)
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) split8(lo[rb], hi[rb], X[(gq + 1) & 1][rb]);
+        }
+      }
     }
-    if (load_a) {
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) a[(qq + 1) & 1][rb] = *reinterpret_cast<const f32x4*>(As + rb * 32 * LD + 8 * (q + 1));
-    }
-    // the requests stay HERE, in front of the group's MFMAs: left alone, hipcc's scheduler sinks a weight request towards its
-    // use three groups later (fewer live registers) and the product waits for L2 every few groups (round 4: read off the
-    // ISA of the update kernels' loops; -18 ... -23 % on the wide kernels at H = 512, -10 % on the 16-row update backward)
-    if (PIN && HN_PIN_LOADS) fence_sched();
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring.v[qq % RS][j][i], a[qq & 1][rb][i], acc[rb][j], 0, 0, 0);
   };
 #pragma unroll 1
-  for (int q0 = 0; q0 < NQ - RS; q0 += RS) {
-#pragma unroll
-    for (int qq = 0; qq < RS; ++qq) group(q0, qq, true, true);
-  }
-#pragma unroll
-  for (int qq = 0; qq < RS; ++qq) group(NQ - RS, qq, MORE || qq + PF < RS, qq + 1 < RS);
+  for (int g0 = 0; g0 < GT - CH; g0 += CH) chunk(g0, false);
+  chunk(GT - CH, true);
 }
 
 // Accumulators that START at the bias (acc[rb][j] = bias of the block's channels, every row): the bias loads are then

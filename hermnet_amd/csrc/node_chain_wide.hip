@@ -71,11 +71,11 @@ __global__ __launch_bounds__(256, 1) void node_pre_fwd_wide_kernel(PreFwdArgs a)
   const rsrc_t x_r = tile_rsrc(a.x + (size_t)row0 * H, nrows * H);
   const rsrc_t hb_r = tile_rsrc(a.hb + ((size_t)t * a.Ns + row0) * H, nrows * H);
   const rsrc_t xh_r = tile_rsrc(a.xh + ((size_t)t * a.Ns + row0) * 3 * H, nrows * 3 * H);
-  const f32x4* w1 = reinterpret_cast<const f32x4*>(a.w1f + (size_t)t * H * H) + lane;
-  const f32x4* w2 = reinterpret_cast<const f32x4*>(a.w2f + (size_t)t * 3 * H * H) + lane;
+  const f32x4* w1 = reinterpret_cast<const f32x4*>(a.w1f + (size_t)t * H * H * 3 / 2) + lane;
+  const f32x4* w2 = reinterpret_cast<const f32x4*>(a.w2f + (size_t)t * 3 * H * H * 3 / 2) + lane;
   const f32x4* bp1[NP];
 #pragma unroll
-  for (int j = 0; j < NP; ++j) bp1[j] = w1 + (size_t)B.cbc[j] * (H / 8) * 64;
+  for (int j = 0; j < NP; ++j) bp1[j] = w1 + (size_t)B.cbc[j] * frag_f4(H);
   BRing<NP, 4> r1;
   b_preload(r1, bp1);
 
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void node_pre_fwd_wide_kernel(PreFwdArgs a)
     if (B.ok[j]) {
       const f32x4* bp2[3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bp2[p] = w2 + (size_t)(p * CB + B.cb[j]) * (H / 8) * 64;
+      for (int p = 0; p < 3; ++p) bp2[p] = w2 + (size_t)(p * CB + B.cb[j]) * frag_f4(H);
       BRing<3, 4> r2;
       b_preload(r2, bp2);
       f32x16 acc2[1][3];
@@ -184,14 +184,14 @@ __global__ __launch_bounds__(256, 1) void node_pre_bwd_wide_kernel(PreBwdArgs a)
     return;
   }
   const Blocks<CB, NP> B(wave);
-  const f32x4* w2t = reinterpret_cast<const f32x4*>(a.w2tf + (size_t)t * 3 * H * H) + lane;
-  const f32x4* w1t = reinterpret_cast<const f32x4*>(a.w1tf + (size_t)t * H * H) + lane;
+  const f32x4* w2t = reinterpret_cast<const f32x4*>(a.w2tf + (size_t)t * 3 * H * H * 3 / 2) + lane;
+  const f32x4* w1t = reinterpret_cast<const f32x4*>(a.w1tf + (size_t)t * H * H * 3 / 2) + lane;
   const f32x4* bpa[NP];
   const f32x4* bpb[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
-    bpa[j] = w2t + (size_t)B.cbc[j] * (3 * H / 8) * 64;
-    bpb[j] = w1t + (size_t)B.cbc[j] * (H / 8) * 64;
+    bpa[j] = w2t + (size_t)B.cbc[j] * frag_f4(3 * H);
+    bpb[j] = w1t + (size_t)B.cbc[j] * frag_f4(H);
   }
   BRing<NP, 4> ra;
   b_preload(ra, bpa);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void node_pre_bwd_wide_kernel(PreBwdArgs a)
     const float* As = buf + mrow * LDC + ch;
     const f32x4* bpk[NP];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) bpk[j] = bpa[j] + (size_t)kc * (KC / 8) * 64;
+    for (int j = 0; j < NP; ++j) bpk[j] = bpa[j] + (size_t)kc * frag_f4(KC);
     mma_panel<KC, LDC, 1, NP, 4, decltype(more)::value>(acc, As, bpk, ra);
   };
 #pragma unroll 1
@@ -269,9 +269,9 @@ __global__ __launch_bounds__(256, 1) void node_update_fwd_wide_kernel(UpdFwdArgs
     return;
   }
   const Blocks<CB, NP> B(wave);
-  const f32x4* wv = reinterpret_cast<const f32x4*>(a.wvf + (size_t)t * 2 * H * H) + lane;
-  const f32x4* wx0 = reinterpret_cast<const f32x4*>(a.wx0f + (size_t)t * 2 * H * H) + lane;
-  const f32x4* wx2 = reinterpret_cast<const f32x4*>(a.wx2f + (size_t)t * 3 * H * H) + lane;
+  const f32x4* wv = reinterpret_cast<const f32x4*>(a.wvf + (size_t)t * 2 * H * H * 3 / 2) + lane;
+  const f32x4* wx0 = reinterpret_cast<const f32x4*>(a.wx0f + (size_t)t * 2 * H * H * 3 / 2) + lane;
+  const f32x4* wx2 = reinterpret_cast<const f32x4*>(a.wx2f + (size_t)t * 3 * H * H * 3 / 2) + lane;
   const int mrow = lane & 31, ch = 4 * (lane >> 5);
   const rsrc_t x1_r = tile_rsrc(a.x1 + (size_t)row0 * H, nrows * H);
   const rsrc_t vec1_r = tile_rsrc(a.vec1 + (size_t)row0 * 3 * H, nrows * 3 * H);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void node_update_fwd_wide_kernel(UpdFwdArgs
 #pragma unroll
     for (int j = 0; j < NP; ++j)
       if (B.ok[j]) {
-        const f32x4* bpv[2] = {wv + (size_t)B.cb[j] * (H / 8) * 64, wv + (size_t)(CB + B.cb[j]) * (H / 8) * 64};
+        const f32x4* bpv[2] = {wv + (size_t)B.cb[j] * frag_f4(H), wv + (size_t)(CB + B.cb[j]) * frag_f4(H)};
         BRing<2, 4> rv;
         b_preload(rv, bpv);
         f32x16 accv[1][2];
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void node_update_fwd_wide_kernel(UpdFwdArgs
     }
   const f32x4* bpx[NP];
 #pragma unroll
-  for (int j = 0; j < NP; ++j) bpx[j] = wx0 + (size_t)B.cbc[j] * (2 * H / 8) * 64;
+  for (int j = 0; j < NP; ++j) bpx[j] = wx0 + (size_t)B.cbc[j] * frag_f4(2 * H);
   BRing<NP, 4> rx;
   b_preload(rx, bpx);
   __syncthreads();
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void node_update_fwd_wide_kernel(UpdFwdArgs
   {
     const f32x4* bpx1[NP];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) bpx1[j] = bpx[j] + (size_t)(H / 8) * 64;
+    for (int j = 0; j < NP; ++j) bpx1[j] = bpx[j] + (size_t)frag_f4(H);
     mma_all<H, LD, NP, true>(acch, bufx + mrow * LD + ch, bpx, rx);
     mma_all<H, LD, NP, false>(acch, bufn + mrow * LD + ch, bpx1, rx);
   }
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void node_update_fwd_wide_kernel(UpdFwdArgs
     const int cblk = cb * 32;
     const f32x4* bpq[3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) bpq[p] = wx2 + (size_t)(p * CB + cb) * (H / 8) * 64;
+    for (int p = 0; p < 3; ++p) bpq[p] = wx2 + (size_t)(p * CB + cb) * frag_f4(H);
     BRing<3, 4> rq;
     b_preload(rq, bpq);
     BlockLoad lvv[3], lv1[3], lv2[3];
@@ -452,15 +452,15 @@ __global__ __launch_bounds__(256, 1) void node_update_bwd_wide_kernel(UpdBwdArgs
   }
   if (a.pend.gn != nullptr) materialise_pending<H, TR>(a, row0, nrows, tid);   // (incoming gradients still in partial sums)
   const Blocks<CB, NP> B(wave);
-  const f32x4* wx2t = reinterpret_cast<const f32x4*>(a.wx2tf + (size_t)t * 3 * H * H) + lane;
-  const f32x4* wx0t = reinterpret_cast<const f32x4*>(a.wx0tf + (size_t)t * 2 * H * H) + lane;
-  const f32x4* wvt = reinterpret_cast<const f32x4*>(a.wvtf + (size_t)t * 2 * H * H) + lane;
+  const f32x4* wx2t = reinterpret_cast<const f32x4*>(a.wx2tf + (size_t)t * 3 * H * H * 3 / 2) + lane;
+  const f32x4* wx0t = reinterpret_cast<const f32x4*>(a.wx0tf + (size_t)t * 2 * H * H * 3 / 2) + lane;
+  const f32x4* wvt = reinterpret_cast<const f32x4*>(a.wvtf + (size_t)t * 2 * H * H * 3 / 2) + lane;
   const f32x4* bpa[NP];
   const f32x4* bpg[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
-    bpa[j] = wx2t + (size_t)B.cbc[j] * (3 * H / 8) * 64;
-    bpg[j] = wvt + (size_t)B.cbc[j] * (2 * H / 8) * 64;
+    bpa[j] = wx2t + (size_t)B.cbc[j] * frag_f4(3 * H);
+    bpg[j] = wvt + (size_t)B.cbc[j] * frag_f4(2 * H);
   }
   BRing<NP, 4> ra;
   b_preload(ra, bpa);
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256, 1) void node_update_bwd_wide_kernel(UpdBwdArgs
     const f32x4* bp1[NP];
     const f32x4* bp2[NP];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) { bp1[j] = bpa[j] + (size_t)(H / 8) * 64; bp2[j] = bpa[j] + (size_t)(2 * H / 8) * 64; }
+    for (int j = 0; j < NP; ++j) { bp1[j] = bpa[j] + (size_t)frag_f4(H); bp2[j] = bpa[j] + (size_t)frag_f4(2 * H); }
     mma_all<H, LD, NP, true>(acc, buf0 + mrow * LD + ch, bpa, ra);
     __syncthreads();                                 // buffer 0 is free
 #pragma unroll
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void node_update_bwd_wide_kernel(UpdBwdArgs
   for (int j = 0; j < NP; ++j) {
     const int cb = wave + 4 * j;
     if (cb >= CB) break;
-    const f32x4* bpx[2] = {wx0t + (size_t)cb * (H / 8) * 64, wx0t + (size_t)(CB + cb) * (H / 8) * 64};
+    const f32x4* bpx[2] = {wx0t + (size_t)cb * frag_f4(H), wx0t + (size_t)(CB + cb) * frag_f4(H)};
     BRing<2, 4> rx;
     b_preload(rx, bpx);
     BlockLoad lgx, lnr;
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256, 1) void node_update_bwd_wide_kernel(UpdBwdArgs
     __syncthreads();
     const f32x4* bpg1[NP];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) bpg1[j] = bpg[j] + (size_t)(H / 8) * 64;
+    for (int j = 0; j < NP; ++j) bpg1[j] = bpg[j] + (size_t)frag_f4(H);
     mma_all<H, LD, NP, true>(accg, buf0 + mrow * LD + ch, bpg, rg);
     mma_all<H, LD, NP, false>(accg, buf1 + mrow * LD + ch, bpg1, rg);
 #pragma unroll

@@ -203,33 +203,42 @@ def chain_tile_rows(H, update=False):
     return int(_lib.load().hermnet_node_chain_tile_rows(int(H), 1 if update else 0))
 
 
-def weight_fragments(w):
-    """nn.Linear weight [out, in] (or a stack [T, out, in]) -> the same values in MFMA B-operand order
-    (include/hermnet_hip.h: frag(W)); out % 32 == 0, in % 8 == 0."""
-    lead = w.shape[:-2]
-    o, k = w.shape[-2:]
-    f = w.reshape(*lead, o // 32, 32, k // 8, 2, 4)
-    n = len(lead)
-    return f.permute(*range(n), n, n + 2, n + 3, n + 1, n + 4).contiguous().reshape(*lead, o * k)
-
-
-def weight_fragments16(w):
-    """The 16-row kernels' weight stream (csrc/node_chain16.hip: mma16_panel; include/hermnet_hip.h: frag16(W)).  Their products
-    run on the bf16 matrix pipe at fp32 accuracy: every weight is split three ways, w = w0 + w1 + w2 exactly (bf16 planes, round
-    to nearest even, each the rounding of what the planes before it leave), and stored in the order the kernels consume it --
-    per 16-row block b of W and 32-deep k-group Q the three planes, smallest first, as v_mfma_f32_16x16x32_bf16 operands:
-        frag16(W)[((b * K/32 + Q) * 3 + s) * 64 + l] = 8 bf16  W_(2-s)[16 b + (l & 15)][32 Q + 8 (l >> 4) .. +7]
-    W [..., out, in], out % 16 == 0, in % 32 == 0 -> float32 [..., out * in * 3 / 2] (6 bytes per weight, opaque)."""
-    lead = w.shape[:-2]
-    o, k = w.shape[-2:]
+def _bf16_planes(w):
+    """w = p0 + p1 + p2 exactly (bf16 planes, each the round-to-nearest-even of what the planes before it leave): the three-way
+    split behind the chain kernels' fp32 products on the bf16 matrix pipe (csrc/node_chain_common.h: split8).  Returned smallest
+    first -- the order the kernels' weight streams hold them in."""
     w32 = w.float()
     p0 = w32.to(torch.bfloat16)
     r1 = w32 - p0.float()
     p1 = r1.to(torch.bfloat16)
     p2 = (r1 - p1.float()).to(torch.bfloat16)
+    return [p2, p1, p0]
+
+
+def weight_fragments(w):
+    """nn.Linear weight [out, in] (or a stack [T, out, in]) -> the chain kernels' weight stream (include/hermnet_hip.h: frag(W);
+    csrc/node_chain_common.h: mma_panel): per 32-row block cb of W and 16-deep k-group Q the three bf16 planes of the weights,
+    smallest first, as v_mfma_f32_32x32x16_bf16 operands:
+        frag(W)[((cb * K/16 + Q) * 3 + s) * 64 + l] = 8 bf16  W_(2-s)[32 cb + (l & 31)][16 Q + 8 (l >> 5) .. +7]
+    out % 32 == 0, in % 16 == 0 -> float32 [..., out * in * 3 / 2] (6 bytes per weight, opaque)."""
+    lead = w.shape[:-2]
+    o, k = w.shape[-2:]
     n = len(lead)
-    f = torch.stack([p2, p1, p0], dim=n).reshape(*lead, 3, o // 16, 16, k // 32, 4, 8)     # [s, b, m, Q, g, e]
-    f = f.permute(*range(n), n + 1, n + 3, n, n + 4, n + 2, n + 5).contiguous()              # [b, Q, s, g, m, e]
+    f = torch.stack(_bf16_planes(w), dim=n).reshape(*lead, 3, o // 32, 32, k // 16, 2, 8)     # [s, cb, m, Q, g, e]
+    f = f.permute(*range(n), n + 1, n + 3, n, n + 4, n + 2, n + 5).contiguous()                # [cb, Q, s, g, m, e]
+    return f.reshape(*lead, o * k * 3).view(torch.float32)
+
+
+def weight_fragments16(w):
+    """The same for the 16-row kernels (csrc/node_chain16.hip: mma16_panel; include/hermnet_hip.h: frag16(W)): per 16-row block b
+    and 32-deep k-group Q the three planes as v_mfma_f32_16x16x32_bf16 operands:
+        frag16(W)[((b * K/32 + Q) * 3 + s) * 64 + l] = 8 bf16  W_(2-s)[16 b + (l & 15)][32 Q + 8 (l >> 4) .. +7]
+    out % 16 == 0, in % 32 == 0 -> float32 [..., out * in * 3 / 2]."""
+    lead = w.shape[:-2]
+    o, k = w.shape[-2:]
+    n = len(lead)
+    f = torch.stack(_bf16_planes(w), dim=n).reshape(*lead, 3, o // 16, 16, k // 32, 4, 8)     # [s, b, m, Q, g, e]
+    f = f.permute(*range(n), n + 1, n + 3, n, n + 4, n + 2, n + 5).contiguous()                # [b, Q, s, g, m, e]
     return f.reshape(*lead, o * k * 3).view(torch.float32)
 
 

@@ -423,12 +423,17 @@ def test_node_chain_restatements_are_consistent(H, T, counts, uniform):
     (gx_auto,) = torch.autograd.grad(xh, x, gxh)
     gx = ref_ops.node_pre_bwd(gxh, hb.detach(), x.detach(), mean.detach(), rstd.detach(), w)
     assert rel_err(gx, gx_auto) < 1e-10
-    # fragment order: frag(W)[((cb * K/8 + q) * 64 + l) * 4 + e] = W[32 cb + (l & 31)][8 q + 4 (l >> 5) + e]
-    W = w.wx0_s                                                   # [T, H, 2H]
-    f = nodeops.weight_fragments(W).view(T, H // 32, 2 * H // 8, 64, 4)
-    for (t, cb, q, l, e) in [(0, 0, 0, 0, 0), (T - 1, H // 32 - 1, 2 * H // 8 - 1, 63, 3), (0, 1, 5, 37, 2)]:
-        assert float(f[t, cb, q, l, e]) == float(W[t, 32 * cb + (l & 31), 8 * q + 4 * (l >> 5) + e])
-    assert torch.equal(f.reshape(T, -1), w.wx0f)
+    # fragment order (three bf16 planes, smallest first): frag(W)[((cb * K/16 + Q) * 3 + s) * 64 + l][e] = W_(2-s)[32 cb + (l & 31)][16 Q + 8 (l >> 5) + e]
+    W = w.wx0_s.float()                                           # [T, H, 2H]
+    planes = nodeops._bf16_planes(W)
+    assert torch.equal((planes[2].double() + planes[1].double()) + planes[0].double(), W.double())     # the split is exact
+    f = nodeops.weight_fragments(W).view(torch.bfloat16).view(T, H // 32, 2 * H // 16, 3, 64, 8)
+    for (t, cb, q, s_, l, e) in [(0, 0, 0, 0, 0, 0), (T - 1, H // 32 - 1, 2 * H // 16 - 1, 2, 63, 7), (0, 1, 5, 1, 37, 2)]:
+        assert float(f[t, cb, q, s_, l, e]) == float(planes[s_][t, 32 * cb + (l & 31), 16 * q + 8 * (l >> 5) + e])
+    assert torch.equal(f.reshape(T, -1).view(torch.float32), w.wx0f)
+    f16 = nodeops.weight_fragments16(W).view(torch.bfloat16).view(T, H // 16, 2 * H // 32, 3, 64, 8)
+    for (t, b_, q, s_, l, e) in [(0, 0, 0, 0, 0, 0), (T - 1, H // 16 - 1, 2 * H // 32 - 1, 2, 63, 7), (T // 2, 3, 2, 1, 41, 5)]:
+        assert float(f16[t, b_, q, s_, l, e]) == float(planes[s_][t, 16 * b_ + (l & 15), 32 * q + 8 * (l >> 4) + e])
 
 
 def test_tall_bmm_is_a_linear_to_second_order(monkeypatch):
