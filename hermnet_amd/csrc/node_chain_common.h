@@ -171,10 +171,13 @@ template <int NJ, int RS>
 struct BRing { f32x4 v[RS][NJ]; };
 
 // ring slots of a product with RB x NJ accumulator blocks per wave
-#ifndef HN_RS_SMALL
-#define HN_RS_SMALL 4
+// (three slots: a k-group is three steps, so the slots of a group's steps are compile-time constants in a loop rolled per GROUP --
+// with four the loop body had to be four groups, twelve steps, and the update kernels spilled)
+#ifndef HN_RS
+#define HN_RS 3
 #endif
-constexpr int ring_size(int rb_nj, bool more) { return rb_nj == 1 ? HN_RS_SMALL : 4; }
+constexpr int kRS = HN_RS;
+constexpr int ring_size(int rb_nj, bool more) { return kRS; }
 
 // Experiment knob (-DHN_STAGGER=n): the workgroup that lands in an ODD wave slot of its SIMD (the second of two
 // co-resident ones) starts n x 8128 cycles late, so that the two do not walk through their matrix phases in lockstep.
@@ -251,24 +254,35 @@ __device__ __forceinline__ void b_preload(BRing<NJ, RS>& r, const f32x4* const (
 template <int KP, int LD, int RB, int NJ, int RS, bool MORE, bool PIN = true>
 __device__ __forceinline__ void mma_panel(f32x16 (&acc)[RB][NJ], const float* As, const f32x4* const (&bp)[NJ],
                                           BRing<NJ, RS>& ring) {
-  constexpr int GT = KP / 16, PF = RS - 1, CH = 4, CS = 3 * CH;     // k-groups; groups / steps of one pass of the rolled loop
-  static_assert(KP % (16 * CH) == 0 && CS % RS == 0, "panel / ring mismatch");
+  // k-groups; groups / steps of one pass of the rolled loop (the fewest groups whose steps fill whole turns of the ring)
+  constexpr int GT = KP / 16, PF = RS - 1, CH = RS % 3 == 0 ? RS / 3 : RS, CS = 3 * CH;
+  static_assert(KP % (16 * CH) == 0 && CS % RS == 0 && GT >= CH, "panel / ring mismatch");
   const float* A8 = As + 4 * ((threadIdx.x & 63) >> 5);             // &tile[row * LD + 8 (l >> 5)]
-  Split8 X[2][RB];                                                  // the planes of k-group g in X[g & 1]
+  // The planes of the current k-group (HN_SPLIT_DB: and, double-buffered, of the next one -- its split then runs beside this
+  // group's MFMAs instead of in front of its own; 12 RB more registers, which the update kernels do not have)
+#ifndef HN_SPLIT_DB
+#define HN_SPLIT_DB 0
+#endif
+  constexpr int NX = HN_SPLIT_DB ? 2 : 1;
+  Split8 X[NX][RB];
   f32x4 lo[RB], hi[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     lo[rb] = *reinterpret_cast<const f32x4*>(A8 + rb * 32 * LD);
     hi[rb] = *reinterpret_cast<const f32x4*>(A8 + rb * 32 * LD + 4);
-    split8(lo[rb], hi[rb], X[0][rb]);
+    if (HN_SPLIT_DB) split8(lo[rb], hi[rb], X[0][rb]);
   }
-  // Four k-groups = twelve steps per pass of a ROLLED loop (ring slots are then compile-time constants): a fully unrolled chain
-  // kernel is more code than the instruction cache holds, and hipcc's scheduler, handed a whole panel as one region, spills
-  // what the caller keeps in flight around the product.
+  // CH k-groups per pass of a ROLLED loop (ring slots are then compile-time constants): a fully unrolled chain kernel is more
+  // code than the instruction cache holds, and hipcc's scheduler, handed a whole panel as one region, spills what the caller
+  // keeps in flight around the product.
   auto chunk = [&](int g0, bool last) {
 #pragma unroll
     for (int gq = 0; gq < CH; ++gq) {
       const bool has_next = !last || gq + 1 < CH;                   // the panel has a group behind this one
+      if (!HN_SPLIT_DB) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) split8(lo[rb], hi[rb], X[0][rb]);
+      }
       if (has_next) {                                               // its tile values: LDS reads one group ahead
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
@@ -293,10 +307,10 @@ __device__ __forceinline__ void mma_panel(f32x16 (&acc)[RB][NJ], const float* As
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
               acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hn_bf16x8, ring.v[sl % RS][j]),
-                                                                   X[gq & 1][rb].p[m], acc[rb][j], 0, 0, 0);
-        if (ps == 1 && has_next) {                                  // (VALU work beside the matrix pipe's)
+                                                                   X[gq & (NX - 1)][rb].p[m], acc[rb][j], 0, 0, 0);
+        if (HN_SPLIT_DB && ps == 1 && has_next) {                   // (VALU work beside the matrix pipe's)
 #pragma unroll
-          for (int rb = 0; rb < RB; ++rb) split8(lo[rb], hi[rb], X[(gq + 1) & 1][rb]);
+          for (int rb = 0; rb < RB; ++rb) split8(lo[rb], hi[rb], X[(gq + 1) & (NX - 1)][rb]);
         }
       }
     }

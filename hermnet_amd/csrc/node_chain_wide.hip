@@ -22,6 +22,13 @@
 #include <type_traits>
 #include "node_chain_common.h"
 
+// ring slots of the wide family's products: one workgroup per CU, so a wave has nobody to hide a late weight fragment behind --
+// five steps ahead (the 32/64-row kernels of node_chain.hip, two or more workgroups per CU, take two: node_chain_common.h)
+#ifndef HN_RS_WIDE
+#define HN_RS_WIDE 6
+#endif
+constexpr int kRSW = HN_RS_WIDE;
+
 namespace {
 
 template <int H_>
@@ -51,8 +58,8 @@ struct Blocks {
 
 // acc[0][j] += W_{blocks} . A^T over K panel `KP` for all NP blocks at once
 template <int KP, int LD, int NP, bool MORE, bool PIN = true>
-__device__ __forceinline__ void mma_all(f32x16 (&acc)[1][NP], const float* As, const f32x4* const (&bp)[NP], BRing<NP, 4>& ring) {
-  mma_panel<KP, LD, 1, NP, 4, MORE, PIN>(acc, As, bp, ring);
+__device__ __forceinline__ void mma_all(f32x16 (&acc)[1][NP], const float* As, const f32x4* const (&bp)[NP], BRing<NP, kRSW>& ring) {
+  mma_panel<KP, LD, 1, NP, kRSW, MORE, PIN>(acc, As, bp, ring);
 }
 
 // =====================================================================================================================
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void node_pre_fwd_wide_kernel(PreFwdArgs a)
   const f32x4* bp1[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) bp1[j] = w1 + (size_t)B.cbc[j] * frag_f4(H);
-  BRing<NP, 4> r1;
+  BRing<NP, kRSW> r1;
   b_preload(r1, bp1);
 
   // ---- LayerNorm without affine (rmnet.py:52): 8 adjacent lanes share a row, statistics over the first Hr channels
@@ -142,11 +149,11 @@ __global__ __launch_bounds__(256, 1) void node_pre_fwd_wide_kernel(PreFwdArgs a)
       const f32x4* bp2[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) bp2[p] = w2 + (size_t)(p * CB + B.cb[j]) * frag_f4(H);
-      BRing<3, 4> r2;
+      BRing<3, kRSW> r2;
       b_preload(r2, bp2);
       f32x16 acc2[1][3];
       zero_acc(acc2);
-      mma_panel<H, LD, 1, 3, 4, false, HN_PIN_PRE>(acc2, As, bp2, r2);
+      mma_panel<H, LD, 1, 3, kRSW, false, HN_PIN_PRE>(acc2, As, bp2, r2);
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         const int cblk = p * H + B.cb[j] * 32;
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void node_pre_bwd_wide_kernel(PreBwdArgs a)
     bpa[j] = w2t + (size_t)B.cbc[j] * frag_f4(3 * H);
     bpb[j] = w1t + (size_t)B.cbc[j] * frag_f4(H);
   }
-  BRing<NP, 4> ra;
+  BRing<NP, kRSW> ra;
   b_preload(ra, bpa);
   const rsrc_t gxh_r = tile_rsrc(a.gxh + ((size_t)t * a.Ns + row0) * 3 * H, nrows * 3 * H);
   const rsrc_t hb_r = tile_rsrc(a.hb + ((size_t)t * a.Ns + row0) * H, nrows * H);
@@ -213,12 +220,12 @@ __global__ __launch_bounds__(256, 1) void node_pre_bwd_wide_kernel(PreBwdArgs a)
     const f32x4* bpk[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) bpk[j] = bpa[j] + (size_t)kc * frag_f4(KC);
-    mma_panel<KC, LDC, 1, NP, 4, decltype(more)::value>(acc, As, bpk, ra);
+    mma_panel<KC, LDC, 1, NP, kRSW, decltype(more)::value>(acc, As, bpk, ra);
   };
 #pragma unroll 1
   for (int kc = 0; kc < NCH - 1; ++kc) chunk(kc, std::true_type());     // the weight stream continues behind the chunk
   chunk(NCH - 1, std::false_type());
-  BRing<NP, 4> rb_;
+  BRing<NP, kRSW> rb_;
   b_preload(rb_, bpb);
   __syncthreads();                                   // the chunk buffers are free
   // ---- gh = ga * ScaledSiLU'(hb) -> tile
@@ -303,11 +310,11 @@ __global__ __launch_bounds__(256, 1) void node_update_fwd_wide_kernel(UpdFwdArgs
     for (int j = 0; j < NP; ++j)
       if (B.ok[j]) {
         const f32x4* bpv[2] = {wv + (size_t)B.cb[j] * frag_f4(H), wv + (size_t)(CB + B.cb[j]) * frag_f4(H)};
-        BRing<2, 4> rv;
+        BRing<2, kRSW> rv;
         b_preload(rv, bpv);
         f32x16 accv[1][2];
         zero_acc(accv);
-        mma_panel<H, LD, 1, 2, 4, false>(accv, buf + mrow * LD + ch, bpv, rv);
+        mma_panel<H, LD, 1, 2, kRSW, false>(accv, buf + mrow * LD + ch, bpv, rv);
         f32x4 v1[4], v2[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void node_update_fwd_wide_kernel(UpdFwdArgs
   const f32x4* bpx[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) bpx[j] = wx0 + (size_t)B.cbc[j] * frag_f4(2 * H);
-  BRing<NP, 4> rx;
+  BRing<NP, kRSW> rx;
   b_preload(rx, bpx);
   __syncthreads();
   // ---- h2 = xin Wx0^T + bx0 (K = 2H: two panels) on all blocks of the wave
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void node_update_fwd_wide_kernel(UpdFwdArgs
     const f32x4* bpq[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) bpq[p] = wx2 + (size_t)(p * CB + cb) * frag_f4(H);
-    BRing<3, 4> rq;
+    BRing<3, kRSW> rq;
     b_preload(rq, bpq);
     BlockLoad lvv[3], lv1[3], lv2[3];
 #pragma unroll
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(256, 1) void node_update_fwd_wide_kernel(UpdFwdArgs
     fence_sched();
     f32x16 accq[1][3];
     zero_acc(accq);
-    mma_panel<H, LD, 1, 3, 4, false>(accq, lds + mrow * LD + ch, bpq, rq);
+    mma_panel<H, LD, 1, 3, kRSW, false>(accq, lds + mrow * LD + ch, bpq, rq);
     fence_sched();
     f32x4 q[4], r[4], xo[4], dot[4], v1d[3][4];
 #pragma unroll
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void node_update_bwd_wide_kernel(UpdBwdArgs
     bpa[j] = wx2t + (size_t)B.cbc[j] * frag_f4(3 * H);
     bpg[j] = wvt + (size_t)B.cbc[j] * frag_f4(2 * H);
   }
-  BRing<NP, 4> ra;
+  BRing<NP, kRSW> ra;
   b_preload(ra, bpa);
   const int mrow = lane & 31, ch = 4 * (lane >> 5);
   const float inv_sqrt_h = rsqrtf((float)H);
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void node_update_bwd_wide_kernel(UpdBwdArgs
     const int cb = wave + 4 * j;
     if (cb >= CB) break;
     const f32x4* bpx[2] = {wx0t + (size_t)cb * frag_f4(H), wx0t + (size_t)(CB + cb) * frag_f4(H)};
-    BRing<2, 4> rx;
+    BRing<2, kRSW> rx;
     b_preload(rx, bpx);
     BlockLoad lgx, lnr;
     issue_block<H>(lgx, lane, gxo_r, cb * 32);
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void node_update_bwd_wide_kernel(UpdBwdArgs
       set_run4(accx[0][0], g, gxv[g] * onr);
       set_run4(accx[0][1], g, (f32x4){0.f, 0.f, 0.f, 0.f});
     }
-    mma_panel<H, LD, 1, 2, 4, false>(accx, buf1 + mrow * LD + ch, bpx, rx);
+    mma_panel<H, LD, 1, 2, kRSW, false>(accx, buf1 + mrow * LD + ch, bpx, rx);
     f32x4 v[4], gn_[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -580,7 +587,7 @@ __global__ __launch_bounds__(256, 1) void node_update_bwd_wide_kernel(UpdBwdArgs
       }
   }
   // ---- gvec1[d] = gv[d] + (gv1[d] | gv2[d]) Wv,  gv1 = gv q3 + s v2,  gv2 = s v1 + gnn v2  (the accumulator starts at gv[d])
-  BRing<NP, 4> rg;
+  BRing<NP, kRSW> rg;
 #pragma unroll 1
   for (int d = 0; d < 3; ++d) {
     f32x16 accg[1][NP];
