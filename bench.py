@@ -409,12 +409,17 @@ def gemm_flops_per_step(N, nk, H, T, layers):
 
 
 def chain_kernel_bounds(gsum, N, nk, H, T, graph=None):
-    """The node chain kernels against their OWN bound (csrc/node_chain.hip): a launch is a few hundred workgroups,
-    each a fixed number of v_mfma_f32_32x32x2_f32 on the four SIMDs of one CU, so the time cannot go below
-    (most workgroups any CU gets) x (a workgroup's FLOPs) / (256 FLOP/clk per CU): the quantised form of the 155 TF
-    peak for this grid.  `frac` = that bound / measured time per launch; `clock` 2.4 GHz as the peak assumes (the
-    in-kernel clock stamps see ~2.0 GHz under this load: `frac_at_2GHz`)."""
+    """The node chain kernels against their OWN bounds (csrc/node_chain.hip): a launch is a few hundred workgroups, each a fixed
+    number of MFMAs on the four SIMDs of one CU, so the time cannot go below (most workgroups any CU gets) x (a workgroup's
+    matrix-pipe time).  Since round 5 an fp32 product runs as six bf16 partial products (v_mfma_f32_32x32x16_bf16, 4096
+    FLOP/clk per CU): 6 x the FLOPs at 16 x the rate of the fp32 MFMA (256 FLOP/clk per CU) = 0.375 of its time.  `bound_us` is
+    that quantised bound, `fp32_pipe_bound_us` what the fp32 MFMAs would have needed for the same grid (the kernels now run
+    BELOW it where frac_fp32_pipe > 1), `hbm_bound_us` the launch's algorithmic bytes at 8 TB/s -- the bound the update kernels
+    are closest to now.  `clock` 2.4 GHz as the peaks assume."""
     cus, flop_per_clk_cu = 256, 256.0
+    io_floats_per_row = {"node_pre_fwd": 5.0 * T * H, "node_pre_bwd": 5.0 * T * H, "node_update_fwd": 24.0 * H,
+                         "node_update_bwd": (27.0 + 4.0 * T) * H}
+    rows_of = {"node_pre_fwd": N, "node_pre_bwd": N, "node_update_fwd": nk, "node_update_bwd": nk}
     from hermnet_amd import nodeops
     tr_pre, tr_upd = nodeops.chain_tile_rows(H), nodeops.chain_tile_rows(H, update=True)
     if graph is not None:          # the update kernels' tile height is picked per row layout (16-row form on small grids)
@@ -429,11 +434,14 @@ def chain_kernel_bounds(gsum, N, nk, H, T, graph=None):
             continue
         ms = gsum[name][1]
         per_cu = (grid + cus - 1) // cus
-        bound_us = per_cu * flops_wg / flop_per_clk_cu / 2.4e9 * 1e6
+        fp32_us = per_cu * flops_wg / flop_per_clk_cu / 2.4e9 * 1e6
+        bound_us = fp32_us * 6.0 / 16.0
+        hbm_us = io_floats_per_row[name] * 4.0 * rows_of[name] / 8e12 * 1e6
         out[name] = {"workgroups": grid, "tile_rows": tr_upd if "update" in name else tr_pre, "most_per_cu": per_cu,
                      "gflop_per_launch": grid * flops_wg / 1e9,
                      "bound_us": bound_us, "measured_us": ms * 1e3, "frac": bound_us / (ms * 1e3),
-                     "frac_at_2GHz": bound_us * 1.2 / (ms * 1e3)}
+                     "fp32_pipe_bound_us": fp32_us, "frac_fp32_pipe": fp32_us / (ms * 1e3),
+                     "hbm_bound_us": hbm_us, "frac_hbm": hbm_us / (ms * 1e3)}
     return out
 
 
@@ -936,14 +944,21 @@ def main():
                 "gflop_per_step": gflop, "ms_per_step": gemm_ms, "launches_per_step": sum(c for c, _ in gsum.values()) / 3.0,
                 "achieved_TFLOPs": (gflop / gemm_ms) if gemm_ms > 0 else None, "peak_TFLOPs_fp32_mfma": FP32_MFMA_PEAK_TF,
                 "mfma_util": (gflop / gemm_ms / FP32_MFMA_PEAK_TF) if gemm_ms > 0 else None,
+                "arithmetic": "fp32 values and fp32 accumulation; every product runs as a three-way bf16 split of both operands, "
+                              "the six largest partial products on v_mfma_f32_{32x32x16,16x16x32}_bf16 (fp32-equivalent: the "
+                              "dropped terms are <= 2^-24 of a product; 6 / 16 of the fp32 MFMA's pipe time). gflop_per_step and "
+                              "mfma_util count the ALGORITHMIC fp32 FLOPs against the fp32 matrix peak",
+                "bf16_pipe": {"executed_gflop_per_step": 6.0 * gflop, "peak_TFLOPs_bf16_dense": 2500.0,
+                              "util": (6.0 * gflop / gemm_ms / 2500.0) if gemm_ms > 0 else None},
                 "own_roofline": chain_kernel_bounds(gsum, N, nk, H, T, data.get("_hn_graph")),
-                "own_roofline_note": "per chain kernel: (most workgroups on one CU) x (FLOPs of a workgroup) / 256 FLOP/clk "
-                                     "at 2.4 GHz = what the fp32 matrix pipe allows THIS grid; frac = bound / measured"}
+                "own_roofline_note": "per chain kernel: bound_us = (most workgroups on one CU) x (a workgroup's bf16-pipe time at "
+                                     "4096 FLOP/clk per CU, 2.4 GHz); fp32_pipe_bound_us = the same grid on the fp32 MFMAs; "
+                                     "hbm_bound_us = algorithmic bytes of the launch at 8 TB/s; frac* = bound / measured"}
         if H == 128 and os.environ.get("HERMNET_DEFER_SUMS", "1") != "0" and not sharded:
             mfma["note_pending_grads"] = ("node_update_bwd of layers 0..L-2 also forms its incoming gradients from the partial sums "
                                           "of the layer above (hn_pending_grads: what message_bwd_finish + layernorm_bwd_parts did "
                                           "in two launches outside this section): +12-15 us per launch of memory-bound work counted "
-                                          "here, 1 % off the step; HERMNET_DEFER_SUMS=0 gives the separate launches (mfma_util 0.50)")
+                                          "here, 1 % off the step; HERMNET_DEFER_SUMS=0 gives the separate launches")
         names = {"c2": "configs[1]: %d-atom 3-element fcc alloy (Al/Ni/Cu)",
                  "c4": "configs[3]: FIXED %d-atom 3-element fcc alloy cell (10x10x250, 36x36x900 A)",
                  "weak": "weak-scaling variant: %d-atom 3-element fcc alloy cell (10x10x25N)"}

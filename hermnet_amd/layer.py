@@ -284,16 +284,19 @@ _PRE_NEXT = {}
 def _boundary_mode():
     """HERMNET_FUSE_BOUNDARY -- how the node launches of a layer boundary are cut, where `nodeops.fused_boundary_supported`
     (width 128, 16-row update tiles, HVNet rows: csrc/node_chain16.hip):
-      4 (default)  the BACKWARD boundary as one launch: the projection's backward of layer l + 1 runs inside the update backward
+      0 (default)  every phase a launch of its own: 64-row projection kernels + 16-row update kernels, the input gradients handed
+                   down as partial sums (the round-4 form);
+      4            the BACKWARD boundary as one launch: the projection's backward of layer l + 1 runs inside the update backward
                    of layer l (sums over the relations in registers, LayerNorm backward on the tile: no [T, N, H] partial sums in
-                   memory); the forward keeps its two launches (64-row projection kernel + 16-row update kernel);
+                   memory);
       1            both boundaries as one launch each (the next layer's projection inside the update launch as well);
-      3            only the forward boundary;    0   neither (the round-4 form);
+      3            only the forward boundary;
       2            the 16-row phases of mode 1 as launches of their own (the bit-for-bit check of the fused kernels).
-    Measured in the model (configs[1], one box, three interleaved rounds, profiles/r05_boundary_ab.log): 0: 2.944, 4: 2.945,
-    3: 2.971, 1: 2.988 ms per step -- the fused forward loses what the 64-row projection kernel gains from its four-times smaller
-    weight stream; the fused backward is as fast as its two launches and saves four launches and 60 MB of traffic per step."""
-    return int(_os.environ.get("HERMNET_FUSE_BOUNDARY", "4"))
+    Measured in the model (configs[1], one box, three interleaved rounds).  With fp32 MFMAs (profiles/r05_boundary_ab.log):
+    0: 2.944, 4: 2.945, 3: 2.971, 1: 2.988 ms per step.  Since the products run as bf16 splits (profiles/r05_boundary_ab_split.log):
+    0: 2.80, 4: 2.82, 3: 2.87, 1: 2.89 -- with the matrix pipe 2.7 x cheaper a tile's time is its weight stream, and a 64-row
+    projection tile streams a quarter of the bytes per row of a 16-row one: the fused forms lose what that gains."""
+    return int(_os.environ.get("HERMNET_FUSE_BOUNDARY", "0"))
 
 
 class FusedRelationalLayer(torch.autograd.Function):

@@ -16,7 +16,8 @@
  *   - float = IEEE fp32 (the reference is fp32-only), indices = int32 (int64 where a parameter says so:
  *     the caller's edge_index / atomic_number / halo index lists arrive as torch LongTensors).
  *
- * ABI version 10 (`hermnet_abi_version`): v10 adds hermnet_shard_step_flags; v9 added the fused layer-boundary node kernels (hermnet_node_update_pre_fwd, the `gxh`
+ * ABI version 11 (`hermnet_abi_version`): v11 changes the weight fragment formats of the node chain kernels (three bf16 planes:
+ * see "chain kernels on the matrix pipe"); v10 adds hermnet_shard_step_flags; v9 added the fused layer-boundary node kernels (hermnet_node_update_pre_fwd, the `gxh`
  * form of hn_pending_grads, hermnet_node_pre_fwd16 / _bwd16) and hermnet_param_guard; v8 the gradients handed down as partial sums
  * (hn_pending_grads); v7 adds the row windows of the message kernels (interior / boundary launches
  * around the halo exchange), node chain kernels for every width that is a multiple of 64 up to 512, hermnet_stream_copy, and drops
@@ -353,13 +354,18 @@ int hermnet_energy_head16_fwd(const float* x, const float* w0_frag16, const floa
 int hermnet_energy_head16_bwd(const float* ge, const float* h, const float* w0t_frag16, const float* w2,
                               const float* row_mask, float* gx, int rows, int hidden, int cols, void* stream);
 
-/* ---- A7 (node MLP) + A11 + A12 as chain kernels on the fp32 matrix pipe (csrc/node_chain.hip) -----------------------
+/* ---- A7 (node MLP) + A11 + A12 as chain kernels on the matrix pipe (csrc/node_chain.hip) ---------------------------------
  * One launch per chain instead of library GEMMs joined by elementwise launches; hidden activations never reach HBM.
- * hidden must be 64, 128 or 256 (hermnet_node_chain_supported; other widths: the stage-wise entry points above around
- * the caller's GEMMs).  Weights arrive in FRAGMENT ORDER: for an nn.Linear weight W [out, in] (or its transpose for
- * the backward products), frag(W)[((cb * in/8 + q) * 64 + l) * 4 + e] = W[32 cb + (l & 31)][8 q + 4 (l >> 5) + e],
- * i.e. W.view(out/32, 32, in/8, 2, 4).permute(0, 2, 3, 1, 4) -- the B operand registers of v_mfma_f32_32x32x2_f32, so
- * that a wave loads one coalesced KiB per k-group straight into the operand.  `[T]` = stacked over the relations.
+ * hidden must be a multiple of 64 up to 512 (hermnet_node_chain_supported; other widths: the stage-wise entry points above
+ * around the caller's GEMMs).  fp32 in, fp32 out, fp32 accumulation; since ABI v11 every product runs on the BF16 matrix pipe
+ * as a three-way split of both operands (x = x0 + x1 + x2 exactly, bf16 planes, round to nearest even of what the planes
+ * before leave; the six largest of the nine partial products, the dropped ones <= 2^-24 of a product each: fp32-equivalent at
+ * 6/16 of the fp32 MFMA's pipe time).  Weights arrive split and in FRAGMENT ORDER: for an nn.Linear weight W [out, in] (or
+ * its transpose for the backward products), per 32-row block cb and 16-deep k-group Q the three planes, smallest first, as
+ * v_mfma_f32_32x32x16_bf16 operands -- lane l: 8 bf16 = 16 bytes --
+ *     frag(W)[((cb * in/16 + Q) * 3 + s) * 64 + l] = W_(2-s)[32 cb + (l & 31)][16 Q + 8 (l >> 5) .. +7]
+ * (out * in * 3 / 2 floats, 6 bytes per weight; hermnet_amd/nodeops.py: weight_fragments), so that a wave loads one coalesced
+ * KiB per step straight into the operand.  `[T]` = stacked over the relations.
  *
  * hermnet_node_pre_fwd   (rmnet.py:52): for every relation t and source row,
  *     hb[t] = LayerNorm(x) W1_t^T + b1_t   (LayerNorm without affine: folded into W1 / b1 by the host; statistics over
@@ -401,8 +407,9 @@ int hermnet_node_pre_bwd(const float* gxh, const float* hb, const float* w2t_fra
  * hermnet_node_update_bwd: (gx_out, gvec_out) -> (gx1, gvec1), the gradients w.r.t. x1 / vec1 (parameters are
  *     constants); wx2t_frag = frag(Wx2^T [H,3H]), wx0t_frag = frag(Wx0^T [2H,H]), wvt_frag = frag(Wv^T [H,2H]).
  * tile_rows (ABI v7): 0 = the width's default row tile (32; 64 at hidden 64); 16 = the 16-row form (hidden 128 only:
- *     v_mfma_f32_16x16x4_f32, csrc/node_chain16.hip) -- every *_frag argument must then be the frag16 copy of the weight,
- *     frag16(W)[((b * K/16 + Q) * 64 + l) * 4 + e] = W[16 b + (l & 15)][16 Q + 4 (l >> 4) + e].
+ *     v_mfma_f32_16x16x32_bf16, csrc/node_chain16.hip) -- every *_frag argument must then be the frag16 copy of the weight,
+ *     frag16(W)[((b * K/32 + Q) * 3 + s) * 64 + l] = 8 bf16 W_(2-s)[16 b + (l & 15)][32 Q + 8 (l >> 4) .. +7]
+ *     (nodeops.weight_fragments16).
  *     hermnet_node_update_tile_rows says which form shortens the launch for a row layout (small grids: 32-row tiles
  *     leave most CUs with one workgroup while a few get two; 16-row tiles cost twice the weight bytes from L2).
  * pending (ABI v8; may be NULL): the incoming gradients of this layer's outputs have not been formed yet -- they still sit
