@@ -94,20 +94,36 @@ constexpr size_t frag16_floats(size_t O, size_t K) { return O * K * 3 / 2; }
 // acc[j] += W_j[:, 0 .. KP) . A^T; `As`: this lane's LDS pointer &tile[(l & 15) * LD + 4 (l >> 4)] (the tile is fp32).
 // The ring holds steps 0 .. RS-2 on entry; MORE: the stream continues behind the panel (its first RS-1 steps are
 // requested and sit in slots 0 .. RS-2 on exit).
-template <int KP, int NB, bool MORE>
-__device__ __forceinline__ void mma16_panel(f32x4 (&acc)[NB], const float* As, const f32x4* const (&bp)[NB], Ring16<NB>& ring) {
-  constexpr int GT = KP / 32, NSTEP = 3 * GT, RS = ring16(NB), PF = RS - 1;
+// RB row blocks share every weight fragment: acc[rb][j] += W_j . A_rb^T for RB activation tiles (`As[rb]`: this lane's pointer
+// into tile rb).  A fragment then feeds RB x (1 .. 3) MFMAs -- the weight stream, which is what a 16-row tile's time is made of
+// (see the knock-outs above), is paid once for RB tiles.  RB > 1 keeps ONE set of planes per tile (split in front of the
+// group's MFMAs); RB = 1 double-buffers them (the split runs beside the previous group's MFMAs).
+template <int KP, int NB, int RB, bool MORE>
+__device__ __forceinline__ void mma16_panel_rb(f32x4 (&acc)[RB][NB], const float* const (&As)[RB], const f32x4* const (&bp)[NB],
+                                               Ring16<NB>& ring) {
+  constexpr int GT = KP / 32, NSTEP = 3 * GT, RS = ring16(NB), PF = RS - 1, NX = RB == 1 ? 2 : 1;
   static_assert(KP % 32 == 0 && (!MORE || NSTEP % RS == 0), "panel / ring mismatch");
-  const float* A8 = As + 4 * ((threadIdx.x & 63) >> 4);          // &tile[(l & 15) * LD + 8 (l >> 4)]
-  f32x4 lo = *reinterpret_cast<const f32x4*>(A8), hi = *reinterpret_cast<const f32x4*>(A8 + 4);
-  Split8 X[2];
-  split8(lo, hi, X[0]);
+  const int g4 = 4 * ((threadIdx.x & 63) >> 4);                 // As + g4 = &tile[(l & 15) * LD + 8 (l >> 4)]
+  f32x4 lo[RB], hi[RB];
+  Split8 X[NX][RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    lo[rb] = *reinterpret_cast<const f32x4*>(As[rb] + g4);
+    hi[rb] = *reinterpret_cast<const f32x4*>(As[rb] + g4 + 4);
+    if (NX == 2) split8(lo[rb], hi[rb], X[0][rb]);
+  }
 #pragma unroll
   for (int Q = 0; Q < GT; ++Q) {
-    const Split8& x = X[Q & 1];
+    if (NX == 1) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) split8(lo[rb], hi[rb], X[0][rb]);
+    }
     if (Q + 1 < GT) {
-      lo = *reinterpret_cast<const f32x4*>(A8 + 32 * (Q + 1));
-      hi = *reinterpret_cast<const f32x4*>(A8 + 32 * (Q + 1) + 4);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        lo[rb] = *reinterpret_cast<const f32x4*>(As[rb] + g4 + 32 * (Q + 1));
+        hi[rb] = *reinterpret_cast<const f32x4*>(As[rb] + g4 + 32 * (Q + 1) + 4);
+      }
     }
 #pragma unroll
     for (int ps = 0; ps < 3; ++ps) {                 // the step of weight plane 2 - ps
@@ -120,11 +136,23 @@ __device__ __forceinline__ void mma16_panel(f32x4 (&acc)[NB], const float* As, c
 #pragma unroll
       for (int m = ps; m >= 0; --m)                  // activation planes ps .. 0: the smaller partial products first
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hn_bf16x8, ring.v[n % RS][j]), x.p[m], acc[j], 0, 0, 0);
-      if (ps == 1 && Q + 1 < GT) split8(lo, hi, X[(Q + 1) & 1]);   // (VALU work beside the matrix pipe's)
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+            acc[rb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hn_bf16x8, ring.v[n % RS][j]),
+                                                                 X[Q & (NX - 1)][rb].p[m], acc[rb][j], 0, 0, 0);
+      if (NX == 2 && ps == 1 && Q + 1 < GT) {        // (VALU work beside the matrix pipe's)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) split8(lo[rb], hi[rb], X[(Q + 1) & 1][rb]);
+      }
     }
   }
+}
+
+template <int KP, int NB, bool MORE>
+__device__ __forceinline__ void mma16_panel(f32x4 (&acc)[NB], const float* As, const f32x4* const (&bp)[NB], Ring16<NB>& ring) {
+  const float* const as1[1] = {As};
+  mma16_panel_rb<KP, NB, 1, MORE>(reinterpret_cast<f32x4 (&)[1][NB]>(acc), as1, bp, ring);
 }
 
 // Coalesced store / load of this wave's [16 rows][32 channels] block pair through the wave-private scratch: lane l owns
@@ -319,9 +347,9 @@ template <int H, bool FUSE>
 __global__ __launch_bounds__(256, HN_U16_MINW_FWD) void node_update_fwd16_kernel(UpdFwdArgs a, PreFwdArgs p) {
   static_assert(H == 128, "four waves x 32 channels");
   constexpr int TR = kTR16, LD = H + 8, NB16 = H / 16;       // NB16: 16-channel blocks per part
-  extern __shared__ __align__(16) float lds[];               // 2 (FUSE: 3) x [TR][LD], then 4 x [16][36] scratch
+  extern __shared__ __align__(16) float lds[];               // 3 x [TR][LD], then 4 x [16][36] scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* scr = lds + (FUSE ? 3 : 2) * TR * LD + wave * kScr16Floats;
+  float* scr = lds + 3 * TR * LD + wave * kScr16Floats;
   const TileInfo ti = find_tile(a.type_rowptr, a.T, a.N, TR, blockIdx.x);
   const int row0 = ti.row0, nrows = ti.nrows, t = ti.t;
   if (t >= a.T) {                                 // rows of unknown elements: zero
@@ -375,49 +403,54 @@ __global__ __launch_bounds__(256, HN_U16_MINW_FWD) void node_update_fwd16_kernel
   // 24 registers held across the whole kernel were what kept a third workgroup off the CU)
   STAMP(0);
   STAMP_HWID();
+  // Round 5, second half: the three components in ONE product (three activation tiles per weight fragment): Wv was streamed
+  // once per component -- 144 of the kernel's 264 fragment requests per wave, and the requests are what a tile's time is made of.
   Tile16Regs<H> regs;
-  tile16_load<H>(regs, vec1_r, 3 * H, 0, tid);
   Ring16<4> rv;
   b16_preload(rv, bpv);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    tile16_load<H>(regs, vec1_r, 3 * H, d * H, tid);
+    tile16_store<H, LD>(lds + d * TR * LD, regs, tid);
+  }
+  __syncthreads();
+  tile16_load<H>(regs, x1_r, H, 0, tid);               // (in flight during the product)
   // (accumulators START at their bias -- a lane's float4 of a block is exactly the bias float4 of its channels --, loaded
   // in front of the preceding epilogue's stores: vmcnt retires in order, a bias load issued behind stores waits for them)
   f32x4 acch[2], accq[6];
+  {
+    f32x4 accv[3][4];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    float* buf = lds + (d & 1) * TR * LD;
-    tile16_store<H, LD>(buf, regs, tid);
-    __syncthreads();
-    if (d < 2) tile16_load<H>(regs, vec1_r, 3 * H, (d + 1) * H, tid);
-    else tile16_load<H>(regs, x1_r, H, 0, tid);
-    f32x4 accv[4] = {zero4(), zero4(), zero4(), zero4()};
-    mma16_panel<H, 4, false>(accv, buf + mrow * LD + ch, bpv, rv);
-    if (d < 2) b16_preload(rv, bpv);
-    if (d == 2) {
+    for (int d = 0; d < 3; ++d)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) acch[s] = ld4g(a.bx0 + (size_t)t * H + cw + 16 * s + ch);
-    }
+      for (int b = 0; b < 4; ++b) accv[d][b] = zero4();
+    const float* const asv[3] = {lds + mrow * LD + ch, lds + TR * LD + mrow * LD + ch, lds + 2 * TR * LD + mrow * LD + ch};
+    mma16_panel_rb<H, 4, 3, false>(accv, asv, bpv, rv);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acch[s] = ld4g(a.bx0 + (size_t)t * H + cw + 16 * s + ch);
     fence_sched();
-    f32x4 v1[2] = {accv[0], accv[1]}, v2[2] = {accv[2], accv[3]};
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      dot[s] += v1[s] * v2[s];
-      sq[s] += v2[s] * v2[s];
-      // (the sums are formed HERE: left alone, hipcc sinks them to their first use behind the last product and keeps the v1 / v2
-      // of all three components alive -- spilled -- until then: node_chain_common.h, pin)
-      pin4(dot[s]);
-      pin4(sq[s]);
+    for (int d = 0; d < 3; ++d) {
+      f32x4 v1[2] = {accv[d][0], accv[d][1]}, v2[2] = {accv[d][2], accv[d][3]};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        dot[s] += v1[s] * v2[s];
+        sq[s] += v2[s] * v2[s];
+        pin4(dot[s]);
+        pin4(sq[s]);
+      }
+      store16<6 * H>(scr, lane, v1, vp_r, d * 2 * H + cw);
+      store16<6 * H>(scr, lane, v2, vp_r, d * 2 * H + H + cw);
     }
-    store16<6 * H>(scr, lane, v1, vp_r, d * 2 * H + cw);
-    store16<6 * H>(scr, lane, v2, vp_r, d * 2 * H + H + cw);
-    STAMP(1 + d);
+    STAMP(3);
   }
-  // ---- xin = [x1 | sqrt(|v2|^2 + 1e-8)]: x1 -> buffer 1 (free since the product of d = 1), the norm -> buffer 0
+  // ---- xin = [x1 | sqrt(|v2|^2 + 1e-8)]: x1 -> buffer 1, the norm -> buffer 0
   float* bufx = lds + TR * LD;
   float* bufn = lds;
-  tile16_store<H, LD>(bufx, regs, tid);
   Ring16<2> rx;
   b16_preload(rx, bpx);
-  __syncthreads();                                   // every wave has finished the product of d = 2 (buffer 0)
+  __syncthreads();                                   // every wave has finished the product over the three vec tiles
+  tile16_store<H, LD>(bufx, regs, tid);
   {
     f32x4 nv[2];
 #pragma unroll
@@ -927,7 +960,7 @@ int launch_fwd16(bool fuse, int tiles, size_t lds_bytes, void* stream, const Upd
 
 int hn_update16_fwd(int hidden, const UpdFwdArgs& a, int tiles, void* stream) {
   if (hidden != 128) return HN_ERR_BAD_ARG;
-  return launch_fwd16(false, tiles, kLdsUpd16, stream, a, PreFwdArgs{});
+  return launch_fwd16(false, tiles, kLdsFwdFused16, stream, a, PreFwdArgs{});
 }
 
 // update of layer l + node projection of layer l + 1 on the same 16-row tiles (p.x is unused: the rows come from the update)
