@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
     else tile_load<TR, H>(regs, x1_r, H, 0, tid);
     f32x16 accv[RB][2 * CPW];
     zero_acc(accv);
-    mma_panel<H, LD, RB, 2 * CPW, ring_size(RB * 2 * CPW, false), false>(accv, buf + mrow * LD + ch, bpv, rv);
+    mma_panel<H, LD, RB, 2 * CPW, ring_size(RB * 2 * CPW, false), false, true, false>(accv, buf + mrow * LD + ch, bpv, rv);
     STAMP(2 + 3 * d);
     if (d < 2) b_preload(rv, bpv);
     else b_preload(rx, bpx);
@@ -402,8 +402,8 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
     const f32x4* bpx1[CPW];
 #pragma unroll
     for (int j = 0; j < CPW; ++j) bpx1[j] = bpx[j] + (size_t)frag_f4(H);
-    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true>(acch, bufx + mrow * LD + ch, bpx, rx);
-    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), false>(acch, bufn + mrow * LD + ch, bpx1, rx);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true, true, false>(acch, bufx + mrow * LD + ch, bpx, rx);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), false, true, false>(acch, bufn + mrow * LD + ch, bpx1, rx);
   }
   STAMP(11);
   BRing<3 * CPW, ring_size(RB * 3 * CPW, false)> rq;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
   STAMP(12);
   f32x16 accq[RB][3 * CPW];
   zero_acc(accq);
-  mma_panel<H, LD, RB, 3 * CPW, ring_size(RB * 3 * CPW, false), false>(accq, lds + mrow * LD + ch, bpq, rq);
+  mma_panel<H, LD, RB, 3 * CPW, ring_size(RB * 3 * CPW, false), false, true, false>(accq, lds + mrow * LD + ch, bpq, rq);
   STAMP(13);
   fence_sched();
   const float inv_sqrt_h = rsqrtf((float)H);
@@ -577,12 +577,12 @@ __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a
     const f32x4* bp2[CPW];
 #pragma unroll
     for (int j = 0; j < CPW; ++j) { bp1[j] = bpa[j] + (size_t)frag_f4(H); bp2[j] = bpa[j] + (size_t)frag_f4(2 * H); }
-    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true>(acc, buf0 + mrow * LD + ch, bpa, ra);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true, true, false>(acc, buf0 + mrow * LD + ch, bpa, ra);
     __syncthreads();                                 // buffer 0 is free
     tile_store<TR, H, LD>(buf0, g3, tid);
-    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true>(acc, buf1 + mrow * LD + ch, bp1, ra);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true, true, false>(acc, buf1 + mrow * LD + ch, bp1, ra);
     __syncthreads();                                 // third part in place, buffer 1 free
-    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), false>(acc, buf0 + mrow * LD + ch, bp2, ra);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), false, true, false>(acc, buf0 + mrow * LD + ch, bp2, ra);
   }
   BRing<2 * CPW, ring_size(RB * 2 * CPW, false)> rx;
   b_preload(rx, bpx);
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a
   HN_REQUEST(0)
   fence_sched();
   __syncthreads();
-  mma_panel<H, LD, RB, 2 * CPW, ring_size(RB * 2 * CPW, false), false>(accx, buf1 + mrow * LD + ch, bpx, rx);
+  mma_panel<H, LD, RB, 2 * CPW, ring_size(RB * 2 * CPW, false), false, true, false>(accx, buf1 + mrow * LD + ch, bpx, rx);
   // (weight rings are requested BEFORE the stores of the epilogue in front of their product: vmcnt retires in order)
   BRing<CPW, ring_size(RB * CPW, true)> rg;
   b_preload(rg, bpg);
@@ -703,8 +703,8 @@ __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a
     const f32x4* bpg1[CPW];
 #pragma unroll
     for (int j = 0; j < CPW; ++j) bpg1[j] = bpg[j] + (size_t)frag_f4(H);
-    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true>(accg, buf0 + mrow * LD + ch, bpg, rg);
-    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), false>(accg, buf1 + mrow * LD + ch, bpg1, rg);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), true, true, false>(accg, buf0 + mrow * LD + ch, bpg, rg);
+    mma_panel<H, LD, RB, CPW, ring_size(RB * CPW, true), false, true, false>(accg, buf1 + mrow * LD + ch, bpg1, rg);
     if (d < 2) b_preload(rg, bpg);
     fence_sched();
     if (d < 2) { HN_ARRIVE(d + 1) }

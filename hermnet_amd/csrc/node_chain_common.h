@@ -251,26 +251,32 @@ __device__ __forceinline__ void b_preload(BRing<NJ, RS>& r, const f32x4* const (
 #ifndef HN_PIN_PRE
 #define HN_PIN_PRE false     // the pre-forward kernels' products
 #endif
-template <int KP, int LD, int RB, int NJ, int RS, bool MORE, bool PIN = true>
+// DB: the activation planes of the NEXT k-group are split beside this group's MFMAs (a second set of planes: 12 RB more
+// registers -- the projection kernels have them, the update kernels, at their 256-register budgets, do not and pass false).
+#ifndef HN_SPLIT_DB
+#define HN_SPLIT_DB 1
+#endif
+template <int KP, int LD, int RB, int NJ, int RS, bool MORE, bool PIN = true, bool DBT = true>
 __device__ __forceinline__ void mma_panel(f32x16 (&acc)[RB][NJ], const float* As, const f32x4* const (&bp)[NJ],
                                           BRing<NJ, RS>& ring) {
-  // k-groups; groups / steps of one pass of the rolled loop (the fewest groups whose steps fill whole turns of the ring)
-  constexpr int GT = KP / 16, PF = RS - 1, CH = RS % 3 == 0 ? RS / 3 : RS, CS = 3 * CH;
+  constexpr bool DB = DBT && HN_SPLIT_DB;
+  // k-groups; groups / steps of one pass of the rolled loop: the fewest groups whose steps fill whole turns of the ring -- an
+  // EVEN number of them when the planes are double-buffered (a group's buffer is then a compile-time constant too)
+  constexpr int CH0 = RS % 3 == 0 ? RS / 3 : RS;
+  constexpr int GT = KP / 16, PF = RS - 1, CH = (DB && CH0 % 2) ? 2 * CH0 : CH0, CS = 3 * CH;
   static_assert(KP % (16 * CH) == 0 && CS % RS == 0 && GT >= CH, "panel / ring mismatch");
   const float* A8 = As + 4 * ((threadIdx.x & 63) >> 5);             // &tile[row * LD + 8 (l >> 5)]
-  // The planes of the current k-group (HN_SPLIT_DB: and, double-buffered, of the next one -- its split then runs beside this
-  // group's MFMAs instead of in front of its own; 12 RB more registers, which the update kernels do not have)
-#ifndef HN_SPLIT_DB
-#define HN_SPLIT_DB 0
-#endif
-  constexpr int NX = HN_SPLIT_DB ? 2 : 1;
+  // The planes of the current k-group and (DB) of the next one: its split runs beside this group's MFMAs instead of in front
+  // of its own (measured: H = 512 node_pre_fwd 412 -> 388 us; nothing at H = 128, where two or three workgroups per CU cover
+  // each other's splits anyway)
+  constexpr int NX = DB ? 2 : 1;
   Split8 X[NX][RB];
   f32x4 lo[RB], hi[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     lo[rb] = *reinterpret_cast<const f32x4*>(A8 + rb * 32 * LD);
     hi[rb] = *reinterpret_cast<const f32x4*>(A8 + rb * 32 * LD + 4);
-    if (HN_SPLIT_DB) split8(lo[rb], hi[rb], X[0][rb]);
+    if (DB) split8(lo[rb], hi[rb], X[0][rb]);
   }
   // CH k-groups per pass of a ROLLED loop (ring slots are then compile-time constants): a fully unrolled chain kernel is more
   // code than the instruction cache holds, and hipcc's scheduler, handed a whole panel as one region, spills what the caller
@@ -279,7 +285,7 @@ __device__ __forceinline__ void mma_panel(f32x16 (&acc)[RB][NJ], const float* As
 #pragma unroll
     for (int gq = 0; gq < CH; ++gq) {
       const bool has_next = !last || gq + 1 < CH;                   // the panel has a group behind this one
-      if (!HN_SPLIT_DB) {
+      if (!DB) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) split8(lo[rb], hi[rb], X[0][rb]);
       }
@@ -308,7 +314,7 @@ __device__ __forceinline__ void mma_panel(f32x16 (&acc)[RB][NJ], const float* As
             for (int j = 0; j < NJ; ++j)
               acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hn_bf16x8, ring.v[sl % RS][j]),
                                                                    X[gq & (NX - 1)][rb].p[m], acc[rb][j], 0, 0, 0);
-        if (HN_SPLIT_DB && ps == 1 && has_next) {                   // (VALU work beside the matrix pipe's)
+        if (DB && ps == 1 && has_next) {                   // (VALU work beside the matrix pipe's)
 #pragma unroll
           for (int rb = 0; rb < RB; ++rb) split8(lo[rb], hi[rb], X[(gq + 1) & (NX - 1)][rb]);
         }

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void node_update_fwd_wide_kernel(UpdFwdArgs
         b_preload(rv, bpv);
         f32x16 accv[1][2];
         zero_acc(accv);
-        mma_panel<H, LD, 1, 2, kRSW, false>(accv, buf + mrow * LD + ch, bpv, rv);
+        mma_panel<H, LD, 1, 2, kRSW, false, true, false>(accv, buf + mrow * LD + ch, bpv, rv);
         f32x4 v1[4], v2[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, 1) void node_update_fwd_wide_kernel(UpdFwdArgs
     fence_sched();
     f32x16 accq[1][3];
     zero_acc(accq);
-    mma_panel<H, LD, 1, 3, kRSW, false>(accq, lds + mrow * LD + ch, bpq, rq);
+    mma_panel<H, LD, 1, 3, kRSW, false, true, false>(accq, lds + mrow * LD + ch, bpq, rq);
     fence_sched();
     f32x4 q[4], r[4], xo[4], dot[4], v1d[3][4];
 #pragma unroll
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void node_update_bwd_wide_kernel(UpdBwdArgs
       set_run4(accx[0][0], g, gxv[g] * onr);
       set_run4(accx[0][1], g, (f32x4){0.f, 0.f, 0.f, 0.f});
     }
-    mma_panel<H, LD, 1, 2, kRSW, false>(accx, buf1 + mrow * LD + ch, bpx, rx);
+    mma_panel<H, LD, 1, 2, kRSW, false, true, false>(accx, buf1 + mrow * LD + ch, bpx, rx);
     f32x4 v[4], gn_[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
