@@ -483,7 +483,9 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restric
   if (r >= n_rows) return;
   const long q0 = rowptr[r], q1 = rowptr[r + 1];
   const int Q = width >> 2;
-  for (int c = l; c < Q; c += LPR) {
+  // (columns beyond the lanes of a row go to further workgroups, blockIdx.y: a sum of a few very wide rows -- the bucketed
+  // projection's weight gradient, 21 rows of 12,288 floats -- was six workgroups walking 48 column groups each)
+  for (int c = blockIdx.y * LPR + l; c < Q; c += LPR * gridDim.y) {
     f4 acc = (f4){0.f, 0.f, 0.f, 0.f};
     long q = q0;
     for (; q + 1 < q1; q += 2) {            // two rows in flight
@@ -508,15 +510,17 @@ extern "C" int hermnet_segment_sum(const float* x, const long* perm, const long*
   const int Q = width >> 2;
   int lpr = 1;
   while (lpr < Q && lpr < 64) lpr <<= 1;
-  const unsigned blocks = (unsigned)((num_rows + (256 / lpr) - 1) / (256 / lpr));
+  const unsigned rblocks = (unsigned)((num_rows + (256 / lpr) - 1) / (256 / lpr));
+  const unsigned cblocks = (unsigned)((Q + lpr - 1) / lpr);
+  const dim3 blocks(rblocks, cblocks < 1024u ? cblocks : 1024u);
   switch (lpr) {
-    case 1: hipLaunchKernelGGL(segment_sum_kernel<1>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
-    case 2: hipLaunchKernelGGL(segment_sum_kernel<2>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
-    case 4: hipLaunchKernelGGL(segment_sum_kernel<4>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
-    case 8: hipLaunchKernelGGL(segment_sum_kernel<8>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
-    case 16: hipLaunchKernelGGL(segment_sum_kernel<16>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
-    case 32: hipLaunchKernelGGL(segment_sum_kernel<32>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
-    default: hipLaunchKernelGGL(segment_sum_kernel<64>, dim3(blocks), dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+    case 1: hipLaunchKernelGGL(segment_sum_kernel<1>, blocks, dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+    case 2: hipLaunchKernelGGL(segment_sum_kernel<2>, blocks, dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+    case 4: hipLaunchKernelGGL(segment_sum_kernel<4>, blocks, dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+    case 8: hipLaunchKernelGGL(segment_sum_kernel<8>, blocks, dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+    case 16: hipLaunchKernelGGL(segment_sum_kernel<16>, blocks, dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+    case 32: hipLaunchKernelGGL(segment_sum_kernel<32>, blocks, dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
+    default: hipLaunchKernelGGL(segment_sum_kernel<64>, blocks, dim3(256), 0, s, x, perm, rowptr, out, num_rows, width); break;
   }
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
