@@ -969,6 +969,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
             "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 inputs, outputs, accumulation and elementwise math everywhere; the node-level matrix products run as "
+                          "exact three-way bf16 splits of both fp32 operands (six partial products, fp32 accumulate: fp32-equivalent, "
+                          "see mfma.arithmetic); parity tests at the reference tolerance 1e-5 unchanged",
             "config": {"workload": (names[cfg] % N_global) + ", HVNet rc=5.0 hidden=128 num_rbf=128 layers=5, E=%d "
                                    "directed edges, energy+forces per step" % E_global,
                        "config": cfg, "atoms_total": N_global, "atoms_owned_rank0": N - halo, "halo_atoms_rank0": halo,
