@@ -654,6 +654,11 @@ def main():
     ap.add_argument("--shard-anyway", action="store_true",
                     help="take the sharded (process-group) code path even with one rank: rehearsal of the RCCL calls "
                          "on a single GPU (launch through torch.distributed.run --nproc-per-node 1)")
+    ap.add_argument("--self-peer", type=int, default=0, metavar="V",
+                    help="one rank whose halo peer is itself (sharding.plan_self_peer, V virtual slabs; V = 1: one slab across "
+                         "the periodic boundary = the load of one rank of an 8-slab plan): the production halo exchange with "
+                         "real rows on ONE GPU over RCCL.  Implies --shard-anyway; world size 1 only")
+    ap.add_argument("--reps", default=None, help="fcc cells nx,ny,nz of the synthetic alloy (default: the config's)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal with several ranks sharing one GPU (exchange staged through the host)")
     ap.add_argument("--launch-rehearsal", action="store_true",
@@ -675,7 +680,13 @@ def main():
         # plain `python bench.py --gpus N`: this process has made no GPU call yet and never will -- it starts the N
         # ranks as fresh children, relays rank 0's line and exits with their code
         raise SystemExit(self_launch(args.gpus, sys.argv[1:], timeout=args.launch_timeout))
-    sharded = world > 1 or args.shard_anyway
+    if args.self_peer and world != 1:
+        raise SystemExit("bench.py --self-peer is a one-rank plan (WORLD_SIZE=%d)" % world)
+    sharded = world > 1 or args.shard_anyway or bool(args.self_peer)
+    if sharded and "RANK" not in os.environ:        # (--shard-anyway / --self-peer started plainly: a one-rank group)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     if args.launch_rehearsal:
         return launch_rehearsal(args, world, rank)
     cfg = args.config if args.config != "auto" else ("c4" if world > 1 else "c2")
@@ -734,6 +745,8 @@ def main():
     for p_ in model.parameters():      # energy/force evaluation: no parameter gradients
         p_.requires_grad_(False)
     reps = {"c2": (10, 10, 25), "c4": (10, 10, 250), "weak": (10, 10, 25 * world)}[cfg]
+    if args.reps:
+        reps = tuple(int(v) for v in args.reps.split(","))
     scaling = "weak" if cfg == "weak" else "strong"
     if sharded:
         # every rank holds the global coordinates (what a calculator is handed per MD step) and plans ITS slab on the
@@ -751,7 +764,8 @@ def main():
         SKIN = 1.0
         # (deferred: no host read per step -- the displacement flag and the padded list's count stay on the device until ONE
         # check() behind the step; the first call of a plan searches exactly, which is also the Data of the timed region)
-        stepper = SlabStepper(gz, gcell, model_kw["rc"], rank, world, skin=SKIN, group=group, deferred=True)
+        stepper = SlabStepper(gz, gcell, model_kw["rc"], rank, world, skin=SKIN, group=group, deferred=True,
+                              self_peer=args.self_peer)
 
         def plan_shard():
             return stepper(gpos)
@@ -976,7 +990,10 @@ def main():
                                    "directed edges, energy+forces per step" % E_global,
                        "config": cfg, "atoms_total": N_global, "atoms_owned_rank0": N - halo, "halo_atoms_rank0": halo,
                        "edges_rank0": E, "tuned_gemm_table": bool(tuned), "gemm_tuning_in_warmup": bool(online_tuning),
-                       "parallelism": "1 GPU" if world == 1 else
+                       "parallelism": ("1 GPU, self-peer plan: %d virtual slab(s), the halo rows exchanged with this rank itself "
+                                       "over %s (all_to_all_single, send_counts = recv_counts = [%d])"
+                                       % (args.self_peer, args.backend, halo)) if args.self_peer else
+                       "1 GPU" if world == 1 else
                        "atom-sharded x%d slabs (slab-local planning), one-hop halo all-to-all per layer over %s"
                        % (world, args.backend)},
             "roofline": {"bound": limiter[dom], "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,

@@ -21,6 +21,10 @@ import torch
 from . import _lib
 
 
+def _no_guard():
+    return None
+
+
 class ParamGuard(object):
     def __init__(self, module):
         self.module = module
@@ -28,11 +32,33 @@ class ParamGuard(object):
         self.armed_for = None           # the cache stamp the fingerprints were recorded for
         self._event = None
         self._flag_host = None
+        self._warned_skipped = False
+
+    # A guard belongs to ONE module instance and holds device state (a HIP event, pinned memory, pointer tables): copies and
+    # pickles of the module get none -- `HVNet._refresh_weights` makes a fresh, unarmed one on the copy's first eval() forward.
+    # (`copy.deepcopy(model)` is how `torch.optim.swa_utils.AveragedModel` and best-model snapshots take their copy;
+    # `torch.save(model)` pickles `module.__dict__`: both met "cannot pickle 'Event' object" before.)
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_no_guard, ())
 
     def _tensors(self):
+        """Every parameter and buffer the fingerprint covers: 32-bit words on the device.  A tensor that is NOT covered (another
+        element size, not contiguous, not on the GPU) is named in a warning once -- a write through `.data` to such a tensor
+        is not detected and needs `model.invalidate_caches()`."""
         m = self.module
-        return [t for t in list(m.parameters()) + list(m.buffers()) if t is not None and t.is_cuda and t.numel() > 0
-                and t.element_size() == 4 and t.is_contiguous()]
+        every = [(n, t) for n, t in list(m.named_parameters()) + list(m.named_buffers()) if t is not None and t.numel() > 0]
+        ok = lambda t: t.is_cuda and t.element_size() == 4 and t.is_contiguous()
+        skipped = [n for n, t in every if not ok(t)]
+        if skipped and not self._warned_skipped:
+            self._warned_skipped = True
+            warnings.warn("hermnet_amd: the stale-cache guard does not cover %d tensor(s) (not 32-bit, not contiguous or not on "
+                          "the GPU): %s -- after writing them through `.data` call model.invalidate_caches()"
+                          % (len(skipped), ", ".join(skipped[:6]) + (" ..." if len(skipped) > 6 else "")),
+                          RuntimeWarning, stacklevel=4)
+        return [t for _, t in every if ok(t)]
 
     def _table(self, dev):
         ts = self._tensors()

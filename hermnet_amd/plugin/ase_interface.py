@@ -110,6 +110,32 @@ def _evaluate(model, data, device, pbc, want_virial, trn_mean=0.0):
     return energy.detach(), forces.detach(), w
 
 
+def _evaluate_finite(model, data, device, pbc, want_virial, trn_mean=0.0):
+    """`_evaluate` + the energy on the host (every caller copies it there anyway), never NaN: the stale-cache guard
+    (`guard.ParamGuard`) answers a write through `.data` behind the cached kernel-ready weights with a NaN step, and ONE NaN
+    force step handed to an integrator corrupts a trajectory for good.  A non-finite energy therefore drops the caches,
+    evaluates again with the current weights (warning once per model), and raises if the result is still not finite."""
+    for attempt in (0, 1):
+        energy, forces, w = _evaluate(model, data, device, pbc, want_virial, trn_mean)
+        e_host = energy.cpu()
+        if bool(torch.isfinite(e_host).all()):
+            return e_host, forces, w
+        if attempt == 0 and hasattr(model, "invalidate_caches"):
+            _warn_repaired(model)
+            model.invalidate_caches()
+    raise FloatingPointError("hermnet_amd: the energy is not finite (%r) also after rebuilding the cached weights: "
+                             "refusing to hand NaN energies / forces to the caller" % (e_host.tolist(),))
+
+
+def _warn_repaired(model):
+    if not model.__dict__.get("_warned_nan_repair"):
+        model.__dict__["_warned_nan_repair"] = True
+        import warnings
+        warnings.warn("hermnet_amd: a step came back NaN (weights written through `.data` behind the cached copies?); the "
+                      "caches were rebuilt and the step re-evaluated.  Call model.invalidate_caches() after such writes.",
+                      RuntimeWarning, stacklevel=3)
+
+
 def model_calc(model, data, device, pbc, ensemble='NVT', trn_mean=0.0, units='metal'):
     """`calculator.py:59-98` / `lmp_calc.py:36-85`: (energy float, forces [N,3] float32, virial [6]).
 
@@ -121,13 +147,13 @@ def model_calc(model, data, device, pbc, ensemble='NVT', trn_mean=0.0, units='me
     if units not in _NKTV2P:
         raise ValueError('Illegal units command')
     npt = ensemble.lower() == 'npt'
-    energy, forces, w = _evaluate(model, data, device, pbc, npt, trn_mean)
+    energy, forces, w = _evaluate_finite(model, data, device, pbc, npt, trn_mean)
     if npt:
         v = (w * _NKTV2P[units]).cpu().numpy()
         virial = np.array([v[0, 0], v[1, 1], v[2, 2], v[0, 1], v[0, 2], v[1, 2]])
     else:
         virial = np.zeros(6, dtype=np.float32)
-    return energy.cpu().item(), forces.cpu().numpy().reshape(-1, 3), virial
+    return energy.item(), forces.cpu().numpy().reshape(-1, 3), virial
 
 
 def stress_from_virial(w, volume):
@@ -192,6 +218,15 @@ class NNCalculator(_Base):
             if not ok:                         # (coordinates many images outside the cell ...): the eager path decides
                 self._graphed = None
                 return None
+        if not np.isfinite(e[0]):
+            # The captured step contains the stale-cache guard's check-and-poison kernel, and a replay cannot read its flag:
+            # after a write through `.data` (an EMA swap) EVERY replay would return NaN.  The results are on the host here:
+            # a NaN drops the caches and the capture, and the eager path evaluates this call again (and raises if the
+            # energy is still not finite) -- NaN forces never reach ASE.
+            _warn_repaired(self.model)
+            self.model.invalidate_caches()
+            self._graphed = None
+            return None
         return float(np.float32(e[0]) + np.float32(self.trn_mean)), f
 
     def calculate(self, atoms, properties=('energy',), system_changes=all_changes):
@@ -220,8 +255,8 @@ class NNCalculator(_Base):
                            reference_compat=self.reference_compat, capacity=cap)
         # stress whenever ASE asks for it (or the ensemble is NPT) on a periodic cell; an open system has none
         want = pbc and cell is not None and (self.ensemble.lower() == 'npt' or 'stress' in tuple(properties))
-        energy, forces, w = _evaluate(self.model, data, self.device_, pbc, want, self.trn_mean)
-        energy = energy.cpu().item()
+        energy, forces, w = _evaluate_finite(self.model, data, self.device_, pbc, want, self.trn_mean)
+        energy = energy.item()
         if dev is not None and cell is not None:
             from ..neighbor import padded_capacity, padded_list_ok
             if cap is not None:

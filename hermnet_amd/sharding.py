@@ -673,6 +673,75 @@ def plan_slab(pos, atomic_number, cell, rc, rank, world, axis=None, group=None, 
     return plan
 
 
+def plan_self_peer(pos, atomic_number, cell, rc, virtual=2, axis=None, group=None, skin=0.0):
+    """A slab plan whose halo peer is THIS rank: the structure is cut into `virtual` equal-count slabs along the slab axis
+    exactly as `plan_slab` cuts it for `virtual` ranks, but all of them live here.  The rank owns every atom; an atom within
+    rc + skin of ANOTHER virtual slab additionally exists as a ghost row per such slab, which is what the targets of that slab
+    read (`slab_data` keeps the pair j -> i only through the instance of j that serves i's slab).  Ghost rows are halo rows in
+    every respect: they are filled by the per-layer exchange -- `all_to_all_single` with send_counts = recv_counts = [k] on a
+    group of ONE rank --, their gradients travel back the same way and are summed into the owners' rows in send-list order.
+
+    Why it exists: one-GPU boxes cannot run two RCCL ranks, so without it the production
+    exchange (asynchronous start, stream wait, in-place unpack, halo re-projection, early / late message ranges, reverse
+    gradient exchange) never carries a row before the first 8-GPU run.  With it all of that executes over RCCL with real
+    payload on one GPU, and the result must equal the unsharded evaluation.  Local order as in `plan_slab`:
+    [interior | owned atoms near a face of their slab | ghosts]."""
+    dev = pos.device
+    n = pos.size(0)
+    V = int(virtual)
+    slab, coord, (lo, hi), axis, margin = slab_owner_device(pos, cell, V, axis)
+    periodic = cell is not None
+    reach = (float(rc) + float(skin)) * margin * (1.0 + 1e-9) + 1e-12
+    if V == 1:
+        # ONE slab whose neighbour through the periodic boundary is itself (what a rank of an 8-slab plan looks like, halo
+        # fraction included): ghosts = the atoms within reach of the slab's faces THROUGH the boundary; a pair uses the
+        # ghost of its source iff it crosses the boundary (`slab_data`: shift along the slab axis != 0)
+        if not periodic:
+            raise ValueError("virtual=1 cuts at the periodic boundary: it needs a cell")
+        ghost = (torch.minimum(torch.remainder(lo[0] - coord, 1.0), torch.remainder(coord - hi[0], 1.0)) <= reach)[None, :]
+    else:
+        near = _within_cutoff_of_slab(coord[None, :], lo[:, None], hi[:, None], reach, periodic)       # [V, N]
+        ghost = near & (slab[None, :] != torch.arange(V, device=dev)[:, None])
+    pairs = torch.nonzero(ghost)                                                   # (served slab, atom), slab-major
+    lo_a, hi_a = lo.index_select(0, slab), hi.index_select(0, slab)
+    near_face = (coord - lo_a <= reach) | (hi_a - coord <= reach)
+    interior = torch.nonzero(~near_face).reshape(-1)
+    boundary = torch.nonzero(near_face).reshape(-1)
+    owned = torch.cat([interior, boundary])
+    local_ids = torch.cat([owned, pairs[:, 1]])
+    g2l = torch.empty(n, dtype=torch.long, device=dev)
+    g2l[owned] = torch.arange(n, device=dev)
+    k = int(pairs.size(0))                                                         # the host read of the plan
+    send_idx = g2l.index_select(0, pairs[:, 1])
+    recv_idx = n + torch.arange(k, device=dev)
+    is_owned = torch.zeros(n + k, dtype=torch.bool, device=dev)
+    is_owned[:n] = True
+    plan = ShardPlan(0, 1, owned, pairs[:, 1].contiguous(), ExchangePlan(send_idx, [k], recv_idx, [k], group),
+                     is_owned, 1, group)
+    plan.owned_local = torch.arange(n, device=dev)
+    plan.local_global = local_ids
+    plan.rc, plan.skin = float(rc), float(skin)
+    plan.pos_ref = pos.detach().clone()
+    plan.z_local = atomic_number[local_ids]
+    plan.batch_local = torch.zeros(n + k, dtype=torch.long, device=dev)
+    plan.target_mask = is_owned.to(torch.uint8)
+    plan.cell = None if cell is None else cell.detach().reshape(1, 3, 3)
+    plan.halo_pos_local = True
+    plan.late_local = torch.ones(n + k, dtype=torch.bool, device=dev)
+    plan.late_local[:interior.numel()] = False
+    # the virtual slab every local row SERVES: an owned row its own, a ghost row the slab it was made for
+    plan.serves_slab = torch.cat([slab.index_select(0, owned), pairs[:, 0]]).contiguous()
+    plan.virtual = V
+    plan.wrap_axis = axis if V == 1 else None
+    return plan
+
+
+def partition_self_peer(pos, atomic_number, cell, rc, virtual=2, axis=None, group=None, reference_compat=False, skin=0.0):
+    """`plan_self_peer` + `slab_data`: (local_data, plan) of the one rank."""
+    plan = plan_self_peer(pos, atomic_number, cell, rc, virtual=virtual, axis=axis, group=group, skin=skin)
+    return slab_data(plan, pos, reference_compat), plan
+
+
 def block_grid(world, cell=None, pos=None):
     """A (pa, pb, pc) factorisation of `world` for `plan_blocks`: the factors go to the longest extents first, so that the
     blocks come out as cubic as the cell allows (a 36 x 36 x 900 A cell at world 8 -> (1, 1, 8): slabs; a 105 A cube ->
@@ -842,6 +911,19 @@ def slab_data(plan, pos, reference_compat=False, capacity=None, want_moved=False
             # structure.  The local order is owned-then-halo, so the cap is applied on global ids here (the capped list
             # of a shard is then exactly the unsharded capped list restricted to the owned targets).
             ei = _cap_by_global_source(ei, plan.local_global, int(plan.pos_ref.size(0)), 32)
+    serves = getattr(plan, "serves_slab", None)
+    if serves is not None:
+        # self-peer plan: an atom near a cut exists twice among the local rows (its owned row and a ghost row per slab it
+        # reaches); a pair j -> i is kept through the ONE instance of j that serves i's virtual slab (the owned row when both
+        # are in the same slab, otherwise the ghost made for i's slab) -- what a rank of a real `virtual`-rank plan would list
+        if total is not None:
+            raise NotImplementedError("the self-peer plan searches exactly (no padded list)")
+        if plan.wrap_axis is not None:      # one virtual slab: the ghost of j iff the pair crosses the periodic boundary
+            keep = (~plan.owned_mask.index_select(0, ei[0])) == (sh[:, plan.wrap_axis] != 0)
+        else:
+            keep = serves.index_select(0, ei[0]) == serves.index_select(0, ei[1])
+        ei = ei[:, keep].contiguous()
+        sh = None if sh is None else sh[keep].contiguous()
     z = plan.z_local
     kw = dict(pos=pos_l, atomic_number=z, edge_index=ei, batch=plan.batch_local)
     if cell is not None:
@@ -953,16 +1035,22 @@ class SlabStepper(object):
 
     says whether the step just taken was valid (every atom within skin/2 of the plan, list complete).  If not, the caller
     repeats the step: the next `stepper(pos)` plans again and / or searches exactly.  The first call of a plan runs the
-    exact search (its count sizes the capacity)."""
+    exact search (its count sizes the capacity).  Several steps may be taken between two checks: the flags are sticky, so
+    `check()` then answers for ALL of them (False: repeat from the last checked state)."""
 
     def __init__(self, atomic_number, cell, rc, rank, world, skin=1.0, axis=None, group=None, reference_compat=False,
-                 grid=None, deferred=False):
-        """`grid` = (pa, pb, pc) or "auto" (`block_grid`): boxes instead of slabs (`plan_blocks`)."""
+                 grid=None, deferred=False, self_peer=0):
+        """`grid` = (pa, pb, pc) or "auto" (`block_grid`): boxes instead of slabs (`plan_blocks`).
+        `self_peer` = V > 1 (world size 1 only): `plan_self_peer` with V virtual slabs -- the halo exchange with real rows on
+        one GPU; searches exactly (no padded list)."""
         self.z, self.cell, self.rc, self.skin = atomic_number, cell, float(rc), float(skin)
         self.rank, self.world, self.axis, self.group = rank, world, axis, group
         self.grid = grid
         self.reference_compat = reference_compat
-        self.deferred = bool(deferred)
+        self.self_peer = int(self_peer or 0)
+        if self.self_peer and world != 1:
+            raise ValueError("a self-peer plan is a plan of ONE rank (world size %d)" % world)
+        self.deferred = bool(deferred) and not self.self_peer
         self.plan = None
         self.replans = 0
         self.repeats = 0                 # steps that `check` asked to be taken again
@@ -973,7 +1061,10 @@ class SlabStepper(object):
         self._force_replan = False
 
     def _replan(self, pos):
-        if self.grid is not None:
+        if self.self_peer:
+            self.plan = plan_self_peer(pos, self.z, self.cell, self.rc, virtual=self.self_peer, axis=self.axis,
+                                       group=self.group, skin=self.skin)
+        elif self.grid is not None:
             self.plan = plan_blocks(pos, self.z, self.cell, self.rc, self.rank, self.world,
                                     grid=None if self.grid == "auto" else self.grid, group=self.group, skin=self.skin)
         else:
@@ -1043,7 +1134,14 @@ class SlabStepper(object):
                 return self._exact(pos)
             # optimistic: the plan as it is, the list padded; both flags stay on the device until `check`
             local = slab_data(self.plan, pos, self.reference_compat, capacity=self._capacity, want_moved=True)
-            self._pending = (local._hn_moved, local.get("_hn_edge_count"), local._hn_list_bad)
+            moved, bad = local._hn_moved, local._hn_list_bad
+            if self._pending is not None:
+                # several steps between two `check()`s: the flags are STICKY -- an earlier step that was invalid keeps the
+                # answer False (two tiny launches, only on this path; the counts are the latest list's)
+                i32 = lambda t: t.reshape(()).to(torch.int32)
+                moved = torch.maximum(i32(moved), i32(self._pending[0]))
+                bad = torch.maximum(i32(bad), i32(self._pending[2]))
+            self._pending = (moved, local.get("_hn_edge_count"), bad)
             return local, self.plan
         # one 0-d read-back decides (the search's own host read follows anyway): on a re-plan step the search and the
         # relation-flag reduction then run ONCE, on the new plan

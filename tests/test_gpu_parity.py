@@ -560,6 +560,109 @@ def _node_chain_case(H, T, counts, uniform, hr):
     assert torch.isfinite(gx1).all() and torch.isfinite(gvec1).all()
 
 
+# ---- parity MARGIN: the goldens assert < 1e-5; these fail at HALF of it, so a precision trade (a trimmed
+# tap, a reordered sum, a dropped partial product) turns a margin test red long before it turns a golden red
+MARGIN_ENERGY, MARGIN_FORCES = 2.5e-6, 5.0e-6
+
+
+@pytest.mark.parametrize("name", SMALL_CASES + ["c2_alloy10k"])
+def test_parity_margin_against_reference_goldens(name):
+    """Every golden of the reference's own code (tests/golden/*.npz, incl. configs[1] at full size): energy within 2.5e-6,
+    forces within 5e-6 of max |F| -- half of BASELINE.json's 1e-5.  Round 5 measured 1.8e-6 / 4.2e-6 at worst
+    (profiles/r05_parity_margin.log)."""
+    dev = _dev()
+    g = Golden(name)
+    model = g.model().to(dev)
+    d = (g.data(regenerate_graph=lambda: synth.fcc_alloy()) if name == "c2_alloy10k" else g.data()).to(dev)
+    d.pos.requires_grad_(True)
+    e = model(d)
+    f = -torch.autograd.grad(e.sum(), d.pos)[0]
+    ee, fe = rel_err(e.detach().cpu(), g.energy), rel_err(f.cpu(), g.forces)
+    print("parity margin %-24s energy %.2e forces %.2e" % (name, ee, fe))
+    assert ee < MARGIN_ENERGY, (name, ee)
+    assert fe < MARGIN_FORCES, (name, fe)
+
+
+def _row_err(a, b):
+    """Per-row relative error: max |a - b| over a row / max |b| over that row (rows at very different scales each count)."""
+    a, b = a.detach().cpu().double().reshape(a.shape[0], -1), b.detach().cpu().double().reshape(b.shape[0], -1)
+    return (a - b).abs().amax(1) / b.abs().amax(1).clamp(min=1e-300)
+
+
+@pytest.mark.parametrize("H,T,counts,tile16", [(128, 3, (70, 91, 45), False), (128, 3, (70, 91, 45), True), (256, 2, (60, 45), False),
+                                               (512, 2, (40, 33), False)])
+def test_node_chain_kernels_on_adversarial_operands(H, T, counts, tile16, monkeypatch):
+    """The node chain kernels run every product as a three-way bf16 split on the bf16 matrix pipe (csrc/node_chain_common.h:
+    split8, mma_panel; node_chain16.hip: mma16_panel) and claim fp32-equivalent results.  Operands chosen to break a sloppier
+    scheme, every ROW judged on its own scale (`_row_err`) against the fp64 restatement:
+      * per-row scales from 1e-12 to 1e+12 (x: LayerNorm input; gradients) and 1e-6 ... 1e+6 (vec: its square enters vdot),
+      * cancelling rows: a constant offset of 1e4 under unit noise (LayerNorm's mean removal), vec rows whose channels
+        alternate in sign so that the vec_proj sums cancel,
+      * rows of the linear backward chain at 1e-30 (the third bf16 plane of such a value sits at 1e-35, just above the bf16
+        denormals: below ~1e-33 the residual planes flush and a row keeps >= 8 significant bits -- documented, not tested).
+    Bound per row: the kernels' usual 5e-6 (2e-6 forward), or 4 x the error a plain fp32 evaluation of the same chain makes on
+    that row, whichever is larger -- cancellation costs fp32 itself digits; the split products must not cost more."""
+    from test_host_logic import _layer_weights_and_graph
+    from hermnet_amd import nodeops
+    import copy
+    dev = _dev()
+    if tile16:
+        monkeypatch.setattr(nodeops, "update_tile_rows", lambda graph, H_: 16)
+    w, g = _layer_weights_and_graph(H, T, counts, uniform=None, unknown=5)
+    w.h_real = 0
+    gen = torch.Generator().manual_seed(11)
+    N = g.N
+    rnd = lambda *s_: torch.randn(*s_, generator=gen)
+    scale = lambda n, lo, hi: 10.0 ** (lo + (hi - lo) * torch.rand(n, generator=gen))
+    x = rnd(N, H) * scale(N, -12, 12)[:, None]
+    x[::7] = 1.0e4 + rnd(x[::7].shape[0], H)                                   # LayerNorm removes 1e4 under unit noise
+    x1 = rnd(N, H) * scale(N, -6, 6)[:, None]
+    alt = torch.tensor([1.0, -1.0]).repeat(H // 2)
+    vec1 = rnd(N, 3, H) * scale(N, -6, 6)[:, None, None]
+    vec1[::5] = (alt[None, None, :] + 1e-3 * rnd(vec1[::5].shape[0], 3, H)) * scale(vec1[::5].shape[0], -3, 3)[:, None, None]
+    gxh = rnd(T, N, 3 * H) * scale(N, -12, 12)[None, :, None]
+    gxh[:, ::9] = rnd(T, gxh[:, ::9].shape[1], 3 * H) * 1.0e-30
+    gxo, gvo = rnd(N, H) * scale(N, -6, 6)[:, None], rnd(N, 3, H) * scale(N, -6, 6)[:, None, None]
+    wd = copy.copy(w)
+    for k, v in vars(w).items():
+        if torch.is_tensor(v):
+            setattr(wd, k, v.to(dev))
+    gd = copy.copy(g)
+    gd.row_active, gd.type_rowptr = g.row_active.to(dev), g.type_rowptr.to(dev)
+    gd._rowptr_c = None
+    c = lambda t: t.to(dev)
+    d64 = lambda t: t.double()
+    nk = g.type_rowptr_host[-1]
+
+    def judge(got, ref64, ref32, floor, what, rows=slice(None)):
+        assert bool(torch.isfinite(got).all()), what
+        err, base = _row_err(got[rows], ref64[rows]), _row_err(ref32[rows], ref64[rows])
+        bad = err > torch.maximum(torch.full_like(err, floor), 4.0 * base)
+        assert not bool(bad.any()), (what, int(bad.sum()), float(err[bad].max()), float(base[bad].max()))
+
+    # the node projection: LayerNorm -> [H -> H] -> ScaledSiLU -> [H -> 3H]; rows of [T, N, .] arrays judged per (t, row)
+    hb, xh, mean, rstd = nodeops.node_pre_fwd(c(x), wd, T)
+    r64, r32 = ref_ops.node_pre_fwd(d64(x), w, T), ref_ops.node_pre_fwd(x, w, T)
+    for k, nm in ((0, "hb"), (1, "xh")):
+        judge((hb, xh)[k].reshape(T * N, -1), r64[k].reshape(T * N, -1), r32[k].reshape(T * N, -1), 2e-6, "pre_fwd " + nm)
+    # its backward down to the per-relation partial sums: LINEAR in gxh -- the split products alone, rows at 1e-30 included
+    parts = nodeops.node_pre_bwd(c(gxh), hb, c(x), mean, rstd, wd, parts_only=True)
+    p64 = ref_ops.node_pre_bwd(d64(gxh), r64[0], d64(x), r64[2], r64[3], w, parts_only=True)
+    p32 = ref_ops.node_pre_bwd(gxh, r32[0], x, r32[2], r32[3], w, parts_only=True)
+    judge(parts.reshape(T * N, -1), p64.reshape(T * N, -1), p32.reshape(T * N, -1), 5e-6, "pre_bwd parts")
+    # PaiNNUpdate and its backward
+    outs = nodeops.node_update_fwd(c(x1), c(vec1), wd, gd)
+    u64, u32 = ref_ops.node_update_fwd(d64(x1), d64(vec1), w, g), ref_ops.node_update_fwd(x1, vec1, w, g)
+    known = slice(0, nk)
+    judge(outs[0], u64[0], u32[0], 3e-6, "update_fwd x", known)
+    judge(outs[1], u64[1], u32[1], 3e-6, "update_fwd vec", known)
+    gx1, gvec1 = nodeops.node_update_bwd(c(gxo), c(gvo), outs[2], outs[3], outs[4], outs[5], wd, gd)
+    b64 = ref_ops.node_update_bwd(d64(gxo), d64(gvo), u64[2], u64[3], u64[4], u64[5], w, g)
+    b32 = ref_ops.node_update_bwd(gxo.clone(), gvo.clone(), u32[2], u32[3], u32[4], u32[5], w, g)
+    judge(gx1, b64[0], b32[0], 5e-6, "update_bwd gx1", known)
+    judge(gvec1, b64[1], b32[1], 5e-6, "update_bwd gvec1", known)
+
+
 @pytest.mark.parametrize("E,H,has_v", [(1000, 128, True), (777, 128, False), (301, 100, True), (50, 512, True), (5, 4, True),
                                        (130, 36, False)])
 def test_edge_message_kernels_match_autograd_to_second_order(E, H, has_v):
@@ -1844,6 +1947,80 @@ def test_calculator_replays_a_captured_step_and_renews_the_capture_when_it_must(
     ref.calculate(_FakeAtoms(pos, z, cell), ["energy", "forces"])
     assert small.graph_captures == 2 and small._graphed[1].capacity > 1024
     assert small.results["energy"] == ref.results["energy"] and np.array_equal(small.results["forces"], ref.results["forces"])
+
+
+@pytest.mark.parametrize("graph_replay", [False, True])
+def test_calculators_never_hand_out_nan_after_a_write_through_dot_data(graph_replay):
+    """the stale-cache guard answers a write through `.data` (an EMA swap) with a NaN step.  Eagerly the
+    calculator handed that ONE NaN step to ASE; with `graph_replay` the check-and-poison kernel is captured and its flag
+    never read, so EVERY replay came back NaN.  Now a non-finite energy on the host drops the caches (and the capture),
+    re-evaluates the same call with the current weights, warns once -- and raises if it is still not finite."""
+    import warnings
+    from hermnet_amd.plugin import NNCalculator
+    _dev()
+    g = Golden("alloy108")
+    d = g.data()
+    z, cell = d.atomic_number.numpy(), d.cell[0].numpy().astype("float64")
+    pos = d.pos.numpy().astype("float64")
+    calc = NNCalculator(g.model(), None, trn_mean=0.0, device_="cuda:0", graph_replay=graph_replay)
+    for _ in range(3):                       # (the guard arms on the second forward; a capture on the first call)
+        calc.calculate(_FakeAtoms(pos, z, cell), ["energy", "forces"])
+    e_old = calc.results["energy"]
+    p_ = [p for n, p in calc.model.named_parameters() if n.endswith("update_layer.xvec_proj.2.weight")][1]
+    p_.data.mul_(1.5)                        # nothing a cache key looks at moves
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for it in range(3):
+            calc.calculate(_FakeAtoms(pos, z, cell), ["energy", "forces"])
+            assert np.isfinite(calc.results["energy"]) and np.isfinite(calc.results["forces"]).all(), it
+            assert calc.results["energy"] != e_old, "the OLD numbers after the weights changed"
+    assert any("NaN" in str(w.message) or "modified behind" in str(w.message) for w in rec)
+    fresh = NNCalculator(g.model(), None, trn_mean=0.0, device_="cuda:0")
+    fresh.model.load_state_dict({k: v.clone() for k, v in calc.model.state_dict().items()})
+    fresh.calculate(_FakeAtoms(pos, z, cell), ["energy", "forces"])
+    assert abs(calc.results["energy"] - fresh.results["energy"]) <= 1e-5 * abs(fresh.results["energy"])
+    assert np.abs(calc.results["forces"] - fresh.results["forces"]).max() <= 1e-5 * np.abs(fresh.results["forces"]).max()
+
+
+def test_a_model_with_an_armed_guard_deep_copies_and_pickles():
+    """from the second eval() forward on `HVNet.__dict__['_guard']` held a HIP event and
+    `copy.deepcopy(model)` (what `torch.optim.swa_utils.AveragedModel` and best-model snapshots do) / `torch.save(model)`
+    raised "cannot pickle 'Event' object".  Copies and pickles now carry no guard; the copy arms its own."""
+    import copy
+    import io
+    dev = _dev()
+    g = Golden("alloy108")
+    model = g.model().to(dev).eval()
+
+    def run(m):
+        d = g.data().to(dev)
+        d.pos.requires_grad_(True)
+        e = m(d)
+        return e.detach().clone(), -torch.autograd.grad(e.sum(), d.pos)[0]
+
+    run(model)
+    e, f = run(model)
+    assert model.__dict__["_guard"]._event is not None          # armed: the situation of the finding
+    clone = copy.deepcopy(model)
+    assert clone.__dict__.get("_guard") is None
+    e_c, f_c = run(clone)
+    run(clone)
+    assert torch.equal(e, e_c) and torch.equal(f, f_c) and clone.__dict__["_guard"] is not model.__dict__["_guard"]
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=False)
+    e_l, f_l = run(loaded)
+    assert torch.equal(e, e_l) and torch.equal(f, f_l)
+    from torch.optim.swa_utils import AveragedModel
+    ema = AveragedModel(model)                                   # deep-copies the model
+    e_a, _ = run(ema.module)
+    assert torch.equal(e, e_a)
+    # the copy is guarded on its own: a write through .data to the COPY gives NaN there, the original is untouched
+    p_ = [p for n, p in clone.named_parameters() if n.endswith("update_layer.xvec_proj.2.weight")][1]
+    p_.data.mul_(1.5)
+    e_bad, _ = run(clone)
+    assert bool(torch.isnan(e_bad).all()) and torch.equal(run(model)[0], e)
 
 
 def test_edge_cases_empty_and_degenerate_graphs():

@@ -453,3 +453,25 @@ def test_tall_bmm_is_a_linear_to_second_order(monkeypatch):
     x, W, bb = mk(24, 5), mk(3, 5), mk(3)
     assert torch.allclose(tr.tall_linear(x, W, bb), torch.nn.functional.linear(x, W, bb))
     assert gradgradcheck(lambda x, W, bb: tr.tall_linear(x, W, bb), (x, W, bb))
+
+
+def test_param_guard_stays_out_of_copies_and_pickles():
+    """an armed guard (HIP event, pinned flag) made `copy.deepcopy(model)` / `torch.save(model)` raise
+    "cannot pickle 'Event' object".  Reproduced on the CPU by attaching an armed guard to a fresh HVNet."""
+    import copy
+    import io
+    import hermnet_amd as hn
+    from hermnet_amd.guard import ParamGuard
+    model = hn.HVNet(["Si"], num_layers=1, hidden_channels=64, num_rbf=16)
+    guard = model.__dict__["_guard"] = ParamGuard(model)
+    guard._event = torch.cuda.Event()
+    clone = copy.deepcopy(model)
+    assert clone.__dict__.get("_guard") is None and model.__dict__["_guard"] is guard
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), clone.state_dict().values()))
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=False)
+    assert loaded.__dict__.get("_guard") is None
+    from torch.optim.swa_utils import AveragedModel
+    assert AveragedModel(model).module.__dict__.get("_guard") is None
