@@ -15,7 +15,7 @@ _ERR = {1: "HN_ERR_BAD_ARG (unsupported shape or null pointer)",
         3: "HN_ERR_LAUNCH (kernel launch failed)"}
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers
-ABI_VERSION = 11         # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
+ABI_VERSION = 12         # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
 
 
 class RbfDesc(ctypes.Structure):
@@ -126,6 +126,10 @@ SIGNATURES = {
                                          ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_fp, ctypes.c_int, c_fp]),
     "hermnet_halo_rows": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "hermnet_halo_accumulate": (ctypes.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
+    "hermnet_halo_proj_rows": (ctypes.c_int, [ctypes.c_int, c_fp, ctypes.c_long, ctypes.c_int, c_fp, ctypes.c_long, ctypes.c_int,
+                                              c_fp, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
+    "hermnet_halo_proj_accumulate": (ctypes.c_int, [c_fp, ctypes.c_long, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, ctypes.c_int,
+                                                    ctypes.c_int, c_fp, c_fp]),
     "hermnet_stream_copy": (ctypes.c_int, [c_fp, c_fp, ctypes.c_size_t, ctypes.c_int, c_fp]),
     "hermnet_param_guard": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),
     "hermnet_shard_step_flags": (ctypes.c_int, [c_fp, ctypes.c_long, c_fp, ctypes.c_int, c_fp, ctypes.c_long, c_fp, c_fp, c_fp,

@@ -641,6 +641,21 @@ int hn_bwd_cl_launch(HnBwdClArgs a, bool has_vec, int rows_override, const int* 
     if (wgs_per_tc < 1) wgs_per_tc = 1;                      // over a whole round would double the kernel's time
     rpb = (int)((rows + wgs_per_tc - 1) / wgs_per_tc);
     if (rpb < 16) rpb = 16;
+    if (a.num_ranges > 0) {
+      // chunks do not straddle a range: every range rounds its own chunk count up, and a grid ONE workgroup over a whole
+      // round (258 workgroups on 256 CUs, one resident each) takes two rounds -- measured on the self-peer step (round 6,
+      // profiles/r06_selfpeer_trace.md): 320 us for 88 % of the rows where the unranged launch takes 275 us for all of them.
+      // Grow the chunk until the ranges' chunks fit the rounds the launch was sized for.
+      for (int it = 0; it < 64; ++it) {
+        long c = 0;
+        for (int k = 0; k < a.num_ranges; ++k) {
+          const int lo = ranges_host[2 * k], hi = ranges_host[2 * k + 1];
+          if (hi > lo) c += (hi - lo + rpb - 1) / rpb;
+        }
+        if (c <= wgs_per_tc) break;
+        rpb += (rpb + 31) / 32;
+      }
+    }
   }
   a.rows_per_block = rpb;
   long chunks = (a.Nsrc + rpb - 1) / rpb;

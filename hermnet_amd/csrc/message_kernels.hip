@@ -982,7 +982,7 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   size_t lds = lds_bytes(a.R);
   if (lds > 160 * 1024) {
-    // num_rbf > 185: the tile of one (relation, column block) no longer fits the LDS.  Two launches over tap-row windows
+    // num_rbf > 176: the tile of one (relation, column block) no longer fits the LDS.  Two launches over tap-row windows
     // (the same split as the backward's, message_bwd_cl.hip: hn_bwd_cl_launch): the first owns the edges whose first tap
     // row is below `split`, writes residual + their sums; the second owns the rest and adds its sums.
     const int rows_all = a.R + 2 * HN_PAD + 1, split = (rows_all - HN_PAD + 1) / 2;
@@ -1031,7 +1031,9 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
                      (!vec || a.T == 1 || gvec_partials);
   if (virtual_targets && !cl_ok) return HN_ERR_BAD_ARG;
   if (num_ranges < 0 || (num_ranges > 0 && !(cl_ok && (use_cl || virtual_targets)))) return HN_ERR_BAD_ARG;   // ranges: that form only
-  if (no_finish && !(cl_ok && use_cl && !virtual_targets && num_ranges == 0 && (!vec || gvec_partials)))
+  // (ranged launches without the finishing launch: the "proj" halo exchange, ABI v12 -- the halo source rows first, the rest
+  // while their partial sums travel; the consumer sums the partials as for the unranged form)
+  if (no_finish && !(cl_ok && use_cl && !virtual_targets && (!vec || gvec_partials)))
     return HN_ERR_BAD_ARG;
   if (cl_ok && (use_cl || virtual_targets)) {
     HnBwdClArgs b = {};

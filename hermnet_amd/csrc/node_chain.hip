@@ -91,18 +91,35 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
       }
 #pragma unroll
     for (int m = 1; m < TPR; m <<= 1) s += __shfl_xor(s, m, 64);
-    const float mu = s / (float)a.Hr;
-    float qq = 0.f;
+    float mu = s / (float)a.Hr;
+    // corrected two-pass statistics (round 6): a lane sums NF * 4 values in sequence, so on a row whose mean dwarfs its spread
+    // (1e3 under unit noise) `mu` carries an error of ~1e-4 of the spread -- 20 x what torch's pairwise sum leaves
+    // (tests/test_gpu_parity.py::test_node_chain_kernels_on_adversarial_operands).  The mean of the DEVIATIONS is that error,
+    // measured at the deviations' own scale: it is taken out of the deviations, the mean and the variance.
+    float qq = 0.f, dd = 0.f;
 #pragma unroll
     for (int k = 0; k < NF; ++k)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[k][e] = (k * TPR + q) * 4 + e < a.Hr ? v[k][e] - mu : 0.f;
+        dd += v[k][e];
         qq = fmaf(v[k][e], v[k][e], qq);
       }
 #pragma unroll
-    for (int m = 1; m < TPR; m <<= 1) qq += __shfl_xor(qq, m, 64);
-    const float rs = rsqrtf(qq / (float)a.Hr + a.eps);
+    for (int m = 1; m < TPR; m <<= 1) {
+      qq += __shfl_xor(qq, m, 64);
+      dd += __shfl_xor(dd, m, 64);
+    }
+    const float dm = dd / (float)a.Hr;
+    mu += dm;
+#pragma unroll
+    for (int k = 0; k < NF; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if ((k * TPR + q) * 4 + e < a.Hr) v[k][e] -= dm;
+    float var = qq / (float)a.Hr;
+    var = fmaf(-dm, dm, var);
+    const float rs = rsqrtf(fmaxf(var, 0.f) + a.eps);
 #pragma unroll
     for (int k = 0; k < NF; ++k) *reinterpret_cast<f32x4*>(tile + lr * LD + (k * TPR + q) * 4) = v[k] * rs;
     // (every relation that wants the tile writes the same statistics: with source ranges relation 0 may skip it)

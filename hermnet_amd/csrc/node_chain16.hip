@@ -237,19 +237,34 @@ __device__ __forceinline__ void layernorm_tile16(float* tile, int tid, int nrows
 #pragma unroll
   for (int m = 1; m < TPR; m <<= 1) s += __shfl_xor(s, m, 64);
   const float inv_h = 1.0f / (float)Hr;
-  const float mu = s * inv_h;
-  float qq = 0.f;
+  float mu = s * inv_h;
+  // corrected two-pass statistics (round 6; see node_chain.hip): the mean of the deviations is the rounding error of `mu`
+  float qq = 0.f, dd = 0.f;
 #pragma unroll
   for (int k = 0; k < NF; ++k)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       v[k][e] = (k * TPR + q) * 4 + e < Hr ? v[k][e] - mu : 0.f;
+      dd += v[k][e];
       qq = fmaf(v[k][e], v[k][e], qq);
     }
 #pragma unroll
-  for (int m = 1; m < TPR; m <<= 1) qq += __shfl_xor(qq, m, 64);
+  for (int m = 1; m < TPR; m <<= 1) {
+    qq += __shfl_xor(qq, m, 64);
+    dd += __shfl_xor(dd, m, 64);
+  }
+  const float dm = dd * inv_h;
+  mu += dm;
+#pragma unroll
+  for (int k = 0; k < NF; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if ((k * TPR + q) * 4 + e < Hr) v[k][e] -= dm;
   float var = qq * inv_h;
   pin(var);                       // (the product stays a product: no contraction with the sum behind it, in any kernel)
+  float dm2 = dm * dm;
+  pin(dm2);
+  var = fmaxf(var - dm2, 0.f);
   const float rs = rsqrtf(var + eps);
 #pragma unroll
   for (int k = 0; k < NF; ++k) *reinterpret_cast<f32x4*>(tile + lr * LD + (k * TPR + q) * 4) = v[k] * rs;

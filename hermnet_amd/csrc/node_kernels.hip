@@ -387,6 +387,75 @@ __global__ __launch_bounds__(256) void halo_accumulate_kernel(float* __restrict_
   st4(row, acc);
 }
 
+// ---- halo exchange of PROJECTED rows (round 6; sharding.py / layer.py: the "proj" form of the exchange) ----------------------
+// What a neighbour rank needs of a halo atom is not x but its projections xh[t] = x_proj_t(LayerNorm(x)) for the T relations
+// and vec -- T + 1 blocks of W = 3H floats.  Sending THEM (12H floats per atom instead of 4H) means the receiver runs no node
+// projection on halo rows at all, forward or backward: no second, windowed launch of the node chain kernels on the halo tiles
+// (each one workgroup latency, ~20-50 us, for a few dozen tiles), no finishing launches in front of the gradient exchange.
+// A packed row = [ a[0][r] | ... | a[S-1][r] | sum_s b[s][r] ]  with a[j] = a + j * a_seg_stride (row stride W), b[s] = b + s *
+// b_slice_stride (row stride W): forward a = xh [T, N, 3H], b = vec [N, 3, H] (one slice); backward a = gxh, b = the
+// per-relation partial sums of gvec [T, N, 3, H], summed over the relations while they are packed.
+//   MODE 0  pack       MODE 1  pack, then clear the sources (every a[j][r] and every b[s][r])
+//   MODE 2  unpack:    a[j][r] = block j, b[0][r] = block S      (idx unique)
+template <int MODE>
+__global__ __launch_bounds__(256) void halo_proj_rows_kernel(float* __restrict__ a, long a_seg_stride, int S,
+                                                             float* __restrict__ b, long b_slice_stride, int nsum,
+                                                             const long* __restrict__ idx, int n, int W,
+                                                             float* __restrict__ buf) {
+  const int q4 = W / 4, blocks = S + 1;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n * blocks * q4) return;
+  const int k = (int)(i / ((long)blocks * q4)), rem = (int)(i % ((long)blocks * q4));
+  const int j = rem / q4, c = (rem % q4) * 4;
+  const long r = idx[k];
+  float* out = buf + ((long)k * blocks + j) * W + c;
+  if (j < S) {
+    float* row = a + (long)j * a_seg_stride + r * W + c;
+    if (MODE == 2) {
+      st4(row, ld4(out));
+    } else {
+      st4(out, ld4(row));
+      if (MODE == 1) st4(row, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+  } else {
+    float* row = b + r * W + c;
+    if (MODE == 2) {
+      st4(row, ld4(out));
+    } else {
+      float4 acc = ld4(row);
+      if (MODE == 1) st4(row, make_float4(0.f, 0.f, 0.f, 0.f));
+      for (int s = 1; s < nsum; ++s) {                 // (ascending relation: a fixed order)
+        const float4 v = ld4(row + (long)s * b_slice_stride);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        if (MODE == 1) st4(row + (long)s * b_slice_stride, make_float4(0.f, 0.f, 0.f, 0.f));
+      }
+      st4(out, acc);
+    }
+  }
+}
+
+// the owner's side of the return path: a[j][seg_rows[u]] += sum of block j of the returned rows of segment u, b[0][seg_rows[u]]
+// += sum of their last blocks -- in list order, no atomics (as halo_accumulate_kernel)
+__global__ __launch_bounds__(256) void halo_proj_accumulate_kernel(float* __restrict__ a, long a_seg_stride, int S,
+                                                                   float* __restrict__ b, const long* __restrict__ seg_rows,
+                                                                   const long* __restrict__ seg_ptr,
+                                                                   const long* __restrict__ seg_pos, int nu, int W,
+                                                                   const float* __restrict__ buf) {
+  const int q4 = W / 4, blocks = S + 1;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nu * blocks * q4) return;
+  const int u = (int)(i / ((long)blocks * q4)), rem = (int)(i % ((long)blocks * q4));
+  const int j = rem / q4, c = (rem % q4) * 4;
+  const long r = seg_rows[u];
+  float* row = j < S ? a + (long)j * a_seg_stride + r * W + c : b + r * W + c;
+  float4 acc = ld4(row);
+  for (long q = seg_ptr[u]; q < seg_ptr[u + 1]; ++q) {
+    const float4 v = ld4(buf + (seg_pos[q] * blocks + j) * W + c);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  st4(row, acc);
+}
+
 // ---- fused read-out (hermnet.py:113-117,129): e[n] = w2 . ScaledSiLU(W0 x[n] + b0) + b2, without a library GEMM --------
 // 0.16 GFLOP at 10k atoms: not worth a matrix-core kernel, but worth two launches and an [N, H/2] round trip less.
 // A 256-thread workgroup owns 32 rows: the weight matrix (K x M floats, <= 64 KB) and the rows' operand tile sit in
@@ -706,6 +775,33 @@ extern "C" int hermnet_halo_rows(int mode, float* x, float* vec, const long* idx
     case 2: hipLaunchKernelGGL(halo_rows_kernel<2>, grid, dim3(256), 0, s, x, vec, idx, n, hidden, buf); break;
     default: return HN_ERR_BAD_ARG;
   }
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_halo_proj_rows(int mode, float* a, long a_seg_stride, int num_seg, float* b, long b_slice_stride,
+                                      int num_sum, const long* idx, int n, int width, float* buf, void* stream) {
+  if (n < 0 || width <= 0 || (width & 3) || num_seg < 1 || num_sum < 1 || (mode == 2 && num_sum != 1)) return HN_ERR_BAD_ARG;
+  if (n == 0) return HN_OK;
+  if (!a || !b || !idx || !buf) return HN_ERR_BAD_ARG;
+  const dim3 grid = grid_for((long)n * (num_seg + 1) * (width / 4), 256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(halo_proj_rows_kernel<0>, grid, dim3(256), 0, s, a, a_seg_stride, num_seg, b, b_slice_stride, num_sum, idx, n, width, buf); break;
+    case 1: hipLaunchKernelGGL(halo_proj_rows_kernel<1>, grid, dim3(256), 0, s, a, a_seg_stride, num_seg, b, b_slice_stride, num_sum, idx, n, width, buf); break;
+    case 2: hipLaunchKernelGGL(halo_proj_rows_kernel<2>, grid, dim3(256), 0, s, a, a_seg_stride, num_seg, b, b_slice_stride, num_sum, idx, n, width, buf); break;
+    default: return HN_ERR_BAD_ARG;
+  }
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_halo_proj_accumulate(float* a, long a_seg_stride, int num_seg, float* b, const long* seg_rows,
+                                            const long* seg_ptr, const long* seg_pos, int num_rows, int width,
+                                            const float* buf, void* stream) {
+  if (num_rows < 0 || width <= 0 || (width & 3) || num_seg < 1) return HN_ERR_BAD_ARG;
+  if (num_rows == 0) return HN_OK;
+  if (!a || !b || !seg_rows || !seg_ptr || !seg_pos || !buf) return HN_ERR_BAD_ARG;
+  hipLaunchKernelGGL(halo_proj_accumulate_kernel, grid_for((long)num_rows * (num_seg + 1) * (width / 4), 256), dim3(256), 0,
+                     (hipStream_t)stream, a, a_seg_stride, num_seg, b, seg_rows, seg_ptr, seg_pos, num_rows, width, buf);
   HN_LAUNCH_END;
 }
 

@@ -74,10 +74,13 @@ class HeteroVertexConv(nn.Module):
         node = data.get("_hn_chain_node")
         # (not under anomaly detection -- its NaN check would read the not-yet-filled buffers -- and not when a tensor hook
         # would: both are debugging situations, which get the finishing launches; HERMNET_DEFER_SUMS=0 forces them)
-        defer = (node is not None and data.vec is not None and data.x.grad_fn is node and data.vec.grad_fn is node
-                 and halo is None and not g.num_src and data.get("_hn_shard") is None
-                 and not torch.is_anomaly_enabled()
-                 and not getattr(data.x, "_backward_hooks", None) and not getattr(data.vec, "_backward_hooks", None))
+        straight = (node is not None and data.vec is not None and data.x.grad_fn is node and data.vec.grad_fn is node
+                    and not g.num_src and not torch.is_anomaly_enabled()
+                    and not getattr(data.x, "_backward_hooks", None) and not getattr(data.vec, "_backward_hooks", None))
+        defer = straight and halo is None and (data.get("_hn_shard") is None or data.get("_hn_lone"))
+        # atom shards: the exchange in its "proj" form (layer.FusedRelationalLayer; HERMNET_HALO_OVERLAP=1: the round-4 form,
+        # x | vec rows with windowed node launches around the exchange; 0: the blocking exchange in front of the layer)
+        proj = straight and halo is not None and os.environ.get("HERMNET_HALO_OVERLAP", "2") not in ("0", "1")
         # the node projection of THIS x, already computed: the first layer's by HVNet.forward (side stream), every later layer's
         # by the fused update launch of the layer below (round 5)
         pre, data._hn_pre0 = data.get("_hn_pre0"), None
@@ -86,11 +89,11 @@ class HeteroVertexConv(nn.Module):
             pre = None
         # the next layer's weights: its projection of the rows this layer produces can run inside this layer's update launch
         w_next = None
-        if ready is not None and li + 1 < len(ready) and halo is None and data.get("_hn_shard") is None:
+        if ready is not None and li + 1 < len(ready) and halo is None and (data.get("_hn_shard") is None or data.get("_hn_lone")):
             w_next = ready[li + 1]
         data.x, data.vec = FusedRelationalLayer.apply(data.x, data.vec, edge, g, data._hn_rbf, w,
                                                       data.get("_hn_edge_sink"), li, halo, defer,
-                                                      None if pre is None else pre[1], w_next)
+                                                      None if pre is None else pre[1], w_next, proj)
         data._hn_pre0 = _PRE_NEXT.pop((id(g), li + 1), None)
         data._hn_chain_node = data.x.grad_fn if (w.chain and _node_chain_enabled() and not g.num_src) else None
         return data
@@ -317,11 +320,19 @@ class HVNet(nn.Module):
                                           "DistributedDataParallel over whole graphs (example/dist_train.py:63)")
             if shard.owned_mask.device != pos.device:
                 shard.to(pos.device)
-            if shard.halo_pos_local:       # coordinates are there; their gradients still go home
+            # ONE rank that neither sends nor receives a row (a plain world-1 plan): nothing to exchange with anybody -- the
+            # collectives (and the stream hand-offs they cost: ~0.12 ms per step, round 4) are skipped and the layers take
+            # the unsharded forms (deferred sums).  With peers every rank joins every collective, rows or not.
+            lone = shard.world == 1 and shard.atom_plan.send_idx.numel() == 0 and shard.atom_plan.recv_idx.numel() == 0
+            data._hn_lone = lone
+            if lone:
+                pass
+            elif shard.halo_pos_local:     # coordinates are there; their gradients still go home
                 pos = HaloGradReturn.apply(pos, shard.atom_plan)
             else:
                 pos = HaloExchange.apply(pos, shard.atom_plan)              # halo coordinates from their owners
-            row_plan = shard.row_plan(graph.row_of_node)
+            if not lone:
+                row_plan = shard.row_plan(graph.row_of_node)
         # hermnet.py:123, row order (pads: Z=0).  eval(): every parameter is a constant, the embedding included
         # (the fused layers produce no parameter gradients; a partial set would be worse than none)
         x = self.embed(graph.z_rows) if train else torch.nn.functional.embedding(graph.z_rows, self.embed.weight.detach())
@@ -440,9 +451,10 @@ class HVNet(nn.Module):
                 perm, lengths = shard.graph_order(batch)
                 energy = torch.segment_reduce(e_own.index_select(0, perm), "sum", lengths=lengths, unsafe=True)
                 cnt = torch.segment_reduce(own.index_select(0, perm), "sum", lengths=lengths, unsafe=True)
-            energy = SumAcrossRanks.apply(energy, shard.group)
+            if shard.world > 1:
+                energy, cnt = SumAcrossRanks.apply(energy, shard.group), (SumAcrossRanks.apply(cnt, shard.group) if self.intensive else cnt)
             if self.intensive:
-                energy = energy / SumAcrossRanks.apply(cnt, shard.group).clamp(min=1)
+                energy = energy / cnt.clamp(min=1)
             return energy
         # (train(): segment_reduce has no second derivative)
         energy = torch.zeros(graph.num_graphs, dtype=x.dtype, device=x.device).index_add(0, batch, per_atom_energy)

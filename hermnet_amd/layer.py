@@ -170,14 +170,22 @@ def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True, r
     b2 = w.b2 if xh_bias else None
     split = _split_t(graph)
     if not finish:
-        gxh = torch.empty_like(xh)
-        part = None if vec is None else torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
+        if out is None:
+            gxh = torch.empty_like(xh)
+            part = None if vec is None else torch.empty((graph.T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
+        else:
+            gxh, part = out
+        rd, rh, nr = None, None, 0
+        if ranges is not None:         # (the "proj" halo exchange: the halo source rows first, the others while they travel)
+            rd, host = ranges
+            nr = len(host)
+            rh = (ctypes.c_int * (2 * nr))(*[v for lo_hi in host for v in lo_hi])
         gs, rs = graph.as_struct(), rbf.struct()
         _lib.check(_launch("message_scatter_bwd" + ("" if vec is not None else "_l0"),
                            lambda: lib.hermnet_message_scatter_bwd(
                                ctypes.byref(gs), ctypes.byref(rs), H, P(xh), P(b2), P(vec), P(w.wt), P(w.brbf), P(edge),
                                P(gx1), P(gvec1), P(gxh), None, None, P(gedge), 0, P(graph.edge_table), P(part),
-                               None, None, 0, _stream())),
+                               P(rd), rh, nr, _stream())),
                    "hermnet_message_scatter_bwd")
         return gxh, part
     if out is None:
@@ -303,7 +311,7 @@ class FusedRelationalLayer(torch.autograd.Function):
     """(x, vec, edge) -> (x_out, vec_out) for one layer, relation (row) order."""
 
     @staticmethod
-    def forward(ctx, x, vec, edge, graph, rbf, w, sink=None, li=0, halo=None, defer=False, pre=None, w_next=None):
+    def forward(ctx, x, vec, edge, graph, rbf, w, sink=None, li=0, halo=None, defer=False, pre=None, w_next=None, proj=False):
         """`edge`: [E,4], or this layer's handle from `EdgeFanout` ([H/64,E,4] stride-0 view; same memory).
         x / vec live in SOURCE rows, the outputs in TARGET rows; the two coincide for HVNet and differ for HTNet
         (`graph.num_src`: one target row per atom and pair relation, relations.build_triadic).
@@ -317,7 +325,9 @@ class FusedRelationalLayer(torch.autograd.Function):
         first layer's beside the relation build; round 5: every later layer's comes out of the fused update launch of the
         layer below).
         `w_next` (round 5): the NEXT layer's weights -- its node projection of the rows this layer produces runs inside this
-        layer's update launch where `nodeops.fused_boundary_supported` (result left in `_PRE_NEXT`)."""
+        layer's update launch where `nodeops.fused_boundary_supported` (result left in `_PRE_NEXT`).
+        `proj` (round 6, with `halo`): x and vec come straight from the chain layer below (as for `defer`), so the exchange may
+        take the "proj" form: projected rows travel forward, partial sums of gradients backward."""
         Ns, H = x.shape
         N = graph.N
         T = graph.T
@@ -330,9 +340,33 @@ class FusedRelationalLayer(torch.autograd.Function):
         ctx.chain = w.chain and _node_chain_enabled()
         if ctx.chain:
             # three launches: node_pre_fwd (LayerNorm + x_proj of every relation), the message kernel, node_update_fwd
+            # atom shards, the "proj" form of the exchange (round 6): the halo rows travel as what the message kernel gathers --
+            # xh[t] of every relation and vec, 12H floats per atom -- so no node kernel runs a second time on the halo tiles
+            # and the backward hands its gradients down as partial sums like the unsharded layer (`defer`)
+            ctx.proj = bool(proj) and halo is not None and vec is not None and (
+                _bwd_sums_deferrable(graph, H) or not (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]))
             if halo is None:
                 hb, xh, mean, rstd = pre if pre is not None else nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges)
                 x1, vec1 = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False)
+            elif ctx.proj:
+                #   project every row (halo rows from stale inputs: replaced below) -> pack (xh | vec) of the rows the peers
+                #   need -> start the all-to-all -> messages into the targets that read no halo row -> the STREAM waits ->
+                #   unpack IN PLACE -> messages into the remaining targets
+                from .sharding import _all_to_all_rows_start, comm_wait
+                plan = halo.plan
+                hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges)
+                send = nodeops.halo_proj_rows(0, xh, vec, plan.send_idx)
+                recv, work = _all_to_all_rows_start(send, plan.send_counts, plan.recv_counts, plan.group)
+                if _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":
+                    # (tests: nothing that runs before the unpack may depend on a halo row)
+                    nodeops.halo_proj_rows(2, xh, vec, plan.recv_idx, torch.full_like(recv, float("nan")))
+                x1, vec1 = out = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False, ranges=halo.fwd_early,
+                                          zero_unknown=True, range_rows=halo.early_rows)
+                comm_wait(work, "fwd", sum(plan.send_counts), sum(plan.recv_counts))
+                nodeops.halo_proj_rows(2, xh, vec, plan.recv_idx, recv)
+                if halo.late_rows > 0:
+                    _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False, ranges=halo.fwd_late, zero_unknown=False,
+                             out=out, range_rows=halo.late_rows)
             else:
                 # The exchange runs behind the node projection AND the message kernel of every target that reads no
                 # halo row ("run interior edges while the halo is in flight"):
@@ -358,7 +392,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                     _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False, ranges=halo.fwd_late, zero_unknown=False,
                              out=out, range_rows=halo.late_rows)
             ctx.halo = halo
-            ctx.defer = bool(defer) and halo is None and vec is not None
+            ctx.defer = (bool(defer) and halo is None and vec is not None) or ctx.proj
             mode = _boundary_mode()
             if (w_next is not None and halo is None and mode in (1, 2, 3)
                     and nodeops.fused_boundary_supported(graph, H, w, w_next)):
@@ -476,6 +510,37 @@ class FusedRelationalLayer(torch.autograd.Function):
         else:
             gedge = torch.zeros(H // 64, graph.E, 4, dtype=torch.float32, device=gx1.device)
         halo = ctx.halo if ctx.chain else None
+        if halo is not None and ctx.proj:
+            # The gradients of the halo SOURCE rows first, as they stand behind the message backward -- gxh[t] of every relation
+            # and the per-relation partial sums of gvec, summed while they are packed; cleared here: the local halo rows were
+            # overwritten in the forward --; they travel to their owners while the other source rows are computed; the owners add
+            # them to their own gxh / partial sums in list order, and ONE node_pre_bwd over every row follows.  The input
+            # gradients go down as partial sums (`defer`): no finishing launch, no windowed node launch, no LayerNorm backward.
+            from .sharding import _all_to_all_rows_start, comm_wait
+            plan = halo.plan
+            gxh = torch.empty_like(xh)
+            gv_parts = torch.empty((T,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
+            bufs = (gxh, gv_parts)
+            if halo.bwd_first_rows[1]:
+                _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=False, ranges=halo.bwd_first_rows,
+                         out=bufs, finish=False)
+            gsend = nodeops.halo_proj_rows(1, gxh, gv_parts, plan.recv_idx)           # pack and clear: none stays here
+            back, work = _all_to_all_rows_start(gsend, plan.recv_counts, plan.send_counts, plan.group)
+            if halo.bwd_rest_rows[1]:
+                _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=False, ranges=halo.bwd_rest_rows,
+                         out=bufs, finish=False)
+            comm_wait(work, "bwd", sum(plan.recv_counts), sum(plan.send_counts))
+            nodeops.halo_proj_accumulate(gxh, gv_parts, plan, back)                 # gradients of my atoms used elsewhere
+            gn_parts = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, src_ranges=graph.src_ranges, parts_only=True)
+            gx_total, gvec_in = torch.empty_like(x), torch.empty_like(vec)          # filled by the layer below
+            if _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":                # (tests: nothing reads them before that)
+                gx_total.fill_(float("nan"))
+                gvec_in.fill_(float("nan"))
+            pend = _PENDING[(id(graph), ctx.li - 1)] = nodeops.PendingGrads(
+                gx_total, gvec_in, gn_parts, gv_parts, x, mean, rstd, gx1, gvec1, w.h_real)
+            pend.w_above = w
+            ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
+            return (gx_total, gvec_in, ge) + (None,) * 10
         if halo is not None:
             # the gradients of the halo rows first: they travel to their owners while the other rows are computed
             from .sharding import _all_to_all_rows_start
@@ -504,7 +569,7 @@ class FusedRelationalLayer(torch.autograd.Function):
             comm_wait(work, "bwd", sum(plan.recv_counts), sum(plan.send_counts))
             nodeops.halo_accumulate(gx_total, gvec_in, plan, back)                  # gradients of my atoms used elsewhere
             ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
-            return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None, None
+            return (gx_total, gvec_in, ge) + (None,) * 10
         ge = gedge if fan else (gedge[0] if gedge.size(0) == 1 else gedge.sum(0))
         if ctx.chain and _bwd_sums_deferrable(graph, H):
             if ctx.defer and ctx.needs_input_grad[0]:
@@ -526,10 +591,10 @@ class FusedRelationalLayer(torch.autograd.Function):
                 pend = _PENDING[(id(graph), ctx.li - 1)] = nodeops.PendingGrads(
                     gx_total, gvec_in, gn_parts, gv_parts, x, mean, rstd, gx1, gvec1, w.h_real, chain=chain)
                 pend.w_above = w            # (keeps the fragment copies alive; the CPU restatement of the tests reads it)
-                return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None, None
+                return (gx_total, gvec_in, ge) + (None,) * 10
             if vec is None and not ctx.needs_input_grad[0]:     # the first layer: nothing below wants gx / gvec
                 _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=False, finish=False)
-                return None, None, ge, None, None, None, None, None, None, None, None, None
+                return (None, None, ge) + (None,) * 10
         gxh, gvec_in, gx_in = _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=not ctx.chain)
         _virtual_residual(graph, gx1, gvec1, gx_in, gvec_in, H)
         gx_total = None
@@ -541,7 +606,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                 gh = nodeops.ssilu_bwd(ga, h, Ns, T, H, H, Ns * H)                   # [Ns, T*H]
                 gn = _launch("gemm", lambda: torch.mm(gh, w.w1cat))                                           # [N, H]
                 gx_total = nodeops.layernorm_bwd(gn, x, mean, rstd, add=gx_in, h_real=w.h_real)
-        return gx_total, gvec_in, ge, None, None, None, None, None, None, None, None, None
+        return (gx_total, gvec_in, ge) + (None,) * 10
 
 
 class EnergyHead(torch.autograd.Function):

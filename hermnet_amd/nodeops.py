@@ -190,6 +190,31 @@ def halo_accumulate(x, vec, plan, buf):
         P(x), P(vec), P(rows), P(ptr), P(pos), int(rows.numel()), x.size(1), P(buf), _stream())), "hermnet_halo_accumulate")
 
 
+def halo_proj_rows(mode, a, b, idx, buf=None):
+    """The exchange of PROJECTED halo rows (csrc/node_kernels.hip: hermnet_halo_proj_rows): a packed row holds the S = a.size(0)
+    blocks a[j][r] and one block  sum_s b[s][r]  (or b[r] when b has no slice axis), each W = a.size(2) floats.  Forward:
+    a = xh [T, N, 3H], b = vec [N, 3, H]; backward: a = gxh, b = the per-relation partial sums of gvec [T, N, 3, H].
+    mode 0 pack, 1 pack and clear every source, 2 unpack (b without a slice axis).  Returns `buf` [n, (S + 1) W]."""
+    S, N, W = a.shape
+    sliced = b.dim() == 4
+    nsum = b.size(0) if sliced else 1
+    n = int(idx.numel())
+    if buf is None:
+        buf = torch.empty(n, (S + 1) * W, dtype=a.dtype, device=a.device)
+    _lib.check(_launch("halo_rows", lambda: _lib.load().hermnet_halo_proj_rows(
+        mode, P(a), N * W, S, P(b), N * W, nsum, P(idx), n, W, P(buf), _stream())), "hermnet_halo_proj_rows")
+    return buf
+
+
+def halo_proj_accumulate(a, b, plan, buf):
+    """a[j][rows[u]] += the sum of block j of the returned rows of segment u, b[0][rows[u]] (or b[rows[u]]) += the sum of their
+    last blocks, in list order (`plan.accumulate_lists()`): the owner's side of the gradient return, no atomics."""
+    rows, ptr, pos = plan.accumulate_lists()
+    S, N, W = a.shape
+    _lib.check(_launch("halo_accumulate", lambda: _lib.load().hermnet_halo_proj_accumulate(
+        P(a), N * W, S, P(b), P(rows), P(ptr), P(pos), int(rows.numel()), W, P(buf), _stream())), "hermnet_halo_proj_accumulate")
+
+
 # ---- node chain kernels (csrc/node_chain.hip): one launch per chain on the fp32 matrix pipe ---------------------------
 def chain_supported(H):
     """Widths the chain kernels are instantiated for: every multiple of 64 up to 512 (csrc/node_chain.hip for 64 / 128 /

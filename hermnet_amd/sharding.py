@@ -169,7 +169,9 @@ class HaloOverlap(object):
     fwd_early  [T,2] int32 (device): per relation the TARGET rows that read no halo row -- their messages run while the
                exchange is in flight; fwd_late: the rest of the relation's row block (incl. the halo rows themselves)
     bwd_first  (device [k,2] int32, host [(lo, hi)]): the SOURCE rows whose gradients travel -- the halo windows widened to
-               the node kernels' row tiles --, computed and sent first; bwd_rest: every other row, computed meanwhile."""
+               the node kernels' row tiles --, computed and sent first; bwd_rest: every other row, computed meanwhile.
+    bwd_first_rows / bwd_rest_rows: the same cut at row granularity (the exact halo windows and their complement): what the
+               "proj" form of the exchange uses (layer.py: projected rows travel, no node kernel runs on a subset of tiles)."""
 
     def __init__(self, plan, windows, fwd_early=None, fwd_late=None, bwd_first=None, bwd_rest=None):
         self.plan, self.windows = plan, windows
@@ -440,7 +442,10 @@ class ShardPlan(object):
                 el = torch.stack([ov.fwd_early, ov.fwd_late]).cpu()          # (one more small host read per plan)
                 ov.early_rows = int((el[0, :, 1] - el[0, :, 0]).clamp(min=0).sum())
                 ov.late_rows = int((el[1, :, 1] - el[1, :, 0]).clamp(min=0).sum())
-                ov.bwd_first, ov.bwd_rest = HaloOverlap.source_ranges(win.cpu().tolist(), tile_rows, n_src, dev)
+                win_host = win.cpu().tolist()
+                ov.bwd_first, ov.bwd_rest = HaloOverlap.source_ranges(win_host, tile_rows, n_src, dev)
+                # the same cut at row granularity: the "proj" exchange (layer.py) runs no node kernel on a subset of the tiles
+                ov.bwd_first_rows, ov.bwd_rest_rows = HaloOverlap.source_ranges(win_host, 1, n_src, dev)
             self._row_plan = self._row_plan[:2] + (ov,)
         return self._row_plan[2]
 

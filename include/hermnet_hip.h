@@ -16,7 +16,8 @@
  *   - float = IEEE fp32 (the reference is fp32-only), indices = int32 (int64 where a parameter says so:
  *     the caller's edge_index / atomic_number / halo index lists arrive as torch LongTensors).
  *
- * ABI version 11 (`hermnet_abi_version`): v11 changes the weight fragment formats of the node chain kernels (three bf16 planes:
+ * ABI version 12 (`hermnet_abi_version`): v12 is ADDITIVE over v11 (hermnet_halo_proj_rows / _accumulate, ranged launches of
+ * hermnet_message_scatter_bwd without the finishing launch; nothing v11 exports changed); v11 changes the weight fragment formats of the node chain kernels (three bf16 planes:
  * see "chain kernels on the matrix pipe"); v10 adds hermnet_shard_step_flags; v9 added the fused layer-boundary node kernels (hermnet_node_update_pre_fwd, the `gxh`
  * form of hn_pending_grads, hermnet_node_pre_fwd16 / _bwd16) and hermnet_param_guard; v8 the gradients handed down as partial sums
  * (hn_pending_grads); v7 adds the row windows of the message kernels (interior / boundary launches
@@ -581,6 +582,22 @@ int hermnet_halo_rows(int mode, float* x, float* vec, const long* idx, int n, in
  * lists prepared once per exchange plan by hermnet_amd/sharding.py) -- no atomics, bit-reproducible. */
 int hermnet_halo_accumulate(float* x, float* vec, const long* seg_rows, const long* seg_ptr, const long* seg_pos,
                             int num_rows, int hidden, const float* buf, void* stream);
+
+/* Halo exchange of PROJECTED rows (ABI v12; the default form of the per-layer exchange where the node chain kernels run:
+ * hermnet_amd/layer.py).  What a neighbour needs of a halo atom is xh[t] = x_proj_t(LayerNorm(x)) for every relation
+ * (rmnet.py:52: the source rows the message gathers, rmnet.py:58) and vec: T + 1 blocks of `width` = 3H floats.  The owner
+ * sends those -- 12H floats per atom instead of 4H -- and the receiver runs NO node projection on halo rows, forward or
+ * backward (no windowed second launch of the chain kernels, no finishing launches in front of the gradient exchange).
+ * A packed row = [ a[0][r] | ... | a[S-1][r] | sum_{s < num_sum} b[s][r] ], a[j] = a + j * a_seg_stride, b[s] = b + s *
+ * b_slice_stride, rows `width` floats apart.  Forward: a = xh [T, N, 3H], b = vec (num_sum 1).  Backward: a = gxh, b = the
+ * per-relation partial sums of gvec [T, N, 3, H] (num_sum T: summed, ascending relation, while they are packed).
+ *   mode 0 pack;  mode 1 pack, then clear every source;  mode 2 unpack (a[j][r] = block j, b[0][r] = block S; idx unique) */
+int hermnet_halo_proj_rows(int mode, float* a, long a_seg_stride, int num_seg, float* b, long b_slice_stride, int num_sum,
+                           const long* idx, int n, int width, float* buf, void* stream);
+/* ... and the owner's side of the return path: a[j][seg_rows[u]] += sum of block j of the returned rows of segment u,
+ * b[seg_rows[u]] += the sum of their last blocks, in list order (lists as for hermnet_halo_accumulate): no atomics. */
+int hermnet_halo_proj_accumulate(float* a, long a_seg_stride, int num_seg, float* b, const long* seg_rows, const long* seg_ptr,
+                                 const long* seg_pos, int num_rows, int width, const float* buf, void* stream);
 
 /* float4 stream copy dst[i] = src[i] (16-byte aligned pointers, num_floats % 4 == 0): not part of the path -- the yardstick
  * for SURVEY.md 8(d)'s "measured copy bandwidth on the box" (bench.py: roofline.measured_copy_GBps; the method of

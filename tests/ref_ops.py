@@ -252,6 +252,31 @@ def halo_rows(mode, x, vec, idx, buf=None):
     return buf
 
 
+def halo_proj_rows(mode, a, b, idx, buf=None):
+    """csrc/node_kernels.hip: hermnet_halo_proj_rows -- packed row = [a[0][r] | ... | a[S-1][r] | sum_s b[s][r]]."""
+    S, N, W = a.shape
+    sliced = b.dim() == 4
+    bv = b.reshape((b.size(0) if sliced else 1), N, W)
+    if mode in (0, 1):
+        buf = torch.cat([a.index_select(1, idx).permute(1, 0, 2).reshape(idx.numel(), S * W),
+                         bv.index_select(1, idx).sum(0)], dim=1)
+        if mode == 1:
+            a.index_fill_(1, idx, 0)
+            bv.index_fill_(1, idx, 0)
+        return buf
+    assert mode == 2 and not sliced
+    a.index_copy_(1, idx, buf[:, :S * W].reshape(-1, S, W).permute(1, 0, 2))
+    bv[0].index_copy_(0, idx, buf[:, S * W:])
+    return buf
+
+
+def halo_proj_accumulate(a, b, plan, buf):
+    S, N, W = a.shape
+    bv = b.reshape(-1, N, W)
+    a.index_add_(1, plan.send_idx, buf[:, :S * W].reshape(-1, S, W).permute(1, 0, 2))
+    bv[0].index_add_(0, plan.send_idx, buf[:, S * W:])
+
+
 def halo_accumulate(x, vec, plan, buf):
     """hermnet_halo_accumulate: returned gradients summed per owned row in send-list order."""
     H = x.size(1)
@@ -422,13 +447,25 @@ def msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True, ra
     `finish=False` (gx = NULL in the C call): (gxh, per-relation partial sums of gvec WITHOUT the residual's identity term)."""
     if not finish:
         T = xh.size(0)
-        gxh, gv, _ = msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=xh_bias)
-        if gv is None:
-            return gxh, None
-        ident = (torch.arange(graph.N) < int(graph.type_rowptr[T])).to(gv.dtype)
-        part = torch.zeros((T,) + tuple(gv.shape), dtype=gv.dtype)
-        part[0] = gv - gvec1 * ident[:, None, None]      # (the split over the relations is the kernel's own business)
-        return gxh, part
+        scratch = gedge if ranges is None else torch.zeros_like(gedge)
+        gxh, gv, _ = msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, scratch, xh_bias=xh_bias)
+        part = None
+        if gv is not None:
+            ident = (torch.arange(graph.N) < int(graph.type_rowptr[T])).to(gv.dtype)
+            part = torch.zeros((T,) + tuple(gv.shape), dtype=gv.dtype)
+            part[0] = gv - gvec1 * ident[:, None, None]      # (the split over the relations is the kernel's own business)
+        if ranges is None:
+            return gxh, part
+        # ranged launch without the finishing launch (the "proj" halo exchange): only these SOURCE rows are written
+        sel = _rows_of_ranges(ranges[1], xh.size(1))
+        if out is None:
+            out = (torch.full_like(gxh, float("nan")), None if part is None else torch.full_like(part, float("nan")))
+        out[0][:, sel] = gxh[:, sel]
+        if part is not None:
+            out[1][:, sel] = part[:, sel]
+        esel = sel[graph.csr_src.long()]
+        gedge[:, esel] = scratch[:, esel]
+        return out
     with torch.enable_grad():
         xh_ = (xh + w.b2 if xh_bias else xh).detach().requires_grad_(True)
         x_ = torch.zeros(xh.size(1), H, dtype=xh.dtype).requires_grad_(True)
