@@ -29,6 +29,12 @@ import time
 
 # read by the HSA runtime when it initialises (first HIP call): must be in the environment before that
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# Atom-sharded runs: HIP multiplexes its streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams that share
+# a queue run in submission order.  With 4 queues the process group's internal stream shared its queue with the default
+# stream -- the "asynchronous" all-to-all then sits in FRONT of the kernels it is meant to hide behind (kernel trace of the
+# self-peer step and tools/overlap_probe.py: overlap 0.05 with 4 queues, 0.57 with 8; profiles/r06_overlap_probe.json).
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or any(a in sys.argv for a in ("--self-peer", "--shard-anyway")):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -469,6 +475,7 @@ def self_launch(ngpus, argv, timeout=None):
     s.close()
     env = dict(os.environ, HERMNET_BENCH_CHILD="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")      # (see the top of this file)
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // ngpus)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)

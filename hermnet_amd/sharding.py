@@ -403,6 +403,24 @@ class ShardPlan(object):
             c = self._graph_order = (batch, batch._version, perm, lengths)
         return c[2], c[3]
 
+    def owned_rows(self, graph, rows):
+        """[rows] float 0 / 1: the node rows (HVNet: graph.N; HTNet: its source rows) that hold an OWNED atom (halo atoms and
+        padding rows: 0) -- the read-out's row mask on a shard; cached with the row layout."""
+        c = getattr(self, "_owned_rows", None)
+        if c is None or c[0] is not graph.row_of_node or c[1].numel() != rows:
+            m = torch.zeros(rows, dtype=torch.float32, device=graph.row_of_node.device)
+            m.index_copy_(0, graph.row_of_node, self.owned_mask.to(torch.float32))
+            c = self._owned_rows = (graph.row_of_node, m)
+        return c[1]
+
+    @property
+    def num_atoms_global(self):
+        """Atoms of the whole structure (single-structure plans: every atom is owned by exactly one rank)."""
+        n = getattr(self, "_n_global", None)
+        if n is None:
+            raise RuntimeError("this plan does not know the size of the whole structure (set plan._n_global)")
+        return n
+
     def row_plan(self, row_of_node):
         """The atom exchange lists in the relation-row order of `row_of_node` (cached per tensor: the row layout of an
         atom set does not change along a trajectory, relations.py)."""
@@ -554,6 +572,7 @@ def partition(data, rank, world, axis=None, group=None):
                      owned_mask, num_graphs, group)
     plan.owned_local = torch.from_numpy(np.nonzero(is_owned)[0])
     plan.local_global = torch.from_numpy(local_ids.copy())
+    plan._n_global = int(n)
     late = ~is_owned                                   # halo atoms, and the owned atoms that have a halo source
     late[ltgt[~is_owned[lsrc]]] = True
     plan.late_local = torch.from_numpy(late.copy())
@@ -666,6 +685,7 @@ def plan_slab(pos, atomic_number, cell, rc, rank, world, axis=None, group=None, 
                      is_owned, 1, group)
     plan.owned_local = torch.arange(n_owned, device=dev)
     plan.local_global = local_ids
+    plan._n_global = int(n)
     plan.rc, plan.skin = float(rc), float(skin)
     plan.pos_ref = pos.detach().clone()
     plan.z_local = atomic_number[local_ids]
@@ -725,6 +745,7 @@ def plan_self_peer(pos, atomic_number, cell, rc, virtual=2, axis=None, group=Non
                      is_owned, 1, group)
     plan.owned_local = torch.arange(n, device=dev)
     plan.local_global = local_ids
+    plan._n_global = int(n)
     plan.rc, plan.skin = float(rc), float(skin)
     plan.pos_ref = pos.detach().clone()
     plan.z_local = atomic_number[local_ids]
@@ -871,6 +892,7 @@ def _finish_plan(pos, atomic_number, cell, rc, skin, rank, world, group, owner, 
                      is_owned, 1, group)
     plan.owned_local = torch.arange(n_owned, device=dev)
     plan.local_global = local_ids
+    plan._n_global = int(n)
     plan.rc, plan.skin = float(rc), float(skin)
     plan.pos_ref = pos.detach().clone()
     plan.z_local = atomic_number[local_ids]
