@@ -298,6 +298,40 @@ def decomposition_secondary(synth, dev, rc, world=8, skin=1.0):
     return out
 
 
+def self_peer_secondary(timeout=240.0):
+    """The load of ONE rank of the 8-slab plan of configs[3], halo exchange included, on this one GPU (VERDICT r5
+    item 1): 12,400 owned atoms (fcc 10 x 10 x 31) + the ~1,400 ghost rows of one slab across the periodic boundary, the
+    per-layer exchange running over RCCL with this rank as its own peer (`sharding.plan_self_peer`, `bench.py --self-peer 1`).
+    A CHILD process (it needs a process group and more hardware queues than the headline run: see the top of this file); its
+    line is condensed here.  What a one-GPU box can say about the 8-GPU curve: `projected_speedup_at_8` = the unsharded 100k
+    cell's step / this step -- compute, launches and stream hand-offs are real, the links are not (a local copy)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--self-peer", "1", "--config", "c2", "--reps", "10,10,31", "--steps", "30",
+           "--warmup", "5", "--no-cpu-baseline"]
+    env = dict(os.environ, HERMNET_BENCH_CHILD="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MASTER_PORT"] = "29583"
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if r.returncode != 0 or not lines:
+        return {"error": "child exited with %d: %s" % (r.returncode, r.stderr[-400:])}
+    d = json.loads(lines[-1])
+    c, sec = d.get("comm", {}), d.get("secondary", {})
+    same = sec.get("single_gpu_same_cell", {})
+    out = {"workload": d["config"]["workload"], "parallelism": d["config"]["parallelism"],
+           "owned_atoms": d["config"]["atoms_owned_rank0"], "ghost_rows": d["config"]["halo_atoms_rank0"],
+           "ms_per_step": d["ms_per_step"], "unsharded_same_cell_ms_per_step": same.get("ms_per_step"),
+           "over_unsharded": (d["ms_per_step"] / same["ms_per_step"]) if same.get("ms_per_step") else None,
+           "ms_per_step_incl_planning": sec.get("ms_per_step_incl_planning"),
+           "exchanges_per_step": c.get("exchanges_per_step"), "bytes_per_row": c.get("bytes_per_row"),
+           "rows_per_exchange": c.get("rows_sent_per_exchange", {}).get("max"),
+           "stream_wait_ms_per_exchange": c.get("stream_wait_ms_per_exchange"),
+           "all_to_all_ms_isolated": c.get("all_to_all_ms_isolated", {}).get("max"), "hidden_fraction": c.get("hidden_fraction"),
+           "energy": d.get("energy")}
+    return out
+
+
 def graph_replay_secondary(hn, synth, dev, model, data, model_kw, steps=20):
     """ms per step of whole-step hipGraph replay: the headline workload and the 1024-molecule batch (launch-bound
     when enqueued eagerly)."""
@@ -565,7 +599,7 @@ def launch_rehearsal(args, world, rank):
     return 0
 
 
-def comm_block(step, plan, data, dev, backend, world, H, layers, kernel_ms_per_step, step_ms_local):
+def comm_block(step, plan, data, dev, backend, world, H, layers, kernel_ms_per_step, step_ms_local, T=3):
     """What the halo exchanges of the sharded step cost, per rank and over the ranks: every
     rank times its stream waits with HIP events (sharding.CommProbe) in a short pass behind the timed region, times the same
     all-to-all in isolation, and the per-rank figures are gathered to rank 0.  hidden fraction = 1 - (time the compute
@@ -582,10 +616,15 @@ def comm_block(step, plan, data, dev, backend, world, H, layers, kernel_ms_per_s
         sharding.set_comm_probe(None)
     ap = plan.atom_plan
     n_send, n_recv = sum(ap.send_counts), sum(ap.recv_counts)
-    # the layer exchange by itself: the same packed rows (4H floats per halo atom), nothing else on the GPU
+    # floats per packed row: the "proj" form of the exchange (the default where it applies: layer.FusedRelationalLayer) moves
+    # xh[t] of the T relations + vec = (T + 1) 3H floats per halo atom, the rows form x | vec = 4H
+    proj = os.environ.get("HERMNET_HALO_OVERLAP", "2") not in ("0", "1") and H == 128
+    row_floats = (T + 1) * 3 * H if proj else 4 * H
+    bytes_row = row_floats * 4
+    # the layer exchange by itself: the same packed rows, nothing else on the GPU
     iso = float("nan")
     try:
-        buf = torch.zeros(n_send, 4 * H, device=dev)
+        buf = torch.zeros(n_send, row_floats, device=dev)
         for _ in range(3):
             sharding._all_to_all_rows(buf, ap.send_counts, ap.recv_counts, ap.group)
         torch.cuda.synchronize()
@@ -618,16 +657,19 @@ def comm_block(step, plan, data, dev, backend, world, H, layers, kernel_ms_per_s
     nf, nb = float(col["async_exchanges_fwd_per_step"].max()), float(col["async_exchanges_bwd_per_step"].max())
     iso_max = float(col["all_to_all_ms_isolated"].max())
     out = {
-        "what": "halo exchange of the sharded step: per layer ONE variable-size all_to_all_single of packed (x | vec) rows each way, "
-                "started asynchronously and waited for by the compute STREAM behind the interior node / message launches",
+        "what": "halo exchange of the sharded step: per layer ONE variable-size all_to_all_single of packed rows each way "
+                "(proj form: the owner's projections xh[t] of every relation | vec forward, the partial sums of their gradients "
+                "backward; rows form: x | vec), started asynchronously and waited for by the compute STREAM behind the messages "
+                "into / out of the rows that read no halo row",
+        "exchange_form": "proj" if proj else "rows",
         "exchanges_per_step": {"features_forward": layers - 1, "gradients_backward": layers - 1, "position_gradient_return": 1,
                                "scalar_all_reduces": 2, "asynchronous_forward": nf, "asynchronous_backward": nb,
                                "blocking": float(col["blocking_exchanges_per_step"].max())},
-        "bytes_per_row": 4 * H * 4,
+        "bytes_per_row": bytes_row,
         "rows_sent_per_exchange": mm("rows_sent_per_exchange"), "rows_received_per_exchange": mm("rows_received_per_exchange"),
-        "bytes_sent_per_exchange": {k: v * 4 * H * 4 for k, v in mm("rows_sent_per_exchange").items()},
+        "bytes_sent_per_exchange": {k: v * bytes_row for k, v in mm("rows_sent_per_exchange").items()},
         "peers": {"sent_to": mm("peers_sent_to"), "received_from": mm("peers_received_from")},
-        "bytes_per_exchange_per_peer_mean": float((col["rows_sent_per_exchange"] / col["peers_sent_to"].clamp(min=1)).mean()) * 4 * H * 4,
+        "bytes_per_exchange_per_peer_mean": float((col["rows_sent_per_exchange"] / col["peers_sent_to"].clamp(min=1)).mean()) * bytes_row,
         "all_to_all_ms_isolated": mm("all_to_all_ms_isolated"),
         "stream_wait_ms_per_exchange": {
             "forward": {k: v / max(nf, 1.0) for k, v in mm("wait_fwd_ms_per_step").items()},
@@ -1055,6 +1097,10 @@ def main():
                 out["secondary"]["launches_per_step"], out["secondary"]["launches_per_step_own_kernels"] = count_launches(step)
             except Exception as ex:
                 out["secondary"]["launches_per_step"] = {"error": repr(ex)}
+            try:
+                out["secondary"]["sharded_rank_of_8_self_peer"] = self_peer_secondary()
+            except Exception as ex:
+                out["secondary"]["sharded_rank_of_8_self_peer"] = {"error": repr(ex)}
             try:
                 out["secondary"]["decomposition_at_8_ranks"] = decomposition_secondary(synth, dev, model_kw["rc"])
             except Exception as ex:
