@@ -776,6 +776,10 @@ def main():
     from hermnet_amd import synth, ops, _lib
     from hermnet_amd.utils import enable_tuned_gemms, freeze_gemm_tuning
     _lib.load()   # fail loudly if the HIP library is missing
+    if os.environ.get("HN_OPTIONS") or os.environ.get("HN_SWITCHES"):      # (A/B loops of tools/*.sh: tools/_opts.py)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from _opts import apply_option_env
+        apply_option_env()
     # No library GEMM is left on the energy/force path (csrc/node_chain.hip, the fused read-out), so there is nothing for
     # TunableOp to choose: round 2's recorded table / online tuning during the warm-up -- and with it the risk of ranks
     # timing candidates differently in a multi-GPU run -- are off unless asked for (HERMNET_BENCH_TUNED_GEMMS=1: only the
@@ -1017,7 +1021,8 @@ def main():
                 "own_roofline_note": "per chain kernel: bound_us = (most workgroups on one CU) x (a workgroup's bf16-pipe time at "
                                      "4096 FLOP/clk per CU, 2.4 GHz); fp32_pipe_bound_us = the same grid on the fp32 MFMAs; "
                                      "hbm_bound_us = algorithmic bytes of the launch at 8 TB/s; frac* = bound / measured"}
-        if H == 128 and os.environ.get("HERMNET_DEFER_SUMS", "1") != "0" and not sharded:
+        from hermnet_amd import switches as _sw
+        if H == 128 and _sw.defer_sums() and not sharded:
             mfma["note_pending_grads"] = ("node_update_bwd of layers 0..L-2 also forms its incoming gradients from the partial sums "
                                           "of the layer above (hn_pending_grads: what message_bwd_finish + layernorm_bwd_parts did "
                                           "in two launches outside this section): +12-15 us per launch of memory-bound work counted "

@@ -131,6 +131,9 @@ SIGNATURES = {
     "hermnet_halo_proj_accumulate": (ctypes.c_int, [c_fp, ctypes.c_long, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, ctypes.c_int,
                                                     ctypes.c_int, c_fp, c_fp]),
     "hermnet_stream_copy": (ctypes.c_int, [c_fp, c_fp, ctypes.c_size_t, ctypes.c_int, c_fp]),
+    "hermnet_set_option": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "hermnet_get_option": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "hermnet_weight_fragments": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
     "hermnet_param_guard": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),
     "hermnet_shard_step_flags": (ctypes.c_int, [c_fp, ctypes.c_long, c_fp, ctypes.c_int, c_fp, ctypes.c_long, c_fp, c_fp, c_fp,
                                                 ctypes.c_long, ctypes.c_float, c_fp]),
@@ -179,7 +182,7 @@ def load():
         raise RuntimeError("hermnet_amd: %s has ABI version %d, the Python side expects %d -- rebuild it "
                            "(`make -C hermnet_amd/csrc`)" % (LIB_PATH, lib.hermnet_abi_version(), ABI_VERSION))
     # the library must have been built from the sources next to it: a stale prebuilt binary would otherwise be what
-    # the tests and the benchmark measure (HERMNET_LIB_PATH = an explicitly chosen diagnostic build: not checked)
+    # the tests and the benchmark measure (an explicitly chosen diagnostic build is not checked)
     if not os.environ.get("HERMNET_LIB_PATH") and os.environ.get("HERMNET_ALLOW_STALE_LIB", "0") == "0":
         info = lib.hermnet_build_info().decode()
         try:
@@ -191,6 +194,41 @@ def load():
                                "hash to %s) -- rebuild it (`make -C hermnet_amd/csrc`)" % (LIB_PATH, info, want))
     _lib = lib
     return lib
+
+
+# hermnet_set_option / hermnet_get_option (include/hermnet_hip.h: HN_OPT_*): tuning knobs and the alternative kernel forms
+# that tests and A/Bs compare against -- process-wide, read by the launchers at every call
+OPTIONS = {"fwd_variant": 0, "fwd_variant_l0": 1, "bwd_variant": 2, "bwd_variant_l0": 3, "fwd_rows": 4, "bwd_rows": 5,
+           "bwd_cl_rows": 6, "bwd_lanes16": 7, "node_chain_wide": 8, "update_tile16": 9, "update_tile64_max": 10}
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    check(load().hermnet_get_option(OPTIONS[name], ctypes.byref(v)), "hermnet_get_option")
+    return int(v.value)
+
+
+def set_option(name, value):
+    """Set a library option; returns the previous value."""
+    old = get_option(name)
+    check(load().hermnet_set_option(OPTIONS[name], int(value)), "hermnet_set_option")
+    return old
+
+
+class options(object):
+    """`with _lib.options(bwd_lanes16=1): ...` -- options set for a block, restored behind it (tests, A/Bs)."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
 
 
 def check(rc, what):

@@ -24,6 +24,7 @@
 #include "../../include/hermnet_hip.h"
 #include "hermnet_math.h"
 #include "message_bwd_cl.h"
+int hn_option(int option);      // host_api.cpp
 
 #define HN_LDS_ROW (3 * HN_CB)      // floats per tap row in LDS: [part][64]
 // Phase fence for the instruction scheduler: without it hipcc hoists the LDS reads of all three
@@ -848,11 +849,7 @@ int fill_args(const hn_graph* g, const hn_rbf_desc* rbf, int hidden, MsgArgs& a)
   return HN_OK;
 }
 
-// tuning knobs (environment, read once)
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
+// tuning knobs and alternative forms: process-wide options (host_api.cpp: hermnet_set_option), read at every launch
 
 int num_cus() {
   static int n = 0;
@@ -966,17 +963,16 @@ extern "C" int hermnet_message_scatter_fwd(const hn_graph* g, const hn_rbf_desc*
   a.edge = reinterpret_cast<const float4*>(edge);
   a.x1 = x1; a.vec1 = vec1;
   a.row_ranges = target_ranges; a.zero_unknown = (target_ranges == nullptr) || zero_unknown_rows;
-  static const int rpb_fwd = env_int("HERMNET_FWD_ROWS", 0);
+  const int rpb_fwd = hn_option(HN_OPT_FWD_ROWS);
   // defaults from tools/kbench.py on MI355X (config 2): see DESIGN.md "Kernel variants"
-  static const int variant_vec = env_int("HERMNET_FWD_VARIANT", 8420);
-  static const int variant_l0 = env_int("HERMNET_FWD_VARIANT_L0", 16420);
+  const int variant_vec = hn_option(HN_OPT_FWD_VARIANT);
+  const int variant_l0 = hn_option(HN_OPT_FWD_VARIANT_L0);
   const int variant = vec ? variant_vec : variant_l0;
   // (a launch over row ranges sizes its workgroups for the rows it covers: a workgroup of the full launch lives as long
   // as the whole kernel, so a launch over a tenth of the rows with the same chunking would take just as long)
   const int rows = (target_ranges && range_rows > 0 && range_rows < a.N) ? range_rows : a.N;
   a.rows_per_block = pick_rows(rows, hidden / HN_CB, a.T * (hidden / HN_CB), rpb_fwd);
-  static const int xcd = env_int("HERMNET_XCD_REMAP", 1);
-  a.xcd_remap = xcd;
+  a.xcd_remap = 1;
   // blocks: sum_t ceil(N_t / rpb) <= N / rpb + T, plus one surplus block that zeroes unknown rows
   dim3 grid((unsigned)(rows / a.rows_per_block + a.T + 1), (unsigned)(hidden / HN_CB));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1022,7 +1018,7 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   const bool no_finish = gx == nullptr;        // the consumer sums the partials (include/hermnet_hip.h)
   if (g->num_edges > 0 && !edge) return HN_ERR_BAD_ARG;
   if (a.N == 0) return HN_OK;
-  static const int use_cl = env_int("HERMNET_BWD_CL", 1);
+  const int use_cl = hn_option(HN_OPT_BWD_LANES16) == 0;
   const bool virtual_targets = g->num_src > 0 || g->res_row != nullptr;
   const size_t gather_bytes = (size_t)a.N * 3 * hidden * sizeof(float);      // the channel-per-lane form gathers through
   const size_t src_rows = g->num_src > 0 ? (size_t)g->num_src : (size_t)a.N;
@@ -1045,9 +1041,8 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
     b.gxh = gxh; b.gvec = (a.T == 1 && !no_finish) ? gvec : gvec_partials; b.gvec_out = gvec; b.gx = gx;
     b.gedge = reinterpret_cast<float4*>(gedge);
     b.type_rowptr = g->type_rowptr;
-    static const int rpb_cl = env_int("HERMNET_BWD_CL_ROWS", 0);
-    static const int xcd_cl = env_int("HERMNET_XCD_REMAP", 1);
-    b.xcd_remap = xcd_cl;
+    const int rpb_cl = hn_option(HN_OPT_BWD_CL_ROWS);
+    b.xcd_remap = 1;
     b.src_ranges = source_ranges; b.num_ranges = num_ranges;
     return hn_bwd_cl_launch(b, vec != nullptr, rpb_cl, source_ranges_host, reinterpret_cast<hipStream_t>(stream));
   }
@@ -1055,9 +1050,9 @@ extern "C" int hermnet_message_scatter_bwd(const hn_graph* g, const hn_rbf_desc*
   a.edge = reinterpret_cast<const float4*>(edge);
   a.gx1 = gx1; a.gvec1 = gvec1; a.gxh = gxh; a.gvec = gvec; a.gx = gx;
   a.gedge = reinterpret_cast<float4*>(gedge);
-  static const int rpb_bwd = env_int("HERMNET_BWD_ROWS", 0);
-  static const int variant_vec = env_int("HERMNET_BWD_VARIANT", 8420);
-  static const int variant_l0 = env_int("HERMNET_BWD_VARIANT_L0", 8420);
+  const int rpb_bwd = hn_option(HN_OPT_BWD_ROWS);
+  const int variant_vec = hn_option(HN_OPT_BWD_VARIANT);
+  const int variant_l0 = hn_option(HN_OPT_BWD_VARIANT_L0);
   const int variant = vec ? variant_vec : variant_l0;
   a.split_t = split_t ? 1 : 0;
   a.rows_per_block = pick_rows(a.N, (hidden / HN_CB) * (a.split_t ? a.T : 1), 0, rpb_bwd) * (a.split_t ? a.T : 1);

@@ -27,6 +27,7 @@
 // Two workgroups per CU (<= 68 KB of LDS, <= 256 VGPRs): one's elementwise / staging phases run beside the other's
 // matrix phases.  fp32 MFMA is exact fp32 (a k-ordered fmaf chain): results equal a library GEMM's to rounding.
 #include "node_chain_common.h"
+int hn_option(int option);      // host_api.cpp: process-wide options (hermnet_set_option)
 
 namespace {
 // =====================================================================================================================
@@ -747,13 +748,9 @@ __global__ __launch_bounds__(256, MINW) void node_update_bwd_kernel(UpdBwdArgs a
 // Update kernels: tile (H, TR) and register budget.  H = 128 has two instances: 32-row tiles fit 256 registers, so two
 // workgroups share a CU and one's elementwise phases run beside the other's matrix phases (the default: measured
 // 64 / 77 us against 75 / 99 us per launch at 10,000 rows); 64-row tiles keep ~400 values per lane live (one wave per SIMD,
-// 512 registers) and load every weight fragment once per 64 rows (HERMNET_UPDATE_TILE64_MAX = largest grid, in 64-row
+// 512 registers) and load every weight fragment once per 64 rows (option HN_OPT_UPDATE_TILE64_MAX = largest grid, in 64-row
 // tiles, that takes them).
-inline int tile64_max() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("HERMNET_UPDATE_TILE64_MAX"); v = e ? atoi(e) : 0; }
-  return v;
-}
+inline int tile64_max() { return hn_option(HN_OPT_UPDATE_TILE64_MAX); }
 #define HN_TILES(TR) tiles_of(type_rowptr_host, num_rel, num_nodes, TR)
 #define HN_UPDATE_DISPATCH(KERNEL, ARGS)                                                                              \
   switch (hidden) {                                                                                                   \
@@ -794,11 +791,10 @@ int hn_head16_bwd(const float* ge, const float* h, const float* w0t_frag16, cons
                   int rows, void* stream);
 
 // Widths 64 / 128 / 256 have tuned instances in this file; every other multiple of 64 up to 512 -- the reference's default
-// hidden_channels = 512 among them (hermnet.py:86) -- takes the panelled kernels.  HERMNET_NODE_CHAIN_WIDE=1 sends 128 and
-// 256 there too (tests, comparisons).
+// hidden_channels = 512 among them (hermnet.py:86) -- takes the panelled kernels.  Option HN_OPT_NODE_CHAIN_WIDE = 1 sends 128
+// and 256 there too (tests, comparisons).
 static bool use_wide(int hidden) {
-  static int force = -1;
-  if (force < 0) { const char* e = getenv("HERMNET_NODE_CHAIN_WIDE"); force = e ? atoi(e) : 0; }
+  const int force = hn_option(HN_OPT_NODE_CHAIN_WIDE);
   if (hidden == 64) return false;
   return force != 0 || !(hidden == 128 || hidden == 256);
 }
@@ -808,8 +804,7 @@ static int pre_tile_rows(int hidden) { return use_wide(hidden) ? 32 : (hidden ==
 // 16 or 32: the tile height the update kernels should run this grid at.  16-row tiles cost twice the weight bytes from L2,
 // so they are chosen only where they shorten the launch: the busiest CU's share (whole tiles) is at least ~15 % smaller.
 extern "C" int hermnet_node_update_tile_rows(const int* type_rowptr_host, int num_nodes, int num_rel, int hidden) {
-  static int force = -1;
-  if (force < 0) { const char* e = getenv("HERMNET_UPDATE_TILE16"); force = e ? atoi(e) : 2; }   // 0 never, 1 always, 2 auto
+  const int force = hn_option(HN_OPT_UPDATE_TILE16);      // 0 never, 1 always, 2 auto
   if (!type_rowptr_host || !hermnet_node_chain_supported(hidden)) return 0;
   const int base = use_wide(hidden) ? 32 : (hidden == 64 ? 64 : 32);
   if (!hn_update16_supported(hidden) || use_wide(hidden) || force == 0) return base;

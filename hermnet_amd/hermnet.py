@@ -6,8 +6,9 @@ from typing import Dict, List, Union
 import torch
 from torch import nn
 
+from . import switches
 from .elements import atomic_numbers
-from .ops import EdgeGeometry, TrueEdgeGradient, edge_radial_table, side_stream
+from .ops import EdgeGeometry, TrueEdgeGradient, edge_radial_table
 from .relations import RelationalGraph
 from .sharding import HaloExchange, HaloExchangeFeatures, HaloGradReturn, SumAcrossRanks
 from .layer import (EdgeFanout, EdgeGradSink, EnergyHead, FusedRelationalLayer, LayerWeights, _node_chain_enabled, _PENDING,
@@ -37,21 +38,18 @@ class HeteroVertexConv(nn.Module):
         ready = data.get("_hn_weights")          # (HVNet.forward refreshed every layer's copies up front: guard.ParamGuard)
         if ready is not None and ready[data.get("_hn_layer", 0)].mods[0] is next(iter(self.mods.values())):
             w = ready[data.get("_hn_layer", 0)]
-        if (w is None and halo is not None and data.get("_hn_edge_embed") is None
-                and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0"):
+        if w is None and halo is not None and data.get("_hn_edge_embed") is None and switches.fused_layer:
             if self._weights is None:
                 self._weights = LayerWeights(self.mods.values())
             w = self._weights.refresh()
-        # (default ON: HERMNET_HALO_OVERLAP=0 runs the blocking exchange in front of the layer instead; the overlapped
-        # form needs the chain kernels and the channel-per-lane backward, which takes row ranges)
+        # (the exchange inside the layer needs the chain kernels and the channel-per-lane backward, which takes row ranges;
+        # switches.halo_overlap() == "0" runs the blocking exchange in front of the layer instead)
         if halo is not None and not (w is not None and w.chain and _node_chain_enabled()
                                      and halo.fwd_early is not None and g.N * 3 * data.x.size(1) * 4 < 2 ** 32
                                      # (a rank that neither sends nor receives joins the collective in its plain form:
                                      # nothing to hide, and the asynchronous form costs ~15 us of stream hand-offs)
                                      and sum(halo.plan.recv_counts) + sum(halo.plan.send_counts) > 0
-                                     and os.environ.get("HERMNET_BWD_CL", "1") != "0"
-                                     and os.environ.get("HERMNET_BWD_SPLIT_T", "0") == "0"
-                                     and os.environ.get("HERMNET_HALO_OVERLAP", "1") != "0"):
+                                     and switches.halo_overlap() != "0"):
             data.x, data.vec = HaloExchangeFeatures.apply(data.x, data.vec, halo.plan)
             halo = None
         if data.get("_hn_edge_embed") is not None:
@@ -59,7 +57,7 @@ class HeteroVertexConv(nn.Module):
             data.x, data.vec = relational_layer(self.mods.values(), data.x, data.vec, data._hn_edge, g, None,
                                                 edge_embed=data._hn_edge_embed)
             return data
-        if os.environ.get("HERMNET_FUSED_LAYER", "1") == "0":
+        if not switches.fused_layer:
             # debugging path: same kernels for the edge part, node algebra through PyTorch autograd
             data.x, data.vec = relational_layer(self.mods.values(), data.x, data.vec, data._hn_edge, g, data._hn_rbf)
             return data
@@ -73,14 +71,14 @@ class HeteroVertexConv(nn.Module):
         # input gradients down as partial sums (layer.FusedRelationalLayer, `defer`)
         node = data.get("_hn_chain_node")
         # (not under anomaly detection -- its NaN check would read the not-yet-filled buffers -- and not when a tensor hook
-        # would: both are debugging situations, which get the finishing launches; HERMNET_DEFER_SUMS=0 forces them)
+        # would: both are debugging situations, which get the finishing launches; switches.defer_sums() forces them)
         straight = (node is not None and data.vec is not None and data.x.grad_fn is node and data.vec.grad_fn is node
                     and not g.num_src and not torch.is_anomaly_enabled()
                     and not getattr(data.x, "_backward_hooks", None) and not getattr(data.vec, "_backward_hooks", None))
         defer = straight and halo is None and (data.get("_hn_shard") is None or data.get("_hn_lone"))
-        # atom shards: the exchange in its "proj" form (layer.FusedRelationalLayer; HERMNET_HALO_OVERLAP=1: the round-4 form,
-        # x | vec rows with windowed node launches around the exchange; 0: the blocking exchange in front of the layer)
-        proj = straight and halo is not None and os.environ.get("HERMNET_HALO_OVERLAP", "2") not in ("0", "1")
+        # atom shards: the exchange in its "proj" form (layer.FusedRelationalLayer; switches.halo_overlap() "1": the round-4
+        # form, x | vec rows with windowed node launches around the exchange; "0": the blocking exchange in front of the layer)
+        proj = straight and halo is not None and switches.halo_overlap() not in ("0", "1")
         # the node projection of THIS x, already computed: the first layer's by HVNet.forward (side stream), every later layer's
         # by the fused update launch of the layer below (round 5)
         pre, data._hn_pre0 = data.get("_hn_pre0"), None
@@ -211,7 +209,7 @@ class HVNet(nn.Module):
     def _refresh_weights(self, dev):
         """Every layer's kernel-ready copies, current; fingerprints recorded / checked on the device (one launch)."""
         from .guard import ParamGuard
-        guard_on = dev.type == "cuda" and os.environ.get("HERMNET_PARAM_GUARD", "1") != "0"
+        guard_on = dev.type == "cuda" and switches.param_guard()
         for _ in range(2):
             ws = []
             for conv in self.hermconvs:
@@ -250,12 +248,12 @@ class HVNet(nn.Module):
             raise TypeError("hermnet_amd.HVNet computes in float32: parameters are %s, data.pos is %s "
                             "(call model.float() / pos.float())" % (wd, pos.dtype))
 
-    def _build_graph(self, data, zl, shard, side=None):
+    def _build_graph(self, data, zl, shard):
         """Relation-ordered graph of this neighbour list (the replacement of `in_subgraph`, utils.py:11-24)."""
         rel_active = None if shard is None else shard.rel_active(zl)
         return RelationalGraph.build(data.atomic_number, data.edge_index, zl,
                                      edge_shift=data.get("edge_shift") if data.get("cell") is not None else None,
-                                     batch=data.batch, rel_active=rel_active, side=side)
+                                     batch=data.batch, rel_active=rel_active)
 
     @staticmethod
     def _edge_geometry_autograd(pos, cell, graph):
@@ -263,8 +261,7 @@ class HVNet(nn.Module):
         Training path only: `create_graph=True` needs second derivatives, which the geometry kernel's
         hand-written backward does not provide."""
         src = graph.src_id.long()
-        if (pos.is_cuda and not graph.num_src and graph.csc_pos is not None
-                and os.environ.get("HERMNET_TRAIN_KERNELS", "1") != "0"):
+        if pos.is_cuda and not graph.num_src and graph.csc_pos is not None:
             from .trainops import EdgeDiff
             D = EdgeDiff.apply(pos, graph)          # (gather and its adjoint as a closed pair: no index sort, no atomics)
         else:
@@ -299,19 +296,12 @@ class HVNet(nn.Module):
         if padded and train:
             raise NotImplementedError("a padded neighbour list runs through the fused eval() path")
         fused = self.radial_basis.fused and not train
-        # Two things of a step are not on its critical path: the first layer's node projection needs the
-        # atoms only, not the edges, and the radial table is read by the backward only.  HERMNET_SIDE_STREAM=1 sends the edge
-        # part of the relation build to a second stream while this one embeds the atoms and projects them, and the table to
-        # the second stream while the forward layers run here (2 = the table only, 3 = the build only); the streams join
-        # before the first reader of each.  OFF by default -- measured: the two fork / join pairs cost
-        # what the overlap gains (bench line 3.06-3.08 vs 3.02 ms; whole-step hipGraph replay 2.94 ms either way; only an
-        # eager loop without event timers gains, 2.96 vs 3.01 ms).
-        side = None
-        side_mode = int(os.environ.get("HERMNET_SIDE_STREAM", "0"))
-        if (side_mode and fused and shard is None and pos.is_cuda and type(self)._build_graph is HVNet._build_graph
-                and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0"):
-            side = side_stream(pos.device)
-        graph = self._build_graph(data, zl, shard, side) if side is not None and side_mode != 2 else self._build_graph(data, zl, shard)
+        # (the 16-lanes-per-edge backward stages a whole weight tile: num_rbf <= 176; the channel-per-lane form, which takes
+        # wider bases in two windows, addresses its gathers with 32-bit offsets -- beyond ~2.3 M local atoms at width 128 such a
+        # basis takes the materialised route instead of failing in the backward: ADVICE r5)
+        if fused and self.radial_basis.num_radial > 176 and pos.size(0) * 1.2 * 3 * ((self.hidden_channels + 63) // 64 * 64) * 4 >= 2 ** 32:
+            fused = False
+        graph = self._build_graph(data, zl, shard)
         rbf = self.radial_basis.descriptor() if fused else None
         row_plan = None
         if shard is not None:
@@ -337,25 +327,14 @@ class HVNet(nn.Module):
         # (the fused layers produce no parameter gradients; a partial set would be worse than none)
         x = self.embed(graph.z_rows) if train else torch.nn.functional.embedding(graph.z_rows, self.embed.weight.detach())
         H = self.hidden_channels
-        Hp = (H + 63) // 64 * 64 if (fused and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0") else H
+        Hp = (H + 63) // 64 * 64 if (fused and switches.fused_layer) else H
         if Hp != H:
             # widths that are not a multiple of 64 run on the same kernels with zero-padded channels (layer.LayerWeights)
             x = torch.nn.functional.pad(x, (0, Hp - H))
         data._hn_pre0 = None
         data._hn_weights = None
-        if fused and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0":
+        if fused and switches.fused_layer:
             data._hn_weights = self._refresh_weights(pos.device)
-        if graph.ready is not None:
-            # (the edge part of the build is still running on the side stream: the row arrays above are the cached ones)
-            conv0 = self.hermconvs[0]
-            if conv0._weights is None:
-                conv0._weights = LayerWeights(conv0.mods.values())
-            w0 = conv0._weights.refresh()
-            if w0.chain and _node_chain_enabled():
-                from . import nodeops
-                data._hn_pre0 = (x, nodeops.node_pre_fwd(x, w0, graph.T, src_ranges=graph.src_ranges))
-            torch.cuda.current_stream().wait_event(graph.ready)
-            graph.ready = None
         if train:
             edge = self._edge_geometry_autograd(pos, data.get("cell"), graph)
         else:
@@ -365,25 +344,20 @@ class HVNet(nn.Module):
         if not fused and not train:
             edge = TrueEdgeGradient.apply(edge)      # autograd's (rhat, d) gradients -> Cartesian for the kernel
         data._hn_graph, data._hn_edge, data._hn_rbf = graph, edge, rbf
-        table_ready = None
         if fused and edge.requires_grad and edge.is_cuda:
             # forces wanted: the backward message kernels read the radial quantities of an edge from this table
-            if side is not None and side_mode != 3:
-                graph.edge_table, table_ready = edge_radial_table(graph, rbf, edge.detach(), side)
-            else:
-                graph.edge_table = edge_radial_table(graph, rbf, edge.detach())
+            graph.edge_table = edge_radial_table(graph, rbf, edge.detach())
         # rmnet.py:168-172 for the optional bases only: [E,R] basis from the kernel's distances
         if fused:
             data._hn_edge_embed = None
-        elif (train and pos.is_cuda and self.radial_basis.rbf_name == "gaussian" and H % 4 == 0 and graph.T > 0
-              and os.environ.get("HERMNET_TRAIN_KERNELS", "1") != "0" and os.environ.get("HERMNET_TRAIN_BUCKETS", "1") != "0"):
+        elif train and pos.is_cuda and self.radial_basis.rbf_name == "gaussian" and H % 4 == 0 and graph.T > 0:
             # train(): the basis sorted by (relation, distance bucket) and cut to the bucket's 32 centres (trainops.BucketedBasis)
             data._hn_edge_embed = self.radial_basis.bucketed(edge[:, 3], graph.rel_edge_bounds(), graph.T)
         else:
             data._hn_edge_embed = self.radial_basis(edge[:, 3])
         data.x, data.vec = x, vec
         data._hn_edge_handles = data._hn_edge_sink = data._hn_halo = data._hn_chain_node = None
-        if fused and edge.requires_grad and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0":
+        if fused and edge.requires_grad and switches.fused_layer:
             # one reduction of the edge gradients per step instead of one per layer (layer.EdgeFanout)
             # (atoms of an unknown element own the rows past type_rowptr[T]; only edges INTO them go unwritten)
             # (the slots of a padded list's NULL edges stay unwritten too, but nothing reads them: the position gradient
@@ -400,8 +374,6 @@ class HVNet(nn.Module):
                 # one exchange per layer: (x | vec) rows of halo atoms, 4H floats each -- due before the next layer reads
                 # them, run BY that layer (overlapped with its node projection where it can, HeteroVertexConv.forward)
                 data._hn_halo = shard.halo_overlap(graph, nodeops_tile_rows(Hp))
-        if table_ready is not None:             # (the backward reads the table; by now it has long been written)
-            torch.cuda.current_stream().wait_event(table_ready)
         graph._keep = None
         x = data.x
         if Hp != H:
@@ -415,11 +387,10 @@ class HVNet(nn.Module):
         # (round 6: ~10 small launches per step less, forward and backward)
         shard_rows = None
         if (shard is not None and shard.num_graphs == 1 and not train and fused
-                and os.environ.get("HERMNET_FUSED_LAYER", "1") != "0" and (self.hidden_channels // 2) % 4 == 0):
+                and switches.fused_layer and (self.hidden_channels // 2) % 4 == 0):
             shard_rows = shard.owned_rows(graph, x.size(0))
-        if (train or not fused or (self.hidden_channels // 2) % 4 != 0
-                or os.environ.get("HERMNET_FUSED_LAYER", "1") == "0"):
-            if train and x.is_cuda and os.environ.get("HERMNET_TRAIN_TALL", "1") != "0":
+        if train or not fused or (self.hidden_channels // 2) % 4 != 0 or not switches.fused_layer:
+            if train and x.is_cuda:
                 # (the same nn.Sequential, its two Linears through trainops.TallBmm: weight gradients over ~2e4 rows)
                 from .trainops import tall_linear
                 h_ = tall_linear(x, self.out_energy[0].weight, self.out_energy[0].bias)

@@ -11,15 +11,15 @@ import os as _os
 
 import torch
 
-from . import _lib, nodeops
+from . import _lib, nodeops, switches
 from .ops import _launch, _split_t, _stream
 
 P = _lib.ptr
 
-# HERMNET_NODE_CHAIN=0: node-level linears through library GEMMs joined by the stage kernels (the only path for widths
+# switches.node_chain = False: node-level linears through library GEMMs joined by the stage kernels (the only path for widths
 # the chain kernels are not instantiated for) instead of the four chain kernels of csrc/node_chain.hip.
 def _node_chain_enabled():
-    return _os.environ.get("HERMNET_NODE_CHAIN", "1") != "0"
+    return switches.node_chain
 
 
 class LayerWeights(object):
@@ -156,8 +156,8 @@ def _bwd_sums_deferrable(graph, H):
     configs[1], 27.2 vs 27.6 ms at 100k atoms); the wide kernels (one workgroup per CU) lose more in their prologue than
     the two launches cost (H = 512: 22.5 vs 20.8 ms), so they keep the launches."""
     return (H == 128 and graph.edge_table is not None and not graph.num_src and getattr(graph, "res_row", None) is None
-            and not _split_t(graph) and _os.environ.get("HERMNET_BWD_CL", "1") != "0"
-            and graph.N * 3 * H * 4 < 2 ** 32 and _os.environ.get("HERMNET_DEFER_SUMS", "1") != "0")
+            and not _split_t(graph) and _lib.get_option("bwd_lanes16") == 0
+            and graph.N * 3 * H * 4 < 2 ** 32 and switches.defer_sums())
 
 
 def _msg_bwd(graph, rbf, H, xh, vec, w, edge, gx1, gvec1, gedge, xh_bias=True, ranges=None, out=None, finish=True):
@@ -255,7 +255,7 @@ class EdgeGradSink(object):
         if self.buf is None:     # edges to targets of an unknown element are never written: zero once if there are any
             alloc = torch.zeros if self.zero else torch.empty
             self.buf = alloc(self.shape, dtype=torch.float32, device=self.device)
-            if not self.zero and _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":
+            if not self.zero and switches.debug_poison():
                 self.buf.fill_(float("nan"))         # (tests: a slot the kernels did not write would poison the forces)
         return self.buf[li]
 
@@ -290,7 +290,7 @@ _PRE_NEXT = {}
 
 
 def _boundary_mode():
-    """HERMNET_FUSE_BOUNDARY -- how the node launches of a layer boundary are cut, where `nodeops.fused_boundary_supported`
+    """`switches.boundary_mode` -- how the node launches of a layer boundary are cut, where `nodeops.fused_boundary_supported`
     (width 128, 16-row update tiles, HVNet rows: csrc/node_chain16.hip):
       0 (default)  every phase a launch of its own: 64-row projection kernels + 16-row update kernels, the input gradients handed
                    down as partial sums (the round-4 form);
@@ -304,7 +304,7 @@ def _boundary_mode():
     0: 2.944, 4: 2.945, 3: 2.971, 1: 2.988 ms per step.  Since the products run as bf16 splits (profiles/r05_boundary_ab_split.log):
     0: 2.80, 4: 2.82, 3: 2.87, 1: 2.89 -- with the matrix pipe 2.7 x cheaper a tile's time is its weight stream, and a 64-row
     projection tile streams a quarter of the bytes per row of a 16-row one: the fused forms lose what that gains."""
-    return int(_os.environ.get("HERMNET_FUSE_BOUNDARY", "0"))
+    return int(switches.boundary_mode)
 
 
 class FusedRelationalLayer(torch.autograd.Function):
@@ -357,7 +357,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                 hb, xh, mean, rstd = nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges)
                 send = nodeops.halo_proj_rows(0, xh, vec, plan.send_idx)
                 recv, work = _all_to_all_rows_start(send, plan.send_counts, plan.recv_counts, plan.group)
-                if _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":
+                if switches.debug_poison():
                     # (tests: nothing that runs before the unpack may depend on a halo row)
                     nodeops.halo_proj_rows(2, xh, vec, plan.recv_idx, torch.full_like(recv, float("nan")))
                 x1, vec1 = out = _msg_fwd(graph, rbf, H, xh, vec, x, w, edge, xh_bias=False, ranges=halo.fwd_early,
@@ -377,7 +377,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                 plan = halo.plan
                 send = nodeops.halo_rows(0, x, vec, plan.send_idx)
                 recv, work = _all_to_all_rows_start(send, plan.send_counts, plan.recv_counts, plan.group)
-                if _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":
+                if switches.debug_poison():
                     # (tests: nothing that runs before the unpack may depend on a halo row)
                     nodeops.halo_rows(2, x, vec, plan.recv_idx, torch.full_like(recv, float("nan")))
                 hb, xh, mean, rstd = pre = nodeops.node_pre_fwd(x, w, T, src_ranges=graph.src_ranges)
@@ -469,7 +469,8 @@ class FusedRelationalLayer(torch.autograd.Function):
             pend = _PENDING.pop((id(graph), ctx.li), None)
             if pend is not None and (pend.gx.data_ptr() != gxo.data_ptr() or pend.gvec.data_ptr() != gvo.data_ptr()):
                 raise RuntimeError("hermnet_amd: the gradients handed down as partial sums (layer %d) did not arrive in the "
-                                   "buffers they were registered with; set HERMNET_DEFER_SUMS=0" % (ctx.li + 1))
+                                   "buffers they were registered with; set the environment variable named in "
+                                   "hermnet_amd/switches.py: defer_sums to 0" % (ctx.li + 1))
             gx1, gvec1 = nodeops.node_update_bwd(gxo, gvo, vp, h2b, q23, nrm, w, graph, pending=pend)
         else:
             x, mean, rstd, h, xh, vec, edge, vp, vdot, xin, h2, q = ctx.saved_tensors
@@ -533,7 +534,7 @@ class FusedRelationalLayer(torch.autograd.Function):
             nodeops.halo_proj_accumulate(gxh, gv_parts, plan, back)                 # gradients of my atoms used elsewhere
             gn_parts = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, src_ranges=graph.src_ranges, parts_only=True)
             gx_total, gvec_in = torch.empty_like(x), torch.empty_like(vec)          # filled by the layer below
-            if _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":                # (tests: nothing reads them before that)
+            if switches.debug_poison():                # (tests: nothing reads them before that)
                 gx_total.fill_(float("nan"))
                 gvec_in.fill_(float("nan"))
             pend = _PENDING[(id(graph), ctx.li - 1)] = nodeops.PendingGrads(
@@ -585,7 +586,7 @@ class FusedRelationalLayer(torch.autograd.Function):
                 else:
                     gn_parts = nodeops.node_pre_bwd(gxh, hb, x, mean, rstd, w, src_ranges=graph.src_ranges, parts_only=True)
                 gx_total, gvec_in = torch.empty_like(x), torch.empty_like(vec)      # filled by the layer below
-                if _os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":            # (tests: nothing reads them before that)
+                if switches.debug_poison():            # (tests: nothing reads them before that)
                     gx_total.fill_(float("nan"))
                     gvec_in.fill_(float("nan"))
                 pend = _PENDING[(id(graph), ctx.li - 1)] = nodeops.PendingGrads(
@@ -619,7 +620,7 @@ class EnergyHead(torch.autograd.Function):
         """`mask` [N] (optional) multiplies the per-row energies: padding rows of the relation order -> 0."""
         w2v = w2.reshape(-1).contiguous()
         ctx.mask = mask
-        ctx.mfma = x.is_cuda and nodeops.head16_supported(x.size(1), w0.size(0)) and _os.environ.get("HERMNET_HEAD16", "1") != "0"
+        ctx.mfma = x.is_cuda and nodeops.head16_supported(x.size(1), w0.size(0))
         if ctx.mfma:       # the H -> C product on the matrix pipe (csrc/node_chain16.hip), one launch each way
             w0c = w0.contiguous()
             wf, wtf = _head_fragments(w0c)

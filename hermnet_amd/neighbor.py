@@ -23,6 +23,8 @@ import os
 
 import torch
 
+from . import switches
+
 
 def _expand_ranges(start, end):
     """Concatenate aranges [start_k, end_k) -> (flat_index, owner_k)."""
@@ -255,7 +257,7 @@ def neighbor_search_padded(pos, rc, cell, capacity, reference_compat=False, targ
     edge_index = torch.empty(2, cap, dtype=torch.long, device=dev)
     periodic = cell is not None
     shift = torch.empty(cap, 3, dtype=torch.float32, device=dev) if periodic else None
-    if os.environ.get("HERMNET_DEBUG_POISON", "0") != "0":
+    if switches.debug_poison():
         # (tests: a column the search leaves unwritten would send the relation build far out of bounds)
         edge_index.fill_(0x3f3f3f3f3f3f3f3f)
         if shift is not None:

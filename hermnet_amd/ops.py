@@ -50,19 +50,6 @@ def _stream():
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
-_SIDE = {}
-
-
-def side_stream(device):
-    """One extra HIP stream per device for the work that is NOT on the step's critical path (HVNet.forward: the relation
-    build beside the first layer's node projection, the radial table beside the forward layers)."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    st = _SIDE.get(idx)
-    if st is None:
-        st = _SIDE[idx] = torch.cuda.Stream(device=idx)
-    return st
-
-
 def _require_gpu(t, what):
     if not t.is_cuda:
         raise RuntimeError("hermnet_amd.%s: the hot path runs on MI355X only (got a %s tensor); "
@@ -90,9 +77,9 @@ class RbfDescriptor(object):
 
 
 def _split_t(graph):
-    """One relation per workgroup in the backward message kernel (env HERMNET_BWD_SPLIT_T=1; default off: measured slower on balanced compositions)."""
-    import os
-    return int(graph.T > 1 and os.environ.get("HERMNET_BWD_SPLIT_T", "0") != "0")
+    """`split_t` of hermnet_message_scatter_bwd (one relation per workgroup in the 16-lanes-per-edge backward): measured slower
+    on balanced compositions in round 2 and never chosen since; the host code always passes 0."""
+    return 0
 
 
 class EdgeGeometry(torch.autograd.Function):
@@ -229,22 +216,13 @@ class MessageScatter(torch.autograd.Function):
         return gxh, gvec, gx, gedge.sum(0), None, None, None, None
 
 
-def edge_radial_table(graph, rbf, edge, side=None):
+def edge_radial_table(graph, rbf, edge):
     """[E+1,32] per-edge radial record (window start, 12 tap pairs, unit vector) in CSC order -- the order the
     channel-per-lane backward kernel walks --; ONE launch per step: geometry and radial basis are the same for every
-    layer (`include/hermnet_hip.h`: hermnet_edge_radial_table).
-    `side` (a torch.cuda.Stream): the launch goes there, behind everything the current stream has been given so far; the
-    caller joins the two before the table's first reader (returns (table, event))."""
+    layer (`include/hermnet_hip.h`: hermnet_edge_radial_table)."""
     E = edge.size(0)
     table = torch.empty(E + 1, 32, dtype=torch.float32, device=edge.device)      # (+1: the stream reads one record ahead)
     gs, rs = graph.as_struct(), rbf.struct()
-    call = lambda: _lib.check(_launch("edge_radial_table", lambda: _lib.load().hermnet_edge_radial_table(
+    _lib.check(_launch("edge_radial_table", lambda: _lib.load().hermnet_edge_radial_table(
         ctypes.byref(gs), ctypes.byref(rs), _lib.ptr(edge), _lib.ptr(table), _stream())), "hermnet_edge_radial_table")
-    if side is None:
-        call()
-        return table
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):          # (no allocation in here: every buffer belongs to the main stream's pool)
-        call()
-        done = side.record_event()
-    return table, done
+    return table

@@ -14,6 +14,8 @@ import os
 
 import torch
 
+from . import switches
+
 _COUNT_CACHE = []      # most recent first: (z tensor, version, batch tensor, version, z_list, result)
 _CONST_CACHE = {}
 
@@ -64,7 +66,6 @@ class RelationalGraph(object):
         self.triadic_pairs = 0     # HTNet: pair relations per centre element (target rows = T_elem * pairs * block)
         self.src_real = None       # HTNet: [num_src] 1 for source rows that hold an atom
         self.src_ranges = None     # HTNet: [T,4] int32, the two source-row ranges a relation gathers from (nodeops.node_pre_fwd)
-        self.ready = None          # event of the side stream the edge part was built on (RelationalGraph.build, `side`)
         self._edge_atoms64 = None  # trainops.EdgeDiff: (source, target) atom of every edge as int64
         self._edge_sum_keys = None
         self._row_graph = None     # hermnet.GraphEnergies: graph index of every row
@@ -79,19 +80,16 @@ class RelationalGraph(object):
         return self._rel_bounds
 
     @staticmethod
-    def build(atomic_number, edge_index, z_list, edge_shift=None, batch=None, rel_active=None, uniform=None, side=None):
+    def build(atomic_number, edge_index, z_list, edge_shift=None, batch=None, rel_active=None, uniform=None):
         """atomic_number [N] int, edge_index [2,E] int (row 0 = source, row 1 = target,
         `hermnet.py:135`), z_list: atomic numbers of the model's elements in module order.
         `uniform`: None = automatic (padding overhead <= 15 %), True/False = forced.
 
         GPU tensors take the device-side build (`csrc/relation_kernels.hip`); host tensors (tests,
         planning) take the PyTorch restatement below, which defines the expected result bit for bit.
-        `side` (a torch.cuda.Stream; device build with a cached row layout only): the edge part of the build is launched
-        there, behind everything the current stream holds; `graph.ready` is then the event the caller's stream must wait
-        for before it touches any edge-ordered array (the row arrays are the cached ones and valid at once)."""
-        if atomic_number.is_cuda and os.environ.get("HERMNET_NATIVE_RELATIONS", "1") != "0":
-            return RelationalGraph._build_native(atomic_number, edge_index, z_list, edge_shift, batch, rel_active,
-                                                 uniform, side)
+        (`switches.native_relations = False`: the restatement for GPU tensors too -- tests.)"""
+        if atomic_number.is_cuda and switches.native_relations:
+            return RelationalGraph._build_native(atomic_number, edge_index, z_list, edge_shift, batch, rel_active, uniform)
         return RelationalGraph._build_torch(atomic_number, edge_index, z_list, edge_shift, batch, rel_active, uniform)
 
     @staticmethod
@@ -139,7 +137,7 @@ class RelationalGraph(object):
         return hit
 
     @staticmethod
-    def _build_native(atomic_number, edge_index, z_list, edge_shift, batch, rel_active, uniform, side=None):
+    def _build_native(atomic_number, edge_index, z_list, edge_shift, batch, rel_active, uniform):
         import ctypes
         from . import _lib
         from .ops import _stream
@@ -179,17 +177,8 @@ class RelationalGraph(object):
         out = _lib.RelationsOut(P(rows["node_order"]), P(rows["row_of_node"]), P(rows["z_rows"]), P(g.row_real), P(g.row_active),
                                 P(g.csr_rowptr), P(g.csr_src), P(g.csr_perm), P(g.src_id), P(g.tgt_id), P(g.shift),
                                 P(g.csc_rowptr), P(g.csc_tgt), P(g.csc_pos), P(g.out_rowptr), P(g.out_edges))
-        call = lambda: _lib.check(lib.hermnet_build_relations(P(z), P(ei), P(shift), NA, E, P(zl), T, P(g.type_rowptr), N,
-                                                              P(act), ctypes.byref(out), 1 if rows_ready else 0, P(work),
-                                                              wbytes, _stream()), "hermnet_build_relations")
-        if side is not None and rows_ready:
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):        # (no allocation in here: every buffer belongs to the main stream's pool)
-                call()
-                g.ready = side.record_event()
-            g._keep = (work, ei, shift, act, z)  # inputs and workspace of kernels that may still be running
-        else:
-            call()
+        _lib.check(lib.hermnet_build_relations(P(z), P(ei), P(shift), NA, E, P(zl), T, P(g.type_rowptr), N, P(act), ctypes.byref(out),
+                                               1 if rows_ready else 0, P(work), wbytes, _stream()), "hermnet_build_relations")
         if not rows_ready:
             # int64 copies for the host code's gathers (embedding, index_select), made once per atom set
             rows["z_rows64"] = rows["z_rows"].long()
@@ -410,7 +399,7 @@ class RelationalGraph(object):
         GPU tensors whose atoms are all of listed elements take the device-side build (`hermnet_build_triadic`, the
         HVNet build's counting sort over the expanded list); everything else the torch-op build below, which defines
         the result (tests/test_htnet.py compares the two)."""
-        if (atomic_number.is_cuda and os.environ.get("HERMNET_NATIVE_RELATIONS", "1") != "0" and len(z_list) > 0
+        if (atomic_number.is_cuda and switches.native_relations and len(z_list) > 0
                 and atomic_number.numel() > 0):
             g = RelationalGraph._build_triadic_native(atomic_number, edge_index, z_list, edge_shift, batch, rel_active)
             if g is not None:

@@ -293,7 +293,7 @@ def _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed):
     b1f = (b1 + torch.bmm(w1, b[:, :, None]).squeeze(2)).reshape(T * H)
     # (every node-level Linear below: trainops.TallBmm -- the weight gradients reduce over ~2e4 rows into [H..3H]^2 results,
     # which the library's single GEMM spreads over a handful of workgroups; there they are batched products over row chunks)
-    tall = x.is_cuda and os.environ.get("HERMNET_TRAIN_TALL", "1") != "0"
+    tall = x.is_cuda
     bmm_b = (lambda a, w, b: TallBmm.apply(a, w, b)) if tall else \
         (lambda a, w, b: torch.bmm(a, w) if b is None else torch.baddbmm(b[:, None, :], a, w))
     h = bmm_b(n[None], w1f.t()[None], b1f[None])[0].view(-1, T, H).transpose(0, 1)                    # [T,N,H]

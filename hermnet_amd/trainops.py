@@ -54,8 +54,7 @@ class SumRows(torch.autograd.Function):
         if x.size(0) == 0:
             return x.new_zeros((key.n_rows,) + tuple(x.shape[1:]))
         width = x[0].numel()
-        if (x.is_cuda and x.dtype == torch.float32 and width % 4 == 0
-                and os.environ.get("HERMNET_TRAIN_KERNELS", "1") != "0"):
+        if x.is_cuda and x.dtype == torch.float32 and width % 4 == 0:
             # one pass: the rows are gathered inside the sum (csrc/train_kernels.hip: hermnet_segment_sum)
             return _segsum(x, key)
         xs = x if key.perm is None else x.index_select(0, key.perm)
@@ -159,7 +158,7 @@ class BucketedBasis(object):
         else:
             wc = win.index_select(0, self.group)
             bc = bias.index_select(0, self.group // self.nb)
-        if not self.phi.is_cuda or os.environ.get("HERMNET_TRAIN_BIAS_COLUMN", "1") == "0":
+        if not self.phi.is_cuda:
             return torch.baddbmm(bc[:, None, :], self.phi, wc).reshape(-1, wc.size(2))
         # The bias rides in the product: a column of ones behind the 32 basis columns (4 columns, so that rows stay 16-byte
         # multiples), the bias as weight row 32.  `baddbmm` with a broadcast bias first COPIES it over the whole [nc, C, 3H]
@@ -277,8 +276,7 @@ def _node_op(op, ins, outs, rows, H, c0=0.0, c1=0.0):
 
 def node_kernels_ok(x):
     """The fused node-level stages take fp32 GPU rows whose width is a multiple of 4 (<= 1024)."""
-    return (x.is_cuda and x.dtype == torch.float32 and x.size(-1) % 4 == 0 and x.size(-1) <= 1024
-            and os.environ.get("HERMNET_TRAIN_NODE_KERNELS", "1") != "0")
+    return x.is_cuda and x.dtype == torch.float32 and x.size(-1) % 4 == 0 and x.size(-1) <= 1024
 
 
 class SiLU2(torch.autograd.Function):
@@ -691,7 +689,8 @@ class MessageAlgebraGrad(torch.autograd.Function):
 
 
 def _row_sums_inside():
-    return os.environ.get("HERMNET_TRAIN_ROW_SUMS", "1") != "0"
+    from . import switches
+    return switches.train_row_sums
 
 
 def _groups_of_sources(k_xh, k_all):
@@ -700,8 +699,7 @@ def _groups_of_sources(k_xh, k_all):
 
 
 def _train_kernels(t):
-    return (t.is_cuda and t.dtype == torch.float32 and (t.size(-1) // 3) % 4 == 0 and t.size(0) > 0
-            and os.environ.get("HERMNET_TRAIN_KERNELS", "1") != "0")
+    return t.is_cuda and t.dtype == torch.float32 and (t.size(-1) // 3) % 4 == 0 and t.size(0) > 0
 
 
 def edge_message(X, R, V, U):

@@ -4,8 +4,7 @@ import os
 
 import torch
 
-TUNED_GEMMS = os.environ.get("HERMNET_TUNED_GEMMS",
-                             os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gemm_gfx950.csv"))
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gemm_gfx950.csv")
 
 
 def prefer_rocblas():

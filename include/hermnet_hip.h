@@ -17,7 +17,10 @@
  *     the caller's edge_index / atomic_number / halo index lists arrive as torch LongTensors).
  *
  * ABI version 12 (`hermnet_abi_version`): v12 is ADDITIVE over v11 (hermnet_halo_proj_rows / _accumulate, ranged launches of
- * hermnet_message_scatter_bwd without the finishing launch; nothing v11 exports changed); v11 changes the weight fragment formats of the node chain kernels (three bf16 planes:
+ * hermnet_message_scatter_bwd without the finishing launch, hermnet_set_option / _get_option in place of the library's environment
+ * variables, hermnet_weight_fragments; no signature, struct or fragment format of v11 changed).  STABLE from v11 on: hn_graph,
+ * hn_rbf_desc, hn_pending_grads, the frag(W) / frag16(W) weight streams, and every entry point's argument list -- later versions
+ * only add entry points; v11 changes the weight fragment formats of the node chain kernels (three bf16 planes:
  * see "chain kernels on the matrix pipe"); v10 adds hermnet_shard_step_flags; v9 added the fused layer-boundary node kernels (hermnet_node_update_pre_fwd, the `gxh`
  * form of hn_pending_grads, hermnet_node_pre_fwd16 / _bwd16) and hermnet_param_guard; v8 the gradients handed down as partial sums
  * (hn_pending_grads); v7 adds the row windows of the message kernels (interior / boundary launches
@@ -57,6 +60,30 @@ extern "C" {
 /* Library / build identification (also used as the "is the native path loaded" probe). */
 int hermnet_abi_version(void);
 const char* hermnet_build_info(void);
+
+/* Options (ABI v12): process-wide integers the launchers read at every call -- tuning knobs and the alternative kernel forms
+ * that tests and A/Bs compare against.  (They replace the HERMNET_* environment variables that the library read once per process
+ * up to ABI v11.)  Defaults are the measured choices; a binder never needs to touch them. */
+#define HN_OPT_FWD_VARIANT 0        /* message forward with vec rows: waves * 1000 + VW * 100 + prefetch * 10 + fused (8420) */
+#define HN_OPT_FWD_VARIANT_L0 1     /* ... of layer 0, vec == 0 (16420) */
+#define HN_OPT_BWD_VARIANT 2        /* the 16-lanes-per-edge backward (8420) */
+#define HN_OPT_BWD_VARIANT_L0 3
+#define HN_OPT_FWD_ROWS 4           /* target rows per workgroup; 0 = sized by the launcher */
+#define HN_OPT_BWD_ROWS 5
+#define HN_OPT_BWD_CL_ROWS 6        /* channel-per-lane backward: source rows per workgroup; 0 = whole rounds of one per CU */
+#define HN_OPT_BWD_LANES16 7        /* 1: the 16-lanes-per-edge backward even where the channel-per-lane form could run */
+#define HN_OPT_NODE_CHAIN_WIDE 8    /* 1: widths 128 / 256 on the panelled chain kernels too */
+#define HN_OPT_UPDATE_TILE16 9      /* 16-row update tiles: 0 never, 1 always, 2 (default) where they shorten the launch */
+#define HN_OPT_UPDATE_TILE64_MAX 10 /* largest grid (in 64-row tiles) that takes the 64-row update kernels at width 128 */
+#define HN_NUM_OPTIONS 11
+int hermnet_set_option(int option, int value);
+int hermnet_get_option(int option, int* value);
+
+/* The chain kernels' weight stream from a row-major fp32 weight W [out_features][in_features], computed on the HOST (both
+ * pointers are host pointers): tile_rows = 32 gives frag(W), 16 gives frag16(W) (see "chain kernels on the matrix pipe"),
+ * out_features * in_features * 3 bf16 values.  The format is STABLE from ABI v11 on; this routine exists so that no binder has
+ * to re-implement it (hermnet_amd/nodeops.py: weight_fragments is the same map in torch ops, checked bit for bit). */
+int hermnet_weight_fragments(const float* w_host, int out_features, int in_features, int tile_rows, unsigned short* frag_host);
 
 /* Radial-basis description shared by the message kernels:
  *   u = d * inv_rc; env(u) per rmnet.py:175-208; Gaussian taps exp(coeff*(u-offset[k])^2)

@@ -158,3 +158,46 @@ def test_argument_checks_of_the_round_4_entry_points_need_no_gpu():
                                        ctypes.byref(pend), None) == BAD
     assert lib.hermnet_node_update_bwd(ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, None, ptr, rp, ptr, ptr, 0, 1, 128, 0,
                                        None, None) == HN_OK                                                 # no rows
+
+
+@pytest.mark.parametrize("out_f,in_f", [(128, 128), (384, 128), (128, 256), (64, 64), (32, 96)])
+def test_weight_fragments_through_the_c_abi_equal_the_host_codes(out_f, in_f):
+    """a binder of the C seam must not re-implement the three-plane weight stream.  `hermnet_weight_fragments`
+    (host pointers in and out) gives frag(W) (tile_rows 32) and frag16(W) (16) bit for bit as `nodeops.weight_fragments` /
+    `weight_fragments16` build them in torch ops -- values that are bf16 ties, denormals, huge, tiny and negative zeros
+    included -- and the planes sum back to the weight exactly."""
+    from hermnet_amd import nodeops
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(out_f * 1000 + in_f)
+    w = torch.randn(out_f, in_f, generator=gen) * (10.0 ** torch.randint(-6, 7, (out_f, 1), generator=gen).float())
+    w[0, :8] = torch.tensor([1.00390625, -1.00390625, 1.01171875, 3.0e38, -3.0e38, 1.0e-38, 1.0e-41, -0.0])   # ties, extremes, a denormal
+    w = w.contiguous()
+    for tile_rows, ref_fn in ((32, nodeops.weight_fragments), (16, nodeops.weight_fragments16)):
+        if out_f % tile_rows or in_f % (16 if tile_rows == 32 else 32):
+            out = np.zeros(out_f * in_f * 3, dtype=np.uint16)
+            assert lib.hermnet_weight_fragments(w.data_ptr(), out_f, in_f, tile_rows, out.ctypes.data) == 1     # HN_ERR_BAD_ARG
+            continue
+        out = np.zeros(out_f * in_f * 3, dtype=np.uint16)
+        assert lib.hermnet_weight_fragments(w.data_ptr(), out_f, in_f, tile_rows, out.ctypes.data) == 0
+        ref = ref_fn(w).view(torch.int16).numpy().view(np.uint16)
+        assert np.array_equal(out, ref), (tile_rows, int((out != ref).sum()))
+    # the planes are an exact split: p0 + p1 + p2 == w (fp32 arithmetic, largest first), barring under / overflow of a residual
+    planes = [p.float() for p in nodeops._bf16_planes(w)]          # smallest first
+    normal = w.abs() >= 1.0e-30                                    # (a denormal's residual planes underflow: documented)
+    assert torch.equal(((planes[2] + planes[1]) + planes[0])[normal], w[normal])
+    assert lib.hermnet_weight_fragments(None, 32, 32, 32, out.ctypes.data) == 1
+
+
+def test_library_options_round_trip():
+    """hermnet_set_option / hermnet_get_option (ABI v12: they replace the environment variables the library read once per
+    process): defaults as documented, a value set is the value read, unknown options are refused."""
+    lib = _lib.load()
+    assert _lib.get_option("fwd_variant") == 8420 and _lib.get_option("fwd_variant_l0") == 16420
+    assert _lib.get_option("update_tile16") == 2 and _lib.get_option("bwd_lanes16") == 0
+    with _lib.options(fwd_rows=17, node_chain_wide=1):
+        assert _lib.get_option("fwd_rows") == 17 and _lib.get_option("node_chain_wide") == 1
+    assert _lib.get_option("fwd_rows") == 0 and _lib.get_option("node_chain_wide") == 0
+    assert lib.hermnet_set_option(99, 1) == 1 and lib.hermnet_set_option(-1, 1) == 1
+    hdr = open(os.path.join(ROOT, "include", "hermnet_hip.h")).read()
+    opts = dict((n.lower(), int(v)) for n, v in re.findall(r"#define HN_OPT_([A-Z0-9_]+) (\d+)", hdr))
+    assert opts == _lib.OPTIONS and int(re.search(r"#define HN_NUM_OPTIONS (\d+)", hdr).group(1)) == len(opts)

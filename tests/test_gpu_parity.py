@@ -442,17 +442,18 @@ def test_layer_boundary_as_one_node_launch_each_way(T, counts, uniform, monkeypa
 
 @pytest.mark.parametrize("name", ["alloy108", "c1_si64", "alloy108_unknown_type", "mol16"])
 def test_fused_layer_boundary_changes_no_bit_of_the_model(name, monkeypatch):
-    """Model level: HERMNET_FUSE_BOUNDARY=1 (one node launch per layer boundary each way, the default) gives bit for bit the
-    energies and forces of the same 16-row phases run as separate launches (=2), with every buffer the consuming launches
-    must fill NaN-poisoned; the round-4 form (=0: 64-row projection kernels, another summation order) agrees to rounding;
+    """Model level: `switches.boundary_mode` = 1 (one node launch per layer boundary each way) gives bit for bit the
+    energies and forces of the same 16-row phases run as separate launches (= 2), with every buffer the consuming launches
+    must fill NaN-poisoned; the default form (= 0: 64-row projection kernels, another summation order) agrees to rounding;
     all three meet the reference's golden."""
+    from hermnet_amd import switches
     dev = _dev()
     g = Golden(name)
     model = g.model().to(dev)
     out = {}
     monkeypatch.setenv("HERMNET_DEBUG_POISON", "1")
     for mode in ("1", "2", "0"):
-        monkeypatch.setenv("HERMNET_FUSE_BOUNDARY", mode)
+        monkeypatch.setattr(switches, "boundary_mode", int(mode))
         d = g.data().to(dev)
         d.pos.requires_grad_(True)
         e = model(d)
@@ -483,8 +484,10 @@ def test_read_out_on_the_matrix_pipe_matches_the_staged_weight_form(rows, monkey
     er = er * mask.double()
     (gr,) = torch.autograd.grad(er, xd, ge.double())
     out = {}
+    from hermnet_amd import nodeops
     for flag in ("1", "0"):
-        monkeypatch.setenv("HERMNET_HEAD16", flag)
+        if flag == "0":       # (the staged-weight VALU form: what widths without the 16-row read-out take)
+            monkeypatch.setattr(nodeops, "head16_supported", lambda H_, C_: False)
         xg = x.to(dev).requires_grad_(True)
         e = EnergyHead.apply(xg, w0.to(dev), b0.to(dev), w2.to(dev), b2.to(dev), mask.to(dev))
         (g,) = torch.autograd.grad(e, xg, ge.to(dev))
@@ -753,8 +756,9 @@ def test_message_algebra_with_row_sums_inside_equals_the_per_edge_kernels(monkey
         y = torch.randn(int(d.batch.max()) + 1, generator=gen).to(dev)
         ft = (0.5 * torch.randn(d.pos.shape, generator=gen)).to(dev)
         res = []
+        from hermnet_amd import switches
         for flag in ("0", "1"):
-            monkeypatch.setenv("HERMNET_TRAIN_ROW_SUMS", flag)
+            monkeypatch.setattr(switches, "train_row_sums", flag == "1")
             model.zero_grad()
             d.pos.requires_grad_(True)
             e = model(d)
@@ -1235,13 +1239,14 @@ def test_bias_on_load_equals_bias_in_operand():
 
 @pytest.mark.parametrize("name", ["alloy108", "alloy108_unknown_type", "mol16"])
 def test_fused_layer_equals_autograd_composed_layer(name, monkeypatch):
-    """The hand-written layer backward vs PyTorch autograd over the same kernels (HERMNET_FUSED_LAYER=0)."""
+    """The hand-written layer backward vs PyTorch autograd over the same kernels (`switches.fused_layer = False`)."""
+    from hermnet_amd import switches
     dev = _dev()
     g = Golden(name)
     model = g.model().to(dev)
     res = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("HERMNET_FUSED_LAYER", flag)
+        monkeypatch.setattr(switches, "fused_layer", flag == "1")
         d = g.data().to(dev)
         d.pos.requires_grad_(True)
         e = model(d)
@@ -1274,7 +1279,8 @@ def test_deferred_gradient_sums_equal_the_finishing_launches_bit_for_bit(name, w
     g = Golden(name)
     # (the round-4 forms of both sides: with the layer boundary fused -- round 5's default at width 128 -- the deferred side runs
     # the projection's backward on 16-row tiles, another summation order: test_fused_layer_boundary_changes_no_bit_of_the_model)
-    monkeypatch.setenv("HERMNET_FUSE_BOUNDARY", "0")
+    from hermnet_amd import switches
+    monkeypatch.setattr(switches, "boundary_mode", 0)
     if width is None:
         model = g.model().to(dev)
     else:
@@ -1301,34 +1307,6 @@ def test_deferred_gradient_sums_equal_the_finishing_launches_bit_for_bit(name, w
     assert torch.isfinite(res[1][1]).all()
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert len(res[1][2]) == len(res[0][2])     # (the same library calls: the launches they no longer make are inside them)
-
-
-@pytest.mark.parametrize("mode", ["1", "2", "3"])
-def test_side_stream_front_of_the_step_changes_no_bit(mode, monkeypatch):
-    """HERMNET_SIDE_STREAM (off by default): relation build beside the first node projection, radial table beside the forward
-    layers, on a second stream -- the same energies and forces, eager and as a captured graph."""
-    from hermnet_amd.graph import GraphedStep
-    dev = _dev()
-    g = Golden("alloy108")
-    model = g.model().to(dev)
-    for p in model.parameters():
-        p.requires_grad_(False)
-    res = []
-    for flag in ("0", mode):
-        monkeypatch.setenv("HERMNET_SIDE_STREAM", flag)
-        d = g.data().to(dev)
-        for _ in range(3):                        # (the second call on the same atoms is the one with a cached row layout)
-            d.pos.requires_grad_(True)
-            e = model(d)
-            f = -torch.autograd.grad(e.sum(), d.pos)[0]
-        torch.cuda.synchronize()
-        step = GraphedStep(model, d)
-        eg, fg = step(d.pos.detach())
-        torch.cuda.synchronize()
-        res.append((e.detach().clone(), f.clone(), eg.clone(), fg.clone()))
-    for a, b in zip(res[0], res[1]):
-        assert torch.equal(a, b)
-    assert torch.equal(res[1][0], res[1][2]) and torch.equal(res[1][1], res[1][3])
 
 
 def test_pending_gradients_in_every_update_backward_form():
@@ -2051,23 +2029,30 @@ def test_edge_cases_empty_and_degenerate_graphs():
     _oracle_vs_hip(d, ["H", "C", "O"], kw, 34)
 
 
-@pytest.mark.parametrize("env", [
-    {"HERMNET_BWD_SPLIT_T": "1"},                                                        # one relation per workgroup
-    {"HERMNET_FWD_VARIANT": "16221", "HERMNET_FWD_VARIANT_L0": "16201",                  # 16-wave, 2 channels per lane
-     "HERMNET_BWD_VARIANT": "16201", "HERMNET_BWD_VARIANT_L0": "16201"},
-    {"HERMNET_FWD_VARIANT": "8410", "HERMNET_FWD_VARIANT_L0": "8420",                    # full prefetch / no prefetch
-     "HERMNET_BWD_VARIANT": "8400", "HERMNET_BWD_VARIANT_L0": "8410", "HERMNET_BWD_ROWS": "24", "HERMNET_FWD_ROWS": "17"},
-    {"HERMNET_NODE_CHAIN_WIDE": "1"},            # widths 128 / 256 on the panelled chain kernels (node_chain_wide.hip)
+@pytest.mark.parametrize("opts", [
+    dict(fwd_variant=16221, fwd_variant_l0=16201, bwd_variant=16201, bwd_variant_l0=16201, bwd_lanes16=1),   # 16 waves, 2 channels per lane
+    dict(fwd_variant=8410, fwd_variant_l0=8420, bwd_variant=8400, bwd_variant_l0=8410, bwd_rows=24, fwd_rows=17,
+         bwd_lanes16=1),                                                                                  # full prefetch / none
+    dict(bwd_cl_rows=48),                           # channel-per-lane backward on small chunks
+    dict(node_chain_wide=1),                        # widths 128 / 256 on the panelled chain kernels (node_chain_wide.hip)
 ])
-def test_alternative_kernel_variants(env):
-    """The non-default template instances of the message kernels (selected by environment, once per process) must
-    give the same energies and forces: three golden cases in a child process per setting."""
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    out = subprocess.run([sys.executable, os.path.join(here, "variant_check.py")], env=dict(os.environ, **env),
-                         capture_output=True, text=True, timeout=280)
-    assert out.returncode == 0 and "VARIANT_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+def test_alternative_kernel_variants(opts):
+    """The non-default template instances of the message kernels and the other kernel families (library options, include/
+    hermnet_hip.h: HN_OPT_*; set for the block, restored behind it) must give the same energies and forces: four golden
+    cases (H = 128 and 256) at 1e-5."""
+    from hermnet_amd import _lib
+    dev = _dev()
+    with _lib.options(**opts):
+        for name in ["c1_si64", "alloy108", "mol16", "alloy32_h256"]:
+            g = Golden(name)
+            model = g.model().to(dev)
+            d = g.data().to(dev)
+            d.pos.requires_grad_(True)
+            e = model(d)
+            f = -torch.autograd.grad(e.sum(), d.pos)[0]
+            ee, fe = rel_err(e.detach().cpu(), g.energy), rel_err(f.cpu(), g.forces)
+            assert ee < 1e-5 and fe < 1e-5, (name, opts, ee, fe)
+    assert _lib.get_option("fwd_variant") == 8420 and _lib.get_option("bwd_lanes16") == 0
 
 
 def test_skewed_composition_uses_tight_layout_and_matches_oracle():
@@ -2108,17 +2093,23 @@ def test_large_gaussian_basis_vs_oracle(R):
         del os.environ["HERMNET_DEBUG_POISON"]
 
 
-@pytest.mark.parametrize("env", [{}, {"HERMNET_BWD_CL": "0"}, {"HERMNET_NODE_CHAIN": "0"}])
+@pytest.mark.parametrize("env", [{}, {"option:bwd_lanes16": 1}, {"switch:node_chain": False}])
 @pytest.mark.parametrize("case", ["alloy108", "alloy108_h64", "alloy108_unknown_type", "mol16", "skewed", "width100"])
-def test_edge_gradient_sink_is_fully_written(case, env, monkeypatch):
+def test_edge_gradient_sink_is_fully_written(case, env, monkeypatch, request):
     """HVNet.forward hands the backward kernels an UNINITIALISED edge-gradient buffer when every edge has a target of a
     known element (hermnet.py: EdgeGradSink(zero=False)): every [layer, H/64, E] slot must then be written by whichever
     backward form runs.  HERMNET_DEBUG_POISON=1 fills the buffer with NaN first: a skipped slot would poison the forces.
     Covers the channel-per-lane and the 16-lanes-per-edge backward, a padded width, rows without edges, and an
     unknown-element case (which must take the zero-filled buffer)."""
+    from hermnet_amd import _lib, switches
     monkeypatch.setenv("HERMNET_DEBUG_POISON", "1")
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        kind, name = k.split(":")
+        if kind == "switch":
+            monkeypatch.setattr(switches, name, v)
+        else:
+            old = _lib.set_option(name, v)
+            request.addfinalizer(lambda n=name, o=old: _lib.set_option(n, o))
     dev = _dev()
     if case in ("skewed", "width100"):
         if case == "skewed":

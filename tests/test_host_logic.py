@@ -179,7 +179,8 @@ def test_host_pipeline_with_reference_ops_matches_golden(name, monkeypatch):
     import hermnet_amd.rmnet as rmod
     g = Golden(name)
     model = g.model()
-    monkeypatch.setenv("HERMNET_FUSED_LAYER", "0")      # autograd-composed layer (debug path of the product)
+    from hermnet_amd import switches
+    monkeypatch.setattr(switches, "fused_layer", False)      # autograd-composed layer (debug path of the product)
     monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
     monkeypatch.setattr(hmod, "EdgeGeometry", _FakeFn(lambda pos, cell, graph: ref_ops.geometry_ref(pos, graph, cell)))
     monkeypatch.setattr(rmod, "MessageScatter", _FakeFn(ref_ops.message_scatter_ref))
@@ -202,7 +203,8 @@ def test_fused_layer_orchestration_matches_golden(name, monkeypatch):
     model = g.model()
     for p in model.parameters():
         p.requires_grad_(False)
-    monkeypatch.setenv("HERMNET_FUSED_LAYER", "1")
+    from hermnet_amd import switches
+    monkeypatch.setattr(switches, "fused_layer", True)
     monkeypatch.setattr(hmod.HVNet, "_require_device", staticmethod(lambda pos: None))
     monkeypatch.setattr(hmod, "EdgeGeometry", ref_ops.RefEdgeGeometry)
     for fn in ["energy_head_fwd", "energy_head_bwd", "layernorm_fwd", "layernorm_bwd", "ssilu_fwd", "ssilu_bwd", "update_mid", "update_out", "update_out_bwd",
@@ -212,7 +214,7 @@ def test_fused_layer_orchestration_matches_golden(name, monkeypatch):
     monkeypatch.setattr(lmod, "_msg_bwd", ref_ops.msg_bwd)
     # both forms of the backward hand-over between layers: finished gradients, and partial sums the update backward of the
     # layer below finishes (hn_pending_grads; on the GPU the form is picked by `_bwd_sums_deferrable`)
-    # ... and the three forms of the layer boundary (round 5): one node launch each way (HERMNET_FUSE_BOUNDARY=1: the next
+    # ... and the three forms of the layer boundary (round 5): one node launch each way (switches.boundary_mode = 1: the next
     # layer's projection inside this layer's update launch, its backward inside the update backward of the layer below), the
     # same 16-row phases as launches of their own (2), the round-4 form (0)
     calls = {}
@@ -225,7 +227,7 @@ def test_fused_layer_orchestration_matches_golden(name, monkeypatch):
     for deferred in (False, True):
         monkeypatch.setattr(lmod, "_bwd_sums_deferrable", lambda graph, H, v=deferred: v)
         for boundary in ("1", "2", "0"):
-            monkeypatch.setenv("HERMNET_FUSE_BOUNDARY", boundary)
+            monkeypatch.setattr(switches, "boundary_mode", int(boundary))
             calls.clear()
             d = g.data()
             d.pos.requires_grad_(True)

@@ -215,9 +215,10 @@ def test_native_triadic_build_is_the_torch_build(case, monkeypatch):
     zl = [atomic_numbers[e] for e in elems]
     d = d.to(dev)
     args = (d.atomic_number, d.edge_index, zl, d.get("edge_shift"), d.batch)
-    monkeypatch.setenv("HERMNET_NATIVE_RELATIONS", "0")
+    from hermnet_amd import switches
+    monkeypatch.setattr(switches, "native_relations", False)
     ref = RelationalGraph.build_triadic(*args)
-    monkeypatch.setenv("HERMNET_NATIVE_RELATIONS", "1")
+    monkeypatch.setattr(switches, "native_relations", True)
     for _ in range(2):
         g = RelationalGraph.build_triadic(*args)
         assert (g.N, g.E, g.T, g.num_src, g.block, g.triadic_pairs, g.num_graphs) == \

@@ -13,6 +13,8 @@ from hermnet_amd import nodeops  # noqa: E402
 from hermnet_amd.layer import LayerWeights  # noqa: E402
 from hermnet_amd.relations import RelationalGraph  # noqa: E402
 from hermnet_amd.rmnet import PaiNNModule  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _opts import apply_option_env  # noqa: E402
 
 
 def main():
@@ -21,6 +23,7 @@ def main():
     T = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 50
     dev = torch.device("cuda")
+    apply_option_env()
     torch.manual_seed(0)
     mods = [PaiNNModule(hidden_channels=H, num_rbf=16).to(dev) for _ in range(T)]
     w = LayerWeights(mods).refresh()

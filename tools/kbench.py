@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the two message kernels on the config-2 graph (10k atoms, E=431,340).
-Tuning knobs come from the environment (read once by the library): HERMNET_BWD_WAVES,
-HERMNET_FWD_ROWS, HERMNET_BWD_ROWS.  Prints avg ms and algorithmic GB/s per kernel."""
+Library options (include/hermnet_hip.h: HN_OPT_*) from HN_OPTIONS="fwd_rows=17,bwd_lanes16=1,..." (tools/_opts.py).
+Prints avg ms and algorithmic GB/s per kernel."""
 import ctypes
 import os
 import sys
@@ -14,12 +14,14 @@ from hermnet_amd import synth, _lib  # noqa: E402
 from hermnet_amd.ops import EdgeGeometry, _stream  # noqa: E402
 from hermnet_amd.relations import RelationalGraph  # noqa: E402
 from bench import algorithmic_bytes  # noqa: E402
+from _opts import apply_option_env  # noqa: E402
 
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     dev = torch.device("cuda:0")
     lib = _lib.load()
+    apply_option_env()
     d = synth.fcc_alloy().to(dev)
     # KBENCH_ORDER=x|y|z: renumber the atoms along one axis first (row order = locality of the gathers)
     axis = os.environ.get("KBENCH_ORDER", "")
@@ -50,7 +52,7 @@ def main():
     xb = rnd(T, 3 * H) * 0.1 if os.environ.get("KBENCH_XH_BIAS", "1") != "0" else None
     x1, vec1 = torch.empty_like(x), torch.empty_like(vec)
     gx1, gvec1 = rnd(N, H), rnd(N, 3, H)
-    split = int(os.environ.get("HERMNET_BWD_SPLIT_T", "0") != "0")
+    split = 0
     gxh, gx = torch.empty_like(xh), torch.empty_like(x)
     gvec = torch.empty(T, N, 3, H, device=dev) if split else torch.empty_like(vec)
     gedge = torch.zeros(H // 64, E, 4, device=dev)
@@ -108,7 +110,7 @@ def main():
                       "epilogue %.1f%% | other %.1f%%; per segment: prologue %.0f, iterations %.0f, epilogue %.0f cycles"
                       % (tot / waves, 100 * stage / tot, 100 * pro / tot, 100 * it / tot, 100 * epi / tot,
                          100 * (tot - stage - pro - it - epi) / tot, pro / segs, it / segs, epi / segs))
-    knobs = {k: v for k, v in os.environ.items() if k.startswith("HERMNET_") or k.startswith("KBENCH_")}
+    knobs = {k: v for k, v in os.environ.items() if k.startswith("HERMNET_") or k.startswith("KBENCH_") or k == "HN_OPTIONS"}
     print("knobs", knobs, "checksum", float(x1.sum() + vec1.sum()), float(gxh.sum() + gvec.sum() + gedge.sum()))
 
 
