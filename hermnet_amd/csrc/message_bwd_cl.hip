@@ -198,6 +198,9 @@ struct EdgeIn {          // what one edge needs from memory (vector part)
 // overlap by eleven rows cover every edge exactly once.  Ownership is wave-uniform like everything else about an edge: a
 // foreign edge walks through the same pipeline with its target gradients multiplied by zero (every sum of the kernel is
 // linear in them) and a clamped tile row; the second launch adds its row sums to the first one's.
+#ifndef HN_KO_BWD
+#define HN_KO_BWD 0      // 1: no contraction, 2: no channel algebra (diagnostic builds: tools/build_variant.sh)
+#endif
 template <bool HAS_VEC, bool WIN>
 __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdClArgs a) {
   extern __shared__ __align__(16) float4 tile[];     // [tap row][64] of (s, a, b, 0)
@@ -440,9 +443,15 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
           }
         };
         lds_wait_all(wA, wB, wC);
+#if HN_KO_BWD == 1
+        // diagnostic build (results wrong, time meaningful): the twelve-tap contraction replaced by three moves -- the weight
+        // rows are still read and waited for, every other instruction of the edge is in place
+        Ss = hn_f2{rec[0] * wA[0].x, rec[1]}; Sa = hn_f2{rec[2] * wB[0].y, rec[3]}; Sb = hn_f2{rec[4] * wC[0].z, rec[5]};
+#else
         taps4(0, wA);
         taps4(4, wB);
         taps4(8, wC);
+#endif
         unsigned waddr_next;
         float own = 1.0f;
         if constexpr (WIN) {
@@ -463,6 +472,15 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
         issue_weights(waddr_next);
         __builtin_amdgcn_sched_barrier(0);
         if (fresh) row_scale();                               // (wave-uniform) first edge of a row
+#if HN_KO_BWD == 2
+        // diagnostic build: the channel algebra replaced by the fewest operations that keep the contraction's results and the
+        // gathered rows alive (results wrong): what the contraction, the loads and the reduction cost without it
+        {
+          gs += Ss.x + Ss.y + cur.gx1; ga += Sa.x + Sa.y + cur.g0; gb += Sb.x + Sb.y + cur.g1 + cur.g2;
+          px[j & 1] = gs; py[j & 1] = ga; pz[j & 1] = gb;
+          return;
+        }
+#endif
         const float rx = tl[1], ry = tl[2], rz = tl[3], invd = tl[4];
         const float gx1 = WIN ? cur.gx1 * own : cur.gx1, g0 = WIN ? cur.g0 * own : cur.g0;
         const float g1 = WIN ? cur.g1 * own : cur.g1, g2 = WIN ? cur.g2 * own : cur.g2;
