@@ -244,14 +244,19 @@ class HaloExchange(torch.autograd.Function):
     def backward(ctx, g):
         plan = ctx.plan
         back = _all_to_all_rows(g.index_select(0, plan.recv_idx), plan.recv_counts, plan.send_counts, plan.group)
-        gx = g.clone()
+        gx = _writable(g)                              # (the producer's fresh tensor where this is its only consumer)
         gx.index_fill_(0, plan.recv_idx, 0)            # the local halo values were overwritten in forward
         if back.size(0) > 0:
-            # an atom that is a halo atom of several peers gets its returns summed in send-list order (no atomics)
             rows, ptr, pos = plan.accumulate_lists()
-            # (unsafe=True: no host-side validation of `lengths` -- it would synchronise every step)
-            seg = torch.segment_reduce(back.index_select(0, pos), "sum", lengths=ptr[1:] - ptr[:-1], unsafe=True)
-            gx.index_add_(0, rows, seg)                # `rows` is unique
+            if rows.numel() == plan.send_idx.numel():
+                # every owned atom goes to at most ONE peer (slabs thicker than the halo reach): the send list has no repeats,
+                # so the returns land on distinct rows -- one launch, deterministic
+                gx.index_add_(0, plan.send_idx, back)
+            else:
+                # an atom that is a halo atom of several peers gets its returns summed in send-list order (no atomics)
+                # (unsafe=True: no host-side validation of `lengths` -- it would synchronise every step)
+                seg = torch.segment_reduce(back.index_select(0, pos), "sum", lengths=ptr[1:] - ptr[:-1], unsafe=True)
+                gx.index_add_(0, rows, seg)            # `rows` is unique
         return gx, None
 
 

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 O=$PWD/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc/FETCH_SIZE -- $B > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc/WRITE_SIZE -- $B > $O/write.log 2>&1
 # issue / stall anatomy of every kernel of the step (SQ block: 8 counters per pass)
