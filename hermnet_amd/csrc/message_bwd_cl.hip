@@ -50,6 +50,10 @@ constexpr int kRec = HN_EDGE_TABLE_FLOATS;   // floats per edge record
 // Records leave through a wave-private LDS transpose: a lane computes one record (128 B), and written straight from its
 // registers every store instruction would touch 64 different 128-byte lines with 16 bytes each (measured 25.7 us for the 55 MB
 // table of configs[1]); through the tile the wave writes its 64 records as eight fully coalesced 1-KiB stores.
+// (measured, profiles/r06_nt_msg_ab.log: 2.832 -> 2.822 ms/step)
+#ifndef HN_NT_TABLE
+#define HN_NT_TABLE 1
+#endif
 __global__ __launch_bounds__(256) void edge_table_kernel(const float4* __restrict__ edge, const int* __restrict__ csc_pos,
                                                          int E, const float* __restrict__ offset, int R, float inv_rc,
                                                          float coeff, int env_kind, int env_p,
@@ -100,7 +104,15 @@ __global__ __launch_bounds__(256) void edge_table_kernel(const float4* __restric
 #pragma unroll
   for (int j = 0; j < kRec / 4; ++j) {
     const int idx = j * 64 + lane, r = idx / (kRec / 4), w = idx % (kRec / 4);
-    if (r < nrec) out[idx] = *reinterpret_cast<const float4*>(st + r * kLd + 4 * w);
+    // (non-temporal where HN_NT_TABLE: the table is written at the start of the step and first read by the backward pass)
+    if (r < nrec) {
+#if HN_NT_TABLE
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(*reinterpret_cast<const f4v*>(st + r * kLd + 4 * w), reinterpret_cast<f4v*>(out + idx));
+#else
+      out[idx] = *reinterpret_cast<const float4*>(st + r * kLd + 4 * w);
+#endif
+    }
   }
   // record E: a copy of the last one -- the message kernel requests record q + 1 without a bounds check
   if (q0 + nrec == E && lane < kRec / 4)
@@ -162,6 +174,16 @@ __device__ __forceinline__ float buf_load(hn_rsrc r, unsigned voff, unsigned sof
 
 __device__ __forceinline__ void buf_store(hn_rsrc r, unsigned voff, unsigned soff, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+// non-temporal forms (aux bit 1 = nt) for what this kernel touches exactly once: the source row's own xh / vec values (saved by
+// the forward milliseconds ago: they come from HBM and nobody reads them again) and the per-edge gradient slots (read once, at
+// the end of the backward pass)
+// Measured (profiles/r06_nt_msg_ab.log, interleaved in one job): configs[1] 2.787 -> 2.765 ms/step.
+#ifndef HN_NT_MSG
+#define HN_NT_MSG 1
+#endif
+__device__ __forceinline__ float buf_load_once(hn_rsrc r, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, HN_NT_MSG ? 2 : 0));
 }
 // descriptor of ONE row of a [rows, 3, H] array (wave-uniform base, 3H floats): the row's three parts are then
 // addressed by scalar offsets and this lane's channel offset -- no per-lane 64-bit address arithmetic
@@ -319,10 +341,10 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
       // (row offsets in 32 bits: the host routes larger arrays to the other kernel form)
       const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(r * (3 * H));
       const hn_rsrc xr = row_rsrc(xh_t, ro, H);
-      raw_s = buf_load(xr, c4, 0); raw_a = buf_load(xr, c4, h4); raw_b = buf_load(xr, c4, 2 * h4);
+      raw_s = buf_load_once(xr, c4, 0); raw_a = buf_load_once(xr, c4, h4); raw_b = buf_load_once(xr, c4, 2 * h4);
       if (HAS_VEC) {
         const hn_rsrc vr = row_rsrc(vec_a, ro, H);
-        raw_v0 = buf_load(vr, c4, 0); raw_v1 = buf_load(vr, c4, h4); raw_v2 = buf_load(vr, c4, 2 * h4);
+        raw_v0 = buf_load_once(vr, c4, 0); raw_v1 = buf_load_once(vr, c4, h4); raw_v2 = buf_load_once(vr, c4, 2 * h4);
       }
       gs = 0.f; ga = 0.f; gb = 0.f; gv0 = 0.f; gv1 = 0.f; gv2 = 0.f;
       fresh = true;
@@ -522,7 +544,12 @@ __global__ __launch_bounds__(1024, 4) void message_scatter_bwd_cl_kernel(HnBwdCl
         if constexpr (WIN) {
           if ((lane & 15) == 0 && k4 + je < cnt && ((own_mask >> je) & 1u)) gedge[pw] = make_float4(sx, sy, sz, 0.f);
         } else {
+#if HN_NT_MSG
+          if ((lane & 15) == 0 && k4 + je < cnt)
+            __builtin_nontemporal_store(hn_f4{sx, sy, sz, 0.f}, reinterpret_cast<hn_f4*>(&gedge[pw]));
+#else
           if ((lane & 15) == 0 && k4 + je < cnt) gedge[pw] = make_float4(sx, sy, sz, 0.f);
+#endif
         }
       };
       using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;

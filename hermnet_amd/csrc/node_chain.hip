@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void node_pre_fwd_kernel(PreFwdArgs a) {
         hv[g] = run4(acc1[rb][j], g);                 // (incl. b1)
         *reinterpret_cast<f32x4*>(tile + lr * LD + c0) = ssilu4(hv[g]);
       }
-      store_block<H>(scr, lane, hv, hb_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
+      store_block<H, true>(scr, lane, hv, hb_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);       // (saved for the backward only)
     }
   STAMP(5);
   __syncthreads();
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void node_pre_bwd_kernel(PreBwdArgs a) {
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int j = 0; j < CPW; ++j) issue_block<H>(lhb[rb][j], lane, hb_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
+    for (int j = 0; j < CPW; ++j) issue_block<H, true>(lhb[rb][j], lane, hb_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
 
   // ---- ga = gxh W2   (K = 3H in chunks, double-buffered through registers)
   f32x16 acc[RB][CPW];
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
         }
         const int ob = ((wr * RB + rb) * 32 * 3 + d) * 2 * H + (wc * CPW + j) * 32;
         store_block<6 * H>(scr, lane, v1, vp_r, ob);
-        store_block<6 * H>(scr, lane, v2, vp_r, ob + H);
+        store_block<6 * H, true>(scr, lane, v2, vp_r, ob + H);
       }
     STAMP(3 + 3 * d);
   }
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
         nv[g] = (f32x4){sqrtf(s2[0]), sqrtf(s2[1]), sqrtf(s2[2]), sqrtf(s2[3])};
         *reinterpret_cast<f32x4*>(bufn + (mrow + rb * 32) * LD + (wc * CPW + j) * 32 + 8 * g + ch) = nv[g];
       }
-      store_block<H>(scr, lane, nv, nrm_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
+      store_block<H, true>(scr, lane, nv, nrm_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
     }
   __syncthreads();
   STAMP(10);
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
         hv[g] = run4(acch[rb][j], g) + ld4g(a.bx0 + (size_t)t * H + c0);
         *reinterpret_cast<f32x4*>(lds + lr * LD + c0) = ssilu4(hv[g]);
       }
-      store_block<H>(scr, lane, hv, h2b_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
+      store_block<H, true>(scr, lane, hv, h2b_r, (wr * RB + rb) * 32 * H + (wc * CPW + j) * 32);
     }
   __syncthreads();
   // ---- (p | q | r) = a2 Wx2^T + bx2, then the update and the residual.  Of the epilogue's inputs, v1 is still in
@@ -479,8 +479,8 @@ __global__ __launch_bounds__(256, MINW) void node_update_fwd_kernel(UpdFwdArgs a
         xo[g] = (x1v + (p + q[g] * dot[rb][j][g] * inv_sqrt_h) * kInvSqrt2) * on;
       }
       const int rblk = (wr * RB + rb) * 32, cblk = (wc * CPW + j) * 32;
-      store_block<2 * H>(scr, lane, q, q23_r, rblk * 2 * H + cblk);
-      store_block<2 * H>(scr, lane, r, q23_r, rblk * 2 * H + H + cblk);
+      store_block<2 * H, true>(scr, lane, q, q23_r, rblk * 2 * H + cblk);
+      store_block<2 * H, true>(scr, lane, r, q23_r, rblk * 2 * H + H + cblk);
       store_block<H>(scr, lane, xo, xo_r, rblk * H + cblk);
 #pragma unroll
       for (int d = 0; d < 3; ++d) {

@@ -157,7 +157,7 @@ __device__ __forceinline__ void mma16_panel(f32x4 (&acc)[NB], const float* As, c
 
 // Coalesced store / load of this wave's [16 rows][32 channels] block pair through the wave-private scratch: lane l owns
 // row l & 15 and the channels 16 s + 4 (l >> 4) .. +3 of sub-block s (v[s]); memory sees 2 x (8 rows x 128 bytes).
-template <int LDG>
+template <int LDG, bool NT = false>
 __device__ __forceinline__ void store16(float* scr, int lane, const f32x4 (&v)[2], rsrc_t r, int off) {
   const int m = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -165,14 +165,17 @@ __device__ __forceinline__ void store16(float* scr, int lane, const f32x4 (&v)[2
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int rr = it * 8 + (lane >> 3), c = (lane & 7) * 4;
-    bst4(r, off + rr * LDG + c, *reinterpret_cast<const f32x4*>(scr + rr * kScr16Ld + c));
+    if (NT) bst4_nt(r, off + rr * LDG + c, *reinterpret_cast<const f32x4*>(scr + rr * kScr16Ld + c));
+    else bst4(r, off + rr * LDG + c, *reinterpret_cast<const f32x4*>(scr + rr * kScr16Ld + c));
   }
 }
 struct Load16 { f32x4 v[2]; };
-template <int LDG>
+template <int LDG, bool NT = false>
 __device__ __forceinline__ void issue16(Load16& b, int lane, rsrc_t r, int off) {
 #pragma unroll
-  for (int it = 0; it < 2; ++it) b.v[it] = bld4(r, off + (it * 8 + (lane >> 3)) * LDG + (lane & 7) * 4);
+  for (int it = 0; it < 2; ++it)
+    b.v[it] = NT ? bld4_nt(r, off + (it * 8 + (lane >> 3)) * LDG + (lane & 7) * 4)
+                 : bld4(r, off + (it * 8 + (lane >> 3)) * LDG + (lane & 7) * 4);
 }
 __device__ __forceinline__ void finish16(float* scr, int lane, const Load16& b, f32x4 (&out)[2]) {
 #pragma unroll
@@ -324,7 +327,7 @@ __device__ __forceinline__ void pre_fwd16_phase(const PreFwdArgs& p, float* bufN
         hv[s] = acc1[s];                               // (incl. b1)
         *reinterpret_cast<f32x4*>(bufA + mrow * LD + cw + 16 * s + ch) = ssilu4(hv[s]);
       }
-      store16<H>(scr, lane, hv, hb_r, cw);
+      store16<H, true>(scr, lane, hv, hb_r, cw);
     }
     __syncthreads();
     // ---- xh = a W2^T + b2
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(256, HN_U16_MINW_FWD) void node_update_fwd16_kernel
         pin4(sq[s]);
       }
       store16<6 * H>(scr, lane, v1, vp_r, d * 2 * H + cw);
-      store16<6 * H>(scr, lane, v2, vp_r, d * 2 * H + H + cw);
+      store16<6 * H, true>(scr, lane, v2, vp_r, d * 2 * H + H + cw);
     }
     STAMP(3);
   }
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256, HN_U16_MINW_FWD) void node_update_fwd16_kernel
       nv[s] = sqrt4(sq[s] + 1e-8f);
       *reinterpret_cast<f32x4*>(bufn + mrow * LD + cw + 16 * s + ch) = nv[s];
     }
-    store16<H>(scr, lane, nv, nrm_r, cw);
+    store16<H, true>(scr, lane, nv, nrm_r, cw);
   }
   __syncthreads();
   STAMP(4);
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(256, HN_U16_MINW_FWD) void node_update_fwd16_kernel
       hv[s] = acch[s];                               // (incl. bx0)
       *reinterpret_cast<f32x4*>(lds + mrow * LD + c0) = ssilu4(hv[s]);
     }
-    store16<H>(scr, lane, hv, h2b_r, cw);
+    store16<H, true>(scr, lane, hv, h2b_r, cw);
   }
   __syncthreads();
   // ---- (p | q | r) = a2 Wx2^T + bx2, then the update and the residual; vec1 is requested before the product
@@ -526,8 +529,8 @@ __global__ __launch_bounds__(256, HN_U16_MINW_FWD) void node_update_fwd16_kernel
     const f32x4 x1v = *reinterpret_cast<const f32x4*>(bufx + mrow * LD + c0);
     xo[s] = (x1v + (p + q[s] * dot[s] * inv_sqrt_h) * kInvSqrt2) * on;
   }
-  store16<2 * H>(scr, lane, q, q23_r, cw);
-  store16<2 * H>(scr, lane, r, q23_r, H + cw);
+  store16<2 * H, true>(scr, lane, q, q23_r, cw);
+  store16<2 * H, true>(scr, lane, r, q23_r, H + cw);
   store16<H>(scr, lane, xo, xo_r, cw);
   if constexpr (FUSE) {
     // the rows this tile has just produced are the next layer's LayerNorm input: a third tile takes them (buffers 0 / 1 may
@@ -748,9 +751,9 @@ __global__ __launch_bounds__(256, HN_U16_MINW_BWD) void node_update_bwd16_kernel
   }
   // h2b, gx and q of this wave's accumulator positions: requested now, transposed behind the first product
   Load16 lh2, lgx, lq2;
-  issue16<H>(lh2, lane, h2b_r, cw);
+  issue16<H, true>(lh2, lane, h2b_r, cw);
   issue16<H>(lgx, lane, gxo_r, cw);
-  issue16<2 * H>(lq2, lane, q23_r, cw);
+  issue16<2 * H, true>(lq2, lane, q23_r, cw);
   __syncthreads();
   STAMP(7);
   // ---- ga2 = gq Wx2  (K = 3H: three panels)
@@ -788,9 +791,9 @@ __global__ __launch_bounds__(256, HN_U16_MINW_BWD) void node_update_bwd16_kernel
   }
   // inputs of the later epilogues, requested one product ahead
   Load16 lnr, lgv, lq3, lw1, lw2;
-  issue16<H>(lnr, lane, nrm_r, cw);
+  issue16<H, true>(lnr, lane, nrm_r, cw);
   issue16<3 * H>(lgv, lane, gvo_r, cw);
-  issue16<2 * H>(lq3, lane, q23_r, H + cw);
+  issue16<2 * H, true>(lq3, lane, q23_r, H + cw);
   issue16<6 * H>(lw1, lane, vp_r, cw);
   issue16<6 * H>(lw2, lane, vp_r, H + cw);
   fence_sched();

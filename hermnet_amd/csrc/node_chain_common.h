@@ -8,6 +8,9 @@
 #include <stdlib.h>
 #include "../../include/hermnet_hip.h"
 
+#ifndef HN_NT_SAVED_LOADS
+#define HN_NT_SAVED_LOADS 0      // (the read-once side of the same tensors: measured, no gain -- profiles/r06_nt_saved_ab.log)
+#endif
 // Argument blocks of the four chain kernels (plain structs shared by both translation units)
 namespace hn_chain {
 struct PreFwdArgs {
@@ -393,9 +396,29 @@ __device__ __forceinline__ f32x4 bld4(rsrc_t r, int off) {
   const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, off * 4, 0, 0);
   return __builtin_bit_cast(f32x4, u);
 }
+// non-temporal load: saved tensors a backward kernel reads exactly once
+__device__ __forceinline__ f32x4 bld4_nt(rsrc_t r, int off) {
+#ifdef HN_KO_LOADS
+  return (f32x4){1.f, 0.5f, 0.25f, 2.f};
+#endif
+  const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, off * 4, 0, HN_NT_SAVED_LOADS ? 2 : 0);
+  return __builtin_bit_cast(f32x4, u);
+}
 __device__ __forceinline__ void bst4(rsrc_t r, int off, f32x4 v) {
   HN_STORE_IF(v)
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off * 4, 0, 0);
+}
+// non-temporal store (aux bit 1 = nt on gfx940+): for the tensors a forward kernel only SAVES for the backward (nobody reads
+// them for several milliseconds: keeping their lines would evict what the next kernels do read)
+// Round 6, measured (profiles/r06_nt_saved_ab.log, interleaved in one job): configs[1] 2.819 -> 2.808 ms/step with the update
+// forward's save-only stores non-temporal; inside a step these kernels run like after a 512 MB cache flush (update forward 37 us
+// on hot buffers, 50 in the step and behind a flush: profiles/r06_chain_thrash.log), i.e. their inputs come from HBM.
+#ifndef HN_NT_SAVED
+#define HN_NT_SAVED 1
+#endif
+__device__ __forceinline__ void bst4_nt(rsrc_t r, int off, f32x4 v) {
+  HN_STORE_IF(v)
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off * 4, 0, HN_NT_SAVED ? 2 : 0);
 }
 
 // Coalesced store of one 32 x 32 accumulator block through a wave-private LDS transpose.  A lane owns a ROW of the
@@ -406,7 +429,7 @@ __device__ __forceinline__ void bst4(rsrc_t r, int off, f32x4 v) {
 // in order, so no barrier or wait is needed between the two halves.  `off_block`: float offset of the block's first
 // row / first channel in the destination, LDG its row stride.
 constexpr int kScrLd = 36, kScrFloats = 32 * kScrLd;
-template <int LDG>
+template <int LDG, bool NT = false>
 __device__ __forceinline__ void store_block(float* scr, int lane, const f32x4 (&v)[4], rsrc_t r, int off_block) {
   const int m = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -414,7 +437,8 @@ __device__ __forceinline__ void store_block(float* scr, int lane, const f32x4 (&
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int rr = it * 8 + (lane >> 3), c = (lane & 7) * 4;
-    bst4(r, off_block + rr * LDG + c, *reinterpret_cast<const f32x4*>(scr + rr * kScrLd + c));
+    if (NT) bst4_nt(r, off_block + rr * LDG + c, *reinterpret_cast<const f32x4*>(scr + rr * kScrLd + c));
+    else bst4(r, off_block + rr * LDG + c, *reinterpret_cast<const f32x4*>(scr + rr * kScrLd + c));
   }
 }
 
@@ -422,10 +446,12 @@ __device__ __forceinline__ void store_block(float* scr, int lane, const f32x4 (&
 // 4 x (8 rows x 128 contiguous bytes) into registers, `finish` (any time later) passes it through the scratch and
 // returns the four runs of this lane's row.
 struct BlockLoad { f32x4 v[4]; };
-template <int LDG>
+template <int LDG, bool NT = false>
 __device__ __forceinline__ void issue_block(BlockLoad& b, int lane, rsrc_t r, int off_block) {
 #pragma unroll
-  for (int it = 0; it < 4; ++it) b.v[it] = bld4(r, off_block + (it * 8 + (lane >> 3)) * LDG + (lane & 7) * 4);
+  for (int it = 0; it < 4; ++it)
+    b.v[it] = NT ? bld4_nt(r, off_block + (it * 8 + (lane >> 3)) * LDG + (lane & 7) * 4)
+                 : bld4(r, off_block + (it * 8 + (lane >> 3)) * LDG + (lane & 7) * 4);
 }
 __device__ __forceinline__ void finish_block(float* scr, int lane, const BlockLoad& b, f32x4 (&out)[4]) {
 #pragma unroll

@@ -56,7 +56,14 @@ def main():
             "update_pre_fwd": (lambda: nodeops.node_update_pre_fwd(x1, vec1, w, g, w), 2 * N * (11 + 4 * T) * H * H),
             "pre_update_bwd": (lambda: nodeops.node_update_bwd(bx, bv, vp, h2b, q23, nrm, w, g, pending=pend_chain), 2 * N * (11 + 4 * T) * H * H),
         })
-    print("rows %d (atoms %d), H %d, T %d" % (N, n, H, T))
+    # CHAIN_BENCH_THRASH=MB: between two timed launches a copy of that many MB runs (every launch then meets the caches the way
+    # it does inside a step -- weights and inputs evicted from L2 by the message kernels' traffic -- instead of 200 back-to-back
+    # launches on hot buffers); launches are timed one by one
+    thrash = int(os.environ.get("CHAIN_BENCH_THRASH", "0"))
+    if thrash:
+        big_a = torch.empty(thrash * (1 << 20) // 4, device=dev)
+        big_b = torch.empty_like(big_a)
+    print("rows %d (atoms %d), H %d, T %d%s" % (N, n, H, T, ", %d MB copy between launches" % thrash if thrash else ""))
     for _ in range(3):                    # every case a few times before any is timed (allocator growth, code objects:
         for fn, _f in cases.values():     # a one-time stall otherwise lands in the first case's interval)
             fn()
@@ -65,13 +72,26 @@ def main():
         for _ in range(5):
             fn()
         torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(reps):
-            fn()
-        b.record()
-        torch.cuda.synchronize()
-        us = a.elapsed_time(b) / reps * 1e3
+        if thrash:
+            evs = []
+            for _ in range(min(reps, 40)):
+                big_b.copy_(big_a)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn()
+                b.record()
+                evs.append((a, b))
+            torch.cuda.synchronize()
+            ts = sorted(a.elapsed_time(b) for a, b in evs)
+            us = ts[len(ts) // 2] * 1e3
+        else:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            us = a.elapsed_time(b) / reps * 1e3
         print("%-16s %8.1f us   %6.1f TFLOP/s  (%.2f of 155)" % (name, us, flop / us / 1e6, flop / us / 1e6 / 155))
 
 
