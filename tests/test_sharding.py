@@ -176,9 +176,9 @@ def _rccl_worker(rank, world, name, port, out):
 
 @pytest.mark.gpu
 def test_rccl_backend_single_rank_smoke():
-    """The production backend ("nccl" = RCCL) on the one GPU of the box: world size 1, so the exchanges are empty,
-    but every collective of the sharded path (variable-size all_to_all_single on device buffers, all_reduce,
-    barrier) goes through RCCL with the same calls a multi-GPU run makes."""
+    """The production backend ("nccl" = RCCL) on the one GPU of the box with a PLAIN one-rank plan: the rank has no peer,
+    so since round 6 it skips the collectives of the step altogether (`HVNet.forward`: `lone`) and must give the golden's
+    numbers; the exchanges themselves run with payload in test_self_peer_exchange_over_rccl_carries_rows."""
     name = "alloy108"
     port = 35500 + os.getpid() % 2000
     out = mp.Manager().dict()
