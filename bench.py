@@ -100,32 +100,27 @@ def cpu_baseline(model_kw, elems, seed):
         if dt > 4.0:          # the next sample costs 4-16x (the in_subgraph loop is O(N*E)): stay within ~1 min
             break
     n, dt_probe, reps = best
-    # 1 warm-up + >= 2 timed steps, median -- the probe above was the warm-up at this size
+    # The probe above was the warm-up at this size; ONE timed step follows.  (Rounds 1-5 timed two faithful and three vectorised
+    # steps: ~85 s of CPU work, most of the driver's wall time for this benchmark; the contract asks for a bounded sample of
+    # about 10-30 s.  A step is ~15 s on 16 cores and repeats to within 1 %: profiles/r05_final_bench.json.)
     sample = synth.fcc_alloy(reps=reps)
-    times = []
-    for _ in range(2):
-        t0 = time.time()
-        orc.energy_and_forces(sd, elems, sample, mode="faithful", **kw)
-        times.append(time.time() - t0)
-    timed = sorted(times)
-    best = (n, 0.5 * (timed[0] + timed[1]), reps)
-    n, dt, reps = best
+    t0 = time.time()
+    orc.energy_and_forces(sd, elems, sample, mode="faithful", **kw)
+    dt = time.time() - t0
     # the same sample through the oracle's vectorised mode (one mask per relation instead of the reference's
-    # O(N*E) in_subgraph loop): the GPU/CPU ratio is not meant to be inflated by that loop
-    # (same protocol as the faithful mode: one warm-up step at this size, then the median of the timed ones)
-    tv = []
-    for _ in range(4):
-        t0 = time.time()
-        orc.energy_and_forces(sd, elems, sample, mode="vectorised", **kw)
-        tv.append(time.time() - t0)
-    tv = sorted(tv[1:])
-    dt_vec = tv[len(tv) // 2]
+    # O(N*E) in_subgraph loop): the GPU/CPU ratio is not meant to be inflated by that loop.
+    # Warm-up on a 2,500-atom slice (allocator, threads), then one timed step at full size.
+    orc.energy_and_forces(sd, elems, synth.fcc_alloy(reps=(5, 5, 25)), mode="vectorised", **kw)
+    t0 = time.time()
+    orc.energy_and_forces(sd, elems, sample, mode="vectorised", **kw)
+    dt_vec = time.time() - t0
     return {"value": n / dt, "unit": "atom-steps/s", "cores": cores, "kind": "port",
-            "vectorised_value": n / dt_vec, "vectorised_timed_steps_s": [round(t_, 2) for t_ in tv],
-            "timed_steps_s": [round(t_, 2) for t_ in times], "warmup_step_s": round(dt_probe, 2),
+            "vectorised_value": n / dt_vec, "vectorised_timed_steps_s": [round(dt_vec, 2)],
+            "timed_steps_s": [round(dt, 2)], "warmup_step_s": round(dt_probe, 2),
             "sample": "oracle mode=faithful (reference op sequence incl. in_subgraph loop), energy+forces steps on a "
-                      "%d-atom slice (fcc %dx%dx%d) of the same alloy/model: one warm-up step at this size, median of "
-                      "the following %d: %.1f s on %d threads" % (n, reps[0], reps[1], reps[2], len(timed), dt, cores)}
+                      "%d-atom slice (fcc %dx%dx%d) of the same alloy/model: one warm-up step at this size, then one timed "
+                      "step: %.1f s on %d threads (about %.0f s of CPU work in all, the vectorised figure included)"
+                      % (n, reps[0], reps[1], reps[2], dt, cores, dt_probe + dt + dt_vec + 3)}
 
 
 def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=10):

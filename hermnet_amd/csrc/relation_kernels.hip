@@ -207,9 +207,12 @@ __global__ __launch_bounds__(kBlock) void edge_keys_hist_kernel(const long* __re
 // scan_apply for the concatenated counters [ n1 + 1 | n2 + ... ]: the running offsets go to `all` (cursor copy for the
 // scatters) and, in their final form, straight to csr_rowptr [n1 + 1] and csc_rowptr [n2 + 1] (second part: minus the E
 // edges in front).  HVNet: n1 = N, n2 = T N; HTNet: n1 = target rows, n2 = relations x source rows.
-__global__ __launch_bounds__(kBlock) void scan_apply_orders_kernel(const int* __restrict__ in, int n, const int* __restrict__ sums,
+// `cursor` (may be `in` itself: every thread has read its own four counters before it writes them): a second copy of the
+// offsets, the one the scatters advance -- written here instead of by a copy launch of its own (round 6).
+__global__ __launch_bounds__(kBlock) void scan_apply_orders_kernel(const int* in, int n, const int* __restrict__ sums,
                                                                   int* __restrict__ all, int n1, long n2, int E,
-                                                                  int* __restrict__ csr_rowptr, int* __restrict__ csc_rowptr) {
+                                                                  int* __restrict__ csr_rowptr, int* __restrict__ csc_rowptr,
+                                                                  int* cursor) {
   __shared__ int lds[4];
   const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
   int x[4], v = 0;
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(kBlock) void scan_apply_orders_kernel(const int* __
     const int i = base + q;
     if (i < n) {
       all[i] = run;
+      if (cursor != nullptr) cursor[i] = run;
       if (i <= n1) csr_rowptr[i] = run;
       else if (i - (n1 + 1) <= n2) csc_rowptr[i - (n1 + 1)] = run - E;
     }
@@ -479,11 +483,10 @@ extern "C" int hermnet_build_relations(const long* atomic_number, const long* ed
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(kBlock), 0, s, hist, n, sums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, s, sums, nb);
     hipLaunchKernelGGL(scan_apply_orders_kernel, dim3(nb), dim3(kBlock), 0, s, hist, n, sums, rp_all, N, (long)T * N, E, out->csr_rowptr,
-                       out->csc_rowptr);
+                       out->csc_rowptr, cursor);
   }
   if (E > 0) {
-    // (the scan wrote its offsets to rp_all; the scatters advance a copy: hist is reused for it)
-    hipLaunchKernelGGL(copy_i32_kernel, grid_for((long)nall), dim3(kBlock), 0, s, rp_all, (int)nall, cursor);
+    // (the scan wrote its offsets to rp_all and, as the copy the scatters advance, back over the counters: `cursor` = hist)
     // CSR: edges grouped by row(target), ascending edge id inside a row
     hipLaunchKernelGGL(scatter_kernel, grid_for(E), dim3(kBlock), 0, s, key1, E, cursor, slots, N);
     hipLaunchKernelGGL(group_rank_sort_kernel, dim3((unsigned)((N + 3) / 4)), dim3(kBlock), 0, s, rp_all, N, slots, out->csr_perm);
@@ -568,10 +571,9 @@ extern "C" int hermnet_build_triadic(const long* atomic_number, const long* edge
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(kBlock), 0, s, hist, nn, sums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kBlock), 0, s, sums, nb);
     hipLaunchKernelGGL(scan_apply_orders_kernel, dim3(nb), dim3(kBlock), 0, s, hist, nn, sums, rp_all, (int)Nt, TR * Ns, (int)E,
-                       out->csr_rowptr, out->csc_rowptr);
+                       out->csr_rowptr, out->csc_rowptr, cursor);
   }
   if (E > 0) {
-    hipLaunchKernelGGL(copy_i32_kernel, grid_for((long)nall), dim3(kBlock), 0, s, rp_all, (int)nall, cursor);
     hipLaunchKernelGGL(scatter_kernel, grid_for(E), dim3(kBlock), 0, s, key1, (int)E, cursor, slots, -1);
     hipLaunchKernelGGL(group_rank_sort_kernel, dim3((unsigned)((Nt + 3) / 4)), dim3(kBlock), 0, s, rp_all, (int)Nt, slots, perm_x);
     hipLaunchKernelGGL(tri_gather_scatter_kernel, grid_for(E), dim3(kBlock), 0, s, edge_index, shift, E0, (int)E, m,
