@@ -160,6 +160,28 @@ def test_argument_checks_of_the_round_4_entry_points_need_no_gpu():
                                        None, None) == HN_OK                                                 # no rows
 
 
+def test_argument_checks_of_the_projected_halo_entry_points_need_no_gpu():
+    """hermnet_halo_proj_rows / hermnet_halo_proj_accumulate (ABI v12): malformed calls are refused before a launch, an empty
+    row list is done."""
+    lib = _lib.load()
+    buf = np.zeros(64, dtype=np.float32)
+    ptr = buf.ctypes.data
+    HN_OK, BAD = 0, 1
+    rows = lambda mode, nseg, nsum, n, width, a=ptr: lib.hermnet_halo_proj_rows(mode, a, 0, nseg, ptr, 0, nsum, ptr, n, width, ptr, None)
+    assert rows(0, 3, 1, 0, 384) == HN_OK                       # no rows: done (whatever the pointers)
+    assert rows(0, 3, 1, 0, 384, a=None) == HN_OK
+    assert rows(0, 3, 1, -1, 384) == BAD                        # negative count
+    assert rows(0, 3, 1, 0, 386) == BAD and rows(0, 3, 1, 0, 0) == BAD          # width % 4, width <= 0
+    assert rows(0, 0, 1, 0, 384) == BAD and rows(1, 3, 0, 0, 384) == BAD        # at least one block and one slice
+    assert rows(2, 3, 3, 0, 384) == BAD                         # unpack takes b without a slice axis
+    assert rows(3, 3, 1, 4, 384) == BAD                         # unknown mode (checked after the pointers, before a launch)
+    assert rows(0, 3, 1, 4, 384, a=None) == BAD                 # rows but no source
+    acc = lambda nseg, nu, width, a=ptr: lib.hermnet_halo_proj_accumulate(a, 0, nseg, ptr, ptr, ptr, ptr, nu, width, ptr, None)
+    assert acc(3, 0, 384) == HN_OK and acc(3, 0, 384, a=None) == HN_OK
+    assert acc(3, -1, 384) == BAD and acc(0, 0, 384) == BAD and acc(3, 0, 382) == BAD
+    assert acc(3, 2, 384, a=None) == BAD
+
+
 @pytest.mark.parametrize("out_f,in_f", [(128, 128), (384, 128), (128, 256), (64, 64), (32, 96)])
 def test_weight_fragments_through_the_c_abi_equal_the_host_codes(out_f, in_f):
     """a binder of the C seam must not re-implement the three-plane weight stream.  `hermnet_weight_fragments`

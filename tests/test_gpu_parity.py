@@ -2002,6 +2002,57 @@ def test_a_model_with_an_armed_guard_deep_copies_and_pickles():
     assert bool(torch.isnan(e_bad).all()) and torch.equal(run(model)[0], e)
 
 
+@pytest.mark.parametrize("T,N,H,n", [(3, 500, 128, 77), (1, 64, 64, 64), (3, 300, 128, 0), (2, 257, 192, 5)])
+def test_halo_proj_rows_kernels_match_the_restatement(T, N, H, n):
+    """hermnet_halo_proj_rows / _accumulate (ABI v12) through the C ABI against tests/ref_ops.py, bit for bit: pack (forward:
+    xh [T, N, 3H] | vec; backward: gxh | the per-relation partial sums of gvec, summed in ascending relation order), pack-and-clear,
+    unpack, and the owner's ordered accumulation with an atom that several peers return (duplicates in the send list)."""
+    from hermnet_amd import nodeops
+    from hermnet_amd.sharding import ExchangePlan
+    dev = _dev()
+    gen = torch.Generator().manual_seed(T * 1000 + N + n)
+    W = 3 * H
+    xh, vec = torch.randn(T, N, W, generator=gen), torch.randn(N, 3, H, generator=gen)
+    gv = torch.randn(T, N, 3, H, generator=gen)
+    idx = torch.randperm(N, generator=gen)[:n].contiguous()
+    c = lambda t: t.to(dev).clone()
+    # pack, forward form (b without a slice axis)
+    got = nodeops.halo_proj_rows(0, c(xh), c(vec), idx.to(dev))
+    ref = ref_ops.halo_proj_rows(0, xh.clone(), vec.clone(), idx)
+    assert got.shape == (n, (T + 1) * W) and torch.equal(got.cpu(), ref)
+    # pack and clear, backward form (T slices summed in ascending order while they are packed)
+    a_d, b_d, a_r, b_r = c(xh), c(gv), xh.clone(), gv.clone()
+    got = nodeops.halo_proj_rows(1, a_d, b_d, idx.to(dev))
+    ref = ref_ops.halo_proj_rows(1, a_r, b_r, idx)
+    want_last = gv[0].reshape(N, W).index_select(0, idx)
+    for t in range(1, T):
+        want_last = want_last + gv[t].reshape(N, W).index_select(0, idx)      # the kernel's order: ((s0 + s1) + s2)
+    assert torch.equal(got.cpu()[:, :T * W], ref[:, :T * W]) and torch.equal(got.cpu()[:, T * W:], want_last)
+    assert torch.allclose(got.cpu(), ref, rtol=0, atol=1e-5)
+    assert torch.equal(a_d.cpu(), a_r) and torch.equal(b_d.cpu(), b_r)          # cleared rows, the others untouched
+    # unpack
+    buf = torch.randn(n, (T + 1) * W, generator=gen)
+    a_d, b_d, a_r, b_r = c(xh), c(vec), xh.clone(), vec.clone()
+    nodeops.halo_proj_rows(2, a_d, b_d, idx.to(dev), c(buf))
+    ref_ops.halo_proj_rows(2, a_r, b_r, idx, buf.clone())
+    assert torch.equal(a_d.cpu(), a_r) and torch.equal(b_d.cpu(), b_r)
+    # the owner's accumulate: send list with repeats (an atom that is a halo atom of two peers), list order
+    if n > 0:
+        send = torch.cat([idx, idx[: max(n // 3, 1)]])
+        plan = ExchangePlan(send.to(dev), [send.numel()], send.to(dev)[:0], [0])
+        back = torch.randn(send.numel(), (T + 1) * W, generator=gen)
+        a_d, b_d = c(xh), c(gv)
+        nodeops.halo_proj_accumulate(a_d, b_d, plan, c(back))
+        a_r, b_r = xh.clone(), gv.clone()
+        rows, ptr, pos = [t_.cpu() for t_ in plan.accumulate_lists()]
+        for u in range(rows.numel()):                      # ordered sums, exactly as the kernel adds them
+            r = int(rows[u])
+            for q in pos[int(ptr[u]):int(ptr[u + 1])].tolist():
+                a_r[:, r] += back[q, :T * W].view(T, W)
+                b_r[0, r] += back[q, T * W:].view(3, H)
+        assert torch.equal(a_d.cpu(), a_r) and torch.equal(b_d.cpu(), b_r)
+
+
 def test_edge_cases_empty_and_degenerate_graphs():
     """Ragged / empty inputs: no edges at all, a single atom, only atoms of unlisted elements, an
     isolated atom next to a bonded cluster, a listed element without atoms (the reference crashes
