@@ -15,7 +15,7 @@ _ERR = {1: "HN_ERR_BAD_ARG (unsupported shape or null pointer)",
         3: "HN_ERR_LAUNCH (kernel launch failed)"}
 
 c_fp = ctypes.c_void_p  # device pointers travel as integers
-ABI_VERSION = 12         # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
+ABI_VERSION = 13         # must equal hermnet_abi_version() of the loaded library (include/hermnet_hip.h)
 
 
 class RbfDesc(ctypes.Structure):
@@ -134,6 +134,10 @@ SIGNATURES = {
     "hermnet_set_option": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "hermnet_get_option": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "hermnet_weight_fragments": (ctypes.c_int, [c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_fp]),
+    "hermnet_band_product_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "hermnet_band_product": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_long, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
+    "hermnet_band_product_grad_a": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_long, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
+    "hermnet_band_product_grad_b": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_long, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
     "hermnet_param_guard": (ctypes.c_int, [c_fp, c_fp, ctypes.c_int, c_fp, ctypes.c_int, c_fp, c_fp, c_fp]),
     "hermnet_shard_step_flags": (ctypes.c_int, [c_fp, ctypes.c_long, c_fp, ctypes.c_int, c_fp, ctypes.c_long, c_fp, c_fp, c_fp,
                                                 ctypes.c_long, ctypes.c_float, c_fp]),

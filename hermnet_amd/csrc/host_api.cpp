@@ -7,7 +7,7 @@
 #include "../../include/hermnet_hip.h"
 #include "hermnet_math.h"
 
-#define HN_ABI_VERSION 12
+#define HN_ABI_VERSION 13
 #ifndef HN_SRC_HASH
 #define HN_SRC_HASH "unknown"
 #endif

@@ -140,11 +140,10 @@ class BucketedBasis(object):
             cg = chunks_per_group.long()
             self.key_w = _RowKey(group, None, cg, cg.numel())
             self.key_b = _RowKey(group // self.nb, None, cg.view(-1, self.nb).sum(1), cg.numel() // self.nb)
-        self._phi1 = None     # phi with a ones column (project)
 
     def project(self, w_rbf, b_rbf, scale):
-        """rbf_proj of every relation (rmnet.py:55) on the bucketed basis -> R [nc * C, 3H] in the sorted edge order;
-        `scale` [3H] multiplies the output channels."""
+        """rbf_proj of every relation (rmnet.py:55) on the bucketed basis -> (R, R) [nc * C, 3H] in the sorted edge order
+        (two autograd outputs over one storage, see below); `scale` [3H] multiplies the output channels."""
         T, S = len(w_rbf), BucketedBasis.WIDTH - 12
         wt = torch.stack([(w_rbf[t] * scale[:, None]).t() for t in range(T)])               # [T, R, 3H]
         need = (self.nb - 1) * S + BucketedBasis.WIDTH                                       # rows the windows reach
@@ -158,18 +157,138 @@ class BucketedBasis(object):
         else:
             wc = win.index_select(0, self.group)
             bc = bias.index_select(0, self.group // self.nb)
-        if not self.phi.is_cuda:
-            return torch.baddbmm(bc[:, None, :], self.phi, wc).reshape(-1, wc.size(2))
-        # The bias rides in the product: a column of ones behind the 32 basis columns (4 columns, so that rows stay 16-byte
-        # multiples), the bias as weight row 32.  `baddbmm` with a broadcast bias first COPIES it over the whole [nc, C, 3H]
-        # output (0.2 ms per layer here) and reads it back, and its bias gradient is a reduction over the same 610 MB; this
-        # way the weight-gradient product delivers it in its row 32.
-        if self._phi1 is None:
-            one = self.phi.new_zeros(self.phi.size(0), self.phi.size(1), 4)
-            one[..., 0] = 1.0
-            self._phi1 = torch.cat([self.phi, one], 2)                                        # once per step, all layers
-        w1 = torch.cat([wc, bc[:, None, :], wc.new_zeros(wc.size(0), 3, wc.size(2))], 1)      # [nc, 36, 3H]
-        return torch.bmm(self._phi1, w1).reshape(-1, wc.size(2))
+        # One product per chunk with the bias added in its epilogue (csrc/band_product.hip); R comes back TWICE -- the same
+        # storage under two autograd outputs: the message algebra reads the first, its backward (a second consumer of R in
+        # the graph) the second, so their two [E,3H] gradients reach BandP.backward separately and are added while the
+        # gradient products read them -- not by an elementwise launch over 610 MB per layer.
+        R, R2 = band_product(self.phi, wc, bc)
+        return R.reshape(-1, wc.size(2)), R2.reshape(-1, wc.size(2))
+
+
+# ---- batched products with a 32-wide side (csrc/band_product.hip): rbf_proj on the bucketed basis and its two derivatives ------
+def _band_kernels(A, N):
+    return (A.is_cuda and A.dtype == torch.float32 and A.size(2) == 32
+            and bool(_lib.load().hermnet_band_product_supported(int(A.size(1)), int(N))) and A.size(1) % 16 == 0)
+
+
+def _sum2(g1, g2):
+    return g1 if g2 is None else g1 + g2
+
+
+class BandP(torch.autograd.Function):
+    """(A [nc,C,32], B [nc,32,N], bias [nc,N] | None, side1, side2) -> (out, out) with out[c] = A[c] B[c] + bias[c]:
+    `hermnet_band_product`.  The two outputs share their storage; a caller with two consumers of `out` in the graph hands each
+    its own output, and the gradients arrive here unsummed (g1, g2) -- BandQ / BandS add them while reading.  The backward
+    forms the gradient of A and passes (g1, g2) on to the stand-ins of `_BandParams` (the parameter side, a node of its own:
+    see `_TallBmmParams`).  P, Q, S are closed under differentiation, so create_graph=True differentiates the backward again."""
+
+    @staticmethod
+    def forward(ctx, A, B, bias, side1, side2):
+        from .ops import _stream
+        ctx.save_for_backward(B)
+        ctx.side = side1 is not None
+        ctx.set_materialize_grads(False)
+        nc, C, N = A.size(0), A.size(1), B.size(2)
+        if _band_kernels(A, N):
+            out = torch.empty(nc, C, N, dtype=A.dtype, device=A.device)
+            P = _lib.ptr
+            _lib.check(_lib.load().hermnet_band_product(P(A), P(B), P(bias), nc, C, N, P(out), _stream()), "hermnet_band_product")
+        else:
+            out = torch.bmm(A, B) if bias is None else torch.baddbmm(bias[:, None, :], A, B)
+        return out, out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        (B,) = ctx.saved_tensors
+        if g1 is None:
+            g1, g2 = g2, None
+        if g1 is None:
+            return None, None, None, None, None
+        gA = BandQ.apply(g1, g2, B) if ctx.needs_input_grad[0] else None
+        return gA, None, None, (g1 if ctx.side else None), (g2 if ctx.side else None)
+
+
+class _BandParams(torch.autograd.Function):
+    """(B, bias | None; A held) -> two stand-ins of A B; the backward forms (gB, gbias) = BandS(A, g1, g2)."""
+
+    @staticmethod
+    def forward(ctx, B, bias, held):
+        ctx.held = held
+        ctx.has_bias = bias is not None
+        ctx.set_materialize_grads(False)
+        A = held.t
+        shape = (A.size(0), A.size(1), B.size(2))
+        return _stand_in(shape, A), _stand_in(shape, A)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        A = ctx.held.t
+        if g1 is None:
+            g1, g2 = g2, None
+        if g1 is None:
+            return None, None, None
+        gB, gb = BandS.apply(A, g1, g2)
+        return gB, (gb if ctx.has_bias else None), None
+
+
+def band_product(A, B, bias):
+    """(out, out): out[c] = A[c] B[c] + bias[c] (`BandP`), the parameter gradients in a node of their own."""
+    A, B, bias = _c(A), _c(B), _c(bias)
+    s1, s2 = _BandParams.apply(B, bias, _Held(A)) if _wants_grad(B, bias) else (None, None)
+    return BandP.apply(A, B, bias, s1, s2)
+
+
+class BandQ(torch.autograd.Function):
+    """(g1, g2 | None [nc,C,N], B [nc,32,N]) -> gA [nc,C,32] = (g1 + g2) B^T: `hermnet_band_product_grad_a`."""
+
+    @staticmethod
+    def forward(ctx, g1, g2, B):
+        from .ops import _stream
+        g1, g2, B = _c(g1), _c(g2), _c(B)
+        ctx.save_for_backward(g1, g2, B)
+        nc, C, N = g1.shape
+        if _band_kernels(B.new_empty(0, C, 32), N):
+            gA = torch.empty(nc, C, 32, dtype=g1.dtype, device=g1.device)
+            P = _lib.ptr
+            _lib.check(_lib.load().hermnet_band_product_grad_a(P(g1), P(g2), P(B), nc, C, N, P(gA), _stream()),
+                       "hermnet_band_product_grad_a")
+            return gA
+        return torch.bmm(_sum2(g1, g2), B.transpose(1, 2))
+
+    @staticmethod
+    def backward(ctx, c):
+        g1, g2, B = ctx.saved_tensors
+        cg = band_product(c, B, None)[0] if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
+        cB = BandS.apply(c, g1, g2)[0] if ctx.needs_input_grad[2] else None
+        return (cg if ctx.needs_input_grad[0] else None), (cg if g2 is not None and ctx.needs_input_grad[1] else None), cB
+
+
+class BandS(torch.autograd.Function):
+    """(A [nc,C,32], g1, g2 | None [nc,C,N]) -> (gB [nc,32,N] = A^T (g1 + g2), gbias [nc,N] = column sums of g1 + g2):
+    `hermnet_band_product_grad_b`."""
+
+    @staticmethod
+    def forward(ctx, A, g1, g2):
+        from .ops import _stream
+        A, g1, g2 = _c(A), _c(g1), _c(g2)
+        ctx.save_for_backward(A, g1, g2)
+        nc, C, N = g1.shape
+        if _band_kernels(A, N):
+            gB = torch.empty(nc, 32, N, dtype=A.dtype, device=A.device)
+            gb = torch.empty(nc, N, dtype=A.dtype, device=A.device)
+            P = _lib.ptr
+            _lib.check(_lib.load().hermnet_band_product_grad_b(P(A), P(g1), P(g2), nc, C, N, P(gB), P(gb), _stream()),
+                       "hermnet_band_product_grad_b")
+            return gB, gb
+        g = _sum2(g1, g2)
+        return torch.bmm(A.transpose(1, 2), g), g.sum(1)
+
+    @staticmethod
+    def backward(ctx, cB, cb):
+        A, g1, g2 = ctx.saved_tensors
+        cA = BandQ.apply(g1, g2, cB) if ctx.needs_input_grad[0] else None
+        cg = band_product(A, cB, cb)[0] if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
+        return cA, (cg if ctx.needs_input_grad[1] else None), (cg if g2 is not None and ctx.needs_input_grad[2] else None)
 
 
 class TallLinear(torch.autograd.Function):
@@ -236,26 +355,86 @@ def _col_sum_over_rows(g):
     return g.view(T, K // C, C, O).sum(2).sum(1)
 
 
-class TallBmm(torch.autograd.Function):
-    """y[t] = a[t] @ w[t] (+ b[t]) for TALL a [T,K,I] (K = the rows of a relation) and small w [T,I,O]: the node-level
-    linears of the training step (rmnet.py:52, 94-100) and the read-out.  Forward and input gradient are ordinary batched
-    GEMMs; the weight gradient goes through `_gram_over_rows`.  The input gradient is again a TallBmm (its own weight
-    gradient, needed by the second-order pass, is the same tall reduction), everything else is differentiable torch code."""
+# ---- the PARAMETER side of a product's backward as a graph node of its own -------------------------------------------------------
+# `ctx.needs_input_grad` of a custom Function says which inputs require grad, not which gradients THIS backward pass needs: in
+# the force pass (autograd.grad(E, pos, create_graph=True); /root/reference/example/dist_train.py:90-92) no parameter gradient
+# is asked for, yet a Function that computes "ga, gw, gb" in one backward forms them all -- every weight gradient of the step a
+# second time (19 tall reductions and their sums per layer pair, 3.3 ms of 42).  The engine prunes NODES: so the parameter
+# gradients live in a node of their own whose forward output is a zero-stride stand-in of the product's shape (no memory, no
+# launch), consumed by the product's node, which hands it its own incoming gradient.  In a pass that differentiates no
+# parameter the node is never run.  The other operand reaches the node in a `_Held` box, not as an input: an input edge to
+# (something that leads to) the positions would make the node part of the force pass; the operand keeps its own history, so
+# a backward of this backward (parameter gradients under create_graph=True) still differentiates through it.
+_ZERO = {}
+
+
+class _Held(object):
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+
+def _stand_in(shape, ref):
+    z = _ZERO.get((ref.device, ref.dtype))
+    if z is None:
+        z = _ZERO[(ref.device, ref.dtype)] = torch.zeros((), dtype=ref.dtype, device=ref.device)
+    return z.expand(shape)
+
+
+def _wants_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+class _TallBmmRows(torch.autograd.Function):
+    """y[t] = a[t] @ w[t] (+ b[t]); the backward forms the gradient of `a` only and passes its incoming gradient on to `side`
+    (the stand-in of `_TallBmmParams`, or None when no parameter requires grad)."""
 
     @staticmethod
-    def forward(ctx, a, w, b):
-        a = a.contiguous()
-        ctx.save_for_backward(a, w)
+    def forward(ctx, a, w, b, side):
+        ctx.save_for_backward(w)
+        ctx.side = side is not None
         return torch.bmm(a, w) if b is None else torch.baddbmm(b[:, None, :], a, w)
 
     @staticmethod
     def backward(ctx, g):
-        a, w = ctx.saved_tensors
+        (w,) = ctx.saved_tensors
         g = g.contiguous()
-        ga = TallBmm.apply(g, w.transpose(1, 2), None) if ctx.needs_input_grad[0] else None
-        gw = _gram_over_rows(a, g) if ctx.needs_input_grad[1] else None
-        gb = _col_sum_over_rows(g) if ctx.needs_input_grad[2] else None
-        return ga, gw, gb
+        ga = tall_bmm(g, w.transpose(1, 2), None) if ctx.needs_input_grad[0] else None
+        return ga, None, None, (g if ctx.side else None)
+
+
+class _TallBmmParams(torch.autograd.Function):
+    """(w, b | None; a held) -> stand-in of a @ w; the backward forms gw = a^T g (`_gram_over_rows`) and gb (column sums)."""
+
+    @staticmethod
+    def forward(ctx, w, b, held):
+        ctx.held = held
+        ctx.has_b = b is not None
+        a = held.t
+        return _stand_in((a.size(0), a.size(1), w.size(2)), a)
+
+    @staticmethod
+    def backward(ctx, g):
+        a = ctx.held.t
+        gw = _gram_over_rows(a, g) if ctx.needs_input_grad[0] else None
+        gb = _col_sum_over_rows(g) if ctx.has_b and ctx.needs_input_grad[1] else None
+        return gw, gb, None
+
+
+def tall_bmm(a, w, b):
+    """y[t] = a[t] @ w[t] (+ b[t]) for TALL a [T,K,I] (K = the rows of a relation) and small w [T,I,O]: the node-level
+    linears of the training step (rmnet.py:52, 94-100) and the read-out.  Forward and input gradient are ordinary batched
+    GEMMs; the weight gradient goes through `_gram_over_rows`, in a graph node of its own (see above).  The input gradient is
+    again a `tall_bmm` (its own weight gradient, needed by the second-order pass, is the same tall reduction)."""
+    a = a.contiguous()
+    side = _TallBmmParams.apply(w, b, _Held(a)) if _wants_grad(w, b) else None
+    return _TallBmmRows.apply(a, w, b, side)
+
+
+class TallBmm(object):
+    apply = staticmethod(tall_bmm)
 
 
 def tall_linear(a, weight, bias=None):
@@ -599,13 +778,15 @@ class MessageAlgebra(torch.autograd.Function):
     of R or None, padding rows of R or None)."""
 
     @staticmethod
-    def forward(ctx, xh, vec, R, U, keys):
+    def forward(ctx, xh, vec, R, U, keys, R2=None):
         from .ops import _stream
         k_tgt, k_all, k_xh, r_rows = keys[:4]
         xh, vec, R, U = _c(xh), _c(vec), _c(R), _c(U)
         E, H = U.size(0), R.size(1) // 3
         P = _lib.ptr
-        ctx.save_for_backward(xh, vec, R, U)
+        # R2: the same values as R under a second autograd identity (BandP's second output) -- the backward below is R's
+        # second consumer in the graph and differentiates through R2, so that R's two gradients are not summed by the engine
+        ctx.save_for_backward(xh, vec, R if R2 is None else R2, U)
         ctx.keys = keys
         if _row_sums_inside():
             # (the sums over a target's edges stay in registers: no [E,4H] round trip through HBM)
@@ -625,7 +806,7 @@ class MessageAlgebra(torch.autograd.Function):
     def backward(ctx, g_dx, g_dv):
         xh, vec, R, U = ctx.saved_tensors
         g_xh, g_vec, gR, gU = MessageAlgebraGrad.apply(g_dx, g_dv, xh, vec, R, U, ctx.keys)
-        return g_xh, g_vec, gR, gU, None
+        return g_xh, g_vec, gR, gU, None, None
 
 
 class MessageAlgebraGrad(torch.autograd.Function):
@@ -766,9 +947,9 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     parts = []
     if isinstance(edge_embed, BucketedBasis):
         if Ek > 0:     # rbf_proj (rmnet.py:55) as one batched product on the bucketed basis; R stays in its sorted order
-            R = edge_embed.project(w_rbf, b_rbf, sc)
+            R, R2 = edge_embed.project(w_rbf, b_rbf, sc)
             dx, dv = MessageAlgebra.apply(xh.reshape(T * Ns, 3 * H), vec, R, edge[:Ek, :3],
-                                          (k_tgt, k_all, k_xh, edge_embed.slot, edge_embed.pad))
+                                          (k_tgt, k_all, k_xh, edge_embed.slot, edge_embed.pad), R2)
     else:
         # (split, not slices: the backward of a split is ONE cat, a slice's zero-fills the whole [E,R] gradient)
         emb = edge_embed.split([bounds[t + 1] - bounds[t] for t in range(T)] + [edge_embed.size(0) - Ek])

@@ -16,7 +16,8 @@
  *   - float = IEEE fp32 (the reference is fp32-only), indices = int32 (int64 where a parameter says so:
  *     the caller's edge_index / atomic_number / halo index lists arrive as torch LongTensors).
  *
- * ABI version 12 (`hermnet_abi_version`): v12 is ADDITIVE over v11 (hermnet_halo_proj_rows / _accumulate, ranged launches of
+ * ABI version 13 (`hermnet_abi_version`): v13 is ADDITIVE over v12 (hermnet_band_product / _grad_a / _grad_b: the training path's
+ * rbf_proj on the bucketed basis); v12 is ADDITIVE over v11 (hermnet_halo_proj_rows / _accumulate, ranged launches of
  * hermnet_message_scatter_bwd without the finishing launch, hermnet_set_option / _get_option in place of the library's environment
  * variables, hermnet_weight_fragments; no signature, struct or fragment format of v11 changed).  STABLE from v11 on: hn_graph,
  * hn_rbf_desc, hn_pending_grads, the frag(W) / frag16(W) weight streams, and every entry point's argument list -- later versions
@@ -654,6 +655,24 @@ int hermnet_param_guard(const void* const* tensor_ptrs, const long* word_counts,
 int hermnet_shard_step_flags(const long* edge_index, long columns, const long* atomic_number, int num_atoms, const long* total,
                              long capacity, int* has_in, const float* pos, const float* pos_ref, long num_pos, float max_dist2,
                              void* stream);
+
+/* rbf_proj of the TRAINING path on the bucketed basis (ABI v13; hermnet_amd/trainops.py: BucketedBasis, BandP / BandQ / BandS;
+ * /root/reference/HermNet/rmnet.py:55 on 32-centre windows, differentiated twice by /root/reference/example/dist_train.py:86-99).
+ * Edges sorted by (relation, distance bucket) form `num_chunks` chunks of `rows_per_chunk` rows (a multiple of 32; _grad_b: of
+ * 16); a chunk has ONE 32 x width weight window (width = 3 * hidden: a multiple of 32, at most 480).  Exact fp32 products on the
+ * fp32 matrix pipe, fixed summation order.
+ *   hermnet_band_product          out[c] = a[c] b[c] + bias[c]       a [nc,C,32]  b [nc,32,width]  bias [nc,width] | NULL  out [nc,C,width]
+ *   hermnet_band_product_grad_a   ga[c]  = (g1[c] + g2[c]) b[c]^T     g1, g2 [nc,C,width] (g2 NULL = absent)               ga  [nc,C,32]
+ *   hermnet_band_product_grad_b   gb[c]  = a[c]^T (g1[c] + g2[c]),  gbias[c] = column sums of g1[c] + g2[c] (gbias NULL = not asked)
+ * g1 + g2: the radial array has two consumers in the autograd graph (the message algebra and its backward); their gradients are
+ * added while they are read.  hermnet_band_product_supported: 1 when (rows_per_chunk, width) is a shape these kernels take. */
+int hermnet_band_product_supported(int rows_per_chunk, int width);
+int hermnet_band_product(const float* a, const float* b, const float* bias, long num_chunks, int rows_per_chunk, int width,
+                         float* out, void* stream);
+int hermnet_band_product_grad_a(const float* g1, const float* g2, const float* b, long num_chunks, int rows_per_chunk, int width,
+                                float* ga, void* stream);
+int hermnet_band_product_grad_b(const float* a, const float* g1, const float* g2, long num_chunks, int rows_per_chunk, int width,
+                                float* gb, float* gbias, void* stream);
 
 /* Host-side (CPU) evaluation of the per-edge radial contraction exactly as the device code
  * computes it (banded 12-tap Gaussian window): rb[c] = b[c] + env(u) * sum_k W[c,k] g_k(u) and

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hermnet_abi_version() == _lib.ABI_VERSION == 12
+    assert lib.hermnet_abi_version() == _lib.ABI_VERSION == 13
     assert b"gfx950" in lib.hermnet_build_info()
 
 

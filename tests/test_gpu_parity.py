@@ -909,7 +909,8 @@ def test_bucketed_basis_projection_matches_dense_to_second_order(E, H, R, T, env
         sc = t(sc0)
         if bucketed:
             bb = m.bucketed(d, bounds, T)
-            out = bb.project(W, b, sc).index_select(0, bb.slot)
+            R1, R2 = bb.project(W, b, sc)                     # one storage under two autograd outputs (trainops.BandP)
+            out = 0.5 * R1.index_select(0, bb.slot) + 0.5 * R2.index_select(0, bb.slot)
         else:
             phi = m(d)
             out = torch.cat([torch.nn.functional.linear(phi[bounds[k]:bounds[k + 1]], W[k] * sc[:, None], b[k] * sc) for k in range(T)])
@@ -2051,6 +2052,37 @@ def test_halo_proj_rows_kernels_match_the_restatement(T, N, H, n):
                 a_r[:, r] += back[q, :T * W].view(T, W)
                 b_r[0, r] += back[q, T * W:].view(3, H)
         assert torch.equal(a_d.cpu(), a_r) and torch.equal(b_d.cpu(), b_r)
+
+
+@pytest.mark.parametrize("nc,C,N", [(5, 1024, 384), (3, 64, 96), (7, 256, 192), (2, 32, 32), (4, 1024, 480), (0, 1024, 384)])
+def test_band_product_kernels_match_fp64(nc, C, N):
+    """hermnet_band_product / _grad_a / _grad_b (ABI v13; rbf_proj of the training path on the bucketed basis,
+    /root/reference/HermNet/rmnet.py:55) through the C ABI against fp64 products: with and without the bias, with one and with
+    two gradient addends; exact fp32 products, so the error is the accumulation's (<= 2e-6 of the operand scale).  Run twice:
+    bit-identical (fixed summation order)."""
+    from hermnet_amd.trainops import band_product, BandQ, BandS, _band_kernels
+    dev = _dev()
+    gen = torch.Generator().manual_seed(nc * 7 + C + N)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    A, B, b, g1, g2 = r(nc, C, 32), r(nc, 32, N), r(nc, N), r(nc, C, N), r(nc, C, N)
+    assert _band_kernels(A.to(dev), N)
+    d = lambda t: t.double()
+    close = lambda got, ref, scale: float((got.cpu().double() - ref).abs().max()) <= 2e-6 * scale if ref.numel() else True
+    for bias in (b, None):
+        out, out2 = band_product(A.to(dev), B.to(dev), None if bias is None else bias.to(dev))
+        ref = torch.bmm(d(A), d(B)) + (0 if bias is None else d(bias)[:, None, :])
+        assert out.data_ptr() == out2.data_ptr() and close(out, ref, 32 ** 0.5 * 4)
+        assert torch.equal(out, band_product(A.to(dev), B.to(dev), None if bias is None else bias.to(dev))[0])
+    for second in (None, g2):
+        gs = d(g1) if second is None else d(g1) + d(g2)
+        s_dev = None if second is None else second.to(dev)
+        gA = BandQ.apply(g1.to(dev), s_dev, B.to(dev))
+        assert close(gA, torch.bmm(gs, d(B).transpose(1, 2)), N ** 0.5 * 6)
+        gB, gb = BandS.apply(A.to(dev), g1.to(dev), s_dev)
+        assert close(gB, torch.bmm(d(A).transpose(1, 2), gs), C ** 0.5 * 6) and close(gb, gs.sum(1), C ** 0.5 * 6)
+        assert torch.equal(gA, BandQ.apply(g1.to(dev), s_dev, B.to(dev)))
+        gB2, gb2 = BandS.apply(A.to(dev), g1.to(dev), s_dev)
+        assert torch.equal(gB, gB2) and torch.equal(gb, gb2)
 
 
 def test_edge_cases_empty_and_degenerate_graphs():

@@ -477,3 +477,61 @@ def test_param_guard_stays_out_of_copies_and_pickles():
     assert loaded.__dict__.get("_guard") is None
     from torch.optim.swa_utils import AveragedModel
     assert AveragedModel(model).module.__dict__.get("_guard") is None
+
+
+def test_band_product_functions_are_closed_under_differentiation():
+    """trainops.BandP / BandQ / BandS (rbf_proj on the bucketed basis, csrc/band_product.hip on the GPU): first and second
+    derivatives against plain torch ops in fp64, with both autograd outputs of BandP consumed (their gradients reach the
+    backward unsummed)."""
+    from hermnet_amd.trainops import band_product
+    gen = torch.Generator().manual_seed(0)
+    nc, C, N = 3, 32, 64
+    r = lambda *s: torch.randn(*s, dtype=torch.double, generator=gen)
+    A0, B0, b0, c1, wA = r(nc, C, 32), r(nc, 32, N), r(nc, N), r(nc, C, N), r(nc, C, 32)
+
+    def run(band, bias=True):
+        A, B, b, cc = [t.clone().requires_grad_(True) for t in (A0, B0, b0, c1)]
+        if band:
+            out, out2 = band_product(A, B, b if bias else None)
+        else:
+            out = out2 = torch.baddbmm(b[:, None, :], A, B) if bias else torch.bmm(A, B)
+        leaves = [A, B] + ([b] if bias else [])
+        L1 = (out * cc).sum() + 0.1 * (out2 ** 3).sum()
+        first = torch.autograd.grad(L1, leaves, create_graph=True)
+        L2 = (first[0] * wA).sum() + sum((g ** 2).sum() for g in first[1:]) + (out2 ** 2).sum()
+        second = torch.autograd.grad(L2, leaves + [cc])
+        return [out.detach()] + [g.detach() for g in first] + list(second)
+
+    for bias in (True, False):
+        for x, y in zip(run(True, bias), run(False, bias)):
+            assert torch.allclose(x, y, rtol=1e-12, atol=1e-12)
+
+
+def test_parameter_gradients_are_not_formed_in_a_pass_that_does_not_ask_for_them(monkeypatch):
+    """The force pass (autograd.grad(E, pos, create_graph=True), /root/reference/example/dist_train.py:90-92) asks for no
+    parameter gradient: the weight-gradient reductions of tall_bmm / band_product sit in graph nodes of their own
+    (trainops._TallBmmParams / _BandParams) that the engine prunes there -- and runs in the pass that does ask."""
+    import hermnet_amd.trainops as tr
+    calls = {"gram": 0, "s": 0}
+    gram, s_apply = tr._gram_over_rows, tr.BandS.apply
+    monkeypatch.setattr(tr, "_gram_over_rows", lambda a, g: (calls.__setitem__("gram", calls["gram"] + 1), gram(a, g))[1])
+    monkeypatch.setattr(tr.BandS, "apply", staticmethod(lambda *a: (calls.__setitem__("s", calls["s"] + 1), s_apply(*a))[1]))
+    gen = torch.Generator().manual_seed(1)
+    r = lambda *sh: torch.randn(*sh, dtype=torch.double, generator=gen).requires_grad_(True)
+    pos, w, b, B, bias = r(2, 32, 32), r(2, 32, 8), r(2, 8), r(2, 32, 64), r(2, 64)
+    y = tr.tall_bmm(pos, w, b)
+    R1, R2 = tr.band_product(pos, B, bias)
+    e = (y ** 2).sum() + (R1 * R2).sum()
+    f, = torch.autograd.grad(e, pos, create_graph=True)
+    assert calls == {"gram": 0, "s": 0}
+    ((f ** 2).sum() + e).backward()
+    assert calls["gram"] >= 2 and calls["s"] >= 2          # first-order term and the term through the force pass
+    ref_pos = pos.detach().clone().requires_grad_(True)
+    params = [t.detach().clone().requires_grad_(True) for t in (w, b, B, bias)]
+    y = torch.baddbmm(params[1][:, None, :], ref_pos, params[0])
+    R = torch.baddbmm(params[3][:, None, :], ref_pos, params[2])
+    e = (y ** 2).sum() + (R * R).sum()
+    f, = torch.autograd.grad(e, ref_pos, create_graph=True)
+    ((f ** 2).sum() + e).backward()
+    for got, ref in zip((pos, w, b, B, bias), [ref_pos] + params):
+        assert torch.allclose(got.grad, ref.grad, rtol=1e-10, atol=1e-10)
