@@ -163,6 +163,144 @@ __global__ __launch_bounds__(256) void band_s_kernel(const float* __restrict__ A
   }
 }
 
+// ---- Q and S from ONE pass over g1 (+ g2): the pass of the step that differentiates the parameters needs both -----------------
+// One workgroup = one chunk.  The chunk streams through LDS in tiles of 64 rows x 128 columns (g1 + g2 summed on the way in);
+// a tile is read twice from LDS, once per product, in the lane pattern each one needs:
+//   Q  wave w owns row block (w & 1) of the slab and column half (w >> 1) of the tile; accumulates over the N / 128 tiles of
+//      the slab, the two column halves are added at the slab's end (a fixed order) and 32 x 32 results stored
+//   S  wave w owns column tile w of the tile, all 64 rows; one accumulator per column panel, kept over the whole chunk
+// 64 products per wave and tile against 32 KB (64 KB with two addends) of HBM traffic: the same ratio as the single kernels,
+// with half of their traffic.  LDS: tile [64][132] + weight panel [32][132] + basis slab [64][32] = 58.9 KB, two workgroups
+// per CU.  DO_S = false: Q alone with the same staging (the 16-byte loads of band_q_kernel's lanes walk 32 rows at once).
+constexpr int kLG = 132;
+template <int NP, bool TWO, bool DO_S>      // N = 128 NP
+__global__ __launch_bounds__(256, 2) void band_qs_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                         const float* __restrict__ g1, const float* __restrict__ g2,
+                                                         float* __restrict__ gA, float* __restrict__ gB,
+                                                         float* __restrict__ gbias, int C) {
+  constexpr int N = 128 * NP;
+  __shared__ __align__(16) float lds[64 * kLG + 32 * kLG + (DO_S ? 64 * 32 : 0)];
+  float* Gt = lds;
+  float* Bp = lds + 64 * kLG;
+  float* As = Bp + 32 * kLG;
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int rb = wave & 1, ch = wave >> 1;
+  const float* Bc = B + (size_t)c * 32 * N;
+  f16 accS[DO_S ? NP : 1];
+  float colsum[DO_S ? NP : 1];
+  if (DO_S) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      colsum[p] = 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) accS[p][v] = 0.f;
+    }
+  }
+  // the tile a thread stages: 8 x 16 bytes, rows (tid >> 5) + 8 i, columns 4 (tid & 31) .. + 3
+  // (a uniform chunk pointer + 32-bit offsets: one offset register per load, shared by both addends)
+  const int lr = tid >> 5, lc = (tid & 31) * 4;
+  const float* gc1 = g1 + (size_t)c * C * N;
+  const float* gc2 = TWO ? g2 + (size_t)c * C * N : nullptr;
+  f4 t1[8], t2[TWO ? 8 : 1];
+  auto fetch = [&](int slab, int p) {
+    const unsigned base = (unsigned)((slab * 64 + lr) * N + 128 * p + lc);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned off = base + (unsigned)(8 * i * N);
+      t1[i] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(gc1 + off));
+      if (TWO) t2[i] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(gc2 + off));
+    }
+  };
+  const int slabs = C / 64;
+  fetch(0, 0);
+  for (int slab = 0; slab < slabs; ++slab) {
+    const size_t row0 = (size_t)c * C + (size_t)slab * 64;
+    f16 accQ;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) accQ[v] = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      __syncthreads();                                   // the previous tile (and the slab's exchange) has been read
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<f4*>(Gt + (lr + 8 * i) * kLG + lc) = TWO ? t1[i] + t2[i] : t1[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)                        // weight panel [32][128]: 1024 x 16 bytes
+        *reinterpret_cast<f4*>(Bp + (lr + 8 * i) * kLG + lc) = ld4(Bc + (size_t)(lr + 8 * i) * N + 128 * p + lc);
+      if (DO_S && p == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) reinterpret_cast<f4*>(As)[tid + 256 * i] = ld4(A + row0 * 32 + 4 * (tid + 256 * i));
+      }
+      __syncthreads();
+      if (p + 1 < NP) fetch(slab, p + 1);
+      else if (slab + 1 < slabs) fetch(slab + 1, 0);
+      {                                                  // Q: 32 rows x 64 columns of reduction
+        const float* gq = Gt + (32 * rb + j) * kLG + 64 * ch + 4 * h;
+        const float* bq = Bp + j * kLG + 64 * ch + 4 * h;
+#pragma unroll 4
+        for (int q = 0; q < 8; ++q) {
+          const f4 gv = *reinterpret_cast<const f4*>(gq + 8 * q), bv = *reinterpret_cast<const f4*>(bq + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) accQ = mma(gv[e], bv[e], accQ);
+        }
+      }
+      if (DO_S) {                                        // S: 64 rows of reduction x 32 columns
+        const float* as = As + h * 32 + j;
+        const float* gs = Gt + h * kLG + 32 * wave + j;
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+          const float gv = gs[2 * s * kLG];
+          accS[p] = mma(as[2 * s * 32], gv, accS[p]);
+          colsum[p] += gv;
+        }
+      }
+    }
+    // the two column halves of Q: half 1 -> LDS -> added by half 0, stored
+    __syncthreads();
+    float* x = Gt + rb * (16 * 64);
+    if (ch == 1) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) x[v * 64 + lane] = accQ[v];
+    }
+    __syncthreads();
+    if (ch == 0) {
+      float* o = gA + (row0 + 32 * rb + 4 * h) * 32 + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[(8 * g + e) * 32] = accQ[4 * g + e] + x[(4 * g + e) * 64 + lane];
+    }
+  }
+  if (DO_S) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      float* o = gB + ((size_t)c * 32 + 4 * h) * N + 128 * p + 32 * wave + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[(size_t)(8 * g + e) * N] = accS[p][4 * g + e];
+      if (gbias) {
+        float cs = colsum[p];
+        cs += __shfl_xor(cs, 32, 64);
+        if (h == 0) gbias[(size_t)c * N + 128 * p + 32 * wave + j] = cs;
+      }
+    }
+  }
+}
+
+template <int NP>
+void launch_qs(const float* a, const float* b, const float* g1, const float* g2, long nc, int C, float* ga, float* gb, float* gbias,
+               hipStream_t s) {
+  const dim3 grid((unsigned)nc), block(256);
+  if (gb) {
+    if (g2) hipLaunchKernelGGL((band_qs_kernel<NP, true, true>), grid, block, 0, s, a, b, g1, g2, ga, gb, gbias, C);
+    else hipLaunchKernelGGL((band_qs_kernel<NP, false, true>), grid, block, 0, s, a, b, g1, g2, ga, gb, gbias, C);
+  } else {
+    if (g2) hipLaunchKernelGGL((band_qs_kernel<NP, true, false>), grid, block, 0, s, a, b, g1, g2, ga, gb, gbias, C);
+    else hipLaunchKernelGGL((band_qs_kernel<NP, false, false>), grid, block, 0, s, a, b, g1, g2, ga, gb, gbias, C);
+  }
+}
+inline bool staged_shape(int C, int N) { return C % 64 == 0 && (N == 128 || N == 256 || N == 384); }
+
 inline int rows_per_workgroup(int C) { return C % 256 == 0 ? 256 : (C % 128 == 0 ? 128 : C); }
 inline bool shape_ok(long nc, int C, int N) { return nc >= 0 && C > 0 && C % 32 == 0 && N > 0 && N % 32 == 0 && N <= 480 && nc * (C / 32) < (1l << 30); }
 
@@ -186,6 +324,12 @@ extern "C" int hermnet_band_product_grad_a(const float* g1, const float* g2, con
   if (!shape_ok(num_chunks, rows_per_chunk, width)) return HN_ERR_BAD_ARG;
   if (num_chunks == 0) return HN_OK;
   if (!g1 || !b || !ga) return HN_ERR_BAD_ARG;
+  if (staged_shape(rows_per_chunk, width)) {
+    if (width == 384) launch_qs<3>(nullptr, b, g1, g2, num_chunks, rows_per_chunk, ga, nullptr, nullptr, (hipStream_t)stream);
+    else if (width == 256) launch_qs<2>(nullptr, b, g1, g2, num_chunks, rows_per_chunk, ga, nullptr, nullptr, (hipStream_t)stream);
+    else launch_qs<1>(nullptr, b, g1, g2, num_chunks, rows_per_chunk, ga, nullptr, nullptr, (hipStream_t)stream);
+    HN_LAUNCH_END;
+  }
   const int rows_wg = rows_per_workgroup(rows_per_chunk);
   const dim3 grid((unsigned)(num_chunks * (rows_per_chunk / rows_wg)));
   const size_t lds = (size_t)32 * (width + 4) * sizeof(float);
@@ -202,5 +346,20 @@ extern "C" int hermnet_band_product_grad_b(const float* a, const float* g1, cons
   const dim3 grid((unsigned)num_chunks, (unsigned)((width / 32 + 3) / 4));
   if (g2) hipLaunchKernelGGL(band_s_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, g1, g2, gb, gbias, rows_per_chunk, width);
   else hipLaunchKernelGGL(band_s_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, g1, g2, gb, gbias, rows_per_chunk, width);
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_band_product_grads(const float* a, const float* b, const float* g1, const float* g2, long num_chunks,
+                                          int rows_per_chunk, int width, float* ga, float* gb, float* gbias, void* stream) {
+  if (!shape_ok(num_chunks, rows_per_chunk, width) || rows_per_chunk % 16) return HN_ERR_BAD_ARG;
+  if (num_chunks == 0) return HN_OK;
+  if (!a || !b || !g1 || !ga || !gb) return HN_ERR_BAD_ARG;
+  if (!staged_shape(rows_per_chunk, width)) {
+    const int rc = hermnet_band_product_grad_a(g1, g2, b, num_chunks, rows_per_chunk, width, ga, stream);
+    return rc != HN_OK ? rc : hermnet_band_product_grad_b(a, g1, g2, num_chunks, rows_per_chunk, width, gb, gbias, stream);
+  }
+  if (width == 384) launch_qs<3>(a, b, g1, g2, num_chunks, rows_per_chunk, ga, gb, gbias, (hipStream_t)stream);
+  else if (width == 256) launch_qs<2>(a, b, g1, g2, num_chunks, rows_per_chunk, ga, gb, gbias, (hipStream_t)stream);
+  else launch_qs<1>(a, b, g1, g2, num_chunks, rows_per_chunk, ga, gb, gbias, (hipStream_t)stream);
   HN_LAUNCH_END;
 }

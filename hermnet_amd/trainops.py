@@ -183,10 +183,11 @@ class BandP(torch.autograd.Function):
     see `_TallBmmParams`).  P, Q, S are closed under differentiation, so create_graph=True differentiates the backward again."""
 
     @staticmethod
-    def forward(ctx, A, B, bias, side1, side2):
+    def forward(ctx, A, B, bias, side1, side2, held):
         from .ops import _stream
         ctx.save_for_backward(B)
         ctx.side = side1 is not None
+        ctx.held = held
         ctx.set_materialize_grads(False)
         nc, C, N = A.size(0), A.size(1), B.size(2)
         if _band_kernels(A, N):
@@ -203,9 +204,23 @@ class BandP(torch.autograd.Function):
         if g1 is None:
             g1, g2 = g2, None
         if g1 is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
+        if ctx.side and ctx.needs_input_grad[0] and not torch.is_grad_enabled() and _band_kernels(ctx.held.t, B.size(2)):
+            # the pass that differentiates the parameters (no graph is being recorded): gA and the parameter side's (gB, gbias)
+            # from ONE pass over g1 (+ g2); `_BandParams.backward` picks its share up from the box it shares with this node
+            from .ops import _stream
+            A, g1, g2 = ctx.held.t, _c(g1), _c(g2)
+            nc, C, N = g1.shape
+            gA = torch.empty(nc, C, 32, dtype=A.dtype, device=A.device)
+            gB = torch.empty(nc, 32, N, dtype=A.dtype, device=A.device)
+            gb = torch.empty(nc, N, dtype=A.dtype, device=A.device)
+            P = _lib.ptr
+            _lib.check(_lib.load().hermnet_band_product_grads(P(A), P(B), P(g1), P(g2), nc, C, N, P(gA), P(gB), P(gb), _stream()),
+                       "hermnet_band_product_grads")
+            ctx.held.ready = (g1, g2, gB, gb)
+            return gA, None, None, g1, g2, None
         gA = BandQ.apply(g1, g2, B) if ctx.needs_input_grad[0] else None
-        return gA, None, None, (g1 if ctx.side else None), (g2 if ctx.side else None)
+        return gA, None, None, (g1 if ctx.side else None), (g2 if ctx.side else None), None
 
 
 class _BandParams(torch.autograd.Function):
@@ -227,15 +242,20 @@ class _BandParams(torch.autograd.Function):
             g1, g2 = g2, None
         if g1 is None:
             return None, None, None
-        gB, gb = BandS.apply(A, g1, g2)
+        ready, ctx.held.ready = ctx.held.ready, None
+        if ready is not None and ready[0] is g1 and ready[1] is g2:          # formed by BandP.backward's single pass
+            gB, gb = ready[2], ready[3]
+        else:
+            gB, gb = BandS.apply(A, g1, g2)
         return gB, (gb if ctx.has_bias else None), None
 
 
 def band_product(A, B, bias):
     """(out, out): out[c] = A[c] B[c] + bias[c] (`BandP`), the parameter gradients in a node of their own."""
     A, B, bias = _c(A), _c(B), _c(bias)
-    s1, s2 = _BandParams.apply(B, bias, _Held(A)) if _wants_grad(B, bias) else (None, None)
-    return BandP.apply(A, B, bias, s1, s2)
+    held = _Held(A)
+    s1, s2 = _BandParams.apply(B, bias, held) if _wants_grad(B, bias) else (None, None)
+    return BandP.apply(A, B, bias, s1, s2, held)
 
 
 class BandQ(torch.autograd.Function):
@@ -369,10 +389,11 @@ _ZERO = {}
 
 
 class _Held(object):
-    __slots__ = ("t",)
+    __slots__ = ("t", "ready")
 
     def __init__(self, t):
         self.t = t
+        self.ready = None
 
 
 

@@ -16,7 +16,7 @@
  *   - float = IEEE fp32 (the reference is fp32-only), indices = int32 (int64 where a parameter says so:
  *     the caller's edge_index / atomic_number / halo index lists arrive as torch LongTensors).
  *
- * ABI version 13 (`hermnet_abi_version`): v13 is ADDITIVE over v12 (hermnet_band_product / _grad_a / _grad_b: the training path's
+ * ABI version 13 (`hermnet_abi_version`): v13 is ADDITIVE over v12 (hermnet_band_product / _grad_a / _grad_b / _grads: the training path's
  * rbf_proj on the bucketed basis); v12 is ADDITIVE over v11 (hermnet_halo_proj_rows / _accumulate, ranged launches of
  * hermnet_message_scatter_bwd without the finishing launch, hermnet_set_option / _get_option in place of the library's environment
  * variables, hermnet_weight_fragments; no signature, struct or fragment format of v11 changed).  STABLE from v11 on: hn_graph,
@@ -664,6 +664,7 @@ int hermnet_shard_step_flags(const long* edge_index, long columns, const long* a
  *   hermnet_band_product          out[c] = a[c] b[c] + bias[c]       a [nc,C,32]  b [nc,32,width]  bias [nc,width] | NULL  out [nc,C,width]
  *   hermnet_band_product_grad_a   ga[c]  = (g1[c] + g2[c]) b[c]^T     g1, g2 [nc,C,width] (g2 NULL = absent)               ga  [nc,C,32]
  *   hermnet_band_product_grad_b   gb[c]  = a[c]^T (g1[c] + g2[c]),  gbias[c] = column sums of g1[c] + g2[c] (gbias NULL = not asked)
+ *   hermnet_band_product_grads    ga, gb and gbias of the two above from ONE pass over g1 (+ g2) (a, b, g1, ga, gb required)
  * g1 + g2: the radial array has two consumers in the autograd graph (the message algebra and its backward); their gradients are
  * added while they are read.  hermnet_band_product_supported: 1 when (rows_per_chunk, width) is a shape these kernels take. */
 int hermnet_band_product_supported(int rows_per_chunk, int width);
@@ -673,6 +674,8 @@ int hermnet_band_product_grad_a(const float* g1, const float* g2, const float* b
                                 float* ga, void* stream);
 int hermnet_band_product_grad_b(const float* a, const float* g1, const float* g2, long num_chunks, int rows_per_chunk, int width,
                                 float* gb, float* gbias, void* stream);
+int hermnet_band_product_grads(const float* a, const float* b, const float* g1, const float* g2, long num_chunks,
+                               int rows_per_chunk, int width, float* ga, float* gb, float* gbias, void* stream);
 
 /* Host-side (CPU) evaluation of the per-edge radial contraction exactly as the device code
  * computes it (banded 12-tap Gaussian window): rb[c] = b[c] + env(u) * sum_k W[c,k] g_k(u) and

@@ -2054,7 +2054,8 @@ def test_halo_proj_rows_kernels_match_the_restatement(T, N, H, n):
         assert torch.equal(a_d.cpu(), a_r) and torch.equal(b_d.cpu(), b_r)
 
 
-@pytest.mark.parametrize("nc,C,N", [(5, 1024, 384), (3, 64, 96), (7, 256, 192), (2, 32, 32), (4, 1024, 480), (0, 1024, 384)])
+@pytest.mark.parametrize("nc,C,N", [(5, 1024, 384), (3, 64, 96), (7, 256, 192), (2, 32, 32), (4, 1024, 480), (0, 1024, 384), (3, 128, 128),
+                                     (2, 192, 256), (300, 1024, 384)])
 def test_band_product_kernels_match_fp64(nc, C, N):
     """hermnet_band_product / _grad_a / _grad_b (ABI v13; rbf_proj of the training path on the bucketed basis,
     /root/reference/HermNet/rmnet.py:55) through the C ABI against fp64 products: with and without the bias, with one and with
@@ -2083,6 +2084,16 @@ def test_band_product_kernels_match_fp64(nc, C, N):
         assert torch.equal(gA, BandQ.apply(g1.to(dev), s_dev, B.to(dev)))
         gB2, gb2 = BandS.apply(A.to(dev), g1.to(dev), s_dev)
         assert torch.equal(gB, gB2) and torch.equal(gb, gb2)
+        # the three from one pass over g1 (+ g2) (hermnet_band_product_grads; staged tiles for widths 128 / 256 / 384)
+        from hermnet_amd import _lib
+        from hermnet_amd.ops import _stream
+        fa, fB, fb = torch.empty_like(gA), torch.empty_like(gB), torch.empty_like(gb)
+        Ad, Bd, g1d, P = A.to(dev), B.to(dev), g1.to(dev), _lib.ptr
+        for _ in range(2):
+            _lib.check(_lib.load().hermnet_band_product_grads(P(Ad), P(Bd), P(g1d), P(s_dev), nc, C, N, P(fa), P(fB), P(fb), _stream()),
+                       "hermnet_band_product_grads")
+            assert close(fa, torch.bmm(gs, d(B).transpose(1, 2)), N ** 0.5 * 6)
+            assert close(fB, torch.bmm(d(A).transpose(1, 2), gs), C ** 0.5 * 6) and close(fb, gs.sum(1), C ** 0.5 * 6)
 
 
 def test_edge_cases_empty_and_degenerate_graphs():
