@@ -27,10 +27,58 @@ namespace {
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16 __attribute__((ext_vector_type(16)));
 
+#ifndef HN_P_TI
+#define HN_P_TI 3      // column tiles of the product kernel in flight per wave (measured: 1: 215 us, 2: 198, 3: 187, 4: 192)
+#endif
 #define HN_LAUNCH_END return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH
 
 __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ f16 mma(float x, float y, f16 acc) { return __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0); }
+
+// The chunk's weight window [32][N] -> LDS rows of `ld` floats.  Four 16-byte loads per thread are in flight before the first LDS
+// write (a load-then-write loop waits out one memory latency per iteration: 12 of them at N = 384, ~25 us per workgroup).
+template <int THREADS>
+__device__ __forceinline__ void stage_weights(float* Bl, const float* Bc, int N, int ld, int tid) {
+  const int n4 = N / 4, total = 8 * N;
+  for (int i0 = tid; i0 < total; i0 += 4 * THREADS) {
+    f4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * THREADS;
+      if (i < total) v[u] = *reinterpret_cast<const f4*>(Bc + 4 * (size_t)i);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * THREADS;
+      if (i < total) *reinterpret_cast<f4*>(Bl + (i / n4) * ld + 4 * (i % n4)) = v[u];
+    }
+  }
+}
+
+template <int TI>
+__device__ __forceinline__ void p_tiles(const f4 (&a)[4], const float* Bl, const float* bc, float* o, int N, int t, int j, int h) {
+  f16 acc[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const float b0 = bc ? bc[(t + i) * 32 + j] : 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[i][v] = b0;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < TI; ++i) acc[i] = mma(a[q][e], Bl[(8 * q + 4 * h + e) * N + (t + i) * 32 + j], acc[i]);
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __builtin_nontemporal_store(acc[i][4 * g + e], o + (size_t)(8 * g + e) * N + (t + i) * 32);
+      }
+}
 
 // ---- P: one workgroup = `rows_wg` rows of one chunk (the chunk's weight window in LDS), a wave = 32 rows x all columns --------
 __global__ __launch_bounds__(256) void band_p_kernel(const float* __restrict__ A, const float* __restrict__ B,
@@ -40,29 +88,32 @@ __global__ __launch_bounds__(256) void band_p_kernel(const float* __restrict__ A
   const int parts = C / rows_wg, c = blockIdx.x / parts, part = blockIdx.x % parts;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
   const float* Bc = B + (size_t)c * 32 * N;
-  for (int i = tid; i < 8 * N; i += 256) reinterpret_cast<f4*>(Bl)[i] = ld4(Bc + 4 * i);
+  // (a row block's basis rows are requested one block ahead -- the first before the weights are staged: fetched at the head of
+  // their own block, its products wait out the trip to memory)
+  const size_t wg_row0 = (size_t)c * C + (size_t)part * rows_wg;
+  f4 an[4] = {};
+  if (wave < rows_wg / 32) {                            // (a workgroup of fewer than 128 rows leaves waves without a block)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) an[q] = ld4(A + (wg_row0 + wave * 32 + j) * 32 + 8 * q + 4 * h);
+  }
+  stage_weights<256>(Bl, Bc, N, N, tid);
   __syncthreads();
   const float* bc = bias ? bias + (size_t)c * N : nullptr;
+  const int t0 = 0, t1 = N / 32;
   for (int rb = wave; rb < rows_wg / 32; rb += 4) {
-    const size_t row0 = (size_t)c * C + (size_t)part * rows_wg + rb * 32;
+    const size_t row0 = wg_row0 + rb * 32;
     f4 a[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] = ld4(A + (row0 + j) * 32 + 8 * q + 4 * h);
-    float* o = out + (row0 + 4 * h) * N + j;
-    for (int t = 0; t < N / 32; ++t) {
-      const float b0 = bc ? bc[t * 32 + j] : 0.f;
-      f16 acc;
+    for (int q = 0; q < 4; ++q) a[q] = an[q];
+    if (rb + 4 < rows_wg / 32) {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) acc[v] = b0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = mma(a[q][e], Bl[(8 * q + 4 * h + e) * N + t * 32 + j], acc);
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) __builtin_nontemporal_store(acc[4 * g + e], o + (size_t)(8 * g + e) * N + t * 32);
+      for (int q = 0; q < 4; ++q) an[q] = ld4(A + (row0 + 128 + j) * 32 + 8 * q + 4 * h);
     }
+    float* o = out + (row0 + 4 * h) * N + j;
+    // HN_P_TI column tiles at a time: their products interleave, so that no product waits for the one it accumulates onto
+    int t = t0;
+    for (; t + HN_P_TI <= t1; t += HN_P_TI) p_tiles<HN_P_TI>(a, Bl, bc, o, N, t, j, h);
+    for (; t < t1; ++t) p_tiles<1>(a, Bl, bc, o, N, t, j, h);
   }
 }
 
@@ -76,10 +127,7 @@ __global__ __launch_bounds__(256) void band_q_kernel(const float* __restrict__ g
   const int parts = C / rows_wg, c = blockIdx.x / parts, part = blockIdx.x % parts;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
   const float* Bc = B + (size_t)c * 32 * N;
-  for (int i = tid; i < 8 * N; i += 256) {
-    const int k = i / (N / 4), n4 = i % (N / 4);
-    *reinterpret_cast<f4*>(Bl + k * LD + 4 * n4) = ld4(Bc + 4 * i);
-  }
+  stage_weights<256>(Bl, Bc, N, LD, tid);
   __syncthreads();
   const float* bl = Bl + j * LD + 4 * h;
   constexpr int U = 4;                                               // 16-byte loads in flight per lane and operand

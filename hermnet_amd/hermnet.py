@@ -352,7 +352,7 @@ class HVNet(nn.Module):
             data._hn_edge_embed = None
         elif train and pos.is_cuda and self.radial_basis.rbf_name == "gaussian" and H % 4 == 0 and graph.T > 0:
             # train(): the basis sorted by (relation, distance bucket) and cut to the bucket's 32 centres (trainops.BucketedBasis)
-            data._hn_edge_embed = self.radial_basis.bucketed(edge[:, 3], graph.rel_edge_bounds(), graph.T)
+            data._hn_edge_embed = self.radial_basis.bucketed(edge[:, 3], graph.rel_edge_bounds(), graph.T, graph.rel_edge_bounds_dev())
         else:
             data._hn_edge_embed = self.radial_basis(edge[:, 3])
         data.x, data.vec = x, vec

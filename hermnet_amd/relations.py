@@ -79,6 +79,10 @@ class RelationalGraph(object):
             self._rel_bounds = self.csr_rowptr[self.type_rowptr.long()].tolist()
         return self._rel_bounds
 
+    def rel_edge_bounds_dev(self):
+        """`rel_edge_bounds` as a device tensor [T + 1] (no host read, no upload)."""
+        return self.csr_rowptr[self.type_rowptr.long()]
+
     @staticmethod
     def build(atomic_number, edge_index, z_list, edge_shift=None, batch=None, rel_active=None, uniform=None):
         """atomic_number [N] int, edge_index [2,E] int (row 0 = source, row 1 = target,

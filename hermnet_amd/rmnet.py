@@ -149,42 +149,62 @@ class RadialBasis(nn.Module):
             rbf = self.rbf.prefactor * (ed ** self.rbf.exp1) * ((1 - ed) ** self.rbf.exp2)
         return env[:, None] * rbf
 
-    def bucketed(self, d, bounds, T):
+    def _spacing(self):
+        """offset[1] - offset[0] as a host float: read once per offset buffer (not once per step)."""
+        off = self.rbf.offset
+        key = (off.data_ptr(), off._version, off.numel())
+        if getattr(self, "_delta", None) is None or self._delta[0] != key:
+            self._delta = (key, float(off[1] - off[0]) if off.numel() > 1 else 1.0)
+        return self._delta[1]
+
+    def bucketed(self, d, bounds, T, bounds_dev=None):
         """`BucketedBasis` of the edges [0, bounds[T]) (CSR order: relation t owns [bounds[t], bounds[t+1])) with
         distances d.  Window of bucket b: centres b*20 - 5 .. b*20 + 26; an edge with floor(u/delta) - 5 = lo goes to
-        bucket (lo + 5) // 20, so the twelve centres lo .. lo + 11 around u lie inside.  One host read (group sizes)."""
+        bucket (lo + 5) // 20, so the twelve centres lo .. lo + 11 around u lie inside.
+
+        No host read: the chunk count is the static bound  ceil(Ek / C) + T nb  (every (relation, bucket) group wastes less
+        than one chunk; the spare chunks -- all padding, ~3 % at configs[4]'s batch -- are given to the last group), so every
+        size below is known before the distances are (round 6: the group sizes used to be read back, which drained the
+        device queue in the middle of the forward pass).  `bounds_dev`: `bounds` as a device tensor (graph.rel_edge_bounds_dev)."""
         Ek, dev = bounds[T], d.device
         W, C = BucketedBasis.WIDTH, BucketedBasis.CHUNK
         S = W - 12
         off = self.rbf.offset
         R = off.numel()
-        delta = float(off[1] - off[0]) if R > 1 else 1.0
+        delta = self._spacing()
         nb = (R + 4) // S + 1
+        G = T * nb
+        nc = (Ek + C - 1) // C + G
         u = d[:Ek] * self.inv_cutoff
         lo = torch.floor(u.detach() / delta).clamp(min=0, max=R + S).long() - 5
         bucket = ((lo + 5) // S).clamp(max=nb - 1)
-        rel = torch.repeat_interleave(torch.arange(T, device=dev),
-                                      torch.tensor([bounds[t + 1] - bounds[t] for t in range(T)], device=dev))
+        ar = torch.arange(Ek, device=dev)
+        if bounds_dev is None:
+            bounds_dev = torch.tensor(bounds, device=dev)
+        rel = torch.bucketize(ar, bounds_dev[1:T + 1].long(), right=True)
         key = rel * nb + bucket
-        cnt = torch.bincount(key, minlength=T * nb)
-        cnt_h = cnt.tolist()                                                                 # the host read
-        chunks = [(c + C - 1) // C for c in cnt_h]
-        nc = sum(chunks)
-        start_pad = torch.tensor([0] + chunks[:-1], device=dev).cumsum(0) * C                # first padded row of a group
-        start = torch.cumsum(cnt, 0) - cnt
         order = torch.argsort(key, stable=True)
         ks = key[order]
+        ends = torch.searchsorted(ks, torch.arange(1, G + 1, device=dev))                     # edges with a key below g + 1
+        cnt = torch.diff(ends, prepend=ends.new_zeros(1))
+        start = ends - cnt                                                                   # first edge of group g in `order`
+        chunks = (cnt + (C - 1)) // C
+        spare = nc - chunks.sum()
+        chunks = torch.cat([chunks[:-1], chunks[-1:] + spare])
+        cend = torch.cumsum(chunks, 0)
+        start_pad = (cend - chunks) * C                                                      # first padded row of a group
         slot = torch.empty(Ek, dtype=torch.long, device=dev)
-        slot.scatter_(0, order, start_pad[ks] + torch.arange(Ek, device=dev) - start[ks])     # (a permutation: plain scatter)
+        slot.scatter_(0, order, start_pad[ks] + ar - start[ks])                              # (a permutation: plain scatter)
         src = torch.full((nc * C,), Ek, dtype=torch.long, device=dev)                        # padding rows -> the dummy entry
-        src.scatter_(0, slot, torch.arange(Ek, device=dev))
-        group = torch.repeat_interleave(torch.arange(T * nb, device=dev), torch.tensor(chunks, device=dev))
-        # the padding rows (no edge points to them): the edge kernels' R gradients zero these instead of the whole buffer
-        import numpy as np
-        first = np.concatenate([[0], np.cumsum(chunks[:-1])]) * C
-        pad = np.concatenate([np.arange(first[i] + cnt_h[i], first[i] + chunks[i] * C) for i in range(len(chunks))] +
-                             [np.zeros(0, dtype=np.int64)]).astype(np.int64)
-        pad = torch.from_numpy(pad).to(dev)
+        src.scatter_(0, slot, ar)
+        group = torch.searchsorted(cend, torch.arange(nc, device=dev), right=True)           # chunk -> group
+        # the padding rows (no edge points to them): the edge kernels' R gradients zero these instead of the whole buffer.
+        # Group g pads [start_pad[g] + cnt[g], start_pad[g] + chunks[g] C): the p-th padding row overall, by its group
+        padcnt = chunks * C - cnt
+        pend = torch.cumsum(padcnt, 0)
+        p_ = torch.arange(nc * C - Ek, device=dev)
+        gi = torch.searchsorted(pend, p_, right=True)
+        pad = (start_pad + cnt - (pend - padcnt))[gi] + p_
         up = torch.cat([u, u.new_zeros(1)]).index_select(0, src)                              # [nc * C], differentiable
         if isinstance(self.envelope, PolynomialEnvelope):
             p = self.envelope.p
@@ -198,7 +218,7 @@ class RadialBasis(nn.Module):
         mu = off[k.clamp(0, R - 1)]
         colok = ((k >= 0) & (k < R)).to(up.dtype)
         phi = torch.exp(self.rbf.coeff * (up.view(nc, C, 1) - mu[:, None, :]) ** 2) * (env.view(nc, C, 1) * colok[:, None, :])
-        return BucketedBasis(phi, group, slot, nb, R, pad, torch.tensor(chunks, device=dev))
+        return BucketedBasis(phi, group, slot, nb, R, pad, chunks)
 
     def descriptor(self):
         if self.rbf_name != "gaussian":
@@ -277,16 +297,25 @@ def _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed):
     B, nk = graph.block, graph.type_rowptr_host[-1]
     ml = [m.message_layer for m in mlist]
     ul = [m.update_layer for m in mlist]
-    st = lambda ts: torch.stack(list(ts), 0)
+    # every per-relation parameter of the layer stacked to [T, ...] by ONE concatenation (kind-major, so that a kind's T
+    # tensors are adjacent: the stacks are views of it) -- thirteen torch.stack launches per layer otherwise
+    kinds = [[m.x_layernorm.weight for m in ml], [m.x_layernorm.bias for m in ml],
+             [m.x_proj[0].weight for m in ml], [m.x_proj[0].bias for m in ml],
+             [m.x_proj[2].weight for m in ml], [m.x_proj[2].bias for m in ml],
+             [m.rbf_proj.weight for m in ml], [m.rbf_proj.bias for m in ml],
+             [u.vec_proj.weight for u in ul],
+             [u.xvec_proj[0].weight for u in ul], [u.xvec_proj[0].bias for u in ul],
+             [u.xvec_proj[2].weight for u in ul], [u.xvec_proj[2].bias for u in ul]]
+    # (split, not slices: the backward of a split is one concatenation, a slice's zero-fills the whole buffer)
+    flat = torch.cat([p.reshape(-1) for ps in kinds for p in ps]).split([ps[0].numel() * T for ps in kinds])
+    g, b, w1, b1, w2, b2, w_rbf, b_rbf, wv, wx0, bx0, wx2, bx2 = [f.view((T,) + tuple(ps[0].shape)) for f, ps in zip(flat, kinds)]
     # --- x_proj(LayerNorm(x)) of every relation for every row (rmnet.py:52)
     # (LayerNorm, SiLU and the two elementwise stages of PaiNNUpdate: one launch per order of differentiation each,
     # trainops / csrc/train_node_kernels.hip, where torch's autograd spreads ~120 small launches per layer)
     fusedn = node_kernels_ok(x)
     silu = SiLU2.apply if fusedn else F.silu
     n = LayerNorm2.apply(x, 1e-5) if fusedn else F.layer_norm(x, (H,))
-    g, b = st(m.x_layernorm.weight for m in ml), st(m.x_layernorm.bias for m in ml)                 # [T,H]
-    w1, b1 = st(m.x_proj[0].weight for m in ml), st(m.x_proj[0].bias for m in ml)                   # [T,H,H], [T,H]
-    w2, b2 = st(m.x_proj[2].weight for m in ml), st(m.x_proj[2].bias for m in ml)                   # [T,3H,H], [T,3H]
+    # g, b [T,H]; w1 [T,H,H], b1 [T,H]; w2 [T,3H,H], b2 [T,3H]
     # the LayerNorm affine of relation t folds into its first Linear (W1 diag(g), b1 + W1 b: [H,H]-sized ops instead of
     # [T,N,H]-sized ones in every order of differentiation), and the T first Linears become ONE [N,H] x [H,T H] product
     w1f = (w1 * g[:, None, :]).reshape(T * H, H)
@@ -299,12 +328,9 @@ def _relational_layer_batched(mlist, x, vec, edge, graph, edge_embed):
     h = bmm_b(n[None], w1f.t()[None], b1f[None])[0].view(-1, T, H).transpose(0, 1)                    # [T,N,H]
     # (ScaledSiLU's constant factor rides on the following weight, not on the [T,N,H] activations)
     xh = bmm_b(silu(h), (w2 * ml[0].x_proj[1].scale_factor).transpose(1, 2), b2)                      # [T,N,3H]
-    x1, vec1 = message_scatter_generic(xh, vec, x, edge, edge_embed, [m.rbf_proj.weight for m in ml],
-                                       [m.rbf_proj.bias for m in ml], graph)
+    x1, vec1 = message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph)
     # --- PaiNNUpdate on the rows of each relation (rmnet.py:94-107), blocks of B rows
-    wv = st(u.vec_proj.weight for u in ul)                                                           # [T,2H,H]
-    wx0, bx0 = st(u.xvec_proj[0].weight for u in ul), st(u.xvec_proj[0].bias for u in ul)           # [T,H,2H], [T,H]
-    wx2, bx2 = st(u.xvec_proj[2].weight for u in ul), st(u.xvec_proj[2].bias for u in ul)           # [T,3H,H], [T,3H]
+    # wv [T,2H,H]; wx0 [T,H,2H], bx0 [T,H]; wx2 [T,3H,H], bx2 [T,3H]
     xt, vt = x1[:nk].view(T, B, H), vec1[:nk].view(T, B, 3, H)
     vp = bmm_b(vt.reshape(T, B * 3, H), wv.transpose(1, 2), None).view(T, B, 3, 2 * H)
     if fusedn:

@@ -136,21 +136,31 @@ class BucketedBasis(object):
         # over the chunks of a group -- index_select's own backward adds them with float atomics, the one place where the
         # training step's gradients were not bit-reproducible from run to run)
         self.key_w = self.key_b = None
+        self._unit = None
         if chunks_per_group is not None and chunks_per_group.numel() % self.nb == 0:
             cg = chunks_per_group.long()
             self.key_w = _RowKey(group, None, cg, cg.numel())
             self.key_b = _RowKey(group // self.nb, None, cg.view(-1, self.nb).sum(1), cg.numel() // self.nb)
 
+    def unit_vectors(self, edge, Ek):
+        """edge[:Ek, :3] (rhat of the known-target edges) as ONE contiguous tensor for all layers of the step: a slice per
+        layer costs a copy forward and a zero-fill + copy + add per layer in each backward pass."""
+        if self._unit is None or self._unit[0] is not edge:
+            self._unit = (edge, edge[:Ek, :3].contiguous())
+        return self._unit[1]
+
     def project(self, w_rbf, b_rbf, scale):
         """rbf_proj of every relation (rmnet.py:55) on the bucketed basis -> (R, R) [nc * C, 3H] in the sorted edge order
         (two autograd outputs over one storage, see below); `scale` [3H] multiplies the output channels."""
         T, S = len(w_rbf), BucketedBasis.WIDTH - 12
-        wt = torch.stack([(w_rbf[t] * scale[:, None]).t() for t in range(T)])               # [T, R, 3H]
+        # (stack first, scale once: two launches where the per-relation form had 2 T)
+        stacked = lambda ps: ps if torch.is_tensor(ps) else torch.stack(list(ps))
+        wt = (stacked(w_rbf) * scale[None, :, None]).transpose(1, 2)                         # [T, R, 3H]
         need = (self.nb - 1) * S + BucketedBasis.WIDTH                                       # rows the windows reach
         wt = F.pad(wt, (0, 0, 5, max(need - 5 - wt.size(1), 0)))                             # centre k sits at row k + 5
         win = wt.unfold(1, BucketedBasis.WIDTH, S)[:, :self.nb]                              # [T, nb, 3H, 32]
         win = win.permute(0, 1, 3, 2).reshape(T * self.nb, BucketedBasis.WIDTH, -1)
-        bias = torch.stack([b_rbf[t] * scale for t in range(T)])                             # [T, 3H]
+        bias = stacked(b_rbf) * scale[None, :]                                               # [T, 3H]
         if self.key_w is not None:
             wc = GatherRows.apply(win.reshape(win.size(0), -1), self.key_w).view(-1, win.size(1), win.size(2))
             bc = GatherRows.apply(bias, self.key_b)
@@ -911,6 +921,12 @@ def edge_message(X, R, V, U):
     return _edge_message_torch(X, R, V, U)
 
 
+def _run_lengths(sorted_keys, n):
+    """How often each of 0 .. n-1 occurs in an ascending key vector (bincount without its host read)."""
+    ends = torch.searchsorted(sorted_keys, torch.arange(1, n + 1, device=sorted_keys.device))
+    return torch.diff(ends, prepend=ends.new_zeros(1))
+
+
 def _row_keys(graph, T, Nt, Ns, bounds):
     """(key of the targets of the first Ek CSR edges [Nt target rows], key of their sources [Ns source rows], key of
     their (relation, source) rows of xh.view(T Ns, 3H), key of the residual rows or None) for `message_scatter_generic`,
@@ -925,23 +941,42 @@ def _row_keys(graph, T, Nt, Ns, bounds):
     nk = int(graph.type_rowptr_host[-1])
     lengths = rowptr[1:] - rowptr[:-1]
     lengths = torch.cat([lengths[:nk], lengths.new_zeros(Nt - nk)])          # edges into unknown-element rows: not summed
-    tgt_row = torch.repeat_interleave(torch.arange(Nt, device=dev), lengths)
+    # (no host reads here: sizes are passed where an op would read them back -- repeat_interleave -- and run lengths come
+    # from the sorted keys, not from bincount, which reads its input's extrema back)
+    tgt_row = torch.repeat_interleave(torch.arange(Nt, device=dev), lengths, output_size=Ek)
     k_tgt = _RowKey(tgt_row, None, lengths, Nt)
     src = graph.csr_src.long()
     crp, cpos = graph.csc_rowptr.long(), graph.csc_pos.long()               # groups (relation, source row) over CSR positions
     # all relations at once: sorted by (source row) = the T groups of a row merged; built by one stable sort
     order = torch.argsort(src[:Ek], stable=True)
-    k_all = _RowKey(src[:Ek], order, torch.bincount(src[:Ek], minlength=Ns), Ns)
+    k_all = _RowKey(src[:Ek], order, _run_lengths(src[:Ek].index_select(0, order), Ns), Ns)
     # rows of xh.view(T * Ns, 3H): (relation of the edge's target, source row) -- the CSC groups themselves
-    rel_of_edge = torch.repeat_interleave(torch.arange(T, device=dev),
-                                          torch.tensor([bounds[t + 1] - bounds[t] for t in range(T)], device=dev))
+    rel_of_edge = torch.bucketize(torch.arange(Ek, device=dev), graph.rel_edge_bounds_dev()[1:T + 1].long(), right=True)
     k_xh = _RowKey(rel_of_edge * Ns + src[:Ek], cpos[:Ek], crp[1:T * Ns + 1] - crp[:T * Ns], T * Ns)
     k_res = None
     if graph.res_row is not None:
         res = graph.res_row.long()
-        k_res = _RowKey(res, torch.argsort(res, stable=True), torch.bincount(res, minlength=Ns), Ns)
-    graph._row_keys = (k_tgt, k_all, k_xh, k_res)
+        order_r = torch.argsort(res, stable=True)
+        k_res = _RowKey(res, order_r, _run_lengths(res.index_select(0, order_r), Ns), Ns)
+    # rows of a known element (the others stay zero, hermnet.py:51): once per graph, not once per layer
+    known = torch.arange(Nt, device=dev) < graph.type_rowptr[T:T + 1].long()
+    graph._row_keys = (k_tgt, k_all, k_xh, k_res, known.to(torch.float32))
     return graph._row_keys
+
+
+_SCALE = {}
+
+
+def _message_scale(H, ref):
+    """[3H] factors of the three message parts (1, 1/sqrt(3H), 1/sqrt(H); rmnet.py:64-66): a constant per width."""
+    key = (H, ref.device, ref.dtype)
+    sc = _SCALE.get(key)
+    if sc is None:
+        sc = ref.new_ones(3 * H)
+        sc[H:2 * H] = 1 / math.sqrt(3.0 * H)
+        sc[2 * H:] = 1 / math.sqrt(H)
+        _SCALE[key] = sc
+    return sc
 
 
 def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
@@ -952,24 +987,21 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     T, Ns, H3 = xh.shape                                       # Ns source rows (rows of x / vec / xh[t])
     H = H3 // 3
     N = graph.N                                                # target rows (= Ns for HVNet; HTNet: one per atom and pair)
-    rel_row = torch.bucketize(torch.arange(N, device=x.device), graph.type_rowptr.long()[1:], right=True)
     # rows are relation-ordered and CSR is row-ordered: the edges of relation t are ONE contiguous CSR range
     # (no per-relation masks or gathers of the edge arrays)
     bounds = graph.rel_edge_bounds()
     Ek = bounds[T]                                             # edges whose target has a known element
-    k_tgt, k_all, k_xh, k_res = _row_keys(graph, T, N, Ns, bounds)
+    k_tgt, k_all, k_xh, k_res, known = _row_keys(graph, T, N, Ns, bounds)
+    known = known.to(x.dtype)
     # the constant factors of the vector message (1/sqrt(3H) on the `a` part, 1/sqrt(H) on `b`, rmnet.py:64-66) ride on
     # the [3H, R] projection weights, not on per-edge tensors
-    sc = x.new_ones(3 * H)
-    sc[H:2 * H] = 1 / math.sqrt(3.0 * H)
-    sc[2 * H:] = 1 / math.sqrt(H)
-    dx = x.new_zeros(N, H)
-    dv = x.new_zeros(N, 3, H)
+    sc = _message_scale(H, x)
+    dx = dv = None
     parts = []
     if isinstance(edge_embed, BucketedBasis):
         if Ek > 0:     # rbf_proj (rmnet.py:55) as one batched product on the bucketed basis; R stays in its sorted order
             R, R2 = edge_embed.project(w_rbf, b_rbf, sc)
-            dx, dv = MessageAlgebra.apply(xh.reshape(T * Ns, 3 * H), vec, R, edge[:Ek, :3],
+            dx, dv = MessageAlgebra.apply(xh.reshape(T * Ns, 3 * H), vec, R, edge_embed.unit_vectors(edge, Ek),
                                           (k_tgt, k_all, k_xh, edge_embed.slot, edge_embed.pad), R2)
     else:
         # (split, not slices: the backward of a split is ONE cat, a slice's zero-fills the whole [E,R] gradient)
@@ -990,7 +1022,8 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
             S, M = edge_message(X, R, V, edge[:Ek, :3])
             dx = SumRows.apply(S, k_tgt)
             dv = SumRows.apply(M, k_tgt)
-    known = (rel_row < T).to(x.dtype)
+    if dx is None:                                             # no edge into a known element
+        dx, dv = x.new_zeros(N, H), x.new_zeros(N, 3, H)
     # the residual (rmnet.py:24-26) reads the target atom's own row: the same row for HVNet, `res_row` for HTNet
     xr = x if k_res is None else GatherRows.apply(x, k_res)
     vr = 0 if vec is None else (vec if k_res is None else GatherRows.apply(vec, k_res))
