@@ -349,6 +349,69 @@ void launch_qs(const float* a, const float* b, const float* g1, const float* g2,
 }
 inline bool staged_shape(int C, int N) { return C % 64 == 0 && (N == 128 || N == 256 || N == 384); }
 
+// ---- the basis window itself: phi[r][k] = w[c][k] e(u_r) exp(coeff (u_r - mu[c][k])^2), c = r / C the row's chunk ------------------
+// (rmnet.py:168-172 on the chunk's 32 centres; e = the polynomial envelope 1 + a u^p + b u^(p+1) + c u^(p+2) for u < 1 on rows
+// that hold an edge, 0 otherwise).  Left to torch the expression and its two derivatives are ~60 elementwise launches per step
+// over [rows, 32] and [rows] arrays.  Eight lanes per row, a lane four centres.
+//   order 0   phi [rows,32]                              from u [rows]
+//   order 1   g_u [rows] = sum_k g[r][k] dphi/du          from g [rows,32], u
+//   order 2   d_g [rows,32] = c_u[r] dphi/du,  d_u [rows] = c_u[r] sum_k g[r][k] d2phi/du2     from c_u [rows], g, u
+struct BasisArgs {
+  const float *u, *mu, *w, *g, *cu;
+  const long* src;
+  float *o0, *o1;
+  long rows, num_edges;
+  int C, p;
+  float coeff;
+};
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void basis_window_kernel(BasisArgs a) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long r = i >> 3;
+  if (r >= a.rows) return;
+  const int l = (int)(i & 7);
+  const long c = r / a.C;
+  const float u = a.u[r];
+  const bool alive = a.src[r] < a.num_edges && u < 1.0f;
+  const int p = a.p;
+  const float ca = -(p + 1) * (p + 2) * 0.5f, cb = (float)(p * (p + 2)), cc = -p * (p + 1) * 0.5f;
+  float up2 = 1.0f;                                   // u^(p-2) (p >= 2)
+  for (int k = 0; k < p - 2; ++k) up2 *= u;
+  const float up1 = p >= 2 ? up2 * u : 1.0f, up0 = up1 * u;                    // u^(p-1), u^p   (p >= 1)
+  const float e = alive ? 1.0f + up0 * (ca + u * (cb + u * cc)) : 0.0f;
+  const float e1 = alive ? up1 * (ca * p + u * (cb * (p + 1) + u * cc * (p + 2))) : 0.0f;
+  const float e2 = alive ? (p >= 2 ? ca * p * (p - 1) * up2 : 0.0f) + up1 * (cb * (p + 1) * p + u * cc * (p + 2) * (p + 1)) : 0.0f;
+  const f4 mu = ld4(a.mu + c * 32 + 4 * l), w = ld4(a.w + c * 32 + 4 * l);
+  f4 G, t;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    t[k] = u - mu[k];
+    G[k] = w[k] * __expf(a.coeff * t[k] * t[k]);
+  }
+  const float c2 = 2.0f * a.coeff;
+  if (ORDER == 0) {
+    *reinterpret_cast<f4*>(a.o0 + r * 32 + 4 * l) = G * e;
+    return;
+  }
+  const f4 d1 = G * (e1 + c2 * t * e);                 // dphi/du
+  const f4 g = ld4(a.g + r * 32 + 4 * l);
+  if (ORDER == 1) {
+    const f4 v = g * d1;
+    float sum = (v.x + v.y) + (v.z + v.w);
+    sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+    if (l == 0) a.o0[r] = sum;
+    return;
+  }
+  const float cu = a.cu[r];
+  *reinterpret_cast<f4*>(a.o0 + r * 32 + 4 * l) = d1 * cu;
+  const f4 d2 = G * (e2 + 2.0f * c2 * t * e1 + (c2 + c2 * c2 * t * t) * e);     // d2phi/du2
+  const f4 v = g * d2;
+  float sum = (v.x + v.y) + (v.z + v.w);
+  sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+  if (l == 0) a.o1[r] = cu * sum;
+}
+
 inline int rows_per_workgroup(int C) { return C % 256 == 0 ? 256 : (C % 128 == 0 ? 128 : C); }
 inline bool shape_ok(long nc, int C, int N) { return nc >= 0 && C > 0 && C % 32 == 0 && N > 0 && N % 32 == 0 && N <= 480 && nc * (C / 32) < (1l << 30); }
 
@@ -409,5 +472,20 @@ extern "C" int hermnet_band_product_grads(const float* a, const float* b, const 
   if (width == 384) launch_qs<3>(a, b, g1, g2, num_chunks, rows_per_chunk, ga, gb, gbias, (hipStream_t)stream);
   else if (width == 256) launch_qs<2>(a, b, g1, g2, num_chunks, rows_per_chunk, ga, gb, gbias, (hipStream_t)stream);
   else launch_qs<1>(a, b, g1, g2, num_chunks, rows_per_chunk, ga, gb, gbias, (hipStream_t)stream);
+  HN_LAUNCH_END;
+}
+
+extern "C" int hermnet_basis_window(int order, const float* u, const long* src, long num_edges, const float* mu, const float* w,
+                                    long num_chunks, int rows_per_chunk, float coeff, int env_p, const float* g, const float* cu,
+                                    float* out0, float* out1, void* stream) {
+  if (order < 0 || order > 2 || num_chunks < 0 || rows_per_chunk <= 0 || env_p < 1 || env_p > 64) return HN_ERR_BAD_ARG;
+  if (num_chunks == 0) return HN_OK;
+  if (!u || !src || !mu || !w || !out0 || (order >= 1 && !g) || (order == 2 && (!cu || !out1))) return HN_ERR_BAD_ARG;
+  BasisArgs a = {u, mu, w, g, cu, src, out0, out1, num_chunks * rows_per_chunk, num_edges, rows_per_chunk, env_p, coeff};
+  const dim3 grid((unsigned)((a.rows * 8 + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+  if (order == 0) hipLaunchKernelGGL(basis_window_kernel<0>, grid, dim3(256), 0, s, a);
+  else if (order == 1) hipLaunchKernelGGL(basis_window_kernel<1>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(basis_window_kernel<2>, grid, dim3(256), 0, s, a);
   HN_LAUNCH_END;
 }

@@ -23,6 +23,18 @@ namespace {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+// streamed once per launch ([E,3H] radial rows and their gradients: 610 MB each at configs[4]'s batch): non-temporal, so that
+// the gathered node rows -- read ~20 times each -- keep the caches
+#ifndef HN_TRAIN_NT
+#define HN_TRAIN_NT 1
+#endif
+__device__ __forceinline__ f4 ld4s(const float* p) {
+  return HN_TRAIN_NT ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p)) : *reinterpret_cast<const f4*>(p);
+}
+__device__ __forceinline__ void st4s(float* p, f4 v) {
+  if (HN_TRAIN_NT) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p));
+  else *reinterpret_cast<f4*>(p) = v;
+}
 __device__ __forceinline__ f4 ld4z(const float* p, size_t off) { return p ? *reinterpret_cast<const f4*>(p + off) : (f4){0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 __device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(256) void edge_msg_fwd_rows_kernel(EdgeMsgArgs a) {
       const float* X = a.X + row_of(a.xi, e) * 3 * H;
       const float* R = a.R + row_of(a.ri, e) * 3 * H;
       const f4 xs = ld4(X + c), xa = ld4(X + H + c), xb = ld4(X + 2 * H + c);
-      const f4 rs = ld4(R + c), ra = ld4(R + H + c), rb = ld4(R + 2 * H + c);
+      const f4 rs = ld4s(R + c), ra = ld4s(R + H + c), rb = ld4s(R + 2 * H + c);
       as += xs * rs;
       const f4 B = xb * rb;
       m0 += B * u0; m1 += B * u1; m2 += B * u2;
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(256) void edge_msg_bwd_rows_kernel(EdgeMsgArgs a) {
           const float u0 = a.U[3 * e], u1 = a.U[3 * e + 1], u2 = a.U[3 * e + 2];
           const size_t bx = row_of(a.xi, e) * 3 * H, bt = row_of(a.ti, e), br = row_of(a.ri, e) * 3 * H;
           const f4 xs = ld4(a.X + bx + c), xa = ld4(a.X + bx + H + c), xb = ld4(a.X + bx + 2 * H + c);
-          const f4 rs = ld4(a.R + br + c), ra = ld4(a.R + br + H + c), rb = ld4(a.R + br + 2 * H + c);
+          const f4 rs = ld4s(a.R + br + c), ra = ld4s(a.R + br + H + c), rb = ld4s(a.R + br + 2 * H + c);
           const f4 gs = ld4(a.GS + bt * H + c);
           const f4 g0 = ld4(a.GM + bt * 3 * H + c), g1 = ld4(a.GM + bt * 3 * H + H + c), g2 = ld4(a.GM + bt * 3 * H + 2 * H + c);
           const f4 gB = g0 * u0 + g1 * u1 + g2 * u2;
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(256) void edge_msg_bwd_rows_kernel(EdgeMsgArgs a) {
             sV0 += g0 * A; sV1 += g1 * A; sV2 += g2 * A;
           }
           sXs += gs * rs; sXb += gB * rb;
-          st4(a.o1 + br + c, gs * xs); st4(a.o1 + br + H + c, gRa); st4(a.o1 + br + 2 * H + c, gB * xb);
+          st4s(a.o1 + br + c, gs * xs); st4s(a.o1 + br + H + c, gRa); st4s(a.o1 + br + 2 * H + c, gB * xb);
           const f4 B = xb * rb;
           s0 = hsum(g0 * B); s1 = hsum(g1 * B); s2 = hsum(g2 * B);
         }
@@ -287,12 +299,12 @@ __global__ __launch_bounds__(256) void edge_msg_bwd2_rows_kernel(EdgeMsgArgs a) 
           const size_t b3 = (size_t)e * 3 * H;
           const size_t bx = row_of(a.xi, e) * 3 * H, bt = row_of(a.ti, e), br = row_of(a.ri, e) * 3 * H;
           const f4 xs = ld4(a.X + bx + c), xa = ld4(a.X + bx + H + c), xb = ld4(a.X + bx + 2 * H + c);
-          const f4 rs = ld4(a.R + br + c), ra = ld4(a.R + br + H + c), rb = ld4(a.R + br + 2 * H + c);
+          const f4 rs = ld4s(a.R + br + c), ra = ld4s(a.R + br + H + c), rb = ld4s(a.R + br + 2 * H + c);
           const f4 gs = ld4(a.GS + bt * H + c);
           const f4 g0 = ld4(a.GM + bt * 3 * H + c), g1 = ld4(a.GM + bt * 3 * H + H + c), g2 = ld4(a.GM + bt * 3 * H + 2 * H + c);
           const f4 cXs = ld4z(a.cX, bx + c), cXa = ld4z(a.cX, bx + H + c), cXb = ld4z(a.cX, bx + 2 * H + c);
           const f4 cRs = ld4z(a.cR, br + c), cRa = ld4z(a.cR, br + H + c), cRb = ld4z(a.cR, br + 2 * H + c);
-          st4(a.o0 + (size_t)e * H + c, cXs * rs + cRs * xs);
+          st4s(a.o0 + (size_t)e * H + c, cXs * rs + cRs * xs);
           const f4 tB = cXb * rb + cRb * xb, B = xb * rb;
           const f4 gB = g0 * u0 + g1 * u1 + g2 * u2, sU = g0 * k0 + g1 * k1 + g2 * k2;
           f4 d0 = tB * u0 + B * k0, d1 = tB * u1 + B * k1, d2 = tB * u2 + B * k2;
@@ -307,9 +319,9 @@ __global__ __launch_bounds__(256) void edge_msg_bwd2_rows_kernel(EdgeMsgArgs a) 
             sXa += cRa * gA + ra * sV; dRa = cXa * gA + xa * sV;
             sV0 += tA * g0; sV1 += tA * g1; sV2 += tA * g2;
           }
-          st4(a.o1 + b3 + c, d0); st4(a.o1 + b3 + H + c, d1); st4(a.o1 + b3 + 2 * H + c, d2);
+          st4s(a.o1 + b3 + c, d0); st4s(a.o1 + b3 + H + c, d1); st4s(a.o1 + b3 + 2 * H + c, d2);
           sXs += cRs * gs; sXb += cRb * gB + rb * sU;
-          st4(a.o3 + br + c, cXs * gs); st4(a.o3 + br + H + c, dRa); st4(a.o3 + br + 2 * H + c, cXb * gB + xb * sU);
+          st4s(a.o3 + br + c, cXs * gs); st4s(a.o3 + br + H + c, dRa); st4s(a.o3 + br + 2 * H + c, cXb * gB + xb * sU);
           s0 = hsum(tB * g0); s1 = hsum(tB * g1); s2 = hsum(tB * g2);
         }
       }
@@ -490,11 +502,11 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restric
     long q = q0;
     for (; q + 1 < q1; q += 2) {            // two rows in flight
       const long i0 = perm ? perm[q] : q, i1 = perm ? perm[q + 1] : q + 1;
-      const f4 v0 = ld4(x + (size_t)i0 * width + 4 * c), v1 = ld4(x + (size_t)i1 * width + 4 * c);
+      const f4 v0 = ld4s(x + (size_t)i0 * width + 4 * c), v1 = ld4s(x + (size_t)i1 * width + 4 * c);   // (each row read once)
       acc += v0;
       acc += v1;
     }
-    if (q < q1) acc += ld4(x + (size_t)(perm ? perm[q] : q) * width + 4 * c);
+    if (q < q1) acc += ld4s(x + (size_t)(perm ? perm[q] : q) * width + 4 * c);
     st4(out + (size_t)r * width + 4 * c, acc);
   }
 }

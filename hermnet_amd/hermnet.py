@@ -325,7 +325,11 @@ class HVNet(nn.Module):
                 row_plan = shard.row_plan(graph.row_of_node)
         # hermnet.py:123, row order (pads: Z=0).  eval(): every parameter is a constant, the embedding included
         # (the fused layers produce no parameter gradients; a partial set would be worse than none)
-        x = self.embed(graph.z_rows) if train else torch.nn.functional.embedding(graph.z_rows, self.embed.weight.detach())
+        if train and pos.is_cuda:
+            from .trainops import embedding_rows
+            x = embedding_rows(self.embed.weight, graph.z_rows.long())
+        else:
+            x = self.embed(graph.z_rows) if train else torch.nn.functional.embedding(graph.z_rows, self.embed.weight.detach())
         H = self.hidden_channels
         Hp = (H + 63) // 64 * 64 if (fused and switches.fused_layer) else H
         if Hp != H:

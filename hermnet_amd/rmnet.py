@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .ops import MessageScatter, RbfDescriptor
-from .trainops import (BucketedBasis, LayerNorm2, SiLU2, TallBmm, UpdateMid, UpdateOut, message_scatter_generic,
+from .trainops import (BasisWindow, BucketedBasis, LayerNorm2, SiLU2, TallBmm, ToSlots, UpdateMid, UpdateOut, message_scatter_generic,
                        node_kernels_ok)
 
 
@@ -205,7 +205,14 @@ class RadialBasis(nn.Module):
         p_ = torch.arange(nc * C - Ek, device=dev)
         gi = torch.searchsorted(pend, p_, right=True)
         pad = (start_pad + cnt - (pend - padcnt))[gi] + p_
-        up = torch.cat([u, u.new_zeros(1)]).index_select(0, src)                              # [nc * C], differentiable
+        up = ToSlots.apply(u, src, slot)                                                      # [nc * C], differentiable
+        k = ((group % nb) * S - 5)[:, None] + torch.arange(W, device=dev)[None, :]           # [nc, 32] centre indices
+        mu = off[k.clamp(0, R - 1)]
+        colok = ((k >= 0) & (k < R)).to(up.dtype)
+        if isinstance(self.envelope, PolynomialEnvelope) and up.is_cuda and up.dtype == torch.float32:
+            # window x envelope and its two derivatives: one launch per order (trainops.BasisWindow)
+            phi = BasisWindow.apply(up.contiguous(), src, mu.contiguous(), colok.contiguous(), Ek, C, self.rbf.coeff, self.envelope.p)
+            return BucketedBasis(phi, group, slot, nb, R, pad, chunks)
         if isinstance(self.envelope, PolynomialEnvelope):
             p = self.envelope.p
             a, b, c = -(p + 1) * (p + 2) / 2, p * (p + 2), -p * (p + 1) / 2
@@ -214,9 +221,6 @@ class RadialBasis(nn.Module):
             us = torch.where(up < 1, up, torch.zeros_like(up))
             env = torch.exp(-(us ** 2) / ((1 - us) * (1 + us)))
         env = torch.where((up < 1) & (src < Ek), env, torch.zeros_like(up))
-        k = ((group % nb) * S - 5)[:, None] + torch.arange(W, device=dev)[None, :]           # [nc, 32] centre indices
-        mu = off[k.clamp(0, R - 1)]
-        colok = ((k >= 0) & (k < R)).to(up.dtype)
         phi = torch.exp(self.rbf.coeff * (up.view(nc, C, 1) - mu[:, None, :]) ** 2) * (env.view(nc, C, 1) * colok[:, None, :])
         return BucketedBasis(phi, group, slot, nb, R, pad, chunks)
 

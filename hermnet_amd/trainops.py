@@ -65,6 +65,114 @@ class SumRows(torch.autograd.Function):
         return GatherRows.apply(g, ctx.key), None
 
 
+class ToSlots(torch.autograd.Function):
+    """y[r] = u[src[r]] for rows r that hold an edge (src[r] < len(u)), 0 for padding rows; `slot` is the inverse map on the
+    edges (slot[e] = the row of edge e, a permutation onto the occupied rows).  The adjoint is therefore a GATHER,
+    g_u[e] = g[slot[e]] -- index_select's own backward is an index_add_ with float atomics, and every padding row hits the one
+    dummy entry (0.28 ms per pass at configs[4]'s batch, and not reproducible bit for bit)."""
+
+    @staticmethod
+    def forward(ctx, u, src, slot):
+        ctx.maps = (src, slot)
+        return torch.cat([u, u.new_zeros((1,) + tuple(u.shape[1:]))]).index_select(0, src)
+
+    @staticmethod
+    def backward(ctx, g):
+        return FromSlots.apply(g, *ctx.maps), None, None
+
+
+class FromSlots(torch.autograd.Function):
+    """y[e] = g[slot[e]]: the adjoint of `ToSlots` (and ToSlots is its adjoint)."""
+
+    @staticmethod
+    def forward(ctx, g, src, slot):
+        ctx.maps = (src, slot)
+        return g.index_select(0, slot)
+
+    @staticmethod
+    def backward(ctx, c):
+        return ToSlots.apply(c, *ctx.maps), None, None
+
+
+class BasisWindow(torch.autograd.Function):
+    """phi [nc,C,32] of the bucketed basis from the sorted distances u [nc*C] (`hermnet_basis_window`, csrc/band_product.hip):
+    Gaussian window of the chunk's 32 centres x polynomial envelope, zero on padding rows (src == num_edges) and beyond the
+    cutoff.  One launch per order of differentiation; differentiable twice (the step needs no more: a third derivative
+    raises instead of returning something else)."""
+
+    @staticmethod
+    def forward(ctx, u, src, mu, w, num_edges, C, coeff, p):
+        ctx.save_for_backward(u, src, mu, w)
+        ctx.consts = (int(num_edges), int(C), float(coeff), int(p))
+        return _basis_window(0, u, src, mu, w, ctx.consts, None, None)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        u, src, mu, w = ctx.saved_tensors
+        return (_BasisWindowGrad.apply(g, u, src, mu, w, ctx.consts),) + (None,) * 7
+
+
+class _BasisWindowGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, u, src, mu, w, consts):
+        g = _c(g)
+        ctx.save_for_backward(g, u, src, mu, w)
+        ctx.consts = consts
+        return _basis_window(1, u, src, mu, w, consts, g, None)[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, cu):
+        g, u, src, mu, w = ctx.saved_tensors
+        d_g, d_u = _basis_window(2, u, src, mu, w, ctx.consts, g, _c(cu))
+        return d_g, d_u, None, None, None, None
+
+
+def _basis_window(order, u, src, mu, w, consts, g, cu):
+    from .ops import _stream
+    num_edges, C, coeff, p = consts
+    nc = mu.size(0)
+    new = lambda *shape: torch.empty(*shape, dtype=u.dtype, device=u.device)
+    out0 = new(nc * C) if order == 1 else new(nc, C, 32)
+    out1 = new(nc * C) if order == 2 else None
+    P = _lib.ptr
+    _lib.check(_lib.load().hermnet_basis_window(order, P(u), P(src), num_edges, P(mu), P(w), nc, C, coeff, p, P(g), P(cu), P(out0),
+                                                P(out1), _stream()), "hermnet_basis_window")
+    return out0, out1
+
+
+class _EmbedRows(torch.autograd.Function):
+    """y = W[index] (nn.Embedding, hermnet.py:123).  The gradient is a sum of ~N rows into a handful of table rows: formed as
+    onehot(index)^T g through `_gram_over_rows` (a batched product over row chunks + a sum: a fixed order, the whole chip) --
+    embedding's own backward sorts the indices with a multi-pass merge sort and scatters (~45 launches, 0.5 ms per step at
+    configs[4]'s batch), a segmented sum leaves one lane group per table row (1.8 ms)."""
+
+    @staticmethod
+    def forward(ctx, W, index):
+        ctx.index, ctx.n = index, W.size(0)
+        return W.index_select(0, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _EmbedRowsT.apply(g, ctx.index, ctx.n), None
+
+
+class _EmbedRowsT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, index, n):
+        ctx.index = index
+        onehot = g.new_zeros(index.numel(), n).scatter_(1, index[:, None], 1.0)
+        return _gram_over_rows(onehot[None], g.contiguous()[None])[0]
+
+    @staticmethod
+    def backward(ctx, c):
+        return _EmbedRows.apply(c, ctx.index), None, None
+
+
+def embedding_rows(weight, index):
+    return _EmbedRows.apply(weight, index)
+
+
 class EdgeDiff(torch.autograd.Function):
     """D[e] = pos[source(e)] - pos[target(e)] over the CSR edges (hermnet.py:135-139) and its adjoint `_EdgeDiffT`, each the
     other's backward (both are linear): differentiable to any order without `index_put_(accumulate=True)` -- the backward of

@@ -676,6 +676,15 @@ int hermnet_band_product_grad_b(const float* a, const float* g1, const float* g2
                                 float* gb, float* gbias, void* stream);
 int hermnet_band_product_grads(const float* a, const float* b, const float* g1, const float* g2, long num_chunks,
                                int rows_per_chunk, int width, float* ga, float* gb, float* gbias, void* stream);
+/* The basis window of the bucketed rbf_proj and its two derivatives (ABI v13; /root/reference/HermNet/rmnet.py:168-193 on the 32
+ * centres of a chunk): phi[r][k] = w[c][k] e(u_r) exp(coeff (u_r - mu[c][k])^2), c = r / rows_per_chunk, e = the polynomial
+ * envelope of exponent env_p for u < 1 on rows with src[r] < num_edges (rows that hold an edge), 0 otherwise.
+ *   order 0: out0 = phi [rows,32];   order 1: out0 = g_u [rows] = sum_k g[r][k] dphi/du  (g [rows,32]);
+ *   order 2: out0 = d_g [rows,32] = cu[r] dphi/du, out1 = d_u [rows] = cu[r] sum_k g[r][k] d2phi/du2  (cu [rows]).
+ * mu, w [num_chunks,32]: centres and column weights (0 for centres outside the basis). */
+int hermnet_basis_window(int order, const float* u, const long* src, long num_edges, const float* mu, const float* w,
+                         long num_chunks, int rows_per_chunk, float coeff, int env_p, const float* g, const float* cu, float* out0,
+                         float* out1, void* stream);
 
 /* Host-side (CPU) evaluation of the per-edge radial contraction exactly as the device code
  * computes it (banded 12-tap Gaussian window): rb[c] = b[c] + env(u) * sum_k W[c,k] g_k(u) and
