@@ -536,3 +536,76 @@ extern "C" int hermnet_segment_sum(const float* x, const long* perm, const long*
   }
   return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
 }
+
+// ---- edge unit vectors (hermnet.py:144-152 with the distance floor of :146-147) and their two derivatives --------------------
+// D [E,3] -> U = D / d, d = max(|D|, 1e-6).  Left to torch (norm, where, div, cat and their first and second order backward)
+// the step spends ~110 launches on [E,3] / [E] arrays here.  One thread per edge.
+//   order 0   U [E,3], d [E]                                                        from D
+//   order 1   gD = (gU - U (U.gU)) / d + U gd                                        from gU*, gd*, D     (P = I - U U^T)
+//   order 2   cotangent C of gD:  c_gU = (C - U (U.C)) / d,  c_gd = U.C,
+//             c_D = [gd P C - ((gU.C) U + (U.gU) P C + (U.C) P gU - (U.C)(U.gU) U) / d] / d          from C, gU*, gd*, D
+// (* = may be NULL: zero).  An edge on the floor (|D| <= 1e-6): d is a constant there, U = D / 1e-6.
+namespace {
+
+struct UnitArgs {
+  const float *D, *gU, *gd, *C;
+  float *o0, *o1, *o2;
+  long E;
+};
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void edge_unit_kernel(UnitArgs a) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= a.E) return;
+  const float x = a.D[3 * e], y = a.D[3 * e + 1], z = a.D[3 * e + 2];
+  const float n = sqrtf(x * x + y * y + z * z);
+  const bool floor = n <= 1.0e-6f;
+  const float d = floor ? 1.0e-6f : n, inv = 1.0f / d;
+  const float u0 = x * inv, u1 = y * inv, u2 = z * inv;
+  if (ORDER == 0) {
+    a.o0[3 * e] = u0; a.o0[3 * e + 1] = u1; a.o0[3 * e + 2] = u2;
+    a.o1[e] = d;
+    return;
+  }
+  const float g0 = a.gU ? a.gU[3 * e] : 0.f, g1 = a.gU ? a.gU[3 * e + 1] : 0.f, g2 = a.gU ? a.gU[3 * e + 2] : 0.f;
+  const float gd = a.gd ? a.gd[e] : 0.f;
+  const float ug = floor ? 0.f : u0 * g0 + u1 * g1 + u2 * g2;          // (on the floor: no projection, no distance term)
+  const float gdl = floor ? 0.f : gd;
+  if (ORDER == 1) {
+    a.o0[3 * e] = (g0 - u0 * ug) * inv + u0 * gdl;
+    a.o0[3 * e + 1] = (g1 - u1 * ug) * inv + u1 * gdl;
+    a.o0[3 * e + 2] = (g2 - u2 * ug) * inv + u2 * gdl;
+    return;
+  }
+  const float c0 = a.C[3 * e], c1 = a.C[3 * e + 1], c2 = a.C[3 * e + 2];
+  const float uc = floor ? 0.f : u0 * c0 + u1 * c1 + u2 * c2;
+  a.o0[3 * e] = (c0 - u0 * uc) * inv; a.o0[3 * e + 1] = (c1 - u1 * uc) * inv; a.o0[3 * e + 2] = (c2 - u2 * uc) * inv;
+  a.o1[e] = uc;
+  if (floor) {
+    a.o2[3 * e] = 0.f; a.o2[3 * e + 1] = 0.f; a.o2[3 * e + 2] = 0.f;
+    return;
+  }
+  const float gc = g0 * c0 + g1 * c1 + g2 * c2;
+  const float pc0 = c0 - u0 * uc, pc1 = c1 - u1 * uc, pc2 = c2 - u2 * uc;      // P C
+  const float pg0 = g0 - u0 * ug, pg1 = g1 - u1 * ug, pg2 = g2 - u2 * ug;      // P gU
+  const float k = gc - uc * ug;
+  a.o2[3 * e] = (gd * pc0 - (k * u0 + ug * pc0 + uc * pg0) * inv) * inv;
+  a.o2[3 * e + 1] = (gd * pc1 - (k * u1 + ug * pc1 + uc * pg1) * inv) * inv;
+  a.o2[3 * e + 2] = (gd * pc2 - (k * u2 + ug * pc2 + uc * pg2) * inv) * inv;
+}
+
+}  // namespace
+
+extern "C" int hermnet_edge_unit(int order, const float* D, const float* gU, const float* gd, const float* C, long num_edges,
+                                 float* out0, float* out1, float* out2, void* stream) {
+  if (order < 0 || order > 2 || num_edges < 0) return HN_ERR_BAD_ARG;
+  if (num_edges == 0) return HN_OK;
+  if (!D || !out0 || (order != 1 && !out1) || (order == 2 && (!C || !out2))) return HN_ERR_BAD_ARG;
+  UnitArgs a = {D, gU, gd, C, out0, out1, out2, num_edges};
+  const dim3 grid((unsigned)((num_edges + 255) / 256));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (order == 0) hipLaunchKernelGGL(edge_unit_kernel<0>, grid, dim3(256), 0, s, a);
+  else if (order == 1) hipLaunchKernelGGL(edge_unit_kernel<1>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(edge_unit_kernel<2>, grid, dim3(256), 0, s, a);
+  return hipGetLastError() == hipSuccess ? HN_OK : HN_ERR_LAUNCH;
+}

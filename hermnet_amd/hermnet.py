@@ -269,6 +269,12 @@ class HVNet(nn.Module):
         if graph.shift is not None and cell is not None:
             c = cell.reshape(-1, 3, 3)
             D = D + torch.einsum("ni,nij->nj", graph.shift.to(D.dtype), c[graph.batch32.long()[src]])
+        if D.is_cuda and D.dtype == torch.float32:
+            from .trainops import EdgeUnit
+            U, d = EdgeUnit.apply(D)                # (one launch per order of differentiation)
+            edge = torch.cat([U, d[:, None]], dim=1)
+            edge._hn_parts = (U, d)                 # the pieces as tensors of their own: consumers that take them skip the slices
+            return edge
         d = D.norm(dim=-1)
         d = torch.where(d.abs() <= 1.0e-6, torch.full_like(d, 1.0e-6), d)           # hermnet.py:146-147
         return torch.cat([D / d[:, None], d[:, None]], dim=1)
@@ -356,7 +362,11 @@ class HVNet(nn.Module):
             data._hn_edge_embed = None
         elif train and pos.is_cuda and self.radial_basis.rbf_name == "gaussian" and H % 4 == 0 and graph.T > 0:
             # train(): the basis sorted by (relation, distance bucket) and cut to the bucket's 32 centres (trainops.BucketedBasis)
-            data._hn_edge_embed = self.radial_basis.bucketed(edge[:, 3], graph.rel_edge_bounds(), graph.T, graph.rel_edge_bounds_dev())
+            parts = getattr(edge, "_hn_parts", None)
+            data._hn_edge_embed = self.radial_basis.bucketed(edge[:, 3] if parts is None else parts[1], graph.rel_edge_bounds(),
+                                                             graph.T, graph.rel_edge_bounds_dev())
+            if parts is not None:
+                data._hn_edge_embed.set_unit_vectors(edge, parts[0], graph.rel_edge_bounds()[graph.T])
         else:
             data._hn_edge_embed = self.radial_basis(edge[:, 3])
         data.x, data.vec = x, vec

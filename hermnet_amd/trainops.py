@@ -94,6 +94,48 @@ class FromSlots(torch.autograd.Function):
         return ToSlots.apply(c, *ctx.maps), None, None
 
 
+class EdgeUnit(torch.autograd.Function):
+    """D [E,3] -> (U = D / d [E,3], d = max(|D|, 1e-6) [E]): hermnet.py:144-152 (`hermnet_edge_unit`, csrc/train_kernels.hip), one
+    launch per order of differentiation; twice differentiable (a third derivative raises)."""
+
+    @staticmethod
+    def forward(ctx, D):
+        D = _c(D)
+        ctx.save_for_backward(D)
+        return _edge_unit(0, D, None, None, None)[:2]
+
+    @staticmethod
+    def backward(ctx, gU, gd):
+        (D,) = ctx.saved_tensors
+        return _EdgeUnitGrad.apply(gU, gd, D)
+
+
+class _EdgeUnitGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gU, gd, D):
+        gU, gd = _c(gU), _c(gd)
+        ctx.save_for_backward(gU, gd, D)
+        return _edge_unit(1, D, gU, gd, None)[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, C):
+        gU, gd, D = ctx.saved_tensors
+        c_gU, c_gd, c_D = _edge_unit(2, D, gU, gd, _c(C))
+        return (c_gU if gU is not None else None), (c_gd if gd is not None else None), c_D
+
+
+def _edge_unit(order, D, gU, gd, C):
+    from .ops import _stream
+    E = D.size(0)
+    new = lambda *shape: torch.empty(*shape, dtype=D.dtype, device=D.device)
+    o0, o1, o2 = new(E, 3), (new(E) if order != 1 else None), (new(E, 3) if order == 2 else None)
+    P = _lib.ptr
+    _lib.check(_lib.load().hermnet_edge_unit(order, P(D), P(gU), P(gd), P(C), E, P(o0), P(o1), P(o2), _stream()),
+               "hermnet_edge_unit")
+    return o0, o1, o2
+
+
 class BasisWindow(torch.autograd.Function):
     """phi [nc,C,32] of the bucketed basis from the sorted distances u [nc*C] (`hermnet_basis_window`, csrc/band_product.hip):
     Gaussian window of the chunk's 32 centres x polynomial envelope, zero on padding rows (src == num_edges) and beyond the
@@ -256,6 +298,10 @@ class BucketedBasis(object):
         if self._unit is None or self._unit[0] is not edge:
             self._unit = (edge, edge[:Ek, :3].contiguous())
         return self._unit[1]
+
+    def set_unit_vectors(self, edge, U, Ek):
+        """The step's unit vectors when the caller holds them as an [E,3] tensor of their own (trainops.EdgeUnit)."""
+        self._unit = (edge, U[:Ek])
 
     def project(self, w_rbf, b_rbf, scale):
         """rbf_proj of every relation (rmnet.py:55) on the bucketed basis -> (R, R) [nc * C, 3H] in the sorted edge order

@@ -676,6 +676,13 @@ int hermnet_band_product_grad_b(const float* a, const float* g1, const float* g2
                                 float* gb, float* gbias, void* stream);
 int hermnet_band_product_grads(const float* a, const float* b, const float* g1, const float* g2, long num_chunks,
                                int rows_per_chunk, int width, float* ga, float* gb, float* gbias, void* stream);
+/* Edge unit vectors and their two derivatives for the training path (ABI v13; /root/reference/HermNet/hermnet.py:144-152 with the
+ * distance floor of :146-147): D [E,3] -> U = D / d, d = max(|D|, 1e-6).
+ *   order 0: out0 = U [E,3], out1 = d [E];   order 1: out0 = gD [E,3] from the cotangents gU [E,3]*, gd [E]*;
+ *   order 2: (cotangent C [E,3] of gD) out0 = c_gU [E,3], out1 = c_gd [E], out2 = c_D [E,3].      (* = may be NULL: zero) */
+int hermnet_edge_unit(int order, const float* D, const float* gU, const float* gd, const float* C, long num_edges, float* out0,
+                      float* out1, float* out2, void* stream);
+
 /* The basis window of the bucketed rbf_proj and its two derivatives (ABI v13; /root/reference/HermNet/rmnet.py:168-193 on the 32
  * centres of a chunk): phi[r][k] = w[c][k] e(u_r) exp(coeff (u_r - mu[c][k])^2), c = r / rows_per_chunk, e = the polynomial
  * envelope of exponent env_p for u < 1 on rows with src[r] < num_edges (rows that hold an edge), 0 otherwise.

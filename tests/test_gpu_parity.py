@@ -832,6 +832,30 @@ def _second_order_vs_float64(fn_gpu, fn_ref, inputs, dev, tol=2e-5):
             assert a is not None and rel_err(a, b) < tol, (k, rel_err(a, b))
 
 
+@pytest.mark.parametrize("E", [5000, 3, 0])
+def test_edge_unit_vectors_match_autograd_to_second_order(E):
+    """trainops.EdgeUnit (`hermnet_edge_unit`: U = D / d, d = max(|D|, 1e-6); /root/reference/HermNet/hermnet.py:144-152) vs float64
+    autograd of the torch expression: values, first-order gradients with create_graph=True and the gradients of a functional
+    of those w.r.t. D and both cotangents; one edge sits on the distance floor."""
+    from hermnet_amd import trainops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(E + 1)
+    D = torch.randn(E, 3, generator=gen) * 2.0
+    if E > 3:
+        D[2] = torch.tensor([3.0e-7, -2.0e-7, 0.0])                      # on the floor: d = 1e-6 (at exactly 0 torch's norm has a NaN gradient)
+
+    def ref(D):
+        d = D.norm(dim=-1)
+        d = torch.where(d.abs() <= 1.0e-6, torch.full_like(d, 1.0e-6), d)
+        return D / d[:, None], d
+
+    if E == 0:
+        U, d = trainops.EdgeUnit.apply(D.to(dev).requires_grad_(True))
+        assert U.shape == (0, 3) and d.shape == (0,)
+        return
+    _second_order_vs_float64(lambda D: trainops.EdgeUnit.apply(D), ref, [D], dev)
+
+
 @pytest.mark.parametrize("R,H", [(700, 128), (33, 36), (5, 512)])
 def test_training_node_stage_kernels_match_autograd_to_second_order(R, H):
     """csrc/train_node_kernels.hip behind trainops.{LayerNorm2, SiLU2, UpdateMid, UpdateOut} (the node-level stages of the
