@@ -182,6 +182,31 @@ def test_argument_checks_of_the_projected_halo_entry_points_need_no_gpu():
     assert acc(3, 2, 384, a=None) == BAD
 
 
+def test_argument_checks_of_the_training_entry_points_of_abi_13_need_no_gpu():
+    """hermnet_band_product / _grad_a / _grad_b / _grads, hermnet_basis_window, hermnet_edge_unit: malformed calls are refused
+    before a launch; nothing to do (no chunks, no edges) is done."""
+    lib = _lib.load()
+    buf = np.zeros(64, dtype=np.float32)
+    ptr = buf.ctypes.data
+    OK, BAD = 0, 1
+    assert lib.hermnet_band_product_supported(1024, 384) == 1 and lib.hermnet_band_product_supported(64, 96) == 1
+    assert lib.hermnet_band_product_supported(1000, 384) == 0 and lib.hermnet_band_product_supported(1024, 100) == 0
+    assert lib.hermnet_band_product_supported(1024, 512) == 0                     # wider than the weight window's LDS image
+    prod = lambda nc, C, N, a=ptr: lib.hermnet_band_product(a, ptr, None, nc, C, N, ptr, None)
+    assert prod(0, 1024, 384) == OK and prod(0, 1024, 384, a=None) == OK
+    assert prod(-1, 1024, 384) == BAD and prod(0, 1000, 384) == BAD and prod(0, 1024, 100) == BAD and prod(2, 1024, 384, a=None) == BAD
+    ga = lambda nc, C, N, g=ptr: lib.hermnet_band_product_grad_a(g, None, ptr, nc, C, N, ptr, None)
+    assert ga(0, 64, 96) == OK and ga(0, 60, 96) == BAD and ga(3, 64, 96, g=None) == BAD
+    gb = lambda nc, C, N, a=ptr: lib.hermnet_band_product_grad_b(a, ptr, None, nc, C, N, ptr, None, None)
+    assert gb(0, 64, 96) == OK and gb(0, 64, 98) == BAD and gb(3, 64, 96, a=None) == BAD
+    gs = lambda nc, C, N, a=ptr: lib.hermnet_band_product_grads(a, ptr, ptr, None, nc, C, N, ptr, ptr, None, None)
+    assert gs(0, 1024, 384) == OK and gs(0, 1024, 385) == BAD and gs(1, 1024, 384, a=None) == BAD
+    bw = lambda order, nc, p, u=ptr: lib.hermnet_basis_window(order, u, ptr, 5, ptr, ptr, nc, 1024, -1.0, p, ptr, ptr, ptr, ptr, None)
+    assert bw(0, 0, 5) == OK and bw(3, 0, 5) == BAD and bw(0, 0, 0) == BAD and bw(0, -1, 5) == BAD and bw(1, 2, 5, u=None) == BAD
+    eu = lambda order, E, D=ptr: lib.hermnet_edge_unit(order, D, None, None, ptr, E, ptr, ptr, ptr, None)
+    assert eu(0, 0) == OK and eu(3, 0) == BAD and eu(0, -1) == BAD and eu(0, 4, D=None) == BAD
+
+
 @pytest.mark.parametrize("out_f,in_f", [(128, 128), (384, 128), (128, 256), (64, 64), (32, 96)])
 def test_weight_fragments_through_the_c_abi_equal_the_host_codes(out_f, in_f):
     """a binder of the C seam must not re-implement the three-plane weight stream.  `hermnet_weight_fragments`
