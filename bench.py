@@ -427,10 +427,23 @@ def training_secondary(hn, synth, dev, model_kw, num_graphs=1024, steps=3):
         loss = train_step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"workload": "configs[4]: %d molecules, %d atoms, %d edges; loss = 0.2 MSE(E) + 0.8 MSE(F), Adam"
-                        % (num_graphs, d.pos.size(0), d.edge_index.size(1)),
-            "ms_per_step": dt * 1e3, "graphs_per_s": num_graphs / dt, "atom_steps_per_s": d.pos.size(0) / dt,
-            "loss": float(loss)}
+    res = {"workload": "configs[4]: %d molecules, %d atoms, %d edges; loss = 0.2 MSE(E) + 0.8 MSE(F), Adam"
+                       % (num_graphs, d.pos.size(0), d.edge_index.size(1)),
+           "ms_per_step": dt * 1e3, "graphs_per_s": num_graphs / dt, "atom_steps_per_s": d.pos.size(0) / dt,
+           "loss": float(loss)}
+
+    def no_optimizer():                     # what tools/train_profile.py counts (forward + force pass + backward)
+        opt.zero_grad()
+        d.pos.requires_grad_(True)
+        pred_e = model(d)
+        pred_f = -torch.autograd.grad(pred_e.sum(), d.pos, create_graph=True)[0]
+        (0.2 * F.mse_loss(pred_e, y) + 0.8 * F.mse_loss(pred_f, ftgt)).backward()
+    try:
+        res["launches_per_step"] = count_launches(train_step)[0]
+        res["launches_per_step_without_optimizer"] = count_launches(no_optimizer)[0]
+    except Exception as ex:
+        res["launches_per_step"] = {"error": repr(ex)}
+    return res
 
 
 def gemm_flops_per_step(N, nk, H, T, layers):

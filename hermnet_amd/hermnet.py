@@ -257,9 +257,10 @@ class HVNet(nn.Module):
 
     @staticmethod
     def _edge_geometry_autograd(pos, cell, graph):
-        """`with_edge` (hermnet.py:133-152) as differentiable device ops, CSR order -> edge[E,4] = (rhat, d).
-        Training path only: `create_graph=True` needs second derivatives, which the geometry kernel's
-        hand-written backward does not provide."""
+        """`with_edge` (hermnet.py:133-152) as differentiable device ops, CSR order -> (edge [E,4] = (rhat, d), parts): parts =
+        (rhat [E,3], d [E]) as tensors of their own where they exist (consumers that take them skip the slices and their
+        zero-filled backward), else None.  Training path only: `create_graph=True` needs second derivatives, which the
+        geometry kernel's hand-written backward does not provide."""
         src = graph.src_id.long()
         if pos.is_cuda and not graph.num_src and graph.csc_pos is not None:
             from .trainops import EdgeDiff
@@ -272,12 +273,10 @@ class HVNet(nn.Module):
         if D.is_cuda and D.dtype == torch.float32:
             from .trainops import EdgeUnit
             U, d = EdgeUnit.apply(D)                # (one launch per order of differentiation)
-            edge = torch.cat([U, d[:, None]], dim=1)
-            edge._hn_parts = (U, d)                 # the pieces as tensors of their own: consumers that take them skip the slices
-            return edge
+            return torch.cat([U, d[:, None]], dim=1), (U, d)
         d = D.norm(dim=-1)
         d = torch.where(d.abs() <= 1.0e-6, torch.full_like(d, 1.0e-6), d)           # hermnet.py:146-147
-        return torch.cat([D / d[:, None], d[:, None]], dim=1)
+        return torch.cat([D / d[:, None], d[:, None]], dim=1), None
 
     def forward(self, data):
         """Two execution modes behind the same signature, chosen like any PyTorch module chooses:
@@ -346,7 +345,7 @@ class HVNet(nn.Module):
         if fused and switches.fused_layer:
             data._hn_weights = self._refresh_weights(pos.device)
         if train:
-            edge = self._edge_geometry_autograd(pos, data.get("cell"), graph)
+            edge, edge_parts = self._edge_geometry_autograd(pos, data.get("cell"), graph)
         else:
             edge = EdgeGeometry.apply(pos, data.get("cell"), graph)      # with_edge, hermnet.py:133-152
 
@@ -362,7 +361,7 @@ class HVNet(nn.Module):
             data._hn_edge_embed = None
         elif train and pos.is_cuda and self.radial_basis.rbf_name == "gaussian" and H % 4 == 0 and graph.T > 0:
             # train(): the basis sorted by (relation, distance bucket) and cut to the bucket's 32 centres (trainops.BucketedBasis)
-            parts = getattr(edge, "_hn_parts", None)
+            parts = edge_parts
             data._hn_edge_embed = self.radial_basis.bucketed(edge[:, 3] if parts is None else parts[1], graph.rel_edge_bounds(),
                                                              graph.T, graph.rel_edge_bounds_dev())
             if parts is not None:
