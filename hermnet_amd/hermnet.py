@@ -362,10 +362,11 @@ class HVNet(nn.Module):
         elif train and pos.is_cuda and self.radial_basis.rbf_name == "gaussian" and H % 4 == 0 and graph.T > 0:
             # train(): the basis sorted by (relation, distance bucket) and cut to the bucket's 32 centres (trainops.BucketedBasis)
             parts = edge_parts
-            data._hn_edge_embed = self.radial_basis.bucketed(edge[:, 3] if parts is None else parts[1], graph.rel_edge_bounds(),
-                                                             graph.T, graph.rel_edge_bounds_dev())
+            Ek = graph.rel_edge_total()              # (no host read when every atom has an element of the model)
+            data._hn_edge_embed = self.radial_basis.bucketed(edge[:, 3] if parts is None else parts[1], Ek, graph.T,
+                                                             graph.rel_edge_bounds_dev())
             if parts is not None:
-                data._hn_edge_embed.set_unit_vectors(edge, parts[0], graph.rel_edge_bounds()[graph.T])
+                data._hn_edge_embed.set_unit_vectors(edge, parts[0], Ek)
         else:
             data._hn_edge_embed = self.radial_basis(edge[:, 3])
         data.x, data.vec = x, vec

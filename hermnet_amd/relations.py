@@ -52,11 +52,12 @@ class RelationalGraph(object):
                  "csc_pos", "out_rowptr", "out_edges", "src_id", "tgt_id", "shift", "row_active", "row_real",
                  "batch_rows", "batch32", "num_graphs", "graph_perm", "graph_lengths", "device", "_cstruct", "_rel_bounds",
                  "edge_table", "num_src", "res_row", "triadic_pairs", "src_real", "_rowptr_c", "src_ranges", "_row_keys",
-                 "_upd_tile", "ready", "_keep", "_edge_atoms64", "_edge_sum_keys", "_row_graph")
+                 "_upd_tile", "ready", "_keep", "_edge_atoms64", "_edge_sum_keys", "_row_graph", "_all_known")
 
     def __init__(self):
         self._cstruct = None
         self._rel_bounds = None
+        self._all_known = False    # every atom has an element of the model (host knowledge from the atom counts): Ek == E
         self._rowptr_c = None      # type_rowptr_host as a ctypes int array (nodeops._rowptr_host)
         self._upd_tile = None      # (H, tile rows of the update kernels for this row layout) (nodeops.update_tile_rows)
         self._row_keys = None      # gather / segmented-sum keys of the differentiable path (trainops._row_keys)
@@ -78,6 +79,14 @@ class RelationalGraph(object):
         if self._rel_bounds is None:
             self._rel_bounds = self.csr_rowptr[self.type_rowptr.long()].tolist()
         return self._rel_bounds
+
+    def rel_edge_total(self):
+        """Number of edges whose target has a known element (= rel_edge_bounds()[T]) WITHOUT a host read where the host
+        already knows it: with no atom of an unknown element every edge counts (the train() path sizes its arrays by it; a
+        read-back here was the last device sync of the training step after the relation build)."""
+        if self._all_known:
+            return self.E
+        return self.rel_edge_bounds()[self.T]
 
     def rel_edge_bounds_dev(self):
         """`rel_edge_bounds` as a device tensor [T + 1] (no host read, no upload)."""
@@ -157,6 +166,7 @@ class RelationalGraph(object):
         rows_cache = hit[4]                   # {(uniform layout key): row arrays}: they depend on the atoms only
         g.uniform, g.block, starts, N = RelationalGraph._layout(cnt_host, T, uniform)
         g.N, g.type_rowptr_host = N, starts[:T + 1]
+        g._all_known = int(cnt_host[T]) == 0
         g.type_rowptr = _cached_i32(tuple(starts[:T + 1]), dev)
         e32 = lambda n: torch.empty(n, dtype=i32, device=dev)
         rows = rows_cache.get((g.uniform, N))

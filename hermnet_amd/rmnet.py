@@ -166,7 +166,7 @@ class RadialBasis(nn.Module):
         than one chunk; the spare chunks -- all padding, ~3 % at configs[4]'s batch -- are given to the last group), so every
         size below is known before the distances are (round 6: the group sizes used to be read back, which drained the
         device queue in the middle of the forward pass).  `bounds_dev`: `bounds` as a device tensor (graph.rel_edge_bounds_dev)."""
-        Ek, dev = bounds[T], d.device
+        Ek, dev = (bounds if isinstance(bounds, int) else bounds[T]), d.device      # (an int: the edge total alone, with bounds_dev)
         W, C = BucketedBasis.WIDTH, BucketedBasis.CHUNK
         S = W - 12
         off = self.rbf.offset
@@ -180,7 +180,7 @@ class RadialBasis(nn.Module):
         bucket = ((lo + 5) // S).clamp(max=nb - 1)
         ar = torch.arange(Ek, device=dev)
         if bounds_dev is None:
-            bounds_dev = torch.tensor(bounds, device=dev)
+            bounds_dev = torch.tensor(list(bounds), device=dev)
         rel = torch.bucketize(ar, bounds_dev[1:T + 1].long(), right=True)
         key = rel * nb + bucket
         order = torch.argsort(key, stable=True)

@@ -1081,7 +1081,7 @@ def _run_lengths(sorted_keys, n):
     return torch.diff(ends, prepend=ends.new_zeros(1))
 
 
-def _row_keys(graph, T, Nt, Ns, bounds):
+def _row_keys(graph, T, Nt, Ns, Ek):
     """(key of the targets of the first Ek CSR edges [Nt target rows], key of their sources [Ns source rows], key of
     their (relation, source) rows of xh.view(T Ns, 3H), key of the residual rows or None) for `message_scatter_generic`,
     from the graph's CSR / CSC orders; built once per graph.  Nt = Ns for HVNet; HTNet has one target row per atom and
@@ -1091,7 +1091,6 @@ def _row_keys(graph, T, Nt, Ns, bounds):
         return keys
     dev = graph.csr_rowptr.device
     rowptr = graph.csr_rowptr.long()
-    Ek = bounds[T]
     nk = int(graph.type_rowptr_host[-1])
     lengths = rowptr[1:] - rowptr[:-1]
     lengths = torch.cat([lengths[:nk], lengths.new_zeros(Nt - nk)])          # edges into unknown-element rows: not summed
@@ -1143,16 +1142,17 @@ def message_scatter_generic(xh, vec, x, edge, edge_embed, w_rbf, b_rbf, graph):
     N = graph.N                                                # target rows (= Ns for HVNet; HTNet: one per atom and pair)
     # rows are relation-ordered and CSR is row-ordered: the edges of relation t are ONE contiguous CSR range
     # (no per-relation masks or gathers of the edge arrays)
-    bounds = graph.rel_edge_bounds()
-    Ek = bounds[T]                                             # edges whose target has a known element
-    k_tgt, k_all, k_xh, k_res, known = _row_keys(graph, T, N, Ns, bounds)
+    bucketed = isinstance(edge_embed, BucketedBasis)
+    bounds = None if bucketed else graph.rel_edge_bounds()     # (per relation: the materialised-basis route only)
+    Ek = graph.rel_edge_total()                                # edges whose target has a known element
+    k_tgt, k_all, k_xh, k_res, known = _row_keys(graph, T, N, Ns, Ek)
     known = known.to(x.dtype)
     # the constant factors of the vector message (1/sqrt(3H) on the `a` part, 1/sqrt(H) on `b`, rmnet.py:64-66) ride on
     # the [3H, R] projection weights, not on per-edge tensors
     sc = _message_scale(H, x)
     dx = dv = None
     parts = []
-    if isinstance(edge_embed, BucketedBasis):
+    if bucketed:
         if Ek > 0:     # rbf_proj (rmnet.py:55) as one batched product on the bucketed basis; R stays in its sorted order
             R, R2 = edge_embed.project(w_rbf, b_rbf, sc)
             dx, dv = MessageAlgebra.apply(xh.reshape(T * Ns, 3 * H), vec, R, edge_embed.unit_vectors(edge, Ek),
