@@ -138,6 +138,7 @@ SIGNATURES = {
     "hermnet_band_product": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_long, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "hermnet_band_product_grad_a": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_long, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "hermnet_band_product_grad_b": (ctypes.c_int, [c_fp, c_fp, c_fp, ctypes.c_long, ctypes.c_int, ctypes.c_int, c_fp, c_fp, c_fp]),
+    "hermnet_col_sum": (ctypes.c_int, [c_fp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, c_fp, c_fp]),
     "hermnet_edge_unit": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, c_fp, c_fp, ctypes.c_long, c_fp, c_fp, c_fp, c_fp]),
     "hermnet_basis_window": (ctypes.c_int, [ctypes.c_int, c_fp, c_fp, ctypes.c_long, c_fp, c_fp, ctypes.c_long, ctypes.c_int,
                                             ctypes.c_float, ctypes.c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),

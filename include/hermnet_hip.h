@@ -676,6 +676,11 @@ int hermnet_band_product_grad_b(const float* a, const float* g1, const float* g2
                                 float* gb, float* gbias, void* stream);
 int hermnet_band_product_grads(const float* a, const float* b, const float* g1, const float* g2, long num_chunks,
                                int rows_per_chunk, int width, float* ga, float* gb, float* gbias, void* stream);
+/* Column sums of x [num_slices, rows, width] over the rows (ABI v13; the bias gradients of the training path's node linears,
+ * /root/reference/HermNet/rmnet.py:52,94-100): partial [num_slices, ceil(rows / rows_per_block), width] holds one sum per block of
+ * rows; the caller adds the partials (fixed order).  width a multiple of 4, at most 1024. */
+int hermnet_col_sum(const float* x, long num_slices, long rows, int width, int rows_per_block, float* partial, void* stream);
+
 /* Edge unit vectors and their two derivatives for the training path (ABI v13; /root/reference/HermNet/hermnet.py:144-152 with the
  * distance floor of :146-147): D [E,3] -> U = D / d, d = max(|D|, 1e-6).
  *   order 0: out0 = U [E,3], out1 = d [E];   order 1: out0 = gD [E,3] from the cotangents gU [E,3]*, gd [E]*;

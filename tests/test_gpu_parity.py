@@ -832,6 +832,24 @@ def _second_order_vs_float64(fn_gpu, fn_ref, inputs, dev, tol=2e-5):
             assert a is not None and rel_err(a, b) < tol, (k, rel_err(a, b))
 
 
+@pytest.mark.parametrize("T,K,O", [(3, 20172, 384), (1, 257, 4), (12, 1681, 128), (2, 300, 1024), (3, 6724, 96)])
+def test_col_sum_kernel_matches_fp64_and_repeats(T, K, O):
+    """`hermnet_col_sum` behind trainops._col_sum_over_rows (the bias gradients of the training step's node linears): against the
+    fp64 sum, bit-identical from run to run, and differentiable (a broadcast)."""
+    from hermnet_amd import trainops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(T + K + O)
+    g = torch.randn(T, K, O, generator=gen)
+    gd = g.to(dev).requires_grad_(True)
+    out = trainops._col_sum_over_rows(gd)
+    ref = g.double().sum(1)
+    assert out.shape == (T, O) and float((out.detach().cpu().double() - ref).abs().max()) < 3e-6 * K ** 0.5 * 4
+    assert torch.equal(out, trainops._col_sum_over_rows(gd))
+    w = torch.randn(T, O, generator=gen).to(dev)
+    (gg,) = torch.autograd.grad((out * w).sum(), gd)
+    assert torch.equal(gg, w[:, None, :].expand(T, K, O))
+
+
 @pytest.mark.parametrize("E", [5000, 3, 0])
 def test_edge_unit_vectors_match_autograd_to_second_order(E):
     """trainops.EdgeUnit (`hermnet_edge_unit`: U = D / d, d = max(|D|, 1e-6); /root/reference/HermNet/hermnet.py:144-152) vs float64
