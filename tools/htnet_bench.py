@@ -13,6 +13,10 @@ import hermnet_amd as hn  # noqa: E402
 from hermnet_amd import synth  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+if os.environ.get("HN_OPTIONS") or os.environ.get("HN_SWITCHES"):      # (A/B loops: tools/_opts.py)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _opts import apply_option_env
+    apply_option_env()
 dev = torch.device("cuda")
 model = hn.HTNet(["Al", "Ni", "Cu"], rc=5.0, num_layers=5, hidden_channels=128, num_rbf=128).eval()
 model.load_state_dict(synth.synth_state_dict(model.state_dict(), 10))
