@@ -97,6 +97,32 @@ def test_eval_mode_after_training_uses_fused_path_and_same_numbers():
     assert float((out["train"][1] - out["eval"][1]).abs().max()) < 1e-5 * float(out["eval"][1].abs().max())
 
 
+@pytest.mark.gpu
+def test_train_and_eval_agree_with_an_atom_of_an_unknown_element():
+    """The train() path sizes its edge arrays by the number of edges with a KNOWN target: with every element in the model that is
+    the host's edge count (no device read, RelationalGraph.rel_edge_total); an atom of an element the model does not have
+    (its row stays zero, hermnet.py:51) takes the read-back route.  Both against eval() on the same data."""
+    dev = torch.device("cuda:0")
+    g = Golden("train_mol8_h64")
+    model = g.model().to(dev)
+    for unknown in (False, True):
+        out = {}
+        for mode in ("train", "eval"):
+            getattr(model, mode)()
+            d = g.data().to(dev)
+            if unknown:
+                z = d.atomic_number.clone()
+                z[3] = 79                                # gold: not an element of this model
+                d.atomic_number = z
+            d.pos.requires_grad_(True)
+            e = model(d)
+            f = -torch.autograd.grad(e.sum(), d.pos)[0]
+            out[mode] = (e.detach(), f, d._hn_graph._all_known)
+        assert out["train"][2] == (not unknown)
+        assert float((out["train"][0] - out["eval"][0]).abs().max()) < 1e-5 * float(out["eval"][0].abs().max())
+        assert float((out["train"][1] - out["eval"][1]).abs().max()) < 1e-5 * float(out["eval"][1].abs().max())
+
+
 def test_training_mode_refuses_host_tensors():
     g = Golden("train_mol8_h64")
     with pytest.raises(RuntimeError):
