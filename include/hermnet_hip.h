@@ -16,8 +16,8 @@
  *   - float = IEEE fp32 (the reference is fp32-only), indices = int32 (int64 where a parameter says so:
  *     the caller's edge_index / atomic_number / halo index lists arrive as torch LongTensors).
  *
- * ABI version 13 (`hermnet_abi_version`): v13 is ADDITIVE over v12 (hermnet_band_product / _grad_a / _grad_b / _grads: the training path's
- * rbf_proj on the bucketed basis); v12 is ADDITIVE over v11 (hermnet_halo_proj_rows / _accumulate, ranged launches of
+ * ABI version 13 (`hermnet_abi_version`): v13 is ADDITIVE over v12 (hermnet_band_product / _grad_a / _grad_b / _grads, hermnet_basis_window,
+ * hermnet_edge_unit, hermnet_col_sum: the training path's rbf_proj on the bucketed basis and its neighbours); v12 is ADDITIVE over v11 (hermnet_halo_proj_rows / _accumulate, ranged launches of
  * hermnet_message_scatter_bwd without the finishing launch, hermnet_set_option / _get_option in place of the library's environment
  * variables, hermnet_weight_fragments; no signature, struct or fragment format of v11 changed).  STABLE from v11 on: hn_graph,
  * hn_rbf_desc, hn_pending_grads, the frag(W) / frag16(W) weight streams, and every entry point's argument list -- later versions
